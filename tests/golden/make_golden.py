@@ -1,0 +1,359 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference; the reference never
+travels to the GPU box).  The fixtures hold inputs' seeds and the reference's
+OUTPUTS only; weights and inputs are regenerated on both sides from seeds with
+``oracle.sedt_oracle.seeded_state_dict`` / ``torch.randn(generator=...)``.
+
+torchvision is not installed here, so ``sys.modules`` gets a minimal shim with the
+four symbols the reference touches: ``models.resnet50`` (our
+restatement of torchvision's published ResNet-50 v1.5 - third-party arithmetic,
+"parity unpinned" by the reference), ``models._utils.IntermediateLayerGetter``,
+``_is_tracing`` and ``ops.boxes.box_area``.  Everything else executed is the
+reference's own code: FrozenBatchNorm2d, Backbone/Joiner, PositionEmbeddingSine,
+Transformer (+ torch.nn.MultiheadAttention), SEDT, SPSEDT, HungarianMatcher,
+SetCriterion.
+
+usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import types
+from collections import OrderedDict
+
+import numpy as np
+import torch
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+
+from oracle import sedt_oracle as O              # noqa: E402
+from oracle.criterion_oracle import synthetic_targets  # noqa: E402
+
+
+# ----------------------------------------------------------------------------- shim
+def install_torchvision_shim():
+    tv = types.ModuleType('torchvision')
+    models = types.ModuleType('torchvision.models')
+    mutils = types.ModuleType('torchvision.models._utils')
+    ops = types.ModuleType('torchvision.ops')
+    boxes = types.ModuleType('torchvision.ops.boxes')
+
+    class IntermediateLayerGetter(nn.ModuleDict):
+        def __init__(self, model, return_layers):
+            orig = dict(return_layers)
+            remaining = dict(return_layers)
+            layers = OrderedDict()
+            for name, module in model.named_children():
+                layers[name] = module
+                remaining.pop(name, None)
+                if not remaining:
+                    break
+            super().__init__(layers)
+            self.return_layers = orig
+
+        def forward(self, x):
+            out = OrderedDict()
+            for name, module in self.items():
+                x = module(x)
+                if name in self.return_layers:
+                    out[self.return_layers[name]] = x
+            return out
+
+    def resnet50(replace_stride_with_dilation=None, pretrained=False, norm_layer=None, **kw):
+        body = O.ResNet50Body(dilation=bool(replace_stride_with_dilation[2]), norm_layer=norm_layer)
+        m = nn.Module()
+        for name in ('conv1', 'bn1', 'relu', 'maxpool', 'layer1', 'layer2', 'layer3', 'layer4'):
+            m.add_module(name, getattr(body, name))
+        m.add_module('avgpool', nn.AdaptiveAvgPool2d((1, 1)))
+        m.add_module('fc', nn.Linear(2048, 1000))
+        return m
+
+    models.resnet50 = resnet50
+    mutils.IntermediateLayerGetter = IntermediateLayerGetter
+    models._utils = mutils
+    boxes.box_area = lambda b: (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    ops.boxes = boxes
+    tv.models, tv.ops = models, ops
+    tv._is_tracing = lambda: False
+    for name, mod in (('torchvision', tv), ('torchvision.models', models), ('torchvision.models._utils', mutils),
+                      ('torchvision.ops', ops), ('torchvision.ops.boxes', boxes)):
+        sys.modules[name] = mod
+
+
+def import_reference():
+    install_torchvision_shim()
+    sys.path.insert(0, REF)
+    import utilities.utils as ru
+    ru.to_cuda_if_available = lambda *a: a[0] if len(a) == 1 else list(a)
+    import sedt as rsedt
+    rsedt.to_cuda_if_available = ru.to_cuda_if_available
+    torch.Tensor.cuda = lambda self, *a, **k: self          # spsedt.py:37-38 hard-codes .cuda()
+    return rsedt, ru
+
+
+def load_ref_transformer_module():
+    spec = importlib.util.spec_from_file_location('ref_transformer', os.path.join(REF, 'sedt', 'transformer.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# ----------------------------------------------------------------------------- helpers
+def ref_args(**over):
+    a = argparse.Namespace(
+        num_classes=10, lr_backbone=1e-4, backbone='resnet50', dilation=True, position_embedding='sine',
+        enc_layers=3, dec_layers=3, dim_feedforward=2048, hidden_dim=256, dropout=0.1, nheads=8, num_queries=10,
+        pre_norm=True, aux_loss=True, dec_at=True, pooling=None, self_sup=False, set_cost_class=1, set_cost_bbox=5,
+        set_cost_giou=2, epsilon=1, alpha=1, ce_loss_coef=1, bbox_loss_coef=5, giou_loss_coef=2, eos_coef=0.1,
+        weak_loss_coef=1, weak_loss_p_coef=1, feature_recon=True, query_shuffle=False, num_patches=10)
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def digest(t, n=64):
+    t = t.detach().float().flatten()
+    idx = torch.linspace(0, t.numel() - 1, n).long()
+    return np.concatenate([[t.mean().item(), t.abs().mean().item()], t[idx].numpy()]).astype(np.float32)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def seeded_load(model, seed):
+    sd = O.seeded_state_dict(model.state_dict(), seed)
+    model.load_state_dict(sd)
+    return model
+
+
+def clip_input(b, t, seed):
+    return torch.randn(b, 1, t, 64, generator=torch.Generator().manual_seed(seed))
+
+
+# ----------------------------------------------------------------------------- fixtures
+def g1_transformer(out):
+    """G1: transformer-only, reference transformer.py loaded by path (pure torch)."""
+    rt = load_ref_transformer_module()
+    cases = {'pre_e3': dict(E=3, pre=True), 'post_e3': dict(E=3, pre=False), 'pre_e6': dict(E=6, pre=True)}
+    res = {}
+    for name, c in cases.items():
+        torch.manual_seed(0)
+        m = rt.Transformer(d_model=256, nhead=8, num_encoder_layers=c['E'], num_decoder_layers=3,
+                           dim_feedforward=2048, dropout=0.1, normalize_before=c['pre'],
+                           return_intermediate_dec=True, self_sup=False).eval()
+        seeded_load(m, 11)
+        g = torch.Generator().manual_seed(21)
+        src = torch.randn(2, 256, 32, 4, generator=g)
+        pos = torch.randn(2, 256, 32, 4, generator=g) * 0.5
+        query = torch.randn(11, 256, generator=g)
+        mask = torch.zeros(2, 32, 4, dtype=torch.bool)
+        mask[1, 25:, :] = True                      # clip 1 has 7 padded time steps (G8-style key padding)
+        with torch.no_grad():
+            hs, mem = m(src, mask, query, pos)
+        res[f'{name}_hs'], res[f'{name}_mem'] = npy(hs), npy(mem)
+    # self-sup branch with block-diagonal decoder mask (transformer.py:49-60)
+    m = rt.Transformer(256, 8, 3, 3, 2048, 0.1, normalize_before=True, return_intermediate_dec=True,
+                       self_sup=True).eval()
+    seeded_load(m, 12)
+    g = torch.Generator().manual_seed(22)
+    src = torch.randn(2, 256, 31, 4, generator=g)
+    pos = torch.randn(2, 256, 31, 4, generator=g) * 0.5
+    qe = torch.randn(20, 2, 256, generator=g)
+    am = torch.ones(20, 20) * float('-inf')
+    for i in range(10):
+        am[2 * i:2 * i + 2, 2 * i:2 * i + 2] = 0
+    with torch.no_grad():
+        hs, mem = m(src, torch.zeros(2, 31, 4, dtype=torch.bool), qe, pos, decoder_mask=am)
+    res['selfsup_hs'], res['selfsup_mem'] = npy(hs), npy(mem)
+    np.savez_compressed(os.path.join(out, 'g1_transformer.npz'), **res)
+    print('G1 ok', {k: v.shape for k, v in res.items()})
+
+
+def g2_g3_sedt(out, rsedt):
+    """G2 eval outputs + stage digests; G3 train-mode (dropout=0) losses and grads; G7 AdamW step."""
+    res = {}
+    for name, kw, T, B in (('urban', dict(enc_layers=3, num_queries=10), 500, 2),
+                           ('dcase', dict(enc_layers=6, num_queries=20), 496, 2)):
+        args = ref_args(dropout=0.0, **kw)
+        model, criterion, _ = rsedt.build_model(args)
+        seeded_load(model, 2020)
+        x = clip_input(B, T, 7)
+        model.eval()
+        stages = {}
+        body = model.backbone[0].body
+        hooks = [body[n].register_forward_hook(lambda m, i, o, n=n: stages.__setitem__(n, o))
+                 for n in ('bn1', 'layer1', 'layer2', 'layer3', 'layer4')]
+        hooks.append(model.input_proj.register_forward_hook(lambda m, i, o: stages.__setitem__('input_proj', o)))
+        for li, l in enumerate(model.transformer.encoder.layers):
+            hooks.append(l.register_forward_hook(lambda m, i, o, li=li: stages.__setitem__(f'enc{li}', o)))
+        for li, l in enumerate(model.transformer.decoder.layers):
+            hooks.append(l.register_forward_hook(lambda m, i, o, li=li: stages.__setitem__(f'dec{li}', o)))
+        with torch.no_grad():
+            o = model(x)
+        for h in hooks:
+            h.remove()
+        for k in ('pred_logits', 'pred_boxes', 'at'):
+            res[f'{name}_eval_{k}'] = npy(o[k])
+        for i, a in enumerate(o['aux_outputs']):
+            res[f'{name}_eval_aux{i}_logits'], res[f'{name}_eval_aux{i}_boxes'] = npy(a['pred_logits']), npy(a['pred_boxes'])
+        for k, v in stages.items():
+            res[f'{name}_stage_{k}'] = digest(v)
+        # G8: ragged batch -> non-trivial padding mask through mask-resize, pos-enc cumsum, key padding
+        xs = [x[0], x[1][:, :T - 140, :]]
+        with torch.no_grad():
+            o = model(xs)
+        for k in ('pred_logits', 'pred_boxes', 'at'):
+            res[f'{name}_ragged_{k}'] = npy(o[k])
+
+        # G3: train mode, dropout 0 -> deterministic; full criterion; grads
+        model.train()
+        targets = synthetic_targets(B, 99, 10)
+        o = model(x)
+        loss_dict, indices = criterion(o, targets, None, slice(B), False, False)
+        wd = criterion.weight_dict
+        total = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+        model.zero_grad()
+        total.backward()
+        res[f'{name}_train_total'] = np.float32(total.item())
+        for k, v in loss_dict.items():
+            res[f'{name}_train_loss_{k}'] = np.float32(v.item())
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+        res[f'{name}_train_gradnorm'] = np.array([dict(model.named_parameters())[n].grad.norm().item() for n in names],
+                                                 dtype=np.float32)
+        res[f'{name}_train_gradnames'] = np.array(names)
+        res[f'{name}_train_frozen'] = np.array([n for n, p in model.named_parameters() if not p.requires_grad])
+        for n in ('backbone.0.body.conv0.weight', 'backbone.0.body.conv0.bias',
+                  'backbone.0.body.layer2.0.conv2.weight', 'backbone.0.body.layer4.2.conv3.weight',
+                  'transformer.encoder.layers.0.self_attn.in_proj_weight',
+                  'transformer.decoder.layers.2.multihead_attn.out_proj.weight', 'query_embed.weight',
+                  'input_proj.bias', 'class_embed.weight'):
+            res[f'{name}_train_grad::{n}'] = digest(dict(model.named_parameters())[n].grad, 32)
+        if name == 'urban':
+            # G7: clip 0.1 + one AdamW step with the reference's two param groups (train_sedt.py:234-240,269-270)
+            groups = [{"params": [p for n, p in model.named_parameters() if "backbone" not in n and p.requires_grad]},
+                      {"params": [p for n, p in model.named_parameters() if "backbone" in n and p.requires_grad],
+                       "lr": 1e-4}]
+            before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+            opt = torch.optim.AdamW(groups, lr=1e-4, weight_decay=1e-4)
+            gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+            opt.step()
+            res['urban_step_total_gradnorm'] = np.float32(gn.item())
+            res['urban_step_delta'] = np.array(
+                [(dict(model.named_parameters())[n].detach() - before[n]).norm().item() for n in names], dtype=np.float32)
+    np.savez_compressed(os.path.join(out, 'g2_g3_sedt.npz'), **res)
+    print('G2/G3/G7/G8 ok', len(res), 'entries')
+
+
+def g4_spsedt(out, rsedt):
+    args = ref_args(enc_layers=6, num_queries=20, dec_at=False, self_sup=True, lr_backbone=0.0, dropout=0.0)
+    model, criterion, _ = rsedt.build_model(args)
+    seeded_load(model, 404)
+    B, P = 2, 10
+    x = clip_input(B, 496, 8)
+    patches = torch.randn(B, P, 1, 128, 64, generator=torch.Generator().manual_seed(9))
+    mask = torch.zeros(B, 496, 64, dtype=torch.bool)
+    res = {}
+    model.eval()
+    with torch.no_grad():
+        o = model((x, mask), patches)
+    for k in ('pred_logits', 'pred_boxes', 'pred_feature', 'gt_feature'):
+        res[f'eval_{k}'] = npy(o[k]) if k != 'pred_feature' else digest(o[k], 256)
+    model.train()
+    torch.manual_seed(31)
+    qm = (torch.rand(20, B, 1) > 0.1).float()       # what spsedt.py:65 will draw after manual_seed(31)
+    torch.manual_seed(31)
+    o = model((x, mask), patches)
+    res['train_query_mask'] = npy(qm)
+    for k in ('pred_logits', 'pred_boxes'):
+        res[f'train_{k}'] = npy(o[k])
+    res['train_pred_feature'] = digest(o['pred_feature'], 256)
+    # SP-SEDT targets: one box per patch, label 0 (DataLoad.py:57-77)
+    g = torch.Generator().manual_seed(5)
+    targets = []
+    for _ in range(B):
+        l = torch.rand(P, generator=g) * 0.3 + 0.05
+        c = l / 2 + torch.rand(P, generator=g) * (1 - l)
+        targets.append({'labels': torch.zeros(P, dtype=torch.int64), 'boxes': torch.stack([c, l], -1)})
+    loss_dict, _ = criterion(o, targets, slice(B), slice(B), False, False)
+    wd = criterion.weight_dict
+    total = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+    model.zero_grad()
+    total.backward()
+    res['train_total'] = np.float32(total.item())
+    for k, v in loss_dict.items():
+        res[f'train_loss_{k}'] = np.float32(v.item())
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    res['train_gradnames'] = np.array(names)
+    res['train_gradnorm'] = np.array([dict(model.named_parameters())[n].grad.norm().item() for n in names], np.float32)
+    res['target_boxes'] = np.stack([npy(t['boxes']) for t in targets])
+    np.savez_compressed(os.path.join(out, 'g4_spsedt.npz'), **res)
+    print('G4 ok')
+
+
+def g5_criterion(out, rsedt):
+    """G5: matcher indices + criterion losses for fixed outputs/targets (host code pin)."""
+    args = ref_args()
+    _, criterion, _ = rsedt.build_model(args)
+    g = torch.Generator().manual_seed(55)
+    B, Q = 6, 10
+    outputs = {'pred_logits': torch.randn(B, Q, 11, generator=g), 'pred_boxes': torch.rand(B, Q, 2, generator=g) * 0.8 + 0.1,
+               'at': torch.rand(B, 10, generator=g),
+               'aux_outputs': [{'pred_logits': torch.randn(B, Q, 11, generator=g),
+                                'pred_boxes': torch.rand(B, Q, 2, generator=g) * 0.8 + 0.1} for _ in range(2)]}
+    targets = synthetic_targets(B, 56, 10)
+    res = {}
+    idx, coef = criterion.matcher({k: v for k, v in outputs.items() if k != 'aux_outputs'}, targets)
+    res['match_src'] = np.concatenate([npy(i) for i, _ in idx])
+    res['match_tgt'] = np.concatenate([npy(j) for _, j in idx])
+    res['match_sizes'] = np.array([len(i) for i, _ in idx])
+    loss_dict, _ = criterion(outputs, targets, None, slice(B), False, False)
+    for k, v in loss_dict.items():
+        res[f'loss_{k}'] = np.float32(v.item())
+    # weak+strong split (DCASE style: first 4 strong, last 2 weak-only with empty boxes)
+    t2 = [dict(t) for t in targets]
+    for t in t2[4:]:
+        t['boxes'] = torch.zeros(0, 2)
+    loss_dict, _ = criterion(outputs, t2, slice(4, 6), slice(4), False, False)
+    for k, v in loss_dict.items():
+        res[f'ws_loss_{k}'] = np.float32(v.item())
+    # normalize=True coefficient path
+    loss_dict, _ = criterion(outputs, targets, None, slice(B), False, True)
+    res['norm_loss_ce'] = np.float32(loss_dict['loss_ce'].item())
+    np.savez_compressed(os.path.join(out, 'g5_criterion.npz'), **res)
+    print('G5 ok')
+
+
+def g6_posenc(out, rsedt):
+    import sedt.position_encoding as rpe
+    import utilities.utils as ru
+    pe = rpe.PositionEmbeddingSine(256, normalize=True)
+    res = {}
+    for h in (32, 31, 8):
+        m = torch.zeros(1, h, 4, dtype=torch.bool)
+        p = pe(ru.NestedTensor(torch.zeros(1, 2048, h, 4), m))
+        res[f'pos_{h}'] = npy(p[0, :, :, 0].t())            # (H, 256)
+    m = torch.zeros(1, 32, 4, dtype=torch.bool)
+    m[0, 23:, :] = True
+    p = pe(ru.NestedTensor(torch.zeros(1, 2048, 32, 4), m))
+    res['pos_32_pad23'] = npy(p[0, :, :, 0].t())
+    np.savez_compressed(os.path.join(out, 'g6_posenc.npz'), **res)
+    print('G6 ok')
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    out = HERE
+    g1_transformer(out)
+    rsedt, ru = import_reference()
+    g6_posenc(out, rsedt)
+    g5_criterion(out, rsedt)
+    g2_g3_sedt(out, rsedt)
+    g4_spsedt(out, rsedt)
