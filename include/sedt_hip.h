@@ -1,0 +1,184 @@
+/* sedt_hip.h - C ABI of libsedt_hip.so, the MI355X (gfx950) implementation of the
+ * SEDT forward/backward hot path.
+ *
+ * Every entry point takes plain device pointers, sizes and a hipStream_t (passed as
+ * void*); no torch types cross this boundary.  All buffers (inputs, parameters,
+ * gradients, outputs, saved activations, workspaces) are owned by the caller; the
+ * library never allocates or frees device memory and keeps no pointer across calls
+ * (the weight-pack cache in a plan handle stores host-side copies of pointer VALUES
+ * only, to detect changes).  Return value: 0 = ok, non-zero = error;
+ * sedt_last_error() returns the message (thread-local).  No exception crosses the ABI.
+ *
+ * dtype codes: SEDT_F32 = parity mode (f32 operands, v_mfma_f32_32x32x2_f32, exact f32
+ * FMA chains); SEDT_BF16 = throughput mode (bf16 operands, f32 accumulate,
+ * v_mfma_f32_32x32x16_bf16).  Parameters and gradients are always f32.
+ *
+ * Reference interface each group replaces (file:line under the reference repo):
+ *   sedt_igemm / sedt_layernorm_* / sedt_attention_*   - the torch operators below
+ *        torch.nn.Conv2d/Linear/LayerNorm/MultiheadAttention at sedt/transformer.py:160-165,
+ *        183-204, 220-233, 248-284, sedt/sedt.py:36, 88-92, 398-409, torchvision Bottleneck
+ *        (sedt/backbone.py:98-100)
+ *   sedt_backbone_*      - Backbone / BackboneBase.forward + autograd      sedt/backbone.py:56-113
+ *   sedt_encoder_* / sedt_decoder_*  - TransformerEncoder/Decoder(+Layer)  sedt/transformer.py:90-297
+ *   sedt_posenc          - PositionEmbeddingSine.forward                   sedt/position_encoding.py:27-47
+ *   sedt_heads_*         - class/bbox/audio-tag heads                      sedt/sedt.py:90-95, 398-409
+ *   sedt_adamw_clip      - clip_grad_norm_ + AdamW.step                    engine.py:77-80
+ */
+#ifndef SEDT_HIP_H
+#define SEDT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEDT_F32 0
+#define SEDT_BF16 1
+
+#define SEDT_ACT_NONE 0
+#define SEDT_ACT_RELU 1
+#define SEDT_ACT_SIGMOID 2
+
+const char* sedt_last_error(void);
+int sedt_version(void);
+
+/* ------------------------------------------------------------------ implicit GEMM
+ * C[M,N] = epilogue( sum_k A(m,k) * B(n,k) )
+ *
+ * trans == 0 (forward / dgrad):
+ *   A(m,k): conv == 0: A[m*lda + k]
+ *           conv == 1: m = (img, ho, wo) over the Ho x Wo "row grid", k = (tap, c) with c < Ci,
+ *                      element = A[pix*lda + c], pix = gathered pixel of the Hi x Wi grid:
+ *                        transposed == 0: hi = ho*sh - ph + kh*dh        (convolution forward)
+ *                        transposed == 1: hi = (ho + ph - kh*dh)/sh      (dgrad: rows are input pixels)
+ *                      out-of-range / non-divisible taps read as 0.
+ *   B(n,k): B[n*ldb + k]    (weights packed [N][taps][Ci])
+ * trans == 1 (wgrad; the reduction runs over pixels):
+ *   A(m,k): A[k*lda + m]                      (dY: k = output pixel, m = output channel)
+ *   B(n,k): conv == 0: B[k*ldb + n]
+ *           conv == 1: n = (tap, c), element = B[pix(k,tap)*ldb + c] (forward gather)
+ *   splitk > 1: partial sums go to slab[z][M][N] (f32) and the epilogue is skipped.
+ *
+ * epilogue, in order: v = acc*scale[n] + bias[n]; if(!act_post_res) v = act(v);
+ *   dropout(v); v += res[(res_mod ? m % res_mod : m)*ldr + n]; if(act_post_res) v = act(v);
+ *   v = mask[m*ldm+n] > 0 ? v : 0; v *= alpha; store as f32 (out_f32) or the compute dtype.
+ */
+typedef struct SedtIgemm {
+  int32_t M, N, K;
+  const void* A;
+  const void* B;
+  int64_t lda, ldb;
+  int32_t trans, conv, transposed;
+  int32_t Hi, Wi, Ci, Ho, Wo;
+  int32_t KH, KW, sh, sw, ph, pw, dh, dw;
+  void* C;
+  int64_t ldc;
+  int32_t out_f32;
+  const float* scale;
+  const float* bias;
+  const void* res;
+  int64_t ldr;
+  int32_t res_mod;
+  const void* mask;
+  int64_t ldm;
+  int32_t act, act_post_res;
+  float alpha;
+  float drop_p;
+  uint32_t seed;            /* effective seed = seed + (seed_ptr ? *seed_ptr : 0): the device word */
+  const uint32_t* seed_ptr; /* lets a captured hipGraph draw a fresh mask on every replay */
+  int32_t splitk;
+  float* slab;
+  int32_t tile_m, tile_n; /* 0 = choose automatically; else 64 or 128 */
+} SedtIgemm;
+
+int sedt_igemm(const SedtIgemm* args, int dtype, void* stream);
+/* recommended split-K factor and slab bytes for a trans==1 problem */
+int sedt_igemm_splitk(int M, int N, int K, int dtype);
+
+/* out[r][c...] = rowscale[r] * sum_z slab[z][r][tap][c], written in (R, Ci, taps) order
+ * (the torch (Cout, Cin, KH, KW) parameter layout) as f32.  taps == 1: plain [R][Ci]. */
+int sedt_wgrad_reduce(const float* slab, int splitk, int R, int taps, int Ci, const float* rowscale,
+                      float* out, void* stream);
+
+/* ------------------------------------------------------------------ elementwise / reductions */
+/* out[c] = sum_r in[r*ld + c]   (in: compute dtype or f32 if in_f32), out f32 */
+int sedt_colsum(const void* in, int64_t ld, int rows, int cols, int in_f32, int dtype, float* out,
+                float* scratch, size_t scratch_bytes, void* stream);
+size_t sedt_colsum_scratch(int rows, int cols);
+/* out = in * keep(seed, r*cols+c) / (1-p)   - the gradient side of the epilogue dropout */
+int sedt_dropout_grad(const void* in, int64_t ldi, void* out, int64_t ldo, int rows, int cols, float p,
+                      uint32_t seed, const uint32_t* seed_ptr, int dtype, void* stream);
+/* out[r][c] = a[r][c] + b[(b_mod ? r % b_mod : r)][c] */
+int sedt_add(const void* a, const void* b, void* out, int rows, int cols, int b_mod, int dtype, void* stream);
+/* dtype conversion f32 <-> compute dtype, elementwise over n */
+int sedt_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, void* stream);
+/* y = g * s * (1 - s) (sigmoid backward), all f32 */
+int sedt_sigmoid_grad(const float* g, const float* s, float* out, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------ LayerNorm (width D = 256)
+ * y = (x-mean)*rstd*gamma+beta ; y2 = y + add (optional) ; saves mean/rstd.  eps = 1e-5. */
+int sedt_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* add, void* y, void* y2,
+                       float* mean, float* rstd, int rows, int D, int dtype, void* stream);
+/* dx = dres + LN'(dy (+dy2)); dgamma/dbeta: f32[D] (deterministic two-stage reduction) */
+int sedt_layernorm_bwd(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean,
+                       const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* scratch,
+                       size_t scratch_bytes, int rows, int D, int dtype, void* stream);
+size_t sedt_layernorm_bwd_scratch(int rows, int D);
+
+/* ------------------------------------------------------------------ attention (head dim 32)
+ * rows are batch-first: q row = b*Lq + i, k/v row = b*Lk + j, head h occupies columns [h*32, h*32+32).
+ * kpm: uint8 [B][Lk] (1 = padded key), amask: f32 [Lq][Lk] additive (may hold -inf), both optional.
+ * probabilities are dropped with (drop_p, seed); lse [B][H][Lq] f32 saved for backward. */
+int sedt_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                       void* o, int64_t ldo, float* lse, const uint8_t* kpm, const float* amask, int B, int H,
+                       int Lq, int Lk, float drop_p, uint32_t seed, const uint32_t* seed_ptr, int dtype, void* stream);
+int sedt_attention_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                       const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
+                       const uint8_t* kpm, const float* amask, void* dq, int64_t lddq, void* dk, int64_t lddk,
+                       void* dv, int64_t lddv, int B, int H, int Lq, int Lk, float drop_p, uint32_t seed,
+                       const uint32_t* seed_ptr, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ position encoding
+ * pos[b][h*W+w][c] for the (B,H,W) uint8 mask (1 = padded): sine over the time axis H only,
+ * normalised, scale 2*pi, temperature 10000, eps 1e-6, D features interleaved sin/cos. */
+int sedt_posenc(const uint8_t* mask, void* pos, int B, int H, int W, int D, int dtype, void* stream);
+/* nearest resize of the (B,Hin,Win) padding mask to (B,Hout,Wout): F.interpolate default */
+int sedt_mask_resize(const uint8_t* in, uint8_t* out, int B, int Hin, int Win, int Hout, int Wout, void* stream);
+
+/* ------------------------------------------------------------------ backbone pieces */
+/* FrozenBatchNorm fold: scale = w*rsqrt(rv+1e-5), bias = b - rm*scale, n channels */
+int sedt_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale, float* bias, int n,
+                 void* stream);
+/* conv weight (Cout,Cin,KH,KW) f32 -> fwd pack [Cout][taps][Cin] and (optional) dgrad pack
+ * [Cin][taps][Cout] * bnscale[Cout], both in the compute dtype */
+int sedt_pack_conv(const float* w, int Cout, int Cin, int taps, const float* bnscale, void* wf, void* wb, int dtype,
+                   void* stream);
+/* stem: conv0 (1->3, 1x1, bias) folded into conv1 (3->64, 7x7, s2, p3):
+ * prep builds Wcat[64][128] = [Weff(49) | 0(15) | Beff(49) | 0(15)]; im2col builds
+ * col[B*Ho*Wo][128] = [x taps | 0 | in-bounds indicators | 0]. */
+int sedt_stem_prep(const float* w0, const float* b0, const float* w1, void* wcat, int dtype, void* stream);
+int sedt_stem_im2col(const float* x, void* col, int B, int H, int W, int dtype, void* stream);
+/* dw0[c] = sum w1[co,c,tap]*G[co][tap], db0[c] = sum w1[co,c,tap]*G[co][64+tap]; G f32 [64][128] */
+int sedt_stem_conv0_grad(const float* G, const float* w1, float* dw0, float* db0, void* stream);
+/* 3x3 stride-2 pad-1 max pooling over NHWC; idx (uint8 argmax tap) saved for backward */
+int sedt_maxpool_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, int dtype, void* stream);
+/* dx = (sum of dy routed by idx) * (relu_src > 0 if relu_src) */
+int sedt_maxpool_bwd(const void* dy, const uint8_t* idx, const void* relu_src, void* dx, int B, int H, int W, int C,
+                     int dtype, void* stream);
+/* global average pool over NHWC pixels: out[b][c] = mean_p x[b][p][c] (f32 out) */
+int sedt_avgpool(const void* x, float* out, int B, int P, int C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ optimizer (engine.py:77-80)
+ * Flat f32 buffers.  sumsq: f32[1] workspace holding the squared global grad norm (computed by
+ * sedt_sumsq), clip_coef = min(1, max_norm/(sqrt(sumsq)+1e-6)) as torch.clip_grad_norm_. */
+int sedt_sumsq(const float* g, int64_t n, float* sumsq, float* scratch, size_t scratch_bytes, int accumulate,
+               void* stream);
+size_t sedt_sumsq_scratch(int64_t n);
+int sedt_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm,
+                    float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

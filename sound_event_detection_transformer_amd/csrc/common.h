@@ -1,0 +1,65 @@
+// common.h - shared device helpers for the gfx950 SEDT kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sedt_hip.h"
+
+namespace sedt {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ---- error plumbing (thread-local message, integer status across the C ABI)
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define SEDT_REQUIRE(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      sedt::set_error(__VA_ARGS__);    \
+      return 1;                        \
+    }                                  \
+  } while (0)
+
+// ---- scalar load/store in the compute dtype
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p, long i) { return (float)p[i]; }
+template <typename T>
+__device__ __forceinline__ void stf(T* p, long i, float v) { p[i] = (T)v; }
+
+// ---- counter-based hash RNG for dropout: one 32-bit draw per (seed, element index).
+// Any kernel can regenerate the keep-mask of element idx without stored masks.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t rng32(uint32_t seed, uint64_t idx) {
+  uint32_t hi = (uint32_t)(idx >> 32), lo = (uint32_t)idx;
+  return mix32(lo ^ mix32(seed ^ (hi * 0x9E3779B9U) ^ 0x85ebca6bU));
+}
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xffffffffU : (uint32_t)t;
+}
+__device__ __forceinline__ bool drop_keep(uint32_t seed, uint64_t idx, uint32_t thresh) {
+  return rng32(seed, idx) >= thresh;
+}
+__device__ __forceinline__ uint32_t eff_seed(uint32_t seed, const uint32_t* seed_ptr) {
+  return seed + (seed_ptr ? *seed_ptr : 0u);
+}
+
+// ---- wave64 reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+}  // namespace sedt

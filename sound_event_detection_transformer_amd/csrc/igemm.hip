@@ -1,0 +1,490 @@
+// igemm.hip - implicit GEMM on MFMA for gfx950 (MI355X).
+//
+// One kernel template serves every contraction on the SEDT hot path:
+//   * nn.Linear / 1x1 conv forward and dgrad            (trans=0, conv=0)
+//   * 3x3 / strided / dilated conv forward              (trans=0, conv=1)
+//   * conv dgrad as a gather over output pixels         (trans=0, conv=1, transposed=1)
+//   * wgrad of all of the above (reduction over pixels)  (trans=1, split-K slabs)
+// with a fused epilogue (FrozenBN scale/bias, bias, ReLU/sigmoid, dropout, residual add,
+// ReLU-mask of the consumer, alpha).  Activations are NHWC so a conv is a GEMM whose A rows
+// are gathered pixels; weights arrive packed [N][taps][Ci] (see pack.hip).
+//
+// Tiling: 256 threads = 4 waves (2x2), workgroup tile BMxBN in {128,64}^2, each wave owns
+// (BM/2)x(BN/2) as 32x32 MFMA tiles.  Operands are staged global -> VGPR -> LDS ([row][k],
+// k contiguous, padded pitch) with the next tile's global loads issued before the current
+// tile's MFMAs and written to the other LDS buffer afterwards: one barrier per K tile.
+//   bf16: BK=64, pitch 72 (144 B: ds_read_b128 of 16 distinct rows hits 16 distinct 16-B slots),
+//         v_mfma_f32_32x32x16_bf16, 8 k per lane fragment read as one ds_read_b128.
+//   f32 : BK=32, pitch 33 (odd: 32 rows x fixed k conflict-free for ds_read_b32),
+//         v_mfma_f32_32x32x2_f32 (exact f32 FMA chain - the parity mode).
+// trans=1 sources have the reduction index as the slow axis; bf16 transposes 4(k)x8(r) blocks
+// in registers before the LDS write so the fragment reads stay ds_read_b128.
+#include "common.h"
+
+namespace sedt {
+
+template <typename T> struct Cfg;
+template <> struct Cfg<float> {
+  static constexpr int BK = 32, PITCH = 33, EPC = 4, KSTEP = 2, UK = 1;
+};
+template <> struct Cfg<bf16_t> {
+  static constexpr int BK = 64, PITCH = 72, EPC = 8, KSTEP = 16, UK = 4;
+};
+
+struct GatherGeom {
+  int Hi, Wi, Ci, Ho, Wo, KH, KW, sh, sw, ph, pw, dh, dw, transposed;
+};
+
+// pixel index (in the Hi x Wi grid of image n) gathered for row-grid position (ho,wo) and tap (kh,kw); -1 = zero
+__device__ __forceinline__ long gather_pix(const GatherGeom& g, int n, int ho, int wo, int kh, int kw) {
+  int hi, wi;
+  if (!g.transposed) {
+    hi = ho * g.sh - g.ph + kh * g.dh;
+    wi = wo * g.sw - g.pw + kw * g.dw;
+    if ((unsigned)hi >= (unsigned)g.Hi || (unsigned)wi >= (unsigned)g.Wi) return -1;
+  } else {
+    int th = ho + g.ph - kh * g.dh, tw = wo + g.pw - kw * g.dw;
+    if (th < 0 || tw < 0) return -1;
+    hi = th / g.sh;
+    wi = tw / g.sw;
+    if (hi * g.sh != th || wi * g.sw != tw || hi >= g.Hi || wi >= g.Wi) return -1;
+  }
+  return ((long)n * g.Hi + hi) * g.Wi + wi;
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 load_chunk(const T* base, long off, int valid_elems, bool vec) {
+  // loads EPC consecutive elements starting at base[off]; elements >= valid_elems read as 0
+  constexpr int EPC = Cfg<T>::EPC;
+  uint4 r = make_uint4(0, 0, 0, 0);
+  if (valid_elems <= 0) return r;
+  if (vec && valid_elems >= EPC) return *reinterpret_cast<const uint4*>(base + off);
+  T tmp[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) tmp[e] = e < valid_elems ? base[off + e] : (T)0.f;
+  r = *reinterpret_cast<uint4*>(tmp);
+  return r;
+}
+
+template <typename T, int BM, int BN, bool TRANS>
+__global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int vecA, const int vecB) {
+  constexpr int BK = Cfg<T>::BK, PITCH = Cfg<T>::PITCH, EPC = Cfg<T>::EPC, KSTEP = Cfg<T>::KSTEP;
+  constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* sA = reinterpret_cast<T*>(smem_raw);  // [2][BM*PITCH]
+  T* sB = sA + 2 * BM * PITCH;             // [2][BN*PITCH]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A);
+  const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B);
+
+  const int nkb_total = (p.K + BK - 1) / BK;
+  int kb_begin = 0, kb_end = nkb_total;
+  if (p.splitk > 1) {
+    int per = (nkb_total + p.splitk - 1) / p.splitk;
+    kb_begin = blockIdx.z * per;
+    kb_end = min(nkb_total, kb_begin + per);
+  }
+  const int nkb = max(0, kb_end - kb_begin);
+
+  GatherGeom g{p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.KH, p.KW, p.sh, p.sw, p.ph, p.pw, p.dh, p.dw, p.transposed};
+  const int HoWo = p.conv ? p.Ho * p.Wo : 1;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ======================================================================== staging
+  // ---- trans == 0: rows are output rows, k contiguous in memory
+  constexpr int CPR = BK / EPC;  // 16-byte chunks per tile row (8)
+  constexpr int RPP = 256 / CPR; // rows per pass (32)
+  constexpr int APASS = TRANS ? 1 : BM / RPP, BPASS = TRANS ? 1 : BN / RPP;
+  // ---- trans == 1: unit = UK k-rows x EPC r-elements
+  constexpr int UK = Cfg<T>::UK;
+  constexpr int AU = (BK / UK) * (BM / EPC), BU = (BK / UK) * (BN / EPC);
+  constexpr int TAP = TRANS ? (AU + 255) / 256 : 1, TBP = TRANS ? (BU + 255) / 256 : 1;
+  constexpr int NRA = TRANS ? TAP * UK : APASS, NRB = TRANS ? TBP * UK : BPASS;
+  uint4 ra[NRA], rb[NRB];
+
+  // per-thread row state (trans == 0)
+  const int chunk = t % CPR, lrow = t / CPR;
+  int a_n[APASS], a_ho[APASS], a_wo[APASS];
+  bool a_ok[APASS];
+  if constexpr (!TRANS) {
+#pragma unroll
+    for (int ps = 0; ps < APASS; ++ps) {
+      int row = m0 + lrow + ps * RPP;
+      a_ok[ps] = row < p.M;
+      if (p.conv) {
+        int n = row / HoWo, rem = row - n * HoWo;
+        a_n[ps] = n;
+        a_ho[ps] = rem / p.Wo;
+        a_wo[ps] = rem - a_ho[ps] * p.Wo;
+      } else {
+        a_n[ps] = row; a_ho[ps] = 0; a_wo[ps] = 0;
+      }
+    }
+  }
+  // per-thread column state for the gathered operand of trans == 1
+  int b_tap_kh[TBP], b_tap_kw[TBP], b_c[TBP];
+  if constexpr (TRANS) {
+#pragma unroll
+    for (int ps = 0; ps < TBP; ++ps) {
+      int u = t + ps * 256;
+      int ju = u % (BN / EPC);
+      int j = n0 + ju * EPC;
+      if (p.conv) {
+        int tap = j / p.Ci;
+        b_c[ps] = j - tap * p.Ci;
+        b_tap_kh[ps] = tap / p.KW;
+        b_tap_kw[ps] = tap - b_tap_kh[ps] * p.KW;
+      } else {
+        b_c[ps] = j; b_tap_kh[ps] = 0; b_tap_kw[ps] = 0;
+      }
+    }
+  }
+
+  auto load_tiles = [&](int kb) {
+    const int k0 = kb * BK;
+    if constexpr (!TRANS) {
+      // A: gathered rows
+      int kh = 0, kw = 0, c0 = k0;
+      if (p.conv) {
+        int tap = k0 / p.Ci;
+        c0 = k0 - tap * p.Ci;
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
+      }
+      const int kvalid = p.K - (k0 + chunk * EPC);  // elements of this chunk inside K
+#pragma unroll
+      for (int ps = 0; ps < APASS; ++ps) {
+        long pix = -1;
+        if (a_ok[ps]) pix = p.conv ? gather_pix(g, a_n[ps], a_ho[ps], a_wo[ps], kh, kw) : (long)a_n[ps];
+        ra[ps] = (pix >= 0) ? load_chunk<T>(Ag, pix * p.lda + c0 + chunk * EPC, kvalid, vecA)
+                            : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int ps = 0; ps < BPASS; ++ps) {
+        int row = n0 + lrow + ps * RPP;
+        rb[ps] = (row < p.N) ? load_chunk<T>(Bg, (long)row * p.ldb + k0 + chunk * EPC, kvalid, vecB)
+                             : make_uint4(0, 0, 0, 0);
+      }
+    } else {
+      // A: dY[k][m], plain
+#pragma unroll
+      for (int ps = 0; ps < TAP; ++ps) {
+        int u = t + ps * 256;
+        int ku = u / (BM / EPC), iu = u % (BM / EPC);
+        int i = m0 + iu * EPC;
+#pragma unroll
+        for (int kk = 0; kk < UK; ++kk) {
+          int k = k0 + ku * UK + kk;
+          bool ok = (u < AU) && (k < p.K);
+          ra[ps * UK + kk] = ok ? load_chunk<T>(Ag, (long)k * p.lda + i, p.M - i, vecA) : make_uint4(0, 0, 0, 0);
+        }
+      }
+      // B: X gathered by pixel k and this thread's tap
+#pragma unroll
+      for (int ps = 0; ps < TBP; ++ps) {
+        int u = t + ps * 256;
+        int ku = u / (BN / EPC), ju = u % (BN / EPC);
+        int j = n0 + ju * EPC;
+#pragma unroll
+        for (int kk = 0; kk < UK; ++kk) {
+          int k = k0 + ku * UK + kk;
+          bool ok = (u < BU) && (k < p.K) && (j < p.N);
+          long pix = -1;
+          if (ok) {
+            if (p.conv) {
+              int n = k / HoWo, rem = k - n * HoWo;
+              int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+              pix = gather_pix(g, n, ho, wo, b_tap_kh[ps], b_tap_kw[ps]);
+            } else {
+              pix = k;
+            }
+          }
+          // a chunk never straddles a tap (Ci % EPC == 0 is required when conv); plain: clip at N
+          int valid = p.conv ? EPC : p.N - j;
+          rb[ps * UK + kk] = (pix >= 0) ? load_chunk<T>(Bg, pix * p.ldb + b_c[ps], valid, vecB) : make_uint4(0, 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    T* dA = sA + buf * BM * PITCH;
+    T* dB = sB + buf * BN * PITCH;
+    if constexpr (!TRANS) {
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int ps = 0; ps < APASS; ++ps)
+          *reinterpret_cast<uint4*>(dA + (lrow + ps * RPP) * PITCH + chunk * EPC) = ra[ps];
+#pragma unroll
+        for (int ps = 0; ps < BPASS; ++ps)
+          *reinterpret_cast<uint4*>(dB + (lrow + ps * RPP) * PITCH + chunk * EPC) = rb[ps];
+      } else {
+#pragma unroll
+        for (int ps = 0; ps < APASS; ++ps) {
+          float* d = reinterpret_cast<float*>(dA) + (lrow + ps * RPP) * PITCH + chunk * EPC;
+          const float* s = reinterpret_cast<const float*>(&ra[ps]);
+          d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+        }
+#pragma unroll
+        for (int ps = 0; ps < BPASS; ++ps) {
+          float* d = reinterpret_cast<float*>(dB) + (lrow + ps * RPP) * PITCH + chunk * EPC;
+          const float* s = reinterpret_cast<const float*>(&rb[ps]);
+          d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3];
+        }
+      }
+    } else {
+      if constexpr (sizeof(T) == 2) {
+        // registers hold 4 k-rows x 8 r (bf16 pairs per dword); emit for each r the 4 k values (8 bytes)
+        auto tr_store = [&](const uint4* r4, T* dst, int ru, int ku) {
+          const uint32_t* w0 = reinterpret_cast<const uint32_t*>(&r4[0]);
+          const uint32_t* w1 = reinterpret_cast<const uint32_t*>(&r4[1]);
+          const uint32_t* w2 = reinterpret_cast<const uint32_t*>(&r4[2]);
+          const uint32_t* w3 = reinterpret_cast<const uint32_t*>(&r4[3]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            uint2 ev, od;
+            ev.x = (w0[q] & 0xffffu) | (w1[q] << 16);
+            ev.y = (w2[q] & 0xffffu) | (w3[q] << 16);
+            od.x = (w0[q] >> 16) | (w1[q] & 0xffff0000u);
+            od.y = (w2[q] >> 16) | (w3[q] & 0xffff0000u);
+            *reinterpret_cast<uint2*>(dst + (ru * 8 + 2 * q) * PITCH + ku * 4) = ev;
+            *reinterpret_cast<uint2*>(dst + (ru * 8 + 2 * q + 1) * PITCH + ku * 4) = od;
+          }
+        };
+#pragma unroll
+        for (int ps = 0; ps < TAP; ++ps) {
+          int u = t + ps * 256;
+          if (u < AU) tr_store(&ra[ps * UK], dA, u % (BM / EPC), u / (BM / EPC));
+        }
+#pragma unroll
+        for (int ps = 0; ps < TBP; ++ps) {
+          int u = t + ps * 256;
+          if (u < BU) tr_store(&rb[ps * UK], dB, u % (BN / EPC), u / (BN / EPC));
+        }
+      } else {
+#pragma unroll
+        for (int ps = 0; ps < TAP; ++ps) {
+          int u = t + ps * 256;
+          if (u < AU) {
+            int ku = u / (BM / EPC), iu = u % (BM / EPC);
+            float* d = reinterpret_cast<float*>(dA) + (iu * 4) * PITCH + ku;
+            const float* s = reinterpret_cast<const float*>(&ra[ps]);
+            d[0] = s[0]; d[PITCH] = s[1]; d[2 * PITCH] = s[2]; d[3 * PITCH] = s[3];
+          }
+        }
+#pragma unroll
+        for (int ps = 0; ps < TBP; ++ps) {
+          int u = t + ps * 256;
+          if (u < BU) {
+            int ku = u / (BN / EPC), ju = u % (BN / EPC);
+            float* d = reinterpret_cast<float*>(dB) + (ju * 4) * PITCH + ku;
+            const float* s = reinterpret_cast<const float*>(&rb[ps]);
+            d[0] = s[0]; d[PITCH] = s[1]; d[2 * PITCH] = s[2]; d[3 * PITCH] = s[3];
+          }
+        }
+      }
+    }
+  };
+
+  auto compute = [&](int buf) {
+    const T* cA = sA + buf * BM * PITCH + (wm + (lane & 31)) * PITCH;
+    const T* cB = sB + buf * BN * PITCH + (wn + (lane & 31)) * PITCH;
+    if constexpr (sizeof(T) == 2) {
+      const int kofs = 8 * (lane >> 5);
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += KSTEP) {
+        bf16x8 a[MI], b[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(cA + i * 32 * PITCH + kk + kofs);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(cB + j * 32 * PITCH + kk + kofs);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      const int kofs = lane >> 5;
+#pragma unroll 4
+      for (int kk = 0; kk < BK; kk += KSTEP) {
+        float a[MI], b[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = cA[i * 32 * PITCH + kk + kofs];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = cB[j * 32 * PITCH + kk + kofs];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  // ======================================================================== main loop
+  if (nkb > 0) {
+    load_tiles(kb_begin);
+    store_tiles(0);
+    __syncthreads();
+    for (int it = 0; it < nkb; ++it) {
+      const int cur = it & 1;
+      const bool more = (it + 1) < nkb;
+      if (more) load_tiles(kb_begin + it + 1);
+      compute(cur);
+      if (more) store_tiles(cur ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ======================================================================== epilogue
+  const bool slab = p.splitk > 1;
+  const uint32_t seed = eff_seed(p.seed, p.seed_ptr);
+  const uint32_t thresh = drop_threshold(p.drop_p);
+  const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+  const T* resT = reinterpret_cast<const T*>(p.res);
+  const T* maskT = reinterpret_cast<const T*>(p.mask);
+  // one 32x32 accumulator tile; called with compile-time (i, j) so acc stays in registers
+  auto epilogue_tile = [&](const f32x16& a, const int i, const int j) {
+    const int col = n0 + wn + j * 32 + (lane & 31);
+    const bool colok = col < p.N;
+    float sc = 1.f, bi = 0.f;
+    if (!slab && colok) {
+      if (p.scale) sc = p.scale[col];
+      if (p.bias) bi = p.bias[col];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (!(row < p.M && colok)) continue;
+      float v = a[r];
+      if (slab) {
+        p.slab[((long)blockIdx.z * p.M + row) * p.N + col] = v;
+        continue;
+      }
+      v = v * sc + bi;
+      if (!p.act_post_res) {
+        if (p.act == SEDT_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == SEDT_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+      }
+      if (p.drop_p > 0.f) v = drop_keep(seed, (uint64_t)row * (uint64_t)p.N + col, thresh) ? v * inv_keep : 0.f;
+      if (resT) {
+        long rr = p.res_mod > 0 ? (row % p.res_mod) : row;
+        v += (float)resT[rr * p.ldr + col];
+      }
+      if (p.act_post_res) {
+        if (p.act == SEDT_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == SEDT_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+      }
+      if (maskT) v = ((float)maskT[(long)row * p.ldm + col] > 0.f) ? v : 0.f;
+      v *= p.alpha;
+      if (p.out_f32) reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = v;
+      else reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = (T)v;
+    }
+  };
+  epilogue_tile(acc[0][0], 0, 0);
+  if constexpr (NI > 1) epilogue_tile(acc[0][1], 0, 1);
+  if constexpr (MI > 1) epilogue_tile(acc[1][0], 1, 0);
+  if constexpr (MI > 1 && NI > 1) epilogue_tile(acc[1][1], 1, 1);
+}
+
+// ---------------------------------------------------------------------------- host side
+template <typename T, int BM, int BN, bool TRANS>
+static int launch_cfg(const SedtIgemm& p, int vecA, int vecB, hipStream_t st) {
+  constexpr size_t lds = (size_t)(BM + BN) * Cfg<T>::PITCH * sizeof(T) * 2;
+  static bool attr_set = false;  // idempotent; a benign race sets it twice
+  auto kern = igemm_kernel<T, BM, BN, TRANS>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) {
+      set_error("igemm: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+      return 1;
+    }
+    attr_set = true;
+  }
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splitk > 1 ? p.splitk : 1);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p, vecA, vecB);
+  return check_launch("igemm");
+}
+
+template <typename T>
+static int launch_typed(const SedtIgemm& p, hipStream_t st) {
+  constexpr int EPC = Cfg<T>::EPC;
+  const size_t es = sizeof(T);
+  auto aligned = [&](const void* ptr, int64_t ld) {
+    return ((reinterpret_cast<uintptr_t>(ptr) % 16) == 0) && ((ld * (int64_t)es) % 16 == 0);
+  };
+  int vecA = aligned(p.A, p.lda), vecB = aligned(p.B, p.ldb);
+  if (p.conv) {
+    SEDT_REQUIRE(p.Ci % EPC == 0, "igemm: conv needs Ci %% %d == 0 (got %d)", EPC, p.Ci);
+    if (!p.trans) SEDT_REQUIRE(p.Ci % Cfg<T>::BK == 0, "igemm: conv needs Ci %% BK == 0 (Ci=%d, BK=%d)", p.Ci, Cfg<T>::BK);
+  }
+  if (!p.trans) {
+    // non-trans vector chunks run along k: k offsets are multiples of EPC, so K must be too (else scalar path)
+    if (p.K % EPC != 0) { vecA = 0; vecB = 0; }
+  }
+  int bm = p.tile_m, bn = p.tile_n;
+  if (bm == 0 || bn == 0) {
+    // heuristic: largest tile that still gives >= ~1 workgroup per CU (256 CUs); small N gets the narrow tile
+    auto tiles = [&](int a, int b) { return (long)((p.M + a - 1) / a) * ((p.N + b - 1) / b) * (p.splitk > 1 ? p.splitk : 1); };
+    if (p.N > 64 && p.M > 64 && tiles(128, 128) >= 256) { bm = 128; bn = 128; }
+    else if (p.M > 64 && tiles(128, 64) >= 256) { bm = 128; bn = 64; }
+    else if (p.N > 64 && p.M > 64 && tiles(64, 64) < 128 && tiles(128, 128) >= 64) { bm = 128; bn = 128; }
+    else { bm = 64; bn = 64; }
+    if (p.N <= 64) bn = 64;
+    if (p.M <= 64) bm = 64;
+    if (bm == 64 && bn == 128) bn = 64;
+  }
+  if (p.splitk > 1) SEDT_REQUIRE(p.slab != nullptr, "igemm: splitk > 1 needs a slab");
+#define SEDT_DISPATCH(BM_, BN_)                                                         \
+  if (bm == BM_ && bn == BN_) {                                                         \
+    return p.trans ? launch_cfg<T, BM_, BN_, true>(p, vecA, vecB, st)                   \
+                   : launch_cfg<T, BM_, BN_, false>(p, vecA, vecB, st);                 \
+  }
+  SEDT_DISPATCH(128, 128)
+  SEDT_DISPATCH(128, 64)
+  SEDT_DISPATCH(64, 64)
+#undef SEDT_DISPATCH
+  set_error("igemm: unsupported tile %dx%d", bm, bn);
+  return 1;
+}
+
+}  // namespace sedt
+
+extern "C" int sedt_igemm(const SedtIgemm* args, int dtype, void* stream) {
+  using namespace sedt;
+  SEDT_REQUIRE(args != nullptr, "igemm: null args");
+  SEDT_REQUIRE(args->M > 0 && args->N > 0 && args->K > 0, "igemm: bad dims M=%d N=%d K=%d", args->M, args->N, args->K);
+  SEDT_REQUIRE(args->A && args->B && (args->C || args->splitk > 1), "igemm: null operand");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SEDT_F32) return launch_typed<float>(*args, st);
+  if (dtype == SEDT_BF16) return launch_typed<bf16_t>(*args, st);
+  set_error("igemm: unsupported dtype %d", dtype);
+  return 1;
+}
+
+extern "C" int sedt_igemm_splitk(int M, int N, int K, int dtype) {
+  // wgrad outputs are small (Cout x taps*Cin) while K (pixels) is long: split K until ~512 workgroups
+  int bk = dtype == SEDT_BF16 ? 64 : 32;
+  int bm = M > 64 ? 128 : 64, bn = N > 64 ? 128 : 64;
+  if (bm == 64) bn = 64;
+  long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  int nkb = (K + bk - 1) / bk;
+  int s = (int)((512 + tiles - 1) / tiles);
+  int maxs = nkb / 4 > 1 ? nkb / 4 : 1;  // at least 4 K tiles per slice
+  if (s > maxs) s = maxs;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  return s;
+}

@@ -1,0 +1,516 @@
+// misc.hip - HBM-bound support kernels of the SEDT path: weight packing, FrozenBN fold, stem
+// im2col, max/avg pooling, position encoding, mask resize, column sums (bias grads), dropout
+// gradient, split-K wgrad reduction, global grad-norm + fused clip/AdamW.
+// All are coalesced along the channel (fastest) axis of the NHWC / [rows][cols] layouts.
+#include <stdarg.h>
+#include <string.h>
+#include "common.h"
+
+namespace sedt {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return 2;
+  }
+  return 0;
+}
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline unsigned nblk(long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+// ------------------------------------------------------------------ wgrad split-K reduce
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, int R, int taps, int Ci,
+                                    const float* __restrict__ rowscale, float* __restrict__ out) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long per = (long)R * taps * Ci;
+  if (e >= per) return;
+  int c = (int)(e % Ci);
+  long rt = e / Ci;
+  int tap = (int)(rt % taps);
+  int r = (int)(rt / taps);
+  float s = 0.f;
+  for (int z = 0; z < splitk; ++z) s += slab[(long)z * per + e];
+  if (rowscale) s *= rowscale[r];
+  out[((long)r * Ci + c) * taps + tap] = s;
+}
+
+// ------------------------------------------------------------------ column sums
+template <typename TI>
+__global__ void colsum_kernel(const TI* __restrict__ in, long ld, int rows, int cols, int rows_per_chunk,
+                              float* __restrict__ out) {
+  __shared__ float red[4][64];
+  int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  int col = blockIdx.x * 64 + tx;
+  int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  float s = 0.f;
+  if (col < cols)
+    for (int r = r0 + ty; r < r1; r += 4) s += (float)in[(long)r * ld + col];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && col < cols) out[(long)blockIdx.y * cols + col] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+}
+
+static int colsum_chunks(int rows) {
+  int c = (rows + 255) / 256;
+  return c < 1 ? 1 : (c > 256 ? 256 : c);
+}
+
+// ------------------------------------------------------------------ elementwise
+template <typename T>
+__global__ void dropout_grad_kernel(const T* __restrict__ in, long ldi, T* __restrict__ out, long ldo, int rows, int cols,
+                                    uint32_t thresh, float inv_keep, uint32_t seed, const uint32_t* seed_ptr) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)rows * cols) return;
+  int r = (int)(e / cols), c = (int)(e % cols);
+  uint32_t sd = eff_seed(seed, seed_ptr);
+  float v = (float)in[(long)r * ldi + c];
+  out[(long)r * ldo + c] = (T)(drop_keep(sd, (uint64_t)e, thresh) ? v * inv_keep : 0.f);
+}
+
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int rows, int cols,
+                           int b_mod) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)rows * cols) return;
+  int r = (int)(e / cols), c = (int)(e % cols);
+  int rb = b_mod > 0 ? r % b_mod : r;
+  out[e] = (T)((float)a[e] + (float)b[(long)rb * cols + c]);
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long n) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) out[e] = (TO)(float)in[e];
+}
+
+__global__ void sigmoid_grad_kernel(const float* g, const float* s, float* out, long n) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) out[e] = g[e] * s[e] * (1.f - s[e]);
+}
+
+// ------------------------------------------------------------------ backbone support
+__global__ void bn_fold_kernel(const float* w, const float* b, const float* rm, const float* rv, float* scale,
+                               float* bias, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float sc = w[i] * rsqrtf(rv[i] + 1e-5f);
+  scale[i] = sc;
+  bias[i] = b[i] - rm[i] * sc;
+}
+
+template <typename T>
+__global__ void pack_conv_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, const float* bnscale,
+                                 T* __restrict__ wf, T* __restrict__ wb) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long n = (long)Cout * Cin * taps;
+  if (e >= n) return;
+  int tap = (int)(e % taps);
+  long r = e / taps;
+  int ci = (int)(r % Cin), co = (int)(r / Cin);
+  float v = w[e];
+  if (wf) wf[((long)co * taps + tap) * Cin + ci] = (T)v;
+  if (wb) wb[((long)ci * taps + tap) * Cout + co] = (T)(bnscale ? v * bnscale[co] : v);
+}
+
+template <typename T>
+__global__ void stem_prep_kernel(const float* w0, const float* b0, const float* w1, T* wcat) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;  // 64*128
+  if (e >= 64 * 128) return;
+  int co = e >> 7, k = e & 127;
+  float v = 0.f;
+  int tap = k & 63;
+  if (tap < 49) {
+    const float* src = (k < 64) ? w0 : b0;
+    for (int c = 0; c < 3; ++c) v += w1[(co * 3 + c) * 49 + tap] * src[c];
+  }
+  wcat[e] = (T)v;
+}
+
+template <typename T>
+__global__ void stem_im2col_kernel(const float* __restrict__ x, T* __restrict__ col, int B, int H, int W, int Ho, int Wo) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long n = (long)B * Ho * Wo * 128;
+  if (e >= n) return;
+  int k = (int)(e & 127);
+  long pix = e >> 7;
+  int wo = (int)(pix % Wo);
+  long r = pix / Wo;
+  int ho = (int)(r % Ho), b = (int)(r / Ho);
+  int tap = k & 63;
+  float v = 0.f;
+  if (tap < 49) {
+    int kh = tap / 7, kw = tap - kh * 7;
+    int hi = 2 * ho - 3 + kh, wi = 2 * wo - 3 + kw;
+    if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = (k < 64) ? x[((long)b * H + hi) * W + wi] : 1.f;
+  }
+  col[e] = (T)v;
+}
+
+__global__ void stem_conv0_grad_kernel(const float* G, const float* w1, float* dw0, float* db0) {
+  __shared__ float red[6][256];
+  int t = threadIdx.x;
+  float acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int e = t; e < 64 * 49; e += 256) {
+    int co = e / 49, tap = e - co * 49;
+    float gx = G[co * 128 + tap], gb = G[co * 128 + 64 + tap];
+    for (int c = 0; c < 3; ++c) {
+      float w = w1[(co * 3 + c) * 49 + tap];
+      acc[c] += w * gx;
+      acc[3 + c] += w * gb;
+    }
+  }
+  for (int i = 0; i < 6; ++i) red[i][t] = acc[i];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (t < s)
+      for (int i = 0; i < 6; ++i) red[i][t] += red[i][t + s];
+    __syncthreads();
+  }
+  if (t < 3) dw0[t] = red[t][0];
+  else if (t < 6) db0[t - 3] = red[t][0];
+}
+
+template <typename T>
+__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int B, int H,
+                                   int W, int C, int Ho, int Wo) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long n = (long)B * Ho * Wo * C;
+  if (e >= n) return;
+  int c = (int)(e % C);
+  long r = e / C;
+  int wo = (int)(r % Wo);
+  r /= Wo;
+  int ho = (int)(r % Ho), b = (int)(r / Ho);
+  float best = -INFINITY;
+  int bi = 0;
+  bool first = true;
+  for (int kh = 0; kh < 3; ++kh) {
+    int hi = 2 * ho - 1 + kh;
+    if ((unsigned)hi >= (unsigned)H) continue;
+    for (int kw = 0; kw < 3; ++kw) {
+      int wi = 2 * wo - 1 + kw;
+      if ((unsigned)wi >= (unsigned)W) continue;
+      float v = (float)x[(((long)b * H + hi) * W + wi) * C + c];
+      if (first || v > best) { best = v; bi = kh * 3 + kw; first = false; }
+    }
+  }
+  y[e] = (T)best;
+  idx[e] = (uint8_t)bi;
+}
+
+template <typename T>
+__global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, const T* __restrict__ relu_src,
+                                   T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long n = (long)B * H * W * C;
+  if (e >= n) return;
+  int c = (int)(e % C);
+  long r = e / C;
+  int wi = (int)(r % W);
+  r /= W;
+  int hi = (int)(r % H), b = (int)(r / H);
+  float s = 0.f;
+  for (int a = 0; a < 2; ++a) {
+    int ho = (hi + 1) / 2 - a;
+    int kh = hi - (2 * ho - 1);
+    if (ho < 0 || ho >= Ho || kh < 0 || kh > 2) continue;
+    for (int d = 0; d < 2; ++d) {
+      int wo = (wi + 1) / 2 - d;
+      int kw = wi - (2 * wo - 1);
+      if (wo < 0 || wo >= Wo || kw < 0 || kw > 2) continue;
+      long o = (((long)b * Ho + ho) * Wo + wo) * C + c;
+      if (idx[o] == kh * 3 + kw) s += (float)dy[o];
+    }
+  }
+  if (relu_src && !((float)relu_src[e] > 0.f)) s = 0.f;
+  dx[e] = (T)s;
+}
+
+template <typename T>
+__global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ out, int B, int P, int C) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)B * C) return;
+  int c = (int)(e % C), b = (int)(e / C);
+  float s = 0.f;
+  for (int q = 0; q < P; ++q) s += (float)x[((long)b * P + q) * C + c];
+  out[e] = s / (float)P;
+}
+
+template <typename T>
+__global__ void posenc_kernel(const uint8_t* __restrict__ mask, T* __restrict__ pos, int B, int H, int W, int D) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long n = (long)B * H * W * D;
+  if (e >= n) return;
+  int c = (int)(e % D);
+  long r = e / D;
+  int w = (int)(r % W);
+  r /= W;
+  int h = (int)(r % H), b = (int)(r / H);
+  const uint8_t* m = mask + (long)b * H * W + w;
+  float cum = 0.f, tot = 0.f;
+  for (int i = 0; i < H; ++i) {
+    float nm = m[(long)i * W] ? 0.f : 1.f;
+    tot += nm;
+    if (i <= h) cum += nm;
+  }
+  float y = cum / (tot + 1e-6f) * 6.283185307179586f;
+  float dim_t = powf(10000.f, (float)(2 * (c / 2)) / (float)D);
+  float a = y / dim_t;
+  pos[e] = (T)((c & 1) ? cosf(a) : sinf(a));
+}
+
+__global__ void mask_resize_kernel(const uint8_t* in, uint8_t* out, int B, int Hin, int Win, int Hout, int Wout) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)B * Hout * Wout) return;
+  int w = (int)(e % Wout);
+  long r = e / Wout;
+  int h = (int)(r % Hout), b = (int)(r / Hout);
+  float sh = (float)Hin / (float)Hout, sw = (float)Win / (float)Wout;
+  int hi = min((int)floorf(h * sh), Hin - 1), wi = min((int)floorf(w * sw), Win - 1);
+  out[e] = in[((long)b * Hin + hi) * Win + wi];
+}
+
+// ------------------------------------------------------------------ optimizer
+__global__ void sumsq_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sumsq_final_kernel(const float* part, int nparts, float* out, int accumulate) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = red[0] + red[1] + red[2] + red[3];
+    out[0] = accumulate ? out[0] + tot : tot;
+  }
+}
+static int sumsq_parts(long n) {
+  long b = (n + 256 * 8 - 1) / (256 * 8);
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+__global__ void adamw_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, long n, const float* sumsq, float max_norm, float lr, float b1,
+                                  float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float coef = 1.f;
+  if (max_norm > 0.f) {
+    coef = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
+    coef = coef < 1.f ? coef : 1.f;
+  }
+  float gr = g[i] * coef;
+  float pi = p[i] * (1.f - lr * wd);
+  float mi = m[i] + (gr - m[i]) * (1.f - b1);
+  float vi = v[i] * b2 + gr * gr * (1.f - b2);
+  float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = pi - (lr / bc1) * (mi / denom);
+  m[i] = mi;
+  v[i] = vi;
+}
+
+}  // namespace sedt
+
+using namespace sedt;
+
+extern "C" const char* sedt_last_error(void) { return g_err; }
+extern "C" int sedt_version(void) { return 1; }
+
+#define BY_DTYPE(dtype, CALL_F32, CALL_BF16)                   \
+  if ((dtype) == SEDT_F32) { CALL_F32; }                       \
+  else if ((dtype) == SEDT_BF16) { CALL_BF16; }                \
+  else { set_error("unsupported dtype %d", (int)(dtype)); return 1; }
+
+extern "C" int sedt_wgrad_reduce(const float* slab, int splitk, int R, int taps, int Ci, const float* rowscale,
+                                 float* out, void* stream) {
+  SEDT_REQUIRE(slab && out && splitk >= 1, "wgrad_reduce: bad args");
+  long n = (long)R * taps * Ci;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(n)), dim3(256), 0, S(stream), slab, splitk, R, taps, Ci, rowscale, out);
+  return check_launch("wgrad_reduce");
+}
+
+extern "C" size_t sedt_colsum_scratch(int rows, int cols) { return (size_t)colsum_chunks(rows) * cols * sizeof(float); }
+
+extern "C" int sedt_colsum(const void* in, int64_t ld, int rows, int cols, int in_f32, int dtype, float* out,
+                           float* scratch, size_t scratch_bytes, void* stream) {
+  int chunks = colsum_chunks(rows);
+  SEDT_REQUIRE(in && out, "colsum: null pointer");
+  SEDT_REQUIRE(chunks == 1 || (scratch && scratch_bytes >= sedt_colsum_scratch(rows, cols)), "colsum: scratch too small");
+  int rpc = (rows + chunks - 1) / chunks;
+  dim3 grid((cols + 63) / 64, chunks);
+  float* stage1 = chunks == 1 ? out : scratch;
+  if (in_f32 || dtype == SEDT_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, S(stream), (const float*)in, (long)ld, rows, cols, rpc, stage1);
+  else
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, S(stream), (const bf16_t*)in, (long)ld, rows, cols, rpc, stage1);
+  if (chunks > 1)
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((cols + 63) / 64, 1), dim3(256), 0, S(stream), (const float*)scratch,
+                       (long)cols, chunks, cols, chunks, out);
+  return check_launch("colsum");
+}
+
+extern "C" int sedt_dropout_grad(const void* in, int64_t ldi, void* out, int64_t ldo, int rows, int cols, float p,
+                                 uint32_t seed, const uint32_t* seed_ptr, int dtype, void* stream) {
+  SEDT_REQUIRE(p >= 0.f && p < 1.f, "dropout_grad: p out of range");
+  long n = (long)rows * cols;
+  uint32_t th = drop_threshold(p);
+  float ik = 1.f / (1.f - p);
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(dropout_grad_kernel<float>, dim3(nblk(n)), dim3(256), 0, S(stream), (const float*)in, (long)ldi,
+                              (float*)out, (long)ldo, rows, cols, th, ik, seed, seed_ptr),
+           hipLaunchKernelGGL(dropout_grad_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, S(stream), (const bf16_t*)in,
+                              (long)ldi, (bf16_t*)out, (long)ldo, rows, cols, th, ik, seed, seed_ptr));
+  return check_launch("dropout_grad");
+}
+
+extern "C" int sedt_add(const void* a, const void* b, void* out, int rows, int cols, int b_mod, int dtype, void* stream) {
+  long n = (long)rows * cols;
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(add_kernel<float>, dim3(nblk(n)), dim3(256), 0, S(stream), (const float*)a, (const float*)b,
+                              (float*)out, rows, cols, b_mod),
+           hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, S(stream), (const bf16_t*)a,
+                              (const bf16_t*)b, (bf16_t*)out, rows, cols, b_mod));
+  return check_launch("add");
+}
+
+extern "C" int sedt_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, void* stream) {
+  dim3 g(nblk(n)), b(256);
+  if (in_dtype == SEDT_F32 && out_dtype == SEDT_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, b, 0, S(stream), (const float*)in, (bf16_t*)out, (long)n);
+  else if (in_dtype == SEDT_BF16 && out_dtype == SEDT_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, b, 0, S(stream), (const bf16_t*)in, (float*)out, (long)n);
+  else if (in_dtype == SEDT_F32 && out_dtype == SEDT_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), g, b, 0, S(stream), (const float*)in, (float*)out, (long)n);
+  else if (in_dtype == SEDT_BF16 && out_dtype == SEDT_BF16)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, S(stream), (const bf16_t*)in, (bf16_t*)out, (long)n);
+  else { set_error("cast: bad dtypes %d -> %d", in_dtype, out_dtype); return 1; }
+  return check_launch("cast");
+}
+
+extern "C" int sedt_sigmoid_grad(const float* g, const float* s, float* out, int64_t n, void* stream) {
+  hipLaunchKernelGGL(sigmoid_grad_kernel, dim3(nblk(n)), dim3(256), 0, S(stream), g, s, out, (long)n);
+  return check_launch("sigmoid_grad");
+}
+
+extern "C" int sedt_bn_fold(const float* w, const float* b, const float* rm, const float* rv, float* scale, float* bias,
+                            int n, void* stream) {
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(nblk(n)), dim3(256), 0, S(stream), w, b, rm, rv, scale, bias, n);
+  return check_launch("bn_fold");
+}
+
+extern "C" int sedt_pack_conv(const float* w, int Cout, int Cin, int taps, const float* bnscale, void* wf, void* wb,
+                              int dtype, void* stream) {
+  long n = (long)Cout * Cin * taps;
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(nblk(n)), dim3(256), 0, S(stream), w, Cout, Cin, taps, bnscale,
+                              (float*)wf, (float*)wb),
+           hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, S(stream), w, Cout, Cin, taps, bnscale,
+                              (bf16_t*)wf, (bf16_t*)wb));
+  return check_launch("pack_conv");
+}
+
+extern "C" int sedt_stem_prep(const float* w0, const float* b0, const float* w1, void* wcat, int dtype, void* stream) {
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(stem_prep_kernel<float>, dim3(32), dim3(256), 0, S(stream), w0, b0, w1, (float*)wcat),
+           hipLaunchKernelGGL(stem_prep_kernel<bf16_t>, dim3(32), dim3(256), 0, S(stream), w0, b0, w1, (bf16_t*)wcat));
+  return check_launch("stem_prep");
+}
+
+extern "C" int sedt_stem_im2col(const float* x, void* col, int B, int H, int W, int dtype, void* stream) {
+  int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  long n = (long)B * Ho * Wo * 128;
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(nblk(n)), dim3(256), 0, S(stream), x, (float*)col, B, H, W, Ho, Wo),
+           hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, S(stream), x, (bf16_t*)col, B, H, W, Ho, Wo));
+  return check_launch("stem_im2col");
+}
+
+extern "C" int sedt_stem_conv0_grad(const float* G, const float* w1, float* dw0, float* db0, void* stream) {
+  hipLaunchKernelGGL(stem_conv0_grad_kernel, dim3(1), dim3(256), 0, S(stream), G, w1, dw0, db0);
+  return check_launch("stem_conv0_grad");
+}
+
+extern "C" int sedt_maxpool_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, int dtype, void* stream) {
+  int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  long n = (long)B * Ho * Wo * C;
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(nblk(n)), dim3(256), 0, S(stream), (const float*)x, (float*)y, idx,
+                              B, H, W, C, Ho, Wo),
+           hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, S(stream), (const bf16_t*)x, (bf16_t*)y,
+                              idx, B, H, W, C, Ho, Wo));
+  return check_launch("maxpool_fwd");
+}
+
+extern "C" int sedt_maxpool_bwd(const void* dy, const uint8_t* idx, const void* relu_src, void* dx, int B, int H, int W,
+                                int C, int dtype, void* stream) {
+  int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  long n = (long)B * H * W * C;
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nblk(n)), dim3(256), 0, S(stream), (const float*)dy, idx,
+                              (const float*)relu_src, (float*)dx, B, H, W, C, Ho, Wo),
+           hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, S(stream), (const bf16_t*)dy, idx,
+                              (const bf16_t*)relu_src, (bf16_t*)dx, B, H, W, C, Ho, Wo));
+  return check_launch("maxpool_bwd");
+}
+
+extern "C" int sedt_avgpool(const void* x, float* out, int B, int P, int C, int dtype, void* stream) {
+  long n = (long)B * C;
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(avgpool_kernel<float>, dim3(nblk(n)), dim3(256), 0, S(stream), (const float*)x, out, B, P, C),
+           hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, S(stream), (const bf16_t*)x, out, B, P, C));
+  return check_launch("avgpool");
+}
+
+extern "C" int sedt_posenc(const uint8_t* mask, void* pos, int B, int H, int W, int D, int dtype, void* stream) {
+  long n = (long)B * H * W * D;
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(posenc_kernel<float>, dim3(nblk(n)), dim3(256), 0, S(stream), mask, (float*)pos, B, H, W, D),
+           hipLaunchKernelGGL(posenc_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, S(stream), mask, (bf16_t*)pos, B, H, W, D));
+  return check_launch("posenc");
+}
+
+extern "C" int sedt_mask_resize(const uint8_t* in, uint8_t* out, int B, int Hin, int Win, int Hout, int Wout, void* stream) {
+  long n = (long)B * Hout * Wout;
+  hipLaunchKernelGGL(mask_resize_kernel, dim3(nblk(n)), dim3(256), 0, S(stream), in, out, B, Hin, Win, Hout, Wout);
+  return check_launch("mask_resize");
+}
+
+extern "C" size_t sedt_sumsq_scratch(int64_t n) { return (size_t)sumsq_parts(n) * sizeof(float); }
+
+extern "C" int sedt_sumsq(const float* g, int64_t n, float* sumsq, float* scratch, size_t scratch_bytes, int accumulate,
+                          void* stream) {
+  int parts = sumsq_parts(n);
+  SEDT_REQUIRE(scratch && scratch_bytes >= (size_t)parts * sizeof(float), "sumsq: scratch too small");
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(parts), dim3(256), 0, S(stream), g, (long)n, scratch);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, S(stream), scratch, parts, sumsq, accumulate);
+  return check_launch("sumsq");
+}
+
+extern "C" int sedt_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm,
+                               float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream) {
+  SEDT_REQUIRE(step >= 1, "adamw: step must be >= 1");
+  float bc1 = 1.f - powf(beta1, (float)step);
+  float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_clip_kernel, dim3(nblk(n)), dim3(256), 0, S(stream), p, g, m, v, (long)n, sumsq, max_norm, lr, beta1,
+                     beta2, eps, weight_decay, bc1, bc2s);
+  return check_launch("adamw_clip");
+}

@@ -1,0 +1,104 @@
+"""ctypes binding of libsedt_hip.so (the C ABI declared in include/sedt_hip.h).
+
+The product path has no fallback: if the library is missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libsedt_hip.so')
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+class SedtIgemm(C.Structure):
+    _fields_ = [
+        ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+        ('A', C.c_void_p), ('B', C.c_void_p),
+        ('lda', C.c_int64), ('ldb', C.c_int64),
+        ('trans', C.c_int32), ('conv', C.c_int32), ('transposed', C.c_int32),
+        ('Hi', C.c_int32), ('Wi', C.c_int32), ('Ci', C.c_int32), ('Ho', C.c_int32), ('Wo', C.c_int32),
+        ('KH', C.c_int32), ('KW', C.c_int32), ('sh', C.c_int32), ('sw', C.c_int32), ('ph', C.c_int32),
+        ('pw', C.c_int32), ('dh', C.c_int32), ('dw', C.c_int32),
+        ('C', C.c_void_p), ('ldc', C.c_int64), ('out_f32', C.c_int32),
+        ('scale', C.c_void_p), ('bias', C.c_void_p),
+        ('res', C.c_void_p), ('ldr', C.c_int64), ('res_mod', C.c_int32),
+        ('mask', C.c_void_p), ('ldm', C.c_int64),
+        ('act', C.c_int32), ('act_post_res', C.c_int32),
+        ('alpha', C.c_float), ('drop_p', C.c_float), ('seed', C.c_uint32), ('seed_ptr', C.c_void_p),
+        ('splitk', C.c_int32), ('slab', C.c_void_p),
+        ('tile_m', C.c_int32), ('tile_n', C.c_int32),
+    ]
+
+
+_vp, _i, _i64, _f, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/sedt_hip.h one to one
+SIGNATURES = {
+    'sedt_last_error': (C.c_char_p, []),
+    'sedt_version': (_i, []),
+    'sedt_igemm': (_i, [C.POINTER(SedtIgemm), _i, _vp]),
+    'sedt_igemm_splitk': (_i, [_i, _i, _i, _i]),
+    'sedt_wgrad_reduce': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'sedt_colsum': (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    'sedt_colsum_scratch': (_sz, [_i, _i]),
+    'sedt_dropout_grad': (_i, [_vp, _i64, _vp, _i64, _i, _i, _f, _u32, _vp, _i, _vp]),
+    'sedt_add': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'sedt_cast': (_i, [_vp, _i, _vp, _i, _i64, _vp]),
+    'sedt_sigmoid_grad': (_i, [_vp, _vp, _vp, _i64, _vp]),
+    'sedt_layernorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'sedt_layernorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    'sedt_layernorm_bwd_scratch': (_sz, [_i, _i]),
+    'sedt_attention_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u32,
+                                _vp, _i, _vp]),
+    'sedt_attention_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp,
+                                _i64, _vp, _i64, _i, _i, _i, _i, _f, _u32, _vp, _i, _vp]),
+    'sedt_posenc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'sedt_mask_resize': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'sedt_bn_fold': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    'sedt_pack_conv': (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    'sedt_stem_prep': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    'sedt_stem_im2col': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'sedt_stem_conv0_grad': (_i, [_vp, _vp, _vp, _vp, _vp]),
+    'sedt_maxpool_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'sedt_maxpool_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'sedt_avgpool': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'sedt_sumsq': (_i, [_vp, _i64, _vp, _vp, _sz, _i, _vp]),
+    'sedt_sumsq_scratch': (_sz, [_i64]),
+    'sedt_adamw_clip': (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(there is no CPU/PyTorch fallback for the SEDT hot path)')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(status, what=''):
+    if status != 0:
+        raise RuntimeError(f'{what}: {load().sedt_last_error().decode()}')
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def p(t):
+    """device pointer of a tensor (or None)"""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,310 @@
+"""Tensor-level wrappers over the C ABI (include/sedt_hip.h).
+
+Every function takes torch tensors that live on the GPU, passes raw device pointers + sizes to
+libsedt_hip.so on the current torch stream and returns torch tensors allocated with the caching
+allocator.  No arithmetic happens in torch here; torch is device memory + streams only.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .lib import F32, BF16, ACT_NONE, ACT_RELU, ACT_SIGMOID, TORCH_DTYPE, p as _p  # noqa: F401
+
+
+class ConvGeom(object):
+    """geometry of one convolution over NHWC activations"""
+    __slots__ = ('Hi', 'Wi', 'Ci', 'Ho', 'Wo', 'Co', 'KH', 'KW', 'sh', 'sw', 'ph', 'pw', 'dh', 'dw')
+
+    def __init__(self, Hi, Wi, Ci, Co, k=1, stride=1, pad=0, dil=1):
+        self.Hi, self.Wi, self.Ci, self.Co = Hi, Wi, Ci, Co
+        self.KH = self.KW = k
+        self.sh = self.sw = stride
+        self.ph = self.pw = pad
+        self.dh = self.dw = dil
+        self.Ho = (Hi + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        self.Wo = (Wi + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+    @property
+    def taps(self):
+        return self.KH * self.KW
+
+    @property
+    def plain(self):
+        return self.KH == 1 and self.KW == 1 and self.sh == 1 and self.sw == 1 and self.ph == 0 and self.pw == 0
+
+
+def _dev_check(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('sedt ops need GPU tensors: the HIP path has no CPU fallback')
+
+
+def igemm(dtype, M, N, K, A, lda, B, ldb, Cout, ldc, *, trans=0, conv=None, transposed=0, out_f32=0, scale=None,
+          bias=None, res=None, ldr=0, res_mod=0, mask=None, ldm=0, act=ACT_NONE, act_post_res=0, alpha=1.0, drop_p=0.0,
+          seed=0, seed_ptr=None, splitk=1, slab=None, tile=(0, 0)):
+    """raw implicit GEMM call; ``conv`` = (Hi, Wi, Ci, Ho, Wo, KH, KW, sh, sw, ph, pw, dh, dw) or None"""
+    _dev_check(A, B, Cout)
+    a = L.SedtIgemm()
+    a.M, a.N, a.K = M, N, K
+    a.A, a.B, a.lda, a.ldb = A.data_ptr(), B.data_ptr(), lda, ldb
+    a.trans, a.transposed = trans, transposed
+    if conv is not None:
+        a.conv = 1
+        (a.Hi, a.Wi, a.Ci, a.Ho, a.Wo, a.KH, a.KW, a.sh, a.sw, a.ph, a.pw, a.dh, a.dw) = conv
+    else:
+        a.conv = 0
+        a.KH = a.KW = a.sh = a.sw = a.dh = a.dw = 1
+    a.C = Cout.data_ptr() if Cout is not None else None
+    a.ldc, a.out_f32 = ldc, out_f32
+    a.scale = scale.data_ptr() if scale is not None else None
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.res = res.data_ptr() if res is not None else None
+    a.ldr, a.res_mod = ldr, res_mod
+    a.mask = mask.data_ptr() if mask is not None else None
+    a.ldm = ldm
+    a.act, a.act_post_res, a.alpha = act, act_post_res, alpha
+    a.drop_p, a.seed = drop_p, seed & 0xffffffff
+    a.seed_ptr = seed_ptr.data_ptr() if seed_ptr is not None else None
+    a.splitk = splitk
+    a.slab = slab.data_ptr() if slab is not None else None
+    a.tile_m, a.tile_n = tile
+    L.check(L.load().sedt_igemm(C.byref(a), dtype, L.stream_ptr()), 'sedt_igemm')
+
+
+def _geom_tuple(g, transposed=False):
+    if transposed:   # rows run over the conv INPUT grid, gathered tensor is dY on the conv OUTPUT grid
+        return (g.Ho, g.Wo, g.Co, g.Hi, g.Wi, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw, g.dh, g.dw)
+    return (g.Hi, g.Wi, g.Ci, g.Ho, g.Wo, g.KH, g.KW, g.sh, g.sw, g.ph, g.pw, g.dh, g.dw)
+
+
+def linear(dtype, x, w, out=None, *, bias=None, out_f32=False, **ep):
+    """y[M,N] = epilogue(x[M,K] @ w[N,K]^T); x/w may be row-strided views (last dim contiguous)"""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), device=x.device, dtype=torch.float32 if out_f32 else TORCH_DTYPE[dtype])
+    igemm(dtype, M, N, K, x, x.stride(0), w, w.stride(0), out, out.stride(0), bias=bias, out_f32=int(out_f32), **ep)
+    return out
+
+
+def conv_fwd(dtype, x, B, g, wf, out=None, **ep):
+    """NHWC conv forward: x [B*Hi*Wi, Ci] (row stride = x.stride(0)), wf packed [Co][taps][Ci]"""
+    M = B * g.Ho * g.Wo
+    if out is None:
+        out = torch.empty((M, g.Co), device=x.device, dtype=TORCH_DTYPE[dtype])
+    conv = None if g.plain else _geom_tuple(g)
+    igemm(dtype, M, g.Co, g.taps * g.Ci, x, x.stride(0), wf, g.taps * g.Ci, out, out.stride(0), conv=conv, **ep)
+    return out
+
+
+def conv_dgrad(dtype, dy, B, g, wb, out=None, **ep):
+    """dx [B*Hi*Wi, Ci] = conv_transpose(dy [B*Ho*Wo, Co]); wb packed [Ci][taps][Co] (BN scale folded in)"""
+    M = B * g.Hi * g.Wi
+    if out is None:
+        out = torch.empty((M, g.Ci), device=dy.device, dtype=TORCH_DTYPE[dtype])
+    conv = None if g.plain else _geom_tuple(g, transposed=True)
+    igemm(dtype, M, g.Ci, g.taps * g.Co, dy, dy.stride(0), wb, g.taps * g.Co, out, out.stride(0), conv=conv,
+          transposed=0 if g.plain else 1, **ep)
+    return out
+
+
+def wgrad(dtype, dy, x, B, g, rowscale=None, out=None):
+    """dW (Co, Ci, KH, KW) f32 = sum over pixels dy[pix][co] * gather(x)[pix][tap][ci] (* rowscale[co])"""
+    lib = L.load()
+    Mo, No, Kp = g.Co, g.taps * g.Ci, B * g.Ho * g.Wo
+    sk = lib.sedt_igemm_splitk(Mo, No, Kp, dtype)
+    slab = torch.empty((sk, Mo, No), device=dy.device, dtype=torch.float32)
+    conv = None if g.plain else _geom_tuple(g)
+    igemm(dtype, Mo, No, Kp, dy, dy.stride(0), x, x.stride(0), slab, No, trans=1, conv=conv, out_f32=1, splitk=sk,
+          slab=slab)
+    if out is None:
+        out = torch.empty((g.Co, g.Ci, g.KH, g.KW), device=dy.device, dtype=torch.float32)
+    L.check(lib.sedt_wgrad_reduce(_p(slab), sk, Mo, g.taps, g.Ci, _p(rowscale), _p(out), L.stream_ptr()), 'wgrad_reduce')
+    return out
+
+
+def linear_wgrad(dtype, dy, x, out=None):
+    """dW [N,K] f32 = dy[M,N]^T @ x[M,K]"""
+    N, K = dy.shape[1], x.shape[1]
+    g = ConvGeom(1, 1, K, N)
+    return wgrad(dtype, dy, x, dy.shape[0], g, out=out.view(N, K, 1, 1) if out is not None else None).view(N, K)
+
+
+def colsum(dtype, x, out=None):
+    """column sums of x[rows, cols] (compute dtype or f32) -> f32[cols]"""
+    lib = L.load()
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty((cols,), device=x.device, dtype=torch.float32)
+    nb = lib.sedt_colsum_scratch(rows, cols)
+    scratch = torch.empty((max(nb // 4, 1),), device=x.device, dtype=torch.float32)
+    L.check(lib.sedt_colsum(_p(x), x.stride(0), rows, cols, int(x.dtype == torch.float32), dtype, _p(out), _p(scratch),
+                            nb, L.stream_ptr()), 'colsum')
+    return out
+
+
+def dropout_grad(dtype, g, p, seed, seed_ptr=None, out=None):
+    rows, cols = g.shape
+    if out is None:
+        out = torch.empty((rows, cols), device=g.device, dtype=g.dtype)
+    L.check(L.load().sedt_dropout_grad(_p(g), g.stride(0), _p(out), out.stride(0), rows, cols, p, seed & 0xffffffff,
+                                       _p(seed_ptr), dtype, L.stream_ptr()), 'dropout_grad')
+    return out
+
+
+def add(dtype, a, b, b_mod=0, out=None):
+    rows, cols = a.shape
+    if out is None:
+        out = torch.empty_like(a)
+    L.check(L.load().sedt_add(_p(a), _p(b), _p(out), rows, cols, b_mod, dtype, L.stream_ptr()), 'add')
+    return out
+
+
+def cast(x, out_dtype):
+    """f32 <-> compute dtype"""
+    code = {torch.float32: F32, torch.bfloat16: BF16}
+    x = x.contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=TORCH_DTYPE[out_dtype])
+    L.check(L.load().sedt_cast(_p(x), code[x.dtype], _p(out), out_dtype, x.numel(), L.stream_ptr()), 'cast')
+    return out
+
+
+def sigmoid_grad(g, s):
+    g, s = g.contiguous(), s.contiguous()
+    out = torch.empty_like(g)
+    L.check(L.load().sedt_sigmoid_grad(_p(g), _p(s), _p(out), g.numel(), L.stream_ptr()), 'sigmoid_grad')
+    return out
+
+
+def layernorm_fwd(dtype, x, gamma, beta, add_t=None):
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    y2 = torch.empty_like(x) if add_t is not None else None
+    mean = torch.empty((rows,), device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    L.check(L.load().sedt_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(add_t), _p(y), _p(y2), _p(mean), _p(rstd), rows, D,
+                                        dtype, L.stream_ptr()), 'layernorm_fwd')
+    return y, y2, mean, rstd
+
+
+def layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2=None, dres=None, want_param_grads=True):
+    lib = L.load()
+    rows, D = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty((D,), device=x.device, dtype=torch.float32) if want_param_grads else None
+    db = torch.empty((D,), device=x.device, dtype=torch.float32) if want_param_grads else None
+    nb = lib.sedt_layernorm_bwd_scratch(rows, D)
+    scratch = torch.empty((nb // 4,), device=x.device, dtype=torch.float32)
+    L.check(lib.sedt_layernorm_bwd(_p(dy), _p(dy2), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dg), _p(db),
+                                   _p(scratch), nb, rows, D, dtype, L.stream_ptr()), 'layernorm_bwd')
+    return dx, dg, db
+
+
+def attention_fwd(dtype, q, k, v, B, H, Lq, Lk, kpm=None, amask=None, drop_p=0.0, seed=0, seed_ptr=None, out=None):
+    """q [B*Lq, >=H*32] / k, v [B*Lk, ...] row-strided views; returns (o [B*Lq, H*32], lse [B,H,Lq])"""
+    if out is None:
+        out = torch.empty((B * Lq, H * 32), device=q.device, dtype=q.dtype)
+    lse = torch.empty((B, H, Lq), device=q.device, dtype=torch.float32)
+    L.check(L.load().sedt_attention_fwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0),
+                                        _p(lse), _p(kpm), _p(amask), B, H, Lq, Lk, drop_p, seed & 0xffffffff, _p(seed_ptr),
+                                        dtype, L.stream_ptr()), 'attention_fwd')
+    return out, lse
+
+
+def attention_bwd(dtype, q, k, v, o, do, lse, B, H, Lq, Lk, dq, dk, dv, kpm=None, amask=None, drop_p=0.0, seed=0,
+                  seed_ptr=None):
+    L.check(L.load().sedt_attention_bwd(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+                                        _p(do), do.stride(0), _p(lse), _p(kpm), _p(amask), _p(dq), dq.stride(0), _p(dk),
+                                        dk.stride(0), _p(dv), dv.stride(0), B, H, Lq, Lk, drop_p, seed & 0xffffffff,
+                                        _p(seed_ptr), dtype, L.stream_ptr()), 'attention_bwd')
+    return dq, dk, dv
+
+
+def posenc(dtype, mask_u8, D):
+    B, H, W = mask_u8.shape
+    pos = torch.empty((B, H * W, D), device=mask_u8.device, dtype=TORCH_DTYPE[dtype])
+    L.check(L.load().sedt_posenc(_p(mask_u8), _p(pos), B, H, W, D, dtype, L.stream_ptr()), 'posenc')
+    return pos
+
+
+def mask_resize(mask_u8, Hout, Wout):
+    B, Hin, Win = mask_u8.shape
+    out = torch.empty((B, Hout, Wout), device=mask_u8.device, dtype=torch.uint8)
+    L.check(L.load().sedt_mask_resize(_p(mask_u8), _p(out), B, Hin, Win, Hout, Wout, L.stream_ptr()), 'mask_resize')
+    return out
+
+
+def bn_fold(w, b, rm, rv, scale=None, bias=None):
+    n = w.numel()
+    if scale is None:
+        scale = torch.empty((n,), device=w.device, dtype=torch.float32)
+        bias = torch.empty_like(scale)
+    L.check(L.load().sedt_bn_fold(_p(w), _p(b), _p(rm), _p(rv), _p(scale), _p(bias), n, L.stream_ptr()), 'bn_fold')
+    return scale, bias
+
+
+def pack_conv(dtype, w, bnscale=None, want_fwd=True, want_bwd=True, wf=None, wb=None):
+    """w (Co, Ci, KH, KW) or (N, K) f32 -> wf [Co][taps][Ci], wb [Ci][taps][Co]*bnscale in the compute dtype"""
+    Co, Ci = w.shape[0], w.shape[1]
+    taps = w.numel() // (Co * Ci)
+    td = TORCH_DTYPE[dtype]
+    if want_fwd and wf is None:
+        wf = torch.empty((Co, taps * Ci), device=w.device, dtype=td)
+    if want_bwd and wb is None:
+        wb = torch.empty((Ci, taps * Co), device=w.device, dtype=td)
+    L.check(L.load().sedt_pack_conv(_p(w), Co, Ci, taps, _p(bnscale), _p(wf), _p(wb), dtype, L.stream_ptr()), 'pack_conv')
+    return wf, wb
+
+
+def stem_prep(dtype, w0, b0, w1):
+    wcat = torch.empty((64, 128), device=w1.device, dtype=TORCH_DTYPE[dtype])
+    L.check(L.load().sedt_stem_prep(_p(w0), _p(b0), _p(w1), _p(wcat), dtype, L.stream_ptr()), 'stem_prep')
+    return wcat
+
+
+def stem_im2col(dtype, x, B, H, W):
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    col = torch.empty((B * Ho * Wo, 128), device=x.device, dtype=TORCH_DTYPE[dtype])
+    L.check(L.load().sedt_stem_im2col(_p(x), _p(col), B, H, W, dtype, L.stream_ptr()), 'stem_im2col')
+    return col, Ho, Wo
+
+
+def stem_conv0_grad(G, w1):
+    dw0 = torch.empty((3, 1, 1, 1), device=G.device, dtype=torch.float32)
+    db0 = torch.empty((3,), device=G.device, dtype=torch.float32)
+    L.check(L.load().sedt_stem_conv0_grad(_p(G), _p(w1), _p(dw0), _p(db0), L.stream_ptr()), 'stem_conv0_grad')
+    return dw0, db0
+
+
+def maxpool_fwd(dtype, x, B, H, W, Cch):
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B * Ho * Wo, Cch), device=x.device, dtype=x.dtype)
+    idx = torch.empty((B * Ho * Wo, Cch), device=x.device, dtype=torch.uint8)
+    L.check(L.load().sedt_maxpool_fwd(_p(x), _p(y), _p(idx), B, H, W, Cch, dtype, L.stream_ptr()), 'maxpool_fwd')
+    return y, idx, Ho, Wo
+
+
+def maxpool_bwd(dtype, dy, idx, relu_src, B, H, W, Cch):
+    dx = torch.empty((B * H * W, Cch), device=dy.device, dtype=dy.dtype)
+    L.check(L.load().sedt_maxpool_bwd(_p(dy), _p(idx), _p(relu_src), _p(dx), B, H, W, Cch, dtype, L.stream_ptr()), 'maxpool_bwd')
+    return dx
+
+
+def avgpool(dtype, x, B, P, Cch):
+    out = torch.empty((B, Cch), device=x.device, dtype=torch.float32)
+    L.check(L.load().sedt_avgpool(_p(x), _p(out), B, P, Cch, dtype, L.stream_ptr()), 'avgpool')
+    return out
+
+
+def sumsq(g, out, accumulate=False):
+    lib = L.load()
+    nb = lib.sedt_sumsq_scratch(g.numel())
+    scratch = torch.empty((nb // 4,), device=g.device, dtype=torch.float32)
+    L.check(lib.sedt_sumsq(_p(g), g.numel(), _p(out), _p(scratch), nb, int(accumulate), L.stream_ptr()), 'sumsq')
+    return out
+
+
+def adamw_clip(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, weight_decay, step):
+    L.check(L.load().sedt_adamw_clip(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq_t), max_norm, lr, beta1, beta2, eps,
+                                     weight_decay, step, L.stream_ptr()), 'adamw_clip')

@@ -1,0 +1,339 @@
+"""GPU: every HIP op through the C ABI against plain PyTorch fp32 on the CPU.
+
+Tolerances: f32 mode rtol 2e-4 (exact-f32 MFMA, different summation order); bf16 mode compares
+against the f32 reference evaluated on bf16-rounded inputs with 2e-2 of the output scale."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+F32, BF16 = 0, 1
+TD = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from sound_event_detection_transformer_amd import ops as o
+    assert torch.cuda.is_available()
+    return o
+
+
+def dev(t, dt):
+    return t.to(TD[dt]).cuda().contiguous()
+
+
+def rnd(t, dt):
+    """what the kernel sees after the dtype cast"""
+    return t.to(TD[dt]).float()
+
+
+def close(got, ref, dt, f32_tol=2e-4, bf16_tol=2e-2):
+    got = got.float().cpu()
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item() / scale
+    tol = f32_tol if dt == F32 else bf16_tol
+    assert err < tol, f'rel err {err:.3e} (tol {tol}) scale {scale:.3e}'
+
+
+G = torch.Generator().manual_seed(1234)
+
+
+def randn(*s):
+    return torch.randn(*s, generator=G)
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+@pytest.mark.parametrize('M,N,K', [(256, 256, 256), (704, 11, 256), (300, 200, 96), (8192, 768, 256), (130, 70, 64),
+                                   (64, 2, 256), (257, 129, 40)])
+def test_linear_epilogues(ops, dt, M, N, K):
+    x, w, b = randn(M, K), randn(N, K) / math.sqrt(K), randn(N)
+    res, msk, sc = randn(M, N), randn(M, N), torch.rand(N, generator=G) + 0.5
+    xr, wr, rr, mr = rnd(x, dt), rnd(w, dt), rnd(res, dt), rnd(msk, dt)
+    # plain + bias
+    y = ops.linear(dt, dev(x, dt), dev(w, dt), bias=b.cuda())
+    close(y, xr @ wr.t() + b, dt)
+    # scale, bias, residual then relu (bottleneck conv3 form), f32 output
+    y = ops.linear(dt, dev(x, dt), dev(w, dt), bias=b.cuda(), scale=sc.cuda(), res=dev(res, dt), ldr=N,
+                   act=ops.ACT_RELU, act_post_res=1, out_f32=True)
+    assert y.dtype == torch.float32
+    close(y, F.relu((xr @ wr.t()) * sc + b + rr), dt)
+    # relu before residual, mask, alpha (dgrad form)
+    y = ops.linear(dt, dev(x, dt), dev(w, dt), res=dev(res, dt), ldr=N, mask=dev(msk, dt), ldm=N, alpha=0.5)
+    close(y, (xr @ wr.t() + rr) * (mr > 0) * 0.5, dt)
+    # sigmoid, broadcast residual rows (res_mod)
+    rm = 7
+    y = ops.linear(dt, dev(x, dt), dev(w, dt), bias=b.cuda(), act=ops.ACT_SIGMOID, res=dev(res[:rm], dt), ldr=N, res_mod=rm)
+    close(y, torch.sigmoid(xr @ wr.t() + b) + rr[torch.arange(M) % rm], dt)
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+@pytest.mark.parametrize('tile', [(128, 128), (128, 64), (64, 64)])
+def test_linear_tiles_and_strided_views(ops, dt, tile):
+    M, N, K = 384, 256, 256
+    big = randn(M, 3 * K)
+    w = randn(N, K) / 16
+    xb = dev(big, dt)
+    xv = xb[:, K:2 * K]                      # column slice: lda = 3K
+    out = torch.zeros((M, 2 * N), device='cuda', dtype=TD[dt])
+    ops.igemm(dt, M, N, K, xv, xv.stride(0), dev(w, dt), K, out[:, N:], out.stride(0), tile=tile)
+    close(out[:, N:], rnd(big[:, K:2 * K], dt) @ rnd(w, dt).t(), dt)
+    assert out[:, :N].abs().max().item() == 0
+
+
+CONVS = [  # Hi, Wi, Ci, Co, k, stride, pad, dil
+    (20, 8, 64, 64, 3, 1, 1, 1), (21, 8, 64, 128, 3, 2, 1, 1), (8, 4, 128, 64, 3, 1, 2, 2), (13, 6, 64, 128, 1, 2, 0, 1),
+    (10, 4, 128, 256, 1, 1, 0, 1)]
+
+
+def _nhwc(x_nchw):
+    return x_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+@pytest.mark.parametrize('cfg', CONVS)
+def test_conv_fwd_dgrad_wgrad(ops, dt, cfg):
+    Hi, Wi, Ci, Co, k, s, pd, dl = cfg
+    B = 3
+    g = ops.ConvGeom(Hi, Wi, Ci, Co, k, s, pd, dl)
+    x = randn(B, Ci, Hi, Wi)
+    w = randn(Co, Ci, k, k) / math.sqrt(Ci * k * k)
+    sc, bi = torch.rand(Co, generator=G) + 0.5, randn(Co)
+    xr, wr = rnd(x, dt).requires_grad_(True), rnd(w, dt).requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, stride=s, padding=pd, dilation=dl)
+    assert y_ref.shape[2:] == (g.Ho, g.Wo)
+    wf, wb = ops.pack_conv(dt, w.cuda(), bnscale=sc.cuda())
+    xd = dev(_nhwc(x).reshape(-1, Ci), dt)
+    # forward with folded FrozenBN + relu
+    y = ops.conv_fwd(dt, xd, B, g, wf, scale=sc.cuda(), bias=bi.cuda(), act=ops.ACT_RELU)
+    ref = F.relu(y_ref * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1))
+    close(y, _nhwc(ref).reshape(-1, Co).detach(), dt)
+    # backward through scale: upstream grad gy (already relu-masked by the caller)
+    gy = randn(B, Co, g.Ho, g.Wo)
+    gyr = rnd(gy, dt)
+    (y_ref * sc.view(1, -1, 1, 1)).backward(gyr)
+    gyd = dev(_nhwc(gy).reshape(-1, Co), dt)
+    dx = ops.conv_dgrad(dt, gyd, B, g, wb)
+    close(dx, _nhwc(xr.grad).reshape(-1, Ci), dt)
+    dw = ops.wgrad(dt, gyd, xd, B, g, rowscale=sc.cuda())
+    assert dw.shape == w.shape and dw.dtype == torch.float32
+    close(dw, wr.grad, dt)
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+@pytest.mark.parametrize('M,N,K', [(704, 11, 256), (8192, 256, 2048), (1920, 2, 256), (300, 768, 256), (77, 10, 256)])
+def test_linear_wgrad_and_colsum(ops, dt, M, N, K):
+    x, gy = randn(M, K), randn(M, N)
+    dw = ops.linear_wgrad(dt, dev(gy, dt), dev(x, dt))
+    close(dw, rnd(gy, dt).t() @ rnd(x, dt), dt)
+    cs = ops.colsum(dt, dev(gy, dt))
+    close(cs, rnd(gy, dt).sum(0), dt, bf16_tol=1e-3)
+    cs = ops.colsum(dt, gy.cuda())           # f32 input in either mode
+    close(cs, gy.sum(0), dt, bf16_tol=1e-4)
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+def test_epilogue_dropout_matches_dropout_grad(ops, dt):
+    M, N, K, pdrop, seed = 512, 256, 64, 0.1, 777
+    x, w = randn(M, K), randn(N, K)
+    seedbuf = torch.tensor([5], dtype=torch.int32).cuda()
+    y = ops.linear(dt, dev(x, dt), dev(w, dt), drop_p=pdrop, seed=seed, seed_ptr=seedbuf)
+    keep = ops.dropout_grad(dt, torch.ones(M, N, dtype=TD[dt]).cuda(), pdrop, seed, seedbuf).float().cpu()
+    rate = (keep > 0).float().mean().item()
+    assert abs(rate - 0.9) < 0.01
+    np.testing.assert_allclose(keep[keep > 0].numpy(), 1 / 0.9, rtol=1e-2)
+    close(y, (rnd(x, dt) @ rnd(w, dt).t()) * keep, dt)
+    keep2 = ops.dropout_grad(dt, torch.ones(M, N, dtype=TD[dt]).cuda(), pdrop, seed + 1, seedbuf).float().cpu()
+    assert ((keep > 0) != (keep2 > 0)).float().mean().item() > 0.1      # a different seed is a different mask
+    seedbuf += 1                                                         # device-side seed word changes the mask too
+    keep3 = ops.dropout_grad(dt, torch.ones(M, N, dtype=TD[dt]).cuda(), pdrop, seed, seedbuf).float().cpu()
+    assert torch.equal(keep2 > 0, keep3 > 0)
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+@pytest.mark.parametrize('rows', [8192, 704, 5])
+def test_layernorm(ops, dt, rows):
+    D = 256
+    x, pos = randn(rows, D) * 2 + 0.3, randn(rows, D)
+    gam, bet = torch.rand(D, generator=G) + 0.5, randn(D) * 0.1
+    xr = rnd(x, dt).requires_grad_(True)
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    y_ref = F.layer_norm(xr, (D,), gr, br, 1e-5)
+    y, y2, mean, rstd = ops.layernorm_fwd(dt, dev(x, dt), gam.cuda(), bet.cuda(), dev(pos, dt))
+    close(y, y_ref.detach(), dt)
+    close(y2, (y_ref + rnd(pos, dt)).detach(), dt)
+    dy, dy2, dres = randn(rows, D), randn(rows, D), randn(rows, D)
+    y_ref.backward(rnd(dy, dt) + rnd(dy2, dt))
+    dx, dg, db = ops.layernorm_bwd(dt, dev(dy, dt), dev(x, dt), gam.cuda(), mean, rstd, dy2=dev(dy2, dt), dres=dev(dres, dt))
+    close(dx, xr.grad + rnd(dres, dt), dt)
+    close(dg, gr.grad, dt, bf16_tol=5e-3)
+    close(db, br.grad, dt, bf16_tol=5e-3)
+
+
+def _attn_ref(q, k, v, B, H, Lq, Lk, kpm, amask, keep=None):
+    """q [B*Lq, H*32] etc -> o [B*Lq, H*32]; explicit math of torch MHA's core"""
+    qh = q.view(B, Lq, H, 32).transpose(1, 2) / math.sqrt(32)
+    kh = k.view(B, Lk, H, 32).transpose(1, 2)
+    vh = v.view(B, Lk, H, 32).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2)
+    if amask is not None:
+        s = s + amask
+    if kpm is not None:
+        s = s.masked_fill(kpm.view(B, 1, 1, Lk).bool(), float('-inf'))
+    p = s.softmax(-1)
+    if keep is not None:
+        p = p * keep
+    return (p @ vh).transpose(1, 2).reshape(B * Lq, H * 32), p
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+@pytest.mark.parametrize('Lq,Lk,masks', [(128, 128, False), (124, 124, True), (11, 128, True), (11, 11, False),
+                                         (20, 20, True), (70, 200, False)])
+def test_attention_fwd_bwd(ops, dt, Lq, Lk, masks):
+    B, H = 3, 8
+    q, k, v, do = randn(B * Lq, 256), randn(B * Lk, 256), randn(B * Lk, 256), randn(B * Lq, 256)
+    kpm = amask = None
+    if masks:
+        kpm = torch.zeros(B, Lk, dtype=torch.uint8)
+        kpm[1, Lk - 5:] = 1
+        amask = torch.zeros(Lq, Lk)
+        amask[torch.rand(Lq, Lk, generator=G) < 0.2] = float('-inf')
+        amask[:, 0] = 0                                           # never a fully masked row
+    qr, kr, vr = (rnd(t, dt).requires_grad_(True) for t in (q, k, v))
+    o_ref, _ = _attn_ref(qr, kr, vr, B, H, Lq, Lk, kpm, amask)
+    o_ref.backward(rnd(do, dt))
+    # q/k live in one buffer like the packed QK projection output (row stride 512)
+    qk = dev(torch.cat([q, q], 1), dt)
+    qd = qk[:, :256]
+    kd, vd = dev(k, dt), dev(v, dt)
+    kpm_d = kpm.cuda() if kpm is not None else None
+    am_d = amask.cuda() if amask is not None else None
+    o, lse = ops.attention_fwd(dt, qd, kd, vd, B, H, Lq, Lk, kpm_d, am_d)
+    close(o, o_ref.detach(), dt)
+    dq, dk, dv = (torch.empty_like(dev(t, dt)) for t in (q, k, v))
+    ops.attention_bwd(dt, qd, kd, vd, o, dev(do, dt), lse, B, H, Lq, Lk, dq, dk, dv, kpm_d, am_d)
+    close(dq, qr.grad, dt, bf16_tol=3e-2)
+    close(dk, kr.grad, dt, bf16_tol=3e-2)
+    close(dv, vr.grad, dt, bf16_tol=3e-2)
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+def test_attention_dropout_consistency(ops, dt):
+    """V = identity exposes the dropped probabilities; backward must use the same regenerated mask."""
+    B, H, Lq, Lk, pd, seed = 2, 8, 40, 32, 0.1, 4242
+    q, k, do = randn(B * Lq, 256), randn(B * Lk, 256), randn(B * Lq, 256)
+    v = torch.eye(32).repeat(B, 8)                                 # [B*32, 256]: every head sees I
+    o, lse = ops.attention_fwd(dt, dev(q, dt), dev(k, dt), dev(v, dt), B, H, Lq, Lk, drop_p=pd, seed=seed)
+    pdrop = o.float().cpu().view(B, Lq, H, 32).transpose(1, 2)     # = P*keep/(1-p)
+    _, p = _attn_ref(rnd(q, dt), rnd(k, dt), rnd(v, dt), B, H, Lq, Lk, None, None)
+    keep = (pdrop > 0).float()
+    assert abs(keep.mean().item() - 0.9) < 0.02
+    close(pdrop, p * keep / 0.9, dt)
+    qr, kr, vr = (rnd(t, dt).requires_grad_(True) for t in (q, k, v))
+    o_ref, _ = _attn_ref(qr, kr, vr, B, H, Lq, Lk, None, None, keep / 0.9)
+    o_ref.backward(rnd(do, dt))
+    dq, dk, dv = (torch.empty_like(dev(t, dt)) for t in (q, k, v))
+    ops.attention_bwd(dt, dev(q, dt), dev(k, dt), dev(v, dt), o, dev(do, dt), lse, B, H, Lq, Lk, dq, dk, dv, drop_p=pd, seed=seed)
+    close(dq, qr.grad, dt, bf16_tol=3e-2)
+    close(dk, kr.grad, dt, bf16_tol=3e-2)
+    close(dv, vr.grad, dt, bf16_tol=3e-2)
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+def test_maxpool(ops, dt):
+    B, H, W, Cc = 2, 25, 16, 64
+    x = randn(B, Cc, H, W)
+    xr = rnd(x, dt).requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 3, 2, 1)
+    y, idx, Ho, Wo = ops.maxpool_fwd(dt, dev(_nhwc(x).reshape(-1, Cc), dt), B, H, W, Cc)
+    assert (Ho, Wo) == tuple(y_ref.shape[2:])
+    close(y, _nhwc(y_ref).reshape(-1, Cc).detach(), dt, bf16_tol=1e-6)
+    gy = randn(B, Cc, Ho, Wo)
+    y_ref.backward(rnd(gy, dt))
+    relu_src = randn(B, Cc, H, W)
+    dx = ops.maxpool_bwd(dt, dev(_nhwc(gy).reshape(-1, Cc), dt), idx, dev(_nhwc(relu_src).reshape(-1, Cc), dt), B, H, W, Cc)
+    ref = xr.grad * (rnd(relu_src, dt) > 0)
+    if dt == F32:
+        close(dx, _nhwc(ref).reshape(-1, Cc), dt)
+    else:   # bf16 ties may route the gradient to another tap of equal value: allow a small mismatch fraction
+        frac = ((dx.float().cpu() - _nhwc(ref).reshape(-1, Cc)).abs() > 1e-2).float().mean().item()
+        assert frac < 0.02
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+@pytest.mark.parametrize('H,W', [(500, 64), (496, 64), (128, 64), (37, 20)])
+def test_stem(ops, dt, H, W):
+    """conv0 (1->3 1x1 + bias) folded into conv1 7x7 s2 p3 with border-aware bias, + FrozenBN + ReLU; conv0 grads"""
+    B = 2
+    x = randn(B, 1, H, W)
+    w0, b0 = (randn(3, 1, 1, 1) * 0.5).requires_grad_(True), (randn(3) * 0.5).requires_grad_(True)
+    w1 = randn(64, 3, 7, 7) / math.sqrt(147)
+    sc, bi = torch.rand(64, generator=G) + 0.5, randn(64) * 0.1
+    pre = F.conv2d(F.conv2d(x, w0, b0), w1, stride=2, padding=3)
+    ref = F.relu(pre * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1))
+    wcat = ops.stem_prep(dt, w0.detach().cuda(), b0.detach().cuda(), w1.cuda())
+    col, Ho, Wo = ops.stem_im2col(dt, x.cuda().contiguous(), B, H, W)
+    assert (Ho, Wo) == tuple(ref.shape[2:])
+    y = ops.linear(dt, col, wcat, scale=sc.cuda(), bias=bi.cuda(), act=ops.ACT_RELU)
+    close(y, _nhwc(ref).reshape(-1, 64).detach(), dt)
+    gy = randn(B, 64, Ho, Wo)
+    gpre = rnd(gy, dt)
+    (pre * sc.view(1, -1, 1, 1)).backward(gpre)
+    gyd = dev(_nhwc(gy).reshape(-1, 64), dt)
+    Gm = ops.linear_wgrad(dt, gyd, col) * sc.cuda().view(-1, 1)        # [64][128], BN scale applied per row
+    dw0, db0 = ops.stem_conv0_grad(Gm.contiguous(), w1.cuda())
+    close(dw0, w0.grad, dt)
+    close(db0, b0.grad, dt)
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+def test_posenc_mask_resize_against_oracle(ops, dt):
+    from oracle import sedt_oracle as O
+    B, T = 3, 500
+    m = torch.zeros(B, T, 64, dtype=torch.bool)
+    m[1, 360:, :] = True
+    m[2, 100:, :] = True
+    small = F.interpolate(m[None].float(), size=(32, 4)).to(torch.bool)[0]
+    got = ops.mask_resize(m.to(torch.uint8).cuda(), 32, 4)
+    assert torch.equal(got.cpu().bool(), small)
+    pe = O.PositionEmbeddingSine(256, normalize=True)(O.NestedTensor(torch.zeros(B, 1, 32, 4), small))   # (B,256,32,4)
+    ref = pe.flatten(2).permute(0, 2, 1)                                                                   # (B,S,256)
+    pos = ops.posenc(dt, got, 256)
+    close(pos, ref, dt, f32_tol=2e-5, bf16_tol=5e-3)
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+def test_small_elementwise(ops, dt):
+    a, b = randn(130, 256), randn(10, 256)
+    close(ops.add(dt, dev(a, dt), dev(b, dt), b_mod=10), rnd(a, dt) + rnd(b, dt)[torch.arange(130) % 10], dt, bf16_tol=1e-2)
+    close(ops.cast(a.cuda(), dt), rnd(a, dt), dt, bf16_tol=1e-6)
+    close(ops.cast(dev(a, dt), F32), rnd(a, dt), F32)
+    s = torch.sigmoid(a)
+    close(ops.sigmoid_grad(b.repeat(13, 1).cuda(), s.cuda()), b.repeat(13, 1) * s * (1 - s), F32)
+    x = randn(6, 32, 2048)
+    close(ops.avgpool(dt, dev(x.reshape(-1, 2048), dt), 6, 32, 2048), rnd(x, dt).mean(1), dt, bf16_tol=1e-3)
+    w, bb, rm, rv = torch.rand(64, generator=G), randn(64), randn(64), torch.rand(64, generator=G) + 0.5
+    sc, bi = ops.bn_fold(w.cuda(), bb.cuda(), rm.cuda(), rv.cuda())
+    close(sc, w * (rv + 1e-5).rsqrt(), F32)
+    close(bi, bb - rm * w * (rv + 1e-5).rsqrt(), F32)
+
+
+def test_adamw_clip_matches_torch(ops):
+    n = 100003
+    p0, g0 = randn(n), randn(n) * 3
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-4, weight_decay=1e-4)
+    p, m, v = p0.cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    ss = torch.zeros(1).cuda()
+    for step in (1, 2, 3):
+        g = g0 * step
+        pr.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_([pr], 0.1)
+        opt.step()
+        ops.sumsq(g.cuda(), ss)
+        assert abs(ss.sqrt().item() - tn.item()) < 1e-3 * tn.item()
+        ops.adamw_clip(p, g.cuda(), m, v, ss, 0.1, 1e-4, 0.9, 0.999, 1e-8, 1e-4, step)
+        np.testing.assert_allclose(p.cpu().numpy(), pr.detach().numpy(), rtol=1e-5, atol=1e-7)
