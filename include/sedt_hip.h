@@ -113,6 +113,8 @@ int sedt_dropout_grad(const void* in, int64_t ldi, void* out, int64_t ldo, int r
 int sedt_add(const void* a, const void* b, void* out, int rows, int cols, int b_mod, int dtype, void* stream);
 /* dtype conversion f32 <-> compute dtype, elementwise over n */
 int sedt_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, void* stream);
+/* out = y > 0 ? g : 0 (ReLU backward), compute dtype, elementwise over n */
+int sedt_relu_mask(const void* g, const void* y, void* out, int64_t n, int dtype, void* stream);
 /* y = g * s * (1 - s) (sigmoid backward), all f32 */
 int sedt_sigmoid_grad(const float* g, const float* s, float* out, int64_t n, void* stream);
 

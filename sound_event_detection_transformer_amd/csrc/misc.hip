@@ -94,6 +94,12 @@ __global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, lon
   if (e < n) out[e] = (TO)(float)in[e];
 }
 
+template <typename T>
+__global__ void relu_mask_kernel(const T* __restrict__ g, const T* __restrict__ y, T* __restrict__ out, long n) {
+  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) out[e] = ((float)y[e] > 0.f) ? g[e] : (T)0.f;
+}
+
 __global__ void sigmoid_grad_kernel(const float* g, const float* s, float* out, long n) {
   long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n) out[e] = g[e] * s[e] * (1.f - s[e]);
@@ -404,6 +410,15 @@ extern "C" int sedt_cast(const void* in, int in_dtype, void* out, int out_dtype,
     hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, S(stream), (const bf16_t*)in, (bf16_t*)out, (long)n);
   else { set_error("cast: bad dtypes %d -> %d", in_dtype, out_dtype); return 1; }
   return check_launch("cast");
+}
+
+extern "C" int sedt_relu_mask(const void* g, const void* y, void* out, int64_t n, int dtype, void* stream) {
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(relu_mask_kernel<float>, dim3(nblk(n)), dim3(256), 0, S(stream), (const float*)g, (const float*)y,
+                              (float*)out, (long)n),
+           hipLaunchKernelGGL(relu_mask_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, S(stream), (const bf16_t*)g,
+                              (const bf16_t*)y, (bf16_t*)out, (long)n));
+  return check_launch("relu_mask");
 }
 
 extern "C" int sedt_sigmoid_grad(const float* g, const float* s, float* out, int64_t n, void* stream) {

@@ -1,0 +1,441 @@
+"""torch.autograd.Function wrappers that run the SEDT blocks on the HIP kernels.
+
+Layouts: activations are NHWC "token" matrices [B*H*W, C] in the compute dtype (f32 parity mode
+or bf16 throughput mode); transformer tokens are batch-first [B*S, d].  Parameters stay ordinary
+f32 nn.Parameters (read through data_ptr() on every call, so EMA swaps / load_state_dict /
+optimizer updates are always seen); gradients are returned as f32 tensors, so DDP hooks,
+clip_grad_norm_ and AdamW work unchanged.  Every Function saves only what its backward needs and
+recomputes dropout masks from (seed, element index).
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops, runtime
+from .lib import F32, BF16
+from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvGeom
+
+
+def _dt_of(t):
+    return F32 if t.dtype == torch.float32 else BF16
+
+
+def _as(t, dt):
+    """cast an incoming activation/gradient to the compute dtype (contiguous)"""
+    want = torch.float32 if dt == F32 else torch.bfloat16
+    t = t.contiguous()
+    return t if t.dtype == want else ops.cast(t, dt)
+
+
+def _wf(dt, w):
+    """forward operand [N][K] of a linear weight"""
+    return w if dt == F32 else ops.cast(w, BF16)
+
+
+def _wb(dt, w):
+    """dgrad operand [K][N] (= W^T) of a linear weight"""
+    return ops.pack_conv(dt, w, want_fwd=False)[1]
+
+
+# ======================================================================================= generic
+class LinearFn(Function):
+    """y = act(x @ W^T + b); act in {none, relu, sigmoid}; optional f32 output (heads)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, out_f32, dt):
+        x = _as(x, dt)
+        y = ops.linear(dt, x, _wf(dt, weight), bias=bias, act=act, out_f32=out_f32)
+        ctx.dt, ctx.act, ctx.out_f32 = dt, act, out_f32
+        ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, y = ctx.saved_tensors
+        dt = ctx.dt
+        gy = gy.contiguous()
+        if ctx.act == ACT_SIGMOID:
+            gy = ops.sigmoid_grad(gy.float() if gy.dtype != torch.float32 else gy, y.float() if y.dtype != torch.float32 else y)
+        elif ctx.act == ACT_RELU:
+            gy = ops.relu_mask(_dt_of(gy), gy, y)
+        g = _as(gy, dt)
+        gx = ops.linear(dt, g, _wb(dt, weight)) if ctx.needs_input_grad[0] else None
+        gw = ops.linear_wgrad(dt, g, x) if ctx.needs_input_grad[1] else None
+        gb = ops.colsum(dt, g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None, None, None
+
+
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, dt):
+        x = _as(x, dt)
+        y, _, mean, rstd = ops.layernorm_fwd(dt, x, gamma, beta)
+        ctx.dt = dt
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(ctx.dt, _as(gy, ctx.dt), x, gamma, mean, rstd)
+        return dx, dg, db, None
+
+
+class AddFn(Function):
+    """out = a + b[(r % b_mod)] ; gradient flows to a only (b is the constant position encoding)."""
+
+    @staticmethod
+    def forward(ctx, a, b, b_mod, dt):
+        return ops.add(dt, _as(a, dt), _as(b, dt), b_mod)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None, None
+
+
+# ======================================================================================= attention + FFN sub-blocks
+def _mha_fwd(dt, q_in, k_in, v_in, same_qk, w_in, b_in, w_out, b_out, res, B, H, Lq, Lk, kpm, amask, p, seeds):
+    """res + drop(out_proj(attention(q_in Wq, k_in Wk, v_in Wv)));  returns (out, saved)."""
+    E = w_in.shape[1]
+    wf = _wf(dt, w_in)
+    if same_qk:                       # q_in is k_in: one GEMM for Q|K (N = 2E)
+        qk = ops.linear(dt, q_in, wf[:2 * E], bias=b_in[:2 * E])
+        q, k = qk[:, :E], qk[:, E:]
+    else:
+        q = ops.linear(dt, q_in, wf[:E], bias=b_in[:E])
+        k = ops.linear(dt, k_in, wf[E:2 * E], bias=b_in[E:2 * E])
+        qk = None
+    v = ops.linear(dt, v_in, wf[2 * E:], bias=b_in[2 * E:])
+    ctxv, lse = ops.attention_fwd(dt, q, k, v, B, H, Lq, Lk, kpm, amask, p, seeds[0])
+    out = ops.linear(dt, ctxv, _wf(dt, w_out), bias=b_out, drop_p=p, seed=seeds[1], res=res, ldr=res.stride(0))
+    saved = dict(q_in=q_in, k_in=k_in, v_in=v_in, same_qk=same_qk, qk=qk, q=q, k=k, v=v, ctxv=ctxv, lse=lse,
+                 dims=(B, H, Lq, Lk), kpm=kpm, amask=amask, p=p, seeds=seeds)
+    return out, saved
+
+
+def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True):
+    """g_out = grad wrt the block output (the residual branch is the caller's business).
+    returns g_q_in, g_k_in, g_v_in, d_in_proj_weight, d_in_proj_bias, d_out_w, d_out_b"""
+    B, H, Lq, Lk = s['dims']
+    E = w_in.shape[1]
+    p = s['p']
+    g1 = ops.dropout_grad(dt, g_out, p, s['seeds'][1]) if p > 0 else g_out
+    d_wo = ops.linear_wgrad(dt, g1, s['ctxv'])
+    d_bo = ops.colsum(dt, g1)
+    g_ctx = ops.linear(dt, g1, _wb(dt, w_out))
+    td = g_out.dtype
+    if s['same_qk']:
+        dqk = torch.empty((B * Lq, 2 * E), device=g_out.device, dtype=td)
+        dq, dk = dqk[:, :E], dqk[:, E:]
+    else:
+        dq = torch.empty((B * Lq, E), device=g_out.device, dtype=td)
+        dk = torch.empty((B * Lk, E), device=g_out.device, dtype=td)
+    dv = torch.empty((B * Lk, E), device=g_out.device, dtype=td)
+    ops.attention_bwd(dt, s['q'], s['k'], s['v'], s['ctxv'], g_ctx, s['lse'], B, H, Lq, Lk, dq, dk, dv, s['kpm'], s['amask'],
+                      p, s['seeds'][0])
+    d_win = torch.empty((3 * E, E), device=g_out.device, dtype=torch.float32)
+    d_bin = torch.empty((3 * E,), device=g_out.device, dtype=torch.float32)
+    wb = _wb(dt, w_in)                                      # [E][3E]
+    g_q = g_k = g_v = None
+    if s['same_qk']:
+        ops.linear_wgrad(dt, dqk, s['q_in'], out=d_win[:2 * E])
+        ops.colsum(dt, dqk, out=d_bin[:2 * E])
+        if need_q or need_k:
+            g_q = ops.linear(dt, dqk, wb[:, :2 * E])        # grad wrt the shared q/k input
+            g_k = None
+    else:
+        ops.linear_wgrad(dt, dq, s['q_in'], out=d_win[:E])
+        ops.linear_wgrad(dt, dk, s['k_in'], out=d_win[E:2 * E])
+        ops.colsum(dt, dq, out=d_bin[:E])
+        ops.colsum(dt, dk, out=d_bin[E:2 * E])
+        if need_q:
+            g_q = ops.linear(dt, dq, wb[:, :E])
+        if need_k:
+            g_k = ops.linear(dt, dk, wb[:, E:2 * E])
+    ops.linear_wgrad(dt, dv, s['v_in'], out=d_win[2 * E:])
+    ops.colsum(dt, dv, out=d_bin[2 * E:])
+    if need_v:
+        g_v = ops.linear(dt, dv, wb[:, 2 * E:])
+    return g_q, g_k, g_v, d_win, d_bin, d_wo, d_bo
+
+
+def _ffn_fwd(dt, x_in, w1, b1, w2, b2, res, p, seeds):
+    h = ops.linear(dt, x_in, _wf(dt, w1), bias=b1, act=ACT_RELU, drop_p=p, seed=seeds[0])
+    out = ops.linear(dt, h, _wf(dt, w2), bias=b2, drop_p=p, seed=seeds[1], res=res, ldr=res.stride(0))
+    return out, dict(x_in=x_in, h=h, p=p, seeds=seeds)
+
+
+def _ffn_bwd(dt, s, g_out, w1, w2, res_for_gx=None):
+    """returns g_x_in (+ res_for_gx), dW1, db1, dW2, db2"""
+    p = s['p']
+    g2 = ops.dropout_grad(dt, g_out, p, s['seeds'][1]) if p > 0 else g_out
+    d_w2 = ops.linear_wgrad(dt, g2, s['h'])
+    d_b2 = ops.colsum(dt, g2)
+    # d_hidden = (g2 @ W2) * [h > 0] / (1-p): h = drop(relu(.)) is positive exactly where kept and active
+    gh = ops.linear(dt, g2, _wb(dt, w2), mask=s['h'], ldm=s['h'].stride(0), alpha=1.0 / (1.0 - p) if p > 0 else 1.0)
+    d_w1 = ops.linear_wgrad(dt, gh, s['x_in'])
+    d_b1 = ops.colsum(dt, gh)
+    if res_for_gx is not None:
+        gx = ops.linear(dt, gh, _wb(dt, w1), res=res_for_gx, ldr=res_for_gx.stride(0))
+    else:
+        gx = ops.linear(dt, gh, _wb(dt, w1))
+    return gx, d_w1, d_b1, d_w2, d_b2
+
+
+# ======================================================================================= encoder layer
+class EncoderLayerFn(Function):
+    """reference sedt/transformer.py:155-212 (forward_pre :192-204, forward_post :177-190), batch-first tokens.
+    params: in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, linear1.w, linear1.b, linear2.w, linear2.b,
+            norm1.w, norm1.b, norm2.w, norm2.b"""
+
+    @staticmethod
+    def forward(ctx, x, pos, kpm, amask, cfg, *P):
+        dt = cfg['dt']
+        (w_in, b_in, w_o, b_o, w1, b1, w2, b2, g1, be1, g2, be2) = P
+        B, S, H = cfg['B'], cfg['S'], cfg['H']
+        p = cfg['dropout'] if cfg['training'] else 0.0
+        seeds = [runtime.next_seed() for _ in range(4)]
+        x = _as(x, dt)
+        pos = _as(pos, dt)
+        sv = {}
+        if cfg['pre_norm']:
+            xn, xnp, m1, r1 = ops.layernorm_fwd(dt, x, g1, be1, add_t=pos)
+            x1, sv['mha'] = _mha_fwd(dt, xnp, xnp, xn, True, w_in, b_in, w_o, b_o, x, B, H, S, S, kpm, amask, p, seeds[0:2])
+            x1n, _, m2, r2 = ops.layernorm_fwd(dt, x1, g2, be2)
+            x2, sv['ffn'] = _ffn_fwd(dt, x1n, w1, b1, w2, b2, x1, p, seeds[2:4])
+            sv.update(x=x, x1=x1, m1=m1, r1=r1, m2=m2, r2=r2)
+        else:
+            xp = ops.add(dt, x, pos)
+            t, sv['mha'] = _mha_fwd(dt, xp, xp, x, True, w_in, b_in, w_o, b_o, x, B, H, S, S, kpm, amask, p, seeds[0:2])
+            x1, _, m1, r1 = ops.layernorm_fwd(dt, t, g1, be1)
+            t2, sv['ffn'] = _ffn_fwd(dt, x1, w1, b1, w2, b2, x1, p, seeds[2:4])
+            x2, _, m2, r2 = ops.layernorm_fwd(dt, t2, g2, be2)
+            sv.update(t=t, t2=t2, m1=m1, r1=r1, m2=m2, r2=r2)
+        ctx.sv, ctx.cfg, ctx.P = sv, cfg, P
+        return x2
+
+    @staticmethod
+    def backward(ctx, gx2):
+        sv, cfg, P = ctx.sv, ctx.cfg, ctx.P
+        dt = cfg['dt']
+        (w_in, b_in, w_o, b_o, w1, b1, w2, b2, g1, be1, g2, be2) = P
+        gx2 = _as(gx2, dt)
+        if cfg['pre_norm']:
+            g_x1n, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], gx2, w1, w2)
+            gx1, d_g2, d_be2 = ops.layernorm_bwd(dt, g_x1n, sv['x1'], g2, sv['m2'], sv['r2'], dres=gx2)
+            g_qk, _, g_v, d_win, d_bin, d_wo, d_bo = _mha_bwd(dt, sv['mha'], gx1, w_in, w_o)
+            # LN1 fed xn (to V) and xn+pos (to Q,K): both gradients land on xn
+            gx, d_g1, d_be1 = ops.layernorm_bwd(dt, g_v, sv['x'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gx1)
+        else:
+            g_t2, d_g2, d_be2 = ops.layernorm_bwd(dt, gx2, sv['t2'], g2, sv['m2'], sv['r2'])
+            g_x1, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], g_t2, w1, w2, res_for_gx=g_t2)
+            g_t, d_g1, d_be1 = ops.layernorm_bwd(dt, g_x1, sv['t'], g1, sv['m1'], sv['r1'])
+            g_qk, _, g_v, d_win, d_bin, d_wo, d_bo = _mha_bwd(dt, sv['mha'], g_t, w_in, w_o)
+            gx = ops.add(dt, ops.add(dt, g_qk, g_v), g_t)
+        ctx.sv = None
+        return (gx, None, None, None, None, d_win, d_bin, d_wo, d_bo, d_w1, d_b1, d_w2, d_b2, d_g1, d_be1, d_g2, d_be2)
+
+
+# ======================================================================================= decoder layer
+class DecoderLayerFn(Function):
+    """reference sedt/transformer.py:215-297.  Inputs: tgt [B*Q,d], memory [B*S,d], memory+pos [B*S,d],
+    query_pos [B*Q,d].  params: self_attn(in_w,in_b,out_w,out_b), multihead_attn(4), linear1(2), linear2(2),
+    norm1(2), norm2(2), norm3(2)"""
+
+    @staticmethod
+    def forward(ctx, tgt, mem, mem_pos, qpos, kpm, tgt_mask, cfg, *P):
+        dt = cfg['dt']
+        (sw_in, sb_in, sw_o, sb_o, cw_in, cb_in, cw_o, cb_o, w1, b1, w2, b2, g1, be1, g2, be2, g3, be3) = P
+        B, S, Q, H = cfg['B'], cfg['S'], cfg['Q'], cfg['H']
+        p = cfg['dropout'] if cfg['training'] else 0.0
+        seeds = [runtime.next_seed() for _ in range(6)]
+        tgt, mem, mem_pos, qpos = _as(tgt, dt), _as(mem, dt), _as(mem_pos, dt), _as(qpos, dt)
+        sv = {}
+        if cfg['pre_norm']:
+            tn, tnp, m1, r1 = ops.layernorm_fwd(dt, tgt, g1, be1, add_t=qpos)
+            t1, sv['sa'] = _mha_fwd(dt, tnp, tnp, tn, True, sw_in, sb_in, sw_o, sb_o, tgt, B, H, Q, Q, None, tgt_mask, p, seeds[0:2])
+            t1n, t1np, m2, r2 = ops.layernorm_fwd(dt, t1, g2, be2, add_t=qpos)
+            t2, sv['ca'] = _mha_fwd(dt, t1np, mem_pos, mem, False, cw_in, cb_in, cw_o, cb_o, t1, B, H, Q, S, kpm, None, p, seeds[2:4])
+            t2n, _, m3, r3 = ops.layernorm_fwd(dt, t2, g3, be3)
+            t3, sv['ffn'] = _ffn_fwd(dt, t2n, w1, b1, w2, b2, t2, p, seeds[4:6])
+            sv.update(tgt=tgt, t1=t1, t2=t2, m1=m1, r1=r1, m2=m2, r2=r2, m3=m3, r3=r3)
+        else:
+            tp = ops.add(dt, tgt, qpos)
+            a, sv['sa'] = _mha_fwd(dt, tp, tp, tgt, True, sw_in, sb_in, sw_o, sb_o, tgt, B, H, Q, Q, None, tgt_mask, p, seeds[0:2])
+            t1, _, m1, r1 = ops.layernorm_fwd(dt, a, g1, be1)
+            t1p = ops.add(dt, t1, qpos)
+            c, sv['ca'] = _mha_fwd(dt, t1p, mem_pos, mem, False, cw_in, cb_in, cw_o, cb_o, t1, B, H, Q, S, kpm, None, p, seeds[2:4])
+            t2, _, m2, r2 = ops.layernorm_fwd(dt, c, g2, be2)
+            f, sv['ffn'] = _ffn_fwd(dt, t2, w1, b1, w2, b2, t2, p, seeds[4:6])
+            t3, _, m3, r3 = ops.layernorm_fwd(dt, f, g3, be3)
+            sv.update(a=a, c=c, f=f, m1=m1, r1=r1, m2=m2, r2=r2, m3=m3, r3=r3)
+        ctx.sv, ctx.cfg, ctx.P = sv, cfg, P
+        return t3
+
+    @staticmethod
+    def backward(ctx, g3_):
+        sv, cfg, P = ctx.sv, ctx.cfg, ctx.P
+        dt = cfg['dt']
+        (sw_in, sb_in, sw_o, sb_o, cw_in, cb_in, cw_o, cb_o, w1, b1, w2, b2, g1, be1, g2, be2, g3, be3) = P
+        gt3 = _as(g3_, dt)
+        if cfg['pre_norm']:
+            g_t2n, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], gt3, w1, w2)
+            gt2, d_g3, d_be3 = ops.layernorm_bwd(dt, g_t2n, sv['t2'], g3, sv['m3'], sv['r3'], dres=gt3)
+            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], gt2, cw_in, cw_o)
+            # LN2 outputs: t1n (unused on its own) and t1n + qpos (cross-attn query)
+            gt1, d_g2, d_be2 = ops.layernorm_bwd(dt, g_q, sv['t1'], g2, sv['m2'], sv['r2'], dres=gt2)
+            g_qpos = g_q
+            g_mem_pos, g_mem = g_k, g_v
+            g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], gt1, sw_in, sw_o)
+            gtgt, d_g1, d_be1 = ops.layernorm_bwd(dt, g_vs, sv['tgt'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gt1)
+            g_qpos = ops.add(dt, g_qpos, g_qk)
+        else:
+            g_f, d_g3, d_be3 = ops.layernorm_bwd(dt, gt3, sv['f'], g3, sv['m3'], sv['r3'])
+            g_t2, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], g_f, w1, w2, res_for_gx=g_f)
+            g_c, d_g2, d_be2 = ops.layernorm_bwd(dt, g_t2, sv['c'], g2, sv['m2'], sv['r2'])
+            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], g_c, cw_in, cw_o)
+            g_t1 = ops.add(dt, g_q, g_c)                     # query path + residual
+            g_qpos = g_q
+            g_mem_pos, g_mem = g_k, g_v
+            g_a, d_g1, d_be1 = ops.layernorm_bwd(dt, g_t1, sv['a'], g1, sv['m1'], sv['r1'])
+            g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], g_a, sw_in, sw_o)
+            gtgt = ops.add(dt, ops.add(dt, g_qk, g_vs), g_a)
+            g_qpos = ops.add(dt, g_qpos, g_qk)
+        ctx.sv = None
+        return (gtgt, g_mem, g_mem_pos, g_qpos, None, None, None,
+                d_swin, d_sbin, d_swo, d_sbo, d_cwin, d_cbin, d_cwo, d_cbo, d_w1, d_b1, d_w2, d_b2,
+                d_g1, d_be1, d_g2, d_be2, d_g3, d_be3)
+
+
+# ======================================================================================= backbone
+def _bn(bn):
+    """fold the four FrozenBatchNorm buffers (backbone.py:43-53) into per-channel scale / bias"""
+    return ops.bn_fold(bn[0], bn[1], bn[2], bn[3])
+
+
+class StemFn(Function):
+    """conv0 (1->3, 1x1, bias) + conv1 (7x7 s2 p3) + FrozenBN + ReLU + maxpool 3x3 s2 p1 (backbone.py:102 + torchvision
+    stem).  conv0 is folded into an effective 1-channel 7x7 conv with a border-aware bias (extra indicator columns in the
+    im2col matrix), so the 3-channel intermediate never exists.  Only conv0 can be trainable (conv1 is frozen)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, bnw, bnb, bnrm, bnrv, dt):
+        B, _, H, W = x.shape
+        x = x.contiguous().float()
+        wcat = ops.stem_prep(dt, w0, b0, w1)
+        col, Ho, Wo = ops.stem_im2col(dt, x, B, H, W)
+        sc, bi = ops.bn_fold(bnw, bnb, bnrm, bnrv)
+        s1 = ops.linear(dt, col, wcat, scale=sc, bias=bi, act=ACT_RELU)
+        pool, idx, Hp, Wp = ops.maxpool_fwd(dt, s1, B, Ho, Wo, 64)
+        ctx.dt, ctx.dims = dt, (B, Ho, Wo)
+        ctx.save_for_backward(col, s1, idx, sc, w1)
+        ctx.mark_non_differentiable(idx)
+        ctx.out_hw = (Hp, Wp)
+        return pool
+
+    @staticmethod
+    def backward(ctx, g):
+        col, s1, idx, sc, w1 = ctx.saved_tensors
+        dt = ctx.dt
+        B, Ho, Wo = ctx.dims
+        gs = ops.maxpool_bwd(dt, _as(g, dt), idx, s1, B, Ho, Wo, 64)          # routed by argmax, masked by the stem ReLU
+        G = ops.wgrad(dt, gs, col, gs.shape[0], ConvGeom(1, 1, 128, 64), rowscale=sc).view(64, 128)
+        dw0, db0 = ops.stem_conv0_grad(G, w1)
+        return None, dw0, db0, None, None, None, None, None, None
+
+
+class BlockCfg(object):
+    """one torchvision Bottleneck: inplanes -> planes (1x1) -> planes (3x3, stride, dilation) -> 4*planes (1x1)"""
+    __slots__ = ('cin', 'planes', 'stride', 'dil', 'ds')
+
+    def __init__(self, cin, planes, stride, dil, ds):
+        self.cin, self.planes, self.stride, self.dil, self.ds = cin, planes, stride, dil, ds
+
+
+class StageFn(Function):
+    """one ResNet stage (layer1..layer4) of Bottleneck blocks on NHWC tokens.
+    per-block tensors: conv1.w, bn1(4), conv2.w, bn2(4), conv3.w, bn3(4) [, ds.conv.w, ds.bn(4)].
+    backward convention inside the stage: gradients handed from block to block are already masked by the ReLU of the
+    tensor they belong to (the mask is fused into the producing dgrad epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *T):
+        dt, B, H, W, blocks = meta['dt'], meta['B'], meta['H'], meta['W'], meta['blocks']
+        x = _as(x, dt)
+        saved = []
+        i = 0
+        for blk in blocks:
+            n = 20 if blk.ds else 15
+            t = T[i:i + n]
+            i += n
+            cin, pl = blk.cin, blk.planes
+            s1, b1 = _bn(t[1:5])
+            s2, b2 = _bn(t[6:10])
+            s3, b3 = _bn(t[11:15])
+            g1 = ConvGeom(H, W, cin, pl, 1)
+            g2 = ConvGeom(H, W, pl, pl, 3, blk.stride, blk.dil, blk.dil)
+            g3 = ConvGeom(g2.Ho, g2.Wo, pl, 4 * pl, 1)
+            w1f, w1b = ops.pack_conv(dt, t[0], bnscale=s1)
+            w2f, w2b = ops.pack_conv(dt, t[5], bnscale=s2)
+            w3f, w3b = ops.pack_conv(dt, t[10], bnscale=s3)
+            a = ops.conv_fwd(dt, x, B, g1, w1f, scale=s1, bias=b1, act=ACT_RELU)
+            b = ops.conv_fwd(dt, a, B, g2, w2f, scale=s2, bias=b2, act=ACT_RELU)
+            rec = dict(blk=blk, x=x, a=a, b=b, g1=g1, g2=g2, g3=g3, s=(s1, s2, s3), wb=(w1b, w2b, w3b), H=H, W=W)
+            if blk.ds:
+                sd, bd = _bn(t[16:20])
+                gd = ConvGeom(H, W, cin, 4 * pl, 1, blk.stride)
+                wdf, wdb = ops.pack_conv(dt, t[15], bnscale=sd)
+                idn = ops.conv_fwd(dt, x, B, gd, wdf, scale=sd, bias=bd)
+                rec.update(gd=gd, sd=sd, wdb=wdb)
+            else:
+                idn = x
+            y = ops.conv_fwd(dt, b, B, g3, w3f, scale=s3, bias=b3, res=idn, ldr=idn.stride(0), act=ACT_RELU, act_post_res=1)
+            rec['y'] = y
+            saved.append(rec)
+            x, H, W = y, g2.Ho, g2.Wo
+        ctx.saved, ctx.meta, ctx.T = saved, meta, T
+        ctx.out_hw = (H, W)
+        return x
+
+    @staticmethod
+    def backward(ctx, gy):
+        saved, meta, T = ctx.saved, ctx.meta, ctx.T
+        dt, B = meta['dt'], meta['B']
+        grads = [None] * len(T)
+        # incoming gradient is w.r.t. the post-ReLU stage output: mask it (idempotent if the consumer already did)
+        gp = ops.relu_mask(dt, _as(gy, dt), saved[-1]['y'])
+        i_end = len(T)
+        need_x_grad = ctx.needs_input_grad[0]
+        for bi_ in range(len(saved) - 1, -1, -1):
+            r = saved[bi_]
+            blk = r['blk']
+            n = 20 if blk.ds else 15
+            base = i_end - n
+            i_end = base
+            t = T[base:base + n]
+            s1, s2, s3 = r['s']
+            w1b, w2b, w3b = r['wb']
+            first = bi_ == 0
+            want_gx = (not first) or need_x_grad
+            # conv3 (1x1): wgrad, dgrad masked by relu(b)
+            if t[10].requires_grad:
+                grads[base + 10] = ops.wgrad(dt, gp, r['b'], B, r['g3'], rowscale=s3)
+            gb = ops.conv_dgrad(dt, gp, B, r['g3'], w3b, mask=r['b'], ldm=r['b'].stride(0))
+            # conv2 (3x3): wgrad, dgrad masked by relu(a)
+            if t[5].requires_grad:
+                grads[base + 5] = ops.wgrad(dt, gb, r['a'], B, r['g2'], rowscale=s2)
+            ga = ops.conv_dgrad(dt, gb, B, r['g2'], w2b, mask=r['a'], ldm=r['a'].stride(0))
+            # conv1 (1x1) wgrad
+            if t[0].requires_grad:
+                grads[base + 0] = ops.wgrad(dt, ga, r['x'], B, r['g1'], rowscale=s1)
+            if blk.ds and t[15].requires_grad:
+                grads[base + 15] = ops.wgrad(dt, gp, r['x'], B, r['gd'], rowscale=r['sd'])
+            if want_gx:
+                side = ops.conv_dgrad(dt, gp, B, r['gd'], r['wdb']) if blk.ds else gp
+                mask_x = (not first) or meta['mask_input']
+                ep = dict(mask=r['x'], ldm=r['x'].stride(0)) if mask_x else {}
+                gp = ops.conv_dgrad(dt, ga, B, r['g1'], w1b, res=side, ldr=side.stride(0), **ep)
+            else:
+                gp = None
+        ctx.saved = None
+        return (gp, None) + tuple(grads)

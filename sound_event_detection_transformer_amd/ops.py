@@ -170,6 +170,13 @@ def cast(x, out_dtype):
     return out
 
 
+def relu_mask(dtype, g, y):
+    g, y = g.contiguous(), y.contiguous()
+    out = torch.empty_like(g)
+    L.check(L.load().sedt_relu_mask(_p(g), _p(y), _p(out), g.numel(), dtype, L.stream_ptr()), 'relu_mask')
+    return out
+
+
 def sigmoid_grad(g, s):
     g, s = g.contiguous(), s.contiguous()
     out = torch.empty_like(g)

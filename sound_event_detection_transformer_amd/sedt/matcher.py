@@ -1,0 +1,81 @@
+"""Hungarian matching (host side, stays off the HIP path by design) - counterpart of reference sedt/matcher.py.
+
+Cost = cost_bbox * L1(fake boxes) + cost_class * (-p[class]) + cost_giou * (-GIoU), solved per clip with
+scipy.optimize.linear_sum_assignment exactly as matcher.py:85-95.  Unlike the reference, the cost tensors of all
+decoder layers are built in one batch on the device and cross to the host in ONE copy (``match_layers``), instead of
+one device->host sync per layer."""
+from collections import Counter
+
+import torch
+from scipy.optimize import linear_sum_assignment
+from torch import nn
+
+from ..utilities.box_ops import interval_giou_pairwise
+
+
+class HungarianMatcher(nn.Module):
+    def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1, epsilon=0, alpha=100):
+        super().__init__()
+        self.cost_class, self.cost_bbox, self.cost_giou = cost_class, cost_bbox, cost_giou
+        self.epsilon, self.alpha = epsilon, alpha
+        assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
+
+    @torch.no_grad()
+    def cost_matrices(self, logits, boxes, tgt_ids, tgt_bbox):
+        """logits [L,B,Q,C+1], boxes [L,B,Q,2], targets concatenated over the batch -> [L,B,Q,Nt]"""
+        prob = logits.float().softmax(-1)
+        cost_class = -prob[..., tgt_ids]
+        c, l = boxes[..., 0].float(), boxes[..., 1].float()
+        tc, tl = tgt_bbox[:, 0], tgt_bbox[:, 1]
+        s1, e1, s2, e2 = c - l / 2, c + l / 2, tc - tl / 2, tc + tl / 2
+        cost_bbox = (s1[..., None] - s2).abs() + (e1[..., None] - e2).abs()      # y extents (0,1) cancel
+        giou = interval_giou_pairwise(c.reshape(-1), l.reshape(-1), tc, tl).view(*c.shape, -1)
+        return self.cost_bbox * cost_bbox + self.cost_class * cost_class - self.cost_giou * giou
+
+    @torch.no_grad()
+    def match_layers(self, logits, boxes, targets):
+        """returns, per layer, the list over clips of (src_idx, tgt_idx) int64 CPU tensors"""
+        L, B, Q = logits.shape[:3]
+        dev = logits.device
+        sizes = [len(v["boxes"]) for v in targets]
+        if sum(sizes) == 0:
+            e = torch.empty(0, dtype=torch.int64)
+            return [[(e, e) for _ in range(B)] for _ in range(L)]
+        tgt_ids = torch.cat([v["labels"][:len(v["boxes"])] for v in targets]).to(dev)
+        tgt_bbox = torch.cat([v["boxes"] for v in targets]).to(dev).float()
+        C = self.cost_matrices(logits, boxes, tgt_ids, tgt_bbox).cpu()          # the one device->host sync
+        out = []
+        for l in range(L):
+            per, off = [], 0
+            for b, n in enumerate(sizes):
+                i, j = linear_sum_assignment(C[l, b, :, off:off + n])
+                per.append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
+                off += n
+            out.append(per)
+        return out
+
+    @staticmethod
+    def coefficients(idx, targets, normalize=False):
+        coef = []
+        for i, (_, tgt) in enumerate(idx):
+            if normalize:
+                num = Counter(tgt.tolist())
+                coef.append(torch.tensor([1 / num[j] for j in tgt.tolist()], dtype=torch.float32))
+            elif "ratio" in targets[i]:
+                coef.append(targets[i]["ratio"].detach().float().cpu())
+            else:
+                coef.append(torch.ones(len(tgt), dtype=torch.float32))
+        return coef
+
+    @torch.no_grad()
+    def forward(self, outputs, targets, fine_tune=False, normalize=False, fl=False):
+        """reference-compatible single-layer interface: (indices, coefficients)"""
+        if fine_tune or fl:
+            raise NotImplementedError('fine_tune re-matching / focal costs (matcher.py:73-78, 99-121) are not built')
+        idx = self.match_layers(outputs["pred_logits"][None], outputs["pred_boxes"][None], targets)[0]
+        return idx, self.coefficients(idx, targets, normalize)
+
+
+def build_matcher(args):
+    return HungarianMatcher(cost_class=args.set_cost_class, cost_bbox=args.set_cost_bbox, cost_giou=args.set_cost_giou,
+                            epsilon=args.epsilon, alpha=args.alpha)

@@ -1,0 +1,190 @@
+"""DETR-style transformer on the HIP path - counterpart of reference sedt/transformer.py.
+
+Same module tree / parameter names (nn.MultiheadAttention instances hold in_proj_weight, in_proj_bias and
+out_proj exactly as in the reference), same ``Transformer.forward`` signature and return values.  Tokens are
+kept batch-first [B*S, d] internally; every layer is one autograd Function over HIP kernels."""
+import copy
+from typing import Optional
+
+import torch
+from torch import nn, Tensor
+
+from .. import functional as Fn
+from .. import runtime
+
+
+def _tokens(x):
+    """(B,C,H,W) any strides -> [B*H*W, C] (zero-copy when the memory is NHWC)"""
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+
+
+def _u8(mask):
+    return None if mask is None else mask.contiguous().view(torch.uint8)
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False):
+        super().__init__()
+        if activation != "relu":
+            raise ValueError('only relu is on the HIP path (the reference never passes another activation)')
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.normalize_before = normalize_before
+        self.nhead, self.p = nhead, dropout
+
+    def params(self):
+        a = self.self_attn
+        return (a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, self.linear1.weight,
+                self.linear1.bias, self.linear2.weight, self.linear2.bias, self.norm1.weight, self.norm1.bias,
+                self.norm2.weight, self.norm2.bias)
+
+    def forward_tokens(self, x, pos, kpm, B, S, src_mask=None):
+        cfg = dict(dt=runtime.compute_dtype(), B=B, S=S, H=self.nhead, dropout=self.p, training=self.training,
+                   pre_norm=self.normalize_before)
+        return Fn.EncoderLayerFn.apply(x, pos, kpm, src_mask, cfg, *self.params())
+
+    def forward(self, src, src_mask: Optional[Tensor] = None, src_key_padding_mask: Optional[Tensor] = None,
+                pos: Optional[Tensor] = None):
+        """seq-first (S,B,d) interface of the reference layer"""
+        S, B, d = src.shape
+        x = src.transpose(0, 1).reshape(B * S, d)
+        p = (pos if pos is not None else torch.zeros_like(src)).transpose(0, 1).reshape(B * S, d)
+        y = self.forward_tokens(x, p, _u8(src_key_padding_mask), B, S, src_mask)
+        return y.view(B, S, d).transpose(0, 1)
+
+
+class TransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False):
+        super().__init__()
+        if activation != "relu":
+            raise ValueError('only relu is on the HIP path (the reference never passes another activation)')
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.norm3 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.dropout3 = nn.Dropout(dropout)
+        self.normalize_before = normalize_before
+        self.nhead, self.p = nhead, dropout
+
+    def params(self):
+        a, c = self.self_attn, self.multihead_attn
+        return (a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+                c.in_proj_weight, c.in_proj_bias, c.out_proj.weight, c.out_proj.bias,
+                self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+                self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.norm3.weight, self.norm3.bias)
+
+    def forward_tokens(self, tgt, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask=None):
+        cfg = dict(dt=runtime.compute_dtype(), B=B, S=S, Q=Q, H=self.nhead, dropout=self.p, training=self.training,
+                   pre_norm=self.normalize_before)
+        return Fn.DecoderLayerFn.apply(tgt, mem, mem_pos, qpos, kpm, tgt_mask, cfg, *self.params())
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers, norm=None):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+
+    def forward_tokens(self, x, pos, kpm, B, S):
+        for layer in self.layers:
+            x = layer.forward_tokens(x, pos, kpm, B, S)
+        if self.norm is not None:
+            x = Fn.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, runtime.compute_dtype())
+        return x
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, norm=None, return_intermediate=False):
+        super().__init__()
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+
+    def forward_tokens(self, tgt, mem, pos, qpos, kpm, B, S, Q, tgt_mask=None):
+        """returns (L, B, Q, d): the shared LayerNorm applied to every layer's output (transformer.py:134-147)"""
+        dt = runtime.compute_dtype()
+        mem_pos = Fn.AddFn.apply(mem, pos, 0, dt)              # key input of every cross-attention
+        out = tgt
+        inter = []
+        for layer in self.layers:
+            out = layer.forward_tokens(out, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask)
+            if self.return_intermediate:
+                inter.append(Fn.LayerNormFn.apply(out, self.norm.weight, self.norm.bias, dt))
+        d = out.shape[1]
+        if self.return_intermediate:
+            return torch.stack(inter).view(len(inter), B, Q, d)
+        return Fn.LayerNormFn.apply(out, self.norm.weight, self.norm.bias, dt).view(1, B, Q, d)
+
+
+class Transformer(nn.Module):
+    def __init__(self, d_model=512, nhead=8, num_encoder_layers=6, num_decoder_layers=6, dim_feedforward=2048,
+                 dropout=0.1, activation="relu", normalize_before=False, return_intermediate_dec=False, self_sup=False):
+        super().__init__()
+        if d_model // nhead != 32 or d_model % nhead:
+            raise ValueError('the HIP attention kernels implement head dim 32 (d_model / nhead)')
+        enc_layer = TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, normalize_before)
+        enc_norm = nn.LayerNorm(d_model) if normalize_before else None
+        self.encoder = TransformerEncoder(enc_layer, num_encoder_layers, enc_norm)
+        dec_layer = TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout, activation, normalize_before)
+        self.decoder = TransformerDecoder(dec_layer, num_decoder_layers, nn.LayerNorm(d_model),
+                                          return_intermediate=return_intermediate_dec)
+        self._reset_parameters()
+        self.d_model, self.nhead, self.self_sup = d_model, nhead, self_sup
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, src, mask, query_embed, pos_embed, enc_at_embed=None, decoder_mask=None):
+        """reference transformer.py:48-86.  src/pos_embed (B,C,H,W); mask (B,H,W) bool; query_embed (Q,C), or
+        (Q,B,C) when self_sup.  Returns hs (L,B,Q,C) and memory (B,S,C) [self_sup: (B,C,H,W)]."""
+        if enc_at_embed is not None:
+            raise NotImplementedError('enc_at_embed is unreachable from SEDT.forward (sedt.py:88) and not built')
+        if not src.is_cuda:
+            raise RuntimeError('the SEDT transformer runs on the MI355X HIP path only (no CPU fallback)')
+        dt = runtime.compute_dtype()
+        B, C, H, W = src.shape
+        S = H * W
+        x = _tokens(src)
+        pos = _tokens(pos_embed)
+        kpm = _u8(mask.flatten(1))
+        if self.self_sup:
+            Q = query_embed.shape[0]
+            qpos = query_embed.permute(1, 0, 2).reshape(B * Q, C)
+        else:
+            Q = query_embed.shape[0]
+            qpos = query_embed.unsqueeze(0).expand(B, Q, C).reshape(B * Q, C)
+        tgt = torch.zeros((B * Q, C), device=src.device, dtype=runtime.torch_dtype())
+        memory = self.encoder.forward_tokens(x, pos, kpm, B, S)
+        tmask = decoder_mask.float().contiguous() if (self.self_sup and decoder_mask is not None) else None
+        hs = self.decoder.forward_tokens(tgt, memory, pos, qpos, kpm, B, S, Q, tmask)
+        if self.self_sup:
+            return hs, memory.view(B, H, W, C).permute(0, 3, 1, 2)
+        return hs, memory.view(B, S, C)
+
+
+def build_transformer(args):
+    return Transformer(d_model=args.hidden_dim, dropout=args.dropout, nhead=args.nheads,
+                       dim_feedforward=args.dim_feedforward, num_encoder_layers=args.enc_layers,
+                       num_decoder_layers=args.dec_layers, normalize_before=args.pre_norm,
+                       return_intermediate_dec=True, self_sup=args.self_sup)
