@@ -34,6 +34,9 @@ class ConvGeom(object):
         return self.KH == 1 and self.KW == 1 and self.sh == 1 and self.sw == 1 and self.ph == 0 and self.pw == 0
 
 
+PROFILE = None   # bench.py sets this to a list: every igemm launch is then bracketed by events on the launch stream
+
+
 def _dev_check(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -69,6 +72,13 @@ def igemm(dtype, M, N, K, A, lda, B, ldb, Cout, ldc, *, trans=0, conv=None, tran
     a.splitk = splitk
     a.slab = slab.data_ptr() if slab is not None else None
     a.tile_m, a.tile_n = tile
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(L.load().sedt_igemm(C.byref(a), dtype, L.stream_ptr()), 'sedt_igemm')
+        e1.record()
+        PROFILE.append((e0, e1, (M, N, K, trans, 0 if conv is None else 1)))
+        return
     L.check(L.load().sedt_igemm(C.byref(a), dtype, L.stream_ptr()), 'sedt_igemm')
 
 
