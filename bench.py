@@ -72,6 +72,7 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dump-igemm', default=None, help='write per-launch igemm timings (json) to this path')
     ap.add_argument('--model-only', action='store_true', help='time fwd+bwd of the model with a fixed differentiable loss')
     args = ap.parse_args()
 
@@ -143,6 +144,9 @@ def main():
         rec = ops.PROFILE
         ops.PROFILE = None
         n = len(rec)
+        if args.dump_igemm:
+            with open(args.dump_igemm, 'w') as f:
+                json.dump([{'ms': a.elapsed_time(b), 'shape': sh} for a, b, sh in rec], f)
         tot_ms = sum(a.elapsed_time(b) for a, b, _ in rec)
         flops_launch = FLOP_PER_CLIP_FWD_BWD * B / max(n, 1)
         avg_s = tot_ms / 1e3 / max(n, 1)

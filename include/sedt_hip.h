@@ -180,6 +180,31 @@ size_t sedt_sumsq_scratch(int64_t n);
 int sedt_adamw_clip(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float max_norm,
                     float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 
+/* multi-tensor form: `table` is a DEVICE array of chunks (<= 65536 elements each) covering every parameter tensor;
+ * one launch updates them all.  sedt_multi_sumsq writes the squared global gradient norm to sumsq[0]
+ * (partial: f32[nchunks] scratch); sedt_multi_adamw applies clip_grad_norm_(max_norm) + AdamW per chunk with the
+ * chunk's own lr / weight decay (the reference's two parameter groups, train_sedt.py:234-240). */
+typedef struct SedtChunk {
+  void* p;
+  const void* g;
+  void* m;
+  void* v;
+  int32_t n;
+  float lr;
+  float wd;
+  int32_t pad_;
+} SedtChunk;
+int sedt_multi_sumsq(const SedtChunk* table, int nchunks, float* partial, float* sumsq, void* stream);
+int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float* sumsq, float max_norm, float beta1, float beta2,
+                     float eps, int step, void* stream);
+
+/* ------------------------------------------------------------------ host-side matching (sedt/matcher.py:95)
+ * HOST pointers.  cost [nlayers][nclips][Q][Nt] f32; clip b owns columns [col_off[b], col_off[b]+ncols[b]).
+ * assign [nlayers][nclips][Q]: index (within the clip) of the target matched to query q, or -1.
+ * Same optimum as scipy.optimize.linear_sum_assignment (min(Q, n_b) pairs per problem). */
+int sedt_hungarian_batch(const float* cost, int nlayers, int nclips, int Q, int Nt, const int32_t* col_off,
+                         const int32_t* ncols, int32_t* assign);
+
 #ifdef __cplusplus
 }
 #endif

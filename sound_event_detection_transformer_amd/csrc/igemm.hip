@@ -436,15 +436,9 @@ static int launch_typed(const SedtIgemm& p, hipStream_t st) {
   }
   int bm = p.tile_m, bn = p.tile_n;
   if (bm == 0 || bn == 0) {
-    // heuristic: largest tile that still gives >= ~1 workgroup per CU (256 CUs); small N gets the narrow tile
-    auto tiles = [&](int a, int b) { return (long)((p.M + a - 1) / a) * ((p.N + b - 1) / b) * (p.splitk > 1 ? p.splitk : 1); };
-    if (p.N > 64 && p.M > 64 && tiles(128, 128) >= 256) { bm = 128; bn = 128; }
-    else if (p.M > 64 && tiles(128, 64) >= 256) { bm = 128; bn = 64; }
-    else if (p.N > 64 && p.M > 64 && tiles(64, 64) < 128 && tiles(128, 128) >= 64) { bm = 128; bn = 128; }
-    else { bm = 64; bn = 64; }
-    if (p.N <= 64) bn = 64;
-    if (p.M <= 64) bm = 64;
-    if (bm == 64 && bn == 128) bn = 64;
+    // measured on MI355X (tools/tune_igemm.py, profiles/): this register-staged pipeline is latency-bound, so the
+    // 64x64 tile (4 workgroups / CU resident) beats the larger tiles at every shape of the SEDT step
+    bm = 64; bn = 64;
   }
   if (p.splitk > 1) SEDT_REQUIRE(p.slab != nullptr, "igemm: splitk > 1 needs a slab");
 #define SEDT_DISPATCH(BM_, BN_)                                                         \
@@ -475,16 +469,15 @@ extern "C" int sedt_igemm(const SedtIgemm* args, int dtype, void* stream) {
 }
 
 extern "C" int sedt_igemm_splitk(int M, int N, int K, int dtype) {
-  // wgrad outputs are small (Cout x taps*Cin) while K (pixels) is long: split K until ~512 workgroups
+  // wgrad outputs are small (Cout x taps*Cin) while K (pixels) is long: split K until ~1536 workgroups of 64x64
+  // (measured: tools/tune_igemm.py), keeping at least 4 K tiles per slice
   int bk = dtype == SEDT_BF16 ? 64 : 32;
-  int bm = M > 64 ? 128 : 64, bn = N > 64 ? 128 : 64;
-  if (bm == 64) bn = 64;
-  long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+  long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
   int nkb = (K + bk - 1) / bk;
-  int s = (int)((512 + tiles - 1) / tiles);
-  int maxs = nkb / 4 > 1 ? nkb / 4 : 1;  // at least 4 K tiles per slice
+  int s = (int)((1536 + tiles - 1) / tiles);
+  int maxs = nkb / 4 > 1 ? nkb / 4 : 1;
   if (s > maxs) s = maxs;
-  if (s > 64) s = 64;
+  if (s > 128) s = 128;
   if (s < 1) s = 1;
   return s;
 }

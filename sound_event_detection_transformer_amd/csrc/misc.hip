@@ -334,6 +334,43 @@ __global__ void adamw_clip_kernel(float* __restrict__ p, const float* __restrict
   v[i] = vi;
 }
 
+// ---- multi-tensor variants: one launch walks a device table of <= 65536-element chunks of many tensors
+__global__ void multi_sumsq_kernel(const SedtChunk* __restrict__ table, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const SedtChunk c = table[blockIdx.x];
+  const float* g = reinterpret_cast<const float*>(c.g);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < c.n; i += blockDim.x) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void multi_adamw_kernel(const SedtChunk* __restrict__ table, const float* sumsq, float max_norm, float b1,
+                                   float b2, float eps, float bc1, float bc2_sqrt) {
+  const SedtChunk c = table[blockIdx.x];
+  float* p = reinterpret_cast<float*>(c.p);
+  const float* g = reinterpret_cast<const float*>(c.g);
+  float* m = reinterpret_cast<float*>(c.m);
+  float* v = reinterpret_cast<float*>(c.v);
+  float coef = 1.f;
+  if (max_norm > 0.f) {
+    coef = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
+    coef = coef < 1.f ? coef : 1.f;
+  }
+  for (int i = threadIdx.x; i < c.n; i += blockDim.x) {
+    float gr = g[i] * coef;
+    float pi = p[i] * (1.f - c.lr * c.wd);
+    float mi = m[i] + (gr - m[i]) * (1.f - b1);
+    float vi = v[i] * b2 + gr * gr * (1.f - b2);
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (c.lr / bc1) * (mi / denom);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
 }  // namespace sedt
 
 using namespace sedt;
@@ -528,4 +565,22 @@ extern "C" int sedt_adamw_clip(float* p, const float* g, float* m, float* v, int
   hipLaunchKernelGGL(adamw_clip_kernel, dim3(nblk(n)), dim3(256), 0, S(stream), p, g, m, v, (long)n, sumsq, max_norm, lr, beta1,
                      beta2, eps, weight_decay, bc1, bc2s);
   return check_launch("adamw_clip");
+}
+
+extern "C" int sedt_multi_sumsq(const SedtChunk* table, int nchunks, float* partial, float* sumsq, void* stream) {
+  SEDT_REQUIRE(table && partial && sumsq && nchunks > 0, "multi_sumsq: bad arguments");
+  hipLaunchKernelGGL(multi_sumsq_kernel, dim3(nchunks), dim3(256), 0, S(stream), table, partial);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, S(stream), partial, nchunks, sumsq, 0);
+  return check_launch("multi_sumsq");
+}
+
+extern "C" int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float* sumsq, float max_norm, float beta1,
+                                float beta2, float eps, int step, void* stream) {
+  SEDT_REQUIRE(table && nchunks > 0 && step >= 1, "multi_adamw: bad arguments");
+  SEDT_REQUIRE(max_norm <= 0.f || sumsq, "multi_adamw: clipping needs sumsq");
+  float bc1 = 1.f - powf(beta1, (float)step);
+  float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(multi_adamw_kernel, dim3(nchunks), dim3(256), 0, S(stream), table, sumsq, max_norm, beta1, beta2, eps, bc1,
+                     bc2s);
+  return check_launch("multi_adamw");
 }

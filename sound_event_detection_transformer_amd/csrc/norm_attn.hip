@@ -92,17 +92,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 }
 
 __global__ void ln_bwd_final_kernel(const float* __restrict__ partial, int nblocks, int D, float* dgamma, float* dbeta) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * D) return;
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += partial[(long)b * 2 * D + c];
-  if (c < D) { if (dgamma) dgamma[c] = s; }
-  else if (dbeta) dbeta[c - D] = s;
+  if (c < 2 * D)
+    for (int b = ty; b < nblocks; b += 4) s += partial[(long)b * 2 * D + c];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < 2 * D) {
+    s = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    if (c < D) { if (dgamma) dgamma[c] = s; }
+    else if (dbeta) dbeta[c - D] = s;
+  }
 }
 
 static int ln_bwd_blocks(int rows) {
   int b = (rows + 3) / 4;
-  return b < 1 ? 1 : (b > 512 ? 512 : b);
+  return b < 1 ? 1 : (b > 256 ? 256 : b);
 }
 
 // ============================================================================ attention
@@ -238,8 +245,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ q, 
   float* Pdw = W2 + wave * LmPad;
   const int d = lane & 31, half = lane >> 5;
 
-  // -------- pass 1: a wave owns query row i, lanes run over keys -> dQ
-  const int nqi = (Lq + 3) / 4;
+  // -------- pass 1 (blockIdx.y == 0): a wave owns query row i, lanes run over keys -> dQ
+  const int nqi = blockIdx.y == 0 ? (Lq + 3) / 4 : 0;
   for (int it = 0; it < nqi; ++it) {
     const int i = it * 4 + wave;
     const bool live = i < Lq;
@@ -270,8 +277,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ q, 
     __syncthreads();
   }
 
-  // -------- pass 2: a wave owns key row j, lanes run over queries -> dK, dV
-  const int nkj = (Lk + 3) / 4;
+  // -------- pass 2 (blockIdx.y == 1): a wave owns key row j, lanes run over queries -> dK, dV
+  const int nkj = blockIdx.y == 1 ? (Lk + 3) / 4 : 0;
   for (int it = 0; it < nkj; ++it) {
     const int j = it * 4 + wave;
     const bool live = j < Lk;
@@ -362,7 +369,7 @@ extern "C" int sedt_layernorm_bwd(const void* dy, const void* dy2, const void* x
   else { set_error("layernorm: unsupported dtype %d / width %d (256 or 512)", dtype, D); return 1; }
 #undef A_
   if (dgamma || dbeta)
-    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, S(stream), scratch, nb, D, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, S(stream), scratch, nb, D, dgamma, dbeta);
   return check_launch("layernorm_bwd");
 }
 
@@ -405,7 +412,7 @@ extern "C" int sedt_attention_bwd(const void* q, int64_t ldq, const void* k, int
   const float scale = 1.f / sqrtf((float)DH);
   const uint32_t th = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
   const float ik = 1.f / (1.f - drop_p);
-  dim3 grid(B * H), block(256);
+  dim3 grid(B * H, 2), block(256);
   if (dtype == SEDT_F32) {
     if (set_lds_attr(attn_bwd_kernel<float>, 160 * 1024, "attention_bwd")) return 1;
     hipLaunchKernelGGL(attn_bwd_kernel<float>, grid, block, lds, S(stream), (const float*)q, (long)ldq, (const float*)k, (long)ldk,

@@ -1,0 +1,84 @@
+"""Fused clip_grad_norm_ + AdamW over all parameter tensors in three launches (reference engine.py:77-80 issues
+~1000 small ones).  Semantics equal torch.nn.utils.clip_grad_norm_(params, max_norm) followed by torch.optim.AdamW."""
+import numpy as np
+import torch
+
+from . import lib as L
+
+_CHUNK = 65536
+_DT = np.dtype([('p', np.uint64), ('g', np.uint64), ('m', np.uint64), ('v', np.uint64), ('n', np.int32), ('lr', np.float32),
+                ('wd', np.float32), ('pad', np.int32)])
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._step = 0
+        self._static = None
+
+    def _build(self):
+        ps, gi = [], []
+        for gidx, group in enumerate(self.param_groups):
+            for p in group['params']:
+                if p.requires_grad:
+                    if p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous():
+                        raise RuntimeError('FusedAdamW needs contiguous f32 GPU parameters')
+                    ps.append(p)
+                    gi.append(gidx)
+        total = sum(p.numel() for p in ps)
+        dev = ps[0].device
+        self._m = torch.zeros(total, device=dev)
+        self._v = torch.zeros(total, device=dev)
+        owner, off_in_p, n, state_off = [], [], [], []
+        so = 0
+        for i, p in enumerate(ps):
+            k = p.numel()
+            for c0 in range(0, k, _CHUNK):
+                owner.append(i); off_in_p.append(c0); n.append(min(_CHUNK, k - c0)); state_off.append(so + c0)
+            so += k
+        self._ps, self._gi = ps, np.asarray(gi)
+        self._owner = np.asarray(owner)
+        self._off = np.asarray(off_in_p, np.uint64) * 4
+        self._tab = np.zeros(len(owner), _DT)
+        self._tab['n'] = n
+        so_b = np.asarray(state_off, np.uint64) * 4
+        self._tab['m'] = np.uint64(self._m.data_ptr()) + so_b
+        self._tab['v'] = np.uint64(self._v.data_ptr()) + so_b
+        self._dev_tab = torch.empty(self._tab.nbytes, dtype=torch.uint8, device=dev)
+        self._partial = torch.empty(len(owner), device=dev)
+        self._sumsq = torch.zeros(1, device=dev)
+        self._host_tab = torch.empty(self._tab.nbytes, dtype=torch.uint8).pin_memory()
+        self._static = True
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm=0.0):
+        if closure is not None:
+            raise NotImplementedError
+        if self._static is None:
+            self._build()
+        ps = self._ps
+        if any(p.grad is None for p in ps):
+            raise RuntimeError('FusedAdamW: every trainable parameter must have a gradient')
+        pbase = np.fromiter((p.data_ptr() for p in ps), np.uint64, len(ps))          # live pointers, every call
+        gbase = np.fromiter((p.grad.data_ptr() for p in ps), np.uint64, len(ps))
+        lrs = np.asarray([g['lr'] for g in self.param_groups], np.float32)
+        wds = np.asarray([g['weight_decay'] for g in self.param_groups], np.float32)
+        t = self._tab
+        t['p'] = pbase[self._owner] + self._off
+        t['g'] = gbase[self._owner] + self._off
+        t['lr'] = lrs[self._gi][self._owner]
+        t['wd'] = wds[self._gi][self._owner]
+        self._host_tab.numpy()[:] = t.view(np.uint8)
+        self._dev_tab.copy_(self._host_tab, non_blocking=True)
+        self._step += 1
+        lib = L.load()
+        g0 = self.param_groups[0]
+        n = len(t)
+        if max_norm > 0:
+            L.check(lib.sedt_multi_sumsq(L.p(self._dev_tab), n, L.p(self._partial), L.p(self._sumsq), L.stream_ptr()), 'multi_sumsq')
+        L.check(lib.sedt_multi_adamw(L.p(self._dev_tab), n, L.p(self._sumsq), float(max_norm), g0['betas'][0], g0['betas'][1],
+                                     g0['eps'], self._step, L.stream_ptr()), 'multi_adamw')
+
+    def grad_norm(self):
+        """global gradient norm of the last clipped step (device tensor)"""
+        return self._sumsq.sqrt()

@@ -109,8 +109,12 @@ from ..utilities import box_ops  # noqa: E402
 
 
 class SetCriterion(nn.Module):
-    """reference sedt.py:134-352 (fl=False, fine_tune=False).  Same loss names, weights and normalisation; all decoder
-    layers are matched with one device->host copy and every loss is vectorised over the batch."""
+    """reference sedt.py:134-352 (fl=False, fine_tune=False): same loss names, weights and normalisation.
+
+    Host-side by design (north star), but organised for the GPU it feeds: ``prepare`` builds the matching costs of ALL
+    decoder layers on the device, brings them to the host in ONE copy, solves every assignment in one C++ call
+    (sedt_hungarian_batch) and uploads dense, fixed-shape target tensors in ONE copy; ``compute`` is then pure
+    fixed-shape device math (no gathers, no per-layer loops), which also makes it capturable in a HIP graph."""
 
     def __init__(self, num_classes, matcher, weight_dict, eos_coef, losses):
         super().__init__()
@@ -119,102 +123,163 @@ class SetCriterion(nn.Module):
         empty_weight = torch.ones(self.num_classes + 1)
         empty_weight[-1] = self.eos_coef
         self.register_buffer('empty_weight', empty_weight)
+        self.last_total = None
+        self._wvec = {}
 
-    # ---- individual losses, given flat match index tensors on the device
-    def _labels(self, logits, m, num_boxes, log):
-        Bs, Q = logits.shape[:2]
-        tc = torch.full((Bs, Q), self.num_classes, dtype=torch.int64, device=logits.device)
-        cb = torch.ones((Bs, Q), dtype=torch.float32, device=logits.device)
-        tc[m['b'], m['s']] = m['labels']
-        cb[m['b'], m['s']] = m['coef']
-        ce = F.cross_entropy(logits.transpose(1, 2), tc, self.empty_weight.to(logits.device), reduction='none')
-        out = {'loss_ce': (ce * cb).sum() / num_boxes}
-        if log:
-            if m['labels'].numel() == 0:
-                out['class_error'] = torch.zeros([], device=logits.device) + 100.0
-            else:
-                acc = (logits[m['b'], m['s']].argmax(-1) == m['labels']).float().mean() * 100
-                out['class_error'] = 100 - acc
-        return out
-
-    def _boxes(self, boxes, m, num_boxes):
-        src = boxes[m['b'], m['s']]
-        tgt = m['boxes']
-        s1, e1, s2, e2 = src[:, 0] - src[:, 1] / 2, src[:, 0] + src[:, 1] / 2, tgt[:, 0] - tgt[:, 1] / 2, tgt[:, 0] + tgt[:, 1] / 2
-        l1 = (s1 - s2).abs() + (e1 - e2).abs()
-        giou = 1 - box_ops.interval_giou_diag(src[:, 0], src[:, 1], tgt[:, 0], tgt[:, 1])
-        return {'loss_bbox': (l1 * m['coef']).sum() / num_boxes, 'loss_giou': (giou * m['coef']).sum() / num_boxes}
-
+    # ------------------------------------------------------------------ host part
     @torch.no_grad()
-    def _cardinality(self, logits, tgt_lengths):
-        card = (logits.argmax(-1) != logits.shape[-1] - 1).sum(1)
-        return {'cardinality_error': F.l1_loss(card.float(), tgt_lengths.float())}
+    def prepare(self, outputs, targets, weak_mask=None, strong_mask=None, normalize=False):
+        import numpy as np
+        from .. import lib as L_
+        if strong_mask is None or strong_mask.start not in (None, 0) or strong_mask.step not in (None, 1):
+            raise NotImplementedError('strong_mask must be slice(0, n): strongly labelled clips come first in every driver')
+        layers = [outputs] + list(outputs.get('aux_outputs', []))
+        L = len(layers)
+        dev = outputs['pred_logits'].device
+        ns = len(targets[strong_mask])
+        st = targets[:ns]
+        logits = torch.stack([o['pred_logits'][:ns] for o in layers]).detach().float()
+        boxes = torch.stack([o['pred_boxes'][:ns] for o in layers]).detach().float()
+        Q = logits.shape[2]
+        sizes = [int(len(t['boxes'])) for t in st]
+        Nt = sum(sizes)
+        n_lab = (weak_mask.stop if weak_mask is not None else strong_mask.stop) if 'at' in outputs else ns
+        n_lab = max(n_lab, ns)
+        lab_sizes = [int(len(targets[i]['labels'])) for i in range(n_lab)]
+        has_ratio = any('ratio' in t for t in targets[:n_lab])
+        parts = []
+        if Nt > 0:
+            tgt_ids = torch.cat([t['labels'][:len(t['boxes'])] for t in st]).to(dev)
+            tgt_bbox = torch.cat([t['boxes'].reshape(-1, 2) for t in st]).to(dev).float()
+            cost = self.matcher.cost_matrices(logits, boxes, tgt_ids, tgt_bbox)
+            parts += [cost.flatten(), tgt_bbox.flatten()]
+        lab_all = torch.cat([targets[i]['labels'] for i in range(n_lab)]).to(dev).float() if sum(lab_sizes) else None
+        if lab_all is not None:
+            parts.append(lab_all)
+        if has_ratio:
+            parts.append(torch.cat([targets[i]['ratio'].detach().float() if 'ratio' in targets[i] else
+                                    torch.ones(lab_sizes[i]) for i in range(n_lab)]).to(dev))
+        host = torch.cat(parts).cpu().numpy() if parts else np.zeros(0, np.float32)   # the ONE device->host copy
+        o = 0
+        assign = -np.ones((L, ns, Q), np.int32)
+        tb = np.zeros((Nt, 2), np.float32)
+        if Nt > 0:
+            cost_h = np.ascontiguousarray(host[o:o + L * ns * Q * Nt]); o += L * ns * Q * Nt
+            tb = host[o:o + 2 * Nt].reshape(Nt, 2); o += 2 * Nt
+            off = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32)
+            nc = np.asarray(sizes, np.int32)
+            L_.check(L_.load().sedt_hungarian_batch(cost_h.ctypes.data, L, ns, Q, Nt, off.ctypes.data, nc.ctypes.data,
+                                                    assign.ctypes.data), 'hungarian_batch')
+        nl = sum(lab_sizes)
+        lab_h = host[o:o + nl].astype(np.int64); o += nl
+        ratio_h = host[o:o + nl] if has_ratio else np.ones(nl, np.float32)
+        lab_off = np.concatenate([[0], np.cumsum(lab_sizes)]).astype(np.int64)
+        # per-clip padded target tables (strong clips: the first len(boxes) labels belong to the boxes)
+        nmax = max(max(sizes) if sizes else 0, 1)
+        lab_pad = np.full((ns, nmax), self.num_classes, np.int64)
+        box_pad = np.full((ns, nmax, 2), 0.5, np.float32)
+        rat_pad = np.ones((ns, nmax), np.float32)
+        bo = 0
+        for b, n in enumerate(sizes):
+            lab_pad[b, :n] = lab_h[lab_off[b]:lab_off[b] + n]
+            box_pad[b, :n] = tb[bo:bo + n]
+            rat_pad[b, :n] = ratio_h[lab_off[b]:lab_off[b] + n]
+            bo += n
+        matched = assign >= 0
+        a = np.clip(assign, 0, None)
+        bi = np.arange(ns)[None, :, None]
+        tc = np.where(matched, lab_pad[bi, a], self.num_classes).astype(np.float32)
+        coef = np.where(matched, rat_pad[bi, a], 1.0).astype(np.float32)          # CE weight of every query
+        wbox = np.where(matched, rat_pad[bi, a], 0.0).astype(np.float32)          # box-loss weight (0 = unmatched)
+        tbox = np.where(matched[..., None], box_pad[bi, a], 0.5).astype(np.float32)
+        num_boxes = float(wbox[0].sum())
+        C = self.num_classes
+        gt_weak = np.zeros((n_lab, C), np.float32)
+        if nl and 'at' in outputs:
+            clip_of = np.repeat(np.arange(n_lab), lab_sizes)
+            np.add.at(gt_weak, (clip_of, lab_h), ratio_h)
+            gt_weak = np.clip(gt_weak, 0, 1)
+        tgt_len = np.asarray([len(t['labels']) for t in targets], np.float32)
+        pack = np.concatenate([tc.ravel(), coef.ravel(), wbox.ravel(), tbox.ravel(), a.astype(np.float32).ravel(),
+                               gt_weak.ravel(), tgt_len, np.asarray([num_boxes], np.float32)])
+        d = torch.from_numpy(pack).to(dev, non_blocking=True)                       # the ONE host->device copy
+        n3 = L * ns * Q
+        dense = {'tc': d[0:n3].view(L, ns, Q).long(), 'coef': d[n3:2 * n3].view(L, ns, Q),
+                 'wbox': d[2 * n3:3 * n3].view(L, ns, Q), 'tbox': d[3 * n3:5 * n3].view(L, ns, Q, 2),
+                 'tidx': d[5 * n3:6 * n3].view(L, ns, Q).long(),
+                 'gt_weak': d[6 * n3:6 * n3 + n_lab * C].view(n_lab, C),
+                 'tgt_len': d[6 * n3 + n_lab * C:6 * n3 + n_lab * C + len(targets)],
+                 'num_boxes': d[-1:], 'ns': ns, 'n_lab': n_lab, 'L': L}
+        idx0 = [(torch.from_numpy(np.nonzero(matched[0, b])[0].astype(np.int64)),
+                 torch.from_numpy(assign[0, b][matched[0, b]].astype(np.int64))) for b in range(ns)]
+        return dense, idx0
 
-    def _weak(self, outputs, targets, strong_mask, weak_mask):
-        if 'at' not in outputs:
-            return {}
-        lm = slice(weak_mask.stop) if weak_mask is not None else slice(strong_mask.stop)
-        pred = outputs['at'][lm]
-        gt = torch.zeros(pred.shape, dtype=torch.float32)
-        for i in range(pred.shape[0]):
-            lab = targets[i]["labels"].cpu()
-            w = targets[i]['ratio'].detach().cpu().float() if 'ratio' in targets[i] else torch.ones(len(lab))
-            gt[i].index_add_(0, lab, w)
-        gt = gt.clamp(0, 1).to(pred.device)
-        return {'loss_weak': F.binary_cross_entropy(pred, gt)}
-
-    def _feature(self, outputs, m, n_clips, num_boxes):
-        tf = outputs['gt_feature']
-        tf = tf.view(n_clips, tf.shape[0] // n_clips, -1)[m['b'], m['t']]
-        sf = outputs['pred_feature'][m['b'], m['s']]
-        sf, tf = F.normalize(sf.float(), dim=1), F.normalize(tf.float(), dim=1)
-        return {'loss_feature': F.mse_loss(sf, tf, reduction='none').sum() / num_boxes}
-
-    @staticmethod
-    def _flat_match(idx, coef, targets, device):
-        b = torch.cat([torch.full_like(s, i) for i, (s, _) in enumerate(idx)])
-        s = torch.cat([s for s, _ in idx])
-        t = torch.cat([t for _, t in idx])
-        labels = torch.cat([tg["labels"].cpu()[J] for tg, (_, J) in zip(targets, idx)])
-        boxes = torch.cat([tg["boxes"].cpu()[J].reshape(-1, 2) for tg, (_, J) in zip(targets, idx)]).float()
-        pack = torch.cat([b[:, None].float(), s[:, None].float(), t[:, None].float(), labels[:, None].float(),
-                          torch.cat(coef)[:, None], boxes], dim=1).to(device, non_blocking=True)   # one host->device copy
-        return {'b': pack[:, 0].long(), 's': pack[:, 1].long(), 't': pack[:, 2].long(), 'labels': pack[:, 3].long(),
-                'coef': pack[:, 4], 'boxes': pack[:, 5:7]}
+    # ------------------------------------------------------------------ device part (fixed shapes)
+    def compute(self, outputs, dense):
+        layers = [outputs] + list(outputs.get('aux_outputs', []))
+        L, ns, nb = dense['L'], dense['ns'], dense['num_boxes']
+        C1 = self.num_classes + 1
+        logits_all = torch.stack([o['pred_logits'] for o in layers]).float()          # [L,B,Q,C+1]
+        boxes = torch.stack([o['pred_boxes'][:ns] for o in layers]).float()           # [L,ns,Q,2]
+        logits = logits_all[:, :ns]
+        out = {}
+        vec = {}
+        if 'labels' in self.losses:
+            ce = F.cross_entropy(logits.reshape(-1, C1), dense['tc'].reshape(-1), self.empty_weight.to(logits.device),
+                                 reduction='none').view(L, -1)
+            vec['loss_ce'] = (ce * dense['coef'].view(L, -1)).sum(1) / nb
+            with torch.no_grad():
+                m = (dense['wbox'][0] > 0)
+                hit = ((logits[0].argmax(-1) == dense['tc'][0]) & m).float().sum()
+                out['class_error'] = 100 - 100 * hit / m.float().sum().clamp(min=1)
+        if 'boxes' in self.losses:
+            s1, e1 = boxes[..., 0] - boxes[..., 1] / 2, boxes[..., 0] + boxes[..., 1] / 2
+            t = dense['tbox']
+            s2, e2 = t[..., 0] - t[..., 1] / 2, t[..., 0] + t[..., 1] / 2
+            l1 = (s1 - s2).abs() + (e1 - e2).abs()
+            inter = (torch.min(e1, e2) - torch.max(s1, s2)).clamp(min=0)
+            union = (e1 - s1) + (e2 - s2) - inter
+            hull = (torch.max(e1, e2) - torch.min(s1, s2)).clamp(min=0)
+            giou = inter / union - (hull - union) / hull
+            w = dense['wbox']
+            vec['loss_bbox'] = (l1 * w).view(L, -1).sum(1) / nb
+            vec['loss_giou'] = ((1 - giou) * w).view(L, -1).sum(1) / nb
+        if 'cardinality' in self.losses:
+            with torch.no_grad():
+                card = (logits_all.argmax(-1) != C1 - 1).sum(2).float()              # [L,B]
+                vec['cardinality_error'] = (card - dense['tgt_len'][None]).abs().mean(1)
+        if 'feature' in self.losses:
+            feats = torch.stack([o['pred_feature'][:ns] for o in layers]).float()     # [L,ns,Q,F]
+            gt = outputs['gt_feature'].float()
+            gt = gt.view(ns, gt.shape[0] // ns, -1)
+            tgt = gt[torch.arange(ns, device=gt.device)[None, :, None], dense['tidx']]   # [L,ns,Q,F]
+            mse = (F.normalize(feats, dim=-1) - F.normalize(tgt, dim=-1)).square().sum(-1)
+            vec['loss_feature'] = (mse * (dense['wbox'] > 0).float()).view(L, -1).sum(1) / nb
+        for k, v in vec.items():
+            for li in range(L):
+                out[k if li == 0 else f'{k}_{li - 1}'] = v[li]
+        if 'weak' in self.losses and 'at' in outputs:
+            out['loss_weak'] = F.binary_cross_entropy(outputs['at'][:dense['n_lab']].float(), dense['gt_weak'])
+        wd = self.weight_dict
+        total = None
+        for k, v in vec.items():
+            wts = [wd.get(k if li == 0 else f'{k}_{li - 1}', 0.0) for li in range(L)]
+            if any(wts):
+                key = (k, L, str(v.device))
+                if key not in self._wvec:                     # uploaded once, then reused (graph-capture safe)
+                    self._wvec[key] = torch.tensor(wts, device=v.device, dtype=v.dtype)
+                term = (v * self._wvec[key]).sum()
+                total = term if total is None else total + term
+        if 'loss_weak' in out and wd.get('loss_weak', 0.0):
+            total = out['loss_weak'] * wd['loss_weak'] + (total if total is not None else 0.0)
+        self.last_total = total
+        return out
 
     def forward(self, outputs, targets, weak_mask=None, strong_mask=None, fine_tune=False, normalize=False, fl=False):
         if fine_tune or fl:
-            raise NotImplementedError('fine_tune / focal-loss branches are not built')
-        if strong_mask is None:
-            raise NotImplementedError('strong_mask=None (no strongly labelled clips) is not used by any driver')
-        dev = outputs['pred_logits'].device
-        layers = [outputs] + list(outputs.get('aux_outputs', []))
-        logits = torch.stack([o['pred_logits'][strong_mask] for o in layers])
-        boxes = torch.stack([o['pred_boxes'][strong_mask] for o in layers])
-        st = targets[strong_mask]
-        all_idx = self.matcher.match_layers(logits.detach(), boxes.detach(), st)
-        coef0 = self.matcher.coefficients(all_idx[0], st, normalize)
-        num_boxes = torch.cat(coef0).sum().clamp(min=0).to(dev) if len(coef0) else torch.zeros([], device=dev)
-        tgt_lengths = torch.as_tensor([len(v["labels"]) for v in targets], device=dev)
-        n_strong = logits.shape[1]
-        losses = {}
-        for li, o in enumerate(layers):
-            coef = coef0 if li == 0 else self.matcher.coefficients(all_idx[li], st, False)
-            m = self._flat_match(all_idx[li], coef, st, dev)
-            d = {}
-            for loss in self.losses:
-                if loss == 'labels':
-                    d.update(self._labels(o['pred_logits'][strong_mask], m, num_boxes, log=(li == 0)))
-                elif loss == 'boxes':
-                    d.update(self._boxes(o['pred_boxes'], m, num_boxes))
-                elif loss == 'cardinality':
-                    d.update(self._cardinality(o['pred_logits'], tgt_lengths))
-                elif loss == 'weak' and li == 0:
-                    d.update(self._weak(o, targets, strong_mask, weak_mask))
-                elif loss == 'feature':
-                    d.update(self._feature(o, m, n_strong, num_boxes))
-            losses.update(d if li == 0 else {k + f'_{li - 1}': v for k, v in d.items()})
-        return losses, all_idx[0]
+            raise NotImplementedError('fine_tune / focal-loss branches (sedt.py:176,211-218; matcher.py:99-121) are not built')
+        dense, idx0 = self.prepare(outputs, targets, weak_mask, strong_mask, normalize)
+        return self.compute(outputs, dense), idx0
 
 
 class PostProcess(nn.Module):

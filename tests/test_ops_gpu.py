@@ -337,3 +337,23 @@ def test_adamw_clip_matches_torch(ops):
         assert abs(ss.sqrt().item() - tn.item()) < 1e-3 * tn.item()
         ops.adamw_clip(p, g.cuda(), m, v, ss, 0.1, 1e-4, 0.9, 0.999, 1e-8, 1e-4, step)
         np.testing.assert_allclose(p.cpu().numpy(), pr.detach().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_fused_multi_tensor_adamw_matches_torch(ops):
+    from sound_event_detection_transformer_amd.optim import FusedAdamW
+    shapes = [(300, 70), (65536 * 2 + 5,), (11,), (64, 3, 7, 7), (1,)]
+    ref = [randn(*s).requires_grad_(True) for s in shapes]
+    mine = [r.detach().clone().cuda().requires_grad_(True) for r in ref]
+    o_ref = torch.optim.AdamW([{'params': ref[:3]}, {'params': ref[3:], 'lr': 3e-4}], lr=1e-4, weight_decay=1e-4)
+    o_my = FusedAdamW([{'params': mine[:3]}, {'params': mine[3:], 'lr': 3e-4}], lr=1e-4, weight_decay=1e-4)
+    for step in range(3):
+        gs = [randn(*s) * (step + 1) for s in shapes]
+        for r, m, g in zip(ref, mine, gs):
+            r.grad = g.clone()
+            m.grad = g.clone().cuda()
+        tn = torch.nn.utils.clip_grad_norm_(ref, 0.1)
+        o_ref.step()
+        o_my.step(max_norm=0.1)
+        assert abs(o_my.grad_norm().item() - tn.item()) < 1e-4 * tn.item()
+        for r, m in zip(ref, mine):
+            np.testing.assert_allclose(m.detach().cpu().numpy(), r.detach().numpy(), rtol=2e-5, atol=1e-7)
