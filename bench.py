@@ -73,6 +73,7 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dump-igemm', default=None, help='write per-launch igemm timings (json) to this path')
+    ap.add_argument('--no-graph', action='store_true', help='issue every kernel from Python instead of replaying HIP graphs')
     ap.add_argument('--model-only', action='store_true', help='time fwd+bwd of the model with a fixed differentiable loss')
     args = ap.parse_args()
 
@@ -107,8 +108,15 @@ def main():
     B = args.batch
     x, targets = synthetic_batch(B, 500, 2020 + rank, dev)
 
+    from sound_event_detection_transformer_amd.engine import GraphedTrainStep
+    graphed = None
+    if not args.no_graph and not args.model_only and world == 1:
+        graphed = GraphedTrainStep(net, criterion, opt, x, targets, None, slice(B), max_norm=0.1)
+
     def step():
-        if args.model_only:
+        if graphed is not None and ops.PROFILE is None:
+            graphed(x, targets)
+        elif args.model_only:
             o = net(x)
             loss = o['pred_logits'].square().mean() + o['pred_boxes'].mean() + o['at'].mean() + \
                 sum(a['pred_logits'].square().mean() + a['pred_boxes'].mean() for a in o['aux_outputs'])
@@ -168,7 +176,7 @@ def main():
                                       "(B,1,500,64), full train step: fwd + host SetCriterion/Hungarian + bwd + clip 0.1 + AdamW, dropout 0.1"
                                       + (" [model-only timing]" if args.model_only else ""),
                           "global_batch": world * B, "parallelism": f"dp{world}"},
-               "roofline": roof, "cpu_baseline": cpu}
+               "roofline": roof, "cpu_baseline": cpu, "hip_graph": graphed is not None}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -196,7 +196,7 @@ typedef struct SedtChunk {
 } SedtChunk;
 int sedt_multi_sumsq(const SedtChunk* table, int nchunks, float* partial, float* sumsq, void* stream);
 int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float* sumsq, float max_norm, float beta1, float beta2,
-                     float eps, int step, void* stream);
+                     float eps, const int32_t* step_ptr /* device: 1-based step count */, void* stream);
 
 /* ------------------------------------------------------------------ host-side matching (sedt/matcher.py:95)
  * HOST pointers.  cost [nlayers][nclips][Q][Nt] f32; clip b owns columns [col_off[b], col_off[b]+ncols[b]).

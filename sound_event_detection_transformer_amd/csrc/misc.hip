@@ -348,8 +348,11 @@ __global__ void multi_sumsq_kernel(const SedtChunk* __restrict__ table, float* _
 }
 
 __global__ void multi_adamw_kernel(const SedtChunk* __restrict__ table, const float* sumsq, float max_norm, float b1,
-                                   float b2, float eps, float bc1, float bc2_sqrt) {
+                                   float b2, float eps, const int32_t* __restrict__ step_ptr) {
   const SedtChunk c = table[blockIdx.x];
+  const float stepf = (float)step_ptr[0];
+  const float bc1 = 1.f - powf(b1, stepf);
+  const float bc2_sqrt = sqrtf(1.f - powf(b2, stepf));
   float* p = reinterpret_cast<float*>(c.p);
   const float* g = reinterpret_cast<const float*>(c.g);
   float* m = reinterpret_cast<float*>(c.m);
@@ -575,12 +578,10 @@ extern "C" int sedt_multi_sumsq(const SedtChunk* table, int nchunks, float* part
 }
 
 extern "C" int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float* sumsq, float max_norm, float beta1,
-                                float beta2, float eps, int step, void* stream) {
-  SEDT_REQUIRE(table && nchunks > 0 && step >= 1, "multi_adamw: bad arguments");
+                                float beta2, float eps, const int32_t* step_ptr, void* stream) {
+  SEDT_REQUIRE(table && nchunks > 0 && step_ptr, "multi_adamw: bad arguments");
   SEDT_REQUIRE(max_norm <= 0.f || sumsq, "multi_adamw: clipping needs sumsq");
-  float bc1 = 1.f - powf(beta1, (float)step);
-  float bc2s = sqrtf(1.f - powf(beta2, (float)step));
-  hipLaunchKernelGGL(multi_adamw_kernel, dim3(nchunks), dim3(256), 0, S(stream), table, sumsq, max_norm, beta1, beta2, eps, bc1,
-                     bc2s);
+  hipLaunchKernelGGL(multi_adamw_kernel, dim3(nchunks), dim3(256), 0, S(stream), table, sumsq, max_norm, beta1, beta2, eps,
+                     step_ptr);
   return check_launch("multi_adamw");
 }

@@ -325,6 +325,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ q, 
 
 template <typename K>
 static int set_lds_attr(K kern, size_t bytes, const char* what) {
+  static bool done = false;   // one static per kernel instantiation: never called again (e.g. during graph capture)
+  if (done) return 0;
+  done = true;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) {
     set_error("%s: hipFuncSetAttribute(%zu B LDS) failed: %s", what, bytes, hipGetErrorString(e));

@@ -16,6 +16,8 @@ def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None
     losses = getattr(criterion, 'last_total', None)      # the same weighted sum, pre-reduced as one dot product
     if losses is None:
         losses = sum(loss_dict[k] * wd[k] for k in loss_dict.keys() if k in wd)
+    else:
+        criterion.last_total = None                      # do not keep the autograd graph alive past this step
     if check_finite:
         v = losses.item()
         if not math.isfinite(v):
@@ -38,3 +40,66 @@ def build_optimizer(model, lr=1e-4, lr_backbone=1e-4, weight_decay=1e-4, fused=T
     if fused:
         return FusedAdamW(groups, lr=lr, weight_decay=weight_decay)
     return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay)
+
+
+class GraphedTrainStep(object):
+    """The training step as two HIP graphs around the host-side matching:
+
+        graph A: model forward                      (static input -> static outputs, saved activations in the graph pool)
+        host   : SetCriterion.prepare               (one D2H copy, batched C++ Hungarian, one H2D copy)
+        graph B: SetCriterion.compute + backward + fused clip/AdamW
+
+    so a step costs two graph launches instead of ~1500 kernel launches issued from Python.  Shapes are static: every
+    batch must have the batch size, clip length and strong/weak split it was captured with.  Dropout masks change on each
+    replay through the device-side seed word (runtime.bump_seed); the Adam step count lives on the device too."""
+
+    def __init__(self, model, criterion, optimizer, example_input, example_targets, mask_weak=None, mask_strong=None,
+                 max_norm=0.1, normalize=False, warmup=3):
+        from . import runtime
+        if not isinstance(optimizer, FusedAdamW):
+            raise RuntimeError('GraphedTrainStep needs FusedAdamW (device-side step count, one pointer table)')
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.mw, self.ms, self.max_norm, self.normalize = mask_weak, mask_strong, max_norm, normalize
+        self.runtime = runtime
+        dev = example_input.device
+        self.dev = dev
+        self.static_x = example_input.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                          # eager steps: lazy inits (LDS attributes, optimizer state)
+                train_step(model, criterion, optimizer, self.static_x, example_targets, mask_weak, mask_strong, max_norm,
+                           normalize, check_finite=False)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        criterion.last_total = None      # drop the warm-up autograd graphs (their AccumulateGrad nodes belong to `side`)
+        optimizer.zero_grad(set_to_none=True)
+        self.g_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fwd):
+            self.static_out = model(self.static_x)
+        dense, _ = criterion.prepare(self.static_out, example_targets, mask_weak, mask_strong, normalize)
+        self.meta = dense['_meta']
+        self.static_pack = dense['_pack'].clone()
+        self.static_dense = criterion.dense_views(self.static_pack, self.meta)
+        self.g_bwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
+            self.static_losses = criterion.compute(self.static_out, self.static_dense)
+            self.static_total = criterion.last_total
+            self.static_total.backward()
+            optimizer.step(max_norm=max_norm)
+        torch.cuda.synchronize()
+
+    def __call__(self, batch_input, targets, check_finite=False):
+        self.static_x.copy_(batch_input, non_blocking=True)
+        self.runtime.bump_seed(self.dev)
+        self.g_fwd.replay()
+        dense, _ = self.criterion.prepare(self.static_out, targets, self.mw, self.ms, self.normalize)
+        if dense['_meta'] != self.meta:
+            raise RuntimeError(f'batch composition changed: captured {self.meta}, got {dense["_meta"]}')
+        self.static_pack.copy_(dense['_pack'], non_blocking=True)
+        self.g_bwd.replay()
+        if check_finite:
+            v = self.static_total.item()
+            if not math.isfinite(v):
+                raise FloatingPointError(f'Loss is {v}, stopping training')
+        return self.static_total, self.static_losses

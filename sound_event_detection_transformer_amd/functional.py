@@ -106,8 +106,9 @@ def _mha_fwd(dt, q_in, k_in, v_in, same_qk, w_in, b_in, w_out, b_out, res, B, H,
         k = ops.linear(dt, k_in, wf[E:2 * E], bias=b_in[E:2 * E])
         qk = None
     v = ops.linear(dt, v_in, wf[2 * E:], bias=b_in[2 * E:])
-    ctxv, lse = ops.attention_fwd(dt, q, k, v, B, H, Lq, Lk, kpm, amask, p, seeds[0])
-    out = ops.linear(dt, ctxv, _wf(dt, w_out), bias=b_out, drop_p=p, seed=seeds[1], res=res, ldr=res.stride(0))
+    sp = runtime.seed_ptr(q_in.device) if p > 0 else None
+    ctxv, lse = ops.attention_fwd(dt, q, k, v, B, H, Lq, Lk, kpm, amask, p, seeds[0], sp)
+    out = ops.linear(dt, ctxv, _wf(dt, w_out), bias=b_out, drop_p=p, seed=seeds[1], seed_ptr=sp, res=res, ldr=res.stride(0))
     saved = dict(q_in=q_in, k_in=k_in, v_in=v_in, same_qk=same_qk, qk=qk, q=q, k=k, v=v, ctxv=ctxv, lse=lse,
                  dims=(B, H, Lq, Lk), kpm=kpm, amask=amask, p=p, seeds=seeds)
     return out, saved
@@ -119,7 +120,8 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True):
     B, H, Lq, Lk = s['dims']
     E = w_in.shape[1]
     p = s['p']
-    g1 = ops.dropout_grad(dt, g_out, p, s['seeds'][1]) if p > 0 else g_out
+    sp = runtime.seed_ptr(g_out.device) if p > 0 else None
+    g1 = ops.dropout_grad(dt, g_out, p, s['seeds'][1], sp) if p > 0 else g_out
     d_wo = ops.linear_wgrad(dt, g1, s['ctxv'])
     d_bo = ops.colsum(dt, g1)
     g_ctx = ops.linear(dt, g1, _wb(dt, w_out))
@@ -132,7 +134,7 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True):
         dk = torch.empty((B * Lk, E), device=g_out.device, dtype=td)
     dv = torch.empty((B * Lk, E), device=g_out.device, dtype=td)
     ops.attention_bwd(dt, s['q'], s['k'], s['v'], s['ctxv'], g_ctx, s['lse'], B, H, Lq, Lk, dq, dk, dv, s['kpm'], s['amask'],
-                      p, s['seeds'][0])
+                      p, s['seeds'][0], sp)
     d_win = torch.empty((3 * E, E), device=g_out.device, dtype=torch.float32)
     d_bin = torch.empty((3 * E,), device=g_out.device, dtype=torch.float32)
     wb = _wb(dt, w_in)                                      # [E][3E]
@@ -160,15 +162,16 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True):
 
 
 def _ffn_fwd(dt, x_in, w1, b1, w2, b2, res, p, seeds):
-    h = ops.linear(dt, x_in, _wf(dt, w1), bias=b1, act=ACT_RELU, drop_p=p, seed=seeds[0])
-    out = ops.linear(dt, h, _wf(dt, w2), bias=b2, drop_p=p, seed=seeds[1], res=res, ldr=res.stride(0))
+    sp = runtime.seed_ptr(x_in.device) if p > 0 else None
+    h = ops.linear(dt, x_in, _wf(dt, w1), bias=b1, act=ACT_RELU, drop_p=p, seed=seeds[0], seed_ptr=sp)
+    out = ops.linear(dt, h, _wf(dt, w2), bias=b2, drop_p=p, seed=seeds[1], seed_ptr=sp, res=res, ldr=res.stride(0))
     return out, dict(x_in=x_in, h=h, p=p, seeds=seeds)
 
 
 def _ffn_bwd(dt, s, g_out, w1, w2, res_for_gx=None):
     """returns g_x_in (+ res_for_gx), dW1, db1, dW2, db2"""
     p = s['p']
-    g2 = ops.dropout_grad(dt, g_out, p, s['seeds'][1]) if p > 0 else g_out
+    g2 = ops.dropout_grad(dt, g_out, p, s['seeds'][1], runtime.seed_ptr(g_out.device)) if p > 0 else g_out
     d_w2 = ops.linear_wgrad(dt, g2, s['h'])
     d_b2 = ops.colsum(dt, g2)
     # d_hidden = (g2 @ W2) * [h > 0] / (1-p): h = drop(relu(.)) is positive exactly where kept and active

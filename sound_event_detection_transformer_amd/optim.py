@@ -47,6 +47,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._dev_tab = torch.empty(self._tab.nbytes, dtype=torch.uint8, device=dev)
         self._partial = torch.empty(len(owner), device=dev)
         self._sumsq = torch.zeros(1, device=dev)
+        self._step_t = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side step count (graph-replay safe)
         self._host_tab = torch.empty(self._tab.nbytes, dtype=torch.uint8).pin_memory()
         self._static = True
 
@@ -71,13 +72,22 @@ class FusedAdamW(torch.optim.Optimizer):
         self._host_tab.numpy()[:] = t.view(np.uint8)
         self._dev_tab.copy_(self._host_tab, non_blocking=True)
         self._step += 1
+        self._step_t.add_(1)
         lib = L.load()
         g0 = self.param_groups[0]
         n = len(t)
         if max_norm > 0:
             L.check(lib.sedt_multi_sumsq(L.p(self._dev_tab), n, L.p(self._partial), L.p(self._sumsq), L.stream_ptr()), 'multi_sumsq')
         L.check(lib.sedt_multi_adamw(L.p(self._dev_tab), n, L.p(self._sumsq), float(max_norm), g0['betas'][0], g0['betas'][1],
-                                     g0['eps'], self._step, L.stream_ptr()), 'multi_adamw')
+                                     g0['eps'], L.p(self._step_t), L.stream_ptr()), 'multi_adamw')
+
+    def refresh_hyperparams(self):
+        """re-read lr / weight_decay of the param groups into the pinned chunk table (a captured graph re-uploads it)"""
+        lrs = np.asarray([g['lr'] for g in self.param_groups], np.float32)
+        wds = np.asarray([g['weight_decay'] for g in self.param_groups], np.float32)
+        self._tab['lr'] = lrs[self._gi][self._owner]
+        self._tab['wd'] = wds[self._gi][self._owner]
+        self._host_tab.numpy()[:] = self._tab.view(np.uint8)
 
     def grad_norm(self):
         """global gradient norm of the last clipped step (device tensor)"""

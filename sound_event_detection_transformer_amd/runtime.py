@@ -27,3 +27,19 @@ def next_seed():
     """a fresh 32-bit seed per dropout site per forward (the kernels hash (seed, element index))"""
     _state['seed'] = (_state['seed'] * 1103515245 + 12345) & 0x7fffffff
     return _state['seed']
+
+
+_seed_tensors = {}
+
+
+def seed_ptr(device):
+    """device-side seed word added to every dropout seed: a captured HIP graph draws fresh masks on each replay after
+    ``bump_seed`` (the per-site seeds baked into the launches stay constant)."""
+    key = str(device)
+    if key not in _seed_tensors:
+        _seed_tensors[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _seed_tensors[key]
+
+
+def bump_seed(device):
+    seed_ptr(device).add_(1)

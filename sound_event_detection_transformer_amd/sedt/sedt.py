@@ -203,16 +203,24 @@ class SetCriterion(nn.Module):
         pack = np.concatenate([tc.ravel(), coef.ravel(), wbox.ravel(), tbox.ravel(), a.astype(np.float32).ravel(),
                                gt_weak.ravel(), tgt_len, np.asarray([num_boxes], np.float32)])
         d = torch.from_numpy(pack).to(dev, non_blocking=True)                       # the ONE host->device copy
-        n3 = L * ns * Q
-        dense = {'tc': d[0:n3].view(L, ns, Q).long(), 'coef': d[n3:2 * n3].view(L, ns, Q),
-                 'wbox': d[2 * n3:3 * n3].view(L, ns, Q), 'tbox': d[3 * n3:5 * n3].view(L, ns, Q, 2),
-                 'tidx': d[5 * n3:6 * n3].view(L, ns, Q).long(),
-                 'gt_weak': d[6 * n3:6 * n3 + n_lab * C].view(n_lab, C),
-                 'tgt_len': d[6 * n3 + n_lab * C:6 * n3 + n_lab * C + len(targets)],
-                 'num_boxes': d[-1:], 'ns': ns, 'n_lab': n_lab, 'L': L}
+        dense = self.dense_views(d, (L, ns, Q, n_lab, C, len(targets)))
         idx0 = [(torch.from_numpy(np.nonzero(matched[0, b])[0].astype(np.int64)),
                  torch.from_numpy(assign[0, b][matched[0, b]].astype(np.int64))) for b in range(ns)]
         return dense, idx0
+
+    @staticmethod
+    def dense_views(d, meta):
+        """views into the packed dense-target buffer (layout fixed by the batch composition, so a captured graph can keep
+        one static buffer and only its contents change).  All entries are f32 VIEWS: integer conversions happen inside
+        ``compute`` so that they are part of a captured graph."""
+        L, ns, Q, n_lab, C, nt = meta
+        n3 = L * ns * Q
+        return {'tc': d[0:n3].view(L, ns, Q), 'coef': d[n3:2 * n3].view(L, ns, Q),
+                'wbox': d[2 * n3:3 * n3].view(L, ns, Q), 'tbox': d[3 * n3:5 * n3].view(L, ns, Q, 2),
+                'tidx': d[5 * n3:6 * n3].view(L, ns, Q),
+                'gt_weak': d[6 * n3:6 * n3 + n_lab * C].view(n_lab, C),
+                'tgt_len': d[6 * n3 + n_lab * C:6 * n3 + n_lab * C + nt],
+                'num_boxes': d[-1:], 'ns': ns, 'n_lab': n_lab, 'L': L, '_pack': d, '_meta': meta}
 
     # ------------------------------------------------------------------ device part (fixed shapes)
     def compute(self, outputs, dense):
@@ -224,13 +232,14 @@ class SetCriterion(nn.Module):
         logits = logits_all[:, :ns]
         out = {}
         vec = {}
+        tc = dense['tc'].long()
         if 'labels' in self.losses:
-            ce = F.cross_entropy(logits.reshape(-1, C1), dense['tc'].reshape(-1), self.empty_weight.to(logits.device),
+            ce = F.cross_entropy(logits.reshape(-1, C1), tc.reshape(-1), self.empty_weight.to(logits.device),
                                  reduction='none').view(L, -1)
             vec['loss_ce'] = (ce * dense['coef'].view(L, -1)).sum(1) / nb
             with torch.no_grad():
                 m = (dense['wbox'][0] > 0)
-                hit = ((logits[0].argmax(-1) == dense['tc'][0]) & m).float().sum()
+                hit = ((logits[0].argmax(-1) == tc[0]) & m).float().sum()
                 out['class_error'] = 100 - 100 * hit / m.float().sum().clamp(min=1)
         if 'boxes' in self.losses:
             s1, e1 = boxes[..., 0] - boxes[..., 1] / 2, boxes[..., 0] + boxes[..., 1] / 2
@@ -252,7 +261,7 @@ class SetCriterion(nn.Module):
             feats = torch.stack([o['pred_feature'][:ns] for o in layers]).float()     # [L,ns,Q,F]
             gt = outputs['gt_feature'].float()
             gt = gt.view(ns, gt.shape[0] // ns, -1)
-            tgt = gt[torch.arange(ns, device=gt.device)[None, :, None], dense['tidx']]   # [L,ns,Q,F]
+            tgt = gt[torch.arange(ns, device=gt.device)[None, :, None], dense['tidx'].long()]   # [L,ns,Q,F]
             mse = (F.normalize(feats, dim=-1) - F.normalize(tgt, dim=-1)).square().sum(-1)
             vec['loss_feature'] = (mse * (dense['wbox'] > 0).float()).view(L, -1).sum(1) / nb
         for k, v in vec.items():

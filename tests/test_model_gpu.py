@@ -249,3 +249,38 @@ def test_dropout_train_mode_runs_and_is_seeded(pkg):
     assert torch.equal(a, b)
     assert not torch.equal(a, c)
     assert torch.isfinite(c).all()
+
+
+def test_graphed_train_step_matches_eager(pkg):
+    """two HIP graphs around the host matching reproduce the eager step (dropout 0 -> deterministic) and keep training"""
+    A, runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import train_step, build_optimizer, GraphedTrainStep
+    runtime.set_compute_dtype('bf16')
+    B = 4
+    x = torch.randn(B, 1, 500, 64, generator=torch.Generator().manual_seed(6)).cuda()
+    batches = [(torch.randn(B, 1, 500, 64, generator=torch.Generator().manual_seed(60 + i)).cuda(), synthetic_targets(B, 70 + i, 10))
+               for i in range(3)]
+    res = {}
+    for mode in ('eager', 'graph'):
+        model, crit = _build(sedt, 3, 10, dropout=0.0)
+        _seed_load(model, 5).cuda().train()
+        crit.cuda()
+        opt = build_optimizer(model)
+        if mode == 'graph':
+            sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+            stepper = GraphedTrainStep(model, crit, opt, x, batches[0][1], None, slice(B), warmup=2)
+            model.load_state_dict(sd0)                       # undo the warm-up updates; optimizer moments restart below
+            opt._m.zero_(); opt._v.zero_(); opt._step_t.zero_()
+        losses = []
+        for xb, tb in batches:
+            if mode == 'eager':
+                l, _ = train_step(model, crit, opt, xb, tb, None, slice(B), max_norm=0.1)
+            else:
+                l, _ = stepper(xb, tb)
+            losses.append(float(l))
+        res[mode] = (losses, {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()})
+    runtime.set_compute_dtype('f32')
+    np.testing.assert_allclose(res['graph'][0], res['eager'][0], rtol=1e-3)
+    for k in res['eager'][1]:
+        assert rel(res['graph'][1][k], res['eager'][1][k]) < 2e-3, k
+    assert res['graph'][0][0] != res['graph'][0][1]
