@@ -19,6 +19,7 @@
 //         v_mfma_f32_32x32x2_f32 (exact f32 FMA chain - the parity mode).
 // trans=1 sources have the reduction index as the slow axis; bf16 transposes 4(k)x8(r) blocks
 // in registers before the LDS write so the fragment reads stay ds_read_b128.
+#include <stdlib.h>
 #include "common.h"
 
 namespace sedt {
@@ -456,6 +457,17 @@ static int launch_typed(const SedtIgemm& p, hipStream_t st) {
 
 }  // namespace sedt
 
+namespace sedt { int igemm2_try(const SedtIgemm& p, hipStream_t st); }
+
+static bool use_v2() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SEDT_IGEMM_V2");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 extern "C" int sedt_igemm(const SedtIgemm* args, int dtype, void* stream) {
   using namespace sedt;
   SEDT_REQUIRE(args != nullptr, "igemm: null args");
@@ -463,7 +475,13 @@ extern "C" int sedt_igemm(const SedtIgemm* args, int dtype, void* stream) {
   SEDT_REQUIRE(args->A && args->B && (args->C || args->splitk > 1), "igemm: null operand");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SEDT_F32) return launch_typed<float>(*args, st);
-  if (dtype == SEDT_BF16) return launch_typed<bf16_t>(*args, st);
+  if (dtype == SEDT_BF16) {
+    if (use_v2()) {                       // LDS-DMA pipeline (igemm2.hip) when the problem fits its envelope
+      int r = igemm2_try(*args, st);
+      if (r >= 0) return r;
+    }
+    return launch_typed<bf16_t>(*args, st);
+  }
   set_error("igemm: unsupported dtype %d", dtype);
   return 1;
 }

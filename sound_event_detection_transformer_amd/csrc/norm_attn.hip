@@ -7,8 +7,8 @@
 //
 // Attention: the whole K/V (and, backward, Q/dO) of one (batch, head) lives in LDS as f32 with
 // pitch 33 (conflict-free row-per-lane reads); a wave owns a query row (forward / dQ pass) or a
-// key row (dK,dV pass), lanes run over the other sequence axis, softmax statistics are wave
-// reductions.  The probabilities are never written to HBM: backward recomputes them from the
+// key row (dK,dV pass), lanes run over the other sequence axis (row operands of the owner are held in
+// registers, the per-lane rows are read as float4 = ds_read_b128), softmax statistics are wave reductions.  The probabilities are never written to HBM: backward recomputes them from the
 // saved log-sum-exp and regenerates the dropout mask from (seed, element index).
 #include "common.h"
 
@@ -114,8 +114,18 @@ static int ln_bwd_blocks(int rows) {
 
 // ============================================================================ attention
 constexpr int DH = 32;      // head dim
-constexpr int KP = DH + 1;  // LDS pitch
+constexpr int KP = DH + 4;  // LDS pitch: 16-B aligned rows; 36*r mod 64 hits 16 distinct 16-B slots for 16 consecutive rows
 constexpr int MAXKPL = 8;   // keys per lane -> L <= 512
+
+__device__ __forceinline__ float dot32(const float (&a)[DH], const float* __restrict__ row) {
+  float acc = 0.f;
+#pragma unroll
+  for (int e = 0; e < DH; e += 4) {
+    const float4 r = *reinterpret_cast<const float4*>(row + e);
+    acc += a[e] * r.x + a[e + 1] * r.y + a[e + 2] * r.z + a[e + 3] * r.w;
+  }
+  return acc;
+}
 
 template <typename T>
 __device__ __forceinline__ void load_rows_lds(float* dst, const T* src, long ld, int L, int tid, int nthreads) {
@@ -162,9 +172,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
         const int j = lane + c * 64;
         s[c] = -INFINITY;
         if (j < Lk) {
-          float a = 0.f;
-#pragma unroll
-          for (int d = 0; d < DH; ++d) a += qr[d] * Ks[j * KP + d];
+          float a = dot32(qr, Ks + j * KP);
           if (amask) a += amask[(long)i * Lk + j];
           if (kpm && kpm[(long)b * Lk + j]) a = -INFINITY;
           s[c] = a;
@@ -252,13 +260,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ q, 
     const bool live = i < Lq;
     if (live) {
       const float li = Ls[i], di = De[i];
-      for (int j = lane; j < Lk; j += 64) {
-        float s = 0.f, dp = 0.f;
+      float qi[DH], doi[DH];
 #pragma unroll
-        for (int e = 0; e < DH; ++e) {
-          s += Qs[i * KP + e] * Ks[j * KP + e];
-          dp += Ds[i * KP + e] * Vs[j * KP + e];
-        }
+      for (int e = 0; e < DH; ++e) { qi[e] = Qs[i * KP + e]; doi[e] = Ds[i * KP + e]; }
+      for (int j = lane; j < Lk; j += 64) {
+        float s = dot32(qi, Ks + j * KP), dp = dot32(doi, Vs + j * KP);
         s *= scale;
         if (amask) s += amask[(long)i * Lk + j];
         if (kpm && kpm[(long)b * Lk + j]) s = -INFINITY;
@@ -284,13 +290,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ q, 
     const bool live = j < Lk;
     if (live) {
       const bool padded = kpm && kpm[(long)b * Lk + j];
-      for (int i = lane; i < Lq; i += 64) {
-        float s = 0.f, dp = 0.f;
+      float kj[DH], vj[DH];
 #pragma unroll
-        for (int e = 0; e < DH; ++e) {
-          s += Qs[i * KP + e] * Ks[j * KP + e];
-          dp += Ds[i * KP + e] * Vs[j * KP + e];
-        }
+      for (int e = 0; e < DH; ++e) { kj[e] = Ks[j * KP + e]; vj[e] = Vs[j * KP + e]; }
+      for (int i = lane; i < Lq; i += 64) {
+        float s = dot32(kj, Qs + i * KP), dp = dot32(vj, Ds + i * KP);
         s *= scale;
         if (amask) s += amask[(long)i * Lk + j];
         if (padded) s = -INFINITY;
