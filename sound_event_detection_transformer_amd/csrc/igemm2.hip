@@ -14,34 +14,11 @@
 //     stores 16 B (residual / ReLU-mask loads are 16 B too) instead of 2-byte strided stores.
 //   * workgroup order is XCD-aware: consecutive tiles of an M panel run on the same XCD and share its L2.
 #include <stdlib.h>
-#include "common.h"
+#include "igemm2_common.h"
 
 namespace sedt {
 
-constexpr int BK2 = 64;           // bf16 elements per K tile = 128 B per row
-constexpr int ROWB = BK2 * 2;     // bytes per LDS row
-
-struct Geom2 {
-  int Hi, Wi, Ci, Ho, Wo, KH, KW, sh, sw, ph, pw, dh, dw, transposed;
-};
-
-__device__ __forceinline__ long gather_pix2(const Geom2& g, int n, int ho, int wo, int kh, int kw) {
-  int hi, wi;
-  if (!g.transposed) {
-    hi = ho * g.sh - g.ph + kh * g.dh;
-    wi = wo * g.sw - g.pw + kw * g.dw;
-    if ((unsigned)hi >= (unsigned)g.Hi || (unsigned)wi >= (unsigned)g.Wi) return -1;
-  } else {
-    int th = ho + g.ph - kh * g.dh, tw = wo + g.pw - kw * g.dw;
-    if (th < 0 || tw < 0) return -1;
-    hi = th / g.sh;
-    wi = tw / g.sw;
-    if (hi * g.sh != th || wi * g.sw != tw || hi >= g.Hi || wi >= g.Wi) return -1;
-  }
-  return ((long)n * g.Hi + hi) * g.Wi + wi;
-}
-
-typedef __attribute__((address_space(3))) void lds_void;
+int wgrad2_try(const SedtIgemm& p, hipStream_t st);   // wgrad2.hip
 
 template <int BM, int BN, int STAGES>
 __global__ __launch_bounds__(256) void igemm2_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes) {
@@ -278,7 +255,15 @@ static int launch2(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipSt
 // returns -1 when the problem is outside v2's envelope (the caller then uses the general v1 kernel)
 int igemm2_try(const SedtIgemm& p, hipStream_t st) {
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  if (p.trans || p.out_f32 || p.splitk > 1 || p.act == SEDT_ACT_SIGMOID) return -1;
+  if (p.trans) {
+    static int wg2 = -1;
+    if (wg2 < 0) {
+      const char* e = getenv("SEDT_WGRAD_V2");
+      wg2 = (e && e[0] == '0') ? 0 : 1;
+    }
+    return wg2 ? wgrad2_try(p, st) : -1;
+  }
+  if (p.out_f32 || p.splitk > 1 || p.act == SEDT_ACT_SIGMOID) return -1;
   if ((p.K & 7) || (p.N & 7) || (p.lda & 7) || (p.ldb & 7) || (p.ldc & 7)) return -1;
   if (!al16(p.A) || !al16(p.B) || !al16(p.C)) return -1;
   if (p.res && (!al16(p.res) || (p.ldr & 7))) return -1;
