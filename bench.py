@@ -101,7 +101,8 @@ def main():
     model.to(dev).train()
     criterion.to(dev)
     net = model
-    if world > 1:
+    if world > 1 and args.no_graph:
+        # eager path: torch DDP (bucketed RCCL all-reduce overlapped with backward)
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
                                                         gradient_as_bucket_view=True)
     opt = build_optimizer(model)
@@ -110,7 +111,7 @@ def main():
 
     from sound_event_detection_transformer_amd.engine import GraphedTrainStep
     graphed = None
-    if not args.no_graph and not args.model_only and world == 1:
+    if not args.no_graph and not args.model_only:
         graphed = GraphedTrainStep(net, criterion, opt, x, targets, None, slice(B), max_norm=0.1)
 
     def step():

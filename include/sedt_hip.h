@@ -194,6 +194,9 @@ typedef struct SedtChunk {
   float wd;
   int32_t pad_;
 } SedtChunk;
+/* chunk.p[i] = chunk.g[i] for every chunk: packs all gradient tensors into one flat f32 buffer (one launch) ahead of
+ * the single RCCL all-reduce of the data-parallel step */
+int sedt_multi_gather(const SedtChunk* table, int nchunks, void* stream);
 int sedt_multi_sumsq(const SedtChunk* table, int nchunks, float* partial, float* sumsq, void* stream);
 int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float* sumsq, float max_norm, float beta1, float beta2,
                      float eps, const int32_t* step_ptr /* device: 1-based step count */, void* stream);

@@ -374,6 +374,13 @@ __global__ void multi_adamw_kernel(const SedtChunk* __restrict__ table, const fl
   }
 }
 
+__global__ void multi_gather_kernel(const SedtChunk* __restrict__ table) {
+  const SedtChunk c = table[blockIdx.x];
+  float* dst = reinterpret_cast<float*>(c.p);
+  const float* src = reinterpret_cast<const float*>(c.g);
+  for (int i = threadIdx.x; i < c.n; i += blockDim.x) dst[i] = src[i];
+}
+
 }  // namespace sedt
 
 using namespace sedt;
@@ -584,4 +591,10 @@ extern "C" int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float
   hipLaunchKernelGGL(multi_adamw_kernel, dim3(nchunks), dim3(256), 0, S(stream), table, sumsq, max_norm, beta1, beta2, eps,
                      step_ptr);
   return check_launch("multi_adamw");
+}
+
+extern "C" int sedt_multi_gather(const SedtChunk* table, int nchunks, void* stream) {
+  SEDT_REQUIRE(table && nchunks > 0, "multi_gather: bad arguments");
+  hipLaunchKernelGGL(multi_gather_kernel, dim3(nchunks), dim3(256), 0, S(stream), table);
+  return check_launch("multi_gather");
 }

@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ q, 
     if (live) {
       const int d = lane & 31, half = lane >> 5;
       float acc = 0.f;
+#pragma unroll 8
       for (int j = half; j < Lk; j += 2) acc += P[j] * Vs[j * KP + d];
       acc += __shfl_xor(acc, 32, 64);
       if (lane < 32) o[((long)b * Lq + i) * ldo + h * DH + d] = (T)acc;
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ q, 
     __syncthreads();
     if (live) {
       float acc = 0.f;
+#pragma unroll 8
       for (int j = half; j < Lk; j += 2) acc += dSw[j] * Ks[j * KP + d];
       acc += __shfl_xor(acc, 32, 64);
       if (lane < 32) dq[((long)b * Lq + i) * lddq + h * DH + d] = (T)(acc * scale);
@@ -312,6 +314,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ q, 
     __syncthreads();
     if (live) {
       float ak = 0.f, av = 0.f;
+#pragma unroll 8
       for (int i = half; i < Lq; i += 2) {
         ak += dSw[i] * Qs[i * KP + d];
         av += Pdw[i] * Ds[i * KP + d];

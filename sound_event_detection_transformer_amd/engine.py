@@ -6,8 +6,25 @@ import torch
 from .optim import FusedAdamW
 
 
+def allreduce_mean(flat):
+    """average one flat gradient buffer over the data-parallel group: RCCL AVG on GPUs; SUM + scale elsewhere
+    (gloo has no AVG and, in this image, no GPU tensors: stage through the host - used by the CPU/gloo tests only)"""
+    dist = torch.distributed
+    world = dist.get_world_size()
+    if dist.get_backend() == 'nccl':
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+    elif flat.is_cuda:
+        h = flat.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        flat.copy_(h.div_(world))
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+    return flat
+
+
 def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None, mask_strong=None, max_norm=0.1,
-               normalize=False, check_finite=True, patches=None):
+               normalize=False, check_finite=True, patches=None, allreduce=False):
     """forward -> SetCriterion -> weighted sum over weight_dict -> backward -> clip_grad_norm_(max_norm) -> step ->
     zero_grad.  Raises on a non-finite loss (the reference calls sys.exit(1), engine.py:70-73)."""
     outputs = model(batch_input, patches) if patches is not None else model(batch_input)
@@ -23,7 +40,13 @@ def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None
         if not math.isfinite(v):
             raise FloatingPointError(f'Loss is {v}, stopping training: {loss_dict}')
     losses.backward()
-    if isinstance(optimizer, FusedAdamW):
+    dp = allreduce and torch.distributed.is_available() and torch.distributed.is_initialized() \
+        and torch.distributed.get_world_size() > 1
+    if isinstance(optimizer, FusedAdamW) and dp:
+        flat = optimizer.gather_grads()                  # plain data parallelism without the DDP wrapper
+        allreduce_mean(flat)
+        optimizer.step(max_norm=max_norm, from_flat=True)
+    elif isinstance(optimizer, FusedAdamW):
         optimizer.step(max_norm=max_norm)                # clip + AdamW fused (three launches for all tensors)
     else:
         if max_norm > 0:
@@ -69,7 +92,7 @@ class GraphedTrainStep(object):
         with torch.cuda.stream(side):
             for _ in range(warmup):                          # eager steps: lazy inits (LDS attributes, optimizer state)
                 train_step(model, criterion, optimizer, self.static_x, example_targets, mask_weak, mask_strong, max_norm,
-                           normalize, check_finite=False)
+                           normalize, check_finite=False, allreduce=True)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         criterion.last_total = None      # drop the warm-up autograd graphs (their AccumulateGrad nodes belong to `side`)
@@ -81,12 +104,24 @@ class GraphedTrainStep(object):
         self.meta = dense['_meta']
         self.static_pack = dense['_pack'].clone()
         self.static_dense = criterion.dense_views(self.static_pack, self.meta)
+        self.world = torch.distributed.get_world_size() if (torch.distributed.is_available()
+                                                            and torch.distributed.is_initialized()) else 1
         self.g_bwd = torch.cuda.CUDAGraph()
+        self.g_opt = None
         with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
             self.static_losses = criterion.compute(self.static_out, self.static_dense)
             self.static_total = criterion.last_total
             self.static_total.backward()
-            optimizer.step(max_norm=max_norm)
+            if self.world == 1:
+                optimizer.step(max_norm=max_norm)
+            else:
+                self.flat_g = optimizer.gather_grads()       # all gradients -> one flat buffer (one launch)
+        if self.world > 1:
+            # data parallel: ONE RCCL all-reduce of the flat gradient buffer between the two graphs, then the fused
+            # clip + AdamW reads the averaged gradients from the flat buffer
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt, pool=self.g_fwd.pool()):
+                optimizer.step(max_norm=max_norm, from_flat=True)
         torch.cuda.synchronize()
 
     def __call__(self, batch_input, targets, check_finite=False):
@@ -98,6 +133,9 @@ class GraphedTrainStep(object):
             raise RuntimeError(f'batch composition changed: captured {self.meta}, got {dense["_meta"]}')
         self.static_pack.copy_(dense['_pack'], non_blocking=True)
         self.g_bwd.replay()
+        if self.g_opt is not None:
+            allreduce_mean(self.flat_g)
+            self.g_opt.replay()
         if check_finite:
             v = self.static_total.item()
             if not math.isfinite(v):

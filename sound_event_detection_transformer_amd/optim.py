@@ -49,24 +49,54 @@ class FusedAdamW(torch.optim.Optimizer):
         self._sumsq = torch.zeros(1, device=dev)
         self._step_t = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side step count (graph-replay safe)
         self._host_tab = torch.empty(self._tab.nbytes, dtype=torch.uint8).pin_memory()
+        self._state_off_b = so_b
+        self._flat_g = None
         self._static = True
 
+    # ---- data-parallel support: all gradients in ONE flat buffer -> one RCCL all-reduce -> update from the flat buffer
+    def enable_flat_grads(self):
+        if self._static is None:
+            self._build()
+        if self._flat_g is None:
+            self._flat_g = torch.zeros_like(self._m)
+            self._gtab = self._tab.copy()
+            self._dev_gtab = torch.empty_like(self._dev_tab)
+            self._host_gtab = torch.empty(self._tab.nbytes, dtype=torch.uint8).pin_memory()
+        return self._flat_g
+
     @torch.no_grad()
-    def step(self, closure=None, max_norm=0.0):
+    def gather_grads(self):
+        """copy every p.grad into the flat gradient buffer (one launch); returns the flat buffer"""
+        flat = self.enable_flat_grads()
+        gbase = np.fromiter((p.grad.data_ptr() for p in self._ps), np.uint64, len(self._ps))
+        t = self._gtab
+        t['p'] = np.uint64(flat.data_ptr()) + self._state_off_b
+        t['g'] = gbase[self._owner] + self._off
+        self._host_gtab.numpy()[:] = t.view(np.uint8)
+        self._dev_gtab.copy_(self._host_gtab, non_blocking=True)
+        L.check(L.load().sedt_multi_gather(L.p(self._dev_gtab), len(t), L.stream_ptr()), 'multi_gather')
+        return flat
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm=0.0, from_flat=False):
+        """from_flat: read the gradients from the flat buffer filled by gather_grads() (and all-reduced by the caller)"""
         if closure is not None:
             raise NotImplementedError
         if self._static is None:
             self._build()
         ps = self._ps
-        if any(p.grad is None for p in ps):
+        if not from_flat and any(p.grad is None for p in ps):
             raise RuntimeError('FusedAdamW: every trainable parameter must have a gradient')
         pbase = np.fromiter((p.data_ptr() for p in ps), np.uint64, len(ps))          # live pointers, every call
-        gbase = np.fromiter((p.grad.data_ptr() for p in ps), np.uint64, len(ps))
+        if from_flat:
+            gbase = None
+        else:
+            gbase = np.fromiter((p.grad.data_ptr() for p in ps), np.uint64, len(ps))
         lrs = np.asarray([g['lr'] for g in self.param_groups], np.float32)
         wds = np.asarray([g['weight_decay'] for g in self.param_groups], np.float32)
         t = self._tab
         t['p'] = pbase[self._owner] + self._off
-        t['g'] = gbase[self._owner] + self._off
+        t['g'] = (np.uint64(self._flat_g.data_ptr()) + self._state_off_b) if from_flat else (gbase[self._owner] + self._off)
         t['lr'] = lrs[self._gi][self._owner]
         t['wd'] = wds[self._gi][self._owner]
         self._host_tab.numpy()[:] = t.view(np.uint8)

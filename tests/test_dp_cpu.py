@@ -1,0 +1,56 @@
+"""CPU, world_size 2, gloo: the data-parallel pieces that run on the host - the flat-gradient mean all-reduce used by the
+graphed DP step, per-rank synthetic batches, and the product criterion's gradients averaged across ranks."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sound_event_detection_transformer_amd.engine import allreduce_mean
+    from sound_event_detection_transformer_amd.sedt import build_model, default_args
+    from bench import synthetic_batch
+    crit = build_model(default_args())[1]
+    B, Q = 4, 10
+    x, targets = synthetic_batch(B, 500, 2020 + rank, None)                  # different data on every rank
+    g = torch.Generator().manual_seed(7)                                       # same "model outputs" generator state
+    outs = {'pred_logits': torch.randn(B, Q, 11, generator=g).requires_grad_(True),
+            'pred_boxes': (torch.rand(B, Q, 2, generator=g) * 0.8 + 0.1).requires_grad_(True),
+            'at': torch.rand(B, 10, generator=g).clamp(0.05, 0.95).requires_grad_(True)}
+    ld, _ = crit(outs, targets, None, slice(B))
+    crit.last_total.backward()
+    local = torch.cat([outs[k].grad.flatten() for k in ('pred_logits', 'pred_boxes', 'at')])
+    flat = local.clone()
+    allreduce_mean(flat)
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    ok = torch.allclose(flat, torch.stack(gathered).mean(0), rtol=1e-6, atol=1e-7)
+    differ = not torch.allclose(gathered[0], gathered[1])
+    xs = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(xs, x.flatten()[:1].clone())
+    if rank == 0:
+        torch.save({'ok': ok, 'differ': differ, 'x_differ': bool(xs[0] != xs[1])}, out)
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_mean_allreduce_gloo_world2(tmp_path):
+    out = str(tmp_path / 'r.pt')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r['ok'] and r['differ'] and r['x_differ'], r

