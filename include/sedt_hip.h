@@ -90,6 +90,9 @@ typedef struct SedtIgemm {
   int32_t splitk;
   float* slab;
   int32_t tile_m, tile_n; /* 0 = choose automatically; else 64 or 128 */
+  float* colsum_out;      /* trans == 1, bf16 LDS-DMA kernel only: if non-null, per-split column sums of A over the
+                             reduction axis (= the bias gradient sum_pix dY[pix][m]) are written to colsum_out[z][M];
+                             sedt_wgrad_reduce adds them up.  sedt_igemm fails if the fast kernel cannot take the problem. */
 } SedtIgemm;
 
 int sedt_igemm(const SedtIgemm* args, int dtype, void* stream);
@@ -100,6 +103,9 @@ int sedt_igemm_splitk(int M, int N, int K, int dtype);
  * (the torch (Cout, Cin, KH, KW) parameter layout) as f32.  taps == 1: plain [R][Ci]. */
 int sedt_wgrad_reduce(const float* slab, int splitk, int R, int taps, int Ci, const float* rowscale,
                       float* out, void* stream);
+/* same, plus bias_out[r] = sum_z colsum_slab[z][r] (no rowscale) when colsum_slab is non-null */
+int sedt_wgrad_reduce_bias(const float* slab, int splitk, int R, int taps, int Ci, const float* rowscale, float* out,
+                           const float* colsum_slab, float* bias_out, void* stream);
 
 /* ------------------------------------------------------------------ elementwise / reductions */
 /* out[c] = sum_r in[r*ld + c]   (in: compute dtype or f32 if in_f32), out f32 */

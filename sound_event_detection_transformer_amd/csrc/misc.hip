@@ -31,9 +31,15 @@ static inline unsigned nblk(long n, int per = 256) { return (unsigned)((n + per 
 
 // ------------------------------------------------------------------ wgrad split-K reduce
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, int R, int taps, int Ci,
-                                    const float* __restrict__ rowscale, float* __restrict__ out) {
+                                    const float* __restrict__ rowscale, float* __restrict__ out,
+                                    const float* __restrict__ colsum_slab, float* __restrict__ bias_out) {
   long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long per = (long)R * taps * Ci;
+  if (colsum_slab && e < R) {
+    float b = 0.f;
+    for (int z = 0; z < splitk; ++z) b += colsum_slab[(long)z * R + e];
+    bias_out[e] = b;
+  }
   if (e >= per) return;
   int c = (int)(e % Ci);
   long rt = e / Ci;
@@ -393,12 +399,19 @@ extern "C" int sedt_version(void) { return 1; }
   else if ((dtype) == SEDT_BF16) { CALL_BF16; }                \
   else { set_error("unsupported dtype %d", (int)(dtype)); return 1; }
 
+extern "C" int sedt_wgrad_reduce_bias(const float* slab, int splitk, int R, int taps, int Ci, const float* rowscale,
+                                      float* out, const float* colsum_slab, float* bias_out, void* stream) {
+  SEDT_REQUIRE(slab && out && splitk >= 1, "wgrad_reduce: bad args");
+  SEDT_REQUIRE((colsum_slab == nullptr) == (bias_out == nullptr), "wgrad_reduce: colsum_slab and bias_out go together");
+  long n = (long)R * taps * Ci;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(n)), dim3(256), 0, S(stream), slab, splitk, R, taps, Ci, rowscale, out,
+                     colsum_slab, bias_out);
+  return check_launch("wgrad_reduce");
+}
+
 extern "C" int sedt_wgrad_reduce(const float* slab, int splitk, int R, int taps, int Ci, const float* rowscale,
                                  float* out, void* stream) {
-  SEDT_REQUIRE(slab && out && splitk >= 1, "wgrad_reduce: bad args");
-  long n = (long)R * taps * Ci;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(n)), dim3(256), 0, S(stream), slab, splitk, R, taps, Ci, rowscale, out);
-  return check_launch("wgrad_reduce");
+  return sedt_wgrad_reduce_bias(slab, splitk, R, taps, Ci, rowscale, out, nullptr, nullptr, stream);
 }
 
 extern "C" size_t sedt_colsum_scratch(int rows, int cols) { return (size_t)colsum_chunks(rows) * cols * sizeof(float); }

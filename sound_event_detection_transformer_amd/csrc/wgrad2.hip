@@ -112,6 +112,21 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const SedtIgemm p, const un
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+  // optional bias gradient: the n-tile-0 workgroups also sum their dY tile over the pixels (thread -> channel t&63,
+  // pixel quarter t>>6; 16 two-byte LDS reads per K tile)
+  const bool do_colsum = p.colsum_out != nullptr && n0 == 0;
+  float bsum = 0.f;
+  const int cs_ch = t & 63, cs_q = t >> 6;
+  auto colsum_tile = [&](int kb) {
+    const unsigned char* st = smem + ((kb - kb_begin) % STAGES) * STAGE_BYTES;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pixrow = cs_q * 16 + r;
+      const int phys = (cs_ch >> 3) ^ ((pixrow >> 1) & 7);
+      bsum += (float)*reinterpret_cast<const bf16_t*>(st + pixrow * ROWB + phys * 16 + (cs_ch & 7) * 2);
+    }
+  };
+
   // transposing fragment reads: lane -> source role (pixel s>>2, channel quad s&3) inside its 16-lane group
   const int grp = lane >> 4, s16 = lane & 15;
   const int src_pix = (grp >> 1) * 8 + (s16 >> 2);   // + 4*h + 16*ks
@@ -143,6 +158,15 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const SedtIgemm p, const un
     __builtin_amdgcn_s_barrier();
     if (it + STAGES - 1 < nkb) issue(kb_begin + it + STAGES - 1);
     compute(kb_begin + it);
+    if (do_colsum) colsum_tile(kb_begin + it);
+  }
+  if (do_colsum) {
+    __builtin_amdgcn_s_barrier();                      // ring no longer read: reuse it for the 4-way reduction
+    float* red = reinterpret_cast<float*>(smem);
+    red[t] = bsum;
+    __syncthreads();
+    if (t < 64 && m0 + t < p.M)
+      p.colsum_out[(long)(p.splitk > 1 ? blockIdx.y : 0) * p.M + m0 + t] = red[t] + red[t + 64] + red[t + 128] + red[t + 192];
   }
 
   float* out = p.splitk > 1 ? p.slab + (long)blockIdx.y * p.M * p.N : reinterpret_cast<float*>(p.C);

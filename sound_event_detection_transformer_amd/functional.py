@@ -60,8 +60,13 @@ class LinearFn(Function):
             gy = ops.relu_mask(_dt_of(gy), gy, y)
         g = _as(gy, dt)
         gx = ops.linear(dt, g, _wb(dt, weight)) if ctx.needs_input_grad[0] else None
-        gw = ops.linear_wgrad(dt, g, x) if ctx.needs_input_grad[1] else None
-        gb = ops.colsum(dt, g) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        gb = torch.empty((g.shape[1],), device=g.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if ctx.needs_input_grad[1]:
+            gw = ops.linear_wgrad(dt, g, x, bias_out=gb)
+        else:
+            gw = None
+            if gb is not None:
+                ops.colsum(dt, g, out=gb)
         return gx, gw, gb, None, None, None
 
 
@@ -122,8 +127,8 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True):
     p = s['p']
     sp = runtime.seed_ptr(g_out.device) if p > 0 else None
     g1 = ops.dropout_grad(dt, g_out, p, s['seeds'][1], sp) if p > 0 else g_out
-    d_wo = ops.linear_wgrad(dt, g1, s['ctxv'])
-    d_bo = ops.colsum(dt, g1)
+    d_bo = torch.empty((E,), device=g_out.device, dtype=torch.float32)
+    d_wo = ops.linear_wgrad(dt, g1, s['ctxv'], bias_out=d_bo)
     g_ctx = ops.linear(dt, g1, _wb(dt, w_out))
     td = g_out.dtype
     if s['same_qk']:
@@ -140,22 +145,18 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True):
     wb = _wb(dt, w_in)                                      # [E][3E]
     g_q = g_k = g_v = None
     if s['same_qk']:
-        ops.linear_wgrad(dt, dqk, s['q_in'], out=d_win[:2 * E])
-        ops.colsum(dt, dqk, out=d_bin[:2 * E])
+        ops.linear_wgrad(dt, dqk, s['q_in'], out=d_win[:2 * E], bias_out=d_bin[:2 * E])
         if need_q or need_k:
             g_q = ops.linear(dt, dqk, wb[:, :2 * E])        # grad wrt the shared q/k input
             g_k = None
     else:
-        ops.linear_wgrad(dt, dq, s['q_in'], out=d_win[:E])
-        ops.linear_wgrad(dt, dk, s['k_in'], out=d_win[E:2 * E])
-        ops.colsum(dt, dq, out=d_bin[:E])
-        ops.colsum(dt, dk, out=d_bin[E:2 * E])
+        ops.linear_wgrad(dt, dq, s['q_in'], out=d_win[:E], bias_out=d_bin[:E])
+        ops.linear_wgrad(dt, dk, s['k_in'], out=d_win[E:2 * E], bias_out=d_bin[E:2 * E])
         if need_q:
             g_q = ops.linear(dt, dq, wb[:, :E])
         if need_k:
             g_k = ops.linear(dt, dk, wb[:, E:2 * E])
-    ops.linear_wgrad(dt, dv, s['v_in'], out=d_win[2 * E:])
-    ops.colsum(dt, dv, out=d_bin[2 * E:])
+    ops.linear_wgrad(dt, dv, s['v_in'], out=d_win[2 * E:], bias_out=d_bin[2 * E:])
     if need_v:
         g_v = ops.linear(dt, dv, wb[:, 2 * E:])
     return g_q, g_k, g_v, d_win, d_bin, d_wo, d_bo
@@ -172,12 +173,12 @@ def _ffn_bwd(dt, s, g_out, w1, w2, res_for_gx=None):
     """returns g_x_in (+ res_for_gx), dW1, db1, dW2, db2"""
     p = s['p']
     g2 = ops.dropout_grad(dt, g_out, p, s['seeds'][1], runtime.seed_ptr(g_out.device)) if p > 0 else g_out
-    d_w2 = ops.linear_wgrad(dt, g2, s['h'])
-    d_b2 = ops.colsum(dt, g2)
+    d_b2 = torch.empty((g2.shape[1],), device=g2.device, dtype=torch.float32)
+    d_w2 = ops.linear_wgrad(dt, g2, s['h'], bias_out=d_b2)
     # d_hidden = (g2 @ W2) * [h > 0] / (1-p): h = drop(relu(.)) is positive exactly where kept and active
     gh = ops.linear(dt, g2, _wb(dt, w2), mask=s['h'], ldm=s['h'].stride(0), alpha=1.0 / (1.0 - p) if p > 0 else 1.0)
-    d_w1 = ops.linear_wgrad(dt, gh, s['x_in'])
-    d_b1 = ops.colsum(dt, gh)
+    d_b1 = torch.empty((gh.shape[1],), device=gh.device, dtype=torch.float32)
+    d_w1 = ops.linear_wgrad(dt, gh, s['x_in'], bias_out=d_b1)
     if res_for_gx is not None:
         gx = ops.linear(dt, gh, _wb(dt, w1), res=res_for_gx, ldr=res_for_gx.stride(0))
     else:

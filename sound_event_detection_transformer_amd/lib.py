@@ -31,6 +31,7 @@ class SedtIgemm(C.Structure):
         ('alpha', C.c_float), ('drop_p', C.c_float), ('seed', C.c_uint32), ('seed_ptr', C.c_void_p),
         ('splitk', C.c_int32), ('slab', C.c_void_p),
         ('tile_m', C.c_int32), ('tile_n', C.c_int32),
+        ('colsum_out', C.c_void_p),
     ]
 
 
@@ -43,6 +44,7 @@ SIGNATURES = {
     'sedt_igemm': (_i, [C.POINTER(SedtIgemm), _i, _vp]),
     'sedt_igemm_splitk': (_i, [_i, _i, _i, _i]),
     'sedt_wgrad_reduce': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'sedt_wgrad_reduce_bias': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'sedt_colsum': (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'sedt_colsum_scratch': (_sz, [_i, _i]),
     'sedt_dropout_grad': (_i, [_vp, _i64, _vp, _i64, _i, _i, _f, _u32, _vp, _i, _vp]),

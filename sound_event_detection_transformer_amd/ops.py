@@ -45,7 +45,7 @@ def _dev_check(*ts):
 
 def igemm(dtype, M, N, K, A, lda, B, ldb, Cout, ldc, *, trans=0, conv=None, transposed=0, out_f32=0, scale=None,
           bias=None, res=None, ldr=0, res_mod=0, mask=None, ldm=0, act=ACT_NONE, act_post_res=0, alpha=1.0, drop_p=0.0,
-          seed=0, seed_ptr=None, splitk=1, slab=None, tile=(0, 0)):
+          seed=0, seed_ptr=None, splitk=1, slab=None, tile=(0, 0), colsum_out=None):
     """raw implicit GEMM call; ``conv`` = (Hi, Wi, Ci, Ho, Wo, KH, KW, sh, sw, ph, pw, dh, dw) or None"""
     _dev_check(A, B, Cout)
     a = L.SedtIgemm()
@@ -72,6 +72,7 @@ def igemm(dtype, M, N, K, A, lda, B, ldb, Cout, ldc, *, trans=0, conv=None, tran
     a.splitk = splitk
     a.slab = slab.data_ptr() if slab is not None else None
     a.tile_m, a.tile_n = tile
+    a.colsum_out = colsum_out.data_ptr() if colsum_out is not None else None
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -119,26 +120,39 @@ def conv_dgrad(dtype, dy, B, g, wb, out=None, **ep):
     return out
 
 
-def wgrad(dtype, dy, x, B, g, rowscale=None, out=None):
-    """dW (Co, Ci, KH, KW) f32 = sum over pixels dy[pix][co] * gather(x)[pix][tap][ci] (* rowscale[co])"""
+def _fused_bias_ok(dtype, dy, x, g):
+    """envelope of the bf16 LDS-DMA wgrad kernel (csrc/wgrad2.hip): only there the bias gradient rides along"""
+    return (dtype == BF16 and L.load() is not None and g.Co % 8 == 0 and (g.taps * g.Ci) % 8 == 0 and dy.stride(0) % 8 == 0
+            and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and g.Ci % 8 == 0)
+
+
+def wgrad(dtype, dy, x, B, g, rowscale=None, out=None, bias_out=None):
+    """dW (Co, Ci, KH, KW) f32 = sum over pixels dy[pix][co] * gather(x)[pix][tap][ci] (* rowscale[co]).
+    bias_out (f32 [Co]): also receives sum over pixels of dy (fused into the wgrad kernel when it can, else a colsum)"""
     lib = L.load()
     Mo, No, Kp = g.Co, g.taps * g.Ci, B * g.Ho * g.Wo
     sk = lib.sedt_igemm_splitk(Mo, No, Kp, dtype)
     slab = torch.empty((sk, Mo, No), device=dy.device, dtype=torch.float32)
     conv = None if g.plain else _geom_tuple(g)
+    fused = bias_out is not None and _fused_bias_ok(dtype, dy, x, g)
+    cs = torch.empty((sk, Mo), device=dy.device, dtype=torch.float32) if fused else None
     igemm(dtype, Mo, No, Kp, dy, dy.stride(0), x, x.stride(0), slab, No, trans=1, conv=conv, out_f32=1, splitk=sk,
-          slab=slab)
+          slab=slab, colsum_out=cs)
     if out is None:
         out = torch.empty((g.Co, g.Ci, g.KH, g.KW), device=dy.device, dtype=torch.float32)
-    L.check(lib.sedt_wgrad_reduce(_p(slab), sk, Mo, g.taps, g.Ci, _p(rowscale), _p(out), L.stream_ptr()), 'wgrad_reduce')
+    L.check(lib.sedt_wgrad_reduce_bias(_p(slab), sk, Mo, g.taps, g.Ci, _p(rowscale), _p(out), _p(cs),
+                                       _p(bias_out) if fused else None, L.stream_ptr()), 'wgrad_reduce')
+    if bias_out is not None and not fused:
+        colsum(dtype, dy, out=bias_out)
     return out
 
 
-def linear_wgrad(dtype, dy, x, out=None):
-    """dW [N,K] f32 = dy[M,N]^T @ x[M,K]"""
+def linear_wgrad(dtype, dy, x, out=None, bias_out=None):
+    """dW [N,K] f32 = dy[M,N]^T @ x[M,K]; bias_out f32 [N] optionally receives the column sums of dy"""
     N, K = dy.shape[1], x.shape[1]
     g = ConvGeom(1, 1, K, N)
-    return wgrad(dtype, dy, x, dy.shape[0], g, out=out.view(N, K, 1, 1) if out is not None else None).view(N, K)
+    return wgrad(dtype, dy, x, dy.shape[0], g, out=out.view(N, K, 1, 1) if out is not None else None,
+                 bias_out=bias_out).view(N, K)
 
 
 def colsum(dtype, x, out=None):

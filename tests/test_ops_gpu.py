@@ -357,3 +357,14 @@ def test_fused_multi_tensor_adamw_matches_torch(ops):
         assert abs(o_my.grad_norm().item() - tn.item()) < 1e-4 * tn.item()
         for r, m in zip(ref, mine):
             np.testing.assert_allclose(m.detach().cpu().numpy(), r.detach().numpy(), rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+@pytest.mark.parametrize('M,N,K', [(8192, 256, 2048), (300, 768, 256), (704, 11, 256), (1000, 64, 64)])
+def test_linear_wgrad_with_fused_bias_grad(ops, dt, M, N, K):
+    """bias gradient = column sums of dY: rides along in the bf16 LDS-DMA wgrad kernel, separate colsum otherwise"""
+    x, gy = randn(M, K), randn(M, N)
+    db = torch.full((N,), float('nan')).cuda()
+    dw = ops.linear_wgrad(dt, dev(gy, dt), dev(x, dt), bias_out=db)
+    close(dw, rnd(gy, dt).t() @ rnd(x, dt), dt)
+    close(db, rnd(gy, dt).sum(0), dt, bf16_tol=2e-3)
