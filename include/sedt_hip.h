@@ -200,6 +200,30 @@ typedef struct SedtChunk {
   float wd;
   int32_t pad_;
 } SedtChunk;
+/* table-driven forms of sedt_bn_fold / sedt_pack_conv: `jobs` is a DEVICE array; one launch serves every FrozenBN layer /
+ * every weight tensor of the model.  Pack: one job per tensor (taps <= 9), e0 = index of the tensor's first workgroup
+ * (ascending; a tensor takes ceil(Cout/32)*ceil(Cin/32) workgroups, each an LDS-staged 32x32xtaps tile); nblocks = total */
+typedef struct SedtBnJob {
+  const float* w;
+  const float* b;
+  const float* rm;
+  const float* rv;
+  float* scale;
+  float* bias;
+  int32_t n;
+  int32_t pad_;
+} SedtBnJob;
+typedef struct SedtPackJob {
+  const float* w;
+  const float* bnscale; /* may be null */
+  void* wf;             /* [Cout][taps][Cin] or null */
+  void* wb;             /* [Cin][taps][Cout] (* bnscale) or null */
+  int64_t e0;
+  int32_t ne, Cout, Cin, taps;
+} SedtPackJob;
+int sedt_multi_bn_fold(const SedtBnJob* jobs, int njobs, void* stream);
+int sedt_multi_pack(const SedtPackJob* jobs, int njobs, int nblocks, int dtype, void* stream);
+
 /* chunk.p[i] = chunk.g[i] for every chunk: packs all gradient tensors into one flat f32 buffer (one launch) ahead of
  * the single RCCL all-reduce of the data-parallel step */
 int sedt_multi_gather(const SedtChunk* table, int nchunks, void* stream);

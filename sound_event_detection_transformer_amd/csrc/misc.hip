@@ -380,6 +380,66 @@ __global__ void multi_adamw_kernel(const SedtChunk* __restrict__ table, const fl
   }
 }
 
+// ---- all FrozenBN folds / all weight packs of a model in one launch each (device job tables)
+__global__ void multi_bn_fold_kernel(const SedtBnJob* __restrict__ jobs) {
+  const SedtBnJob j = jobs[blockIdx.x];
+  for (int i = threadIdx.x; i < j.n; i += blockDim.x) {
+    float sc = j.w[i] * rsqrtf(j.rv[i] + 1e-5f);
+    j.scale[i] = sc;
+    j.bias[i] = j.b[i] - j.rm[i] * sc;
+  }
+}
+
+// one workgroup = one 32(co) x 32(ci) x taps tile of one weight tensor, staged through LDS so that the f32 source rows
+// ([co][ci][tap], tap fastest) are read coalesced and both packed layouts are written in 64-byte runs
+template <typename T>
+__global__ __launch_bounds__(256) void multi_pack_kernel(const SedtPackJob* __restrict__ jobs, int njobs) {
+  __shared__ float tile[32 * (32 * 9 + 1)];
+  // find the tensor this block belongs to: jobs[].e0 holds the first block index of each tensor (ascending)
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].e0 <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SedtPackJob j = jobs[lo];
+  const int taps = j.taps;
+  const int tci = (j.Cin + 31) / 32;
+  const int tb = (int)((long)blockIdx.x - j.e0);
+  T* wf = reinterpret_cast<T*>(j.wf);
+  T* wb = reinterpret_cast<T*>(j.wb);
+  const int rowlen = 32 * taps, pitch = rowlen + 1;
+  // taps > 9 (the 7x7 stem conv): process in tap groups of 9 columns is not needed - such tensors use the plain path
+  const int co0 = (tb / tci) * 32, ci0 = (tb % tci) * 32;
+  const int nco = min(32, j.Cout - co0), nci = min(32, j.Cin - ci0);
+  const int valid = nci * taps;
+  for (int idx = threadIdx.x; idx < 32 * rowlen; idx += 256) {
+    const int co = idx / rowlen, off = idx - co * rowlen;
+    float v = 0.f;
+    if (co < nco && off < valid) v = j.w[((long)(co0 + co) * j.Cin + ci0) * taps + off];
+    tile[co * pitch + off] = v;
+  }
+  __syncthreads();
+  if (wf) {
+    for (int idx = threadIdx.x; idx < 32 * rowlen; idx += 256) {     // (co, tap, ci) with ci fastest
+      const int ci = idx & 31, r = idx >> 5;
+      const int tap = r % taps, co = r / taps;
+      if (co < nco && ci < nci)
+        wf[((long)(co0 + co) * taps + tap) * j.Cin + ci0 + ci] = (T)tile[co * pitch + ci * taps + tap];
+    }
+  }
+  if (wb) {
+    for (int idx = threadIdx.x; idx < 32 * rowlen; idx += 256) {     // (ci, tap, co) with co fastest
+      const int co = idx & 31, r = idx >> 5;
+      const int tap = r % taps, ci = r / taps;
+      if (co < nco && ci < nci) {
+        float v = tile[co * pitch + ci * taps + tap];
+        if (j.bnscale) v *= j.bnscale[co0 + co];
+        wb[((long)(ci0 + ci) * taps + tap) * j.Cout + co0 + co] = (T)v;
+      }
+    }
+  }
+}
+
 __global__ void multi_gather_kernel(const SedtChunk* __restrict__ table) {
   const SedtChunk c = table[blockIdx.x];
   float* dst = reinterpret_cast<float*>(c.p);
@@ -610,4 +670,17 @@ extern "C" int sedt_multi_gather(const SedtChunk* table, int nchunks, void* stre
   SEDT_REQUIRE(table && nchunks > 0, "multi_gather: bad arguments");
   hipLaunchKernelGGL(multi_gather_kernel, dim3(nchunks), dim3(256), 0, S(stream), table);
   return check_launch("multi_gather");
+}
+
+extern "C" int sedt_multi_bn_fold(const SedtBnJob* jobs, int njobs, void* stream) {
+  SEDT_REQUIRE(jobs && njobs > 0, "multi_bn_fold: bad arguments");
+  hipLaunchKernelGGL(multi_bn_fold_kernel, dim3(njobs), dim3(256), 0, S(stream), jobs);
+  return check_launch("multi_bn_fold");
+}
+
+extern "C" int sedt_multi_pack(const SedtPackJob* jobs, int njobs, int nblocks, int dtype, void* stream) {
+  SEDT_REQUIRE(jobs && njobs > 0 && nblocks > 0, "multi_pack: bad arguments");
+  BY_DTYPE(dtype, hipLaunchKernelGGL(multi_pack_kernel<float>, dim3(nblocks), dim3(256), 0, S(stream), jobs, njobs),
+           hipLaunchKernelGGL(multi_pack_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, S(stream), jobs, njobs));
+  return check_launch("multi_pack");
 }

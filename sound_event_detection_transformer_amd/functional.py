@@ -10,7 +10,7 @@ recomputes dropout masks from (seed, element index).
 import torch
 from torch.autograd import Function
 
-from . import ops, runtime
+from . import ops, packing, runtime
 from .lib import F32, BF16
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ConvGeom
 
@@ -36,6 +36,25 @@ def _wb(dt, w):
     return ops.pack_conv(dt, w, want_fwd=False)[1]
 
 
+def _prep_linear(dt, w, need_b):
+    """(forward operand [N][K], dgrad operand [K][N] or None): from the model's PackPlan when one is active (two launches
+    for ALL weights), else packed on the spot"""
+    hit = packing.lookup(w)
+    if hit is not None:
+        return hit[0], hit[1]
+    return _wf(dt, w), (_wb(dt, w) if need_b else None)
+
+
+def _prep_conv(dt, w, bn):
+    """(wf, wb, scale, bias) of one conv + FrozenBN"""
+    hit = packing.lookup(w)
+    if hit is not None and hit[2] is not None:
+        return hit
+    sc, bi = ops.bn_fold(bn[0], bn[1], bn[2], bn[3])
+    wf, wb = ops.pack_conv(dt, w, bnscale=sc)
+    return wf, wb, sc, bi
+
+
 # ======================================================================================= generic
 class LinearFn(Function):
     """y = act(x @ W^T + b); act in {none, relu, sigmoid}; optional f32 output (heads)."""
@@ -43,7 +62,8 @@ class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act, out_f32, dt):
         x = _as(x, dt)
-        y = ops.linear(dt, x, _wf(dt, weight), bias=bias, act=act, out_f32=out_f32)
+        wf, ctx.wb = _prep_linear(dt, weight, ctx.needs_input_grad[0])
+        y = ops.linear(dt, x, wf, bias=bias, act=act, out_f32=out_f32)
         ctx.dt, ctx.act, ctx.out_f32 = dt, act, out_f32
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
         ctx.has_bias = bias is not None
@@ -59,7 +79,7 @@ class LinearFn(Function):
         elif ctx.act == ACT_RELU:
             gy = ops.relu_mask(_dt_of(gy), gy, y)
         g = _as(gy, dt)
-        gx = ops.linear(dt, g, _wb(dt, weight)) if ctx.needs_input_grad[0] else None
+        gx = ops.linear(dt, g, ctx.wb) if ctx.needs_input_grad[0] else None
         gb = torch.empty((g.shape[1],), device=g.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         if ctx.needs_input_grad[1]:
             gw = ops.linear_wgrad(dt, g, x, bias_out=gb)
@@ -99,10 +119,11 @@ class AddFn(Function):
 
 
 # ======================================================================================= attention + FFN sub-blocks
-def _mha_fwd(dt, q_in, k_in, v_in, same_qk, w_in, b_in, w_out, b_out, res, B, H, Lq, Lk, kpm, amask, p, seeds):
+def _mha_fwd(dt, q_in, k_in, v_in, same_qk, w_in, b_in, w_out, b_out, res, B, H, Lq, Lk, kpm, amask, p, seeds, train=True):
     """res + drop(out_proj(attention(q_in Wq, k_in Wk, v_in Wv)));  returns (out, saved)."""
     E = w_in.shape[1]
-    wf = _wf(dt, w_in)
+    wf, wb_in = _prep_linear(dt, w_in, train)
+    wf_o, wb_o = _prep_linear(dt, w_out, train)
     if same_qk:                       # q_in is k_in: one GEMM for Q|K (N = 2E)
         qk = ops.linear(dt, q_in, wf[:2 * E], bias=b_in[:2 * E])
         q, k = qk[:, :E], qk[:, E:]
@@ -113,8 +134,8 @@ def _mha_fwd(dt, q_in, k_in, v_in, same_qk, w_in, b_in, w_out, b_out, res, B, H,
     v = ops.linear(dt, v_in, wf[2 * E:], bias=b_in[2 * E:])
     sp = runtime.seed_ptr(q_in.device) if p > 0 else None
     ctxv, lse = ops.attention_fwd(dt, q, k, v, B, H, Lq, Lk, kpm, amask, p, seeds[0], sp)
-    out = ops.linear(dt, ctxv, _wf(dt, w_out), bias=b_out, drop_p=p, seed=seeds[1], seed_ptr=sp, res=res, ldr=res.stride(0))
-    saved = dict(q_in=q_in, k_in=k_in, v_in=v_in, same_qk=same_qk, qk=qk, q=q, k=k, v=v, ctxv=ctxv, lse=lse,
+    out = ops.linear(dt, ctxv, wf_o, bias=b_out, drop_p=p, seed=seeds[1], seed_ptr=sp, res=res, ldr=res.stride(0))
+    saved = dict(wb_in=wb_in, wb_o=wb_o, q_in=q_in, k_in=k_in, v_in=v_in, same_qk=same_qk, qk=qk, q=q, k=k, v=v, ctxv=ctxv, lse=lse,
                  dims=(B, H, Lq, Lk), kpm=kpm, amask=amask, p=p, seeds=seeds)
     return out, saved
 
@@ -129,7 +150,7 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True):
     g1 = ops.dropout_grad(dt, g_out, p, s['seeds'][1], sp) if p > 0 else g_out
     d_bo = torch.empty((E,), device=g_out.device, dtype=torch.float32)
     d_wo = ops.linear_wgrad(dt, g1, s['ctxv'], bias_out=d_bo)
-    g_ctx = ops.linear(dt, g1, _wb(dt, w_out))
+    g_ctx = ops.linear(dt, g1, s['wb_o'])
     td = g_out.dtype
     if s['same_qk']:
         dqk = torch.empty((B * Lq, 2 * E), device=g_out.device, dtype=td)
@@ -142,7 +163,7 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True):
                       p, s['seeds'][0], sp)
     d_win = torch.empty((3 * E, E), device=g_out.device, dtype=torch.float32)
     d_bin = torch.empty((3 * E,), device=g_out.device, dtype=torch.float32)
-    wb = _wb(dt, w_in)                                      # [E][3E]
+    wb = s['wb_in']                                         # [E][3E]
     g_q = g_k = g_v = None
     if s['same_qk']:
         ops.linear_wgrad(dt, dqk, s['q_in'], out=d_win[:2 * E], bias_out=d_bin[:2 * E])
@@ -162,11 +183,13 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True):
     return g_q, g_k, g_v, d_win, d_bin, d_wo, d_bo
 
 
-def _ffn_fwd(dt, x_in, w1, b1, w2, b2, res, p, seeds):
+def _ffn_fwd(dt, x_in, w1, b1, w2, b2, res, p, seeds, train=True):
     sp = runtime.seed_ptr(x_in.device) if p > 0 else None
-    h = ops.linear(dt, x_in, _wf(dt, w1), bias=b1, act=ACT_RELU, drop_p=p, seed=seeds[0], seed_ptr=sp)
-    out = ops.linear(dt, h, _wf(dt, w2), bias=b2, drop_p=p, seed=seeds[1], seed_ptr=sp, res=res, ldr=res.stride(0))
-    return out, dict(x_in=x_in, h=h, p=p, seeds=seeds)
+    wf1, wb1 = _prep_linear(dt, w1, train)
+    wf2, wb2 = _prep_linear(dt, w2, train)
+    h = ops.linear(dt, x_in, wf1, bias=b1, act=ACT_RELU, drop_p=p, seed=seeds[0], seed_ptr=sp)
+    out = ops.linear(dt, h, wf2, bias=b2, drop_p=p, seed=seeds[1], seed_ptr=sp, res=res, ldr=res.stride(0))
+    return out, dict(x_in=x_in, h=h, p=p, seeds=seeds, wb1=wb1, wb2=wb2)
 
 
 def _ffn_bwd(dt, s, g_out, w1, w2, res_for_gx=None):
@@ -176,13 +199,13 @@ def _ffn_bwd(dt, s, g_out, w1, w2, res_for_gx=None):
     d_b2 = torch.empty((g2.shape[1],), device=g2.device, dtype=torch.float32)
     d_w2 = ops.linear_wgrad(dt, g2, s['h'], bias_out=d_b2)
     # d_hidden = (g2 @ W2) * [h > 0] / (1-p): h = drop(relu(.)) is positive exactly where kept and active
-    gh = ops.linear(dt, g2, _wb(dt, w2), mask=s['h'], ldm=s['h'].stride(0), alpha=1.0 / (1.0 - p) if p > 0 else 1.0)
+    gh = ops.linear(dt, g2, s['wb2'], mask=s['h'], ldm=s['h'].stride(0), alpha=1.0 / (1.0 - p) if p > 0 else 1.0)
     d_b1 = torch.empty((gh.shape[1],), device=gh.device, dtype=torch.float32)
     d_w1 = ops.linear_wgrad(dt, gh, s['x_in'], bias_out=d_b1)
     if res_for_gx is not None:
-        gx = ops.linear(dt, gh, _wb(dt, w1), res=res_for_gx, ldr=res_for_gx.stride(0))
+        gx = ops.linear(dt, gh, s['wb1'], res=res_for_gx, ldr=res_for_gx.stride(0))
     else:
-        gx = ops.linear(dt, gh, _wb(dt, w1))
+        gx = ops.linear(dt, gh, s['wb1'])
     return gx, d_w1, d_b1, d_w2, d_b2
 
 
@@ -202,17 +225,18 @@ class EncoderLayerFn(Function):
         x = _as(x, dt)
         pos = _as(pos, dt)
         sv = {}
+        tr = any(ctx.needs_input_grad)
         if cfg['pre_norm']:
             xn, xnp, m1, r1 = ops.layernorm_fwd(dt, x, g1, be1, add_t=pos)
-            x1, sv['mha'] = _mha_fwd(dt, xnp, xnp, xn, True, w_in, b_in, w_o, b_o, x, B, H, S, S, kpm, amask, p, seeds[0:2])
+            x1, sv['mha'] = _mha_fwd(dt, xnp, xnp, xn, True, w_in, b_in, w_o, b_o, x, B, H, S, S, kpm, amask, p, seeds[0:2], tr)
             x1n, _, m2, r2 = ops.layernorm_fwd(dt, x1, g2, be2)
-            x2, sv['ffn'] = _ffn_fwd(dt, x1n, w1, b1, w2, b2, x1, p, seeds[2:4])
+            x2, sv['ffn'] = _ffn_fwd(dt, x1n, w1, b1, w2, b2, x1, p, seeds[2:4], tr)
             sv.update(x=x, x1=x1, m1=m1, r1=r1, m2=m2, r2=r2)
         else:
             xp = ops.add(dt, x, pos)
-            t, sv['mha'] = _mha_fwd(dt, xp, xp, x, True, w_in, b_in, w_o, b_o, x, B, H, S, S, kpm, amask, p, seeds[0:2])
+            t, sv['mha'] = _mha_fwd(dt, xp, xp, x, True, w_in, b_in, w_o, b_o, x, B, H, S, S, kpm, amask, p, seeds[0:2], tr)
             x1, _, m1, r1 = ops.layernorm_fwd(dt, t, g1, be1)
-            t2, sv['ffn'] = _ffn_fwd(dt, x1, w1, b1, w2, b2, x1, p, seeds[2:4])
+            t2, sv['ffn'] = _ffn_fwd(dt, x1, w1, b1, w2, b2, x1, p, seeds[2:4], tr)
             x2, _, m2, r2 = ops.layernorm_fwd(dt, t2, g2, be2)
             sv.update(t=t, t2=t2, m1=m1, r1=r1, m2=m2, r2=r2)
         ctx.sv, ctx.cfg, ctx.P = sv, cfg, P
@@ -255,22 +279,23 @@ class DecoderLayerFn(Function):
         seeds = [runtime.next_seed() for _ in range(6)]
         tgt, mem, mem_pos, qpos = _as(tgt, dt), _as(mem, dt), _as(mem_pos, dt), _as(qpos, dt)
         sv = {}
+        tr = any(ctx.needs_input_grad)
         if cfg['pre_norm']:
             tn, tnp, m1, r1 = ops.layernorm_fwd(dt, tgt, g1, be1, add_t=qpos)
-            t1, sv['sa'] = _mha_fwd(dt, tnp, tnp, tn, True, sw_in, sb_in, sw_o, sb_o, tgt, B, H, Q, Q, None, tgt_mask, p, seeds[0:2])
+            t1, sv['sa'] = _mha_fwd(dt, tnp, tnp, tn, True, sw_in, sb_in, sw_o, sb_o, tgt, B, H, Q, Q, None, tgt_mask, p, seeds[0:2], tr)
             t1n, t1np, m2, r2 = ops.layernorm_fwd(dt, t1, g2, be2, add_t=qpos)
-            t2, sv['ca'] = _mha_fwd(dt, t1np, mem_pos, mem, False, cw_in, cb_in, cw_o, cb_o, t1, B, H, Q, S, kpm, None, p, seeds[2:4])
+            t2, sv['ca'] = _mha_fwd(dt, t1np, mem_pos, mem, False, cw_in, cb_in, cw_o, cb_o, t1, B, H, Q, S, kpm, None, p, seeds[2:4], tr)
             t2n, _, m3, r3 = ops.layernorm_fwd(dt, t2, g3, be3)
-            t3, sv['ffn'] = _ffn_fwd(dt, t2n, w1, b1, w2, b2, t2, p, seeds[4:6])
+            t3, sv['ffn'] = _ffn_fwd(dt, t2n, w1, b1, w2, b2, t2, p, seeds[4:6], tr)
             sv.update(tgt=tgt, t1=t1, t2=t2, m1=m1, r1=r1, m2=m2, r2=r2, m3=m3, r3=r3)
         else:
             tp = ops.add(dt, tgt, qpos)
-            a, sv['sa'] = _mha_fwd(dt, tp, tp, tgt, True, sw_in, sb_in, sw_o, sb_o, tgt, B, H, Q, Q, None, tgt_mask, p, seeds[0:2])
+            a, sv['sa'] = _mha_fwd(dt, tp, tp, tgt, True, sw_in, sb_in, sw_o, sb_o, tgt, B, H, Q, Q, None, tgt_mask, p, seeds[0:2], tr)
             t1, _, m1, r1 = ops.layernorm_fwd(dt, a, g1, be1)
             t1p = ops.add(dt, t1, qpos)
-            c, sv['ca'] = _mha_fwd(dt, t1p, mem_pos, mem, False, cw_in, cb_in, cw_o, cb_o, t1, B, H, Q, S, kpm, None, p, seeds[2:4])
+            c, sv['ca'] = _mha_fwd(dt, t1p, mem_pos, mem, False, cw_in, cb_in, cw_o, cb_o, t1, B, H, Q, S, kpm, None, p, seeds[2:4], tr)
             t2, _, m2, r2 = ops.layernorm_fwd(dt, c, g2, be2)
-            f, sv['ffn'] = _ffn_fwd(dt, t2, w1, b1, w2, b2, t2, p, seeds[4:6])
+            f, sv['ffn'] = _ffn_fwd(dt, t2, w1, b1, w2, b2, t2, p, seeds[4:6], tr)
             t3, _, m3, r3 = ops.layernorm_fwd(dt, f, g3, be3)
             sv.update(a=a, c=c, f=f, m1=m1, r1=r1, m2=m2, r2=r2, m3=m3, r3=r3)
         ctx.sv, ctx.cfg, ctx.P = sv, cfg, P
@@ -328,7 +353,7 @@ class StemFn(Function):
         x = x.contiguous().float()
         wcat = ops.stem_prep(dt, w0, b0, w1)
         col, Ho, Wo = ops.stem_im2col(dt, x, B, H, W)
-        sc, bi = ops.bn_fold(bnw, bnb, bnrm, bnrv)
+        _, _, sc, bi = _prep_conv(dt, w1, (bnw, bnb, bnrm, bnrv))
         s1 = ops.linear(dt, col, wcat, scale=sc, bias=bi, act=ACT_RELU)
         pool, idx, Hp, Wp = ops.maxpool_fwd(dt, s1, B, Ho, Wo, 64)
         ctx.dt, ctx.dims = dt, (B, Ho, Wo)
@@ -373,22 +398,18 @@ class StageFn(Function):
             t = T[i:i + n]
             i += n
             cin, pl = blk.cin, blk.planes
-            s1, b1 = _bn(t[1:5])
-            s2, b2 = _bn(t[6:10])
-            s3, b3 = _bn(t[11:15])
+            w1f, w1b, s1, b1 = _prep_conv(dt, t[0], t[1:5])
+            w2f, w2b, s2, b2 = _prep_conv(dt, t[5], t[6:10])
+            w3f, w3b, s3, b3 = _prep_conv(dt, t[10], t[11:15])
             g1 = ConvGeom(H, W, cin, pl, 1)
             g2 = ConvGeom(H, W, pl, pl, 3, blk.stride, blk.dil, blk.dil)
             g3 = ConvGeom(g2.Ho, g2.Wo, pl, 4 * pl, 1)
-            w1f, w1b = ops.pack_conv(dt, t[0], bnscale=s1)
-            w2f, w2b = ops.pack_conv(dt, t[5], bnscale=s2)
-            w3f, w3b = ops.pack_conv(dt, t[10], bnscale=s3)
             a = ops.conv_fwd(dt, x, B, g1, w1f, scale=s1, bias=b1, act=ACT_RELU)
             b = ops.conv_fwd(dt, a, B, g2, w2f, scale=s2, bias=b2, act=ACT_RELU)
             rec = dict(blk=blk, x=x, a=a, b=b, g1=g1, g2=g2, g3=g3, s=(s1, s2, s3), wb=(w1b, w2b, w3b), H=H, W=W)
             if blk.ds:
-                sd, bd = _bn(t[16:20])
+                wdf, wdb, sd, bd = _prep_conv(dt, t[15], t[16:20])
                 gd = ConvGeom(H, W, cin, 4 * pl, 1, blk.stride)
-                wdf, wdb = ops.pack_conv(dt, t[15], bnscale=sd)
                 idn = ops.conv_fwd(dt, x, B, gd, wdf, scale=sd, bias=bd)
                 rec.update(gd=gd, sd=sd, wdb=wdb)
             else:

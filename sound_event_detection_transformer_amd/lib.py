@@ -71,6 +71,8 @@ SIGNATURES = {
     'sedt_avgpool': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'sedt_sumsq': (_i, [_vp, _i64, _vp, _vp, _sz, _i, _vp]),
     'sedt_sumsq_scratch': (_sz, [_i64]),
+    'sedt_multi_bn_fold': (_i, [_vp, _i, _vp]),
+    'sedt_multi_pack': (_i, [_vp, _i, _i, _i, _vp]),
     'sedt_multi_gather': (_i, [_vp, _i, _vp]),
     'sedt_multi_sumsq': (_i, [_vp, _i, _vp, _vp, _vp]),
     'sedt_multi_adamw': (_i, [_vp, _i, _vp, _f, _f, _f, _f, _vp, _vp]),

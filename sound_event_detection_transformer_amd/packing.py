@@ -1,0 +1,138 @@
+"""All per-forward weight preparation of a model in two launches.
+
+Every forward needs, for each weight tensor, its compute-dtype copy in the forward layout ([Cout][taps][Cin]) and - when
+training - the dgrad layout ([Cin][taps][Cout], FrozenBN scale folded in), plus the folded scale/bias of every
+FrozenBatchNorm.  Issued per tensor that is ~180 tiny launches per step; a ``PackPlan`` keeps persistent destination
+buffers and device job tables and does it in ONE bn-fold launch + ONE pack launch.  Parameter pointers are re-read on
+every run (EMA swaps / load_state_dict keep working); the tables are re-uploaded only when a pointer changed."""
+import numpy as np
+import torch
+
+from . import lib as L
+from .lib import F32, BF16, TORCH_DTYPE
+
+_BN = np.dtype([('w', np.uint64), ('b', np.uint64), ('rm', np.uint64), ('rv', np.uint64), ('scale', np.uint64),
+                ('bias', np.uint64), ('n', np.int32), ('pad', np.int32)])
+_PK = np.dtype([('w', np.uint64), ('bnscale', np.uint64), ('wf', np.uint64), ('wb', np.uint64), ('e0', np.int64),
+                ('ne', np.int32), ('Cout', np.int32), ('Cin', np.int32), ('taps', np.int32)])
+_CHUNK = 32768
+
+_active = []          # stack of plans whose prepared tensors are valid right now (inside a model forward)
+
+
+def lookup(weight):
+    """(wf, wb, scale, bias) prepared for this parameter (or a view of it) by the active plan, or None"""
+    for plan in reversed(_active):
+        hit = plan.table.get(weight.data_ptr())
+        if hit is not None:
+            return hit
+    return None
+
+
+class PackPlan(object):
+    def __init__(self, dt, device, convs, linears, bn_only=()):
+        """convs: list of (weight Parameter, (bn_w, bn_b, bn_rm, bn_rv) or None); linears: list of weight Parameters (2-D).
+        A linear in f32 mode uses the parameter itself as the forward operand."""
+        self.dt, self.device = dt, device
+        td = TORCH_DTYPE[dt]
+        es = 4 if dt == F32 else 2
+        bns = [(w, bn) for w, bn in list(convs) + list(bn_only) if bn is not None]
+        nbn = sum(bn[0].numel() for _, bn in bns)
+        self.scale_buf = torch.empty(max(nbn, 1), device=device, dtype=torch.float32)
+        self.bias_buf = torch.empty(max(nbn, 1), device=device, dtype=torch.float32)
+        total = 0
+        items = []
+        for w, bn in convs:
+            items.append((w, bn, True, True))
+            total += 2 * w.numel()
+        for w in linears:
+            need_f = dt != F32
+            items.append((w, None, need_f, True))
+            total += (2 if need_f else 1) * w.numel()
+        for w, bn in bn_only:
+            items.append((w, bn, False, False))
+        self.wbuf = torch.empty(total + 64, device=device, dtype=td)
+        self.table = {}
+        self._nblocks = 0
+        self._entries = []
+        self._params, self._bn_tensors = [], []
+        bn_rows, pk_rows = [], []
+        off, boff = 0, 0
+        base = self.wbuf.data_ptr()
+        for w, bn, need_f, need_b in items:
+            Co, Ci = w.shape[0], w.shape[1]
+            taps = w.numel() // (Co * Ci)
+            n = w.numel()
+            wf = wb = None
+            wf_ptr = wb_ptr = 0
+            if need_f:
+                off = (off + 7) // 8 * 8
+                wf = self.wbuf[off:off + n].view(Co, taps * Ci)
+                wf_ptr = base + off * es
+                off += n
+            if need_b:
+                off = (off + 7) // 8 * 8
+                wb = self.wbuf[off:off + n].view(Ci, taps * Co)
+                wb_ptr = base + off * es
+                off += n
+            sc = bi = None
+            sc_ptr = 0
+            if bn is not None:
+                c = bn[0].numel()
+                sc, bi = self.scale_buf[boff:boff + c], self.bias_buf[boff:boff + c]
+                sc_ptr = sc.data_ptr()
+                bn_rows.append((len(self._bn_tensors), sc_ptr, bi.data_ptr(), c))
+                self._bn_tensors.append(bn)
+                boff += c
+            self._entries.append((w, wf if need_f else None, wb, sc, bi))
+            if not need_f and not need_b:
+                continue
+            if taps > 9:
+                raise ValueError('PackPlan handles kernels up to 3x3 (the 7x7 stem conv is folded separately)')
+            pk_rows.append((len(self._params), sc_ptr, wf_ptr, wb_ptr, self._nblocks, 0, Co, Ci, taps))
+            self._nblocks += ((Co + 31) // 32) * ((Ci + 31) // 32)
+            self._params.append(w)
+        self._bn = np.zeros(len(bn_rows), _BN)
+        for r, (bi_, scp, bip, c) in enumerate(bn_rows):
+            self._bn[r]['scale'], self._bn[r]['bias'], self._bn[r]['n'] = scp, bip, c
+        self._bn_owner = np.asarray([r[0] for r in bn_rows], np.int64)
+        self._pk = np.zeros(len(pk_rows), _PK)
+        for r, (pi, scp, wfp, wbp, e0, ne, Co, Ci, taps) in enumerate(pk_rows):
+            row = self._pk[r]
+            row['bnscale'], row['wf'], row['wb'], row['e0'], row['ne'] = scp, wfp, wbp, e0, ne
+            row['Cout'], row['Cin'], row['taps'] = Co, Ci, taps
+        self._pk_owner = np.asarray([r[0] for r in pk_rows], np.int64)
+        self._dev_bn = torch.empty(max(self._bn.nbytes, 8), dtype=torch.uint8, device=device)
+        self._dev_pk = torch.empty(max(self._pk.nbytes, 8), dtype=torch.uint8, device=device)
+        self._host_bn = torch.empty(max(self._bn.nbytes, 8), dtype=torch.uint8).pin_memory()
+        self._host_pk = torch.empty(max(self._pk.nbytes, 8), dtype=torch.uint8).pin_memory()
+        self._last = None
+
+    def run(self):
+        wp = np.fromiter((w.data_ptr() for w in self._params), np.uint64, len(self._params))
+        bp = np.asarray([[t.data_ptr() for t in bn] for bn in self._bn_tensors], np.uint64).reshape(-1, 4)
+        key = (wp.tobytes(), bp.tobytes())
+        if key != self._last:
+            self._pk['w'] = wp[self._pk_owner]
+            self._host_pk.numpy()[:self._pk.nbytes] = self._pk.view(np.uint8)
+            self._dev_pk.copy_(self._host_pk, non_blocking=True)
+            if len(self._bn):
+                o = self._bn_owner
+                self._bn['w'], self._bn['b'], self._bn['rm'], self._bn['rv'] = bp[o, 0], bp[o, 1], bp[o, 2], bp[o, 3]
+                self._host_bn.numpy()[:self._bn.nbytes] = self._bn.view(np.uint8)
+                self._dev_bn.copy_(self._host_bn, non_blocking=True)
+            self._last = key
+            self.table = {w.data_ptr(): (wf if wf is not None else w, wb, sc, bi) for w, wf, wb, sc, bi in self._entries}
+        lib = L.load()
+        if len(self._bn):
+            L.check(lib.sedt_multi_bn_fold(L.p(self._dev_bn), len(self._bn), L.stream_ptr()), 'multi_bn_fold')
+        L.check(lib.sedt_multi_pack(L.p(self._dev_pk), len(self._pk), self._nblocks, self.dt, L.stream_ptr()), 'multi_pack')
+
+    def __enter__(self):
+        self.run()
+        _active.append(self)
+        return self
+
+    def __exit__(self, *a):
+        _active.remove(self)
+        return False

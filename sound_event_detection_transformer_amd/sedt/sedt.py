@@ -7,7 +7,7 @@ import torch
 from torch import nn
 
 from .. import functional as Fn
-from .. import runtime
+from .. import packing, runtime
 from ..ops import ACT_NONE, ACT_RELU, ACT_SIGMOID
 from ..utilities.utils import NestedTensor, nested_tensor_from_tensor_list
 
@@ -71,9 +71,42 @@ class SEDT(nn.Module):
         else:
             self.query_embed = nn.Embedding(num_queries, hidden_dim)
 
+    def pack_plan(self):
+        """the model's PackPlan (two launches prepare every weight / FrozenBN of the forward), cached per dtype/device"""
+        dt, dev = runtime.compute_dtype(), self.query_embed.weight.device
+        key = (dt, str(dev))
+        plans = self.__dict__.setdefault('_plans', {})
+        if key not in plans:
+            body = self.backbone[0].body
+            convs = []
+            bn_only = [(body.conv1.weight, body.bn1.tensors())]        # 7x7 stem: only its FrozenBN fold is needed
+            for layer in (body.layer1, body.layer2, body.layer3, body.layer4):
+                for b in layer:
+                    convs += [(b.conv1.weight, b.bn1.tensors()), (b.conv2.weight, b.bn2.tensors()), (b.conv3.weight, b.bn3.tensors())]
+                    if b.downsample is not None:
+                        convs.append((b.downsample[0].weight, b.downsample[1].tensors()))
+            lin = [self.input_proj.weight.view(self.input_proj.out_channels, self.input_proj.in_channels)]
+            for l in self.transformer.encoder.layers:
+                lin += [l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.linear1.weight, l.linear2.weight]
+            for l in self.transformer.decoder.layers:
+                lin += [l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.multihead_attn.in_proj_weight,
+                        l.multihead_attn.out_proj.weight, l.linear1.weight, l.linear2.weight]
+            lin += [self.class_embed.weight] + [m.weight for m in self.bbox_embed.layers]
+            for name in ('weak_class_embed', 'patch2query'):
+                if hasattr(self, name):
+                    lin.append(getattr(self, name).weight)
+            if hasattr(self, 'feature_align'):
+                lin += [m.weight for m in self.feature_align.layers]
+            plans[key] = packing.PackPlan(dt, dev, convs, lin, bn_only)
+        return plans[key]
+
     def forward(self, samples):
         """samples: NestedTensor | list of (1,T,F) tensors | (B,1,T,F) tensor.  Returns pred_logits (B,Q,C+1),
         pred_boxes (B,Q,2) = (centre, length) in [0,1], at (B,C) when dec_at, aux_outputs per decoder layer."""
+        with self.pack_plan():
+            return self._forward(samples)
+
+    def _forward(self, samples):
         if isinstance(samples, (list, torch.Tensor)):
             samples = nested_tensor_from_tensor_list(samples)
         features, pos = self.backbone(samples)

@@ -30,6 +30,10 @@ class SPSEDT(SEDT):
     def forward(self, samples, patches: torch.Tensor, query_mask=None):
         """samples = (tensors (B,1,T,F), mask (B,T,F)); patches (B,P,1,h,w).  ``query_mask`` (Q,B,1) optionally injects
         the Bernoulli(1-mask_ratio) query-patch mask that spsedt.py:65 draws with torch.rand."""
+        with self.pack_plan():
+            return self._forward_sp(samples, patches, query_mask)
+
+    def _forward_sp(self, samples, patches, query_mask=None):
         dev = self.query_embed.weight.device
         bnp = patches.shape[1]
         samples = NestedTensor(samples[0].to(dev), samples[1].to(dev))
