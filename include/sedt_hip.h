@@ -107,6 +107,20 @@ int sedt_wgrad_reduce(const float* slab, int splitk, int R, int taps, int Ci, co
 int sedt_wgrad_reduce_bias(const float* slab, int splitk, int R, int taps, int Ci, const float* rowscale, float* out,
                            const float* colsum_slab, float* bias_out, void* stream);
 
+/* up to SEDT_MAX_REDUCE_JOBS split-K reductions in ONE launch (jobs are copied into the kernel arguments, so a captured
+ * graph holds them by value).  `jobs` is a HOST array; fields as the arguments of sedt_wgrad_reduce_bias. */
+#define SEDT_MAX_REDUCE_JOBS 40
+typedef struct SedtReduceJob {
+  const float* slab;
+  const float* rowscale;
+  float* out;
+  const float* colsum_slab;
+  float* bias_out;
+  int32_t splitk, R, taps, Ci;
+  int32_t blk0, pad_;     /* blk0 is filled by the library */
+} SedtReduceJob;
+int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, void* stream);
+
 /* ------------------------------------------------------------------ elementwise / reductions */
 /* out[c] = sum_r in[r*ld + c]   (in: compute dtype or f32 if in_f32), out f32 */
 int sedt_colsum(const void* in, int64_t ld, int rows, int cols, int in_f32, int dtype, float* out,

@@ -491,12 +491,18 @@ extern "C" int sedt_igemm(const SedtIgemm* args, int dtype, void* stream) {
 }
 
 extern "C" int sedt_igemm_splitk(int M, int N, int K, int dtype) {
-  // wgrad outputs are small (Cout x taps*Cin) while K (pixels) is long: split K until ~1536 workgroups of 64x64
-  // (measured: tools/tune_igemm.py), keeping at least 4 K tiles per slice
+  // wgrad outputs are small (Cout x taps*Cin) while K (pixels) is long: split K until ~TARGET workgroups of 64x64,
+  // keeping at least 4 K tiles per slice.  Every split costs a 64x64 f32 partial tile written and re-read, so the target
+  // balances occupancy against slab traffic (measured on the full step: SEDT_SPLITK_TARGET sweep)
+  static int target = -1;
+  if (target < 0) {
+    const char* e = getenv("SEDT_SPLITK_TARGET");
+    target = e ? atoi(e) : 768;
+  }
   int bk = dtype == SEDT_BF16 ? 64 : 32;
   long tiles = (long)((M + 63) / 64) * ((N + 63) / 64);
   int nkb = (K + bk - 1) / bk;
-  int s = (int)((1536 + tiles - 1) / tiles);
+  int s = (int)((target + tiles - 1) / tiles);
   int maxs = nkb / 4 > 1 ? nkb / 4 : 1;
   if (s > maxs) s = maxs;
   if (s > 128) s = 128;

@@ -277,7 +277,11 @@ int igemm2_try(const SedtIgemm& p, hipStream_t st) {
   int bm = p.tile_m, bn = p.tile_n;
   // measured (tools/tune_igemm.py on MI355X): occupancy beats prefetch depth at every SEDT shape - the 64x64 tile with a
   // 2-stage ring (32 KB LDS, 5 workgroups per CU) wins or ties; SEDT_IGEMM_STAGES / tile_m override for experiments
-  if (bm == 0 || bn == 0) { bm = 64; bn = 64; }
+  if (bm == 0 || bn == 0) {
+    bm = 64; bn = 64;
+    // gathered (3x3) convs amortise the A gather over a wider N tile when enough tiles remain to fill the chip
+    if (p.conv && p.KH * p.KW > 1 && (p.N % 128) == 0 && (long)((p.M + 63) / 64) * (p.N / 128) >= 500) bn = 128;
+  }
   static int stages = -1;
   if (stages < 0) {
     const char* e = getenv("SEDT_IGEMM_STAGES");
@@ -286,6 +290,13 @@ int igemm2_try(const SedtIgemm& p, hipStream_t st) {
   if (bm == 128 && bn == 128) {
     if (stages == 3) return launch2<128, 128, 3>(p, (unsigned)a_bytes, (unsigned)b_bytes, st);
     return launch2<128, 128, 2>(p, (unsigned)a_bytes, (unsigned)b_bytes, st);
+  }
+  if (bm == 128 && bn == 64) {
+    if (stages == 3) return launch2<128, 64, 3>(p, (unsigned)a_bytes, (unsigned)b_bytes, st);
+    return launch2<128, 64, 2>(p, (unsigned)a_bytes, (unsigned)b_bytes, st);
+  }
+  if (bm == 64 && bn == 128) {
+    return launch2<64, 128, 2>(p, (unsigned)a_bytes, (unsigned)b_bytes, st);
   }
   if (bm == 64 && bn == 64) {
     if (stages == 4) return launch2<64, 64, 4>(p, (unsigned)a_bytes, (unsigned)b_bytes, st);

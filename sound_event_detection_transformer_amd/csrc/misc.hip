@@ -51,6 +51,36 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, 
   out[((long)r * Ci + c) * taps + tap] = s;
 }
 
+struct ReduceJobs {
+  int n;
+  SedtReduceJob j[SEDT_MAX_REDUCE_JOBS];
+};
+
+__global__ void multi_wgrad_reduce_kernel(const ReduceJobs jobs) {
+  int lo = 0, hi = jobs.n - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (jobs.j[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SedtReduceJob& J = jobs.j[lo];
+  const long e = (long)(blockIdx.x - J.blk0) * blockDim.x + threadIdx.x;
+  const long per = (long)J.R * J.taps * J.Ci;
+  if (J.colsum_slab && e < J.R) {
+    float b = 0.f;
+    for (int z = 0; z < J.splitk; ++z) b += J.colsum_slab[(long)z * J.R + e];
+    J.bias_out[e] = b;
+  }
+  if (e >= per) return;
+  const int c = (int)(e % J.Ci);
+  const long rt = e / J.Ci;
+  const int tap = (int)(rt % J.taps);
+  const int r = (int)(rt / J.taps);
+  float s = 0.f;
+  for (int z = 0; z < J.splitk; ++z) s += J.slab[(long)z * per + e];
+  if (J.rowscale) s *= J.rowscale[r];
+  J.out[((long)r * J.Ci + c) * J.taps + tap] = s;
+}
+
 // ------------------------------------------------------------------ column sums
 template <typename TI>
 __global__ void colsum_kernel(const TI* __restrict__ in, long ld, int rows, int cols, int rows_per_chunk,
@@ -683,4 +713,21 @@ extern "C" int sedt_multi_pack(const SedtPackJob* jobs, int njobs, int nblocks, 
   BY_DTYPE(dtype, hipLaunchKernelGGL(multi_pack_kernel<float>, dim3(nblocks), dim3(256), 0, S(stream), jobs, njobs),
            hipLaunchKernelGGL(multi_pack_kernel<bf16_t>, dim3(nblocks), dim3(256), 0, S(stream), jobs, njobs));
   return check_launch("multi_pack");
+}
+
+extern "C" int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, void* stream) {
+  SEDT_REQUIRE(jobs && njobs > 0 && njobs <= SEDT_MAX_REDUCE_JOBS, "multi_wgrad_reduce: 1..%d jobs", SEDT_MAX_REDUCE_JOBS);
+  ReduceJobs a;
+  a.n = njobs;
+  int blk = 0;
+  for (int i = 0; i < njobs; ++i) {
+    a.j[i] = jobs[i];
+    SEDT_REQUIRE(jobs[i].slab && jobs[i].out && jobs[i].splitk >= 1, "multi_wgrad_reduce: bad job %d", i);
+    SEDT_REQUIRE((jobs[i].colsum_slab == nullptr) == (jobs[i].bias_out == nullptr), "multi_wgrad_reduce: job %d colsum/bias", i);
+    a.j[i].blk0 = blk;
+    long n = (long)jobs[i].R * jobs[i].taps * jobs[i].Ci;
+    blk += (int)((n + 255) / 256);
+  }
+  hipLaunchKernelGGL(multi_wgrad_reduce_kernel, dim3(blk), dim3(256), 0, S(stream), a);
+  return check_launch("multi_wgrad_reduce");
 }

@@ -140,7 +140,7 @@ def _mha_fwd(dt, q_in, k_in, v_in, same_qk, w_in, b_in, w_out, b_out, res, B, H,
     return out, saved
 
 
-def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True):
+def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, batch=None):
     """g_out = grad wrt the block output (the residual branch is the caller's business).
     returns g_q_in, g_k_in, g_v_in, d_in_proj_weight, d_in_proj_bias, d_out_w, d_out_b"""
     B, H, Lq, Lk = s['dims']
@@ -149,7 +149,7 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True):
     sp = runtime.seed_ptr(g_out.device) if p > 0 else None
     g1 = ops.dropout_grad(dt, g_out, p, s['seeds'][1], sp) if p > 0 else g_out
     d_bo = torch.empty((E,), device=g_out.device, dtype=torch.float32)
-    d_wo = ops.linear_wgrad(dt, g1, s['ctxv'], bias_out=d_bo)
+    d_wo = ops.linear_wgrad(dt, g1, s['ctxv'], bias_out=d_bo, batch=batch)
     g_ctx = ops.linear(dt, g1, s['wb_o'])
     td = g_out.dtype
     if s['same_qk']:
@@ -166,18 +166,18 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True):
     wb = s['wb_in']                                         # [E][3E]
     g_q = g_k = g_v = None
     if s['same_qk']:
-        ops.linear_wgrad(dt, dqk, s['q_in'], out=d_win[:2 * E], bias_out=d_bin[:2 * E])
+        ops.linear_wgrad(dt, dqk, s['q_in'], out=d_win[:2 * E], bias_out=d_bin[:2 * E], batch=batch)
         if need_q or need_k:
             g_q = ops.linear(dt, dqk, wb[:, :2 * E])        # grad wrt the shared q/k input
             g_k = None
     else:
-        ops.linear_wgrad(dt, dq, s['q_in'], out=d_win[:E], bias_out=d_bin[:E])
-        ops.linear_wgrad(dt, dk, s['k_in'], out=d_win[E:2 * E], bias_out=d_bin[E:2 * E])
+        ops.linear_wgrad(dt, dq, s['q_in'], out=d_win[:E], bias_out=d_bin[:E], batch=batch)
+        ops.linear_wgrad(dt, dk, s['k_in'], out=d_win[E:2 * E], bias_out=d_bin[E:2 * E], batch=batch)
         if need_q:
             g_q = ops.linear(dt, dq, wb[:, :E])
         if need_k:
             g_k = ops.linear(dt, dk, wb[:, E:2 * E])
-    ops.linear_wgrad(dt, dv, s['v_in'], out=d_win[2 * E:], bias_out=d_bin[2 * E:])
+    ops.linear_wgrad(dt, dv, s['v_in'], out=d_win[2 * E:], bias_out=d_bin[2 * E:], batch=batch)
     if need_v:
         g_v = ops.linear(dt, dv, wb[:, 2 * E:])
     return g_q, g_k, g_v, d_win, d_bin, d_wo, d_bo
@@ -192,16 +192,16 @@ def _ffn_fwd(dt, x_in, w1, b1, w2, b2, res, p, seeds, train=True):
     return out, dict(x_in=x_in, h=h, p=p, seeds=seeds, wb1=wb1, wb2=wb2)
 
 
-def _ffn_bwd(dt, s, g_out, w1, w2, res_for_gx=None):
+def _ffn_bwd(dt, s, g_out, w1, w2, res_for_gx=None, batch=None):
     """returns g_x_in (+ res_for_gx), dW1, db1, dW2, db2"""
     p = s['p']
     g2 = ops.dropout_grad(dt, g_out, p, s['seeds'][1], runtime.seed_ptr(g_out.device)) if p > 0 else g_out
     d_b2 = torch.empty((g2.shape[1],), device=g2.device, dtype=torch.float32)
-    d_w2 = ops.linear_wgrad(dt, g2, s['h'], bias_out=d_b2)
+    d_w2 = ops.linear_wgrad(dt, g2, s['h'], bias_out=d_b2, batch=batch)
     # d_hidden = (g2 @ W2) * [h > 0] / (1-p): h = drop(relu(.)) is positive exactly where kept and active
     gh = ops.linear(dt, g2, s['wb2'], mask=s['h'], ldm=s['h'].stride(0), alpha=1.0 / (1.0 - p) if p > 0 else 1.0)
     d_b1 = torch.empty((gh.shape[1],), device=gh.device, dtype=torch.float32)
-    d_w1 = ops.linear_wgrad(dt, gh, s['x_in'], bias_out=d_b1)
+    d_w1 = ops.linear_wgrad(dt, gh, s['x_in'], bias_out=d_b1, batch=batch)
     if res_for_gx is not None:
         gx = ops.linear(dt, gh, s['wb1'], res=res_for_gx, ldr=res_for_gx.stride(0))
     else:
@@ -248,18 +248,20 @@ class EncoderLayerFn(Function):
         dt = cfg['dt']
         (w_in, b_in, w_o, b_o, w1, b1, w2, b2, g1, be1, g2, be2) = P
         gx2 = _as(gx2, dt)
+        rb = ops.ReduceBatch()
         if cfg['pre_norm']:
-            g_x1n, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], gx2, w1, w2)
+            g_x1n, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], gx2, w1, w2, batch=rb)
             gx1, d_g2, d_be2 = ops.layernorm_bwd(dt, g_x1n, sv['x1'], g2, sv['m2'], sv['r2'], dres=gx2)
-            g_qk, _, g_v, d_win, d_bin, d_wo, d_bo = _mha_bwd(dt, sv['mha'], gx1, w_in, w_o)
+            g_qk, _, g_v, d_win, d_bin, d_wo, d_bo = _mha_bwd(dt, sv['mha'], gx1, w_in, w_o, batch=rb)
             # LN1 fed xn (to V) and xn+pos (to Q,K): both gradients land on xn
             gx, d_g1, d_be1 = ops.layernorm_bwd(dt, g_v, sv['x'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gx1)
         else:
             g_t2, d_g2, d_be2 = ops.layernorm_bwd(dt, gx2, sv['t2'], g2, sv['m2'], sv['r2'])
-            g_x1, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], g_t2, w1, w2, res_for_gx=g_t2)
+            g_x1, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], g_t2, w1, w2, res_for_gx=g_t2, batch=rb)
             g_t, d_g1, d_be1 = ops.layernorm_bwd(dt, g_x1, sv['t'], g1, sv['m1'], sv['r1'])
-            g_qk, _, g_v, d_win, d_bin, d_wo, d_bo = _mha_bwd(dt, sv['mha'], g_t, w_in, w_o)
+            g_qk, _, g_v, d_win, d_bin, d_wo, d_bo = _mha_bwd(dt, sv['mha'], g_t, w_in, w_o, batch=rb)
             gx = ops.add(dt, ops.add(dt, g_qk, g_v), g_t)
+        rb.flush()
         ctx.sv = None
         return (gx, None, None, None, None, d_win, d_bin, d_wo, d_bo, d_w1, d_b1, d_w2, d_b2, d_g1, d_be1, d_g2, d_be2)
 
@@ -307,29 +309,31 @@ class DecoderLayerFn(Function):
         dt = cfg['dt']
         (sw_in, sb_in, sw_o, sb_o, cw_in, cb_in, cw_o, cb_o, w1, b1, w2, b2, g1, be1, g2, be2, g3, be3) = P
         gt3 = _as(g3_, dt)
+        rb = ops.ReduceBatch()
         if cfg['pre_norm']:
-            g_t2n, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], gt3, w1, w2)
+            g_t2n, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], gt3, w1, w2, batch=rb)
             gt2, d_g3, d_be3 = ops.layernorm_bwd(dt, g_t2n, sv['t2'], g3, sv['m3'], sv['r3'], dres=gt3)
-            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], gt2, cw_in, cw_o)
+            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], gt2, cw_in, cw_o, batch=rb)
             # LN2 outputs: t1n (unused on its own) and t1n + qpos (cross-attn query)
             gt1, d_g2, d_be2 = ops.layernorm_bwd(dt, g_q, sv['t1'], g2, sv['m2'], sv['r2'], dres=gt2)
             g_qpos = g_q
             g_mem_pos, g_mem = g_k, g_v
-            g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], gt1, sw_in, sw_o)
+            g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], gt1, sw_in, sw_o, batch=rb)
             gtgt, d_g1, d_be1 = ops.layernorm_bwd(dt, g_vs, sv['tgt'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gt1)
             g_qpos = ops.add(dt, g_qpos, g_qk)
         else:
             g_f, d_g3, d_be3 = ops.layernorm_bwd(dt, gt3, sv['f'], g3, sv['m3'], sv['r3'])
-            g_t2, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], g_f, w1, w2, res_for_gx=g_f)
+            g_t2, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], g_f, w1, w2, res_for_gx=g_f, batch=rb)
             g_c, d_g2, d_be2 = ops.layernorm_bwd(dt, g_t2, sv['c'], g2, sv['m2'], sv['r2'])
-            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], g_c, cw_in, cw_o)
+            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], g_c, cw_in, cw_o, batch=rb)
             g_t1 = ops.add(dt, g_q, g_c)                     # query path + residual
             g_qpos = g_q
             g_mem_pos, g_mem = g_k, g_v
             g_a, d_g1, d_be1 = ops.layernorm_bwd(dt, g_t1, sv['a'], g1, sv['m1'], sv['r1'])
-            g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], g_a, sw_in, sw_o)
+            g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], g_a, sw_in, sw_o, batch=rb)
             gtgt = ops.add(dt, ops.add(dt, g_qk, g_vs), g_a)
             g_qpos = ops.add(dt, g_qpos, g_qk)
+        rb.flush()
         ctx.sv = None
         return (gtgt, g_mem, g_mem_pos, g_qpos, None, None, None,
                 d_swin, d_sbin, d_swo, d_sbo, d_cwin, d_cbin, d_cwo, d_cbo, d_w1, d_b1, d_w2, d_b2,
@@ -429,6 +433,7 @@ class StageFn(Function):
         grads = [None] * len(T)
         # incoming gradient is w.r.t. the post-ReLU stage output: mask it (idempotent if the consumer already did)
         gp = ops.relu_mask(dt, _as(gy, dt), saved[-1]['y'])
+        rb = ops.ReduceBatch()
         i_end = len(T)
         need_x_grad = ctx.needs_input_grad[0]
         for bi_ in range(len(saved) - 1, -1, -1):
@@ -444,17 +449,17 @@ class StageFn(Function):
             want_gx = (not first) or need_x_grad
             # conv3 (1x1): wgrad, dgrad masked by relu(b)
             if t[10].requires_grad:
-                grads[base + 10] = ops.wgrad(dt, gp, r['b'], B, r['g3'], rowscale=s3)
+                grads[base + 10] = ops.wgrad(dt, gp, r['b'], B, r['g3'], rowscale=s3, batch=rb)
             gb = ops.conv_dgrad(dt, gp, B, r['g3'], w3b, mask=r['b'], ldm=r['b'].stride(0))
             # conv2 (3x3): wgrad, dgrad masked by relu(a)
             if t[5].requires_grad:
-                grads[base + 5] = ops.wgrad(dt, gb, r['a'], B, r['g2'], rowscale=s2)
+                grads[base + 5] = ops.wgrad(dt, gb, r['a'], B, r['g2'], rowscale=s2, batch=rb)
             ga = ops.conv_dgrad(dt, gb, B, r['g2'], w2b, mask=r['a'], ldm=r['a'].stride(0))
             # conv1 (1x1) wgrad
             if t[0].requires_grad:
-                grads[base + 0] = ops.wgrad(dt, ga, r['x'], B, r['g1'], rowscale=s1)
+                grads[base + 0] = ops.wgrad(dt, ga, r['x'], B, r['g1'], rowscale=s1, batch=rb)
             if blk.ds and t[15].requires_grad:
-                grads[base + 15] = ops.wgrad(dt, gp, r['x'], B, r['gd'], rowscale=r['sd'])
+                grads[base + 15] = ops.wgrad(dt, gp, r['x'], B, r['gd'], rowscale=r['sd'], batch=rb)
             if want_gx:
                 side = ops.conv_dgrad(dt, gp, B, r['gd'], r['wdb']) if blk.ds else gp
                 mask_x = (not first) or meta['mask_input']
@@ -462,5 +467,6 @@ class StageFn(Function):
                 gp = ops.conv_dgrad(dt, ga, B, r['g1'], w1b, res=side, ldr=side.stride(0), **ep)
             else:
                 gp = None
+        rb.flush()
         ctx.saved = None
         return (gp, None) + tuple(grads)

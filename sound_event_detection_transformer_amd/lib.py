@@ -35,6 +35,13 @@ class SedtIgemm(C.Structure):
     ]
 
 
+class SedtReduceJob(C.Structure):
+    _fields_ = [('slab', C.c_void_p), ('rowscale', C.c_void_p), ('out', C.c_void_p), ('colsum_slab', C.c_void_p),
+                ('bias_out', C.c_void_p), ('splitk', C.c_int32), ('R', C.c_int32), ('taps', C.c_int32), ('Ci', C.c_int32),
+                ('blk0', C.c_int32), ('pad_', C.c_int32)]
+
+
+MAX_REDUCE_JOBS = 40
 _vp, _i, _i64, _f, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32, C.c_size_t
 
 # name -> (restype, argtypes); mirrors include/sedt_hip.h one to one
@@ -45,6 +52,7 @@ SIGNATURES = {
     'sedt_igemm_splitk': (_i, [_i, _i, _i, _i]),
     'sedt_wgrad_reduce': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sedt_wgrad_reduce_bias': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'sedt_multi_wgrad_reduce': (_i, [C.POINTER(SedtReduceJob), _i, _vp]),
     'sedt_colsum': (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'sedt_colsum_scratch': (_sz, [_i, _i]),
     'sedt_dropout_grad': (_i, [_vp, _i64, _vp, _i64, _i, _i, _f, _u32, _vp, _i, _vp]),

@@ -126,9 +126,34 @@ def _fused_bias_ok(dtype, dy, x, g):
             and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and g.Ci % 8 == 0)
 
 
-def wgrad(dtype, dy, x, B, g, rowscale=None, out=None, bias_out=None):
+class ReduceBatch(object):
+    """collects the split-K reductions of several wgrads and issues them as ONE launch (flush); keeps the slabs alive"""
+
+    def __init__(self):
+        self.jobs, self.keep = [], []
+
+    def add(self, slab, sk, R, taps, Ci, rowscale, out, cs, bias_out):
+        j = L.SedtReduceJob()
+        j.slab, j.out, j.splitk, j.R, j.taps, j.Ci = slab.data_ptr(), out.data_ptr(), sk, R, taps, Ci
+        j.rowscale = rowscale.data_ptr() if rowscale is not None else None
+        j.colsum_slab = cs.data_ptr() if cs is not None else None
+        j.bias_out = bias_out.data_ptr() if (cs is not None and bias_out is not None) else None
+        self.jobs.append(j)
+        self.keep.append((slab, cs, rowscale, out, bias_out))
+        if len(self.jobs) == L.MAX_REDUCE_JOBS:
+            self.flush()
+
+    def flush(self):
+        if self.jobs:
+            arr = (L.SedtReduceJob * len(self.jobs))(*self.jobs)
+            L.check(L.load().sedt_multi_wgrad_reduce(arr, len(self.jobs), L.stream_ptr()), 'multi_wgrad_reduce')
+        self.jobs, self.keep = [], []
+
+
+def wgrad(dtype, dy, x, B, g, rowscale=None, out=None, bias_out=None, batch=None):
     """dW (Co, Ci, KH, KW) f32 = sum over pixels dy[pix][co] * gather(x)[pix][tap][ci] (* rowscale[co]).
-    bias_out (f32 [Co]): also receives sum over pixels of dy (fused into the wgrad kernel when it can, else a colsum)"""
+    bias_out (f32 [Co]): also receives sum over pixels of dy (fused into the wgrad kernel when it can, else a colsum).
+    batch: a ReduceBatch - the split-K reduction is deferred until batch.flush() (the result is valid only then)"""
     lib = L.load()
     Mo, No, Kp = g.Co, g.taps * g.Ci, B * g.Ho * g.Wo
     sk = lib.sedt_igemm_splitk(Mo, No, Kp, dtype)
@@ -140,19 +165,22 @@ def wgrad(dtype, dy, x, B, g, rowscale=None, out=None, bias_out=None):
           slab=slab, colsum_out=cs)
     if out is None:
         out = torch.empty((g.Co, g.Ci, g.KH, g.KW), device=dy.device, dtype=torch.float32)
-    L.check(lib.sedt_wgrad_reduce_bias(_p(slab), sk, Mo, g.taps, g.Ci, _p(rowscale), _p(out), _p(cs),
-                                       _p(bias_out) if fused else None, L.stream_ptr()), 'wgrad_reduce')
+    if batch is not None:
+        batch.add(slab, sk, Mo, g.taps, g.Ci, rowscale, out, cs, bias_out if fused else None)
+    else:
+        L.check(lib.sedt_wgrad_reduce_bias(_p(slab), sk, Mo, g.taps, g.Ci, _p(rowscale), _p(out), _p(cs),
+                                           _p(bias_out) if fused else None, L.stream_ptr()), 'wgrad_reduce')
     if bias_out is not None and not fused:
         colsum(dtype, dy, out=bias_out)
     return out
 
 
-def linear_wgrad(dtype, dy, x, out=None, bias_out=None):
+def linear_wgrad(dtype, dy, x, out=None, bias_out=None, batch=None):
     """dW [N,K] f32 = dy[M,N]^T @ x[M,K]; bias_out f32 [N] optionally receives the column sums of dy"""
     N, K = dy.shape[1], x.shape[1]
     g = ConvGeom(1, 1, K, N)
     return wgrad(dtype, dy, x, dy.shape[0], g, out=out.view(N, K, 1, 1) if out is not None else None,
-                 bias_out=bias_out).view(N, K)
+                 bias_out=bias_out, batch=batch).view(N, K)
 
 
 def colsum(dtype, x, out=None):

@@ -47,11 +47,13 @@ def main():
         dx = torch.empty_like(x)
         flops = 2.0 * B * g.Ho * g.Wo * Co * Ci * k * k
         row = {'name': name, 'gflop': flops / 1e9}
-        for tile in (((128, 128), (64, 64)) if not os.environ.get('SKIP_FWD') else ()):
+        for tile in (((128, 128), (128, 64), (64, 128), (64, 64)) if not os.environ.get('SKIP_FWD') else ()):
             t = time_call(lambda: ops.conv_fwd(BF16, x, B, g, wf, out=y, act=1, res=y, ldr=Co, tile=tile))
             row[f'fwd{tile}'] = (round(t, 1), round(flops / t / 1e6, 0))
             t = time_call(lambda: ops.conv_dgrad(BF16, gy, B, g, wb, out=dx, mask=x, ldm=Ci, tile=tile))
             row[f'dgrad{tile}'] = (round(t, 1), round(flops / t / 1e6, 0))
+            t = time_call(lambda: ops.conv_fwd(BF16, x, B, g, wf, out=y, tile=tile))
+            row[f'plain{tile}'] = (round(t, 1), round(flops / t / 1e6, 0))
         if os.environ.get('SKIP_WGRAD'):
             res.append(row); print(json.dumps(row), flush=True); continue
         # wgrad with split-K as chosen by the library, per tile
