@@ -1,0 +1,383 @@
+// attn_mfma.hip - bf16 multi-head attention forward/backward on MFMA for gfx950 (head dim 32, L <= 256).
+//
+// One workgroup per (batch, head); Q/K/V (and dO) tiles of that head are staged once in LDS as bf16 [L][32] images
+// (64-B rows).  All four contractions run on v_mfma_f32_32x32x16_bf16:
+//
+//   forward, wave = 32 queries:   S^T = K Q^T   (lane <-> query, registers <-> keys: softmax statistics are in-lane
+//                                                reductions + one cross-half shuffle)
+//                                 O  += P V      P straight from the S^T accumulators (k-slot s of half h <-> key
+//                                                16u + (s&3) + 8(s>>2) + 4h); the matching V^T fragment is read with
+//                                                ds_read_b64_tr_b16 (same k-slot order), so no cross-lane movement.
+//   backward pass A (32 queries): S^T, dP^T = V dO^T, dS^T = P^T (dP^T - delta)  ->  dQ += dS K   (K^T via tr reads)
+//   backward pass B (32 keys):    S = Q K^T, dP = dO V^T (lane <-> key, registers <-> queries)
+//                                 dV^T += dO^T Pd,  dK^T += Q^T dS            (dO^T, Q^T via tr reads)
+//
+// Probabilities never touch HBM: backward recomputes them from the saved log-sum-exp; the dropout mask is the counter
+// hash of ((b*H+h)*Lq + q)*Lk + k, identical in forward and backward (and to the f32 reference kernels).
+#include "common.h"
+
+namespace sedt {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+constexpr int AD = 32;          // head dim
+constexpr int AROW = AD * 2;    // bytes per image row
+constexpr int AMAXT = 8;        // key / query tiles of 32 -> L <= 256
+
+__device__ __forceinline__ int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }   // C-layout row of register r
+
+// stage rows [0, L) of a [*, ld] bf16 matrix (32 columns from `src`) into a zero-padded [Lpad][32] LDS image
+__device__ __forceinline__ void stage_image(unsigned char* img, const bf16_t* src, long ld, int L, int Lpad, int tid, int nthr) {
+  for (int u = tid; u < Lpad * 4; u += nthr) {     // 4 x 16-byte chunks per row
+    const int r = u >> 2, c = u & 3;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < L) v = *reinterpret_cast<const uint4*>(src + (long)r * ld + c * 8);
+    *reinterpret_cast<uint4*>(img + r * AROW + c * 16) = v;
+  }
+}
+
+// A/B fragment whose 32 "rows" are image rows row0..row0+31 and whose k-slots are the 16 dims [16*ks, +16)
+__device__ __forceinline__ bf16x8 frag_rows(const unsigned char* img, int row0, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8*>(img + (row0 + (lane & 31)) * AROW + (ks * 16 + 8 * (lane >> 5)) * 2);
+}
+
+// fragment whose 32 "rows"/"cols" are the 32 dims and whose k-slots are image rows: slot s of half h <-> row
+// base16 + (s&3) + 8*(s>>2) + 4*h  (the order in which a C-layout accumulator holds its rows).  Two transposing reads.
+__device__ __forceinline__ bf16x8 frag_cols_tr(const unsigned char* img, int base16, int lane) {
+  const int h = lane >> 5, dgrp = (lane >> 4) & 1, s16 = lane & 15;
+  const unsigned char* p = img + (base16 + 4 * h + (s16 >> 2)) * AROW + (16 * dgrp + 4 * (s16 & 3)) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + 8 * AROW));
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+  return o;
+}
+
+// ============================================================================================ forward
+template <int NT>   // key tiles
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ k,
+                                                            long ldk, const bf16_t* __restrict__ v, long ldv,
+                                                            bf16_t* __restrict__ o, long ldo, float* __restrict__ lse,
+                                                            const uint8_t* __restrict__ kpm, const float* __restrict__ amask,
+                                                            int H, int Lq, int Lk, float scale, uint32_t thresh, float inv_keep,
+                                                            uint32_t seed, const uint32_t* seed_ptr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int LkP = NT * 32, LqP = (Lq + 31) & ~31;
+  unsigned char* Ki = smem;
+  unsigned char* Vi = Ki + LkP * AROW;
+  unsigned char* Qi = Vi + LkP * AROW;
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
+  stage_image(Ki, k + (long)b * Lk * ldk + h * AD, ldk, Lk, LkP, tid, nthr);
+  stage_image(Vi, v + (long)b * Lk * ldv + h * AD, ldv, Lk, LkP, tid, nthr);
+  stage_image(Qi, q + (long)b * Lq * ldq + h * AD, ldq, Lq, LqP, tid, nthr);
+  __syncthreads();
+  const uint32_t sd = eff_seed(seed, seed_ptr);
+  const int hf = lane >> 5;
+  for (int q0 = wave * 32; q0 < Lq; q0 += nwave * 32) {
+    const int qi = q0 + (lane & 31);                   // this lane's query
+    f32x16 st[NT];
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ki, kt * 32, ks, lane), frag_rows(Qi, q0, ks, lane), st[kt], 0, 0, 0);
+    }
+    // scores -> masked, running max
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + crow(r, hf);
+        float s = st[kt][r] * scale;
+        if (amask && qi < Lq && key < Lk) s += amask[(long)qi * Lk + key];
+        if (key >= Lk || (kpm && kpm[(long)b * Lk + key])) s = -INFINITY;
+        st[kt][r] = s;
+        m = fmaxf(m, s);
+      }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(st[kt][r] - m);
+        st[kt][r] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    if (hf == 0 && qi < Lq) lse[((long)b * H + h) * Lq + qi] = m + __logf(sum);
+    // O = P V
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float pv[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          float p = st[kt][8 * u + s] * inv;
+          if (thresh) {
+            const int key = kt * 32 + crow(8 * u + s, hf);
+            p = drop_keep(sd, ((uint64_t)bh * Lq + qi) * Lk + key, thresh) ? p * inv_keep : 0.f;
+          }
+          pv[s] = p;
+        }
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(pv), frag_cols_tr(Vi, kt * 32 + 16 * u, lane), oacc, 0, 0, 0);
+      }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = q0 + crow(r, hf);
+      if (qr < Lq) o[((long)b * Lq + qr) * ldo + h * AD + (lane & 31)] = (bf16_t)oacc[r];
+    }
+  }
+}
+
+// ============================================================================================ backward
+template <int NTQ, int NTK>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ k,
+                                                            long ldk, const bf16_t* __restrict__ v, long ldv,
+                                                            const bf16_t* __restrict__ o, long ldo, const bf16_t* __restrict__ dout,
+                                                            long lddo, const float* __restrict__ lse, const uint8_t* __restrict__ kpm,
+                                                            const float* __restrict__ amask, bf16_t* __restrict__ dq, long lddq,
+                                                            bf16_t* __restrict__ dk, long lddk, bf16_t* __restrict__ dv, long lddv,
+                                                            int H, int Lq, int Lk, float scale, uint32_t thresh, float inv_keep,
+                                                            uint32_t seed, const uint32_t* seed_ptr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int LqP = NTQ * 32, LkP = NTK * 32;
+  unsigned char* Qi = smem;
+  unsigned char* Ki = Qi + LqP * AROW;
+  unsigned char* Vi = Ki + LkP * AROW;
+  unsigned char* Di = Vi + LkP * AROW;                  // dO image
+  float* Ls = reinterpret_cast<float*>(Di + LqP * AROW);   // lse   [LqP]
+  float* De = Ls + LqP;                                 // delta [LqP]
+  const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
+  stage_image(Qi, q + (long)b * Lq * ldq + h * AD, ldq, Lq, LqP, tid, nthr);
+  stage_image(Ki, k + (long)b * Lk * ldk + h * AD, ldk, Lk, LkP, tid, nthr);
+  stage_image(Vi, v + (long)b * Lk * ldv + h * AD, ldv, Lk, LkP, tid, nthr);
+  stage_image(Di, dout + (long)b * Lq * lddo + h * AD, lddo, Lq, LqP, tid, nthr);
+  for (int i = tid; i < LqP; i += nthr) {
+    float dl = 0.f, l = 0.f;
+    if (i < Lq) {
+      l = lse[((long)b * H + h) * Lq + i];
+      const bf16_t* op = o + ((long)b * Lq + i) * ldo + h * AD;
+      const bf16_t* dp = dout + ((long)b * Lq + i) * lddo + h * AD;
+#pragma unroll
+      for (int d = 0; d < AD; ++d) dl += (float)op[d] * (float)dp[d];
+    }
+    Ls[i] = l;
+    De[i] = dl;
+  }
+  __syncthreads();
+  const uint32_t sd = eff_seed(seed, seed_ptr);
+  const int hf = lane >> 5;
+
+  // ---------------- pass A: this wave's 32 queries, all keys -> dQ
+  for (int q0 = wave * 32; q0 < Lq; q0 += nwave * 32) {
+    const int qi = q0 + (lane & 31);
+    const float lq = Ls[qi], dlq = De[qi];
+    f32x16 dqa;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqa[r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NTK; ++kt) {
+      f32x16 st, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 qf = frag_rows(Qi, q0, ks, lane), df = frag_rows(Di, q0, ks, lane);
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ki, kt * 32, ks, lane), qf, st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Vi, kt * 32, ks, lane), df, dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float ds[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int r = 8 * u + s, key = kt * 32 + crow(r, hf);
+          float sc = st[r] * scale;
+          if (amask && qi < Lq && key < Lk) sc += amask[(long)qi * Lk + key];
+          if (key >= Lk || (kpm && kpm[(long)b * Lk + key])) sc = -INFINITY;
+          const float p = __expf(sc - lq);
+          float g = dp[r];
+          if (thresh) g = drop_keep(sd, ((uint64_t)bh * Lq + qi) * Lk + key, thresh) ? g * inv_keep : 0.f;
+          ds[s] = (qi < Lq) ? p * (g - dlq) : 0.f;
+        }
+        dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(ds), frag_cols_tr(Ki, kt * 32 + 16 * u, lane), dqa, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = q0 + crow(r, hf);
+      if (qr < Lq) dq[((long)b * Lq + qr) * lddq + h * AD + (lane & 31)] = (bf16_t)(dqa[r] * scale);
+    }
+  }
+
+  // ---------------- pass B: this wave's 32 keys, all queries -> dK, dV (accumulated transposed: rows = dims, cols = keys)
+  for (int k0 = wave * 32; k0 < Lk; k0 += nwave * 32) {
+    const int kj = k0 + (lane & 31);                    // this lane's key
+    const bool kdead = kj >= Lk || (kpm && kpm[(long)b * Lk + kj]);
+    f32x16 dkt, dvt;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dkt[r] = 0.f; dvt[r] = 0.f; }
+#pragma unroll
+    for (int qt = 0; qt < NTQ; ++qt) {
+      f32x16 sa, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sa[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kf = frag_rows(Ki, k0, ks, lane), vf = frag_rows(Vi, k0, ks, lane);
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Qi, qt * 32, ks, lane), kf, sa, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Di, qt * 32, ks, lane), vf, dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float pd[8], ds[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int r = 8 * u + s, qr = qt * 32 + crow(r, hf);
+          float sc = sa[r] * scale;
+          if (amask && qr < Lq && kj < Lk) sc += amask[(long)qr * Lk + kj];
+          if (kdead) sc = -INFINITY;
+          float p = (qr < Lq) ? __expf(sc - Ls[qr]) : 0.f;
+          float g = dp[r], pk = p;
+          if (thresh) {
+            const bool keep = drop_keep(sd, ((uint64_t)bh * Lq + qr) * Lk + kj, thresh);
+            g = keep ? g * inv_keep : 0.f;
+            pk = keep ? p * inv_keep : 0.f;
+          }
+          pd[s] = pk;
+          ds[s] = p * (g - De[qr]);
+        }
+        dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Di, qt * 32 + 16 * u, lane), pack8(pd), dvt, 0, 0, 0);
+        dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Qi, qt * 32 + 16 * u, lane), pack8(ds), dkt, 0, 0, 0);
+      }
+    }
+    // dvt/dkt: register r <-> dim crow(r, hf), lane <-> key: four 4-dim (8-byte) stores per row
+    if (kj < Lk) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        bf16x4 a, c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = (bf16_t)(dkt[4 * g4 + e] * scale); c[e] = (bf16_t)dvt[4 * g4 + e]; }
+        const int d0 = 8 * g4 + 4 * hf;
+        *reinterpret_cast<bf16x4*>(dk + ((long)b * Lk + kj) * lddk + h * AD + d0) = a;
+        *reinterpret_cast<bf16x4*>(dv + ((long)b * Lk + kj) * lddv + h * AD + d0) = c;
+      }
+    }
+  }
+}
+
+template <typename K>
+static int set_attr_once(K kern, bool& done, size_t bytes, const char* what) {
+  if (done) return 0;
+  done = true;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
+    return 1;
+  }
+  return 0;
+}
+
+static bool aligned_ok(const void* p, int64_t ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 7) == 0; }
+
+// returns -1 if outside the envelope (caller falls back to the generic kernels)
+int attn_fwd_mfma_try(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
+                      float* lse, const uint8_t* kpm, const float* amask, int B, int H, int Lq, int Lk, float drop_p,
+                      uint32_t seed, const uint32_t* seed_ptr, hipStream_t st) {
+  if (Lk > 32 * AMAXT || Lq > 32 * AMAXT) return -1;
+  if (!aligned_ok(q, ldq) || !aligned_ok(k, ldk) || !aligned_ok(v, ldv)) return -1;
+  const int nt = (Lk + 31) / 32, LqP = (Lq + 31) & ~31;
+  const size_t lds = (size_t)(2 * nt * 32 + LqP) * AROW;
+  const int nwave = std::min(4, (Lq + 31) / 32);
+  const float scale = 1.f / sqrtf((float)AD);
+  const uint32_t th = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+  const float ik = 1.f / (1.f - drop_p);
+  dim3 grid(B * H), block(64 * nwave);
+#define SEDT_AF(NT_)                                                                                                       \
+  case NT_: {                                                                                                              \
+    static bool done = false;                                                                                              \
+    if (set_attr_once(attn_fwd_mfma_kernel<NT_>, done, 64 * 1024, "attention_fwd")) return 1;                              \
+    hipLaunchKernelGGL(attn_fwd_mfma_kernel<NT_>, grid, block, lds, st, (const bf16_t*)q, (long)ldq, (const bf16_t*)k,     \
+                       (long)ldk, (const bf16_t*)v, (long)ldv, (bf16_t*)o, (long)ldo, lse, kpm, amask, H, Lq, Lk, scale,   \
+                       th, ik, seed, seed_ptr);                                                                            \
+    break;                                                                                                                 \
+  }
+  switch (nt) {
+    SEDT_AF(1) SEDT_AF(2) SEDT_AF(3) SEDT_AF(4) SEDT_AF(5) SEDT_AF(6) SEDT_AF(7) SEDT_AF(8)
+    default: return -1;
+  }
+#undef SEDT_AF
+  return check_launch("attention_fwd_mfma");
+}
+
+template <int NTQ>
+static int launch_bwd_q(int ntk, dim3 grid, dim3 block, size_t lds, hipStream_t st, const void* q, int64_t ldq, const void* k,
+                        int64_t ldk, const void* v, int64_t ldv, const void* o, int64_t ldo, const void* dout, int64_t lddo,
+                        const float* lse, const uint8_t* kpm, const float* amask, void* dq, int64_t lddq, void* dk, int64_t lddk,
+                        void* dv, int64_t lddv, int H, int Lq, int Lk, float scale, uint32_t th, float ik, uint32_t seed,
+                        const uint32_t* seed_ptr) {
+#define SEDT_AB(NTK_)                                                                                                      \
+  case NTK_: {                                                                                                             \
+    static bool done = false;                                                                                              \
+    if (set_attr_once(attn_bwd_mfma_kernel<NTQ, NTK_>, done, 96 * 1024, "attention_bwd")) return 1;                        \
+    hipLaunchKernelGGL((attn_bwd_mfma_kernel<NTQ, NTK_>), grid, block, lds, st, (const bf16_t*)q, (long)ldq, (const bf16_t*)k, \
+                       (long)ldk, (const bf16_t*)v, (long)ldv, (const bf16_t*)o, (long)ldo, (const bf16_t*)dout, (long)lddo, lse, \
+                       kpm, amask, (bf16_t*)dq, (long)lddq, (bf16_t*)dk, (long)lddk, (bf16_t*)dv, (long)lddv, H, Lq, Lk, scale, \
+                       th, ik, seed, seed_ptr);                                                                            \
+    break;                                                                                                                 \
+  }
+  switch (ntk) {
+    SEDT_AB(1) SEDT_AB(2) SEDT_AB(3) SEDT_AB(4)
+    default: return -1;
+  }
+#undef SEDT_AB
+  return check_launch("attention_bwd_mfma");
+}
+
+int attn_bwd_mfma_try(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
+                      int64_t ldo, const void* dout, int64_t lddo, const float* lse, const uint8_t* kpm, const float* amask,
+                      void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B, int H, int Lq, int Lk,
+                      float drop_p, uint32_t seed, const uint32_t* seed_ptr, hipStream_t st) {
+  if (Lk > 128 || Lq > 128) return -1;                    // template matrix kept small: 4 x 4 tile counts
+  if (!aligned_ok(q, ldq) || !aligned_ok(k, ldk) || !aligned_ok(v, ldv) || !aligned_ok(dout, lddo)) return -1;
+  if ((lddk & 3) || (lddv & 3) || (reinterpret_cast<uintptr_t>(dk) & 7) || (reinterpret_cast<uintptr_t>(dv) & 7)) return -1;
+  const int ntq = (Lq + 31) / 32, ntk = (Lk + 31) / 32;
+  const size_t lds = (size_t)(2 * ntq * 32 + 2 * ntk * 32) * AROW + 2 * ntq * 32 * sizeof(float);
+  const int nwave = std::min(4, std::max(ntq, ntk));
+  const float scale = 1.f / sqrtf((float)AD);
+  const uint32_t th = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+  const float ik = 1.f / (1.f - drop_p);
+  dim3 grid(B * H), block(64 * nwave);
+#define SEDT_ARGS ntk, grid, block, lds, st, q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, kpm, amask, dq, lddq, dk, lddk, dv, \
+                  lddv, H, Lq, Lk, scale, th, ik, seed, seed_ptr
+  switch (ntq) {
+    case 1: return launch_bwd_q<1>(SEDT_ARGS);
+    case 2: return launch_bwd_q<2>(SEDT_ARGS);
+    case 3: return launch_bwd_q<3>(SEDT_ARGS);
+    case 4: return launch_bwd_q<4>(SEDT_ARGS);
+    default: return -1;
+  }
+#undef SEDT_ARGS
+}
+
+}  // namespace sedt

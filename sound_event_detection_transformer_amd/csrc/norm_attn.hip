@@ -10,6 +10,7 @@
 // key row (dK,dV pass), lanes run over the other sequence axis (row operands of the owner are held in
 // registers, the per-lane rows are read as float4 = ds_read_b128), softmax statistics are wave reductions.  The probabilities are never written to HBM: backward recomputes them from the
 // saved log-sum-exp and regenerates the dropout mask from (seed, element index).
+#include <stdlib.h>
 #include "common.h"
 
 namespace sedt {
@@ -345,6 +346,24 @@ static int set_lds_attr(K kern, size_t bytes, const char* what) {
 
 }  // namespace sedt
 
+namespace sedt {
+int attn_fwd_mfma_try(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
+                      float* lse, const uint8_t* kpm, const float* amask, int B, int H, int Lq, int Lk, float drop_p,
+                      uint32_t seed, const uint32_t* seed_ptr, hipStream_t st);
+int attn_bwd_mfma_try(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
+                      int64_t ldo, const void* dout, int64_t lddo, const float* lse, const uint8_t* kpm, const float* amask,
+                      void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B, int H, int Lq, int Lk,
+                      float drop_p, uint32_t seed, const uint32_t* seed_ptr, hipStream_t st);
+static bool use_attn_mfma() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SEDT_ATTN_MFMA");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+}  // namespace sedt
+
 using namespace sedt;
 
 extern "C" int sedt_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* add, void* y, void* y2,
@@ -389,6 +408,10 @@ extern "C" int sedt_attention_fwd(const void* q, int64_t ldq, const void* k, int
   SEDT_REQUIRE(q && k && v && o && lse, "attention_fwd: null pointer");
   SEDT_REQUIRE(Lk >= 1 && Lk <= 64 * MAXKPL && Lq >= 1, "attention_fwd: Lk=%d out of range (1..%d)", Lk, 64 * MAXKPL);
   SEDT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attention_fwd: drop_p out of range");
+  if (dtype == SEDT_BF16 && use_attn_mfma()) {          // MFMA kernels (attn_mfma.hip) when the problem fits
+    int r = attn_fwd_mfma_try(q, ldq, k, ldk, v, ldv, o, ldo, lse, kpm, amask, B, H, Lq, Lk, drop_p, seed, seed_ptr, S(stream));
+    if (r >= 0) return r;
+  }
   const int LkPad = (Lk + 63) & ~63;
   size_t lds = ((size_t)2 * Lk * KP + 4 * LkPad) * sizeof(float);
   SEDT_REQUIRE(lds <= 160 * 1024, "attention_fwd: Lk=%d needs %zu B of LDS", Lk, lds);
@@ -416,6 +439,11 @@ extern "C" int sedt_attention_bwd(const void* q, int64_t ldq, const void* k, int
                                   const uint32_t* seed_ptr, int dtype, void* stream) {
   SEDT_REQUIRE(q && k && v && o && dout && lse && dq && dk && dv, "attention_bwd: null pointer");
   SEDT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "attention_bwd: drop_p out of range");
+  if (dtype == SEDT_BF16 && use_attn_mfma()) {
+    int r = attn_bwd_mfma_try(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, kpm, amask, dq, lddq, dk, lddk, dv, lddv, B, H, Lq,
+                              Lk, drop_p, seed, seed_ptr, S(stream));
+    if (r >= 0) return r;
+  }
   const int LmPad = (std::max(Lq, Lk) + 63) & ~63;
   size_t lds = ((size_t)2 * Lq * KP + 2 * Lk * KP + 2 * Lq + 8 * LmPad) * sizeof(float);
   SEDT_REQUIRE(lds <= 160 * 1024, "attention_bwd: Lq=%d Lk=%d need %zu B of LDS", Lq, Lk, lds);
