@@ -21,7 +21,8 @@ namespace sedt {
 int wgrad2_try(const SedtIgemm& p, hipStream_t st);   // wgrad2.hip
 
 template <int BM, int BN, int STAGES>
-__global__ __launch_bounds__(256) void igemm2_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes) {
+__global__ __launch_bounds__(256) void igemm2_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes,
+                                                     const int nmajor) {
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int STAGE_BYTES = (BM + BN) * ROWB;
   constexpr int GA = BM / 32, GB = BN / 32;     // DMA instructions per wave per tile for A / B (8 rows each, 4 waves)
@@ -40,7 +41,12 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const SedtIgemm p, const un
     const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
     vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
-  const int m0 = (vid / ntn) * BM, n0 = (vid % ntn) * BN;
+  // each XCD owns a contiguous run of tile ids (its own L2).  m-major runs (n fastest) keep an A panel resident and re-read
+  // all of B per M tile - right while B (weights) fits the 4 MB L2; when it does not (layer4 3x3: 4.7 MB), n-major runs
+  // keep a B panel resident and stream A instead.
+  int m0, n0;
+  if (nmajor) { n0 = (vid / ntm) * BN; m0 = (vid % ntm) * BM; }
+  else { m0 = (vid / ntn) * BM; n0 = (vid % ntn) * BN; }
 
   const int nkb = (p.K + BK2 - 1) / BK2;
   Geom2 g{p.Hi, p.Wi, p.Ci, p.Ho, p.Wo, p.KH, p.KW, p.sh, p.sw, p.ph, p.pw, p.dh, p.dw, p.transposed};
@@ -248,7 +254,13 @@ static int launch2(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipSt
     attr_set = true;
   }
   const int nwg = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, p, a_bytes, b_bytes);
+  static int force = -2;
+  if (force == -2) {
+    const char* e = getenv("SEDT_IGEMM_NMAJOR");
+    force = e ? atoi(e) : -1;
+  }
+  const int nmajor = force > 0 ? 1 : 0;   // measured on the full step: m-major wins even for the 4.7 MB layer4 3x3 weights
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, p, a_bytes, b_bytes, nmajor);
   return check_launch("igemm2");
 }
 

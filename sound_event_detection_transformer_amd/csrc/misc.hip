@@ -4,6 +4,7 @@
 // All are coalesced along the channel (fastest) axis of the NHWC / [rows][cols] layouts.
 #include <stdarg.h>
 #include <string.h>
+#include <type_traits>
 #include "common.h"
 
 namespace sedt {
@@ -251,32 +252,56 @@ __global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, u
   idx[e] = (uint8_t)bi;
 }
 
-template <typename T>
+// thread = one input pixel x VEC consecutive channels (16 bytes of dy / relu_src / dx at a time when C % VEC == 0)
+template <typename T, int VEC>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, const T* __restrict__ relu_src,
                                    T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
+  const int CV = C / VEC;
   long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long n = (long)B * H * W * C;
+  long n = (long)B * H * W * CV;
   if (e >= n) return;
-  int c = (int)(e % C);
-  long r = e / C;
-  int wi = (int)(r % W);
+  const int c = (int)(e % CV) * VEC;
+  long r = e / CV;
+  const int wi = (int)(r % W);
   r /= W;
-  int hi = (int)(r % H), b = (int)(r / H);
-  float s = 0.f;
+  const int hi = (int)(r % H), b = (int)(r / H);
+  float s[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) s[v] = 0.f;
   for (int a = 0; a < 2; ++a) {
-    int ho = (hi + 1) / 2 - a;
-    int kh = hi - (2 * ho - 1);
+    const int ho = (hi + 1) / 2 - a;
+    const int kh = hi - (2 * ho - 1);
     if (ho < 0 || ho >= Ho || kh < 0 || kh > 2) continue;
     for (int d = 0; d < 2; ++d) {
-      int wo = (wi + 1) / 2 - d;
-      int kw = wi - (2 * wo - 1);
+      const int wo = (wi + 1) / 2 - d;
+      const int kw = wi - (2 * wo - 1);
       if (wo < 0 || wo >= Wo || kw < 0 || kw > 2) continue;
-      long o = (((long)b * Ho + ho) * Wo + wo) * C + c;
-      if (idx[o] == kh * 3 + kw) s += (float)dy[o];
+      const long o = (((long)b * Ho + ho) * Wo + wo) * C + c;
+      T gv[VEC];
+      uint8_t iv[VEC];
+      *reinterpret_cast<typename std::conditional<sizeof(T) * VEC == 16, uint4, uint2>::type*>(gv) =
+          *reinterpret_cast<const typename std::conditional<sizeof(T) * VEC == 16, uint4, uint2>::type*>(dy + o);
+      *reinterpret_cast<typename std::conditional<VEC == 8, uint2, uint32_t>::type*>(iv) =
+          *reinterpret_cast<const typename std::conditional<VEC == 8, uint2, uint32_t>::type*>(idx + o);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v)
+        if (iv[v] == kh * 3 + kw) s[v] += (float)gv[v];
     }
   }
-  if (relu_src && !((float)relu_src[e] > 0.f)) s = 0.f;
-  dx[e] = (T)s;
+  const long xo = (((long)b * H + hi) * W + wi) * C + c;
+  T ov[VEC];
+  if (relu_src) {
+    T rv[VEC];
+    *reinterpret_cast<typename std::conditional<sizeof(T) * VEC == 16, uint4, uint2>::type*>(rv) =
+        *reinterpret_cast<const typename std::conditional<sizeof(T) * VEC == 16, uint4, uint2>::type*>(relu_src + xo);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) ov[v] = ((float)rv[v] > 0.f) ? (T)s[v] : (T)0.f;
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) ov[v] = (T)s[v];
+  }
+  *reinterpret_cast<typename std::conditional<sizeof(T) * VEC == 16, uint4, uint2>::type*>(dx + xo) =
+      *reinterpret_cast<typename std::conditional<sizeof(T) * VEC == 16, uint4, uint2>::type*>(ov);
 }
 
 template <typename T>
@@ -628,12 +653,23 @@ extern "C" int sedt_maxpool_fwd(const void* x, void* y, uint8_t* idx, int B, int
 extern "C" int sedt_maxpool_bwd(const void* dy, const uint8_t* idx, const void* relu_src, void* dx, int B, int H, int W,
                                 int C, int dtype, void* stream) {
   int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  long n = (long)B * H * W * C;
-  BY_DTYPE(dtype,
-           hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(nblk(n)), dim3(256), 0, S(stream), (const float*)dy, idx,
-                              (const float*)relu_src, (float*)dx, B, H, W, C, Ho, Wo),
-           hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, S(stream), (const bf16_t*)dy, idx,
-                              (const bf16_t*)relu_src, (bf16_t*)dx, B, H, W, C, Ho, Wo));
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (dtype == SEDT_BF16) {
+    SEDT_REQUIRE(C % 8 == 0 && al(dy) && al(dx) && (!relu_src || al(relu_src)) && (reinterpret_cast<uintptr_t>(idx) & 7) == 0,
+                 "maxpool_bwd: needs C %% 8 == 0 and 16-byte aligned tensors");
+    long n = (long)B * H * W * (C / 8);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8>), dim3(nblk(n)), dim3(256), 0, S(stream), (const bf16_t*)dy, idx,
+                       (const bf16_t*)relu_src, (bf16_t*)dx, B, H, W, C, Ho, Wo);
+  } else if (dtype == SEDT_F32) {
+    SEDT_REQUIRE(C % 4 == 0 && al(dy) && al(dx) && (!relu_src || al(relu_src)) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0,
+                 "maxpool_bwd: needs C %% 4 == 0 and 16-byte aligned tensors");
+    long n = (long)B * H * W * (C / 4);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4>), dim3(nblk(n)), dim3(256), 0, S(stream), (const float*)dy, idx,
+                       (const float*)relu_src, (float*)dx, B, H, W, C, Ho, Wo);
+  } else {
+    set_error("unsupported dtype %d", dtype);
+    return 1;
+  }
   return check_launch("maxpool_bwd");
 }
 

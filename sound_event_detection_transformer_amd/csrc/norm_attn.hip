@@ -92,17 +92,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     partial[(long)blockIdx.x * 2 * D + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
 
-__global__ void ln_bwd_final_kernel(const float* __restrict__ partial, int nblocks, int D, float* dgamma, float* dbeta) {
-  __shared__ float red[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void ln_bwd_final_kernel(const float* __restrict__ partial, int nblocks, int D, float* dgamma,
+                                                            float* dbeta) {
+  __shared__ float red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 64 columns x 16 row groups
   const int c = blockIdx.x * 64 + tx;
   float s = 0.f;
   if (c < 2 * D)
-    for (int b = ty; b < nblocks; b += 4) s += partial[(long)b * 2 * D + c];
+    for (int b = ty; b < nblocks; b += 16) s += partial[(long)b * 2 * D + c];
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && c < 2 * D) {
-    s = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][tx];
     if (c < D) { if (dgamma) dgamma[c] = s; }
     else if (dbeta) dbeta[c - D] = s;
   }
@@ -110,7 +113,7 @@ __global__ void ln_bwd_final_kernel(const float* __restrict__ partial, int nbloc
 
 static int ln_bwd_blocks(int rows) {
   int b = (rows + 3) / 4;
-  return b < 1 ? 1 : (b > 256 ? 256 : b);
+  return b < 1 ? 1 : (b > 128 ? 128 : b);
 }
 
 // ============================================================================ attention
@@ -398,7 +401,7 @@ extern "C" int sedt_layernorm_bwd(const void* dy, const void* dy2, const void* x
   else { set_error("layernorm: unsupported dtype %d / width %d (256 or 512)", dtype, D); return 1; }
 #undef A_
   if (dgamma || dbeta)
-    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, S(stream), scratch, nb, D, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_bwd_final_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, S(stream), scratch, nb, D, dgamma, dbeta);
   return check_launch("layernorm_bwd");
 }
 

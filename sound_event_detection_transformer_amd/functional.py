@@ -60,8 +60,11 @@ class LinearFn(Function):
     """y = act(x @ W^T + b); act in {none, relu, sigmoid}; optional f32 output (heads)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, out_f32, dt):
+    def forward(ctx, x, weight, bias, act, out_f32, dt, relu_input=False):
+        """relu_input: x is a post-ReLU tensor whose producer expects a gradient already masked by x > 0 (fused into the
+        dgrad epilogue here instead of a separate pass in the producer's backward)"""
         x = _as(x, dt)
+        ctx.relu_input = relu_input
         wf, ctx.wb = _prep_linear(dt, weight, ctx.needs_input_grad[0])
         y = ops.linear(dt, x, wf, bias=bias, act=act, out_f32=out_f32)
         ctx.dt, ctx.act, ctx.out_f32 = dt, act, out_f32
@@ -79,7 +82,9 @@ class LinearFn(Function):
         elif ctx.act == ACT_RELU:
             gy = ops.relu_mask(_dt_of(gy), gy, y)
         g = _as(gy, dt)
-        gx = ops.linear(dt, g, ctx.wb) if ctx.needs_input_grad[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.linear(dt, g, ctx.wb, mask=x, ldm=x.stride(0)) if ctx.relu_input else ops.linear(dt, g, ctx.wb)
         gb = torch.empty((g.shape[1],), device=g.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         if ctx.needs_input_grad[1]:
             gw = ops.linear_wgrad(dt, g, x, bias_out=gb)
@@ -87,7 +92,7 @@ class LinearFn(Function):
             gw = None
             if gb is not None:
                 ops.colsum(dt, g, out=gb)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 class LayerNormFn(Function):
@@ -432,7 +437,7 @@ class StageFn(Function):
         dt, B = meta['dt'], meta['B']
         grads = [None] * len(T)
         # incoming gradient is w.r.t. the post-ReLU stage output: mask it (idempotent if the consumer already did)
-        gp = ops.relu_mask(dt, _as(gy, dt), saved[-1]['y'])
+        gp = _as(gy, dt) if meta.get('grad_premasked') else ops.relu_mask(dt, _as(gy, dt), saved[-1]['y'])
         rb = ops.ReduceBatch()
         i_end = len(T)
         need_x_grad = ctx.needs_input_grad[0]

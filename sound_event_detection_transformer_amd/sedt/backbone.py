@@ -69,6 +69,8 @@ class ResNet50Body(nn.Module):
         self.layer2 = self._make_layer(128, 4, stride=2)
         self.layer3 = self._make_layer(256, 6, stride=2)
         self.layer4 = self._make_layer(512, 3, stride=2, dilate=dilation)
+        # set by SEDT: its input_proj returns the feature-map gradient already masked by [feature > 0]
+        self.premasked_consumer = False
 
     def _make_layer(self, planes, blocks, stride=1, dilate=False):
         prev = self.dilation
@@ -85,8 +87,10 @@ class ResNet50Body(nn.Module):
             layers.append(Bottleneck(self.inplanes, planes, dilation=self.dilation))
         return nn.Sequential(*layers)
 
-    def forward(self, x):
-        """x (B,1,T,F) f32 -> feature map (B,2048,H,W) in the compute dtype, channels-last strides (NHWC memory)"""
+    def forward(self, x, premasked=False):
+        """x (B,1,T,F) f32 -> feature map (B,2048,H,W) in the compute dtype, channels-last strides (NHWC memory).
+        premasked: the caller promises that the gradient it returns for the feature map is already multiplied by
+        [feature > 0] (SEDT.input_proj does, fused in its dgrad epilogue)"""
         if not x.is_cuda:
             raise RuntimeError('the SEDT backbone runs on the MI355X HIP path only (no CPU fallback)')
         dt = runtime.compute_dtype()
@@ -96,7 +100,10 @@ class ResNet50Body(nn.Module):
         H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1              # maxpool 3x3 s2 p1
         for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
             blocks = [b.cfg for b in layer]
-            meta = dict(dt=dt, B=B, H=H, W=W, blocks=blocks, mask_input=li > 0)
+            # consumers of a stage output (the next stage, or SEDT.input_proj) return gradients already masked by the
+            # stage's final ReLU, so the stage backward need not mask again (premasked=False -> standalone use)
+            meta = dict(dt=dt, B=B, H=H, W=W, blocks=blocks, mask_input=li > 0,
+                        grad_premasked=True if li < 3 else (premasked or self.premasked_consumer))
             ts = [t for b in layer for t in b.tensors()]
             tok = Fn.StageFn.apply(tok, meta, *ts)
             for c in blocks:

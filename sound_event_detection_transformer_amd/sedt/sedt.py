@@ -24,11 +24,13 @@ class HipLinear(nn.Linear):
 class HipConv1x1(nn.Conv2d):
     """1x1 nn.Conv2d (input_proj, sedt.py:36) as a GEMM over NHWC tokens; returns (B,Cout,H,W) with channels-last strides"""
 
+    relu_input = False      # SEDT sets it: the input is the backbone's post-ReLU feature map (see ResNet50Body.forward)
+
     def forward(self, x):
         B, C, H, W = x.shape
         tok = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
         y = Fn.LinearFn.apply(tok, self.weight.view(self.out_channels, self.in_channels), self.bias, ACT_NONE, False,
-                              runtime.compute_dtype())
+                              runtime.compute_dtype(), self.relu_input)
         return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
 
 
@@ -62,6 +64,12 @@ class SEDT(nn.Module):
         self.bbox_embed = MLP(hidden_dim, hidden_dim, 2, 3)
         self.input_proj = HipConv1x1(backbone.num_channels, hidden_dim, kernel_size=1)
         self.backbone = backbone
+        body = getattr(backbone[0], 'body', None) if isinstance(backbone, nn.Sequential) else None
+        if body is not None and hasattr(body, 'premasked_consumer'):
+            # contract between the two modules: input_proj's dgrad epilogue applies the ReLU mask of layer4's output,
+            # so layer4's backward skips its own masking pass
+            self.input_proj.relu_input = True
+            body.premasked_consumer = True
         self.aux_loss = aux_loss
         self.dec_at = dec_at
         self.pooling = pooling
