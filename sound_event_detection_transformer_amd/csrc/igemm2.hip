@@ -19,6 +19,7 @@
 namespace sedt {
 
 int wgrad2_try(const SedtIgemm& p, hipStream_t st);   // wgrad2.hip
+int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, int bn, hipStream_t st);   // igemm3.hip
 
 template <int BM, int BN, int STAGES>
 __global__ __launch_bounds__(256) void igemm2_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes,
@@ -293,6 +294,10 @@ int igemm2_try(const SedtIgemm& p, hipStream_t st) {
     bm = 64; bn = 64;
     // gathered (3x3) convs amortise the A gather over a wider N tile when enough tiles remain to fill the chip
     if (p.conv && p.KH * p.KW > 1 && (p.N % 128) == 0 && (long)((p.M + 63) / 64) * (p.N / 128) >= 500) bn = 128;
+  }
+  {   // the lean-issue kernel takes the common cases
+    int r3 = igemm3_try(p, (unsigned)a_bytes, (unsigned)b_bytes, bm, bn, st);
+    if (r3 >= 0) return r3;
   }
   static int stages = -1;
   if (stages < 0) {
