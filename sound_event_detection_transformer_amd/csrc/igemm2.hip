@@ -292,8 +292,9 @@ int igemm2_try(const SedtIgemm& p, hipStream_t st) {
   // 2-stage ring (32 KB LDS, 5 workgroups per CU) wins or ties; SEDT_IGEMM_STAGES / tile_m override for experiments
   if (bm == 0 || bn == 0) {
     bm = 64; bn = 64;
-    // gathered (3x3) convs amortise the A gather over a wider N tile when enough tiles remain to fill the chip
-    if (p.conv && p.KH * p.KW > 1 && (p.N % 128) == 0 && (long)((p.M + 63) / 64) * (p.N / 128) >= 500) bn = 128;
+    // measured with the lean-issue kernel (tools/tune_igemm.py): the wider N tile (one A fragment feeds two MFMAs) wins
+    // once K is deep and enough tiles remain to fill the chip; everything else prefers the 64x64 tile's occupancy
+    if ((p.N % 128) == 0 && p.K >= 512 && (long)((p.M + 63) / 64) * (p.N / 128) >= 500) bn = 128;
   }
   {   // the lean-issue kernel takes the common cases
     int r3 = igemm3_try(p, (unsigned)a_bytes, (unsigned)b_bytes, bm, bn, st);

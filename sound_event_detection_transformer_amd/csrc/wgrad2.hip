@@ -13,6 +13,8 @@
 
 namespace sedt {
 
+int wgrad3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st);   // wgrad3.hip
+
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -212,6 +214,10 @@ int wgrad2_try(const SedtIgemm& p, hipStream_t st) {
   long b_rows = p.conv ? (long)((p.K + (long)p.Ho * p.Wo - 1) / ((long)p.Ho * p.Wo)) * p.Hi * p.Wi : (long)p.K;
   long b_bytes = ((b_rows - 1) * p.ldb + (p.conv ? p.Ci : p.N)) * 2;
   if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31) || a_bytes <= 0 || b_bytes <= 0) return -1;
+  {   // the lean-issue kernel takes the common cases
+    int r3 = wgrad3_try(p, (unsigned)a_bytes, (unsigned)b_bytes, st);
+    if (r3 >= 0) return r3;
+  }
   static int stages = -1;
   if (stages < 0) {
     const char* e = getenv("SEDT_WGRAD_STAGES");
