@@ -12,8 +12,8 @@
 //   * the wave id is made uniform once (readfirstlane), so every LDS-DMA destination / M0 value is scalar arithmetic;
 //   * fragment read offsets are per-thread constants; the loop is unrolled by the ring depth so the stage base is an
 //     instruction immediate.
-// Envelope: trans == 0, bf16, K % 64 == 0, forward gather or stride-1 dgrad gather with <= 32 taps; everything else
-// (strided dgrad, tails, f32 output) stays on igemm2 / igemm.
+// Envelope: trans == 0, bf16, K % 64 == 0, forward or dgrad gather (square stride) with <= 32 taps; everything else
+// (K tails, f32 output, sigmoid) stays on igemm2 / igemm.
 #include <stdlib.h>
 #include <type_traits>
 #include "igemm2_common.h"
@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void igemm3_kernel(const SedtIgemm p, const un
   // ---- per-lane DMA rows
   const int lrow = lane >> 3, pc = lane & 7;
   const int taps = p.conv ? p.KH * p.KW : 1;
-  const int sg = (p.conv && p.transposed) ? -1 : 1;       // stride-1 dgrad: the tap shift is subtracted
+  const int sg = (p.conv && p.transposed) ? -1 : 1;       // dgrad: the tap shift is subtracted
+  const long tsub = (p.conv && p.transposed) ? p.lda / p.sh : p.lda;   // elements per (sub-)pixel step, see below
   unsigned a_off[GA], a_mask[GA];
 #pragma unroll
   for (int i = 0; i < GA; ++i) {
@@ -65,12 +66,21 @@ __global__ __launch_bounds__(256) void igemm3_kernel(const SedtIgemm p, const un
       const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
       const int hb = p.transposed ? ho + p.ph : ho * p.sh - p.ph;
       const int wb = p.transposed ? wo + p.pw : wo * p.sw - p.pw;
-      off = (((long)n * p.Hi + hb) * p.Wi + wb) * p.lda + swz;
+      // forward: pixel (hb + kh*dh, wb + kw*dw).  dgrad (transposed): pixel ((hb - kh*dh)/s, (wb - kw*dw)/s) where both
+      // divide; its byte offset is [(hb - kh*dh)*Wi + (wb - kw*dw)] * (pitch/s) - the division cancels against the pixel
+      // pitch - so "lane base + wave-uniform tap delta" holds for strided dgrads too (tsub = pitch/s in elements).
+      off = ((long)n * p.Hi * p.Wi) * p.lda + ((long)hb * p.Wi + wb) * tsub + swz;
       if (row < p.M)
         for (int tp = 0; tp < taps; ++tp) {
           const int kh = tp / p.KW, kw = tp - kh * p.KW;
-          const int hi = hb + sg * kh * p.dh, wi = wb + sg * kw * p.dw;
-          if ((unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi) mask |= 1u << tp;
+          int hi = hb + sg * kh * p.dh, wi = wb + sg * kw * p.dw;
+          bool ok = hi >= 0 && wi >= 0;
+          if (p.transposed) {
+            ok = ok && (hi % p.sh) == 0 && (wi % p.sw) == 0;
+            hi /= p.sh;
+            wi /= p.sw;
+          }
+          if (ok && hi < p.Hi && wi < p.Wi) mask |= 1u << tp;
         }
     } else {
       off = (long)row * p.lda + swz;
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(256) void igemm3_kernel(const SedtIgemm p, const un
   // ---- wave-uniform K position: channel offset inside the tap, tap index, its pixel shift in bytes
   int c0 = 0, tap = 0, kh = 0, kw = 0, k0 = 0;
   int tapdelta = 0;
-  const int rowbytes = (int)(p.lda * 2);
+  const int rowbytes = (int)(tsub * 2);
   auto advance = [&]() {
     k0 += BK2;
     c0 += BK2;
@@ -282,7 +292,7 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
   }
   if (!on) return -1;
   if (p.K % BK2) return -1;
-  if (p.conv && (p.KH * p.KW > 32 || (p.transposed && (p.sh != 1 || p.sw != 1)))) return -1;
+  if (p.conv && (p.KH * p.KW > 32 || (p.transposed && (p.sh != p.sw || (p.lda % p.sh) != 0)))) return -1;
   if ((reinterpret_cast<uintptr_t>(p.scale) & 15) || (reinterpret_cast<uintptr_t>(p.bias) & 15)) return -1;
   if (bm == 64 && bn == 64) return launch3<64, 64>(p, a_bytes, b_bytes, st);
   if (bm == 64 && bn == 128) return launch3<64, 128>(p, a_bytes, b_bytes, st);
