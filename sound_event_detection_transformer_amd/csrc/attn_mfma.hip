@@ -50,7 +50,7 @@ __device__ __forceinline__ bf16x8 frag_cols_tr(const unsigned char* img, int bas
   const unsigned char* p = img + (base16 + 4 * h + (s16 >> 2)) * AROW + (16 * dgrp + 4 * (s16 & 3)) * 2;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)p);
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(p + 8 * AROW));
-  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);   // register concatenation, no ALU
   return __builtin_bit_cast(bf16x8, v);
 }
 

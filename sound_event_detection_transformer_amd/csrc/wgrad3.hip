@@ -20,7 +20,8 @@ typedef __attribute__((address_space(3))) w3_s16x4 w3_lds_s16x4;
 __device__ __forceinline__ int w3_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 template <int BN>   // BM = 64 output channels, BN = 64 or 128 columns of (tap, cin)
-__global__ __launch_bounds__(256) void wgrad3_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes) {
+__global__ __launch_bounds__(256) void wgrad3_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes,
+                                                     const int nmajor) {
   constexpr int BM = 64, BKP = 64;
   constexpr int NI = BN / 64;                         // 32-wide column tiles per wave (wave tile 32 x BN/2)
   constexpr int A_BYTES = BKP * ROWB;                 // dY image: 64 pixels x 64 channels
@@ -40,7 +41,11 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(const SedtIgemm p, const un
     const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
     vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
-  const int m0 = (vid / ntn) * BM, n0 = (vid % ntn) * BN;
+  // an XCD owns a contiguous run of tile ids.  When X (the N side: taps*Cin columns) is the larger operand, give each XCD
+  // a few column tiles x all channel tiles (n-major) so X is streamed from HBM once in total instead of once per XCD.
+  int m0, n0;
+  if (nmajor) { n0 = (vid / ntm) * BN; m0 = (vid % ntm) * BM; }
+  else { m0 = (vid / ntn) * BM; n0 = (vid % ntn) * BN; }
 
   const int nkb_total = (p.K + BKP - 1) / BKP;
   int kb_begin = 0, kb_end = nkb_total;
@@ -167,11 +172,11 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(const SedtIgemm p, const un
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const w3_s16x4 a0 = tr(st + a_rd[ks][0]), a1 = tr(st + a_rd[ks][1]);
-      w3_s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      const w3_s16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);   // register concatenation, no ALU
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const w3_s16x4 b0 = tr(st + b_rd[ks][j][0]), b1 = tr(st + b_rd[ks][j][1]);
-        w3_s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        const w3_s16x8 bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[j], 0, 0, 0);
       }
     }
@@ -249,7 +254,13 @@ static int launch_wgrad3(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes,
     attr_set = true;
   }
   const int nwg = ((p.N + BN - 1) / BN) * ((p.M + 63) / 64);
-  hipLaunchKernelGGL(kern, dim3(nwg, p.splitk > 1 ? p.splitk : 1), dim3(256), lds, st, p, a_bytes, b_bytes);
+  static int force = -2;
+  if (force == -2) {
+    const char* e = getenv("SEDT_WGRAD_NMAJOR");
+    force = e ? atoi(e) : -1;
+  }
+  const int nmajor = force >= 0 ? force : (p.N > p.M ? 1 : 0);
+  hipLaunchKernelGGL(kern, dim3(nwg, p.splitk > 1 ? p.splitk : 1), dim3(256), lds, st, p, a_bytes, b_bytes, nmajor);
   return check_launch("wgrad3");
 }
 
