@@ -22,7 +22,7 @@ namespace sedt {
 
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <int BM, int BN>
+template <int BM, int BN, int S>   // S = ring depth (stages)
 __global__ __launch_bounds__(256) void igemm3_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes) {
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int STAGE_BYTES = (BM + BN) * ROWB;
@@ -173,24 +173,31 @@ __global__ __launch_bounds__(256) void igemm3_kernel(const SedtIgemm p, const un
     }
   };
 
-  // ---- 2-stage pipeline, unrolled by the ring depth
-  if (nkb > 0) issue(0);
+  // ---- S-stage pipeline, unrolled by the ring depth (stage indices are literals after unrolling).  A wave waits only for
+  //      its own oldest tile: (S-2) later tiles x G DMA instructions may stay in flight.
+  constexpr int G = GA + GB;
+#pragma unroll
+  for (int s0 = 0; s0 < S - 1; ++s0)
+    if (s0 < nkb) issue(s0);
   int it = 0;
-  for (; it + 2 <= nkb; it += 2) {          // full pairs: straight-line body, one back-edge (keeps acc in place)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    issue(1);
-    compute(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (it + 2 < nkb) issue(0);
-    compute(1);
+  for (; it + S <= nkb; it += S) {
+#pragma unroll
+    for (int ph = 0; ph < S; ++ph) {
+      const bool more = it + ph + S - 1 < nkb;
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (more) issue((ph + S - 1) % S);
+      compute(ph);
+    }
   }
-  if (it < nkb) {                            // odd tail
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    compute(0);
-  }
+#pragma unroll
+  for (int ph = 0; ph < S - 1; ++ph)
+    if (it + ph < nkb) {                     // tail: already issued, nothing left to prefetch
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      compute(ph);
+    }
   __builtin_amdgcn_s_barrier();
 
   // ---- epilogue through LDS (identical to igemm2)
@@ -263,13 +270,13 @@ __global__ __launch_bounds__(256) void igemm3_kernel(const SedtIgemm p, const un
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int S>
 static int launch3(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
-  constexpr size_t ring = (size_t)2 * (BM + BN) * ROWB;
+  constexpr size_t ring = (size_t)S * (BM + BN) * ROWB;
   constexpr size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);
   constexpr size_t lds = ring > ctile ? ring : ctile;
   static bool attr_set = false;
-  auto kern = igemm3_kernel<BM, BN>;
+  auto kern = igemm3_kernel<BM, BN, S>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
@@ -294,10 +301,28 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
   if (p.K % BK2) return -1;
   if (p.conv && (p.KH * p.KW > 32 || (p.transposed && (p.sh != p.sw || (p.lda % p.sh) != 0)))) return -1;
   if ((reinterpret_cast<uintptr_t>(p.scale) & 15) || (reinterpret_cast<uintptr_t>(p.bias) & 15)) return -1;
-  if (bm == 64 && bn == 64) return launch3<64, 64>(p, a_bytes, b_bytes, st);
-  if (bm == 64 && bn == 128) return launch3<64, 128>(p, a_bytes, b_bytes, st);
-  if (bm == 128 && bn == 64) return launch3<128, 64>(p, a_bytes, b_bytes, st);
-  if (bm == 128 && bn == 128) return launch3<128, 128>(p, a_bytes, b_bytes, st);
+  static int stages = -1;
+  if (stages < 0) {
+    const char* e = getenv("SEDT_IGEMM3_STAGES");
+    stages = e ? atoi(e) : 0;
+  }
+  int S = stages;
+  if (S == 0) {
+    // deep-K problems with few workgroups per CU cannot hide the DMA latency by occupancy: give them a deeper ring
+    const long nwg = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+    S = (p.K >= 1024 && nwg <= 3 * 256) ? 3 : 2;
+  }
+#define SEDT_L3(BM_, BN_)                                                      \
+  if (bm == BM_ && bn == BN_) {                                                \
+    if (S == 3) return launch3<BM_, BN_, 3>(p, a_bytes, b_bytes, st);          \
+    if (S == 4 && BM_ + BN_ <= 192) return launch3<BM_, BN_, 4>(p, a_bytes, b_bytes, st); \
+    return launch3<BM_, BN_, 2>(p, a_bytes, b_bytes, st);                      \
+  }
+  SEDT_L3(64, 64)
+  SEDT_L3(64, 128)
+  SEDT_L3(128, 64)
+  SEDT_L3(128, 128)
+#undef SEDT_L3
   return -1;
 }
 
