@@ -245,6 +245,48 @@ int sedt_multi_sumsq(const SedtChunk* table, int nchunks, float* partial, float*
 int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float* sumsq, float max_norm, float beta1, float beta2,
                      float eps, const int32_t* step_ptr /* device: 1-based step count */, void* stream);
 
+/* ------------------------------------------------------------------ device half of SetCriterion (sedt/sedt.py:161-283)
+ * After the host matching the targets are dense: for dense layer d (0 = final decoder layer, d>=1 = aux layer d-1),
+ * strong clip b < ns, query q: tc = target class (as f32), coef = CE weight multiplier, wbox = box-loss weight (0 =
+ * unmatched), tbox = target (centre, length).  logits [L][B][Q][C+1] / boxes [L][B][Q][2] are the model's stacked head
+ * outputs; layer_of[d] is the slice that dense layer d reads.  One launch writes
+ *   out[4d+0..3] = loss_ce, loss_bbox, loss_giou, cardinality_error of dense layer d (unweighted, as the reference logs)
+ *   out[4L] = class-error hits, out[4L+1] = matched count, out[4L+2] = loss_weak,
+ *   out[4L+3] = weighted total (sum_k weight_k * loss_k), out[4L+4] = class_error
+ * and the UNWEIGHTED per-term gradients: dlogits = d loss_ce_d / d logits, dboxes = d loss_bbox_d / d boxes, dboxes2 =
+ * d loss_giou_d / d boxes (each layer slice holds the gradient of its own layer's loss), dat = d loss_weak / d at.
+ * at / gt_weak / dat may be null together (model without audio-tag head).
+ * sedt_set_criterion_bwd combines them with the gradient g[4L+5] that reached `out`:
+ *   glogits = (g[4d] + g[4L+3] w_ce[d]) dlogits,  gboxes = (g[4d+1] + g[4L+3] w_bbox[d]) dboxes + (g[4d+2] + ...) dboxes2,
+ *   gat = (g[4L+2] + g[4L+3] w_weak) dat. */
+#define SEDT_CRIT_MAXL 8
+#define SEDT_CRIT_MAXOUT (4 * SEDT_CRIT_MAXL + 5)
+typedef struct SedtCriterion {
+  const float* logits;
+  const float* boxes;
+  const float* at;       /* [Bat][C] probabilities, rows < n_lab are labelled */
+  const float* tc;       /* [L][ns][Q] */
+  const float* coef;     /* [L][ns][Q] */
+  const float* wbox;     /* [L][ns][Q] */
+  const float* tbox;     /* [L][ns][Q][2] */
+  const float* gt_weak;  /* [n_lab][C] */
+  const float* tgt_len;  /* [B] */
+  const float* num_boxes;    /* [1] */
+  const float* empty_weight; /* [C+1] */
+  float* dlogits;
+  float* dboxes;
+  float* dboxes2;
+  float* dat;
+  float* out; /* [4L+5] */
+  int32_t L, B, ns, Q, C, n_lab, Bat;
+  int32_t layer_of[SEDT_CRIT_MAXL];
+  float w_ce[SEDT_CRIT_MAXL], w_bbox[SEDT_CRIT_MAXL], w_giou[SEDT_CRIT_MAXL];
+  float w_weak;
+} SedtCriterion;
+int sedt_set_criterion(const SedtCriterion* args, void* stream);
+int sedt_set_criterion_bwd(const SedtCriterion* args, const float* g, float* glogits, float* gboxes, float* gat,
+                           void* stream);
+
 /* ------------------------------------------------------------------ host-side matching (sedt/matcher.py:95)
  * HOST pointers.  cost [nlayers][nclips][Q][Nt] f32; clip b owns columns [col_off[b], col_off[b]+ncols[b]).
  * assign [nlayers][nclips][Q]: index (within the clip) of the target matched to query q, or -1.

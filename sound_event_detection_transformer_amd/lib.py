@@ -41,6 +41,17 @@ class SedtReduceJob(C.Structure):
                 ('blk0', C.c_int32), ('pad_', C.c_int32)]
 
 
+CRIT_MAXL = 8
+
+
+class SedtCriterion(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('logits', 'boxes', 'at', 'tc', 'coef', 'wbox', 'tbox', 'gt_weak', 'tgt_len',
+                                           'num_boxes', 'empty_weight', 'dlogits', 'dboxes', 'dboxes2', 'dat', 'out')] + \
+               [(n, C.c_int32) for n in ('L', 'B', 'ns', 'Q', 'C', 'n_lab', 'Bat')] + \
+               [('layer_of', C.c_int32 * CRIT_MAXL), ('w_ce', C.c_float * CRIT_MAXL), ('w_bbox', C.c_float * CRIT_MAXL),
+                ('w_giou', C.c_float * CRIT_MAXL), ('w_weak', C.c_float)]
+
+
 MAX_REDUCE_JOBS = 40
 _vp, _i, _i64, _f, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32, C.c_size_t
 
@@ -84,6 +95,8 @@ SIGNATURES = {
     'sedt_multi_gather': (_i, [_vp, _i, _vp]),
     'sedt_multi_sumsq': (_i, [_vp, _i, _vp, _vp, _vp]),
     'sedt_multi_adamw': (_i, [_vp, _i, _vp, _f, _f, _f, _f, _vp, _vp]),
+    'sedt_set_criterion': (_i, [C.POINTER(SedtCriterion), _vp]),
+    'sedt_set_criterion_bwd': (_i, [C.POINTER(SedtCriterion), _vp, _vp, _vp, _vp, _vp]),
     'sedt_hungarian_batch': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sedt_adamw_clip': (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _i, _vp]),
 }

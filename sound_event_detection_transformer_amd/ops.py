@@ -367,3 +367,44 @@ def sumsq(g, out, accumulate=False):
 def adamw_clip(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, weight_decay, step):
     L.check(L.load().sedt_adamw_clip(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(sumsq_t), max_norm, lr, beta1, beta2, eps,
                                      weight_decay, step, L.stream_ptr()), 'adamw_clip')
+
+
+def set_criterion(logits, boxes, at, dense, empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak):
+    """device half of SetCriterion in one launch (csrc/criterion.hip).  logits [L,B,Q,C+1], boxes [L,B,Q,2], at [Bat,C] or
+    None - all f32 contiguous; dense = SetCriterion.dense_views(...).  Returns (out[4L+5], state); state feeds
+    set_criterion_bwd."""
+    _dev_check(logits, boxes)
+    Lh, B, Q, C1 = logits.shape
+    assert logits.dtype == torch.float32 and boxes.dtype == torch.float32 and logits.is_contiguous() and boxes.is_contiguous()
+    assert boxes.shape == (Lh, B, Q, 2) and Lh <= L.CRIT_MAXL and len(layer_of) == Lh
+    a = L.SedtCriterion()
+    dl, db, db2 = torch.empty_like(logits), torch.empty_like(boxes), torch.empty_like(boxes)
+    dat = None
+    out = torch.empty(4 * Lh + 5, device=logits.device, dtype=torch.float32)
+    a.logits, a.boxes, a.out = logits.data_ptr(), boxes.data_ptr(), out.data_ptr()
+    a.dlogits, a.dboxes, a.dboxes2 = dl.data_ptr(), db.data_ptr(), db2.data_ptr()
+    for k in ('tc', 'coef', 'wbox', 'tbox', 'tgt_len', 'num_boxes'):
+        setattr(a, k, dense[k].data_ptr())
+    a.empty_weight = empty_weight.data_ptr()
+    a.L, a.B, a.ns, a.Q, a.C, a.n_lab = Lh, B, dense['ns'], Q, C1 - 1, dense['n_lab']
+    assert dense['tgt_len'].numel() == B and dense['L'] == Lh and empty_weight.is_cuda and empty_weight.numel() == C1
+    if at is not None:
+        assert at.dtype == torch.float32 and at.is_contiguous() and at.dim() == 2 and at.shape[1] == C1 - 1
+        dat = torch.empty_like(at)
+        a.at, a.dat, a.gt_weak, a.Bat = at.data_ptr(), dat.data_ptr(), dense['gt_weak'].data_ptr(), at.shape[0]
+        assert dense['n_lab'] <= at.shape[0]
+    for i in range(Lh):
+        a.layer_of[i], a.w_ce[i], a.w_bbox[i], a.w_giou[i] = layer_of[i], w_ce[i], w_bbox[i], w_giou[i]
+    a.w_weak = w_weak
+    L.check(L.load().sedt_set_criterion(a, L.stream_ptr()), 'set_criterion')
+    return out, (a, dl, db, db2, dat)
+
+
+def set_criterion_bwd(state, g):
+    """gradients of (logits, boxes, at) given the gradient g[4L+5] of the loss vector"""
+    a, dl, db, db2, dat = state
+    g = g.contiguous().float()
+    gl, gb = torch.empty_like(dl), torch.empty_like(db)
+    gat = None if dat is None else torch.empty_like(dat)
+    L.check(L.load().sedt_set_criterion_bwd(a, _p(g), _p(gl), _p(gb), _p(gat), L.stream_ptr()), 'set_criterion_bwd')
+    return gl, gb, gat

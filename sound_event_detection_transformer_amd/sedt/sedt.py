@@ -135,6 +135,7 @@ class SEDT(nn.Module):
         out['pred_boxes'] = outputs_coord[-1]
         if self.aux_loss:
             out['aux_outputs'] = self._set_aux_loss(outputs_class, outputs_coord)
+            out['_stacked'] = (outputs_class, outputs_coord)      # all decoder layers, for the fused criterion kernel
         return out
 
     def _set_aux_loss(self, outputs_class, outputs_coord):
@@ -147,6 +148,27 @@ class SEDT(nn.Module):
 import torch.nn.functional as F  # noqa: E402
 
 from ..utilities import box_ops  # noqa: E402
+
+
+class _CriterionFn(torch.autograd.Function):
+    """autograd node around ops.set_criterion / set_criterion_bwd: forward computes the loss vector and every per-term
+    gradient; backward combines them with the gradient that reached the vector (weighted total and/or single entries)."""
+
+    @staticmethod
+    def forward(ctx, logits_all, boxes_all, at, dense, empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak):
+        from .. import ops
+        out, ctx.state = ops.set_criterion(logits_all.detach().float().contiguous(), boxes_all.detach().float().contiguous(),
+                                           None if at is None else at.detach().float().contiguous(), dense,
+                                           empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak)
+        ctx.dts = (logits_all.dtype, boxes_all.dtype, None if at is None else at.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import ops
+        gl, gb, gat = ops.set_criterion_bwd(ctx.state, g)
+        return (gl.to(ctx.dts[0]), gb.to(ctx.dts[1]), None if gat is None else gat.to(ctx.dts[2]),
+                None, None, None, None, None, None, None)
 
 
 class SetCriterion(nn.Module):
@@ -264,7 +286,52 @@ class SetCriterion(nn.Module):
                 'num_boxes': d[-1:], 'ns': ns, 'n_lab': n_lab, 'L': L, '_pack': d, '_meta': meta}
 
     # ------------------------------------------------------------------ device part (fixed shapes)
+    def _weights(self, name, L):
+        return [float(self.weight_dict.get(name if d == 0 else f'{name}_{d - 1}', 0.0)) for d in range(L)]
+
+    def _compute_fused(self, outputs, dense):
+        """all losses + their gradients in ONE launch (csrc/criterion.hip) when the model handed over its stacked head
+        outputs; the dict returned has the same keys / values as the op-by-op path below."""
+        logits_all, boxes_all = outputs['_stacked']
+        L = dense['L']
+        at = outputs['at'] if ('weak' in self.losses and 'at' in outputs) else None
+        if at is not None and at.dim() == 1:
+            at = at[None]
+        zero = [0.0] * L
+        ew = self.empty_weight
+        if ew.device != logits_all.device or ew.dtype != torch.float32:      # criterion left on the CPU: upload once
+            key = ('ew', str(logits_all.device))
+            if key not in self._wvec:
+                self._wvec[key] = ew.detach().to(logits_all.device, torch.float32)
+            ew = self._wvec[key]
+        vec = _CriterionFn.apply(
+            logits_all, boxes_all, at, dense, ew, [L - 1] + list(range(L - 1)),
+            self._weights('loss_ce', L) if 'labels' in self.losses else zero,
+            self._weights('loss_bbox', L) if 'boxes' in self.losses else zero,
+            self._weights('loss_giou', L) if 'boxes' in self.losses else zero,
+            float(self.weight_dict.get('loss_weak', 0.0)) if at is not None else 0.0)
+        out = {}
+        names = []
+        if 'labels' in self.losses:
+            names.append((0, 'loss_ce'))
+            out['class_error'] = vec[4 * L + 4].detach()
+        if 'boxes' in self.losses:
+            names += [(1, 'loss_bbox'), (2, 'loss_giou')]
+        if 'cardinality' in self.losses:
+            names.append((3, 'cardinality_error'))
+        for slot, k in names:
+            for d in range(L):
+                v = vec[4 * d + slot]
+                out[k if d == 0 else f'{k}_{d - 1}'] = v.detach() if slot == 3 else v
+        if at is not None:
+            out['loss_weak'] = vec[4 * L + 2]
+        self.last_total = vec[4 * L + 3]
+        return out
+
     def compute(self, outputs, dense):
+        if '_stacked' in outputs and outputs['pred_logits'].is_cuda and 'feature' not in self.losses \
+                and outputs['_stacked'][0].shape[0] == dense['L'] <= 8:
+            return self._compute_fused(outputs, dense)
         layers = [outputs] + list(outputs.get('aux_outputs', []))
         L, ns, nb = dense['L'], dense['ns'], dense['num_boxes']
         C1 = self.num_classes + 1

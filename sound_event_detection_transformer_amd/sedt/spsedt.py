@@ -73,4 +73,5 @@ class SPSEDT(SEDT):
             if self.aux_loss:
                 out['aux_outputs'] = [{'pred_logits': a, 'pred_boxes': b}
                                       for a, b in zip(outputs_class[:-1], outputs_coord[:-1])]
+                out['_stacked'] = (outputs_class, outputs_coord)
         return out
