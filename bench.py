@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 A step = one full training step of BASELINE.json configs[1] (URBAN-SED SEDT, enc_layers=3, dec_at, num_queries=10,
-B=64 per GPU, bf16): forward on the HIP path, host SetCriterion + Hungarian matching, backward on the HIP path,
+B=64 per GPU, bf16): forward on the HIP path, Hungarian matching + SetCriterion (on the device inside the step's HIP
+graph by default; --host-matching keeps the reference's host-side matching), backward on the HIP path,
 clip_grad_norm_(0.1), AdamW - with dropout 0.1 active.  Inputs are resident in HBM before the timed region.
 Prints ONE JSON line (rank 0) with the `roofline` (dominant kernel: the MFMA implicit GEMM, timed live with HIP events
 on the launch stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores, bounded sample) objects.
@@ -26,14 +27,8 @@ MFMA_PEAK_F32 = 157.3e12
 
 
 def synthetic_batch(B, T, seed, device):
-    from oracle.criterion_oracle import synthetic_targets       # data generator only (no arithmetic of the path)
-    g = torch.Generator().manual_seed(seed)
-    x = torch.randn(B, 1, T, 64, generator=g)
-    targets = synthetic_targets(B, seed + 1, 10)
-    if device is not None:
-        x = x.to(device)
-        targets = [{k: v.to(device) for k, v in t.items()} for t in targets]
-    return x, targets
+    from sound_event_detection_transformer_amd.utilities.synthetic import synthetic_batch as sb
+    return sb(B, T, seed, device)
 
 
 def cpu_baseline(batch=8, steps=2):
@@ -42,7 +37,7 @@ def cpu_baseline(batch=8, steps=2):
     from oracle.criterion_oracle import build_oracle_criterion
     cores = torch.get_num_threads()
     model = O.build_oracle_model(10, 10, 3, 3, True, True, True, dropout=0.1)
-    model.load_state_dict(O.seeded_state_dict(model.state_dict(), 2020))
+    model.load_state_dict(seeded_state_dict(model.state_dict(), 2020))
     model.train()
     crit = build_oracle_criterion(10, 3, True, True)
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
@@ -73,6 +68,8 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dump-igemm', default=None, help='write per-launch igemm timings (json) to this path')
+    ap.add_argument('--host-matching', action='store_true',
+                    help='solve the Hungarian matching on the host between two HIP graphs (the reference split) instead of on the device')
     ap.add_argument('--no-graph', action='store_true', help='issue every kernel from Python instead of replaying HIP graphs')
     ap.add_argument('--model-only', action='store_true', help='time fwd+bwd of the model with a fixed differentiable loss')
     args = ap.parse_args()
@@ -92,12 +89,12 @@ def main():
     from sound_event_detection_transformer_amd import runtime, ops
     from sound_event_detection_transformer_amd.sedt import build_model, default_args
     from sound_event_detection_transformer_amd.engine import train_step, build_optimizer
-    from oracle import sedt_oracle as O       # seeded_state_dict only: canonical deterministic weights
+    from sound_event_detection_transformer_amd.utilities.synthetic import seeded_state_dict
 
     runtime.set_compute_dtype(args.dtype)
     torch.manual_seed(2020)
     model, criterion, _ = build_model(default_args(enc_layers=3, num_queries=10, dec_at=True, dropout=0.1))
-    model.load_state_dict(O.seeded_state_dict(model.state_dict(), 2020))
+    model.load_state_dict(seeded_state_dict(model.state_dict(), 2020))
     model.to(dev).train()
     criterion.to(dev)
     net = model
@@ -112,7 +109,8 @@ def main():
     from sound_event_detection_transformer_amd.engine import GraphedTrainStep
     graphed = None
     if not args.no_graph and not args.model_only:
-        graphed = GraphedTrainStep(net, criterion, opt, x, targets, None, slice(B), max_norm=0.1)
+        graphed = GraphedTrainStep(net, criterion, opt, x, targets, None, slice(B), max_norm=0.1,
+                                   device_matching=not args.host_matching)
 
     def step():
         if graphed is not None and ops.PROFILE is None:
@@ -174,7 +172,8 @@ def main():
                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "URBAN-SED SEDT enc_layers=3 dec_at num_queries=10 B=64/GPU, 10 s @ 64-mel "
-                                      "(B,1,500,64), full train step: fwd + host SetCriterion/Hungarian + bwd + clip 0.1 + AdamW, dropout 0.1"
+                                      "(B,1,500,64), full train step: fwd + Hungarian matching (" + ("host" if (args.host_matching or args.no_graph) else "device") +
+                                      ") + SetCriterion + bwd + clip 0.1 + AdamW, dropout 0.1"
                                       + (" [model-only timing]" if args.model_only else ""),
                           "global_batch": world * B, "parallelism": f"dp{world}"},
                "roofline": roof, "cpu_baseline": cpu, "hip_graph": graphed is not None}

@@ -261,6 +261,7 @@ int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float* sumsq, fl
  *   gat = (g[4L+2] + g[4L+3] w_weak) dat. */
 #define SEDT_CRIT_MAXL 8
 #define SEDT_CRIT_MAXOUT (4 * SEDT_CRIT_MAXL + 5)
+#define SEDT_CRIT_MAXCARD 8192 /* limit on L * B */
 typedef struct SedtCriterion {
   const float* logits;
   const float* boxes;
@@ -271,7 +272,7 @@ typedef struct SedtCriterion {
   const float* tbox;     /* [L][ns][Q][2] */
   const float* gt_weak;  /* [n_lab][C] */
   const float* tgt_len;  /* [B] */
-  const float* num_boxes;    /* [1] */
+  const float* num_boxes;    /* [1], or null: computed as sum(wbox[0]) */
   const float* empty_weight; /* [C+1] */
   float* dlogits;
   float* dboxes;
@@ -286,6 +287,38 @@ typedef struct SedtCriterion {
 int sedt_set_criterion(const SedtCriterion* args, void* stream);
 int sedt_set_criterion_bwd(const SedtCriterion* args, const float* g, float* glogits, float* gboxes, float* gat,
                            void* stream);
+
+/* ------------------------------------------------------------------ device-side matching (sedt/matcher.py:60-95)
+ * The Hungarian assignment of every (decoder layer, strong clip) and the dense targets sedt_set_criterion reads, in one
+ * launch and without leaving the device (one wave per problem; Q <= 63 queries, <= 63 targets per clip).
+ * Targets arrive concatenated over the batch: lab_cat[lab_off[b] .. lab_off[b+1]) = labels of clip b (all B clips; for a
+ * strong clip the first n_b labels belong to its n_b boxes), box_cat[box_off[b] .. box_off[b+1]) = (centre, length) of
+ * the events of strong clip b < ns, ratio_cat (optional) aligned with lab_cat.  Cost = w_bbox*L1 + w_class*(-p[class])
+ * - w_giou*GIoU; same optimum and tie-breaking as sedt_hungarian_batch.
+ * Outputs: tc/coef/wbox/tidx [L][ns][Q], tbox [L][ns][Q][2], tgt_len [B], gt_weak [n_lab][C] (may be null),
+ * assign [L][ns][Q] int32 (may be null): index of the matched target within its clip or -1.
+ * max_targets: capacity per clip the caller guarantees (LDS sizing; box_off differences must not exceed it). */
+typedef struct SedtMatch {
+  const float* logits;   /* [L][B][Q][C+1] */
+  const float* boxes;    /* [L][B][Q][2] */
+  const int64_t* lab_cat;
+  const int32_t* lab_off; /* [B+1] */
+  const float* box_cat;
+  const int32_t* box_off; /* [ns+1] */
+  const float* ratio_cat; /* or null */
+  float* tc;
+  float* coef;
+  float* wbox;
+  float* tbox;
+  float* tidx;
+  float* tgt_len;
+  float* gt_weak;
+  int32_t* assign;
+  int32_t L, B, ns, Q, C, n_lab, max_targets;
+  int32_t layer_of[SEDT_CRIT_MAXL];
+  float w_class, w_bbox, w_giou;
+} SedtMatch;
+int sedt_match_targets(const SedtMatch* args, void* stream);
 
 /* ------------------------------------------------------------------ host-side matching (sedt/matcher.py:95)
  * HOST pointers.  cost [nlayers][nclips][Q][Nt] f32; clip b owns columns [col_off[b], col_off[b]+ncols[b]).

@@ -17,9 +17,26 @@ __device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
 
 __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion a) {
   __shared__ float red[16][SEDT_CRIT_MAXOUT];
+  __shared__ int card[SEDT_CRIT_MAXCARD];      // predicted-event count of every (dense layer, clip): integer LDS atomics
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int L = a.L, B = a.B, ns = a.ns, Q = a.Q, C1 = a.C + 1, C = a.C;
-  const float nb = a.num_boxes[0];
+  __shared__ float nb_sh;
+  if (a.num_boxes) {
+    if (t == 0) nb_sh = a.num_boxes[0];
+  } else {                                      // num_boxes = sum of the box weights of the final layer (sedt.py:330)
+    float sv = 0.f;
+    for (int i = t; i < ns * Q; i += 1024) sv += a.wbox[i];
+    sv = wave_sum(sv);
+    if (lane == 0) red[wave][0] = sv;
+    __syncthreads();
+    if (t == 0) {
+      float v = 0.f;
+      for (int w = 0; w < 16; ++w) v += red[w][0];
+      nb_sh = v;
+    }
+  }
+  __syncthreads();
+  const float nb = nb_sh;
   const float inv_nb = 1.f / nb;
   float acc[SEDT_CRIT_MAXOUT];
 #pragma unroll
@@ -27,6 +44,8 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
   // output slots: [4*d + 0..3] = ce, bbox, giou, cardinality of dense layer d; then class_error hits, matched count, weak
   const int SLOT_HIT = 4 * L, SLOT_CNT = 4 * L + 1, SLOT_WEAK = 4 * L + 2;
 
+  for (int i = t; i < L * B; i += 1024) card[i] = 0;
+  __syncthreads();
   // ---------------- classification + boxes: one row = (dense layer d, clip b, query q)
   const int nrows = L * B * Q;
   for (int r = t; r < nrows; r += 1024) {
@@ -36,6 +55,11 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
     float* gx = a.dlogits + (((long)ml * B + b) * Q + q) * C1;
     float* gbx = a.dboxes + (((long)ml * B + b) * Q + q) * 2;
     float* gbx2 = a.dboxes2 + (((long)ml * B + b) * Q + q) * 2;
+    float m = -INFINITY;
+    int amax = 0;
+    for (int c = 0; c < C1; ++c)
+      if (x[c] > m) { m = x[c]; amax = c; }
+    if (amax != C) atomicAdd(&card[d * B + b], 1);
     if (b >= ns) {                                                // not strongly labelled: no CE / box loss, zero grads
       for (int c = 0; c < C1; ++c) gx[c] = 0.f;
       gbx[0] = 0.f; gbx[1] = 0.f;
@@ -45,10 +69,6 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
     const long di = ((long)d * ns + b) * Q + q;
     const int tc = (int)a.tc[di];
     const float coef = a.coef[di], wb = a.wbox[di];
-    float m = -INFINITY;
-    int amax = 0;
-    for (int c = 0; c < C1; ++c)
-      if (x[c] > m) { m = x[c]; amax = c; }
     float se = 0.f;
     for (int c = 0; c < C1; ++c) se += __expf(x[c] - m);
     const float lse = m + __logf(se);
@@ -96,21 +116,9 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
     gbx2[1] = gl2;
   }
 
-  // ---------------- cardinality: one (dense layer, clip) per thread iteration, over ALL clips
-  for (int r = t; r < L * B; r += 1024) {
-    const int b = r % B, d = r / B;
-    const int ml = a.layer_of[d];
-    int cnt = 0;
-    for (int q = 0; q < Q; ++q) {
-      const float* x = a.logits + (((long)ml * B + b) * Q + q) * C1;
-      float m = x[0];
-      int am = 0;
-      for (int c = 1; c < C1; ++c)
-        if (x[c] > m) { m = x[c]; am = c; }
-      cnt += am != C;
-    }
-    acc[4 * d + 3] += fabsf((float)cnt - a.tgt_len[b]) / (float)B;
-  }
+  // ---------------- cardinality: |#predicted events - #targets| averaged over ALL clips
+  __syncthreads();
+  for (int r = t; r < L * B; r += 1024) acc[4 * (r / B) + 3] += fabsf((float)card[r] - a.tgt_len[r % B]) / (float)B;
 
   // ---------------- audio-tag BCE (mean over n_lab x C), torch semantics: log clamped at -100, grad denominator >= 1e-12
   if (a.at) {
@@ -172,6 +180,152 @@ __global__ __launch_bounds__(256) void set_criterion_bwd_kernel(const SedtCriter
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Device-side Hungarian matching (reference sedt/matcher.py:60-95 + the target bookkeeping of sedt.py:161-283).
+// One wave per problem (decoder layer, strong clip): the cost matrix (Q queries x n targets, both <= 63) is built in
+// LDS, then the shortest-augmenting-path algorithm with potentials runs with ONE LANE PER COLUMN: the column scan of
+// each step is a single wave-wide min/argmin (ties -> lowest column, as the serial scan of csrc/host.cpp), potentials in
+// double precision like scipy.  The assignment is turned into the dense targets the loss kernel reads, so a training
+// step needs no device->host copy at all and the whole step can live in one HIP graph.
+__device__ __forceinline__ double shfl_d(double v, int src) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl(lo, src, 64);
+  hi = __shfl(hi, src, 64);
+  return __hiloint2double(hi, lo);
+}
+
+// rows (n) <= cols (m) <= 63; cost(i, j) for 0-based row i, column j.  Returns in lane j (1..m) the 1-based row assigned
+// to column j (0 = none).  Every lane of the wave must call this.
+template <typename F>
+__device__ int wave_lsa(int n, int m, F cost) {
+  const int lane = threadIdx.x & 63;
+  const double INF = 1e300;
+  double u = 0.0, v = 0.0;        // lane r: potential of row r (1-based); lane j: potential of column j
+  int p = 0, way = 0;             // lane j: row matched to column j; predecessor column on the alternating path
+  for (int i = 1; i <= n; ++i) {
+    if (lane == 0) p = i;
+    int j0 = 0;
+    double minv = INF;
+    bool used = false, in_rows = false;
+    do {
+      if (lane == j0) used = true;
+      const int i0 = __shfl(p, j0, 64);
+      if (lane == i0) in_rows = true;
+      const double u0 = shfl_d(u, i0);
+      const bool cand = lane >= 1 && lane <= m && !used;
+      if (cand) {
+        const double cur = (double)cost(i0 - 1, lane - 1) - u0 - v;
+        if (cur < minv) { minv = cur; way = j0; }
+      }
+      // delta = min over candidate columns, j1 = lowest column attaining it
+      double best = cand ? minv : INF;
+      int bj = cand ? lane : 64;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double ob = shfl_d(best, lane ^ o);
+        const int oj = __shfl(bj, lane ^ o, 64);
+        if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+      }
+      const double delta = best;
+      if (in_rows) u += delta;
+      if (used) v -= delta; else minv -= delta;
+      j0 = bj;
+    } while (__shfl(p, j0, 64) != 0);
+    do {                          // augment along the path
+      const int j1 = __shfl(way, j0, 64);
+      const int pj1 = __shfl(p, j1, 64);
+      if (lane == j0) p = pj1;
+      j0 = j1;
+    } while (j0);
+  }
+  return p;
+}
+
+__global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  const int L = a.L, B = a.B, ns = a.ns, Q = a.Q, C = a.C, C1 = a.C + 1;
+  if ((int)blockIdx.x == L * ns) {
+    // ---- bookkeeping block: per-clip target counts (cardinality) and the clip-level tag targets (sedt.py:199-209)
+    for (int b = lane; b < B; b += 64) {
+      const int o = a.lab_off[b], n = a.lab_off[b + 1] - o;
+      a.tgt_len[b] = (float)n;
+      if (a.gt_weak && b < a.n_lab) {
+        float* g = a.gt_weak + (long)b * C;
+        for (int c = 0; c < C; ++c) g[c] = 0.f;
+        for (int j = 0; j < n; ++j) g[a.lab_cat[o + j]] += a.ratio_cat ? a.ratio_cat[o + j] : 1.f;
+        for (int c = 0; c < C; ++c) g[c] = fminf(fmaxf(g[c], 0.f), 1.f);
+      }
+    }
+    return;
+  }
+  const int d = blockIdx.x / ns, b = blockIdx.x % ns;
+  const int ml = a.layer_of[d];
+  const int bo = a.box_off[b], n = a.box_off[b + 1] - bo, lo = a.lab_off[b];
+  float* prob = lds;                       // [Q][C1]
+  float* cst = lds + Q * C1;               // [Q][n]
+  // softmax rows
+  if (lane < Q) {
+    const float* x = a.logits + (((long)ml * B + b) * Q + lane) * C1;
+    float m = -INFINITY;
+    for (int c = 0; c < C1; ++c) m = fmaxf(m, x[c]);
+    float se = 0.f;
+    for (int c = 0; c < C1; ++c) se += expf(x[c] - m);
+    for (int c = 0; c < C1; ++c) prob[lane * C1 + c] = expf(x[c] - m) / se;
+  }
+  __syncthreads();
+  for (int i = lane; i < Q * n; i += 64) {
+    const int q = i / n, t = i % n;
+    const float* bx = a.boxes + (((long)ml * B + b) * Q + q) * 2;
+    const float c1 = bx[0], l1 = bx[1], c2 = a.box_cat[2 * (bo + t)], l2 = a.box_cat[2 * (bo + t) + 1];
+    const float s1 = c1 - l1 / 2, e1 = c1 + l1 / 2, s2 = c2 - l2 / 2, e2 = c2 + l2 / 2;
+    const float cost_bbox = fabsf(s1 - s2) + fabsf(e1 - e2);
+    const float inter = fmaxf(fminf(e1, e2) - fmaxf(s1, s2), 0.f);
+    const float uni = (e1 - s1) + (e2 - s2) - inter;
+    const float hull = fmaxf(fmaxf(e1, e2) - fminf(s1, s2), 0.f);
+    const float giou = inter / uni - (hull - uni) / hull;
+    const float cost_class = -prob[q * C1 + (int)a.lab_cat[lo + t]];
+    cst[q * n + t] = a.w_bbox * cost_bbox + a.w_class * cost_class - a.w_giou * giou;
+  }
+  __syncthreads();
+  // assignment: target index matched to query `lane`, or -1
+  int asg = -1;
+  if (n > 0) {
+    if (n <= Q) {          // every target gets a query: rows = targets, columns = queries
+      const int p = wave_lsa(n, Q, [&](int t, int q) { return cst[q * n + t]; });
+      if (lane >= 1 && lane <= Q && p > 0) {
+        // lane j holds column j = query j-1; move the result to the lane of the query
+        asg = p - 1;
+      }
+      asg = __shfl(asg, lane + 1 < 64 ? lane + 1 : 63, 64);
+      if (lane >= Q) asg = -1;
+    } else {               // more targets than queries: rows = queries, columns = targets
+      const int p = wave_lsa(Q, n, [&](int q, int t) { return cst[q * n + t]; });
+      // lane j (1..n) holds the query (1-based) matched to target j-1: scatter through LDS
+      int* tmp = reinterpret_cast<int*>(lds);
+      __syncthreads();
+      if (lane < Q) tmp[lane] = -1;
+      __syncthreads();
+      if (lane >= 1 && lane <= n && p > 0) tmp[p - 1] = lane - 1;
+      __syncthreads();
+      if (lane < Q) asg = tmp[lane];
+    }
+  }
+  if (lane < Q) {
+    const long di = ((long)d * ns + b) * Q + lane;
+    const bool hit = asg >= 0;
+    const int t = hit ? asg : 0;
+    const float ratio = (hit && a.ratio_cat) ? a.ratio_cat[lo + t] : 1.f;
+    a.tc[di] = hit ? (float)a.lab_cat[lo + t] : (float)C;
+    a.coef[di] = ratio;
+    a.wbox[di] = hit ? ratio : 0.f;
+    a.tbox[2 * di] = hit ? a.box_cat[2 * (bo + t)] : 0.5f;
+    a.tbox[2 * di + 1] = hit ? a.box_cat[2 * (bo + t) + 1] : 0.5f;
+    a.tidx[di] = (float)t;
+    if (a.assign) a.assign[di] = asg;
+  }
+}
+
 }  // namespace sedt
 
 extern "C" int sedt_set_criterion(const SedtCriterion* args, void* stream) {
@@ -179,10 +333,11 @@ extern "C" int sedt_set_criterion(const SedtCriterion* args, void* stream) {
   SEDT_REQUIRE(args != nullptr, "set_criterion: null args");
   const SedtCriterion& a = *args;
   SEDT_REQUIRE(a.L >= 1 && a.L <= SEDT_CRIT_MAXL && a.C >= 1 && a.C <= 63, "set_criterion: L=%d (1..%d), C=%d", a.L, SEDT_CRIT_MAXL, a.C);
-  SEDT_REQUIRE(a.logits && a.boxes && a.dlogits && a.dboxes && a.dboxes2 && a.tc && a.coef && a.wbox && a.tbox && a.tgt_len && a.num_boxes &&
+  SEDT_REQUIRE(a.logits && a.boxes && a.dlogits && a.dboxes && a.dboxes2 && a.tc && a.coef && a.wbox && a.tbox && a.tgt_len &&
                    a.empty_weight && a.out,
                "set_criterion: null pointer");
   SEDT_REQUIRE((a.at == nullptr) == (a.dat == nullptr), "set_criterion: at and dat go together");
+  SEDT_REQUIRE(a.L * a.B <= SEDT_CRIT_MAXCARD, "set_criterion: L*B = %d exceeds %d", a.L * a.B, SEDT_CRIT_MAXCARD);
   hipLaunchKernelGGL(set_criterion_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), a);
   return check_launch("set_criterion");
 }
@@ -198,4 +353,19 @@ extern "C" int sedt_set_criterion_bwd(const SedtCriterion* args, const float* g,
   hipLaunchKernelGGL(set_criterion_bwd_kernel, dim3((rows + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, g,
                      glogits, gboxes, gat);
   return check_launch("set_criterion_bwd");
+}
+
+extern "C" int sedt_match_targets(const SedtMatch* args, void* stream) {
+  using namespace sedt;
+  SEDT_REQUIRE(args != nullptr, "match_targets: null args");
+  const SedtMatch& a = *args;
+  SEDT_REQUIRE(a.L >= 1 && a.L <= SEDT_CRIT_MAXL && a.Q >= 1 && a.Q <= 63 && a.C >= 1 && a.C <= 63 && a.ns >= 0 && a.ns <= a.B,
+               "match_targets: L=%d Q=%d (<=63) C=%d ns=%d B=%d", a.L, a.Q, a.C, a.ns, a.B);
+  SEDT_REQUIRE(a.max_targets >= 1 && a.max_targets <= 63, "match_targets: max_targets=%d (1..63 per clip)", a.max_targets);
+  SEDT_REQUIRE(a.logits && a.boxes && a.lab_cat && a.lab_off && a.box_cat && a.box_off && a.tc && a.coef && a.wbox && a.tbox &&
+                   a.tidx && a.tgt_len,
+               "match_targets: null pointer");
+  const size_t lds = (size_t)a.Q * (a.C + 1 + a.max_targets) * sizeof(float);
+  hipLaunchKernelGGL(match_targets_kernel, dim3(a.L * a.ns + 1), dim3(64), lds, reinterpret_cast<hipStream_t>(stream), a);
+  return check_launch("match_targets");
 }

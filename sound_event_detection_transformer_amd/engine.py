@@ -66,19 +66,26 @@ def build_optimizer(model, lr=1e-4, lr_backbone=1e-4, weight_decay=1e-4, fused=T
 
 
 class GraphedTrainStep(object):
-    """The training step as two HIP graphs around the host-side matching:
+    """The training step as HIP graphs.
 
-        graph A: model forward                      (static input -> static outputs, saved activations in the graph pool)
-        host   : SetCriterion.prepare               (one D2H copy, batched C++ Hungarian, one H2D copy)
-        graph B: SetCriterion.compute + backward + fused clip/AdamW
+    device_matching=True (default): ONE graph holds the whole step - model forward, the Hungarian matching of every
+    (decoder layer, clip) on the device (ops.match_targets), the fused loss kernel, backward and the fused clip/AdamW.
+    Per batch the host only refreshes the static input and the flat target tables (asynchronous copies) and replays;
+    nothing depends on a device->host copy, so the host runs ahead of the GPU and the GPU never waits for it.
 
-    so a step costs two graph launches instead of ~1500 kernel launches issued from Python.  Shapes are static: every
-    batch must have the batch size, clip length and strong/weak split it was captured with.  Dropout masks change on each
-    replay through the device-side seed word (runtime.bump_seed); the Adam step count lives on the device too."""
+    device_matching=False: the reference's split - graph A (forward), SetCriterion.prepare on the host (one D2H copy,
+    batched C++ Hungarian, one H2D copy), graph B (loss + backward + optimizer).
+
+    Shapes are static: every batch must have the batch size, clip length and strong/weak split it was captured with (and,
+    for the host split, the same per-clip target counts).  Dropout masks change on each replay through the device-side
+    seed word (runtime.bump_seed); the Adam step count lives on the device too.  Data parallel (world > 1): the graph
+    ends with the gather of all gradients into one flat buffer, ONE RCCL all-reduce follows, then an optimizer graph."""
 
     def __init__(self, model, criterion, optimizer, example_input, example_targets, mask_weak=None, mask_strong=None,
-                 max_norm=0.1, normalize=False, warmup=3):
+                 max_norm=0.1, normalize=False, warmup=3, device_matching=True, max_targets=32):
+        import gc
         from . import runtime
+        from .sedt import TargetTables
         if not isinstance(optimizer, FusedAdamW):
             raise RuntimeError('GraphedTrainStep needs FusedAdamW (device-side step count, one pointer table)')
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
@@ -97,42 +104,64 @@ class GraphedTrainStep(object):
         torch.cuda.synchronize()
         criterion.last_total = None      # drop the warm-up autograd graphs (their AccumulateGrad nodes belong to `side`)
         optimizer.zero_grad(set_to_none=True)
-        self.g_fwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fwd):
-            self.static_out = model(self.static_x)
-        dense, _ = criterion.prepare(self.static_out, example_targets, mask_weak, mask_strong, normalize)
-        self.meta = dense['_meta']
-        self.static_pack = dense['_pack'].clone()
-        self.static_dense = criterion.dense_views(self.static_pack, self.meta)
+        gc.collect()
         self.world = torch.distributed.get_world_size() if (torch.distributed.is_available()
                                                             and torch.distributed.is_initialized()) else 1
-        self.g_bwd = torch.cuda.CUDAGraph()
-        self.g_opt = None
-        with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
-            self.static_losses = criterion.compute(self.static_out, self.static_dense)
-            self.static_total = criterion.last_total
-            self.static_total.backward()
-            if self.world == 1:
-                optimizer.step(max_norm=max_norm)
-            else:
-                self.flat_g = optimizer.gather_grads()       # all gradients -> one flat buffer (one launch)
+        self.device_matching = device_matching
+        self.g_fwd = torch.cuda.CUDAGraph()
+        self.g_bwd = self.g_opt = None
+        if device_matching:
+            if mask_strong is None or mask_strong.start not in (None, 0) or mask_strong.step not in (None, 1):
+                raise NotImplementedError('strong_mask must be slice(0, n)')
+            B = len(example_targets)
+            ns = len(example_targets[mask_strong])
+            n_lab = mask_weak.stop if mask_weak is not None else mask_strong.stop
+            self.tables = TargetTables(B, ns, n_lab, dev, max_targets=max_targets,
+                                       with_ratio=any('ratio' in t for t in example_targets)).load(example_targets)
+            with torch.cuda.graph(self.g_fwd):
+                self.static_out = model(self.static_x)
+                self.static_dense = criterion.prepare_device(self.static_out, self.tables)
+                self._backward_and_step()
+        else:
+            with torch.cuda.graph(self.g_fwd):
+                self.static_out = model(self.static_x)
+            dense, _ = criterion.prepare(self.static_out, example_targets, mask_weak, mask_strong, normalize)
+            self.meta = dense['_meta']
+            self.static_pack = dense['_pack'].clone()
+            self.static_dense = criterion.dense_views(self.static_pack, self.meta)
+            self.g_bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
+                self._backward_and_step()
         if self.world > 1:
-            # data parallel: ONE RCCL all-reduce of the flat gradient buffer between the two graphs, then the fused
+            # data parallel: ONE RCCL all-reduce of the flat gradient buffer between the graphs, then the fused
             # clip + AdamW reads the averaged gradients from the flat buffer
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, pool=self.g_fwd.pool()):
                 optimizer.step(max_norm=max_norm, from_flat=True)
         torch.cuda.synchronize()
 
+    def _backward_and_step(self):
+        self.static_losses = self.criterion.compute(self.static_out, self.static_dense)
+        self.static_total = self.criterion.last_total
+        self.static_total.backward()
+        if self.world == 1:
+            self.optimizer.step(max_norm=self.max_norm)
+        else:
+            self.flat_g = self.optimizer.gather_grads()      # all gradients -> one flat buffer (one launch)
+
     def __call__(self, batch_input, targets, check_finite=False):
         self.static_x.copy_(batch_input, non_blocking=True)
         self.runtime.bump_seed(self.dev)
-        self.g_fwd.replay()
-        dense, _ = self.criterion.prepare(self.static_out, targets, self.mw, self.ms, self.normalize)
-        if dense['_meta'] != self.meta:
-            raise RuntimeError(f'batch composition changed: captured {self.meta}, got {dense["_meta"]}')
-        self.static_pack.copy_(dense['_pack'], non_blocking=True)
-        self.g_bwd.replay()
+        if self.device_matching:
+            self.tables.load(targets)
+            self.g_fwd.replay()
+        else:
+            self.g_fwd.replay()
+            dense, _ = self.criterion.prepare(self.static_out, targets, self.mw, self.ms, self.normalize)
+            if dense['_meta'] != self.meta:
+                raise RuntimeError(f'batch composition changed: captured {self.meta}, got {dense["_meta"]}')
+            self.static_pack.copy_(dense['_pack'], non_blocking=True)
+            self.g_bwd.replay()
         if self.g_opt is not None:
             allreduce_mean(self.flat_g)
             self.g_opt.replay()

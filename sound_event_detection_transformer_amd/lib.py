@@ -52,6 +52,13 @@ class SedtCriterion(C.Structure):
                 ('w_giou', C.c_float * CRIT_MAXL), ('w_weak', C.c_float)]
 
 
+class SedtMatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('logits', 'boxes', 'lab_cat', 'lab_off', 'box_cat', 'box_off', 'ratio_cat', 'tc',
+                                           'coef', 'wbox', 'tbox', 'tidx', 'tgt_len', 'gt_weak', 'assign')] + \
+               [(n, C.c_int32) for n in ('L', 'B', 'ns', 'Q', 'C', 'n_lab', 'max_targets')] + \
+               [('layer_of', C.c_int32 * CRIT_MAXL), ('w_class', C.c_float), ('w_bbox', C.c_float), ('w_giou', C.c_float)]
+
+
 MAX_REDUCE_JOBS = 40
 _vp, _i, _i64, _f, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32, C.c_size_t
 
@@ -97,6 +104,7 @@ SIGNATURES = {
     'sedt_multi_adamw': (_i, [_vp, _i, _vp, _f, _f, _f, _f, _vp, _vp]),
     'sedt_set_criterion': (_i, [C.POINTER(SedtCriterion), _vp]),
     'sedt_set_criterion_bwd': (_i, [C.POINTER(SedtCriterion), _vp, _vp, _vp, _vp, _vp]),
+    'sedt_match_targets': (_i, [C.POINTER(SedtMatch), _vp]),
     'sedt_hungarian_batch': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sedt_adamw_clip': (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _i, _vp]),
 }

@@ -383,8 +383,10 @@ def set_criterion(logits, boxes, at, dense, empty_weight, layer_of, w_ce, w_bbox
     out = torch.empty(4 * Lh + 5, device=logits.device, dtype=torch.float32)
     a.logits, a.boxes, a.out = logits.data_ptr(), boxes.data_ptr(), out.data_ptr()
     a.dlogits, a.dboxes, a.dboxes2 = dl.data_ptr(), db.data_ptr(), db2.data_ptr()
-    for k in ('tc', 'coef', 'wbox', 'tbox', 'tgt_len', 'num_boxes'):
+    for k in ('tc', 'coef', 'wbox', 'tbox', 'tgt_len'):
         setattr(a, k, dense[k].data_ptr())
+    if dense.get('num_boxes') is not None:          # None: the kernel sums the final layer's box weights itself
+        a.num_boxes = dense['num_boxes'].data_ptr()
     a.empty_weight = empty_weight.data_ptr()
     a.L, a.B, a.ns, a.Q, a.C, a.n_lab = Lh, B, dense['ns'], Q, C1 - 1, dense['n_lab']
     assert dense['tgt_len'].numel() == B and dense['L'] == Lh and empty_weight.is_cuda and empty_weight.numel() == C1
@@ -408,3 +410,35 @@ def set_criterion_bwd(state, g):
     gat = None if dat is None else torch.empty_like(dat)
     L.check(L.load().sedt_set_criterion_bwd(a, _p(g), _p(gl), _p(gb), _p(gat), L.stream_ptr()), 'set_criterion_bwd')
     return gl, gb, gat
+
+
+def match_targets(logits, boxes, tables, dense, layer_of, w_class, w_bbox, w_giou, max_targets, assign=None):
+    """device-side Hungarian matching + dense targets in one launch (csrc/criterion.hip).  tables: dict with lab_cat (int64),
+    lab_off (int32 [B+1]), box_cat (f32 [N,2]), box_off (int32 [ns+1]), ratio_cat (f32 or None); dense: the views of
+    SetCriterion.dense_views, written in place."""
+    _dev_check(logits, boxes)
+    Lh, B, Q, C1 = logits.shape
+    assert logits.dtype == torch.float32 and boxes.dtype == torch.float32 and logits.is_contiguous() and boxes.is_contiguous()
+    a = L.SedtMatch()
+    a.logits, a.boxes = logits.data_ptr(), boxes.data_ptr()
+    assert tables['lab_cat'].dtype == torch.int64 and tables['lab_off'].dtype == torch.int32 and tables['box_off'].dtype == torch.int32
+    assert tables['box_cat'].dtype == torch.float32 and tables['lab_off'].numel() >= B + 1 and tables['box_off'].numel() >= dense['ns'] + 1
+    for k in ('lab_cat', 'lab_off', 'box_cat', 'box_off'):
+        assert tables[k].is_cuda and tables[k].is_contiguous()
+        setattr(a, k, tables[k].data_ptr())
+    if tables.get('ratio_cat') is not None:
+        assert tables['ratio_cat'].dtype == torch.float32 and tables['ratio_cat'].is_cuda
+        a.ratio_cat = tables['ratio_cat'].data_ptr()
+    for k in ('tc', 'coef', 'wbox', 'tbox', 'tidx', 'tgt_len'):
+        setattr(a, k, dense[k].data_ptr())
+    if dense['gt_weak'].numel():
+        a.gt_weak = dense['gt_weak'].data_ptr()
+    if assign is not None:
+        assert assign.dtype == torch.int32 and assign.numel() == Lh * dense['ns'] * Q
+        a.assign = assign.data_ptr()
+    a.L, a.B, a.ns, a.Q, a.C, a.n_lab, a.max_targets = Lh, B, dense['ns'], Q, C1 - 1, dense['n_lab'], max_targets
+    assert dense['L'] == Lh and dense['tgt_len'].numel() == B
+    for i in range(Lh):
+        a.layer_of[i] = layer_of[i]
+    a.w_class, a.w_bbox, a.w_giou = w_class, w_bbox, w_giou
+    L.check(L.load().sedt_match_targets(a, L.stream_ptr()), 'match_targets')

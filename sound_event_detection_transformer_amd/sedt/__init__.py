@@ -1,6 +1,6 @@
 """Drop-in counterpart of the reference ``sedt`` package (sedt/__init__.py:1-63) on the MI355X HIP path."""
 from .spsedt import SPSEDT
-from .sedt import SEDT, SetCriterion, PostProcess, MLP
+from .sedt import SEDT, SetCriterion, PostProcess, MLP, TargetTables
 from .backbone import build_backbone
 from .transformer import build_transformer, Transformer, TransformerDecoder, TransformerDecoderLayer
 from .matcher import build_matcher, HungarianMatcher

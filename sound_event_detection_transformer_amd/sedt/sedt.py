@@ -150,6 +150,70 @@ import torch.nn.functional as F  # noqa: E402
 from ..utilities import box_ops  # noqa: E402
 
 
+class TargetTables(object):
+    """The targets of one batch as the flat device tables the matching kernel reads (include/sedt_hip.h, SedtMatch):
+    labels / boxes / ratios concatenated over the clips plus int32 offset tables.  Buffers are allocated once with a
+    fixed capacity (max_targets per clip), so a captured HIP graph can keep reading them while ``load`` refreshes their
+    contents for every batch with asynchronous copies only (offsets travel through a small ring of pinned buffers)."""
+
+    def __init__(self, batch, ns, n_lab, device, max_targets=32, with_ratio=False, slots=4):
+        if not 1 <= max_targets <= 63:
+            raise ValueError('max_targets must be in 1..63 (one wave lane per target)')
+        self.B, self.ns, self.n_lab, self.max_targets, self.dev = batch, ns, max(n_lab, ns), max_targets, device
+        self.lab_cat = torch.zeros(batch * max_targets, dtype=torch.int64, device=device)
+        self.box_cat = torch.zeros(max(ns, 1) * max_targets, 2, dtype=torch.float32, device=device)
+        self.ratio_cat = torch.ones(batch * max_targets, dtype=torch.float32, device=device) if with_ratio else None
+        self.off = torch.zeros(batch + ns + 2, dtype=torch.int32, device=device)
+        self._pin = [torch.zeros(batch + ns + 2, dtype=torch.int32).pin_memory() for _ in range(slots)] if device.type == 'cuda' else None
+        self._ev = [None] * slots
+        self._slot = 0
+
+    def as_dict(self):
+        return {'lab_cat': self.lab_cat, 'box_cat': self.box_cat, 'ratio_cat': self.ratio_cat,
+                'lab_off': self.off[:self.B + 1], 'box_off': self.off[self.B + 1:]}
+
+    @torch.no_grad()
+    def load(self, targets):
+        B, ns = self.B, self.ns
+        if len(targets) != B:
+            raise ValueError(f'expected {B} clips, got {len(targets)}')
+        nlab = [int(t['labels'].shape[0]) for t in targets]
+        nbox = [int(targets[b]['boxes'].reshape(-1, 2).shape[0]) for b in range(ns)]
+        if max(nlab + nbox + [0]) > self.max_targets:
+            raise ValueError(f'a clip has more than max_targets={self.max_targets} events')
+        if any(nb > nl for nb, nl in zip(nbox, nlab)):
+            raise ValueError('a strong clip has more boxes than labels')
+        k = self._slot
+        self._slot = (k + 1) % len(self._ev)
+        off = [0]
+        for n in nlab:
+            off.append(off[-1] + n)
+        off.append(0)
+        for n in nbox:
+            off.append(off[-1] + n)
+        if self._pin is not None:
+            if self._ev[k] is not None:
+                self._ev[k].synchronize()                     # the copy that last used this pinned slot has long finished
+            self._pin[k].copy_(torch.tensor(off, dtype=torch.int32))
+            self.off.copy_(self._pin[k], non_blocking=True)
+            self._ev[k] = torch.cuda.Event()
+            self._ev[k].record()
+        else:
+            self.off.copy_(torch.tensor(off, dtype=torch.int32))
+        nl, nb = sum(nlab), sum(nbox)
+        if nl:
+            self.lab_cat[:nl].copy_(torch.cat([t['labels'].reshape(-1) for t in targets]), non_blocking=True)
+        if nb:
+            self.box_cat[:nb].copy_(torch.cat([targets[b]['boxes'].reshape(-1, 2).float() for b in range(ns)]), non_blocking=True)
+        if self.ratio_cat is not None and nl:
+            self.ratio_cat[:nl].copy_(torch.cat([t['ratio'].detach().float().reshape(-1) if 'ratio' in t else
+                                                 torch.ones(n, device=t['labels'].device) for t, n in zip(targets, nlab)]),
+                                      non_blocking=True)
+        elif any('ratio' in t for t in targets):
+            raise ValueError('targets carry pseudo-label ratios: build TargetTables(with_ratio=True)')
+        return self
+
+
 class _CriterionFn(torch.autograd.Function):
     """autograd node around ops.set_criterion / set_criterion_bwd: forward computes the loss vector and every per-term
     gradient; backward combines them with the gradient that reached the vector (weighted total and/or single entries)."""
@@ -285,6 +349,32 @@ class SetCriterion(nn.Module):
                 'tgt_len': d[6 * n3 + n_lab * C:6 * n3 + n_lab * C + nt],
                 'num_boxes': d[-1:], 'ns': ns, 'n_lab': n_lab, 'L': L, '_pack': d, '_meta': meta}
 
+    # ------------------------------------------------------------------ device matching (no host round trip)
+    def prepare_device(self, outputs, tables, pack=None, assign=None):
+        """same result as ``prepare`` (dense targets of all decoder layers), but the assignment problems are solved ON the
+        device (ops.match_targets: one wave per problem) from the flat target tables of ``TargetTables`` - no device->host
+        copy, no host work that depends on model outputs, so the whole train step can be captured in ONE HIP graph."""
+        from .. import ops
+        if '_stacked' not in outputs:
+            raise RuntimeError('prepare_device needs the stacked head outputs (model built with aux_loss=True)')
+        logits_all, boxes_all = outputs['_stacked']
+        L, B, Q, C1 = logits_all.shape
+        meta = (L, tables.ns, Q, tables.n_lab if 'at' in outputs else tables.ns, C1 - 1, B)
+        if pack is None:
+            pack = torch.zeros(self.dense_numel(meta), device=logits_all.device, dtype=torch.float32)
+        dense = self.dense_views(pack, meta)
+        dense['num_boxes'] = None                   # the loss kernel sums the final layer's box weights itself
+        m = self.matcher
+        ops.match_targets(logits_all.detach().float().contiguous(), boxes_all.detach().float().contiguous(), tables.as_dict(),
+                          dense, [L - 1] + list(range(L - 1)), float(m.cost_class), float(m.cost_bbox), float(m.cost_giou),
+                          tables.max_targets, assign=assign)
+        return dense
+
+    @staticmethod
+    def dense_numel(meta):
+        L, ns, Q, n_lab, C, nt = meta
+        return 6 * L * ns * Q + n_lab * C + nt + 1
+
     # ------------------------------------------------------------------ device part (fixed shapes)
     def _weights(self, name, L):
         return [float(self.weight_dict.get(name if d == 0 else f'{name}_{d - 1}', 0.0)) for d in range(L)]
@@ -330,10 +420,12 @@ class SetCriterion(nn.Module):
 
     def compute(self, outputs, dense):
         if '_stacked' in outputs and outputs['pred_logits'].is_cuda and 'feature' not in self.losses \
-                and outputs['_stacked'][0].shape[0] == dense['L'] <= 8:
+                and outputs['_stacked'][0].shape[0] == dense['L'] <= 8 and 8 * outputs['pred_logits'].shape[0] <= 8192:
             return self._compute_fused(outputs, dense)
         layers = [outputs] + list(outputs.get('aux_outputs', []))
         L, ns, nb = dense['L'], dense['ns'], dense['num_boxes']
+        if nb is None:
+            nb = dense['wbox'][0].sum()
         C1 = self.num_classes + 1
         logits_all = torch.stack([o['pred_logits'] for o in layers]).float()          # [L,B,Q,C+1]
         boxes = torch.stack([o['pred_boxes'][:ns] for o in layers]).float()           # [L,ns,Q,2]

@@ -112,3 +112,82 @@ def test_total_only_backward_equals_entrywise():
     sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict).backward()
     for a, b in ((la, la2), (ba, ba2), (at, at2)):
         assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-8)
+
+
+def _rand_case(B, Q, ns, seed, max_events=9, empty=(), ratio=False):
+    gen = torch.Generator().manual_seed(seed)
+    L = 3
+    la = torch.randn(L, B, Q, 11, generator=gen)
+    ba = torch.rand(L, B, Q, 2, generator=gen) * 0.8 + 0.1
+    targets = synthetic_targets(B, seed + 1, 10)
+    for i, t in enumerate(targets):
+        n = min(len(t['labels']), max_events)
+        t['labels'], t['boxes'] = t['labels'][:n], t['boxes'][:n]
+        if i in empty:
+            t['labels'], t['boxes'] = t['labels'][:0], t['boxes'][:0]
+        if ratio:
+            t['ratio'] = torch.rand(len(t['labels']), generator=gen) * 0.5 + 0.5
+        if i >= ns:
+            t['boxes'] = torch.zeros(0, 2)
+    o = {'pred_logits': la[-1].cuda(), 'pred_boxes': ba[-1].cuda(), 'at': torch.rand(B, 10, generator=gen).cuda(),
+         'aux_outputs': [{'pred_logits': a.cuda(), 'pred_boxes': b.cuda()} for a, b in zip(la[:-1], ba[:-1])],
+         '_stacked': (la.cuda(), ba.cuda())}
+    return o, targets
+
+
+@pytest.mark.parametrize('B,Q,ns,kw', [
+    (6, 10, 6, {}), (6, 10, 4, {}), (8, 4, 8, {}),            # Q=4 < up to 9 targets: more targets than queries
+    (8, 10, 8, {'empty': (0, 3)}), (6, 10, 4, {'ratio': True}), (64, 10, 64, {}), (5, 63, 5, {}), (3, 1, 3, {}),
+])
+def test_device_matching_equals_host_matching(B, Q, ns, kw):
+    """ops.match_targets (wave-parallel Hungarian + dense targets on the device) == SetCriterion.prepare (C++ Hungarian
+    on the host, itself pinned to scipy/the reference by golden G5): identical assignments and dense targets"""
+    from sound_event_detection_transformer_amd.sedt import TargetTables
+    crit = _crit()
+    for seed in (11, 12, 13):
+        o, targets = _rand_case(B, Q, ns, seed, **kw)
+        wm = slice(ns, B) if ns < B else None
+        tg = _cuda_targets(targets)
+        host, _ = crit.prepare(o, tg, wm, slice(ns))
+        tables = TargetTables(B, ns, B, torch.device('cuda'), max_targets=16, with_ratio=bool(kw.get('ratio'))).load(tg)
+        assign = torch.full((3, ns, Q), -7, dtype=torch.int32, device='cuda')
+        dev = crit.prepare_device(o, tables, assign=assign)
+        for k in ('tc', 'coef', 'wbox', 'tbox', 'gt_weak', 'tgt_len'):
+            assert torch.equal(dev[k], host[k]), (k, seed)
+        m = host['wbox'] > 0
+        assert torch.equal(dev['tidx'][m], host['tidx'][m])
+        assert torch.equal(assign >= 0, m)
+        # and the losses computed from them agree (num_boxes is summed on the device in this path)
+        la, ba = o['_stacked']
+        ld_h = crit.compute(o, host)
+        th = crit.last_total.item()
+        ld_d = crit.compute(o, dev)
+        assert abs(crit.last_total.item() - th) <= 1e-6 * abs(th)
+        for k in ld_h:
+            assert abs(ld_h[k].item() - ld_d[k].item()) <= 1e-6 * max(1.0, abs(ld_h[k].item())), k
+
+
+def test_device_matching_golden_indices(golden_dir):
+    """the reference's own matching of fixture G5 (final layer)"""
+    from sound_event_detection_transformer_amd.sedt import TargetTables
+    g = np.load(os.path.join(golden_dir, 'g5_criterion.npz'))
+    crit = _crit()
+    outputs, targets, B = _fixed()
+    o, *_ = _stacked_gpu(outputs)
+    tables = TargetTables(B, B, B, torch.device('cuda'), max_targets=16).load(_cuda_targets(targets))
+    assign = torch.zeros(3, B, 10, dtype=torch.int32, device='cuda')
+    crit.prepare_device(o, tables, assign=assign)
+    a = assign[0].cpu().numpy()
+    src = np.concatenate([np.nonzero(a[b] >= 0)[0] for b in range(B)])
+    tgt = np.concatenate([a[b][a[b] >= 0] for b in range(B)])
+    np.testing.assert_array_equal(src, g['match_src'])
+    np.testing.assert_array_equal(tgt, g['match_tgt'])
+
+
+def test_target_tables_capacity_errors():
+    from sound_event_detection_transformer_amd.sedt import TargetTables
+    _, targets = _rand_case(4, 10, 4, 5)
+    with pytest.raises(ValueError):
+        TargetTables(4, 4, 4, torch.device('cuda'), max_targets=2).load(_cuda_targets(targets))
+    with pytest.raises(ValueError):
+        TargetTables(5, 4, 4, torch.device('cuda'), max_targets=16).load(_cuda_targets(targets))

@@ -252,7 +252,8 @@ def test_dropout_train_mode_runs_and_is_seeded(pkg):
 
 
 def test_graphed_train_step_matches_eager(pkg):
-    """two HIP graphs around the host matching reproduce the eager step (dropout 0 -> deterministic) and keep training"""
+    """the one-graph step (device matching) and the two-graph step (host matching) both reproduce the eager step
+    (dropout 0 -> deterministic) on batches whose targets change, and keep training"""
     A, runtime, sedt = pkg
     from sound_event_detection_transformer_amd.engine import train_step, build_optimizer, GraphedTrainStep
     runtime.set_compute_dtype('bf16')
@@ -261,14 +262,15 @@ def test_graphed_train_step_matches_eager(pkg):
     batches = [(torch.randn(B, 1, 500, 64, generator=torch.Generator().manual_seed(60 + i)).cuda(), synthetic_targets(B, 70 + i, 10))
                for i in range(3)]
     res = {}
-    for mode in ('eager', 'graph'):
+    for mode in ('eager', 'graph', 'graph_host'):
         model, crit = _build(sedt, 3, 10, dropout=0.0)
         _seed_load(model, 5).cuda().train()
         crit.cuda()
         opt = build_optimizer(model)
-        if mode == 'graph':
+        if mode != 'eager':
             sd0 = {k: v.clone() for k, v in model.state_dict().items()}
-            stepper = GraphedTrainStep(model, crit, opt, x, batches[0][1], None, slice(B), warmup=2)
+            stepper = GraphedTrainStep(model, crit, opt, x, batches[0][1], None, slice(B), warmup=2,
+                                       device_matching=(mode == 'graph'))
             model.load_state_dict(sd0)                       # undo the warm-up updates; optimizer moments restart below
             opt._m.zero_(); opt._v.zero_(); opt._step_t.zero_()
         losses = []
@@ -280,7 +282,8 @@ def test_graphed_train_step_matches_eager(pkg):
             losses.append(float(l))
         res[mode] = (losses, {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()})
     runtime.set_compute_dtype('f32')
-    np.testing.assert_allclose(res['graph'][0], res['eager'][0], rtol=1e-3)
-    for k in res['eager'][1]:
-        assert rel(res['graph'][1][k], res['eager'][1][k]) < 2e-3, k
+    for mode in ('graph', 'graph_host'):
+        np.testing.assert_allclose(res[mode][0], res['eager'][0], rtol=1e-3)
+        for k in res['eager'][1]:
+            assert rel(res[mode][1][k], res['eager'][1][k]) < 2e-3, (mode, k)
     assert res['graph'][0][0] != res['graph'][0][1]

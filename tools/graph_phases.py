@@ -1,0 +1,51 @@
+"""Where a graphed train step spends its time: graph A (forward), host matching section, graph B (loss+bwd+optimizer)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sound_event_detection_transformer_amd import runtime                                       # noqa: E402
+from sound_event_detection_transformer_amd.sedt import build_model, default_args                # noqa: E402
+from sound_event_detection_transformer_amd.engine import GraphedTrainStep, build_optimizer      # noqa: E402
+from sound_event_detection_transformer_amd.utilities.synthetic import seeded_state_dict, synthetic_batch   # noqa: E402
+
+runtime.set_compute_dtype('bf16')
+dev = torch.device('cuda:0')
+B = 64
+model, criterion, _ = build_model(default_args(enc_layers=3, num_queries=10, dec_at=True, dropout=0.1))
+model.load_state_dict(seeded_state_dict(model.state_dict(), 2020))
+model.to(dev).train()
+criterion.to(dev)
+opt = build_optimizer(model)
+x, targets = synthetic_batch(B, 500, 2020, dev)
+g = GraphedTrainStep(model, criterion, opt, x, targets, None, slice(B), max_norm=0.1)
+for _ in range(5):
+    g(x, targets)
+torch.cuda.synchronize()
+N = 30
+ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(N)]
+host = []
+t0 = time.perf_counter()
+for i in range(N):
+    e = ev[i]
+    g.static_x.copy_(x, non_blocking=True)
+    runtime.bump_seed(dev)
+    e[0].record()
+    g.g_fwd.replay()
+    e[1].record()
+    h0 = time.perf_counter()
+    dense, _ = criterion.prepare(g.static_out, targets, None, slice(B), False)
+    g.static_pack.copy_(dense['_pack'], non_blocking=True)
+    host.append(time.perf_counter() - h0)
+    e[2].record()
+    g.g_bwd.replay()
+    e[3].record()
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / N * 1e3
+a = sum(e[0].elapsed_time(e[1]) for e in ev) / N
+m = sum(e[1].elapsed_time(e[2]) for e in ev) / N
+b = sum(e[2].elapsed_time(e[3]) for e in ev) / N
+print(f'wall {wall:.3f} ms/step | graph A {a:.3f} | matching section (GPU timeline) {m:.3f} | graph B {b:.3f} | '
+      f'host time in prepare {sum(host) / N * 1e3:.3f}')
