@@ -70,6 +70,7 @@ def main():
     ap.add_argument('--dump-igemm', default=None, help='write per-launch igemm timings (json) to this path')
     ap.add_argument('--host-matching', action='store_true',
                     help='solve the Hungarian matching on the host between two HIP graphs (the reference split) instead of on the device')
+    ap.add_argument('--sync-wgrad', action='store_true', help='keep the weight-gradient GEMMs on the main stream (no parallel graph branch)')
     ap.add_argument('--no-graph', action='store_true', help='issue every kernel from Python instead of replaying HIP graphs')
     ap.add_argument('--model-only', action='store_true', help='time fwd+bwd of the model with a fixed differentiable loss')
     args = ap.parse_args()
@@ -110,7 +111,7 @@ def main():
     graphed = None
     if not args.no_graph and not args.model_only:
         graphed = GraphedTrainStep(net, criterion, opt, x, targets, None, slice(B), max_norm=0.1,
-                                   device_matching=not args.host_matching)
+                                   device_matching=not args.host_matching, async_wgrad=not args.sync_wgrad)
 
     def step():
         if graphed is not None and ops.PROFILE is None:

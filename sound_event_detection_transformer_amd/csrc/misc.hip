@@ -5,6 +5,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include <type_traits>
+#include <algorithm>
 #include "common.h"
 
 namespace sedt {
@@ -57,29 +58,86 @@ struct ReduceJobs {
   SedtReduceJob j[SEDT_MAX_REDUCE_JOBS];
 };
 
-__global__ void multi_wgrad_reduce_kernel(const ReduceJobs jobs) {
+// blocks of one job: taps == 1 (and 4 | Ci): 1024 consecutive elements per block, float4 per thread;
+// taps > 1 and 64 | Ci: one (row, 64-channel chunk) with all its taps per block - the [tap][c] -> [c][tap] transposition
+// goes through LDS so that slab reads and gradient writes are both contiguous runs; otherwise 256 scalar elements.
+__host__ __device__ inline int reduce_job_mode(const SedtReduceJob& J) {
+  if (J.taps == 1 && (J.Ci & 3) == 0) return 0;
+  if (J.taps > 1 && J.taps <= 9 && (J.Ci & 63) == 0) return 1;
+  return 2;
+}
+__host__ __device__ inline int reduce_job_blocks(const SedtReduceJob& J) {
+  const long per = (long)J.R * J.taps * J.Ci;
+  const int mode = reduce_job_mode(J);
+  if (mode == 0) return (int)((per + 1023) / 1024);
+  if (mode == 1) return J.R * (J.Ci / 64);
+  return (int)((per + 255) / 256);
+}
+
+__global__ __launch_bounds__(256) void multi_wgrad_reduce_kernel(const ReduceJobs jobs) {
+  __shared__ float tile[9][65];
   int lo = 0, hi = jobs.n - 1;
   while (lo < hi) {
     int mid = (lo + hi + 1) >> 1;
     if (jobs.j[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const SedtReduceJob& J = jobs.j[lo];
-  const long e = (long)(blockIdx.x - J.blk0) * blockDim.x + threadIdx.x;
+  const int blk = blockIdx.x - J.blk0;
   const long per = (long)J.R * J.taps * J.Ci;
-  if (J.colsum_slab && e < J.R) {
-    float b = 0.f;
-    for (int z = 0; z < J.splitk; ++z) b += J.colsum_slab[(long)z * J.R + e];
-    J.bias_out[e] = b;
+  if (J.colsum_slab) {
+    const long e = (long)blk * 256 + threadIdx.x;
+    if (e < J.R) {
+      float b = 0.f;
+      for (int z = 0; z < J.splitk; ++z) b += J.colsum_slab[(long)z * J.R + e];
+      J.bias_out[e] = b;
+    }
   }
-  if (e >= per) return;
-  const int c = (int)(e % J.Ci);
-  const long rt = e / J.Ci;
-  const int tap = (int)(rt % J.taps);
-  const int r = (int)(rt / J.taps);
-  float s = 0.f;
-  for (int z = 0; z < J.splitk; ++z) s += J.slab[(long)z * per + e];
-  if (J.rowscale) s *= J.rowscale[r];
-  J.out[((long)r * J.Ci + c) * J.taps + tap] = s;
+  const int mode = reduce_job_mode(J);
+  if (mode == 0) {
+    const long e = ((long)blk * 256 + threadIdx.x) * 4;
+    if (e >= per) return;
+    float4 s = *reinterpret_cast<const float4*>(J.slab + e);
+    for (int z = 1; z < J.splitk; ++z) {
+      const float4 a = *reinterpret_cast<const float4*>(J.slab + (long)z * per + e);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    if (J.rowscale) {
+      const float sc = J.rowscale[e / J.Ci];
+      s.x *= sc; s.y *= sc; s.z *= sc; s.w *= sc;
+    }
+    *reinterpret_cast<float4*>(J.out + e) = s;
+  } else if (mode == 1) {
+    const int chunks = J.Ci / 64;
+    const int r = blk / chunks, c0 = (blk - r * chunks) * 64;
+    if (r >= J.R) return;                       // surplus blocks that only carried bias sums
+    const int n = J.taps * 64;
+    const float sc = J.rowscale ? J.rowscale[r] : 1.f;
+    const long rbase = (long)r * J.taps * J.Ci;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const int tap = i >> 6, c = i & 63;
+      const long e = rbase + (long)tap * J.Ci + c0 + c;
+      float v = 0.f;
+      for (int z = 0; z < J.splitk; ++z) v += J.slab[(long)z * per + e];
+      tile[tap][c] = v * sc;
+    }
+    __syncthreads();
+    float* o = J.out + ((long)r * J.Ci + c0) * J.taps;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const int c = i / J.taps, tap = i - c * J.taps;
+      o[i] = tile[tap][c];
+    }
+  } else {
+    const long e = (long)blk * 256 + threadIdx.x;
+    if (e >= per) return;
+    const int c = (int)(e % J.Ci);
+    const long rt = e / J.Ci;
+    const int tap = (int)(rt % J.taps);
+    const int r = (int)(rt / J.taps);
+    float s = 0.f;
+    for (int z = 0; z < J.splitk; ++z) s += J.slab[(long)z * per + e];
+    if (J.rowscale) s *= J.rowscale[r];
+    J.out[((long)r * J.Ci + c) * J.taps + tap] = s;
+  }
 }
 
 // ------------------------------------------------------------------ column sums
@@ -401,7 +459,17 @@ __global__ void multi_sumsq_kernel(const SedtChunk* __restrict__ table, float* _
   const SedtChunk c = table[blockIdx.x];
   const float* g = reinterpret_cast<const float*>(c.g);
   float s = 0.f;
-  for (int i = threadIdx.x; i < c.n; i += blockDim.x) s += g[i] * g[i];
+  int i0 = 0;
+  if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {          // 16-byte loads over the aligned body
+    const int n4 = c.n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+      const float4 a = g4[i];
+      s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+    }
+    i0 = n4 << 2;
+  }
+  for (int i = i0 + threadIdx.x; i < c.n; i += blockDim.x) s += g[i] * g[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -423,15 +491,37 @@ __global__ void multi_adamw_kernel(const SedtChunk* __restrict__ table, const fl
     coef = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
     coef = coef < 1.f ? coef : 1.f;
   }
-  for (int i = threadIdx.x; i < c.n; i += blockDim.x) {
-    float gr = g[i] * coef;
-    float pi = p[i] * (1.f - c.lr * c.wd);
-    float mi = m[i] + (gr - m[i]) * (1.f - b1);
-    float vi = v[i] * b2 + gr * gr * (1.f - b2);
-    float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = pi - (c.lr / bc1) * (mi / denom);
-    m[i] = mi;
-    v[i] = vi;
+  const float decay = 1.f - c.lr * c.wd, slr = c.lr / bc1;
+  auto upd = [&](float& pi, float gi, float& mi, float& vi) {
+    const float gr = gi * coef;
+    pi *= decay;
+    mi = mi + (gr - mi) * (1.f - b1);
+    vi = vi * b2 + gr * gr * (1.f - b2);
+    pi -= slr * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  };
+  int i0 = 0;
+  if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+        reinterpret_cast<uintptr_t>(v)) & 15) == 0) {          // 16-byte accesses over the aligned body
+    const int n4 = c.n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+      float4 pp = p4[i], mm = m4[i], vv = v4[i];
+      const float4 gg = g4[i];
+      upd(pp.x, gg.x, mm.x, vv.x);
+      upd(pp.y, gg.y, mm.y, vv.y);
+      upd(pp.z, gg.z, mm.z, vv.z);
+      upd(pp.w, gg.w, mm.w, vv.w);
+      p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    i0 = n4 << 2;
+  }
+  for (int i = i0 + threadIdx.x; i < c.n; i += blockDim.x) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    upd(pi, g[i], mi, vi);
+    p[i] = pi; m[i] = mi; v[i] = vi;
   }
 }
 
@@ -761,8 +851,9 @@ extern "C" int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, voi
     SEDT_REQUIRE(jobs[i].slab && jobs[i].out && jobs[i].splitk >= 1, "multi_wgrad_reduce: bad job %d", i);
     SEDT_REQUIRE((jobs[i].colsum_slab == nullptr) == (jobs[i].bias_out == nullptr), "multi_wgrad_reduce: job %d colsum/bias", i);
     a.j[i].blk0 = blk;
-    long n = (long)jobs[i].R * jobs[i].taps * jobs[i].Ci;
-    blk += (int)((n + 255) / 256);
+    int nb = reduce_job_blocks(jobs[i]);
+    if (jobs[i].colsum_slab) nb = std::max(nb, (jobs[i].R + 255) / 256);   // the bias sums ride on the first blocks
+    blk += nb;
   }
   hipLaunchKernelGGL(multi_wgrad_reduce_kernel, dim3(blk), dim3(256), 0, S(stream), a);
   return check_launch("multi_wgrad_reduce");

@@ -47,6 +47,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
+template <typename T, int N>
+struct alignas(sizeof(T) * N) VecT { T v[N]; };
+
 template <typename T, int VPT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
                                                      const T* __restrict__ x, const float* __restrict__ gamma,
@@ -54,6 +57,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const T* __restrict__ dres, T* __restrict__ dx,
                                                      float* __restrict__ partial, int rows) {
   constexpr int D = VPT * 64;
+  typedef VecT<T, VPT> V;                       // one 8/16-byte access per lane and tensor
   __shared__ float red[4][2 * D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float g[VPT], dg[VPT], db[VPT];
@@ -62,14 +66,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     const long base = (long)row * D + lane * VPT;
     const float mu = mean[row], rs = rstd[row];
+    const V vdy = *reinterpret_cast<const V*>(dy + base);
+    const V vx = *reinterpret_cast<const V*>(x + base);
+    V vdy2, vres;
+    if (dy2) vdy2 = *reinterpret_cast<const V*>(dy2 + base);
+    if (dres) vres = *reinterpret_cast<const V*>(dres + base);
     float xh[VPT], dyt[VPT];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
-      float d = (float)dy[base + i];
-      if (dy2) d += (float)dy2[base + i];
+      float d = (float)vdy.v[i];
+      if (dy2) d += (float)vdy2.v[i];
       dyt[i] = d;
-      xh[i] = ((float)x[base + i] - mu) * rs;
+      xh[i] = ((float)vx.v[i] - mu) * rs;
       float dgv = d * g[i];
       c1 += dgv;
       c2 += dgv * xh[i];
@@ -78,12 +87,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
     c1 = wave_sum(c1) * (1.f / D);
     c2 = wave_sum(c2) * (1.f / D);
+    V out;
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
       float o = rs * (dyt[i] * g[i] - c1 - xh[i] * c2);
-      if (dres) o += (float)dres[base + i];
-      dx[base + i] = (T)o;
+      if (dres) o += (float)vres.v[i];
+      out.v[i] = (T)o;
     }
+    *reinterpret_cast<V*>(dx + base) = out;
   }
 #pragma unroll
   for (int i = 0; i < VPT; ++i) { red[wave][lane * VPT + i] = dg[i]; red[wave][D + lane * VPT + i] = db[i]; }
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(1024) void ln_bwd_final_kernel(const float* __restr
 
 static int ln_bwd_blocks(int rows) {
   int b = (rows + 3) / 4;
-  return b < 1 ? 1 : (b > 128 ? 128 : b);
+  return b < 1 ? 1 : (b > 512 ? 512 : b);
 }
 
 // ============================================================================ attention

@@ -82,7 +82,7 @@ class GraphedTrainStep(object):
     ends with the gather of all gradients into one flat buffer, ONE RCCL all-reduce follows, then an optimizer graph."""
 
     def __init__(self, model, criterion, optimizer, example_input, example_targets, mask_weak=None, mask_strong=None,
-                 max_norm=0.1, normalize=False, warmup=3, device_matching=True, max_targets=32):
+                 max_norm=0.1, normalize=False, warmup=3, device_matching=True, max_targets=32, async_wgrad=True):
         import gc
         from . import runtime
         from .sedt import TargetTables
@@ -91,6 +91,7 @@ class GraphedTrainStep(object):
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.mw, self.ms, self.max_norm, self.normalize = mask_weak, mask_strong, max_norm, normalize
         self.runtime = runtime
+        self.async_wgrad = async_wgrad
         dev = example_input.device
         self.dev = dev
         self.static_x = example_input.clone()
@@ -143,7 +144,8 @@ class GraphedTrainStep(object):
     def _backward_and_step(self):
         self.static_losses = self.criterion.compute(self.static_out, self.static_dense)
         self.static_total = self.criterion.last_total
-        self.static_total.backward()
+        with self.runtime.async_wgrad(self.async_wgrad):     # wgrads as a parallel branch of the graph; joined on exit
+            self.static_total.backward()
         if self.world == 1:
             self.optimizer.step(max_norm=self.max_norm)
         else:

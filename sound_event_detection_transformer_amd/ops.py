@@ -127,10 +127,17 @@ def _fused_bias_ok(dtype, dy, x, g):
 
 
 class ReduceBatch(object):
-    """collects the split-K reductions of several wgrads and issues them as ONE launch (flush); keeps the slabs alive"""
+    """collects the split-K reductions of several wgrads and issues them as ONE launch (flush); keeps the slabs alive.
+    Inside a runtime.async_wgrad() scope the wgrad GEMMs themselves are deferred too: flush() then issues all of them
+    plus the reduction as ONE block on the side stream (one fork per layer instead of one per GEMM)."""
 
     def __init__(self):
-        self.jobs, self.keep = [], []
+        self.jobs, self.keep, self.deferred, self.operands = [], [], [], []
+        self._running = False
+
+    def defer(self, body, operands):
+        self.deferred.append(body)
+        self.operands.extend(t for t in operands if t is not None)
 
     def add(self, slab, sk, R, taps, Ci, rowscale, out, cs, bias_out):
         j = L.SedtReduceJob()
@@ -141,37 +148,57 @@ class ReduceBatch(object):
         self.jobs.append(j)
         self.keep.append((slab, cs, rowscale, out, bias_out))
         if len(self.jobs) == L.MAX_REDUCE_JOBS:
-            self.flush()
+            self._launch()
 
-    def flush(self):
+    def _launch(self):
         if self.jobs:
             arr = (L.SedtReduceJob * len(self.jobs))(*self.jobs)
             L.check(L.load().sedt_multi_wgrad_reduce(arr, len(self.jobs), L.stream_ptr()), 'multi_wgrad_reduce')
         self.jobs, self.keep = [], []
+
+    def flush(self):
+        if self.deferred:
+            from . import runtime
+            with runtime.side(*self.operands):
+                for body in self.deferred:
+                    body()
+                self._launch()
+            self.deferred, self.operands = [], []
+        else:
+            self._launch()
 
 
 def wgrad(dtype, dy, x, B, g, rowscale=None, out=None, bias_out=None, batch=None):
     """dW (Co, Ci, KH, KW) f32 = sum over pixels dy[pix][co] * gather(x)[pix][tap][ci] (* rowscale[co]).
     bias_out (f32 [Co]): also receives sum over pixels of dy (fused into the wgrad kernel when it can, else a colsum).
     batch: a ReduceBatch - the split-K reduction is deferred until batch.flush() (the result is valid only then)"""
+    from . import runtime
     lib = L.load()
     Mo, No, Kp = g.Co, g.taps * g.Ci, B * g.Ho * g.Wo
     sk = lib.sedt_igemm_splitk(Mo, No, Kp, dtype)
-    slab = torch.empty((sk, Mo, No), device=dy.device, dtype=torch.float32)
-    conv = None if g.plain else _geom_tuple(g)
-    fused = bias_out is not None and _fused_bias_ok(dtype, dy, x, g)
-    cs = torch.empty((sk, Mo), device=dy.device, dtype=torch.float32) if fused else None
-    igemm(dtype, Mo, No, Kp, dy, dy.stride(0), x, x.stride(0), slab, No, trans=1, conv=conv, out_f32=1, splitk=sk,
-          slab=slab, colsum_out=cs)
     if out is None:
         out = torch.empty((g.Co, g.Ci, g.KH, g.KW), device=dy.device, dtype=torch.float32)
-    if batch is not None:
-        batch.add(slab, sk, Mo, g.taps, g.Ci, rowscale, out, cs, bias_out if fused else None)
+
+    def body():
+        slab = torch.empty((sk, Mo, No), device=dy.device, dtype=torch.float32)
+        conv = None if g.plain else _geom_tuple(g)
+        fused = bias_out is not None and _fused_bias_ok(dtype, dy, x, g)
+        cs = torch.empty((sk, Mo), device=dy.device, dtype=torch.float32) if fused else None
+        igemm(dtype, Mo, No, Kp, dy, dy.stride(0), x, x.stride(0), slab, No, trans=1, conv=conv, out_f32=1, splitk=sk,
+              slab=slab, colsum_out=cs)
+        if batch is not None:
+            batch.add(slab, sk, Mo, g.taps, g.Ci, rowscale, out, cs, bias_out if fused else None)
+        else:
+            L.check(lib.sedt_wgrad_reduce_bias(_p(slab), sk, Mo, g.taps, g.Ci, _p(rowscale), _p(out), _p(cs),
+                                               _p(bias_out) if fused else None, L.stream_ptr()), 'wgrad_reduce')
+        if bias_out is not None and not fused:
+            colsum(dtype, dy, out=bias_out)
+
+    if batch is not None and runtime.async_wgrad_on():
+        batch.defer(body, (dy, x, rowscale))              # issued by batch.flush() as part of one side-stream block
     else:
-        L.check(lib.sedt_wgrad_reduce_bias(_p(slab), sk, Mo, g.taps, g.Ci, _p(rowscale), _p(out), _p(cs),
-                                           _p(bias_out) if fused else None, L.stream_ptr()), 'wgrad_reduce')
-    if bias_out is not None and not fused:
-        colsum(dtype, dy, out=bias_out)
+        with runtime.side(dy, x, rowscale):               # off the dgrad critical path when runtime.async_wgrad is on
+            body()
     return out
 
 
@@ -330,9 +357,11 @@ def stem_im2col(dtype, x, B, H, W):
 
 
 def stem_conv0_grad(G, w1):
+    from . import runtime
     dw0 = torch.empty((3, 1, 1, 1), device=G.device, dtype=torch.float32)
     db0 = torch.empty((3,), device=G.device, dtype=torch.float32)
-    L.check(L.load().sedt_stem_conv0_grad(_p(G), _p(w1), _p(dw0), _p(db0), L.stream_ptr()), 'stem_conv0_grad')
+    with runtime.side(G):                       # G comes from a wgrad: stay on its stream
+        L.check(L.load().sedt_stem_conv0_grad(_p(G), _p(w1), _p(dw0), _p(db0), L.stream_ptr()), 'stem_conv0_grad')
     return dw0, db0
 
 

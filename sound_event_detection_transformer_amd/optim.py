@@ -25,7 +25,7 @@ class FusedAdamW(torch.optim.Optimizer):
                         raise RuntimeError('FusedAdamW needs contiguous f32 GPU parameters')
                     ps.append(p)
                     gi.append(gidx)
-        total = sum(p.numel() for p in ps)
+        total = sum((p.numel() + 3) // 4 * 4 for p in ps)     # every tensor's state starts 16-byte aligned (float4 kernels)
         dev = ps[0].device
         self._m = torch.zeros(total, device=dev)
         self._v = torch.zeros(total, device=dev)
@@ -35,7 +35,7 @@ class FusedAdamW(torch.optim.Optimizer):
             k = p.numel()
             for c0 in range(0, k, _CHUNK):
                 owner.append(i); off_in_p.append(c0); n.append(min(_CHUNK, k - c0)); state_off.append(so + c0)
-            so += k
+            so += (k + 3) // 4 * 4
         self._ps, self._gi = ps, np.asarray(gi)
         self._owner = np.asarray(owner)
         self._off = np.asarray(off_in_p, np.uint64) * 4

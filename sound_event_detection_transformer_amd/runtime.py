@@ -43,3 +43,77 @@ def seed_ptr(device):
 
 def bump_seed(device):
     seed_ptr(device).add_(1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Asynchronous weight gradients.  In the backward pass the dgrad chain (layer n -> layer n-1) is the critical path; the
+# weight gradients only feed the optimizer.  Inside an ``async_wgrad()`` scope every wgrad GEMM (+ its split-K
+# reduction) is issued on a second HIP stream that forks from the main stream where its operands are ready, so the two
+# run concurrently (and become parallel branches when the step is captured into a HIP graph).  The scope's exit - or an
+# explicit ``join_wgrad()`` - makes the main stream wait for the side stream; only then may anything read the weight
+# gradients.  Operands are kept referenced until the join, because the caching allocator would otherwise hand their
+# memory to later main-stream allocations while the side stream is still reading it.
+_aw = {'on': False, 'streams': {}, 'held': [], 'forked': False}
+
+
+def async_wgrad_on():
+    return _aw['on']
+
+
+def side_stream(device):
+    key = str(device)
+    if key not in _aw['streams']:
+        _aw['streams'][key] = torch.cuda.Stream(device=device)
+    return _aw['streams'][key]
+
+
+def join_wgrad():
+    if _aw['forked']:
+        for s in _aw['streams'].values():
+            torch.cuda.current_stream(s.device).wait_stream(s)
+        _aw['forked'] = False
+    _aw['held'].clear()
+
+
+class async_wgrad(object):
+    """context manager: weight gradients computed inside are valid only after the scope exits (or join_wgrad())"""
+
+    def __init__(self, enable=True):
+        self.enable = enable
+
+    def __enter__(self):
+        self.prev = _aw['on']
+        _aw['on'] = bool(self.enable)
+        return self
+
+    def __exit__(self, *exc):
+        _aw['on'] = self.prev
+        if not self.prev:
+            join_wgrad()
+        return False
+
+
+class side(object):
+    """``with runtime.side(t1, t2, ...):`` - run the body on the wgrad stream (when async wgrad is on), after everything
+    issued so far on the current stream; t1.. are the tensors the body reads that were produced on the current stream."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.cm = None
+
+    def __enter__(self):
+        if not _aw['on']:
+            return self
+        dev = next(t.device for t in self.tensors if t is not None)
+        s = side_stream(dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        _aw['held'].extend(t for t in self.tensors if t is not None)
+        _aw['forked'] = True
+        self.cm = torch.cuda.stream(s)
+        self.cm.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.cm is not None:
+            self.cm.__exit__(*exc)
+        return False
