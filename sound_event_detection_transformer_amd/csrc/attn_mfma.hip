@@ -61,84 +61,107 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
   return o;
 }
 
+// additive key bias of one (batch) row into LDS: 0 for live keys, -inf for padded keys (kpm) and for the zero-padded tail
+__device__ __forceinline__ void stage_key_bias(float* kb, const uint8_t* kpm_row, int Lk, int LkP, int tid, int nthr) {
+  for (int i = tid; i < LkP; i += nthr) kb[i] = (i >= Lk || (kpm_row && kpm_row[i])) ? -INFINITY : 0.f;
+}
+
 // ============================================================================================ forward
-template <int NT>   // key tiles
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ k,
-                                                            long ldk, const bf16_t* __restrict__ v, long ldv,
-                                                            bf16_t* __restrict__ o, long ldo, float* __restrict__ lse,
-                                                            const uint8_t* __restrict__ kpm, const float* __restrict__ amask,
-                                                            int H, int Lq, int Lk, float scale, uint32_t thresh, float inv_keep,
-                                                            uint32_t seed, const uint32_t* seed_ptr) {
+template <int NT, bool AMASK>   // key tiles; additive attention mask present
+__global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ k,
+                                                               long ldk, const bf16_t* __restrict__ v, long ldv,
+                                                               bf16_t* __restrict__ o, long ldo, float* __restrict__ lse,
+                                                               const uint8_t* __restrict__ kpm, const float* __restrict__ amask,
+                                                               int H, int Lq, int Lk, float scale, uint32_t thresh, float inv_keep,
+                                                               uint32_t seed, const uint32_t* seed_ptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int LkP = NT * 32, LqP = (Lq + 31) & ~31;
   unsigned char* Ki = smem;
   unsigned char* Vi = Ki + LkP * AROW;
   unsigned char* Qi = Vi + LkP * AROW;
+  float* Kb = reinterpret_cast<float*>(Qi + LqP * AROW);
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
   stage_image(Ki, k + (long)b * Lk * ldk + h * AD, ldk, Lk, LkP, tid, nthr);
   stage_image(Vi, v + (long)b * Lk * ldv + h * AD, ldv, Lk, LkP, tid, nthr);
   stage_image(Qi, q + (long)b * Lq * ldq + h * AD, ldq, Lq, LqP, tid, nthr);
+  stage_key_bias(Kb, kpm ? kpm + (long)b * Lk : nullptr, Lk, LkP, tid, nthr);
   __syncthreads();
   const uint32_t sd = eff_seed(seed, seed_ptr);
   const int hf = lane >> 5;
   for (int q0 = wave * 32; q0 < Lq; q0 += nwave * 32) {
     const int qi = q0 + (lane & 31);                   // this lane's query
-    f32x16 st[NT];
+    const bf16x8 qf0 = frag_rows(Qi, q0, 0, lane), qf1 = frag_rows(Qi, q0, 1, lane);
+    // one score tile (32 keys x this wave's 32 queries): S^T = K Q^T, scaled and masked.  Register r of half hf <-> key
+    // 8*(r>>2) + 4*hf + (r&3): four consecutive keys per register group
+    auto score_tile = [&](int kt, f32x16& st) {
 #pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = 0.f;
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ki, kt * 32, 0, lane), qf0, st, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ki, kt * 32, 1, lane), qf1, st, 0, 0, 0);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int key0 = kt * 32 + 8 * g4 + 4 * hf;
+        const float4 kb = *reinterpret_cast<const float4*>(Kb + key0);
+        const float kbv[4] = {kb.x, kb.y, kb.z, kb.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float sc = st[4 * g4 + e] * scale + kbv[e];
+          if (AMASK) { if (qi < Lq && key0 + e < Lk) sc += amask[(long)qi * Lk + key0 + e]; }
+          st[4 * g4 + e] = sc;
+        }
+      }
+    };
+    // pass 1: softmax statistics, one tile at a time (running max / rescaled sum), so only one tile is live in registers
+    float m = -INFINITY, sum = 0.f;
+#pragma unroll 1
     for (int kt = 0; kt < NT; ++kt) {
+      f32x16 st;
+      score_tile(kt, st);
+      float tm = st[0];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
+      for (int r = 1; r < 16; ++r) tm = fmaxf(tm, st[r]);
+      const float mn = fmaxf(m, tm);
+      if (mn > -INFINITY) {
+        float ts = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ki, kt * 32, ks, lane), frag_rows(Qi, q0, ks, lane), st[kt], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) ts += __expf(st[r] - mn);
+        sum = sum * __expf(m - mn) + ts;
+        m = mn;
+      }
     }
-    // scores -> masked, running max
-    float m = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + crow(r, hf);
-        float s = st[kt][r] * scale;
-        if (amask && qi < Lq && key < Lk) s += amask[(long)qi * Lk + key];
-        if (key >= Lk || (kpm && kpm[(long)b * Lk + key])) s = -INFINITY;
-        st[kt][r] = s;
-        m = fmaxf(m, s);
-      }
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __expf(st[kt][r] - m);
-        st[kt][r] = e;
-        sum += e;
-      }
-    sum += __shfl_xor(sum, 32, 64);
+    {
+      const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(sum, 32, 64);
+      const float M = fmaxf(m, m2);
+      sum = (m > -INFINITY ? sum * __expf(m - M) : 0.f) + (m2 > -INFINITY ? s2 * __expf(m2 - M) : 0.f);
+      m = M;
+    }
     const float inv = 1.f / sum;
     if (hf == 0 && qi < Lq) lse[((long)b * H + h) * Lq + qi] = m + __logf(sum);
-    // O = P V
+    const uint64_t rowbase = ((uint64_t)bh * Lq + qi) * Lk;
+    // pass 2: O = dropout(P) V, scores recomputed tile by tile (two MFMAs per tile - cheaper than keeping them)
     f32x16 oacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll 1
+    for (int kt = 0; kt < NT; ++kt) {
+      f32x16 st;
+      score_tile(kt, st);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         float pv[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          float p = st[kt][8 * u + s] * inv;
+        for (int s8 = 0; s8 < 8; ++s8) {
+          float p = __expf(st[8 * u + s8] - m) * inv;
           if (thresh) {
-            const int key = kt * 32 + crow(8 * u + s, hf);
-            p = drop_keep(sd, ((uint64_t)bh * Lq + qi) * Lk + key, thresh) ? p * inv_keep : 0.f;
+            const int key = kt * 32 + crow(8 * u + s8, hf);
+            p = drop_keep(sd, rowbase + key, thresh) ? p * inv_keep : 0.f;
           }
-          pv[s] = p;
+          pv[s8] = p;
         }
         oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(pv), frag_cols_tr(Vi, kt * 32 + 16 * u, lane), oacc, 0, 0, 0);
       }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qr = q0 + crow(r, hf);
@@ -148,15 +171,15 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16_t* __rest
 }
 
 // ============================================================================================ backward
-template <int NTQ, int NTK>
-__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ k,
-                                                            long ldk, const bf16_t* __restrict__ v, long ldv,
-                                                            const bf16_t* __restrict__ o, long ldo, const bf16_t* __restrict__ dout,
-                                                            long lddo, const float* __restrict__ lse, const uint8_t* __restrict__ kpm,
-                                                            const float* __restrict__ amask, bf16_t* __restrict__ dq, long lddq,
-                                                            bf16_t* __restrict__ dk, long lddk, bf16_t* __restrict__ dv, long lddv,
-                                                            int H, int Lq, int Lk, float scale, uint32_t thresh, float inv_keep,
-                                                            uint32_t seed, const uint32_t* seed_ptr) {
+template <int NTQ, int NTK, bool AMASK>
+__global__ __launch_bounds__(256, 2) void attn_bwd_mfma_kernel(const bf16_t* __restrict__ q, long ldq, const bf16_t* __restrict__ k,
+                                                               long ldk, const bf16_t* __restrict__ v, long ldv,
+                                                               const bf16_t* __restrict__ o, long ldo, const bf16_t* __restrict__ dout,
+                                                               long lddo, const float* __restrict__ lse, const uint8_t* __restrict__ kpm,
+                                                               const float* __restrict__ amask, bf16_t* __restrict__ dq, long lddq,
+                                                               bf16_t* __restrict__ dk, long lddk, bf16_t* __restrict__ dv, long lddv,
+                                                               int H, int Lq, int Lk, float scale, uint32_t thresh, float inv_keep,
+                                                               uint32_t seed, const uint32_t* seed_ptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int LqP = NTQ * 32, LkP = NTK * 32;
   unsigned char* Qi = smem;
@@ -165,20 +188,26 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
   unsigned char* Di = Vi + LkP * AROW;                  // dO image
   float* Ls = reinterpret_cast<float*>(Di + LqP * AROW);   // lse   [LqP]
   float* De = Ls + LqP;                                 // delta [LqP]
+  float* Kb = De + LqP;                                 // key bias [LkP]
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
   stage_image(Qi, q + (long)b * Lq * ldq + h * AD, ldq, Lq, LqP, tid, nthr);
   stage_image(Ki, k + (long)b * Lk * ldk + h * AD, ldk, Lk, LkP, tid, nthr);
   stage_image(Vi, v + (long)b * Lk * ldv + h * AD, ldv, Lk, LkP, tid, nthr);
   stage_image(Di, dout + (long)b * Lq * lddo + h * AD, lddo, Lq, LqP, tid, nthr);
+  stage_key_bias(Kb, kpm ? kpm + (long)b * Lk : nullptr, Lk, LkP, tid, nthr);
   for (int i = tid; i < LqP; i += nthr) {
     float dl = 0.f, l = 0.f;
     if (i < Lq) {
       l = lse[((long)b * H + h) * Lq + i];
-      const bf16_t* op = o + ((long)b * Lq + i) * ldo + h * AD;
-      const bf16_t* dp = dout + ((long)b * Lq + i) * lddo + h * AD;
+      const uint4* op = reinterpret_cast<const uint4*>(o + ((long)b * Lq + i) * ldo + h * AD);
+      const uint4* dp = reinterpret_cast<const uint4*>(dout + ((long)b * Lq + i) * lddo + h * AD);
 #pragma unroll
-      for (int d = 0; d < AD; ++d) dl += (float)op[d] * (float)dp[d];
+      for (int c = 0; c < 4; ++c) {
+        const bf16x8 a = __builtin_bit_cast(bf16x8, op[c]), g = __builtin_bit_cast(bf16x8, dp[c]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += (float)a[e] * (float)g[e];
+      }
     }
     Ls[i] = l;
     De[i] = dl;
@@ -191,10 +220,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
   for (int q0 = wave * 32; q0 < Lq; q0 += nwave * 32) {
     const int qi = q0 + (lane & 31);
     const float lq = Ls[qi], dlq = De[qi];
+    const uint64_t rowbase = ((uint64_t)bh * Lq + qi) * Lk;
     f32x16 dqa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqa[r] = 0.f;
-#pragma unroll
+#pragma unroll 1
     for (int kt = 0; kt < NTK; ++kt) {
       f32x16 st, dp;
 #pragma unroll
@@ -209,15 +239,20 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
       for (int u = 0; u < 2; ++u) {
         float ds[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const int r = 8 * u + s, key = kt * 32 + crow(r, hf);
-          float sc = st[r] * scale;
-          if (amask && qi < Lq && key < Lk) sc += amask[(long)qi * Lk + key];
-          if (key >= Lk || (kpm && kpm[(long)b * Lk + key])) sc = -INFINITY;
-          const float p = __expf(sc - lq);
-          float g = dp[r];
-          if (thresh) g = drop_keep(sd, ((uint64_t)bh * Lq + qi) * Lk + key, thresh) ? g * inv_keep : 0.f;
-          ds[s] = (qi < Lq) ? p * (g - dlq) : 0.f;
+        for (int g2 = 0; g2 < 2; ++g2) {
+          const int key0 = kt * 32 + 16 * u + 8 * g2 + 4 * hf;
+          const float4 kb = *reinterpret_cast<const float4*>(Kb + key0);
+          const float kbv[4] = {kb.x, kb.y, kb.z, kb.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 8 * u + 4 * g2 + e, key = key0 + e;
+            float sc = st[r] * scale + kbv[e];
+            if (AMASK) { if (qi < Lq && key < Lk) sc += amask[(long)qi * Lk + key]; }
+            const float p = __expf(sc - lq);
+            float g = dp[r];
+            if (thresh) g = drop_keep(sd, rowbase + key, thresh) ? g * inv_keep : 0.f;
+            ds[4 * g2 + e] = (qi < Lq) ? p * (g - dlq) : 0.f;
+          }
         }
         dqa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(ds), frag_cols_tr(Ki, kt * 32 + 16 * u, lane), dqa, 0, 0, 0);
       }
@@ -232,11 +267,11 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
   // ---------------- pass B: this wave's 32 keys, all queries -> dK, dV (accumulated transposed: rows = dims, cols = keys)
   for (int k0 = wave * 32; k0 < Lk; k0 += nwave * 32) {
     const int kj = k0 + (lane & 31);                    // this lane's key
-    const bool kdead = kj >= Lk || (kpm && kpm[(long)b * Lk + kj]);
+    const float kbj = Kb[kj];
     f32x16 dkt, dvt;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dkt[r] = 0.f; dvt[r] = 0.f; }
-#pragma unroll
+#pragma unroll 1
     for (int qt = 0; qt < NTQ; ++qt) {
       f32x16 sa, dp;
 #pragma unroll
@@ -251,20 +286,25 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const bf16_t* __rest
       for (int u = 0; u < 2; ++u) {
         float pd[8], ds[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const int r = 8 * u + s, qr = qt * 32 + crow(r, hf);
-          float sc = sa[r] * scale;
-          if (amask && qr < Lq && kj < Lk) sc += amask[(long)qr * Lk + kj];
-          if (kdead) sc = -INFINITY;
-          float p = (qr < Lq) ? __expf(sc - Ls[qr]) : 0.f;
-          float g = dp[r], pk = p;
-          if (thresh) {
-            const bool keep = drop_keep(sd, ((uint64_t)bh * Lq + qr) * Lk + kj, thresh);
-            g = keep ? g * inv_keep : 0.f;
-            pk = keep ? p * inv_keep : 0.f;
+        for (int g2 = 0; g2 < 2; ++g2) {
+          const int qr0 = qt * 32 + 16 * u + 8 * g2 + 4 * hf;
+          const float4 l4 = *reinterpret_cast<const float4*>(Ls + qr0), d4 = *reinterpret_cast<const float4*>(De + qr0);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 8 * u + 4 * g2 + e, qr = qr0 + e;
+            float sc = sa[r] * scale + kbj;
+            if (AMASK) { if (qr < Lq && kj < Lk) sc += amask[(long)qr * Lk + kj]; }
+            float p = (qr < Lq) ? __expf(sc - lv[e]) : 0.f;
+            float g = dp[r], pk = p;
+            if (thresh) {
+              const bool keep = drop_keep(sd, ((uint64_t)bh * Lq + qr) * Lk + kj, thresh);
+              g = keep ? g * inv_keep : 0.f;
+              pk = keep ? p * inv_keep : 0.f;
+            }
+            pd[4 * g2 + e] = pk;
+            ds[4 * g2 + e] = p * (g - dv4[e]);
           }
-          pd[s] = pk;
-          ds[s] = p * (g - De[qr]);
         }
         dvt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Di, qt * 32 + 16 * u, lane), pack8(pd), dvt, 0, 0, 0);
         dkt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_cols_tr(Qi, qt * 32 + 16 * u, lane), pack8(ds), dkt, 0, 0, 0);
@@ -307,26 +347,30 @@ int attn_fwd_mfma_try(const void* q, int64_t ldq, const void* k, int64_t ldk, co
   if (Lk > 32 * AMAXT || Lq > 32 * AMAXT) return -1;
   if (!aligned_ok(q, ldq) || !aligned_ok(k, ldk) || !aligned_ok(v, ldv)) return -1;
   const int nt = (Lk + 31) / 32, LqP = (Lq + 31) & ~31;
-  const size_t lds = (size_t)(2 * nt * 32 + LqP) * AROW;
-  const int nwave = std::min(4, (Lq + 31) / 32);
+  const size_t lds = (size_t)(2 * nt * 32 + LqP) * AROW + (size_t)nt * 32 * sizeof(float);
+  const int nwave = 4;     // all four waves stage K/V/Q; waves beyond the query tiles then idle
   const float scale = 1.f / sqrtf((float)AD);
   const uint32_t th = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
   const float ik = 1.f / (1.f - drop_p);
   dim3 grid(B * H), block(64 * nwave);
-#define SEDT_AF(NT_)                                                                                                       \
-  case NT_: {                                                                                                              \
+#define SEDT_AF1(NT_, AM_)                                                                                                 \
+  {                                                                                                                        \
     static bool done = false;                                                                                              \
-    if (set_attr_once(attn_fwd_mfma_kernel<NT_>, done, 64 * 1024, "attention_fwd")) return 1;                              \
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel<NT_>, grid, block, lds, st, (const bf16_t*)q, (long)ldq, (const bf16_t*)k,     \
+    if (set_attr_once(attn_fwd_mfma_kernel<NT_, AM_>, done, 64 * 1024, "attention_fwd")) return 1;                         \
+    hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT_, AM_>), grid, block, lds, st, (const bf16_t*)q, (long)ldq, (const bf16_t*)k, \
                        (long)ldk, (const bf16_t*)v, (long)ldv, (bf16_t*)o, (long)ldo, lse, kpm, amask, H, Lq, Lk, scale,   \
                        th, ik, seed, seed_ptr);                                                                            \
-    break;                                                                                                                 \
   }
+#define SEDT_AF(NT_)                                                                                                       \
+  case NT_:                                                                                                                \
+    if (amask) SEDT_AF1(NT_, true) else SEDT_AF1(NT_, false)                                                               \
+    break;
   switch (nt) {
     SEDT_AF(1) SEDT_AF(2) SEDT_AF(3) SEDT_AF(4) SEDT_AF(5) SEDT_AF(6) SEDT_AF(7) SEDT_AF(8)
     default: return -1;
   }
 #undef SEDT_AF
+#undef SEDT_AF1
   return check_launch("attention_fwd_mfma");
 }
 
@@ -336,21 +380,25 @@ static int launch_bwd_q(int ntk, dim3 grid, dim3 block, size_t lds, hipStream_t 
                         const float* lse, const uint8_t* kpm, const float* amask, void* dq, int64_t lddq, void* dk, int64_t lddk,
                         void* dv, int64_t lddv, int H, int Lq, int Lk, float scale, uint32_t th, float ik, uint32_t seed,
                         const uint32_t* seed_ptr) {
-#define SEDT_AB(NTK_)                                                                                                      \
-  case NTK_: {                                                                                                             \
+#define SEDT_AB1(NTK_, AM_)                                                                                                \
+  {                                                                                                                        \
     static bool done = false;                                                                                              \
-    if (set_attr_once(attn_bwd_mfma_kernel<NTQ, NTK_>, done, 96 * 1024, "attention_bwd")) return 1;                        \
-    hipLaunchKernelGGL((attn_bwd_mfma_kernel<NTQ, NTK_>), grid, block, lds, st, (const bf16_t*)q, (long)ldq, (const bf16_t*)k, \
-                       (long)ldk, (const bf16_t*)v, (long)ldv, (const bf16_t*)o, (long)ldo, (const bf16_t*)dout, (long)lddo, lse, \
-                       kpm, amask, (bf16_t*)dq, (long)lddq, (bf16_t*)dk, (long)lddk, (bf16_t*)dv, (long)lddv, H, Lq, Lk, scale, \
-                       th, ik, seed, seed_ptr);                                                                            \
-    break;                                                                                                                 \
+    if (set_attr_once(attn_bwd_mfma_kernel<NTQ, NTK_, AM_>, done, 96 * 1024, "attention_bwd")) return 1;                   \
+    hipLaunchKernelGGL((attn_bwd_mfma_kernel<NTQ, NTK_, AM_>), grid, block, lds, st, (const bf16_t*)q, (long)ldq,          \
+                       (const bf16_t*)k, (long)ldk, (const bf16_t*)v, (long)ldv, (const bf16_t*)o, (long)ldo,              \
+                       (const bf16_t*)dout, (long)lddo, lse, kpm, amask, (bf16_t*)dq, (long)lddq, (bf16_t*)dk, (long)lddk, \
+                       (bf16_t*)dv, (long)lddv, H, Lq, Lk, scale, th, ik, seed, seed_ptr);                                 \
   }
+#define SEDT_AB(NTK_)                                                                                                      \
+  case NTK_:                                                                                                               \
+    if (amask) SEDT_AB1(NTK_, true) else SEDT_AB1(NTK_, false)                                                             \
+    break;
   switch (ntk) {
     SEDT_AB(1) SEDT_AB(2) SEDT_AB(3) SEDT_AB(4)
     default: return -1;
   }
 #undef SEDT_AB
+#undef SEDT_AB1
   return check_launch("attention_bwd_mfma");
 }
 
@@ -362,7 +410,7 @@ int attn_bwd_mfma_try(const void* q, int64_t ldq, const void* k, int64_t ldk, co
   if (!aligned_ok(q, ldq) || !aligned_ok(k, ldk) || !aligned_ok(v, ldv) || !aligned_ok(dout, lddo)) return -1;
   if ((lddk & 3) || (lddv & 3) || (reinterpret_cast<uintptr_t>(dk) & 7) || (reinterpret_cast<uintptr_t>(dv) & 7)) return -1;
   const int ntq = (Lq + 31) / 32, ntk = (Lk + 31) / 32;
-  const size_t lds = (size_t)(2 * ntq * 32 + 2 * ntk * 32) * AROW + 2 * ntq * 32 * sizeof(float);
+  const size_t lds = (size_t)(2 * ntq * 32 + 2 * ntk * 32) * AROW + (size_t)(2 * ntq * 32 + ntk * 32) * sizeof(float);
   const int nwave = std::min(4, std::max(ntq, ntk));
   const float scale = 1.f / sqrtf((float)AD);
   const uint32_t th = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
