@@ -19,6 +19,15 @@ typedef __attribute__((address_space(3))) w3_s16x4 w3_lds_s16x4;
 
 __device__ __forceinline__ int w3_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// XOR swizzle of the 16-byte chunk index of image row `row`.  A transposing read (ds_read_b64_tr_b16) serves lanes 0-31 in
+// one LDS cycle and they touch rows r, r+1, r+2, r+3 x 64 bytes: rows r and r+2 start in the same 32 banks, so their
+// swizzles must differ in chunk bit 2 (the other 64-byte half of the row) - the bit-reversed row pair index does that
+// (the plain (row>>1)&7 of the b128-read kernels gave 2-way conflicts here: 50 % of the LDS cycles by SQ_LDS_BANK_CONFLICT).
+__device__ __forceinline__ int w3_swz(int row) {
+  const int v = (row >> 1) & 7;
+  return ((v & 1) << 2) | (v & 2) | (v >> 2);
+}
+
 template <int BN>   // BM = 64 output channels, BN = 64 or 128 columns of (tap, cin)
 __global__ __launch_bounds__(256) void wgrad3_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes,
                                                      const int nmajor) {
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(const SedtIgemm p, const un
 #pragma unroll
   for (int i = 0; i < GA; ++i) {
     const int trow = (i * 4 + wave) * 8 + lrow;
-    const int col = m0 + (pc ^ ((trow >> 1) & 7)) * 8;
+    const int col = m0 + (pc ^ w3_swz(trow)) * 8;
     a_trow[i] = trow;
     a_ok[i] = col < p.M;
     a_poff[i] = (unsigned)((((long)kb_begin * BKP + trow) * p.lda + col) * 2);
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(const SedtIgemm p, const un
     const int instr = i * 4 + wave;
     const int trow = instr * B_RPI + lane / B_CPR;
     const int pchunk = lane % B_CPR;
-    const int lchunk = (pchunk & ~7) | ((pchunk & 7) ^ ((trow >> 1) & 7));
+    const int lchunk = (pchunk & ~7) | ((pchunk & 7) ^ w3_swz(trow));
     const int j = n0 + lchunk * 8;
     b_trow[i] = trow;
     bool ok = j < p.N;
@@ -157,12 +166,12 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(const SedtIgemm p, const un
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
       const int pixrow = ks * 16 + src_pix + 4 * h2;
-      a_rd[ks][h2] = pixrow * ROWB + (((a_ch >> 3) ^ ((pixrow >> 1) & 7)) * 16) + ((a_ch >> 2) & 1) * 8;
+      a_rd[ks][h2] = pixrow * ROWB + (((a_ch >> 3) ^ w3_swz(pixrow)) * 16) + ((a_ch >> 2) & 1) * 8;
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int b_ch = wn + j * 32 + (grp & 1) * 16 + (s16 & 3) * 4;
         const int ch8 = b_ch >> 3;
-        const int phys = (ch8 & ~7) | ((ch8 & 7) ^ ((pixrow >> 1) & 7));
+        const int phys = (ch8 & ~7) | ((ch8 & 7) ^ w3_swz(pixrow));
         b_rd[ks][j][h2] = A_BYTES + pixrow * B_ROWB + phys * 16 + ((b_ch >> 2) & 1) * 8;
       }
     }
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(const SedtIgemm p, const un
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int pixrow = cs_q * 16 + r;
-      const int phys = (cs_ch >> 3) ^ ((pixrow >> 1) & 7);
+      const int phys = (cs_ch >> 3) ^ w3_swz(pixrow);
       bsum += (float)*reinterpret_cast<const bf16_t*>(st + pixrow * ROWB + phys * 16 + (cs_ch & 7) * 2);
     }
   };

@@ -6,21 +6,31 @@ import torch
 from .optim import FusedAdamW
 
 
-def allreduce_mean(flat):
+class _Done(object):
+    def wait(self):
+        return True
+
+
+def allreduce_mean(flat, async_op=False):
     """average one flat gradient buffer over the data-parallel group: RCCL AVG on GPUs; SUM + scale elsewhere
-    (gloo has no AVG and, in this image, no GPU tensors: stage through the host - used by the CPU/gloo tests only)"""
+    (gloo has no AVG and, in this image, no GPU tensors: stage through the host - used by the CPU/gloo tests only).
+    async_op (RCCL): returns the work handle; the collective runs on RCCL's stream after everything already queued on the
+    current stream, and later kernels of the current stream overlap with it until handle.wait()."""
     dist = torch.distributed
     world = dist.get_world_size()
     if dist.get_backend() == 'nccl':
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
-    elif flat.is_cuda:
+        work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=async_op)
+        return work if async_op else flat
+    if flat.numel() == 0:
+        return _Done() if async_op else flat
+    if flat.is_cuda:
         h = flat.cpu()
         dist.all_reduce(h, op=dist.ReduceOp.SUM)
         flat.copy_(h.div_(world))
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(world)
-    return flat
+    return _Done() if async_op else flat
 
 
 def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None, mask_strong=None, max_norm=0.1,
@@ -78,11 +88,17 @@ class GraphedTrainStep(object):
 
     Shapes are static: every batch must have the batch size, clip length and strong/weak split it was captured with (and,
     for the host split, the same per-clip target counts).  Dropout masks change on each replay through the device-side
-    seed word (runtime.bump_seed); the Adam step count lives on the device too.  Data parallel (world > 1): the graph
-    ends with the gather of all gradients into one flat buffer, ONE RCCL all-reduce follows, then an optimizer graph."""
+    seed word (runtime.bump_seed); the Adam step count lives on the device too.
+
+    Data parallel (world > 1): gradients are packed into ONE flat f32 buffer and averaged with RCCL between the backward
+    graph and an optimizer graph.  With a SEDT backbone the backward is cut after layer3 (overlap_allreduce=True): the
+    first graph ends with the gradients of everything above the cut (transformer, heads, layer4, layer3 = 90 % of the
+    bytes) packed into the head of the flat buffer, their all-reduce is launched asynchronously, and a second graph runs
+    the backward of layer2 / layer1 / stem meanwhile; the small tail is reduced after it."""
 
     def __init__(self, model, criterion, optimizer, example_input, example_targets, mask_weak=None, mask_strong=None,
-                 max_norm=0.1, normalize=False, warmup=3, device_matching=True, max_targets=32, async_wgrad=True):
+                 max_norm=0.1, normalize=False, warmup=3, device_matching=True, max_targets=32, async_wgrad=True,
+                 overlap_allreduce=True):
         import gc
         from . import runtime
         from .sedt import TargetTables
@@ -92,6 +108,18 @@ class GraphedTrainStep(object):
         self.mw, self.ms, self.max_norm, self.normalize = mask_weak, mask_strong, max_norm, normalize
         self.runtime = runtime
         self.async_wgrad = async_wgrad
+        self.world = torch.distributed.get_world_size() if (torch.distributed.is_available()
+                                                            and torch.distributed.is_initialized()) else 1
+        # data-parallel overlap: parameters whose gradients come last (stem conv0 + layer2) go to the tail of the flat layout
+        self.cut_body = None
+        if self.world > 1 and overlap_allreduce and device_matching:
+            net = getattr(model, 'module', model)
+            body = getattr(getattr(net, 'backbone', [None])[0], 'body', None) if hasattr(net, 'backbone') else None
+            if body is not None and hasattr(body, 'stage_out') and optimizer._static is None:
+                tail = [p for n, p in body.named_parameters() if p.requires_grad and (n.startswith('conv0.') or n.startswith('layer2.'))]
+                if tail:
+                    optimizer.set_tail_params(tail)
+                    self.cut_body = body
         dev = example_input.device
         self.dev = dev
         self.static_x = example_input.clone()
@@ -106,11 +134,9 @@ class GraphedTrainStep(object):
         criterion.last_total = None      # drop the warm-up autograd graphs (their AccumulateGrad nodes belong to `side`)
         optimizer.zero_grad(set_to_none=True)
         gc.collect()
-        self.world = torch.distributed.get_world_size() if (torch.distributed.is_available()
-                                                            and torch.distributed.is_initialized()) else 1
         self.device_matching = device_matching
         self.g_fwd = torch.cuda.CUDAGraph()
-        self.g_bwd = self.g_opt = None
+        self.g_bwd = self.g_opt = self.g_low = None
         if device_matching:
             if mask_strong is None or mask_strong.start not in (None, 0) or mask_strong.step not in (None, 1):
                 raise NotImplementedError('strong_mask must be slice(0, n)')
@@ -122,7 +148,14 @@ class GraphedTrainStep(object):
             with torch.cuda.graph(self.g_fwd):
                 self.static_out = model(self.static_x)
                 self.static_dense = criterion.prepare_device(self.static_out, self.tables)
-                self._backward_and_step()
+                if self.cut_body is None:
+                    self._backward_and_step()
+                else:
+                    self._backward_above_cut()
+            if self.cut_body is not None:
+                self.g_low = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_low, pool=self.g_fwd.pool()):
+                    self._backward_below_cut()
         else:
             with torch.cuda.graph(self.g_fwd):
                 self.static_out = model(self.static_x)
@@ -140,6 +173,26 @@ class GraphedTrainStep(object):
             with torch.cuda.graph(self.g_opt, pool=self.g_fwd.pool()):
                 optimizer.step(max_norm=max_norm, from_flat=True)
         torch.cuda.synchronize()
+
+    def _backward_above_cut(self):
+        """loss + backward down to the output of layer2; gradients of all parameters above -> head of the flat buffer"""
+        self.static_losses = self.criterion.compute(self.static_out, self.static_dense)
+        self.static_total = self.criterion.last_total
+        head, self._tail = self.optimizer.head_tail_params()
+        self._cut = self.cut_body.stage_out[1]
+        with self.runtime.async_wgrad(self.async_wgrad):
+            grads = torch.autograd.grad(self.static_total, [self._cut] + head)
+        self._g_cut = grads[0]
+        for p, g in zip(head, grads[1:]):
+            p.grad = g
+        self.flat_head = self.optimizer.gather_grads('head')
+
+    def _backward_below_cut(self):
+        with self.runtime.async_wgrad(self.async_wgrad):
+            grads = torch.autograd.grad(self._cut, self._tail, grad_outputs=self._g_cut)
+        for p, g in zip(self._tail, grads):
+            p.grad = g
+        self.flat_tail = self.optimizer.gather_grads('tail')
 
     def _backward_and_step(self):
         self.static_losses = self.criterion.compute(self.static_out, self.static_dense)
@@ -164,7 +217,14 @@ class GraphedTrainStep(object):
                 raise RuntimeError(f'batch composition changed: captured {self.meta}, got {dense["_meta"]}')
             self.static_pack.copy_(dense['_pack'], non_blocking=True)
             self.g_bwd.replay()
-        if self.g_opt is not None:
+        if self.g_low is not None:
+            w1 = allreduce_mean(self.flat_head, async_op=True)     # RCCL reduces the head while the tail's backward runs
+            self.g_low.replay()
+            w2 = allreduce_mean(self.flat_tail, async_op=True)
+            w1.wait()
+            w2.wait()
+            self.g_opt.replay()
+        elif self.g_opt is not None:
             allreduce_mean(self.flat_g)
             self.g_opt.replay()
         if check_finite:

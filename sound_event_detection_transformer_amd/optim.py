@@ -15,6 +15,15 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._step = 0
         self._static = None
+        self._tail_ids = set()
+
+    def set_tail_params(self, params):
+        """put these parameters LAST in the flat state / gradient layout (call before the first step).  The data-parallel
+        step reduces the head part of the flat gradient buffer while the backward of the tail parameters' layers still
+        runs (engine.GraphedTrainStep): the tail is the part of the model whose gradients are produced last."""
+        if self._static is not None:
+            raise RuntimeError('set_tail_params must be called before the optimizer state is built (first step)')
+        self._tail_ids = {id(p) for p in params}
 
     def _build(self):
         ps, gi = [], []
@@ -25,17 +34,24 @@ class FusedAdamW(torch.optim.Optimizer):
                         raise RuntimeError('FusedAdamW needs contiguous f32 GPU parameters')
                     ps.append(p)
                     gi.append(gidx)
+        order = sorted(range(len(ps)), key=lambda i: id(ps[i]) in self._tail_ids)      # stable: tail parameters last
+        ps, gi = [ps[i] for i in order], [gi[i] for i in order]
         total = sum((p.numel() + 3) // 4 * 4 for p in ps)     # every tensor's state starts 16-byte aligned (float4 kernels)
         dev = ps[0].device
         self._m = torch.zeros(total, device=dev)
         self._v = torch.zeros(total, device=dev)
         owner, off_in_p, n, state_off = [], [], [], []
         so = 0
+        self._tail_chunk0, self._tail_elem0 = None, None
         for i, p in enumerate(ps):
             k = p.numel()
+            if id(p) in self._tail_ids and self._tail_chunk0 is None:
+                self._tail_chunk0, self._tail_elem0 = len(owner), so
             for c0 in range(0, k, _CHUNK):
                 owner.append(i); off_in_p.append(c0); n.append(min(_CHUNK, k - c0)); state_off.append(so + c0)
             so += (k + 3) // 4 * 4
+        if self._tail_chunk0 is None:
+            self._tail_chunk0, self._tail_elem0 = len(owner), so
         self._ps, self._gi = ps, np.asarray(gi)
         self._owner = np.asarray(owner)
         self._off = np.asarray(off_in_p, np.uint64) * 4
@@ -64,18 +80,33 @@ class FusedAdamW(torch.optim.Optimizer):
             self._host_gtab = torch.empty(self._tab.nbytes, dtype=torch.uint8).pin_memory()
         return self._flat_g
 
+    def head_tail_params(self):
+        """(parameters before the tail, tail parameters) in flat-layout order"""
+        if self._static is None:
+            self._build()
+        head = [p for p in self._ps if id(p) not in self._tail_ids]
+        return head, [p for p in self._ps if id(p) in self._tail_ids]
+
     @torch.no_grad()
-    def gather_grads(self):
-        """copy every p.grad into the flat gradient buffer (one launch); returns the flat buffer"""
+    def gather_grads(self, part=None):
+        """copy p.grad of every parameter (part=None), of the head ('head') or of the tail parameters ('tail') into the
+        flat gradient buffer (one launch); returns the matching view of the flat buffer"""
         flat = self.enable_flat_grads()
-        gbase = np.fromiter((p.grad.data_ptr() for p in self._ps), np.uint64, len(self._ps))
+        c0, e0, n = self._tail_chunk0, self._tail_elem0, len(self._gtab)
+        lo, hi, view = {None: (0, n, flat), 'head': (0, c0, flat[:e0]), 'tail': (c0, n, flat[e0:])}[part]
+        sel = [p for p in self._ps if part is None or (id(p) in self._tail_ids) == (part == 'tail')]
+        if any(p.grad is None for p in sel):
+            raise RuntimeError('gather_grads: a parameter of the requested part has no gradient')
+        gbase = np.fromiter((p.grad.data_ptr() if p.grad is not None else 0 for p in self._ps), np.uint64, len(self._ps))
         t = self._gtab
         t['p'] = np.uint64(flat.data_ptr()) + self._state_off_b
-        t['g'] = gbase[self._owner] + self._off
-        self._host_gtab.numpy()[:] = t.view(np.uint8)
-        self._dev_gtab.copy_(self._host_gtab, non_blocking=True)
-        L.check(L.load().sedt_multi_gather(L.p(self._dev_gtab), len(t), L.stream_ptr()), 'multi_gather')
-        return flat
+        t['g'][lo:hi] = (gbase[self._owner] + self._off)[lo:hi]
+        if hi > lo:
+            isz = _DT.itemsize
+            self._host_gtab.numpy()[lo * isz:hi * isz] = t[lo:hi].view(np.uint8)
+            self._dev_gtab[lo * isz:hi * isz].copy_(self._host_gtab[lo * isz:hi * isz], non_blocking=True)
+            L.check(L.load().sedt_multi_gather(L.p(self._dev_gtab[lo * isz:]), hi - lo, L.stream_ptr()), 'multi_gather')
+        return view
 
     @torch.no_grad()
     def step(self, closure=None, max_norm=0.0, from_flat=False):
