@@ -37,7 +37,7 @@ def cpu_baseline(batch=8, steps=2):
     from oracle.criterion_oracle import build_oracle_criterion
     cores = torch.get_num_threads()
     model = O.build_oracle_model(10, 10, 3, 3, True, True, True, dropout=0.1)
-    model.load_state_dict(seeded_state_dict(model.state_dict(), 2020))
+    model.load_state_dict(O.seeded_state_dict(model.state_dict(), 2020))
     model.train()
     crit = build_oracle_criterion(10, 3, True, True)
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
@@ -160,7 +160,7 @@ def main():
         avg_s = tot_ms / 1e3 / max(n, 1)
         peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
         ach = flops_launch / avg_s / 1e12
-        roof = {"bound": "mfma", "kernel": "sedt::igemm_kernel", "achieved": round(ach, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+        roof = {"bound": "mfma", "kernel": "sedt::igemm3_kernel + sedt::wgrad3_kernel (MFMA implicit-GEMM family: every conv/linear fwd, dgrad, wgrad launch)", "achieved": round(ach, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                 "frac": round(ach / (peak / 1e12), 4), "traffic": None, "launches_per_step": n,
                 "avg_launch_us": round(avg_s * 1e6, 2), "igemm_ms_per_step": round(tot_ms, 3),
                 "algorithmic_flop_per_launch": flops_launch}
