@@ -54,6 +54,10 @@ __device__ __forceinline__ uint32_t eff_seed(uint32_t seed, const uint32_t* seed
   return seed + (seed_ptr ? *seed_ptr : 0u);
 }
 
+// ---- N elements moved as one 8/16/32-byte access
+template <typename T, int N>
+struct alignas(sizeof(T) * N) VecT { T v[N]; };
+
 // ---- wave64 reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -122,9 +122,16 @@ __global__ __launch_bounds__(256) void multi_wgrad_reduce_kernel(const ReduceJob
     }
     __syncthreads();
     float* o = J.out + ((long)r * J.Ci + c0) * J.taps;
-    for (int i = threadIdx.x; i < n; i += 256) {
-      const int c = i / J.taps, tap = i - c * J.taps;
-      o[i] = tile[tap][c];
+    if (J.taps == 9) {                               // compile-time divisor for the 3x3 case
+      for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = i / 9, tap = i - c * 9;
+        o[i] = tile[tap][c];
+      }
+    } else {
+      for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = i / J.taps, tap = i - c * J.taps;
+        o[i] = tile[tap][c];
+      }
     }
   } else {
     const long e = (long)blk * 256 + threadIdx.x;
@@ -238,24 +245,32 @@ __global__ void stem_prep_kernel(const float* w0, const float* b0, const float* 
   wcat[e] = (T)v;
 }
 
+// thread = one output pixel x 8 consecutive columns (one 16/32-byte store); 32-bit index arithmetic, the tap -> (kh, kw)
+// split has a compile-time divisor.  Columns: [0,49) taps of x, [64,113) in-bounds indicators, the rest zero.
 template <typename T>
-__global__ void stem_im2col_kernel(const float* __restrict__ x, T* __restrict__ col, int B, int H, int W, int Ho, int Wo) {
-  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long n = (long)B * Ho * Wo * 128;
-  if (e >= n) return;
-  int k = (int)(e & 127);
-  long pix = e >> 7;
-  int wo = (int)(pix % Wo);
-  long r = pix / Wo;
-  int ho = (int)(r % Ho), b = (int)(r / Ho);
-  int tap = k & 63;
-  float v = 0.f;
-  if (tap < 49) {
-    int kh = tap / 7, kw = tap - kh * 7;
-    int hi = 2 * ho - 3 + kh, wi = 2 * wo - 3 + kw;
-    if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = (k < 64) ? x[((long)b * H + hi) * W + wi] : 1.f;
+__global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x, T* __restrict__ col, int B, int H, int W,
+                                                          int Ho, int Wo) {
+  const int npix = B * Ho * Wo;
+  const int pix = blockIdx.x * 16 + (threadIdx.x >> 4), chunk = threadIdx.x & 15;
+  if (pix >= npix) return;
+  const int wo = pix % Wo, r = pix / Wo;
+  const int ho = r % Ho, b = r / Ho;
+  const int k0 = chunk * 8;
+  const bool ind = k0 >= 64;
+  const float* xb = x + (long)b * H * W;
+  VecT<T, 8> out;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int tap = (k0 & 63) + e;
+    float v = 0.f;
+    if (tap < 49) {
+      const int kh = tap / 7, kw = tap - kh * 7;
+      const int hi = 2 * ho - 3 + kh, wi = 2 * wo - 3 + kw;
+      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = ind ? 1.f : xb[hi * W + wi];
+    }
+    out.v[e] = (T)v;
   }
-  col[e] = (T)v;
+  *reinterpret_cast<VecT<T, 8>*>(col + (long)pix * 128 + k0) = out;
 }
 
 __global__ void stem_conv0_grad_kernel(const float* G, const float* w1, float* dw0, float* db0) {
@@ -282,32 +297,46 @@ __global__ void stem_conv0_grad_kernel(const float* G, const float* w1, float* d
   else if (t < 6) db0[t - 3] = red[t][0];
 }
 
-template <typename T>
-__global__ void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx, int B, int H,
-                                   int W, int C, int Ho, int Wo) {
-  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long n = (long)B * Ho * Wo * C;
-  if (e >= n) return;
-  int c = (int)(e % C);
-  long r = e / C;
-  int wo = (int)(r % Wo);
-  r /= Wo;
-  int ho = (int)(r % Ho), b = (int)(r / Ho);
-  float best = -INFINITY;
-  int bi = 0;
+// thread = one output pixel x VEC consecutive channels: 16-byte loads of the (up to) nine window taps, one 16-byte store of
+// the maxima and VEC argmax bytes; 32-bit index arithmetic.  First maximum wins (scan order kh, kw), as torch does.
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx,
+                                                          int B, int H, int W, int C, int Ho, int Wo) {
+  const int CV = C / VEC;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)B * Ho * Wo * CV) return;
+  const int c = (int)(e % CV) * VEC;
+  const int pix = (int)(e / CV);
+  const int wo = pix % Wo, r = pix / Wo;
+  const int ho = r % Ho, b = r / Ho;
+  float best[VEC];
+  uint8_t bi[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { best[v] = -INFINITY; bi[v] = 0; }
   bool first = true;
+#pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
-    int hi = 2 * ho - 1 + kh;
+    const int hi = 2 * ho - 1 + kh;
     if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-      int wi = 2 * wo - 1 + kw;
+      const int wi = 2 * wo - 1 + kw;
       if ((unsigned)wi >= (unsigned)W) continue;
-      float v = (float)x[(((long)b * H + hi) * W + wi) * C + c];
-      if (first || v > best) { best = v; bi = kh * 3 + kw; first = false; }
+      const VecT<T, VEC> xv = *reinterpret_cast<const VecT<T, VEC>*>(x + (((long)b * H + hi) * W + wi) * C + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float f = (float)xv.v[v];
+        if (first || f > best[v]) { best[v] = f; bi[v] = (uint8_t)(kh * 3 + kw); }
+      }
+      first = false;
     }
   }
-  y[e] = (T)best;
-  idx[e] = (uint8_t)bi;
+  VecT<T, VEC> yo;
+  VecT<uint8_t, VEC> io;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { yo.v[v] = (T)best[v]; io.v[v] = bi[v]; }
+  *reinterpret_cast<VecT<T, VEC>*>(y + (long)pix * C + c) = yo;
+  *reinterpret_cast<VecT<uint8_t, VEC>*>(idx + (long)pix * C + c) = io;
 }
 
 // thread = one input pixel x VEC consecutive channels (16 bytes of dy / relu_src / dx at a time when C % VEC == 0)
@@ -319,10 +348,9 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
   long n = (long)B * H * W * CV;
   if (e >= n) return;
   const int c = (int)(e % CV) * VEC;
-  long r = e / CV;
-  const int wi = (int)(r % W);
-  r /= W;
-  const int hi = (int)(r % H), b = (int)(r / H);
+  const int ipix = (int)(e / CV);
+  const int wi = ipix % W, r = ipix / W;
+  const int hi = r % H, b = r / H;
   float s[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) s[v] = 0.f;
@@ -535,29 +563,21 @@ __global__ void multi_bn_fold_kernel(const SedtBnJob* __restrict__ jobs) {
   }
 }
 
-// one workgroup = one 32(co) x 32(ci) x taps tile of one weight tensor, staged through LDS so that the f32 source rows
-// ([co][ci][tap], tap fastest) are read coalesced and both packed layouts are written in 64-byte runs
-template <typename T>
-__global__ __launch_bounds__(256) void multi_pack_kernel(const SedtPackJob* __restrict__ jobs, int njobs) {
-  __shared__ float tile[32 * (32 * 9 + 1)];
-  // find the tensor this block belongs to: jobs[].e0 holds the first block index of each tensor (ascending)
-  int lo = 0, hi = njobs - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid].e0 <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const SedtPackJob j = jobs[lo];
-  const int taps = j.taps;
-  const int tci = (j.Cin + 31) / 32;
-  const int tb = (int)((long)blockIdx.x - j.e0);
+// one workgroup = one TS(co) x TS(ci) x taps tile of one weight tensor (TS = 64 for 1x1 kernels / linears, 32 for 3x3),
+// staged through LDS so that the f32 source rows ([co][ci][tap], tap fastest) are read in 128/256-byte runs and both packed
+// layouts are written in 64/128-byte runs.  PackPlan (packing.py) counts blocks with the same rule.
+template <typename T, int TAPS>      // TAPS = 0: run-time tap count
+__device__ __forceinline__ void pack_tile(const SedtPackJob& j, int tb, float* tile) {
+  const int taps = TAPS ? TAPS : j.taps;          // compile-time in the common cases: no integer divisions in the loops
+  const int sh = taps == 1 ? 6 : 5, TS = 1 << sh;
+  const int tci = (j.Cin + TS - 1) >> sh;
   T* wf = reinterpret_cast<T*>(j.wf);
   T* wb = reinterpret_cast<T*>(j.wb);
-  const int rowlen = 32 * taps, pitch = rowlen + 1;
-  // taps > 9 (the 7x7 stem conv): process in tap groups of 9 columns is not needed - such tensors use the plain path
-  const int co0 = (tb / tci) * 32, ci0 = (tb % tci) * 32;
-  const int nco = min(32, j.Cout - co0), nci = min(32, j.Cin - ci0);
+  const int rowlen = TS * taps, pitch = rowlen + 1;
+  const int co0 = (tb / tci) << sh, ci0 = (tb % tci) << sh;
+  const int nco = min(TS, j.Cout - co0), nci = min(TS, j.Cin - ci0);
   const int valid = nci * taps;
-  for (int idx = threadIdx.x; idx < 32 * rowlen; idx += 256) {
+  for (int idx = threadIdx.x; idx < TS * rowlen; idx += 256) {
     const int co = idx / rowlen, off = idx - co * rowlen;
     float v = 0.f;
     if (co < nco && off < valid) v = j.w[((long)(co0 + co) * j.Cin + ci0) * taps + off];
@@ -565,17 +585,17 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const SedtPackJob* __re
   }
   __syncthreads();
   if (wf) {
-    for (int idx = threadIdx.x; idx < 32 * rowlen; idx += 256) {     // (co, tap, ci) with ci fastest
-      const int ci = idx & 31, r = idx >> 5;
-      const int tap = r % taps, co = r / taps;
+    for (int idx = threadIdx.x; idx < TS * rowlen; idx += 256) {     // (co, tap, ci) with ci fastest
+      const int ci = idx & (TS - 1), r = idx >> sh;
+      const int co = r / taps, tap = r - co * taps;
       if (co < nco && ci < nci)
         wf[((long)(co0 + co) * taps + tap) * j.Cin + ci0 + ci] = (T)tile[co * pitch + ci * taps + tap];
     }
   }
   if (wb) {
-    for (int idx = threadIdx.x; idx < 32 * rowlen; idx += 256) {     // (ci, tap, co) with co fastest
-      const int co = idx & 31, r = idx >> 5;
-      const int tap = r % taps, ci = r / taps;
+    for (int idx = threadIdx.x; idx < TS * rowlen; idx += 256) {     // (ci, tap, co) with co fastest
+      const int co = idx & (TS - 1), r = idx >> sh;
+      const int ci = r / taps, tap = r - ci * taps;
       if (co < nco && ci < nci) {
         float v = tile[co * pitch + ci * taps + tap];
         if (j.bnscale) v *= j.bnscale[co0 + co];
@@ -583,6 +603,22 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const SedtPackJob* __re
       }
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void multi_pack_kernel(const SedtPackJob* __restrict__ jobs, int njobs) {
+  __shared__ float tile[32 * (32 * 9 + 1)];         // >= 64 * 65 as well
+  // find the tensor this block belongs to: jobs[].e0 holds the first block index of each tensor (ascending)
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].e0 <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SedtPackJob j = jobs[lo];
+  const int tb = (int)((long)blockIdx.x - j.e0);
+  if (j.taps == 1) pack_tile<T, 1>(j, tb, tile);
+  else if (j.taps == 9) pack_tile<T, 9>(j, tb, tile);
+  else pack_tile<T, 0>(j, tb, tile);
 }
 
 __global__ void multi_gather_kernel(const SedtChunk* __restrict__ table) {
@@ -717,10 +753,12 @@ extern "C" int sedt_stem_prep(const float* w0, const float* b0, const float* w1,
 
 extern "C" int sedt_stem_im2col(const float* x, void* col, int B, int H, int W, int dtype, void* stream) {
   int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  long n = (long)B * Ho * Wo * 128;
+  const long npix = (long)B * Ho * Wo;
+  SEDT_REQUIRE(npix * 128 < (1L << 31) * 16 && npix < (1L << 31) - 16, "stem_im2col: too many pixels for 32-bit indexing");
+  const unsigned nb = (unsigned)((npix + 15) / 16);
   BY_DTYPE(dtype,
-           hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(nblk(n)), dim3(256), 0, S(stream), x, (float*)col, B, H, W, Ho, Wo),
-           hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, S(stream), x, (bf16_t*)col, B, H, W, Ho, Wo));
+           hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(nb), dim3(256), 0, S(stream), x, (float*)col, B, H, W, Ho, Wo),
+           hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(nb), dim3(256), 0, S(stream), x, (bf16_t*)col, B, H, W, Ho, Wo));
   return check_launch("stem_im2col");
 }
 
@@ -731,12 +769,22 @@ extern "C" int sedt_stem_conv0_grad(const float* G, const float* w1, float* dw0,
 
 extern "C" int sedt_maxpool_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, int dtype, void* stream) {
   int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-  long n = (long)B * Ho * Wo * C;
-  BY_DTYPE(dtype,
-           hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(nblk(n)), dim3(256), 0, S(stream), (const float*)x, (float*)y, idx,
-                              B, H, W, C, Ho, Wo),
-           hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, S(stream), (const bf16_t*)x, (bf16_t*)y,
-                              idx, B, H, W, C, Ho, Wo));
+  auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+  SEDT_REQUIRE((long)B * H * W < (1L << 31), "maxpool_fwd: too many pixels for 32-bit indexing");
+  if (dtype == SEDT_BF16) {
+    SEDT_REQUIRE(C % 8 == 0 && al(x, 16) && al(y, 16) && al(idx, 8), "maxpool_fwd: needs C %% 8 == 0 and 16-byte aligned tensors");
+    long n = (long)B * Ho * Wo * (C / 8);
+    hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 8>), dim3(nblk(n)), dim3(256), 0, S(stream), (const bf16_t*)x, (bf16_t*)y, idx,
+                       B, H, W, C, Ho, Wo);
+  } else if (dtype == SEDT_F32) {
+    SEDT_REQUIRE(C % 4 == 0 && al(x, 16) && al(y, 16) && al(idx, 4), "maxpool_fwd: needs C %% 4 == 0 and 16-byte aligned tensors");
+    long n = (long)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL((maxpool_fwd_kernel<float, 4>), dim3(nblk(n)), dim3(256), 0, S(stream), (const float*)x, (float*)y, idx, B,
+                       H, W, C, Ho, Wo);
+  } else {
+    set_error("maxpool_fwd: unsupported dtype %d", dtype);
+    return 1;
+  }
   return check_launch("maxpool_fwd");
 }
 

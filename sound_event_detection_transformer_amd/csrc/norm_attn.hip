@@ -47,9 +47,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-template <typename T, int N>
-struct alignas(sizeof(T) * N) VecT { T v[N]; };
-
 template <typename T, int VPT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
                                                      const T* __restrict__ x, const float* __restrict__ gamma,
@@ -109,8 +106,19 @@ __global__ __launch_bounds__(1024) void ln_bwd_final_kernel(const float* __restr
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;     // 64 columns x 16 row groups
   const int c = blockIdx.x * 64 + tx;
   float s = 0.f;
-  if (c < 2 * D)
-    for (int b = ty; b < nblocks; b += 16) s += partial[(long)b * 2 * D + c];
+  if (c < 2 * D) {
+    // four independent partial sums: keeps four loads in flight per thread (the loop is latency-, not bandwidth-bound)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = ty;
+    for (; b + 48 < nblocks; b += 64) {
+      s0 += partial[(long)b * 2 * D + c];
+      s1 += partial[(long)(b + 16) * 2 * D + c];
+      s2 += partial[(long)(b + 32) * 2 * D + c];
+      s3 += partial[(long)(b + 48) * 2 * D + c];
+    }
+    for (; b < nblocks; b += 16) s0 += partial[(long)b * 2 * D + c];
+    s = (s0 + s1) + (s2 + s3);
+  }
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && c < 2 * D) {

@@ -90,7 +90,8 @@ class PackPlan(object):
             if taps > 9:
                 raise ValueError('PackPlan handles kernels up to 3x3 (the 7x7 stem conv is folded separately)')
             pk_rows.append((len(self._params), sc_ptr, wf_ptr, wb_ptr, self._nblocks, 0, Co, Ci, taps))
-            self._nblocks += ((Co + 31) // 32) * ((Ci + 31) // 32)
+            ts = 64 if taps == 1 else 32                      # tile edge of multi_pack_kernel (csrc/misc.hip)
+            self._nblocks += ((Co + ts - 1) // ts) * ((Ci + ts - 1) // ts)
             self._params.append(w)
         self._bn = np.zeros(len(bn_rows), _BN)
         for r, (bi_, scp, bip, c) in enumerate(bn_rows):
