@@ -147,6 +147,10 @@ int sedt_layernorm_bwd(const void* dy, const void* dy2, const void* x, const flo
                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* scratch,
                        size_t scratch_bytes, int rows, int D, int dtype, void* stream);
 size_t sedt_layernorm_bwd_scratch(int rows, int D);
+/* second stage of sedt_layernorm_bwd on its own (call sedt_layernorm_bwd with dgamma = dbeta = NULL first): reduces the
+ * per-workgroup partial sums in `scratch` to dgamma / dbeta.  Lets a caller move the parameter-gradient half off the
+ * critical path of the backward pass (another stream). */
+int sedt_layernorm_bwd_final(const float* scratch, int rows, int D, float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------ attention (head dim 32)
  * rows are batch-first: q row = b*Lq + i, k/v row = b*Lk + j, head h occupies columns [h*32, h*32+32).

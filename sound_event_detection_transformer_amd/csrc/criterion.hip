@@ -9,151 +9,162 @@
 // (d loss_ce_d / d logits, d loss_bbox_d / d boxes, d loss_giou_d / d boxes, d loss_weak / d at); a second one-launch
 // kernel combines them with whatever gradient arrives at the loss vector (the weighted total and/or single entries),
 // so `sum(loss_dict[k] * weight_dict[k])` in a caller's own train loop differentiates exactly as with the reference.
+#include <algorithm>
 #include "common.h"
 
 namespace sedt {
 
 __device__ __forceinline__ float sgn(float x) { return (x > 0.f) - (x < 0.f); }
 
+// deterministic sum of one value per thread over the 1024-thread workgroup (result valid in every thread)
+__device__ __forceinline__ float block_sum_1024(float v, float* red /* [17] */) {
+  const int t = threadIdx.x;
+  v = wave_sum(v);
+  __syncthreads();                 // red may still be read from the previous call
+  if ((t & 63) == 0) red[t >> 6] = v;
+  __syncthreads();
+  if (t == 0) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    red[16] = s;
+  }
+  __syncthreads();
+  return red[16];
+}
+
 __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion a) {
-  __shared__ float red[16][SEDT_CRIT_MAXOUT];
+  __shared__ float red[17];
   __shared__ int card[SEDT_CRIT_MAXCARD];      // predicted-event count of every (dense layer, clip): integer LDS atomics
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x;
   const int L = a.L, B = a.B, ns = a.ns, Q = a.Q, C1 = a.C + 1, C = a.C;
-  __shared__ float nb_sh;
-  if (a.num_boxes) {
-    if (t == 0) nb_sh = a.num_boxes[0];
-  } else {                                      // num_boxes = sum of the box weights of the final layer (sedt.py:330)
+  float nb;
+  if (a.num_boxes) nb = a.num_boxes[0];
+  else {                                        // num_boxes = sum of the box weights of the final layer (sedt.py:330)
     float sv = 0.f;
     for (int i = t; i < ns * Q; i += 1024) sv += a.wbox[i];
-    sv = wave_sum(sv);
-    if (lane == 0) red[wave][0] = sv;
-    __syncthreads();
-    if (t == 0) {
-      float v = 0.f;
-      for (int w = 0; w < 16; ++w) v += red[w][0];
-      nb_sh = v;
-    }
+    nb = block_sum_1024(sv, red);
   }
-  __syncthreads();
-  const float nb = nb_sh;
   const float inv_nb = 1.f / nb;
-  float acc[SEDT_CRIT_MAXOUT];
-#pragma unroll
-  for (int i = 0; i < SEDT_CRIT_MAXOUT; ++i) acc[i] = 0.f;
   // output slots: [4*d + 0..3] = ce, bbox, giou, cardinality of dense layer d; then class_error hits, matched count, weak
   const int SLOT_HIT = 4 * L, SLOT_CNT = 4 * L + 1, SLOT_WEAK = 4 * L + 2;
-
   for (int i = t; i < L * B; i += 1024) card[i] = 0;
   __syncthreads();
-  // ---------------- classification + boxes: one row = (dense layer d, clip b, query q)
-  const int nrows = L * B * Q;
-  for (int r = t; r < nrows; r += 1024) {
-    const int q = r % Q, b = (r / Q) % B, d = r / (Q * B);
-    const int ml = a.layer_of[d];                                 // which slice of the model's stacked outputs
-    const float* x = a.logits + (((long)ml * B + b) * Q + q) * C1;
-    float* gx = a.dlogits + (((long)ml * B + b) * Q + q) * C1;
-    float* gbx = a.dboxes + (((long)ml * B + b) * Q + q) * 2;
-    float* gbx2 = a.dboxes2 + (((long)ml * B + b) * Q + q) * 2;
-    float m = -INFINITY;
-    int amax = 0;
-    for (int c = 0; c < C1; ++c)
-      if (x[c] > m) { m = x[c]; amax = c; }
-    if (amax != C) atomicAdd(&card[d * B + b], 1);
-    if (b >= ns) {                                                // not strongly labelled: no CE / box loss, zero grads
-      for (int c = 0; c < C1; ++c) gx[c] = 0.f;
-      gbx[0] = 0.f; gbx[1] = 0.f;
-      gbx2[0] = 0.f; gbx2[1] = 0.f;
-      continue;
+
+  float total = 0.f;
+  // ---------------- per dense layer d (uniform loop: every accumulator is a plain register, every sum a block reduction)
+  for (int d = 0; d < L; ++d) {
+    const int ml = a.layer_of[d];               // which slice of the model's stacked outputs
+    float l_ce = 0.f, l_bb = 0.f, l_gi = 0.f, n_hit = 0.f, n_cnt = 0.f;
+    for (int rr = t; rr < B * Q; rr += 1024) {  // one row = (clip b, query q)
+      const int b = rr / Q, q = rr - b * Q;
+      const long mrow = ((long)ml * B + b) * Q + q;
+      const float* x = a.logits + mrow * C1;
+      float* gx = a.dlogits + mrow * C1;
+      float* gbx = a.dboxes + mrow * 2;
+      float* gbx2 = a.dboxes2 + mrow * 2;
+      float m = -INFINITY;
+      int amax = 0;
+      for (int c = 0; c < C1; ++c)
+        if (x[c] > m) { m = x[c]; amax = c; }
+      if (amax != C) atomicAdd(&card[d * B + b], 1);
+      if (b >= ns) {                            // not strongly labelled: no CE / box loss, zero grads
+        for (int c = 0; c < C1; ++c) gx[c] = 0.f;
+        gbx[0] = 0.f; gbx[1] = 0.f;
+        gbx2[0] = 0.f; gbx2[1] = 0.f;
+        continue;
+      }
+      const long di = ((long)d * ns + b) * Q + q;
+      const int tc = (int)a.tc[di];
+      const float coef = a.coef[di], wb = a.wbox[di];
+      float se = 0.f;
+      for (int c = 0; c < C1; ++c) se += __expf(x[c] - m);
+      const float lse = m + __logf(se);
+      const float w = a.empty_weight[tc];
+      l_ce += w * (lse - x[tc]) * coef * inv_nb;
+      const float gscale = coef * w * inv_nb;
+      for (int c = 0; c < C1; ++c) gx[c] = gscale * (__expf(x[c] - lse) - (c == tc ? 1.f : 0.f));
+      if (d == 0 && wb > 0.f) {
+        n_cnt += 1.f;
+        if (amax == tc) n_hit += 1.f;
+      }
+      // boxes (centre, length) -> interval [s, e]
+      const float* bx = a.boxes + mrow * 2;
+      float gc = 0.f, gl = 0.f, gc2 = 0.f, gl2 = 0.f;
+      if (wb > 0.f) {
+        const float s1 = bx[0] - 0.5f * bx[1], e1 = bx[0] + 0.5f * bx[1];
+        const float tcn = a.tbox[2 * di], tln = a.tbox[2 * di + 1];
+        const float s2 = tcn - 0.5f * tln, e2 = tcn + 0.5f * tln;
+        // L1 on the fake boxes [s,0,e,1]: |s1-s2| + |e1-e2|
+        l_bb += (fabsf(s1 - s2) + fabsf(e1 - e2)) * wb * inv_nb;
+        const float gs = wb * inv_nb * sgn(s1 - s2), ge = wb * inv_nb * sgn(e1 - e2);
+        gc = gs + ge;
+        gl = 0.5f * (ge - gs);
+        // GIoU
+        const float lo = fmaxf(s1, s2), hi = fminf(e1, e2);
+        const float inter = fmaxf(hi - lo, 0.f);
+        const float di_e = (hi - lo > 0.f && e1 < e2) ? 1.f : 0.f;     // d inter / d e1
+        const float di_s = (hi - lo > 0.f && s1 > s2) ? -1.f : 0.f;    // d inter / d s1
+        const float uni = (e1 - s1) + (e2 - s2) - inter;
+        const float du_e = 1.f - di_e, du_s = -1.f - di_s;
+        const float hull = fmaxf(fmaxf(e1, e2) - fminf(s1, s2), 0.f);
+        const float dh_e = e1 > e2 ? 1.f : 0.f, dh_s = s1 < s2 ? -1.f : 0.f;
+        const float giou = inter / uni - (hull - uni) / hull;
+        l_gi += (1.f - giou) * wb * inv_nb;
+        // d giou = d(inter/uni) + d(uni/hull)
+        const float dg_e = (di_e * uni - inter * du_e) / (uni * uni) + (du_e * hull - uni * dh_e) / (hull * hull);
+        const float dg_s = (di_s * uni - inter * du_s) / (uni * uni) + (du_s * hull - uni * dh_s) / (hull * hull);
+        const float k = -wb * inv_nb;
+        gc2 = k * (dg_s + dg_e);
+        gl2 = 0.5f * k * (dg_e - dg_s);
+      }
+      gbx[0] = gc;
+      gbx[1] = gl;
+      gbx2[0] = gc2;
+      gbx2[1] = gl2;
     }
-    const long di = ((long)d * ns + b) * Q + q;
-    const int tc = (int)a.tc[di];
-    const float coef = a.coef[di], wb = a.wbox[di];
-    float se = 0.f;
-    for (int c = 0; c < C1; ++c) se += __expf(x[c] - m);
-    const float lse = m + __logf(se);
-    const float w = a.empty_weight[tc];
-    acc[4 * d + 0] += w * (lse - x[tc]) * coef * inv_nb;
-    const float gscale = coef * w * inv_nb;
-    for (int c = 0; c < C1; ++c) gx[c] = gscale * (__expf(x[c] - lse) - (c == tc ? 1.f : 0.f));
-    if (d == 0 && wb > 0.f) {
-      acc[SLOT_CNT] += 1.f;
-      if (amax == tc) acc[SLOT_HIT] += 1.f;
+    l_ce = block_sum_1024(l_ce, red);
+    l_bb = block_sum_1024(l_bb, red);
+    l_gi = block_sum_1024(l_gi, red);           // (the barriers inside also publish this layer's card[] counters)
+    float cerr = 0.f;                           // |#predicted events - #targets| averaged over ALL clips
+    for (int b = t; b < B; b += 1024) cerr += fabsf((float)card[d * B + b] - a.tgt_len[b]) / (float)B;
+    cerr = block_sum_1024(cerr, red);
+    if (d == 0) {
+      n_hit = block_sum_1024(n_hit, red);
+      n_cnt = block_sum_1024(n_cnt, red);
+      if (t == 0) {
+        a.out[SLOT_HIT] = n_hit;
+        a.out[SLOT_CNT] = n_cnt;
+        a.out[4 * L + 4] = 100.f - 100.f * n_hit / fmaxf(n_cnt, 1.f);     // class_error
+      }
     }
-    // boxes (centre, length) -> interval [s, e]
-    const float* bx = a.boxes + (((long)ml * B + b) * Q + q) * 2;
-    float gc = 0.f, gl = 0.f, gc2 = 0.f, gl2 = 0.f;
-    if (wb > 0.f) {
-      const float s1 = bx[0] - 0.5f * bx[1], e1 = bx[0] + 0.5f * bx[1];
-      const float tcn = a.tbox[2 * di], tln = a.tbox[2 * di + 1];
-      const float s2 = tcn - 0.5f * tln, e2 = tcn + 0.5f * tln;
-      // L1 on the fake boxes [s,0,e,1]: |s1-s2| + |e1-e2|
-      acc[4 * d + 1] += (fabsf(s1 - s2) + fabsf(e1 - e2)) * wb * inv_nb;
-      float gs = wb * inv_nb * sgn(s1 - s2), ge = wb * inv_nb * sgn(e1 - e2);
-      gc = gs + ge;
-      gl = 0.5f * (ge - gs);
-      // GIoU
-      const float lo = fmaxf(s1, s2), hi = fminf(e1, e2);
-      const float inter = fmaxf(hi - lo, 0.f);
-      const float di_e = (hi - lo > 0.f && e1 < e2) ? 1.f : 0.f;     // d inter / d e1
-      const float di_s = (hi - lo > 0.f && s1 > s2) ? -1.f : 0.f;    // d inter / d s1
-      const float uni = (e1 - s1) + (e2 - s2) - inter;
-      const float du_e = 1.f - di_e, du_s = -1.f - di_s;
-      const float hull = fmaxf(fmaxf(e1, e2) - fminf(s1, s2), 0.f);
-      const float dh_e = e1 > e2 ? 1.f : 0.f, dh_s = s1 < s2 ? -1.f : 0.f;
-      const float giou = inter / uni - (hull - uni) / hull;
-      acc[4 * d + 2] += (1.f - giou) * wb * inv_nb;
-      // d giou = d(inter/uni) + d(uni/hull)
-      const float dg_e = (di_e * uni - inter * du_e) / (uni * uni) + (du_e * hull - uni * dh_e) / (hull * hull);
-      const float dg_s = (di_s * uni - inter * du_s) / (uni * uni) + (du_s * hull - uni * dh_s) / (hull * hull);
-      const float k = -wb * inv_nb;
-      gc2 = k * (dg_s + dg_e);
-      gl2 = 0.5f * k * (dg_e - dg_s);
+    if (t == 0) {
+      a.out[4 * d] = l_ce;
+      a.out[4 * d + 1] = l_bb;
+      a.out[4 * d + 2] = l_gi;
+      a.out[4 * d + 3] = cerr;
     }
-    gbx[0] = gc;
-    gbx[1] = gl;
-    gbx2[0] = gc2;
-    gbx2[1] = gl2;
+    total += a.w_ce[d] * l_ce + a.w_bbox[d] * l_bb + a.w_giou[d] * l_gi;
   }
 
-  // ---------------- cardinality: |#predicted events - #targets| averaged over ALL clips
-  __syncthreads();
-  for (int r = t; r < L * B; r += 1024) acc[4 * (r / B) + 3] += fabsf((float)card[r] - a.tgt_len[r % B]) / (float)B;
-
   // ---------------- audio-tag BCE (mean over n_lab x C), torch semantics: log clamped at -100, grad denominator >= 1e-12
+  float weak = 0.f;
   if (a.at) {
     const int n = a.n_lab * C;
     for (int r = t; r < a.Bat * C; r += 1024) {
       float g = 0.f;
       if (r < n) {
         const float p = a.at[r], y = a.gt_weak[r];
-        acc[SLOT_WEAK] += -(y * fmaxf(__logf(p), -100.f) + (1.f - y) * fmaxf(__logf(1.f - p), -100.f)) / (float)n;
+        weak += -(y * fmaxf(__logf(p), -100.f) + (1.f - y) * fmaxf(__logf(1.f - p), -100.f)) / (float)n;
         g = (p - y) / fmaxf(p * (1.f - p), 1e-12f) / (float)n;
       }
       a.dat[r] = g;
     }
+    weak = block_sum_1024(weak, red);
+    total += a.w_weak * weak;
   }
-
-  // ---------------- block reduction of the scalar outputs
-  const int nout = 4 * L + 3;
-  for (int i = 0; i < nout; ++i) {
-    const float v = wave_sum(acc[i]);
-    if (lane == 0) red[wave][i] = v;
-  }
-  __syncthreads();
-  if (t < nout) {
-    float v = 0.f;
-    for (int w = 0; w < 16; ++w) v += red[w][t];
-    a.out[t] = v;
-  }
-  __syncthreads();
   if (t == 0) {
-    float total = 0.f;
-    for (int d = 0; d < L; ++d)
-      total += a.w_ce[d] * a.out[4 * d] + a.w_bbox[d] * a.out[4 * d + 1] + a.w_giou[d] * a.out[4 * d + 2];
-    if (a.at) total += a.w_weak * a.out[SLOT_WEAK];
-    a.out[nout] = total;                                                               // weighted total
-    a.out[nout + 1] = 100.f - 100.f * a.out[SLOT_HIT] / fmaxf(a.out[SLOT_CNT], 1.f);   // class_error
+    a.out[SLOT_WEAK] = weak;
+    a.out[4 * L + 3] = total;                   // weighted total
   }
 }
 
@@ -247,14 +258,15 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
   const int L = a.L, B = a.B, ns = a.ns, Q = a.Q, C = a.C, C1 = a.C + 1;
   if ((int)blockIdx.x == L * ns) {
     // ---- bookkeeping block: per-clip target counts (cardinality) and the clip-level tag targets (sedt.py:199-209)
+    float* row = lds + lane * (C + 1);          // this lane's tag row lives in LDS until it is complete
     for (int b = lane; b < B; b += 64) {
       const int o = a.lab_off[b], n = a.lab_off[b + 1] - o;
       a.tgt_len[b] = (float)n;
       if (a.gt_weak && b < a.n_lab) {
+        for (int c = 0; c < C; ++c) row[c] = 0.f;
+        for (int j = 0; j < n; ++j) row[a.lab_cat[o + j]] += a.ratio_cat ? a.ratio_cat[o + j] : 1.f;
         float* g = a.gt_weak + (long)b * C;
-        for (int c = 0; c < C; ++c) g[c] = 0.f;
-        for (int j = 0; j < n; ++j) g[a.lab_cat[o + j]] += a.ratio_cat ? a.ratio_cat[o + j] : 1.f;
-        for (int c = 0; c < C; ++c) g[c] = fminf(fmaxf(g[c], 0.f), 1.f);
+        for (int c = 0; c < C; ++c) g[c] = fminf(fmaxf(row[c], 0.f), 1.f);
       }
     }
     return;
@@ -365,7 +377,7 @@ extern "C" int sedt_match_targets(const SedtMatch* args, void* stream) {
   SEDT_REQUIRE(a.logits && a.boxes && a.lab_cat && a.lab_off && a.box_cat && a.box_off && a.tc && a.coef && a.wbox && a.tbox &&
                    a.tidx && a.tgt_len,
                "match_targets: null pointer");
-  const size_t lds = (size_t)a.Q * (a.C + 1 + a.max_targets) * sizeof(float);
+  const size_t lds = std::max((size_t)a.Q * (a.C + 1 + a.max_targets), (size_t)64 * (a.C + 1)) * sizeof(float);
   hipLaunchKernelGGL(match_targets_kernel, dim3(a.L * a.ns + 1), dim3(64), lds, reinterpret_cast<hipStream_t>(stream), a);
   return check_launch("match_targets");
 }

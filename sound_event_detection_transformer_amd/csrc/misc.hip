@@ -400,27 +400,35 @@ __global__ void avgpool_kernel(const T* __restrict__ x, float* __restrict__ out,
   out[e] = s / (float)P;
 }
 
+// thread = one pixel x 8 consecutive channels (4 sin/cos pairs): the cumulative count of unmasked rows is computed once per
+// thread instead of once per channel
 template <typename T>
-__global__ void posenc_kernel(const uint8_t* __restrict__ mask, T* __restrict__ pos, int B, int H, int W, int D) {
-  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long n = (long)B * H * W * D;
-  if (e >= n) return;
-  int c = (int)(e % D);
-  long r = e / D;
-  int w = (int)(r % W);
-  r /= W;
-  int h = (int)(r % H), b = (int)(r / H);
+__global__ __launch_bounds__(256) void posenc_kernel(const uint8_t* __restrict__ mask, T* __restrict__ pos, int B, int H, int W,
+                                                     int D) {
+  const int DV = D / 8;
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long)B * H * W * DV) return;
+  const int c0 = (int)(e % DV) * 8;
+  const int pix = (int)(e / DV);
+  const int w = pix % W, r = pix / W;
+  const int h = r % H, b = r / H;
   const uint8_t* m = mask + (long)b * H * W + w;
   float cum = 0.f, tot = 0.f;
   for (int i = 0; i < H; ++i) {
-    float nm = m[(long)i * W] ? 0.f : 1.f;
+    const float nm = m[(long)i * W] ? 0.f : 1.f;
     tot += nm;
     if (i <= h) cum += nm;
   }
-  float y = cum / (tot + 1e-6f) * 6.283185307179586f;
-  float dim_t = powf(10000.f, (float)(2 * (c / 2)) / (float)D);
-  float a = y / dim_t;
-  pos[e] = (T)((c & 1) ? cosf(a) : sinf(a));
+  const float y = cum / (tot + 1e-6f) * 6.283185307179586f;
+  VecT<T, 8> out;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float dim_t = powf(10000.f, (float)(c0 + 2 * q) / (float)D);
+    const float a = y / dim_t;
+    out.v[2 * q] = (T)sinf(a);
+    out.v[2 * q + 1] = (T)cosf(a);
+  }
+  *reinterpret_cast<VecT<T, 8>*>(pos + (long)pix * D + c0) = out;
 }
 
 __global__ void mask_resize_kernel(const uint8_t* in, uint8_t* out, int B, int Hin, int Win, int Hout, int Wout) {
@@ -820,7 +828,9 @@ extern "C" int sedt_avgpool(const void* x, float* out, int B, int P, int C, int 
 }
 
 extern "C" int sedt_posenc(const uint8_t* mask, void* pos, int B, int H, int W, int D, int dtype, void* stream) {
-  long n = (long)B * H * W * D;
+  SEDT_REQUIRE(D % 8 == 0 && (reinterpret_cast<uintptr_t>(pos) & 31) == 0 && (long)B * H * W < (1L << 31),
+               "posenc: needs D %% 8 == 0, a 32-byte aligned output and < 2^31 pixels");
+  long n = (long)B * H * W * (D / 8);
   BY_DTYPE(dtype,
            hipLaunchKernelGGL(posenc_kernel<float>, dim3(nblk(n)), dim3(256), 0, S(stream), mask, (float*)pos, B, H, W, D),
            hipLaunchKernelGGL(posenc_kernel<bf16_t>, dim3(nblk(n)), dim3(256), 0, S(stream), mask, (bf16_t*)pos, B, H, W, D));

@@ -424,6 +424,13 @@ extern "C" int sedt_layernorm_bwd(const void* dy, const void* dy2, const void* x
   return check_launch("layernorm_bwd");
 }
 
+extern "C" int sedt_layernorm_bwd_final(const float* scratch, int rows, int D, float* dgamma, float* dbeta, void* stream) {
+  SEDT_REQUIRE(scratch && (dgamma || dbeta) && rows > 0 && D > 0, "layernorm_bwd_final: bad arguments");
+  hipLaunchKernelGGL(ln_bwd_final_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, S(stream), scratch, ln_bwd_blocks(rows), D, dgamma,
+                     dbeta);
+  return check_launch("layernorm_bwd_final");
+}
+
 extern "C" int sedt_attention_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                                   int64_t ldo, float* lse, const uint8_t* kpm, const float* amask, int B, int H, int Lq, int Lk,
                                   float drop_p, uint32_t seed, const uint32_t* seed_ptr, int dtype, void* stream) {

@@ -256,14 +256,14 @@ class EncoderLayerFn(Function):
         rb = ops.ReduceBatch()
         if cfg['pre_norm']:
             g_x1n, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], gx2, w1, w2, batch=rb)
-            gx1, d_g2, d_be2 = ops.layernorm_bwd(dt, g_x1n, sv['x1'], g2, sv['m2'], sv['r2'], dres=gx2)
+            gx1, d_g2, d_be2 = ops.layernorm_bwd(dt, g_x1n, sv['x1'], g2, sv['m2'], sv['r2'], dres=gx2, batch=rb)
             g_qk, _, g_v, d_win, d_bin, d_wo, d_bo = _mha_bwd(dt, sv['mha'], gx1, w_in, w_o, batch=rb)
             # LN1 fed xn (to V) and xn+pos (to Q,K): both gradients land on xn
-            gx, d_g1, d_be1 = ops.layernorm_bwd(dt, g_v, sv['x'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gx1)
+            gx, d_g1, d_be1 = ops.layernorm_bwd(dt, g_v, sv['x'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gx1, batch=rb)
         else:
-            g_t2, d_g2, d_be2 = ops.layernorm_bwd(dt, gx2, sv['t2'], g2, sv['m2'], sv['r2'])
+            g_t2, d_g2, d_be2 = ops.layernorm_bwd(dt, gx2, sv['t2'], g2, sv['m2'], sv['r2'], batch=rb)
             g_x1, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], g_t2, w1, w2, res_for_gx=g_t2, batch=rb)
-            g_t, d_g1, d_be1 = ops.layernorm_bwd(dt, g_x1, sv['t'], g1, sv['m1'], sv['r1'])
+            g_t, d_g1, d_be1 = ops.layernorm_bwd(dt, g_x1, sv['t'], g1, sv['m1'], sv['r1'], batch=rb)
             g_qk, _, g_v, d_win, d_bin, d_wo, d_bo = _mha_bwd(dt, sv['mha'], g_t, w_in, w_o, batch=rb)
             gx = ops.add(dt, ops.add(dt, g_qk, g_v), g_t)
         rb.flush()
@@ -317,24 +317,24 @@ class DecoderLayerFn(Function):
         rb = ops.ReduceBatch()
         if cfg['pre_norm']:
             g_t2n, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], gt3, w1, w2, batch=rb)
-            gt2, d_g3, d_be3 = ops.layernorm_bwd(dt, g_t2n, sv['t2'], g3, sv['m3'], sv['r3'], dres=gt3)
+            gt2, d_g3, d_be3 = ops.layernorm_bwd(dt, g_t2n, sv['t2'], g3, sv['m3'], sv['r3'], dres=gt3, batch=rb)
             g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], gt2, cw_in, cw_o, batch=rb)
             # LN2 outputs: t1n (unused on its own) and t1n + qpos (cross-attn query)
-            gt1, d_g2, d_be2 = ops.layernorm_bwd(dt, g_q, sv['t1'], g2, sv['m2'], sv['r2'], dres=gt2)
+            gt1, d_g2, d_be2 = ops.layernorm_bwd(dt, g_q, sv['t1'], g2, sv['m2'], sv['r2'], dres=gt2, batch=rb)
             g_qpos = g_q
             g_mem_pos, g_mem = g_k, g_v
             g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], gt1, sw_in, sw_o, batch=rb)
-            gtgt, d_g1, d_be1 = ops.layernorm_bwd(dt, g_vs, sv['tgt'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gt1)
+            gtgt, d_g1, d_be1 = ops.layernorm_bwd(dt, g_vs, sv['tgt'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gt1, batch=rb)
             g_qpos = ops.add(dt, g_qpos, g_qk)
         else:
-            g_f, d_g3, d_be3 = ops.layernorm_bwd(dt, gt3, sv['f'], g3, sv['m3'], sv['r3'])
+            g_f, d_g3, d_be3 = ops.layernorm_bwd(dt, gt3, sv['f'], g3, sv['m3'], sv['r3'], batch=rb)
             g_t2, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], g_f, w1, w2, res_for_gx=g_f, batch=rb)
-            g_c, d_g2, d_be2 = ops.layernorm_bwd(dt, g_t2, sv['c'], g2, sv['m2'], sv['r2'])
+            g_c, d_g2, d_be2 = ops.layernorm_bwd(dt, g_t2, sv['c'], g2, sv['m2'], sv['r2'], batch=rb)
             g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], g_c, cw_in, cw_o, batch=rb)
             g_t1 = ops.add(dt, g_q, g_c)                     # query path + residual
             g_qpos = g_q
             g_mem_pos, g_mem = g_k, g_v
-            g_a, d_g1, d_be1 = ops.layernorm_bwd(dt, g_t1, sv['a'], g1, sv['m1'], sv['r1'])
+            g_a, d_g1, d_be1 = ops.layernorm_bwd(dt, g_t1, sv['a'], g1, sv['m1'], sv['r1'], batch=rb)
             g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], g_a, sw_in, sw_o, batch=rb)
             gtgt = ops.add(dt, ops.add(dt, g_qk, g_vs), g_a)
             g_qpos = ops.add(dt, g_qpos, g_qk)

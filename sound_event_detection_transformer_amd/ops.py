@@ -274,7 +274,9 @@ def layernorm_fwd(dtype, x, gamma, beta, add_t=None):
     return y, y2, mean, rstd
 
 
-def layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2=None, dres=None, want_param_grads=True):
+def layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2=None, dres=None, want_param_grads=True, batch=None):
+    """batch (a ReduceBatch inside runtime.async_wgrad): the gamma/beta reduction - which only feeds the optimizer - is
+    deferred to batch.flush() and runs with the layer's weight gradients on the side stream"""
     lib = L.load()
     rows, D = x.shape
     dx = torch.empty_like(x)
@@ -282,6 +284,13 @@ def layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2=None, dres=None, want_par
     db = torch.empty((D,), device=x.device, dtype=torch.float32) if want_param_grads else None
     nb = lib.sedt_layernorm_bwd_scratch(rows, D)
     scratch = torch.empty((nb // 4,), device=x.device, dtype=torch.float32)
+    from . import runtime
+    if want_param_grads and batch is not None and runtime.async_wgrad_on():
+        L.check(lib.sedt_layernorm_bwd(_p(dy), _p(dy2), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), None, None,
+                                       _p(scratch), nb, rows, D, dtype, L.stream_ptr()), 'layernorm_bwd')
+        batch.defer(lambda: L.check(lib.sedt_layernorm_bwd_final(_p(scratch), rows, D, _p(dg), _p(db), L.stream_ptr()),
+                                    'layernorm_bwd_final'), (scratch,))
+        return dx, dg, db
     L.check(lib.sedt_layernorm_bwd(_p(dy), _p(dy2), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dg), _p(db),
                                    _p(scratch), nb, rows, D, dtype, L.stream_ptr()), 'layernorm_bwd')
     return dx, dg, db

@@ -31,10 +31,25 @@ class NestedTensor(object):
         return str(self.tensors)
 
 
+_MASKS = {}
+
+
+def _no_padding_mask(b, h, w, device):
+    """all-False (B,T,F) padding mask, created once per shape (read-only by convention: nothing in the path writes masks)"""
+    key = (b, h, w, str(device))
+    if key not in _MASKS:
+        if len(_MASKS) > 16:
+            _MASKS.clear()
+        _MASKS[key] = torch.zeros((b, h, w), dtype=torch.bool, device=device)
+    return _MASKS[key]
+
+
 def nested_tensor_from_tensor_list(tensor_list: List[Tensor]) -> NestedTensor:
     """pad (C,T,F) clips to the batch maximum; mask is True on padding (reference utils.py:470-492)"""
     if isinstance(tensor_list, Tensor) and tensor_list.ndim == 4:
-        tensor_list = list(tensor_list)
+        # an already batched (B,C,T,F) tensor: no padding anywhere - use it as is, with a cached all-False mask
+        b, _, h, w = tensor_list.shape
+        return NestedTensor(tensor_list, _no_padding_mask(b, h, w, tensor_list.device))
     if tensor_list[0].ndim != 3:
         raise ValueError('not supported')
     c = max(t.shape[0] for t in tensor_list)
@@ -45,8 +60,7 @@ def nested_tensor_from_tensor_list(tensor_list: List[Tensor]) -> NestedTensor:
     same = all(tuple(t.shape) == (c, h, w) for t in tensor_list)
     if same:                       # the training pipeline pads every clip to fixed frames: no per-clip copies
         tensor = torch.stack(list(tensor_list))
-        mask = torch.zeros((b, h, w), dtype=torch.bool, device=device)
-        return NestedTensor(tensor, mask)
+        return NestedTensor(tensor, _no_padding_mask(b, h, w, device))
     tensor = torch.zeros((b, c, h, w), dtype=dtype, device=device)
     mask = torch.ones((b, h, w), dtype=torch.bool, device=device)
     for img, pad_img, m in zip(tensor_list, tensor, mask):
