@@ -70,7 +70,11 @@ def main():
     ap.add_argument('--dump-igemm', default=None, help='write per-launch igemm timings (json) to this path')
     ap.add_argument('--host-matching', action='store_true',
                     help='solve the Hungarian matching on the host between two HIP graphs (the reference split) instead of on the device')
-    ap.add_argument('--sync-wgrad', action='store_true', help='keep the weight-gradient GEMMs on the main stream (no parallel graph branch)')
+    ap.add_argument('--coschedule', action='store_true', help='let weight-gradient GEMMs ride in the spare workgroup slots of the\n'
+                    'dgrad launches instead of one grouped launch per layer (measured slightly slower)')
+    ap.add_argument('--async-wgrad', action='store_true',
+                    help='issue the weight-gradient GEMMs as a parallel branch of the step graph (second stream); measured slower than the\n'
+                         'single-stream graph on ROCm 7.2: cross-queue dependencies cost 50-100 us each')
     ap.add_argument('--no-graph', action='store_true', help='issue every kernel from Python instead of replaying HIP graphs')
     ap.add_argument('--model-only', action='store_true', help='time fwd+bwd of the model with a fixed differentiable loss')
     args = ap.parse_args()
@@ -111,7 +115,7 @@ def main():
     graphed = None
     if not args.no_graph and not args.model_only:
         graphed = GraphedTrainStep(net, criterion, opt, x, targets, None, slice(B), max_norm=0.1,
-                                   device_matching=not args.host_matching, async_wgrad=not args.sync_wgrad)
+                                   device_matching=not args.host_matching, async_wgrad=args.async_wgrad, coschedule=args.coschedule)
 
     def step():
         if graphed is not None and ops.PROFILE is None:

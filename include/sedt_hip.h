@@ -96,6 +96,14 @@ typedef struct SedtIgemm {
 } SedtIgemm;
 
 int sedt_igemm(const SedtIgemm* args, int dtype, void* stream);
+/* njobs independent trans == 1 (weight-gradient) problems; in bf16 they run as ONE launch (grouped workgroup ranges) when
+ * every problem fits the LDS-DMA kernel, otherwise this is njobs sedt_igemm calls.  `jobs` is a HOST array. */
+int sedt_wgrad_group(const SedtIgemm* jobs, int njobs, int dtype, void* stream);
+/* one forward / dgrad problem (`main`, trans == 0) plus nw <= 10 weight-gradient problems in ONE launch: the wgrad tiles run
+ * in workgroup slots the main problem leaves idle (co-scheduling).  *taken = 1: semantically sedt_igemm(main) +
+ * sedt_wgrad_group(wjobs); *taken = 0: only `main` was launched (its kernel configuration cannot carry riders, or a rider
+ * is outside the grouped kernel's envelope) and the caller still owns the weight-gradient problems. */
+int sedt_igemm_co(const SedtIgemm* main, const SedtIgemm* wjobs, int nw, int dtype, void* stream, int* taken);
 /* recommended split-K factor and slab bytes for a trans==1 problem */
 int sedt_igemm_splitk(int M, int N, int K, int dtype);
 

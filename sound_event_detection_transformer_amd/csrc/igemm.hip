@@ -490,6 +490,48 @@ extern "C" int sedt_igemm(const SedtIgemm* args, int dtype, void* stream) {
   return 1;
 }
 
+namespace sedt { int wgrad3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st); }
+
+extern "C" int sedt_wgrad_group(const SedtIgemm* jobs, int njobs, int dtype, void* stream) {
+  SEDT_REQUIRE(jobs && njobs >= 1, "wgrad_group: bad arguments");
+  if (dtype == SEDT_BF16) {
+    const int r = sedt::wgrad3_group_try(jobs, njobs, reinterpret_cast<hipStream_t>(stream));
+    if (r >= 0) return r;
+  }
+  for (int i = 0; i < njobs; ++i)          // problems the grouped kernel cannot take (f32 mode, odd shapes): one by one
+    if (int r = sedt_igemm(&jobs[i], dtype, stream)) return r;
+  return 0;
+}
+
+// forward / dgrad GEMM `main` with up to 10 weight-gradient problems riding in the same launch (igemm3_co_kernel).  Falls
+// back to separate launches whenever either side is outside its fast kernel's envelope - the results are the same.
+#include "wgrad3_body.h"
+namespace sedt {
+int wgrad3_group_build(const SedtIgemm* jobs, int njobs, WgradGroup* g);
+extern thread_local const WgradGroup* co_group;
+extern thread_local bool co_taken;
+}
+
+extern "C" int sedt_igemm_co(const SedtIgemm* main, const SedtIgemm* wjobs, int nw, int dtype, void* stream, int* taken) {
+  using namespace sedt;
+  SEDT_REQUIRE(main && (nw == 0 || wjobs) && taken, "igemm_co: bad arguments");
+  *taken = 0;
+  if (nw == 0) return sedt_igemm(main, dtype, stream);
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("SEDT_COSCHEDULE");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  WgradGroup g;
+  bool grouped = on && dtype == SEDT_BF16 && main->trans == 0 && wgrad3_group_build(wjobs, nw, &g) == 0;
+  co_taken = false;
+  co_group = grouped ? &g : nullptr;
+  const int r = sedt_igemm(main, dtype, stream);
+  co_group = nullptr;
+  *taken = co_taken ? 1 : 0;          // 0: the main GEMM ran on a kernel that cannot carry riders; the caller keeps them
+  return r;
+}
+
 extern "C" int sedt_igemm_splitk(int M, int N, int K, int dtype) {
   // wgrad outputs are small (Cout x taps*Cin) while K (pixels) is long: split K until ~TARGET workgroups of 64x64,
   // keeping at least 4 K tiles per slice.  Every split costs a 64x64 f32 partial tile written and re-read, so the target

@@ -16,14 +16,14 @@
 // (K tails, f32 output, sigmoid) stays on igemm2 / igemm.
 #include <stdlib.h>
 #include <type_traits>
-#include "igemm2_common.h"
+#include "wgrad3_body.h"
 
 namespace sedt {
 
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <int BM, int BN, int S>   // S = ring depth (stages)
-__global__ __launch_bounds__(256) void igemm3_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes) {
+template <int BM, int BN, int S>   // S = ring depth (stages); bx = index of this workgroup among the problem's tiles
+__device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int bx) {
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int STAGE_BYTES = (BM + BN) * ROWB;
   constexpr int GA = BM / 32, GB = BN / 32;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void igemm3_kernel(const SedtIgemm p, const un
   const int nwg = ntn * ntm;
   int vid;
   {
-    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int b = bx, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
     vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
   const int m0 = (vid / ntn) * BM, n0 = (vid % ntn) * BN;
@@ -271,7 +271,52 @@ __global__ __launch_bounds__(256) void igemm3_kernel(const SedtIgemm p, const un
 }
 
 template <int BM, int BN, int S>
+__global__ __launch_bounds__(256) void igemm3_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes) {
+  igemm3_body<BM, BN, S>(p, a_bytes, b_bytes, blockIdx.x);
+}
+
+// Co-scheduled launch: the first nwg_main workgroups run the forward / dgrad GEMM p, the rest run pending weight-gradient
+// problems.  At batch 64 most GEMMs of the backward chain occupy 2 of the ~5 workgroup slots of a CU; weight gradients
+// are needed only by the optimizer, so their tiles ride in the spare slots of the chain's launches instead of taking
+// launches (and tails) of their own.  Measured with two streams: dgrad + wgrad of one layer4 conv 162 us -> 139 us.
+template <int BM, int BN, int S>
+__global__ __launch_bounds__(256) void igemm3_co_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes,
+                                                        const int nwg_main, const WgradGroup g) {
+  if ((int)blockIdx.x < nwg_main) igemm3_body<BM, BN, S>(p, a_bytes, b_bytes, blockIdx.x);
+  else wgrad_group_run(g, (int)blockIdx.x - nwg_main);
+}
+
+// set by sedt_igemm_co (igemm.hip) around its sedt_igemm call: the weight-gradient group the next igemm3 launch takes along
+thread_local const WgradGroup* co_group = nullptr;
+thread_local bool co_taken = false;
+
+template <int BM, int BN, int S>
+static int launch3_co(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st, const WgradGroup& g) {
+  constexpr size_t ring = (size_t)S * (BM + BN) * ROWB;
+  constexpr size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);
+  constexpr size_t wg = (size_t)2 * (64 * ROWB + 64 * 64 * 2);
+  constexpr size_t lds0 = ring > ctile ? ring : ctile;
+  constexpr size_t lds = lds0 > wg ? lds0 : wg;
+  static bool attr_set = false;
+  auto kern = igemm3_co_kernel<BM, BN, S>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("igemm3 co: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+      return 1;
+    }
+    attr_set = true;
+  }
+  const int nwg = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+  hipLaunchKernelGGL(kern, dim3(nwg + g.blk0[g.n]), dim3(256), lds, st, p, a_bytes, b_bytes, nwg, g);
+  co_taken = true;
+  return check_launch("igemm3_co");
+}
+
+template <int BM, int BN, int S>
 static int launch3(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  // riders inherit the launch's LDS allocation: only the 32 KB configuration keeps their occupancy (5 workgroups per CU)
+  if (co_group != nullptr && !co_taken && BM == 64 && BN == 64 && S == 2) return launch3_co<BM, BN, S>(p, a_bytes, b_bytes, st, *co_group);
   constexpr size_t ring = (size_t)S * (BM + BN) * ROWB;
   constexpr size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);
   constexpr size_t lds = ring > ctile ? ring : ctile;

@@ -201,8 +201,8 @@ static int launch_wgrad2(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes,
   return check_launch("wgrad2");
 }
 
-// returns -1 when the problem is outside the envelope (the caller then uses the general v1 kernel)
-int wgrad2_try(const SedtIgemm& p, hipStream_t st) {
+// 0 when the problem fits the LDS-DMA weight-gradient kernels (v2 / v3); fills the buffer-descriptor sizes
+int wgrad2_envelope(const SedtIgemm& p, long* a_bytes_out, long* b_bytes_out) {
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (p.scale || p.bias || p.res || p.mask || p.act != SEDT_ACT_NONE || p.drop_p > 0.f || p.alpha != 1.f) return -1;
   if (p.splitk <= 1 && !p.out_f32) return -1;
@@ -214,6 +214,15 @@ int wgrad2_try(const SedtIgemm& p, hipStream_t st) {
   long b_rows = p.conv ? (long)((p.K + (long)p.Ho * p.Wo - 1) / ((long)p.Ho * p.Wo)) * p.Hi * p.Wi : (long)p.K;
   long b_bytes = ((b_rows - 1) * p.ldb + (p.conv ? p.Ci : p.N)) * 2;
   if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31) || a_bytes <= 0 || b_bytes <= 0) return -1;
+  *a_bytes_out = a_bytes;
+  *b_bytes_out = b_bytes;
+  return 0;
+}
+
+// returns -1 when the problem is outside the envelope (the caller then uses the general v1 kernel)
+int wgrad2_try(const SedtIgemm& p, hipStream_t st) {
+  long a_bytes, b_bytes;
+  if (wgrad2_envelope(p, &a_bytes, &b_bytes) != 0) return -1;
   {   // the lean-issue kernel takes the common cases
     int r3 = wgrad3_try(p, (unsigned)a_bytes, (unsigned)b_bytes, st);
     if (r3 >= 0) return r3;

@@ -3,6 +3,7 @@ import math
 
 import torch
 
+from . import ops
 from .optim import FusedAdamW
 
 
@@ -94,11 +95,16 @@ class GraphedTrainStep(object):
     graph and an optimizer graph.  With a SEDT backbone the backward is cut after layer3 (overlap_allreduce=True): the
     first graph ends with the gradients of everything above the cut (transformer, heads, layer4, layer3 = 90 % of the
     bytes) packed into the head of the flat buffer, their all-reduce is launched asynchronously, and a second graph runs
-    the backward of layer2 / layer1 / stem meanwhile; the small tail is reduced after it."""
+    the backward of layer2 / layer1 / stem meanwhile; the small tail is reduced after it.
+
+    Two alternatives for the weight gradients are implemented and measured slower than the default (a layer's wgrads as ONE
+    grouped launch on the main stream): async_wgrad=True issues them as a parallel branch of the graph (ROCm 7.2 pays
+    50-100 us per cross-queue dependency: 7.6 vs 7.3 ms/step), coschedule=True lets them ride in the spare workgroup
+    slots of later dgrad launches (ops.WgradPool; 7.3 vs 7.2 ms/step)."""
 
     def __init__(self, model, criterion, optimizer, example_input, example_targets, mask_weak=None, mask_strong=None,
-                 max_norm=0.1, normalize=False, warmup=3, device_matching=True, max_targets=32, async_wgrad=True,
-                 overlap_allreduce=True):
+                 max_norm=0.1, normalize=False, warmup=3, device_matching=True, max_targets=32, async_wgrad=False,
+                 overlap_allreduce=True, coschedule=False):
         import gc
         from . import runtime
         from .sedt import TargetTables
@@ -108,6 +114,7 @@ class GraphedTrainStep(object):
         self.mw, self.ms, self.max_norm, self.normalize = mask_weak, mask_strong, max_norm, normalize
         self.runtime = runtime
         self.async_wgrad = async_wgrad
+        self.coschedule = coschedule and not async_wgrad
         self.world = torch.distributed.get_world_size() if (torch.distributed.is_available()
                                                             and torch.distributed.is_initialized()) else 1
         # data-parallel overlap: parameters whose gradients come last (stem conv0 + layer2) go to the tail of the flat layout
@@ -180,7 +187,7 @@ class GraphedTrainStep(object):
         self.static_total = self.criterion.last_total
         head, self._tail = self.optimizer.head_tail_params()
         self._cut = self.cut_body.stage_out[1]
-        with self.runtime.async_wgrad(self.async_wgrad):
+        with self.runtime.async_wgrad(self.async_wgrad), ops.coschedule(self.coschedule):
             grads = torch.autograd.grad(self.static_total, [self._cut] + head)
         self._g_cut = grads[0]
         for p, g in zip(head, grads[1:]):
@@ -188,7 +195,7 @@ class GraphedTrainStep(object):
         self.flat_head = self.optimizer.gather_grads('head')
 
     def _backward_below_cut(self):
-        with self.runtime.async_wgrad(self.async_wgrad):
+        with self.runtime.async_wgrad(self.async_wgrad), ops.coschedule(self.coschedule):
             grads = torch.autograd.grad(self._cut, self._tail, grad_outputs=self._g_cut)
         for p, g in zip(self._tail, grads):
             p.grad = g
@@ -197,7 +204,8 @@ class GraphedTrainStep(object):
     def _backward_and_step(self):
         self.static_losses = self.criterion.compute(self.static_out, self.static_dense)
         self.static_total = self.criterion.last_total
-        with self.runtime.async_wgrad(self.async_wgrad):     # wgrads as a parallel branch of the graph; joined on exit
+        # weight gradients ride in the spare workgroup slots of the dgrad chain's launches; drained on exit
+        with self.runtime.async_wgrad(self.async_wgrad), ops.coschedule(self.coschedule):
             self.static_total.backward()
         if self.world == 1:
             self.optimizer.step(max_norm=self.max_norm)

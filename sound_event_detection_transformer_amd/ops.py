@@ -43,10 +43,10 @@ def _dev_check(*ts):
             raise RuntimeError('sedt ops need GPU tensors: the HIP path has no CPU fallback')
 
 
-def igemm(dtype, M, N, K, A, lda, B, ldb, Cout, ldc, *, trans=0, conv=None, transposed=0, out_f32=0, scale=None,
-          bias=None, res=None, ldr=0, res_mod=0, mask=None, ldm=0, act=ACT_NONE, act_post_res=0, alpha=1.0, drop_p=0.0,
-          seed=0, seed_ptr=None, splitk=1, slab=None, tile=(0, 0), colsum_out=None):
-    """raw implicit GEMM call; ``conv`` = (Hi, Wi, Ci, Ho, Wo, KH, KW, sh, sw, ph, pw, dh, dw) or None"""
+def igemm_args(M, N, K, A, lda, B, ldb, Cout, ldc, *, trans=0, conv=None, transposed=0, out_f32=0, scale=None,
+               bias=None, res=None, ldr=0, res_mod=0, mask=None, ldm=0, act=ACT_NONE, act_post_res=0, alpha=1.0, drop_p=0.0,
+               seed=0, seed_ptr=None, splitk=1, slab=None, tile=(0, 0), colsum_out=None):
+    """the SedtIgemm argument block of one implicit GEMM; ``conv`` = (Hi, Wi, Ci, Ho, Wo, KH, KW, sh, sw, ph, pw, dh, dw)"""
     _dev_check(A, B, Cout)
     a = L.SedtIgemm()
     a.M, a.N, a.K = M, N, K
@@ -73,6 +73,91 @@ def igemm(dtype, M, N, K, A, lda, B, ldb, Cout, ldc, *, trans=0, conv=None, tran
     a.slab = slab.data_ptr() if slab is not None else None
     a.tile_m, a.tile_n = tile
     a.colsum_out = colsum_out.data_ptr() if colsum_out is not None else None
+    return a
+
+
+class WgradPool(object):
+    """Weight-gradient GEMMs waiting for a ride (co-scheduling, csrc/igemm3.hip: igemm3_co_kernel).
+
+    In the backward pass only the dgrad chain is ordered; a layer's weight gradients are needed by the optimizer alone.
+    While ``coschedule()`` is active, ReduceBatch.flush() parks the layer's wgrad problems here instead of launching
+    them, and every following forward/dgrad GEMM launch takes a few along in the workgroup slots it would leave idle
+    (at batch 64 most GEMMs of the chain fill 2 of ~5 slots per CU).  ``drain()`` - called before anything reads the
+    gradients - launches what is left and then all split-K reductions."""
+    SLOTS = 1280                    # 256 CUs x 5 resident workgroups of the 32 KB-LDS GEMM kernels
+    MAX_RIDERS = 10
+
+    def __init__(self):
+        self.gemms, self.reduces, self.keep, self.dtype = [], [], [], None
+
+    def push(self, group, dtype, jobs, keep, operands):
+        self.gemms.extend(group)
+        self.reduces.extend(jobs)
+        self.keep.append((keep, operands))
+        self.dtype = dtype
+
+    def take(self, main_tiles):
+        room = max(self.SLOTS - main_tiles, 512)
+        out = []
+        while self.gemms and len(out) < self.MAX_RIDERS:
+            a = self.gemms[0][0]
+            wgs = ((a.M + 63) // 64) * ((a.N + 63) // 64) * max(a.splitk, 1)
+            if out and wgs > room:
+                break
+            out.append(self.gemms.pop(0))
+            room -= wgs
+        return out
+
+    def give_back(self, items):
+        self.gemms[0:0] = items
+
+    def drain(self):
+        lib = L.load()
+        while self.gemms:
+            chunk, self.gemms = self.gemms[:10], self.gemms[10:]
+            arr = (L.SedtIgemm * len(chunk))(*[a for a, _ in chunk])
+            L.check(lib.sedt_wgrad_group(arr, len(chunk), self.dtype, L.stream_ptr()), 'wgrad_group')
+        while self.reduces:
+            chunk, self.reduces = self.reduces[:L.MAX_REDUCE_JOBS], self.reduces[L.MAX_REDUCE_JOBS:]
+            arr = (L.SedtReduceJob * len(chunk))(*chunk)
+            L.check(lib.sedt_multi_wgrad_reduce(arr, len(chunk), L.stream_ptr()), 'multi_wgrad_reduce')
+        self.keep = []
+
+
+POOL = WgradPool()
+_co = {'on': False}
+
+
+class coschedule(object):
+    """context manager: weight gradients computed inside are complete only after the scope exits (it drains the pool)"""
+
+    def __init__(self, enable=True):
+        self.enable = enable
+
+    def __enter__(self):
+        self.prev = _co['on']
+        _co['on'] = bool(self.enable) and PROFILE is None
+        return self
+
+    def __exit__(self, *exc):
+        _co['on'] = self.prev
+        if not self.prev:
+            POOL.drain()
+        return False
+
+
+def igemm(dtype, M, N, K, A, lda, B, ldb, Cout, ldc, **kw):
+    """raw implicit GEMM call (arguments as igemm_args)"""
+    a = igemm_args(M, N, K, A, lda, B, ldb, Cout, ldc, **kw)
+    conv, trans = kw.get('conv'), kw.get('trans', 0)
+    if _co['on'] and POOL.gemms and not trans and dtype == BF16:
+        riders = POOL.take(((M + 63) // 64) * ((N + 63) // 64))
+        arr = (L.SedtIgemm * len(riders))(*[r[0] for r in riders])
+        taken = C.c_int(0)
+        L.check(L.load().sedt_igemm_co(C.byref(a), arr, len(riders), dtype, L.stream_ptr(), C.byref(taken)), 'sedt_igemm_co')
+        if not taken.value:
+            POOL.give_back(riders)
+        return
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -133,7 +218,28 @@ class ReduceBatch(object):
 
     def __init__(self):
         self.jobs, self.keep, self.deferred, self.operands = [], [], [], []
-        self._running = False
+        self.group, self.group_dtype = [], None
+
+    def add_gemm(self, dtype, args, shape):
+        """a weight-gradient GEMM to be issued with the others of this batch in one grouped launch"""
+        self.group.append((args, shape))
+        self.group_dtype = dtype
+
+    def _launch_group(self):
+        if not self.group:
+            return
+        lib = L.load()
+        if PROFILE is not None:                       # bench.py's per-launch timing wants every GEMM on its own
+            for a, shape in self.group:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                L.check(lib.sedt_igemm(C.byref(a), self.group_dtype, L.stream_ptr()), 'sedt_igemm')
+                e1.record()
+                PROFILE.append((e0, e1, shape))
+        else:
+            arr = (L.SedtIgemm * len(self.group))(*[a for a, _ in self.group])
+            L.check(lib.sedt_wgrad_group(arr, len(self.group), self.group_dtype, L.stream_ptr()), 'wgrad_group')
+        self.group = []
 
     def defer(self, body, operands):
         self.deferred.append(body)
@@ -147,7 +253,8 @@ class ReduceBatch(object):
         j.bias_out = bias_out.data_ptr() if (cs is not None and bias_out is not None) else None
         self.jobs.append(j)
         self.keep.append((slab, cs, rowscale, out, bias_out))
-        if len(self.jobs) == L.MAX_REDUCE_JOBS:
+        if len(self.jobs) == L.MAX_REDUCE_JOBS and not _co['on']:
+            self._launch_group()
             self._launch()
 
     def _launch(self):
@@ -157,14 +264,25 @@ class ReduceBatch(object):
         self.jobs, self.keep = [], []
 
     def flush(self):
+        from . import runtime
+        if _co['on'] and not runtime.async_wgrad_on():
+            for body in self.deferred:              # allocate slabs / build the argument blocks; the GEMMs are not launched:
+                body()                              # they ride along with later launches of the dgrad chain
+            self.deferred = []
+            if self.group_dtype in (None, BF16):
+                # (not the gradient tensors themselves: an extra reference would make autograd clone them before they are written)
+                POOL.push(self.group, BF16, self.jobs, [k[:3] for k in self.keep], self.operands)
+                self.group, self.jobs, self.keep, self.operands = [], [], [], []
+                return
         if self.deferred:
-            from . import runtime
-            with runtime.side(*self.operands):
+            with runtime.side(*self.operands):      # (the current stream itself unless runtime.async_wgrad is on)
                 for body in self.deferred:
                     body()
+                self._launch_group()
                 self._launch()
             self.deferred, self.operands = [], []
         else:
+            self._launch_group()
             self._launch()
 
 
@@ -184,18 +302,21 @@ def wgrad(dtype, dy, x, B, g, rowscale=None, out=None, bias_out=None, batch=None
         conv = None if g.plain else _geom_tuple(g)
         fused = bias_out is not None and _fused_bias_ok(dtype, dy, x, g)
         cs = torch.empty((sk, Mo), device=dy.device, dtype=torch.float32) if fused else None
-        igemm(dtype, Mo, No, Kp, dy, dy.stride(0), x, x.stride(0), slab, No, trans=1, conv=conv, out_f32=1, splitk=sk,
-              slab=slab, colsum_out=cs)
         if batch is not None:
+            batch.add_gemm(dtype, igemm_args(Mo, No, Kp, dy, dy.stride(0), x, x.stride(0), slab, No, trans=1, conv=conv,
+                                             out_f32=1, splitk=sk, slab=slab, colsum_out=cs),
+                           (Mo, No, Kp, 1, 0 if conv is None else 1))
             batch.add(slab, sk, Mo, g.taps, g.Ci, rowscale, out, cs, bias_out if fused else None)
         else:
+            igemm(dtype, Mo, No, Kp, dy, dy.stride(0), x, x.stride(0), slab, No, trans=1, conv=conv, out_f32=1, splitk=sk,
+                  slab=slab, colsum_out=cs)
             L.check(lib.sedt_wgrad_reduce_bias(_p(slab), sk, Mo, g.taps, g.Ci, _p(rowscale), _p(out), _p(cs),
                                                _p(bias_out) if fused else None, L.stream_ptr()), 'wgrad_reduce')
         if bias_out is not None and not fused:
             colsum(dtype, dy, out=bias_out)
 
-    if batch is not None and runtime.async_wgrad_on():
-        batch.defer(body, (dy, x, rowscale))              # issued by batch.flush() as part of one side-stream block
+    if batch is not None:
+        batch.defer(body, (dy, x, rowscale))              # issued by batch.flush(): one grouped launch for the whole layer
     else:
         with runtime.side(dy, x, rowscale):               # off the dgrad critical path when runtime.async_wgrad is on
             body()

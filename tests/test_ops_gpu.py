@@ -368,3 +368,54 @@ def test_linear_wgrad_with_fused_bias_grad(ops, dt, M, N, K):
     dw = ops.linear_wgrad(dt, dev(gy, dt), dev(x, dt), bias_out=db)
     close(dw, rnd(gy, dt).t() @ rnd(x, dt), dt)
     close(db, rnd(gy, dt).sum(0), dt, bf16_tol=2e-3)
+
+
+def test_igemm_co_matches_separate_launches(ops):
+    """co-scheduled launch (a dgrad GEMM + weight-gradient problems riding in the same grid) == the same GEMMs launched
+    one by one: bit-identical outputs (same kernels bodies, same per-tile arithmetic)"""
+    import ctypes as C
+    from sound_event_detection_transformer_amd import lib as L
+    B = 8
+    torch.manual_seed(3)
+
+    def problem(Hi, Wi, Ci, Co, k, s, pd, dl):
+        g = ops.ConvGeom(Hi, Wi, Ci, Co, k, s, pd, dl)
+        x = torch.randn(B * Hi * Wi, Ci, device='cuda').bfloat16()
+        gy = torch.randn(B * g.Ho * g.Wo, Co, device='cuda').bfloat16()
+        return g, x, gy
+
+    def wgrad_args(g, x, gy):
+        Mo, No, Kp = g.Co, g.taps * g.Ci, B * g.Ho * g.Wo
+        sk = L.load().sedt_igemm_splitk(Mo, No, Kp, L.BF16)
+        slab = torch.zeros((sk, Mo, No), device='cuda', dtype=torch.float32)
+        conv = None if g.plain else ops._geom_tuple(g)
+        a = ops.igemm_args(Mo, No, Kp, gy, gy.stride(0), x, x.stride(0), slab, No, trans=1, conv=conv, out_f32=1, splitk=sk,
+                           slab=slab)
+        return a, slab
+
+    g0, x0, gy0 = problem(32, 8, 64, 64, 3, 1, 1, 1)          # K = 576 -> the 64x64 2-stage kernel, which can carry riders
+    w0 = torch.randn(64, 64, 3, 3, device='cuda') / 24.0
+    _, wb0 = ops.pack_conv(L.BF16, w0)
+    riders = [problem(32, 4, 256, 256, 3, 1, 1, 1), problem(32, 4, 512, 128, 1, 1, 0, 1), problem(16, 8, 64, 64, 3, 1, 1, 1)]
+    outs = {}
+    for mode in ('separate', 'co'):
+        dx = torch.zeros_like(x0)
+        main = ops.igemm_args(x0.shape[0], g0.Ci, g0.taps * g0.Co, gy0, gy0.stride(0), wb0, g0.taps * g0.Co, dx, dx.stride(0),
+                              conv=ops._geom_tuple(g0, transposed=True), transposed=1, mask=x0, ldm=x0.stride(0))
+        ws = [wgrad_args(*r) for r in riders]
+        arr = (L.SedtIgemm * len(ws))(*[a for a, _ in ws])
+        lib = L.load()
+        if mode == 'co':
+            taken = C.c_int(0)
+            L.check(lib.sedt_igemm_co(C.byref(main), arr, len(ws), L.BF16, L.stream_ptr(), C.byref(taken)), 'igemm_co')
+            assert taken.value == 1
+        else:
+            L.check(lib.sedt_igemm(C.byref(main), L.BF16, L.stream_ptr()), 'igemm')
+            for a, _ in ws:
+                L.check(lib.sedt_igemm(C.byref(a), L.BF16, L.stream_ptr()), 'igemm')
+        torch.cuda.synchronize()
+        outs[mode] = [dx] + [s for _, s in ws]
+    for a, b in zip(outs['separate'], outs['co']):
+        assert torch.isfinite(b.float()).all()
+        assert torch.equal(a, b)
+    assert outs['co'][0].abs().sum() > 0 and all(o.abs().sum() > 0 for o in outs['co'][1:])
