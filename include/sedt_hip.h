@@ -253,6 +253,9 @@ int sedt_multi_pack(const SedtPackJob* jobs, int njobs, int nblocks, int dtype, 
 /* chunk.p[i] = chunk.g[i] for every chunk: packs all gradient tensors into one flat f32 buffer (one launch) ahead of
  * the single RCCL all-reduce of the data-parallel step */
 int sedt_multi_gather(const SedtChunk* table, int nchunks, void* stream);
+/* mean-teacher update of every tensor in one launch (utilities/utils.py:62-67, EMA.update):
+ * chunk.m[i] = (1 - decay) * chunk.p[i] + decay * chunk.m[i]   (p = student parameter, m = shadow) */
+int sedt_multi_ema(const SedtChunk* table, int nchunks, float decay, void* stream);
 int sedt_multi_sumsq(const SedtChunk* table, int nchunks, float* partial, float* sumsq, void* stream);
 int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float* sumsq, float max_norm, float beta1, float beta2,
                      float eps, const int32_t* step_ptr /* device: 1-based step count */, void* stream);

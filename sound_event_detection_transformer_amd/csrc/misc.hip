@@ -561,6 +561,28 @@ __global__ void multi_adamw_kernel(const SedtChunk* __restrict__ table, const fl
   }
 }
 
+// mean-teacher weights (reference utilities/utils.py:62-67): shadow = (1 - decay) * p + decay * shadow, chunk.m = shadow
+__global__ void multi_ema_kernel(const SedtChunk* __restrict__ table, float decay) {
+  const SedtChunk c = table[blockIdx.x];
+  const float* p = reinterpret_cast<const float*>(c.p);
+  float* sh = reinterpret_cast<float*>(c.m);
+  const float om = 1.f - decay;
+  int i0 = 0;
+  if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(sh)) & 15) == 0) {
+    const int n4 = c.n >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    float4* s4 = reinterpret_cast<float4*>(sh);
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+      const float4 a = p4[i];
+      float4 b = s4[i];
+      b.x = om * a.x + decay * b.x; b.y = om * a.y + decay * b.y; b.z = om * a.z + decay * b.z; b.w = om * a.w + decay * b.w;
+      s4[i] = b;
+    }
+    i0 = n4 << 2;
+  }
+  for (int i = i0 + threadIdx.x; i < c.n; i += blockDim.x) sh[i] = om * p[i] + decay * sh[i];
+}
+
 // ---- all FrozenBN folds / all weight packs of a model in one launch each (device job tables)
 __global__ void multi_bn_fold_kernel(const SedtBnJob* __restrict__ jobs) {
   const SedtBnJob j = jobs[blockIdx.x];
@@ -878,6 +900,12 @@ extern "C" int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float
   hipLaunchKernelGGL(multi_adamw_kernel, dim3(nchunks), dim3(256), 0, S(stream), table, sumsq, max_norm, beta1, beta2, eps,
                      step_ptr);
   return check_launch("multi_adamw");
+}
+
+extern "C" int sedt_multi_ema(const SedtChunk* table, int nchunks, float decay, void* stream) {
+  SEDT_REQUIRE(table && nchunks > 0 && decay >= 0.f && decay <= 1.f, "multi_ema: bad arguments");
+  hipLaunchKernelGGL(multi_ema_kernel, dim3(nchunks), dim3(256), 0, S(stream), table, decay);
+  return check_launch("multi_ema");
 }
 
 extern "C" int sedt_multi_gather(const SedtChunk* table, int nchunks, void* stream) {

@@ -103,6 +103,7 @@ SIGNATURES = {
     'sedt_multi_bn_fold': (_i, [_vp, _i, _vp]),
     'sedt_multi_pack': (_i, [_vp, _i, _i, _i, _vp]),
     'sedt_multi_gather': (_i, [_vp, _i, _vp]),
+    'sedt_multi_ema': (_i, [_vp, _i, _f, _vp]),
     'sedt_multi_sumsq': (_i, [_vp, _i, _vp, _vp, _vp]),
     'sedt_multi_adamw': (_i, [_vp, _i, _vp, _f, _f, _f, _f, _vp, _vp]),
     'sedt_set_criterion': (_i, [C.POINTER(SedtCriterion), _vp]),

@@ -67,3 +67,69 @@ def nested_tensor_from_tensor_list(tensor_list: List[Tensor]) -> NestedTensor:
         pad_img[: img.shape[0], : img.shape[1], : img.shape[2]].copy_(img)
         m[: img.shape[1], :img.shape[2]] = False
     return NestedTensor(tensor, mask)
+
+
+class EMA(object):
+    """Mean-teacher weights - the reference's utilities/utils.py:46-81 API (register / load / update / apply_shadow /
+    restore; ``shadow`` and ``backup`` dicts keyed by parameter name), with ``update`` as ONE launch over all tensors
+    (sedt_multi_ema) instead of ~300 per-tensor ops.  apply_shadow / restore swap ``param.data`` pointers exactly like the
+    reference; the HIP modules read ``data_ptr()`` on every call, so the swapped weights are what the next forward uses."""
+    _CHUNK = 65536
+
+    def __init__(self, model, decay):
+        self.model, self.decay = model, decay
+        self.shadow, self.backup = {}, {}
+        self._tab = None
+
+    def load(self, ema_model):
+        for name, param in ema_model.named_parameters():
+            self.shadow[name] = param.data.clone()
+        self._tab = None
+
+    def register(self):
+        for name, param in self.model.named_parameters():
+            if param.requires_grad:
+                self.shadow[name] = param.data.clone()
+        self._tab = None
+
+    def _params(self):
+        return [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
+
+    @torch.no_grad()
+    def update(self):
+        ps = self._params()
+        for n, _ in ps:
+            assert n in self.shadow
+        fused = ps and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and self.shadow[n].is_contiguous()
+                           for n, p in ps)
+        if not fused:                                # host-side models (the CPU oracle in tests): the reference loop
+            for n, p in ps:
+                self.shadow[n] = ((1.0 - self.decay) * p.data + self.decay * self.shadow[n]).clone()
+            return
+        import numpy as np
+        from .. import lib as L
+        from ..optim import _DT
+        key = tuple((p.data_ptr(), self.shadow[n].data_ptr(), p.numel()) for n, p in ps)
+        if self._tab is None or self._tab[0] != key:
+            rows = []
+            for pp, sp, k in key:
+                for c0 in range(0, k, self._CHUNK):
+                    rows.append((pp + 4 * c0, sp + 4 * c0, min(self._CHUNK, k - c0)))
+            t = np.zeros(len(rows), _DT)
+            t['p'], t['m'], t['n'] = [r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows]
+            dev = ps[0][1].device
+            self._tab = (key, torch.from_numpy(t.view(np.uint8).copy()).to(dev), len(rows))
+        _, tab, n = self._tab
+        L.check(L.load().sedt_multi_ema(L.p(tab), n, float(self.decay), L.stream_ptr()), 'multi_ema')
+
+    def apply_shadow(self):
+        for name, param in self._params():
+            assert name in self.shadow
+            self.backup[name] = param.data
+            param.data = self.shadow[name]
+
+    def restore(self):
+        for name, param in self._params():
+            assert name in self.backup
+            param.data = self.backup[name]
+        self.backup = {}

@@ -60,3 +60,20 @@ def test_criterion_gradients_match_oracle():
     assert abs(a[0] - b[0]) < 1e-5
     for x, y in zip(a[1:], b[1:]):
         torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-6)
+
+
+def test_ema_host_loop_matches_reference_formula():
+    """EMA on a host-side module (no HIP involved): the reference's per-tensor update (utils.py:62-67)"""
+    from sound_event_detection_transformer_amd.utilities.utils import EMA
+    m = torch.nn.Linear(4, 3)
+    ema = EMA(m, 0.5)
+    ema.register()
+    w0 = m.weight.data.clone()
+    with torch.no_grad():
+        m.weight.add_(1.0)
+    ema.update()
+    assert torch.allclose(ema.shadow['weight'], 0.5 * (w0 + 1.0) + 0.5 * w0)
+    ema.apply_shadow()
+    assert torch.equal(m.weight.data, ema.shadow['weight'])
+    ema.restore()
+    assert torch.equal(m.weight.data, w0 + 1.0)

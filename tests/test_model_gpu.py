@@ -287,3 +287,48 @@ def test_graphed_train_step_matches_eager(pkg):
         for k in res['eager'][1]:
             assert rel(res[mode][1][k], res['eager'][1][k]) < 2e-3, (mode, k)
     assert res['graph'][0][0] != res['graph'][0][1]
+
+
+def test_ema_fused_update_and_pointer_swap(pkg):
+    """mean-teacher row (reference utils.py:46-81): one-launch EMA.update == the reference's per-tensor formula (f32, exact
+    up to one rounding), apply_shadow/restore swap param.data and the HIP forward follows the swapped pointers"""
+    A, runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.utilities.utils import EMA
+    runtime.set_compute_dtype('f32')
+    model, _ = _build(sedt, 1, 10)
+    _seed_load(model, 11).cuda().eval()
+    ema = EMA(model, 0.9)
+    ema.register()
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert set(ema.shadow) == set(names)
+    ref = {n: ema.shadow[n].clone() for n in names}
+    g = torch.Generator().manual_seed(5)
+    for step in range(3):
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if p.requires_grad:
+                    p.add_(torch.randn(p.shape, generator=g).cuda() * 0.01)
+        ema.update()
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                ref[n] = (1.0 - 0.9) * p.data + 0.9 * ref[n]
+    for n in names:
+        assert torch.allclose(ema.shadow[n], ref[n], rtol=1e-6, atol=1e-7), n
+    x = torch.randn(2, 1, 500, 64, generator=torch.Generator().manual_seed(7)).cuda()
+    with torch.no_grad():
+        student = model(x)['pred_logits'].clone()
+        ema.apply_shadow()
+        teacher = model(x)['pred_logits'].clone()
+        ema.restore()
+        again = model(x)['pred_logits'].clone()
+    assert not ema.backup
+    assert torch.equal(student, again)
+    assert not torch.equal(student, teacher)
+    # the teacher output is what a model loaded with the shadow weights computes
+    twin, _ = _build(sedt, 1, 10)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd.update({n: ema.shadow[n] for n in names})
+    twin.load_state_dict(sd)
+    twin.cuda().eval()
+    with torch.no_grad():
+        assert torch.equal(twin(x)['pred_logits'], teacher)
