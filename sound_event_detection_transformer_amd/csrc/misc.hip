@@ -85,11 +85,20 @@ __global__ __launch_bounds__(256) void multi_wgrad_reduce_kernel(const ReduceJob
   const int blk = blockIdx.x - J.blk0;
   const long per = (long)J.R * J.taps * J.Ci;
   if (J.colsum_slab) {
+    // column sums over the split slices: the fused bias gradient of a wgrad, or (per == 0, splitk = partial rows) the
+    // gamma/beta reduction of a LayerNorm backward riding in the same launch
     const long e = (long)blk * 256 + threadIdx.x;
     if (e < J.R) {
-      float b = 0.f;
-      for (int z = 0; z < J.splitk; ++z) b += J.colsum_slab[(long)z * J.R + e];
-      J.bias_out[e] = b;
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+      int z = 0;
+      for (; z + 4 <= J.splitk; z += 4) {
+        b0 += J.colsum_slab[(long)z * J.R + e];
+        b1 += J.colsum_slab[(long)(z + 1) * J.R + e];
+        b2 += J.colsum_slab[(long)(z + 2) * J.R + e];
+        b3 += J.colsum_slab[(long)(z + 3) * J.R + e];
+      }
+      for (; z < J.splitk; ++z) b0 += J.colsum_slab[(long)z * J.R + e];
+      J.bias_out[e] = (b0 + b1) + (b2 + b3);
     }
   }
   const int mode = reduce_job_mode(J);
@@ -934,7 +943,9 @@ extern "C" int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, voi
   int blk = 0;
   for (int i = 0; i < njobs; ++i) {
     a.j[i] = jobs[i];
-    SEDT_REQUIRE(jobs[i].slab && jobs[i].out && jobs[i].splitk >= 1, "multi_wgrad_reduce: bad job %d", i);
+    const bool sums_only = (long)jobs[i].R * jobs[i].taps * jobs[i].Ci == 0;      // column sums only (LayerNorm gamma/beta)
+    SEDT_REQUIRE((sums_only ? jobs[i].colsum_slab != nullptr : (jobs[i].slab && jobs[i].out)) && jobs[i].splitk >= 1,
+                 "multi_wgrad_reduce: bad job %d", i);
     SEDT_REQUIRE((jobs[i].colsum_slab == nullptr) == (jobs[i].bias_out == nullptr), "multi_wgrad_reduce: job %d colsum/bias", i);
     a.j[i].blk0 = blk;
     int nb = reduce_job_blocks(jobs[i]);

@@ -257,10 +257,18 @@ class ReduceBatch(object):
             self._launch_group()
             self._launch()
 
+    def add_colsum(self, partial, nrows, ncols, out):
+        """out[c] = sum_r partial[r][c] in the same launch as the split-K reductions (LayerNorm gamma/beta partials)"""
+        j = L.SedtReduceJob()
+        j.colsum_slab, j.bias_out, j.splitk, j.R, j.taps, j.Ci = partial.data_ptr(), out.data_ptr(), nrows, ncols, 1, 0
+        self.jobs.append(j)
+        self.keep.append((partial, None, None, out, None))
+
     def _launch(self):
-        if self.jobs:
-            arr = (L.SedtReduceJob * len(self.jobs))(*self.jobs)
-            L.check(L.load().sedt_multi_wgrad_reduce(arr, len(self.jobs), L.stream_ptr()), 'multi_wgrad_reduce')
+        for i in range(0, len(self.jobs), L.MAX_REDUCE_JOBS):
+            chunk = self.jobs[i:i + L.MAX_REDUCE_JOBS]
+            arr = (L.SedtReduceJob * len(chunk))(*chunk)
+            L.check(L.load().sedt_multi_wgrad_reduce(arr, len(chunk), L.stream_ptr()), 'multi_wgrad_reduce')
         self.jobs, self.keep = [], []
 
     def flush(self):
@@ -406,12 +414,14 @@ def layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2=None, dres=None, want_par
     nb = lib.sedt_layernorm_bwd_scratch(rows, D)
     scratch = torch.empty((nb // 4,), device=x.device, dtype=torch.float32)
     from . import runtime
-    if want_param_grads and batch is not None and runtime.async_wgrad_on():
+    if want_param_grads and batch is not None:
+        # dx now; the gamma/beta reduction of the per-workgroup partials only feeds the optimizer: it rides in the layer's
+        # split-K reduction launch (batch.flush()) as one more job
         L.check(lib.sedt_layernorm_bwd(_p(dy), _p(dy2), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), None, None,
                                        _p(scratch), nb, rows, D, dtype, L.stream_ptr()), 'layernorm_bwd')
-        batch.defer(lambda: L.check(lib.sedt_layernorm_bwd_final(_p(scratch), rows, D, _p(dg), _p(db), L.stream_ptr()),
-                                    'layernorm_bwd_final'), (scratch,))
-        return dx, dg, db
+        dgb = torch.empty((2 * D,), device=x.device, dtype=torch.float32)
+        batch.add_colsum(scratch, nb // (2 * D * 4), 2 * D, dgb)
+        return dx, dgb[:D], dgb[D:]
     L.check(lib.sedt_layernorm_bwd(_p(dy), _p(dy2), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dg), _p(db),
                                    _p(scratch), nb, rows, D, dtype, L.stream_ptr()), 'layernorm_bwd')
     return dx, dg, db
