@@ -96,6 +96,9 @@ typedef struct SedtIgemm {
 } SedtIgemm;
 
 int sedt_igemm(const SedtIgemm* args, int dtype, void* stream);
+/* njobs (<= 8 per launch) independent trans == 0 problems - e.g. the q / k / v projections of an attention block; one
+ * launch when every problem resolves to the 64x64 2-stage bf16 kernel, otherwise njobs sedt_igemm calls.  HOST array. */
+int sedt_igemm_group(const SedtIgemm* jobs, int njobs, int dtype, void* stream);
 /* njobs independent trans == 1 (weight-gradient) problems; in bf16 they run as ONE launch (grouped workgroup ranges) when
  * every problem fits the LDS-DMA kernel, otherwise this is njobs sedt_igemm calls.  `jobs` is a HOST array. */
 int sedt_wgrad_group(const SedtIgemm* jobs, int njobs, int dtype, void* stream);

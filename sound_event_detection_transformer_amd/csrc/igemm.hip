@@ -490,7 +490,21 @@ extern "C" int sedt_igemm(const SedtIgemm* args, int dtype, void* stream) {
   return 1;
 }
 
-namespace sedt { int wgrad3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st); }
+namespace sedt {
+int wgrad3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st);
+int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st);
+}
+
+extern "C" int sedt_igemm_group(const SedtIgemm* jobs, int njobs, int dtype, void* stream) {
+  SEDT_REQUIRE(jobs && njobs >= 1, "igemm_group: bad arguments");
+  if (dtype == SEDT_BF16 && njobs >= 2) {
+    const int r = sedt::igemm3_group_try(jobs, njobs, reinterpret_cast<hipStream_t>(stream));
+    if (r >= 0) return r;
+  }
+  for (int i = 0; i < njobs; ++i)
+    if (int r = sedt_igemm(&jobs[i], dtype, stream)) return r;
+  return 0;
+}
 
 extern "C" int sedt_wgrad_group(const SedtIgemm* jobs, int njobs, int dtype, void* stream) {
   SEDT_REQUIRE(jobs && njobs >= 1, "wgrad_group: bad arguments");

@@ -19,6 +19,7 @@
 namespace sedt {
 
 int wgrad2_try(const SedtIgemm& p, hipStream_t st);   // wgrad2.hip
+bool igemm3_planning();                                 // igemm3.hip
 int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, int bn, hipStream_t st);   // igemm3.hip
 
 template <int BM, int BN, int STAGES>
@@ -299,6 +300,7 @@ int igemm2_try(const SedtIgemm& p, hipStream_t st) {
   {   // the lean-issue kernel takes the common cases
     int r3 = igemm3_try(p, (unsigned)a_bytes, (unsigned)b_bytes, bm, bn, st);
     if (r3 >= 0) return r3;
+    if (igemm3_planning()) return -1;      // dry run (sedt_igemm_group): never launch from here
   }
   static int stages = -1;
   if (stages < 0) {

@@ -290,6 +290,30 @@ __global__ __launch_bounds__(256) void igemm3_co_kernel(const SedtIgemm p, const
 thread_local const WgradGroup* co_group = nullptr;
 thread_local bool co_taken = false;
 
+// dry run: igemm3_try resolves the kernel configuration of a problem without launching (sedt_igemm_group uses it)
+struct Igemm3Plan {
+  bool on, ok;
+  int bm, bn, s;
+  unsigned a_bytes, b_bytes;
+};
+thread_local Igemm3Plan plan3 = {false, false, 0, 0, 0, 0u, 0u};
+
+// several independent forward / dgrad problems of the 64x64 2-stage configuration in ONE launch (the q / k / v projections
+// of an attention block and their three dgrads are independent GEMMs of a few microseconds each)
+constexpr int IG_MAXG = 8;
+struct IgemmGroup {
+  int n;
+  int blk0[IG_MAXG + 1];
+  unsigned a_bytes[IG_MAXG], b_bytes[IG_MAXG];
+  SedtIgemm p[IG_MAXG];
+};
+
+__global__ __launch_bounds__(256) void igemm3_group_kernel(const IgemmGroup g) {
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.blk0[i + 1]) ++i;
+  igemm3_body<64, 64, 2>(g.p[i], g.a_bytes[i], g.b_bytes[i], (int)blockIdx.x - g.blk0[i]);
+}
+
 template <int BM, int BN, int S>
 static int launch3_co(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st, const WgradGroup& g) {
   constexpr size_t ring = (size_t)S * (BM + BN) * ROWB;
@@ -315,6 +339,12 @@ static int launch3_co(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hi
 
 template <int BM, int BN, int S>
 static int launch3(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  if (plan3.on) {
+    plan3.ok = true;
+    plan3.bm = BM; plan3.bn = BN; plan3.s = S;
+    plan3.a_bytes = a_bytes; plan3.b_bytes = b_bytes;
+    return 0;
+  }
   // riders inherit the launch's LDS allocation: only the 32 KB configuration keeps their occupancy (5 workgroups per CU)
   if (co_group != nullptr && !co_taken && BM == 64 && BN == 64 && S == 2) return launch3_co<BM, BN, S>(p, a_bytes, b_bytes, st, *co_group);
   constexpr size_t ring = (size_t)S * (BM + BN) * ROWB;
@@ -333,6 +363,50 @@ static int launch3(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipSt
   const int nwg = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), lds, st, p, a_bytes, b_bytes);
   return check_launch("igemm3");
+}
+
+int igemm2_try(const SedtIgemm& p, hipStream_t st);   // igemm2.hip: envelope checks + tile choice, then igemm3_try
+bool igemm3_planning() { return plan3.on; }
+
+// 0 = launched as one grouped kernel, -1 = some problem does not resolve to the 64x64 2-stage kernel (nothing launched)
+int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("SEDT_IGEMM_GROUP");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!on || njobs < 2 || njobs > IG_MAXG) return -1;
+  IgemmGroup g;
+  g.n = njobs;
+  int blk = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const SedtIgemm& p = jobs[i];
+    if (p.trans) return -1;
+    plan3 = {true, false, 0, 0, 0, 0u, 0u};
+    const int r = igemm2_try(p, st);
+    const Igemm3Plan got = plan3;
+    plan3.on = false;
+    if (r != 0 || !got.ok || got.bm != 64 || got.bn != 64 || got.s != 2) return -1;
+    g.p[i] = p;
+    g.a_bytes[i] = got.a_bytes;
+    g.b_bytes[i] = got.b_bytes;
+    g.blk0[i] = blk;
+    blk += ((p.N + 63) / 64) * ((p.M + 63) / 64);
+  }
+  g.blk0[njobs] = blk;
+  constexpr size_t lds = (size_t)2 * (64 + 64) * ROWB;      // ring 32 KB >= the 17 KB epilogue tile
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm3_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) {
+      set_error("igemm3 group: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(igemm3_group_kernel, dim3(blk), dim3(256), lds, st, g);
+  return check_launch("igemm3_group");
 }
 
 // -1 = outside the envelope

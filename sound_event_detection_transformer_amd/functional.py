@@ -129,14 +129,13 @@ def _mha_fwd(dt, q_in, k_in, v_in, same_qk, w_in, b_in, w_out, b_out, res, B, H,
     E = w_in.shape[1]
     wf, wb_in = _prep_linear(dt, w_in, train)
     wf_o, wb_o = _prep_linear(dt, w_out, train)
-    if same_qk:                       # q_in is k_in: one GEMM for Q|K (N = 2E)
-        qk = ops.linear(dt, q_in, wf[:2 * E], bias=b_in[:2 * E])
+    if same_qk:                       # q_in is k_in: one GEMM for Q|K (N = 2E); the V projection rides in the same launch
+        qk, v = ops.linear_group(dt, [(q_in, wf[:2 * E], dict(bias=b_in[:2 * E])), (v_in, wf[2 * E:], dict(bias=b_in[2 * E:]))])
         q, k = qk[:, :E], qk[:, E:]
     else:
-        q = ops.linear(dt, q_in, wf[:E], bias=b_in[:E])
-        k = ops.linear(dt, k_in, wf[E:2 * E], bias=b_in[E:2 * E])
+        q, k, v = ops.linear_group(dt, [(q_in, wf[:E], dict(bias=b_in[:E])), (k_in, wf[E:2 * E], dict(bias=b_in[E:2 * E])),
+                                        (v_in, wf[2 * E:], dict(bias=b_in[2 * E:]))])
         qk = None
-    v = ops.linear(dt, v_in, wf[2 * E:], bias=b_in[2 * E:])
     sp = runtime.seed_ptr(q_in.device) if p > 0 else None
     ctxv, lse = ops.attention_fwd(dt, q, k, v, B, H, Lq, Lk, kpm, amask, p, seeds[0], sp)
     out = ops.linear(dt, ctxv, wf_o, bias=b_out, drop_p=p, seed=seeds[1], seed_ptr=sp, res=res, ldr=res.stride(0))
@@ -170,21 +169,24 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, b
     d_bin = torch.empty((3 * E,), device=g_out.device, dtype=torch.float32)
     wb = s['wb_in']                                         # [E][3E]
     g_q = g_k = g_v = None
+    dgrads = []                                             # independent input gradients: one grouped launch
     if s['same_qk']:
         ops.linear_wgrad(dt, dqk, s['q_in'], out=d_win[:2 * E], bias_out=d_bin[:2 * E], batch=batch)
         if need_q or need_k:
-            g_q = ops.linear(dt, dqk, wb[:, :2 * E])        # grad wrt the shared q/k input
-            g_k = None
+            dgrads.append(('q', dqk, wb[:, :2 * E]))        # grad wrt the shared q/k input
     else:
         ops.linear_wgrad(dt, dq, s['q_in'], out=d_win[:E], bias_out=d_bin[:E], batch=batch)
         ops.linear_wgrad(dt, dk, s['k_in'], out=d_win[E:2 * E], bias_out=d_bin[E:2 * E], batch=batch)
         if need_q:
-            g_q = ops.linear(dt, dq, wb[:, :E])
+            dgrads.append(('q', dq, wb[:, :E]))
         if need_k:
-            g_k = ops.linear(dt, dk, wb[:, E:2 * E])
+            dgrads.append(('k', dk, wb[:, E:2 * E]))
     ops.linear_wgrad(dt, dv, s['v_in'], out=d_win[2 * E:], bias_out=d_bin[2 * E:], batch=batch)
     if need_v:
-        g_v = ops.linear(dt, dv, wb[:, 2 * E:])
+        dgrads.append(('v', dv, wb[:, 2 * E:]))
+    if dgrads:
+        got = dict(zip([n for n, _, _ in dgrads], ops.linear_group(dt, [(g, w, {}) for _, g, w in dgrads])))
+        g_q, g_k, g_v = got.get('q'), got.get('k'), got.get('v')
     return g_q, g_k, g_v, d_win, d_bin, d_wo, d_bo
 
 

@@ -67,6 +67,7 @@ SIGNATURES = {
     'sedt_last_error': (C.c_char_p, []),
     'sedt_version': (_i, []),
     'sedt_igemm': (_i, [C.POINTER(SedtIgemm), _i, _vp]),
+    'sedt_igemm_group': (_i, [C.POINTER(SedtIgemm), _i, _i, _vp]),
     'sedt_wgrad_group': (_i, [C.POINTER(SedtIgemm), _i, _i, _vp]),
     'sedt_igemm_co': (_i, [C.POINTER(SedtIgemm), C.POINTER(SedtIgemm), _i, _i, _vp, C.POINTER(C.c_int)]),
     'sedt_igemm_splitk': (_i, [_i, _i, _i, _i]),

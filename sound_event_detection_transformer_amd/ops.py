@@ -184,6 +184,29 @@ def linear(dtype, x, w, out=None, *, bias=None, out_f32=False, **ep):
     return out
 
 
+def linear_group(dtype, items):
+    """several independent ``linear`` calls (each item: (x, w, kwargs of linear)) as one launch when the kernel allows it
+    (sedt_igemm_group) - the q / k / v projections of an attention block, or their three dgrads.  Returns the outputs."""
+    outs, args = [], []
+    for x, w, kw in items:
+        kw = dict(kw)
+        M, K = x.shape
+        N = w.shape[0]
+        out_f32 = kw.pop('out_f32', False)
+        out = kw.pop('out', None)
+        if out is None:
+            out = torch.empty((M, N), device=x.device, dtype=torch.float32 if out_f32 else TORCH_DTYPE[dtype])
+        outs.append(out)
+        args.append(((M, N, K, x, x.stride(0), w, w.stride(0), out, out.stride(0)), dict(out_f32=int(out_f32), **kw)))
+    if len(args) == 1 or PROFILE is not None or (_co['on'] and POOL.gemms):
+        for a, kw in args:
+            igemm(dtype, *a, **kw)
+        return outs
+    arr = (L.SedtIgemm * len(args))(*[igemm_args(*a, **kw) for a, kw in args])
+    L.check(L.load().sedt_igemm_group(arr, len(args), dtype, L.stream_ptr()), 'igemm_group')
+    return outs
+
+
 def conv_fwd(dtype, x, B, g, wf, out=None, **ep):
     """NHWC conv forward: x [B*Hi*Wi, Ci] (row stride = x.stride(0)), wf packed [Co][taps][Ci]"""
     M = B * g.Ho * g.Wo
