@@ -104,7 +104,7 @@ class GraphedTrainStep(object):
 
     def __init__(self, model, criterion, optimizer, example_input, example_targets, mask_weak=None, mask_strong=None,
                  max_norm=0.1, normalize=False, warmup=3, device_matching=True, max_targets=32, async_wgrad=False,
-                 overlap_allreduce=True, coschedule=False):
+                 overlap_allreduce=True, coschedule=False, data_parallel=None):
         import gc
         from . import runtime
         from .sedt import TargetTables
@@ -119,7 +119,12 @@ class GraphedTrainStep(object):
                                                             and torch.distributed.is_initialized()) else 1
         # data-parallel overlap: parameters whose gradients come last (stem conv0 + layer2) go to the tail of the flat layout
         self.cut_body = None
-        if self.world > 1 and overlap_allreduce and device_matching:
+        # data_parallel=True forces the data-parallel schedule (flat gradients, all-reduce, optimizer graph) even in a
+        # one-process group: lets a single GPU exercise the RCCL calls of the multi-GPU path
+        self.dp = (self.world > 1) if data_parallel is None else bool(data_parallel)
+        if self.dp and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            raise RuntimeError('data_parallel=True needs an initialised torch.distributed process group')
+        if self.dp and overlap_allreduce and device_matching:
             net = getattr(model, 'module', model)
             body = getattr(getattr(net, 'backbone', [None])[0], 'body', None) if hasattr(net, 'backbone') else None
             if body is not None and hasattr(body, 'stage_out') and optimizer._static is None:
@@ -140,6 +145,8 @@ class GraphedTrainStep(object):
         torch.cuda.synchronize()
         criterion.last_total = None      # drop the warm-up autograd graphs (their AccumulateGrad nodes belong to `side`)
         optimizer.zero_grad(set_to_none=True)
+        if self.dp:
+            optimizer.enable_flat_grads()                    # pinned staging + flat buffer: not allocatable during capture
         gc.collect()
         self.device_matching = device_matching
         self.g_fwd = torch.cuda.CUDAGraph()
@@ -173,7 +180,7 @@ class GraphedTrainStep(object):
             self.g_bwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
                 self._backward_and_step()
-        if self.world > 1:
+        if self.dp:
             # data parallel: ONE RCCL all-reduce of the flat gradient buffer between the graphs, then the fused
             # clip + AdamW reads the averaged gradients from the flat buffer
             self.g_opt = torch.cuda.CUDAGraph()
@@ -207,7 +214,7 @@ class GraphedTrainStep(object):
         # weight gradients ride in the spare workgroup slots of the dgrad chain's launches; drained on exit
         with self.runtime.async_wgrad(self.async_wgrad), ops.coschedule(self.coschedule):
             self.static_total.backward()
-        if self.world == 1:
+        if not self.dp:
             self.optimizer.step(max_norm=self.max_norm)
         else:
             self.flat_g = self.optimizer.gather_grads()      # all gradients -> one flat buffer (one launch)
