@@ -149,6 +149,11 @@ def main():
 
     # ---- roofline of the dominant kernel: every igemm launch of ONE extra step bracketed by HIP events on its stream
     roof = None
+    if rank != 0 and world > 1 and args.no_graph:
+        ops.PROFILE = []                      # eager DDP: the extra step contains collectives, every rank must take part
+        step()
+        torch.cuda.synchronize()
+        ops.PROFILE = None
     if rank == 0:
         ops.PROFILE = []
         step()
