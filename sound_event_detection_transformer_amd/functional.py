@@ -111,6 +111,19 @@ class LayerNormFn(Function):
         return dx, dg, db, None
 
 
+class CastFn(Function):
+    """x in the compute dtype; the gradient is cast back to x's dtype (one conversion however many consumers x has)"""
+
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.src_dtype = x.dtype
+        return _as(x, dt)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.src_dtype), None
+
+
 class AddFn(Function):
     """out = a + b[(r % b_mod)] ; gradient flows to a only (b is the constant position encoding)."""
 

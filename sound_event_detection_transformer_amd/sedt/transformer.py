@@ -123,15 +123,17 @@ class TransformerDecoder(nn.Module):
         """returns (L, B, Q, d): the shared LayerNorm applied to every layer's output (transformer.py:134-147)"""
         dt = runtime.compute_dtype()
         mem_pos = Fn.AddFn.apply(mem, pos, 0, dt)              # key input of every cross-attention
+        qpos = Fn.CastFn.apply(qpos, dt)                       # once for all layers (their gradients add up in the compute dtype)
         out = tgt
-        inter = []
+        outs = []
         for layer in self.layers:
             out = layer.forward_tokens(out, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask)
-            if self.return_intermediate:
-                inter.append(Fn.LayerNormFn.apply(out, self.norm.weight, self.norm.bias, dt))
+            outs.append(out)
         d = out.shape[1]
         if self.return_intermediate:
-            return torch.stack(inter).view(len(inter), B, Q, d)
+            # the shared LayerNorm of every layer's output (transformer.py:134-147) as ONE call over the stacked rows
+            stacked = torch.cat(outs) if len(outs) > 1 else outs[0]
+            return Fn.LayerNormFn.apply(stacked, self.norm.weight, self.norm.bias, dt).view(len(outs), B, Q, d)
         return Fn.LayerNormFn.apply(out, self.norm.weight, self.norm.bias, dt).view(1, B, Q, d)
 
 
