@@ -22,8 +22,8 @@ __device__ __forceinline__ int w3_swz(int row) {
 }
 
 // the workgroup program; bx = tile index of this workgroup inside its problem, by = its split-K slice
-template <int BN>   // BM = 64 output channels, BN = 64 or 128 columns of (tap, cin)
-__device__ __forceinline__ void wgrad3_body(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int nmajor,
+template <int BN, bool CONV>   // BM = 64 output channels, BN = 64 or 128 columns of (tap, cin); CONV: gathered (tap) B operand
+__device__ __forceinline__ void wgrad3_impl(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int nmajor,
                                             const int bx, const int by) {
   constexpr int BM = 64, BKP = 64;
   constexpr int NI = BN / 64;                         // 32-wide column tiles per wave (wave tile 32 x BN/2)
@@ -84,9 +84,9 @@ __device__ __forceinline__ void wgrad3_body(const SedtIgemm& p, const unsigned a
   unsigned b_poff[GB];
   int b_ho[GB], b_hoff[GB], b_trow[GB];
   bool b_wok[GB];
-  const int step_h = p.conv ? BKP / p.Wo : 0;
-  const unsigned b_step = p.conv ? (unsigned)((long)step_h * p.sh * p.Wi * p.ldb * 2) : (unsigned)(BKP * p.ldb * 2);
-  const unsigned b_wrap = p.conv ? (unsigned)(((long)p.Hi * p.Wi - (long)p.Ho * p.sh * p.Wi) * p.ldb * 2) : 0u;
+  const int step_h = CONV ? BKP / p.Wo : 0;
+  const unsigned b_step = CONV ? (unsigned)((long)step_h * p.sh * p.Wi * p.ldb * 2) : (unsigned)(BKP * p.ldb * 2);
+  const unsigned b_wrap = CONV ? (unsigned)(((long)p.Hi * p.Wi - (long)p.Ho * p.sh * p.Wi) * p.ldb * 2) : 0u;
 #pragma unroll
   for (int i = 0; i < GB; ++i) {
     const int instr = i * 4 + wave;
@@ -97,7 +97,7 @@ __device__ __forceinline__ void wgrad3_body(const SedtIgemm& p, const unsigned a
     b_trow[i] = trow;
     bool ok = j < p.N;
     long off;
-    if (p.conv) {
+    if (CONV) {
       const int tap = j / p.Ci, c = j - tap * p.Ci;
       const int kh = tap / p.KW, kw = tap - kh * p.KW;
       const int pix = kb_begin * BKP + trow;
@@ -121,22 +121,23 @@ __device__ __forceinline__ void wgrad3_body(const SedtIgemm& p, const unsigned a
   auto issue = [&](const int stage) {
     unsigned char* st = smem + stage * STAGE_BYTES;
     const int left = p.K - kbase;                    // pixels of this tile inside K
+    const bool full = left >= BKP;                   // uniform: every tile but the last skips the per-row bound checks
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
       unsigned voff = OOB;
-      if (a_ok[i] && a_trow[i] < left) voff = a_poff[i];
+      if (a_ok[i] && (full || a_trow[i] < left)) voff = a_poff[i];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(st + ((i * 4 + wave) * 8) * ROWB), 16, voff, 0, 0, 0);
       a_poff[i] += a_step;
     }
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
       unsigned voff = OOB;
-      bool ok = b_wok[i] && b_trow[i] < left;
-      if (p.conv) ok = ok && (unsigned)(b_ho[i] * p.sh + b_hoff[i]) < (unsigned)p.Hi;
+      bool ok = b_wok[i] && (full || b_trow[i] < left);
+      if (CONV) ok = ok && (unsigned)(b_ho[i] * p.sh + b_hoff[i]) < (unsigned)p.Hi;
       if (ok) voff = b_poff[i];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(st + A_BYTES + ((i * 4 + wave) * B_RPI) * B_ROWB), 16, voff, 0, 0, 0);
       b_poff[i] += b_step;
-      if (p.conv) {
+      if (CONV) {
         b_ho[i] += step_h;
         if (b_ho[i] >= p.Ho) { b_ho[i] -= p.Ho; b_poff[i] += b_wrap; }
       }
@@ -241,6 +242,13 @@ __device__ __forceinline__ void wgrad3_body(const SedtIgemm& p, const unsigned a
       }
     }
   }
+}
+
+template <int BN>
+__device__ __forceinline__ void wgrad3_body(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int nmajor,
+                                            const int bx, const int by) {
+  if (p.conv) wgrad3_impl<BN, true>(p, a_bytes, b_bytes, nmajor, bx, by);      // uniform branch: two specialised programs
+  else wgrad3_impl<BN, false>(p, a_bytes, b_bytes, nmajor, bx, by);
 }
 
 // several independent weight-gradient problems in ONE launch: the wgrads of a layer are small (a ResNet block: 3-4
