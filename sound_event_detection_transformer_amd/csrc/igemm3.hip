@@ -22,17 +22,25 @@ namespace sedt {
 
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <int BM, int BN, int S>   // S = ring depth (stages); bx = index of this workgroup among the problem's tiles
+// S = ring depth (stages); bx = index of this workgroup among the problem's tiles; NW = waves per workgroup: 4, or 8 = two
+// groups of four that each own the full output tile but only half of the k16 steps of every K tile (their accumulators are
+// added through LDS in the epilogue).  The 8-wave form gives a 128x128 tile - 64 flop per byte fetched from L2 instead of
+// 43 for 64x128 - enough waves to hide latency when a problem has only one workgroup per CU (M = 8192, N = 512).
+template <int BM, int BN, int S, int NW = 4>
 __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int bx) {
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int STAGE_BYTES = (BM + BN) * ROWB;
-  constexpr int GA = BM / 32, GB = BN / 32;
+  constexpr int GA = BM / (8 * NW), GB = BN / (8 * NW);
+  constexpr int NT = NW * 64;
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(GA >= 1 && GB >= 1, "tile too small for the wave count");
   constexpr unsigned OOB = 0x80000000u;          // >= 2^31 > num_records; stays out of range after adding any K offset
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = uniform_i32(t >> 6);
-  const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+  const int kgrp = wave >> 2;                          // 0, or 0/1 with 8 waves: which half of the k16 steps
+  const int wm = ((wave & 3) >> 1) * WM, wn = (wave & 1) * WN;
 
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
   const int nwg = ntn * ntm;
@@ -55,7 +63,7 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
   unsigned a_off[GA], a_mask[GA];
 #pragma unroll
   for (int i = 0; i < GA; ++i) {
-    const int trow = (i * 4 + wave) * 8 + lrow;
+    const int trow = (i * NW + wave) * 8 + lrow;
     const int row = m0 + trow;
     const int swz = (pc ^ ((trow >> 1) & 7)) * 8;
     unsigned mask = 0;
@@ -92,7 +100,7 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
   unsigned b_off[GB];
 #pragma unroll
   for (int i = 0; i < GB; ++i) {
-    const int trow = (i * 4 + wave) * 8 + lrow;
+    const int trow = (i * NW + wave) * 8 + lrow;
     const int row = n0 + trow;
     const int swz = (pc ^ ((trow >> 1) & 7)) * 8;
     b_off[i] = row < p.N ? (unsigned)(((long)row * p.ldb + swz) * 2) : OOB;
@@ -121,14 +129,14 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
     for (int i = 0; i < GA; ++i) {
       unsigned voff = OOB;
       if (a_mask[i] & tapbit) voff = a_off[i] + koff;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(st + ((i * 4 + wave) * 8) * ROWB), 16, voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(st + ((i * NW + wave) * 8) * ROWB), 16, voff, 0, 0, 0);
     }
     const unsigned kb2 = (unsigned)(k0 * 2);
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
       // (a local, not the expression, as the builtin argument: clang's host pass otherwise drops the kernel stub)
       unsigned bv = b_off[i] + kb2;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(st + (BM + (i * 4 + wave) * 8) * ROWB), 16, bv, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(st + (BM + (i * NW + wave) * 8) * ROWB), 16, bv, 0, 0, 0);
     }
     advance();
   };
@@ -143,29 +151,32 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
 
   // fragment read offsets inside a stage (constants of the thread)
   const int frow = lane & 31, fhalf = lane >> 5;
-  int a_rd[4][MI], b_rd[4][NI];
+  constexpr int NKQ = NW == 8 ? 2 : 4;                  // k16 steps of a K tile handled by this wave
+  int a_rd[NKQ][MI], b_rd[NKQ][NI];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
+  for (int kq = 0; kq < NKQ; ++kq) {
+    const int ks = NW == 8 ? 2 * kgrp + kq : kq;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int row = wm + i * 32 + frow;
-      a_rd[ks][i] = row * ROWB + (((ks * 2 + fhalf) ^ ((row >> 1) & 7)) * 16);
+      a_rd[kq][i] = row * ROWB + (((ks * 2 + fhalf) ^ ((row >> 1) & 7)) * 16);
     }
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
       const int row = wn + j * 32 + frow;
-      b_rd[ks][j] = (BM + row) * ROWB + (((ks * 2 + fhalf) ^ ((row >> 1) & 7)) * 16);
+      b_rd[kq][j] = (BM + row) * ROWB + (((ks * 2 + fhalf) ^ ((row >> 1) & 7)) * 16);
     }
   }
   auto compute = [&](const int stage) {
     const unsigned char* st = smem + stage * STAGE_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int kq = 0; kq < (NW == 8 ? 2 : 4); ++kq) {
+      const int ks = NW == 8 ? 2 * kgrp + kq : kq;
       bf16x8 a[MI], b[NI];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(st + a_rd[ks][i]);
+      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(st + a_rd[kq][i]);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(st + b_rd[ks][j]);
+      for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(st + b_rd[kq][j]);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -203,16 +214,32 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
   // ---- epilogue through LDS (identical to igemm2)
   constexpr int CP = BN + 4;
   float* Cs = reinterpret_cast<float*>(smem);
+  if (NW == 4 || kgrp == 0) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-        Cs[row * CP + wn + j * 32 + frow] = acc[i][j][r];
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+          Cs[row * CP + wn + j * 32 + frow] = acc[i][j][r];
+        }
+  }
   __syncthreads();
+  if (NW == 8) {                     // second wave group: add its half of the K sum
+    if (kgrp == 1) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+            Cs[row * CP + wn + j * 32 + frow] += acc[i][j][r];
+          }
+    }
+    __syncthreads();
+  }
 
   const uint32_t seed = eff_seed(p.seed, p.seed_ptr);
   const uint32_t thresh = drop_threshold(p.drop_p);
@@ -221,7 +248,7 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
   const bf16_t* maskT = reinterpret_cast<const bf16_t*>(p.mask);
   bf16_t* outT = reinterpret_cast<bf16_t*>(p.C);
   constexpr int CPR = BN / 8;
-  for (int u = t; u < BM * CPR; u += 256) {
+  for (int u = t; u < BM * CPR; u += NT) {
     const int trow = u / CPR, cc = (u % CPR) * 8;
     const int row = m0 + trow, col = n0 + cc;
     if (row >= p.M || col >= p.N) continue;
@@ -273,6 +300,31 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
 template <int BM, int BN, int S>
 __global__ __launch_bounds__(256) void igemm3_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes) {
   igemm3_body<BM, BN, S>(p, a_bytes, b_bytes, blockIdx.x);
+}
+
+template <int BM, int BN, int S>
+__global__ __launch_bounds__(512) void igemm3_w8_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes) {
+  igemm3_body<BM, BN, S, 8>(p, a_bytes, b_bytes, blockIdx.x);
+}
+
+template <int BM, int BN, int S>
+static int launch3_w8(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  constexpr size_t ring = (size_t)S * (BM + BN) * ROWB;
+  constexpr size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);
+  constexpr size_t lds = ring > ctile ? ring : ctile;
+  static bool attr_set = false;
+  auto kern = igemm3_w8_kernel<BM, BN, S>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("igemm3 w8: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+      return 1;
+    }
+    attr_set = true;
+  }
+  const int nwg = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, st, p, a_bytes, b_bytes);
+  return check_launch("igemm3_w8");
 }
 
 // Co-scheduled launch: the first nwg_main workgroups run the forward / dgrad GEMM p, the rest run pending weight-gradient
@@ -430,6 +482,20 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
     // deep-K problems with few workgroups per CU cannot hide the DMA latency by occupancy: give them a deeper ring
     const long nwg = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
     S = (p.K >= 1024 && nwg <= 3 * 256) ? 3 : 2;
+  }
+  static int nw_env = -1;
+  if (nw_env < 0) {
+    const char* e = getenv("SEDT_IGEMM3_NW");
+    nw_env = e ? atoi(e) : 0;
+  }
+  // measured (tools/tune_igemm.py, SEDT_IGEMM3_NW): the 64x128 tile runs 2-14 % faster with 8 waves (two groups splitting the
+  // k16 steps) at every shape that selects it; 128x128 / 128x64 with 8 waves are experiment-only (SEDT_IGEMM3_NW=8)
+  if (!plan3.on && co_group == nullptr && nw_env != 4) {
+    if (bm == 64 && bn == 128) return S >= 3 ? launch3_w8<64, 128, 3>(p, a_bytes, b_bytes, st) : launch3_w8<64, 128, 2>(p, a_bytes, b_bytes, st);
+    if (nw_env == 8 && bm == 128 && bn == 128)
+      return S >= 3 ? launch3_w8<128, 128, 3>(p, a_bytes, b_bytes, st) : launch3_w8<128, 128, 2>(p, a_bytes, b_bytes, st);
+    if (nw_env == 8 && bm == 128 && bn == 64)
+      return S >= 3 ? launch3_w8<128, 64, 3>(p, a_bytes, b_bytes, st) : launch3_w8<128, 64, 2>(p, a_bytes, b_bytes, st);
   }
 #define SEDT_L3(BM_, BN_)                                                      \
   if (bm == BM_ && bn == BN_) {                                                \
