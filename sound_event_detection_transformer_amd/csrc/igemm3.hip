@@ -55,6 +55,26 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, b_bytes, 0x00020000);
 
+  // ---- epilogue operands (residual, ReLU mask of the consumer) are fetched NOW into registers: the small-K problems of
+  //      layer1/layer2 are HBM streams whose per-workgroup time is a chain of memory round trips (A tile -> residual ->
+  //      store); issuing the residual/mask loads first overlaps them with the whole K loop.  They are older than every
+  //      LDS-DMA, so the counted vmcnt waits of the ring stay valid.
+  constexpr int CPR = BN / 8;                          // 16-byte chunks per tile row
+  constexpr int NCH = BM * CPR / NT;                   // chunks per thread
+  static_assert(BM * CPR % NT == 0, "epilogue chunks must divide evenly");
+  const bf16_t* resT = reinterpret_cast<const bf16_t*>(p.res);
+  const bf16_t* maskT = reinterpret_cast<const bf16_t*>(p.mask);
+  bf16x8 res_pf[NCH], mask_pf[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int u = t + c * NT;
+    const int row = m0 + u / CPR, col = n0 + (u % CPR) * 8;
+    if (row < p.M && col < p.N) {
+      if (resT) res_pf[c] = *reinterpret_cast<const bf16x8*>(resT + (long)(p.res_mod > 0 ? (row % p.res_mod) : row) * p.ldr + col);
+      if (maskT) mask_pf[c] = *reinterpret_cast<const bf16x8*>(maskT + (long)row * p.ldm + col);
+    }
+  }
+
   // ---- per-lane DMA rows
   const int lrow = lane >> 3, pc = lane & 7;
   const int taps = p.conv ? p.KH * p.KW : 1;
@@ -187,15 +207,23 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
   // ---- S-stage pipeline, unrolled by the ring depth (stage indices are literals after unrolling).  A wave waits only for
   //      its own oldest tile: (S-2) later tiles x G DMA instructions may stay in flight.
   constexpr int G = GA + GB;
+  if constexpr (S == 1) {
+    // single K tile (K = 64: the 64 -> 256 convolutions of layer1): no ring, half the LDS, twice the resident workgroups -
+    // these problems are pure HBM streams and only occupancy hides their latency
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    compute(0);
+  }
 #pragma unroll
   for (int s0 = 0; s0 < S - 1; ++s0)
     if (s0 < nkb) issue(s0);
   int it = 0;
-  for (; it + S <= nkb; it += S) {
+  for (; S > 1 && it + S <= nkb; it += S) {
 #pragma unroll
     for (int ph = 0; ph < S; ++ph) {
       const bool more = it + ph + S - 1 < nkb;
-      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S >= 2 ? S - 2 : 0) * G) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (more) issue((ph + S - 1) % S);
@@ -244,11 +272,10 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
   const uint32_t seed = eff_seed(p.seed, p.seed_ptr);
   const uint32_t thresh = drop_threshold(p.drop_p);
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-  const bf16_t* resT = reinterpret_cast<const bf16_t*>(p.res);
-  const bf16_t* maskT = reinterpret_cast<const bf16_t*>(p.mask);
   bf16_t* outT = reinterpret_cast<bf16_t*>(p.C);
-  constexpr int CPR = BN / 8;
-  for (int u = t; u < BM * CPR; u += NT) {
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int u = t + c * NT;
     const int trow = u / CPR, cc = (u % CPR) * 8;
     const int row = m0 + trow, col = n0 + cc;
     if (row >= p.M || col >= p.N) continue;
@@ -276,8 +303,7 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
       for (int e = 0; e < 8; ++e) v[e] = drop_keep(seed, base + e, thresh) ? v[e] * inv_keep : 0.f;
     }
     if (resT) {
-      const long rr = p.res_mod > 0 ? (row % p.res_mod) : row;
-      const bf16x8 rv = *reinterpret_cast<const bf16x8*>(resT + rr * p.ldr + col);
+      const bf16x8 rv = res_pf[c];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
     }
@@ -286,7 +312,7 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
     if (maskT) {
-      const bf16x8 mv = *reinterpret_cast<const bf16x8*>(maskT + (long)row * p.ldm + col);
+      const bf16x8 mv = mask_pf[c];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ((float)mv[e] > 0.f) ? v[e] : 0.f;
     }
@@ -497,6 +523,7 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
     if (nw_env == 8 && bm == 128 && bn == 64)
       return S >= 3 ? launch3_w8<128, 64, 3>(p, a_bytes, b_bytes, st) : launch3_w8<128, 64, 2>(p, a_bytes, b_bytes, st);
   }
+  if (bm == 64 && bn == 64 && p.K == BK2 && !plan3.on && co_group == nullptr) return launch3<64, 64, 1>(p, a_bytes, b_bytes, st);
 #define SEDT_L3(BM_, BN_)                                                      \
   if (bm == BM_ && bn == BN_) {                                                \
     if (S == 3) return launch3<BM_, BN_, 3>(p, a_bytes, b_bytes, st);          \
