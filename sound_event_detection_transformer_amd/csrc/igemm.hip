@@ -563,5 +563,26 @@ extern "C" int sedt_igemm_splitk(int M, int N, int K, int dtype) {
   if (s > maxs) s = maxs;
   if (s > 128) s = 128;
   if (s < 1) s = 1;
+  // K-slice mapping (bf16 grouped launches, csrc/wgrad3_body.h): with a split factor that is a multiple of 8, XCD x works
+  // on K slice x of EVERY output tile, so each private 4 MB L2 fetches 1/8 of both operands instead of one operand in
+  // full (PMC: the wgrad launches fetched 8x their algorithmic bytes).  The price is more f32 slabs; take it when the
+  // estimated fabric traffic drops by a fifth: operands A = K*M*2 B (dY), B = K*Cin*2 B (X; 3x3 kernels re-use a pixel for
+  // 9 taps), slabs 2 * s * M*N*4 B (written, then read by the reduction).
+  static int kslice = -1;
+  if (kslice < 0) {
+    const char* e = getenv("SEDT_WGRAD_KSLICE");
+    kslice = (e && e[0] == '1') ? 1 : 0;      // opt-in: measured -33 % fetched bytes for the wgrad launches, same run time
+  }
+  if (kslice && dtype == SEDT_BF16) {
+    const int taps = (N % 9 == 0 && (N / 9) % 64 == 0) ? 9 : 1;
+    const double A = 2.0 * K * M, B = 2.0 * K * (N / taps);
+    const double cur = (N > M ? 8.0 * A + B : A + 8.0 * B) + 2.0 * s * 4.0 * M * N;
+    int s8 = ((s + 7) / 8) * 8;
+    if (s8 < 8) s8 = 8;
+    if (s8 <= maxs && s8 <= 128) {
+      const double ks = A + B + 2.0 * s8 * 4.0 * M * N;
+      if (ks < 0.8 * cur) s = s8;
+    }
+  }
   return s;
 }

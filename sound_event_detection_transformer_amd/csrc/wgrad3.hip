@@ -90,9 +90,9 @@ int wgrad3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
       g.a_bytes[i] = (unsigned)ab[i];
       g.b_bytes[i] = (unsigned)bb[i];
       g.nwg[i] = ((p.N + 63) / 64) * ((p.M + 63) / 64);
-      g.nmajor[i] = p.N > p.M ? 1 : 0;
+      g.nmajor[i] = (p.N > p.M ? 1 : 0) + ((p.splitk >= 8 && p.splitk % 8 == 0) ? 2 : 0);
       g.blk0[i] = blk;
-      blk += g.nwg[i] * (p.splitk > 1 ? p.splitk : 1);
+      blk += (g.nwg[i] * (p.splitk > 1 ? p.splitk : 1) + 7) / 8 * 8;      // ranges start on multiples of 8 (XCD = id & 7)
     }
     g.blk0[g.n] = blk;
     hipLaunchKernelGGL(wgrad3_group_kernel, dim3(blk), dim3(256), lds, st, g);
@@ -114,7 +114,7 @@ int wgrad3_group_build(const SedtIgemm* jobs, int njobs, WgradGroup* g) {
     g->a_bytes[i] = (unsigned)ab;
     g->b_bytes[i] = (unsigned)bb;
     g->nwg[i] = ((p.N + 63) / 64) * ((p.M + 63) / 64);
-    g->nmajor[i] = p.N > p.M ? 1 : 0;
+    g->nmajor[i] = p.N > p.M ? 1 : 0;            // (riders of a co-scheduled launch do not start on an XCD boundary: no K-slice map)
     g->blk0[i] = blk;
     blk += g->nwg[i] * (p.splitk > 1 ? p.splitk : 1);
   }

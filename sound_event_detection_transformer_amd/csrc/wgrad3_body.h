@@ -22,6 +22,8 @@ __device__ __forceinline__ int w3_swz(int row) {
 }
 
 // the workgroup program; bx = tile index of this workgroup inside its problem, by = its split-K slice
+// nmajor: 0 = m-major tile order, 1 = n-major, both over XCD-contiguous tile ranges; 2/3 = the same orders with bx used as
+// the tile id directly (K-slice mapping: the caller already placed all tiles of one K slice on one XCD)
 template <int BN, bool CONV>   // BM = 64 output channels, BN = 64 or 128 columns of (tap, cin); CONV: gathered (tap) B operand
 __device__ __forceinline__ void wgrad3_impl(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int nmajor,
                                             const int bx, const int by) {
@@ -39,15 +41,15 @@ __device__ __forceinline__ void wgrad3_impl(const SedtIgemm& p, const unsigned a
 
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
   const int nwg = ntn * ntm;
-  int vid;
-  {
+  int vid = bx;
+  if (nmajor < 2) {
     const int b = bx, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
     vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
   // an XCD owns a contiguous run of tile ids.  When X (the N side: taps*Cin columns) is the larger operand, give each XCD
   // a few column tiles x all channel tiles (n-major) so X is streamed from HBM once in total instead of once per XCD.
   int m0, n0;
-  if (nmajor) { n0 = (vid / ntm) * BN; m0 = (vid % ntm) * BM; }
+  if (nmajor & 1) { n0 = (vid / ntm) * BN; m0 = (vid % ntm) * BM; }
   else { m0 = (vid / ntn) * BM; n0 = (vid % ntn) * BN; }
 
   const int nkb_total = (p.K + BKP - 1) / BKP;
@@ -271,7 +273,16 @@ __device__ __forceinline__ void wgrad_group_run(const WgradGroup& g, const int b
   int i = 0;
   while (i + 1 < g.n && b >= g.blk0[i + 1]) ++i;
   const int local = b - g.blk0[i];
-  wgrad3_body<64>(g.p[i], g.a_bytes[i], g.b_bytes[i], g.nmajor[i], local % g.nwg[i], local / g.nwg[i]);
+  const int nwg = g.nwg[i], sk = g.p[i].splitk > 1 ? g.p[i].splitk : 1;
+  if (local >= nwg * sk) return;                       // padding workgroups (problem ranges start on multiples of 8)
+  if (g.nmajor[i] >= 2) {
+    // K-slice mapping: workgroup ids are dealt to the 8 XCDs round-robin and blk0 is a multiple of 8, so (local & 7) is
+    // the XCD; it works through K slices xcd, xcd + 8, ... - all tiles of a slice before the next
+    const int j = local >> 3;
+    wgrad3_body<64>(g.p[i], g.a_bytes[i], g.b_bytes[i], g.nmajor[i], j % nwg, (local & 7) + 8 * (j / nwg));
+  } else {
+    wgrad3_body<64>(g.p[i], g.a_bytes[i], g.b_bytes[i], g.nmajor[i], local % nwg, local / nwg);
+  }
 }
 
 }  // namespace sedt
