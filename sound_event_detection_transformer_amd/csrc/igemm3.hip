@@ -187,21 +187,32 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
       b_rd[kq][j] = (BM + row) * ROWB + (((ks * 2 + fhalf) ^ ((row >> 1) & 7)) * 16);
     }
   }
-  auto compute = [&](const int stage) {
+  // A stage is consumed in two steps so that the LDS-DMA issue of the NEXT tile sits between them: fragment reads first
+  // (all k16 steps of the stage), then - after the DMA bookkeeping has overlapped the LDS latency - the MFMAs back to back.
+  // The waves of a workgroup run in lockstep between barriers, so nothing else hides that latency.
+  bf16x8 fa[NKQ][MI], fb[NKQ][NI];
+  auto load_frags = [&](const int stage) {
     const unsigned char* st = smem + stage * STAGE_BYTES;
 #pragma unroll
-    for (int kq = 0; kq < (NW == 8 ? 2 : 4); ++kq) {
-      const int ks = NW == 8 ? 2 * kgrp + kq : kq;
-      bf16x8 a[MI], b[NI];
+    for (int kq = 0; kq < NKQ; ++kq) {
 #pragma unroll
-      for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const bf16x8*>(st + a_rd[kq][i]);
+      for (int i = 0; i < MI; ++i) fa[kq][i] = *reinterpret_cast<const bf16x8*>(st + a_rd[kq][i]);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const bf16x8*>(st + b_rd[kq][j]);
+      for (int j = 0; j < NI; ++j) fb[kq][j] = *reinterpret_cast<const bf16x8*>(st + b_rd[kq][j]);
+    }
+  };
+  auto mfma_all = [&]() {
+#pragma unroll
+    for (int kq = 0; kq < NKQ; ++kq)
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kq][i], fb[kq][j], acc[i][j], 0, 0, 0);
+  };
+  auto compute = [&](const int stage) {
+    load_frags(stage);
+    mfma_all();
   };
 
   // ---- S-stage pipeline, unrolled by the ring depth (stage indices are literals after unrolling).  A wave waits only for
@@ -226,8 +237,9 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
       if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S >= 2 ? S - 2 : 0) * G) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      load_frags(ph);
       if (more) issue((ph + S - 1) % S);
-      compute(ph);
+      mfma_all();
     }
   }
 #pragma unroll
