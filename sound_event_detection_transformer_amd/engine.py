@@ -144,6 +144,8 @@ class GraphedTrainStep(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         criterion.last_total = None      # drop the warm-up autograd graphs (their AccumulateGrad nodes belong to `side`)
+        if self.cut_body is not None:
+            self.cut_body.keep_stage_out = True              # the capture below needs the layer2 output as the cut tensor
         optimizer.zero_grad(set_to_none=True)
         if self.dp:
             optimizer.enable_flat_grads()                    # pinned staging + flat buffer: not allocatable during capture

@@ -71,8 +71,10 @@ class ResNet50Body(nn.Module):
         self.layer4 = self._make_layer(512, 3, stride=2, dilate=dilation)
         # set by SEDT: its input_proj returns the feature-map gradient already masked by [feature > 0]
         self.premasked_consumer = False
-        # token-level outputs of layer1..layer4 of the last forward (engine.GraphedTrainStep cuts the backward after
-        # layer2 to overlap the gradient all-reduce of everything above with the backward of everything below)
+        # token-level outputs of layer1..layer4 of the last forward, kept only on request (engine.GraphedTrainStep cuts the
+        # backward after layer2 to overlap the gradient all-reduce of everything above with the backward of everything
+        # below); holding them keeps the forward's autograd graph alive, so the default is off
+        self.keep_stage_out = False
         self.stage_out = [None] * 4
 
     def _make_layer(self, planes, blocks, stride=1, dilate=False):
@@ -109,7 +111,8 @@ class ResNet50Body(nn.Module):
                         grad_premasked=True if li < 3 else (premasked or self.premasked_consumer))
             ts = [t for b in layer for t in b.tensors()]
             tok = Fn.StageFn.apply(tok, meta, *ts)
-            self.stage_out[li] = tok
+            if self.keep_stage_out:
+                self.stage_out[li] = tok
             for c in blocks:
                 H, W = (H - 1) // c.stride + 1, (W - 1) // c.stride + 1
         C = tok.shape[1]
