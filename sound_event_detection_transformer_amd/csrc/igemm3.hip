@@ -26,8 +26,9 @@ __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_read
 // groups of four that each own the full output tile but only half of the k16 steps of every K tile (their accumulators are
 // added through LDS in the epilogue).  The 8-wave form gives a 128x128 tile - 64 flop per byte fetched from L2 instead of
 // 43 for 64x128 - enough waves to hide latency when a problem has only one workgroup per CU (M = 8192, N = 512).
-template <int BM, int BN, int S, int NW = 4>
-__device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int bx) {
+// CONV: gathered A operand (tap walk); false = plain row-major A, whose per-K-tile bookkeeping is ONE scalar add.
+template <int BM, int BN, int S, int NW, bool CONV>
+__device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int bx) {
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int STAGE_BYTES = (BM + BN) * ROWB;
   constexpr int GA = BM / (8 * NW), GB = BN / (8 * NW);
@@ -77,9 +78,9 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
 
   // ---- per-lane DMA rows
   const int lrow = lane >> 3, pc = lane & 7;
-  const int taps = p.conv ? p.KH * p.KW : 1;
-  const int sg = (p.conv && p.transposed) ? -1 : 1;       // dgrad: the tap shift is subtracted
-  const long tsub = (p.conv && p.transposed) ? p.lda / p.sh : p.lda;   // elements per (sub-)pixel step, see below
+  const int taps = CONV ? p.KH * p.KW : 1;
+  const int sg = (CONV && p.transposed) ? -1 : 1;         // dgrad: the tap shift is subtracted
+  const long tsub = (CONV && p.transposed) ? p.lda / p.sh : p.lda;     // elements per (sub-)pixel step, see below
   unsigned a_off[GA], a_mask[GA];
 #pragma unroll
   for (int i = 0; i < GA; ++i) {
@@ -88,7 +89,7 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
     const int swz = (pc ^ ((trow >> 1) & 7)) * 8;
     unsigned mask = 0;
     long off;
-    if (p.conv) {
+    if (CONV) {
       const int HoWo = p.Ho * p.Wo;
       const int n = row / HoWo, rem = row - n * HoWo;
       const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
@@ -115,6 +116,7 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
       mask = row < p.M ? 1u : 0u;
     }
     a_off[i] = (unsigned)(off * 2);
+    if (!CONV && !mask) a_off[i] = OOB;        // plain rows beyond M: the offset itself is out of range, no per-tile test
     a_mask[i] = mask;
   }
   unsigned b_off[GB];
@@ -132,8 +134,9 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
   const int rowbytes = (int)(tsub * 2);
   auto advance = [&]() {
     k0 += BK2;
+    if (!CONV) return;
     c0 += BK2;
-    if (p.conv && c0 >= p.Ci) {
+    if (c0 >= p.Ci) {
       c0 = 0;
       ++tap;
       if (++kw == p.KW) { kw = 0; ++kh; }
@@ -143,15 +146,15 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
 
   auto issue = [&](const int stage) {      // called with literal stages only: folds to immediates after inlining
     unsigned char* st = smem + stage * STAGE_BYTES;
-    const unsigned koff = (unsigned)(tapdelta + c0 * 2);
+    const unsigned kb2 = (unsigned)(k0 * 2);
+    const unsigned koff = CONV ? (unsigned)(tapdelta + c0 * 2) : kb2;
     const unsigned tapbit = 1u << tap;
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
-      unsigned voff = OOB;
-      if (a_mask[i] & tapbit) voff = a_off[i] + koff;
+      unsigned voff = a_off[i] + koff;
+      if (CONV && !(a_mask[i] & tapbit)) voff = OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(st + ((i * NW + wave) * 8) * ROWB), 16, voff, 0, 0, 0);
     }
-    const unsigned kb2 = (unsigned)(k0 * 2);
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
       // (a local, not the expression, as the builtin argument: clang's host pass otherwise drops the kernel stub)
@@ -230,6 +233,17 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
   for (int s0 = 0; s0 < S - 1; ++s0)
     if (s0 < nkb) issue(s0);
   int it = 0;
+  // steady state: whole rounds in which every phase still has a tile to prefetch - no per-phase tests
+  for (; S > 1 && it + 2 * S - 1 <= nkb; it += S) {
+#pragma unroll
+    for (int ph = 0; ph < S; ++ph) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S >= 2 ? S - 2 : 0) * G) : "memory");
+      __builtin_amdgcn_s_barrier();
+      load_frags(ph);
+      issue((ph + S - 1) % S);
+      mfma_all();
+    }
+  }
   for (; S > 1 && it + S <= nkb; it += S) {
 #pragma unroll
     for (int ph = 0; ph < S; ++ph) {
@@ -333,6 +347,12 @@ __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a
     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(v[e] * p.alpha);
     *reinterpret_cast<bf16x8*>(outT + (long)row * p.ldc + col) = o;
   }
+}
+
+template <int BM, int BN, int S, int NW = 4>
+__device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int bx) {
+  if (p.conv) igemm3_impl<BM, BN, S, NW, true>(p, a_bytes, b_bytes, bx);      // uniform branch: two specialised programs
+  else igemm3_impl<BM, BN, S, NW, false>(p, a_bytes, b_bytes, bx);
 }
 
 template <int BM, int BN, int S>
