@@ -137,6 +137,9 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     if (!CONV) return;
     c0 += BK2;
     if (c0 >= p.Ci) {
+      // (the empty volatile asm keeps this rare block a real branch: if-converted, its ~15 scalar instructions - two of
+      // them multiplies - would run on every K tile)
+      asm volatile("" ::: "memory");
       c0 = 0;
       ++tap;
       if (++kw == p.KW) { kw = 0; ++kh; }
