@@ -540,9 +540,10 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
   }
   int S = stages;
   if (S == 0) {
-    // deep-K problems with few workgroups per CU cannot hide the DMA latency by occupancy: give them a deeper ring
-    const long nwg = (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-    S = (p.K >= 1024 && nwg <= 3 * 256) ? 3 : 2;
+    // re-tuned after the 8-wave / lean-bookkeeping changes (full step, SEDT_IGEMM3_STAGES sweep: 2 everywhere 8881,
+    // old rule "3 when K >= 1024 and <= 3 workgroups per CU" 9447, 3 everywhere 9590, 4 9457 clips/s): two tiles in flight
+    // pay at every depth that has them
+    S = p.K >= 3 * BK2 ? 3 : 2;
   }
   static int nw_env = -1;
   if (nw_env < 0) {

@@ -393,15 +393,14 @@ def test_igemm_co_matches_separate_launches(ops):
                            slab=slab)
         return a, slab
 
-    g0, x0, gy0 = problem(32, 8, 64, 64, 3, 1, 1, 1)          # K = 576 -> the 64x64 2-stage kernel, which can carry riders
-    w0 = torch.randn(64, 64, 3, 3, device='cuda') / 24.0
-    _, wb0 = ops.pack_conv(L.BF16, w0)
+    # main problem: a plain GEMM with K = 128 -> the 64x64 2-stage kernel, the configuration that can carry riders
+    xm = torch.randn(4096, 128, device='cuda').bfloat16()
+    wm = (torch.randn(64, 128, device='cuda') / 11.0).bfloat16()
     riders = [problem(32, 4, 256, 256, 3, 1, 1, 1), problem(32, 4, 512, 128, 1, 1, 0, 1), problem(16, 8, 64, 64, 3, 1, 1, 1)]
     outs = {}
     for mode in ('separate', 'co'):
-        dx = torch.zeros_like(x0)
-        main = ops.igemm_args(x0.shape[0], g0.Ci, g0.taps * g0.Co, gy0, gy0.stride(0), wb0, g0.taps * g0.Co, dx, dx.stride(0),
-                              conv=ops._geom_tuple(g0, transposed=True), transposed=1, mask=x0, ldm=x0.stride(0))
+        dx = torch.zeros((4096, 64), device='cuda', dtype=torch.bfloat16)
+        main = ops.igemm_args(4096, 64, 128, xm, xm.stride(0), wm, wm.stride(0), dx, dx.stride(0), act=ops.ACT_RELU)
         ws = [wgrad_args(*r) for r in riders]
         arr = (L.SedtIgemm * len(ws))(*[a for a, _ in ws])
         lib = L.load()
