@@ -297,7 +297,7 @@ int igemm2_try(const SedtIgemm& p, hipStream_t st) {
     // once K is deep and enough tiles remain to fill the chip; everything else prefers the 64x64 tile's occupancy
     // (with the 8-wave form of that tile - igemm3.hip - the tile-count condition of the 4-wave kernel no longer applies)
     // (a grouped launch - igemm3_planning() - runs on the 64x64 program: worth it for the launch-bound decoder-sized problems)
-    if ((p.N % 128) == 0 && (p.K >= 512 || p.N >= 512) && !(igemm3_planning() && p.M <= 1024)) bn = 128;
+    if ((p.N % 128) == 0 && p.K >= 512 && !(igemm3_planning() && p.M <= 1024)) bn = 128;
   }
   {   // the lean-issue kernel takes the common cases
     int r3 = igemm3_try(p, (unsigned)a_bytes, (unsigned)b_bytes, bm, bn, st);
