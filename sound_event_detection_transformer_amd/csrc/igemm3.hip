@@ -411,7 +411,7 @@ struct Igemm3Plan {
 };
 thread_local Igemm3Plan plan3 = {false, false, 0, 0, 0, 0u, 0u};
 
-// several independent forward / dgrad problems of the 64x64 2-stage configuration in ONE launch (the q / k / v projections
+// several independent forward / dgrad problems of the 64x64 configuration (all with the same ring depth) in ONE launch (the q / k / v projections
 // of an attention block and their three dgrads are independent GEMMs of a few microseconds each)
 constexpr int IG_MAXG = 8;
 struct IgemmGroup {
@@ -421,10 +421,11 @@ struct IgemmGroup {
   SedtIgemm p[IG_MAXG];
 };
 
+template <int S>
 __global__ __launch_bounds__(256) void igemm3_group_kernel(const IgemmGroup g) {
   int i = 0;
   while (i + 1 < g.n && (int)blockIdx.x >= g.blk0[i + 1]) ++i;
-  igemm3_body<64, 64, 2>(g.p[i], g.a_bytes[i], g.b_bytes[i], (int)blockIdx.x - g.blk0[i]);
+  igemm3_body<64, 64, S>(g.p[i], g.a_bytes[i], g.b_bytes[i], (int)blockIdx.x - g.blk0[i]);
 }
 
 template <int BM, int BN, int S>
@@ -491,7 +492,7 @@ int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
   if (!on || njobs < 2 || njobs > IG_MAXG) return -1;
   IgemmGroup g;
   g.n = njobs;
-  int blk = 0;
+  int blk = 0, S = 0;
   for (int i = 0; i < njobs; ++i) {
     const SedtIgemm& p = jobs[i];
     if (p.trans) return -1;
@@ -499,7 +500,9 @@ int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
     const int r = igemm2_try(p, st);
     const Igemm3Plan got = plan3;
     plan3.on = false;
-    if (r != 0 || !got.ok || got.bm != 64 || got.bn != 64 || got.s != 2) return -1;
+    if (r != 0 || !got.ok || got.bm != 64 || got.bn != 64 || (got.s != 2 && got.s != 3)) return -1;
+    if (i == 0) S = got.s;
+    if (got.s != S) return -1;
     g.p[i] = p;
     g.a_bytes[i] = got.a_bytes;
     g.b_bytes[i] = got.b_bytes;
@@ -507,18 +510,33 @@ int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
     blk += ((p.N + 63) / 64) * ((p.M + 63) / 64);
   }
   g.blk0[njobs] = blk;
-  constexpr size_t lds = (size_t)2 * (64 + 64) * ROWB;      // ring 32 KB >= the 17 KB epilogue tile
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm3_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) {
-      set_error("igemm3 group: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return 1;
+  if (S == 3) {
+    constexpr size_t lds = (size_t)3 * (64 + 64) * ROWB;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm3_group_kernel<3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        set_error("igemm3 group: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        return 1;
+      }
+      attr_set = true;
     }
-    attr_set = true;
+    hipLaunchKernelGGL(igemm3_group_kernel<3>, dim3(blk), dim3(256), lds, st, g);
+  } else {
+    constexpr size_t lds = (size_t)2 * (64 + 64) * ROWB;      // ring 32 KB >= the 17 KB epilogue tile
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm3_group_kernel<2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) {
+        set_error("igemm3 group: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+        return 1;
+      }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(igemm3_group_kernel<2>, dim3(blk), dim3(256), lds, st, g);
   }
-  hipLaunchKernelGGL(igemm3_group_kernel, dim3(blk), dim3(256), lds, st, g);
   return check_launch("igemm3_group");
 }
 
