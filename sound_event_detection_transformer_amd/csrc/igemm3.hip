@@ -130,32 +130,37 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
 
   // ---- wave-uniform K position: channel offset inside the tap, tap index, its pixel shift in bytes
   int c0 = 0, tap = 0, kh = 0, kw = 0, k0 = 0;
-  int tapdelta = 0;
   const int rowbytes = (int)(tsub * 2);
+  // CONV: per A row, the offset of the CURRENT tap with its validity folded in (out of range when the tap misses the image);
+  // it changes only when the tap does, so a K tile costs one add per row
+  unsigned a_cur[GA];
+#pragma unroll
+  for (int i = 0; i < GA; ++i) a_cur[i] = (!CONV || (a_mask[i] & 1u)) ? a_off[i] : OOB;
   auto advance = [&]() {
     k0 += BK2;
     if (!CONV) return;
     c0 += BK2;
     if (c0 >= p.Ci) {
-      // (the empty volatile asm keeps this rare block a real branch: if-converted, its ~15 scalar instructions - two of
-      // them multiplies - would run on every K tile)
+      // (the empty volatile asm keeps this rare block a real branch: if-converted, its instructions - two scalar
+      // multiplies among them - would run on every K tile)
       asm volatile("" ::: "memory");
       c0 = 0;
       ++tap;
       if (++kw == p.KW) { kw = 0; ++kh; }
-      tapdelta = sg * (kh * p.dh * p.Wi + kw * p.dw) * rowbytes;
+      const unsigned tapdelta = (unsigned)(sg * (kh * p.dh * p.Wi + kw * p.dw) * rowbytes);
+      const unsigned tapbit = 1u << tap;
+#pragma unroll
+      for (int i = 0; i < GA; ++i) a_cur[i] = (a_mask[i] & tapbit) ? a_off[i] + tapdelta : OOB;
     }
   };
 
   auto issue = [&](const int stage) {      // called with literal stages only: folds to immediates after inlining
     unsigned char* st = smem + stage * STAGE_BYTES;
     const unsigned kb2 = (unsigned)(k0 * 2);
-    const unsigned koff = CONV ? (unsigned)(tapdelta + c0 * 2) : kb2;
-    const unsigned tapbit = 1u << tap;
+    const unsigned koff = CONV ? (unsigned)(c0 * 2) : kb2;      // (an out-of-range a_cur stays out of range: c0 * 2 < 2^31)
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
-      unsigned voff = a_off[i] + koff;
-      if (CONV && !(a_mask[i] & tapbit)) voff = OOB;
+      unsigned voff = a_cur[i] + koff;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(st + ((i * NW + wave) * 8) * ROWB), 16, voff, 0, 0, 0);
     }
 #pragma unroll
