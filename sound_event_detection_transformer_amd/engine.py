@@ -34,10 +34,30 @@ def allreduce_mean(flat, async_op=False):
     return _Done() if async_op else flat
 
 
+_step_streams = {}
+
+
 def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None, mask_strong=None, max_norm=0.1,
                normalize=False, check_finite=True, patches=None, allreduce=False):
     """forward -> SetCriterion -> weighted sum over weight_dict -> backward -> clip_grad_norm_(max_norm) -> step ->
-    zero_grad.  Raises on a non-finite loss (the reference calls sys.exit(1), engine.py:70-73)."""
+    zero_grad.  Raises on a non-finite loss (the reference calls sys.exit(1), engine.py:70-73).
+
+    When called on the default stream the step runs on a dedicated side stream (ordered after / before the caller's
+    stream): a backward pass executed on the DEFAULT stream leaves the parameters' gradient accumulators tied to it, and
+    a later HIP-graph capture of the backward (GraphedTrainStep) is then invalidated - ROCm 7.2 faults in
+    hipStreamEndCapture instead of reporting it."""
+    dev = batch_input.device if torch.is_tensor(batch_input) else None
+    if dev is not None and dev.type == 'cuda' and torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev):
+        key = str(dev)
+        if key not in _step_streams:
+            _step_streams[key] = torch.cuda.Stream(device=dev)
+        side, cur = _step_streams[key], torch.cuda.current_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            out = train_step(model, criterion, optimizer, batch_input, targets, mask_weak, mask_strong, max_norm, normalize,
+                             check_finite, patches, allreduce)
+        cur.wait_stream(side)
+        return out
     outputs = model(batch_input, patches) if patches is not None else model(batch_input)
     loss_dict, _ = criterion(outputs, targets, mask_weak, mask_strong, False, normalize)
     wd = criterion.weight_dict
@@ -64,7 +84,9 @@ def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None
             torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
         optimizer.step()
     optimizer.zero_grad(set_to_none=True)
-    return losses.detach(), loss_dict
+    # logging values only: detached, so that a caller holding on to them does not keep this step's autograd graph (and the
+    # parameters' AccumulateGrad nodes of this stream) alive - a later HIP-graph capture of the backward would break on them
+    return losses.detach(), {k: v.detach() for k, v in loss_dict.items()}
 
 
 def build_optimizer(model, lr=1e-4, lr_backbone=1e-4, weight_decay=1e-4, fused=True):
@@ -86,6 +108,10 @@ class GraphedTrainStep(object):
 
     device_matching=False: the reference's split - graph A (forward), SetCriterion.prepare on the host (one D2H copy,
     batched C++ Hungarian, one H2D copy), graph B (loss + backward + optimizer).
+
+    Before constructing one, drop every tensor that still carries an autograd graph of an earlier EAGER backward on the
+    default stream (loss dicts, model outputs): live AccumulateGrad nodes of another stream invalidate the capture of the
+    backward (PyTorch warns 'AccumulateGrad node's stream does not match'; ROCm then faults in hipStreamEndCapture).
 
     Shapes are static: every batch must have the batch size, clip length and strong/weak split it was captured with (and,
     for the host split, the same per-clip target counts).  Dropout masks change on each replay through the device-side

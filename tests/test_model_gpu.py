@@ -357,6 +357,8 @@ def test_graphed_step_weak_strong_split_matches_eager(pkg):
         opt = build_optimizer(model)
         if mode == 'graph':
             sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+            # an eager step first (regression: a backward executed on the default stream used to invalidate the capture)
+            train_step(model, crit, opt, batches[0][0], batches[0][1], slice(ns, B), slice(ns), max_norm=0.1)
             stepper = GraphedTrainStep(model, crit, opt, batches[0][0], batches[0][1], slice(ns, B), slice(ns), warmup=2)
             model.load_state_dict(sd0)
             opt._m.zero_(); opt._v.zero_(); opt._step_t.zero_()
