@@ -46,7 +46,9 @@ def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None
     stream): a backward pass executed on the DEFAULT stream leaves the parameters' gradient accumulators tied to it, and
     a later HIP-graph capture of the backward (GraphedTrainStep) is then invalidated - ROCm 7.2 faults in
     hipStreamEndCapture instead of reporting it."""
-    dev = batch_input.device if torch.is_tensor(batch_input) else None
+    first = batch_input if torch.is_tensor(batch_input) else (getattr(batch_input, 'tensors', None) if not isinstance(
+        batch_input, (tuple, list)) else (batch_input[0] if len(batch_input) and torch.is_tensor(batch_input[0]) else None))
+    dev = first.device if torch.is_tensor(first) else None
     if dev is not None and dev.type == 'cuda' and torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev):
         key = str(dev)
         if key not in _step_streams:

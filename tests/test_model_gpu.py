@@ -374,3 +374,32 @@ def test_graphed_step_weak_strong_split_matches_eager(pkg):
     np.testing.assert_allclose(res['graph'][0], res['eager'][0], rtol=1e-3)
     for k in res['eager'][1]:
         assert rel(res['graph'][1][k], res['eager'][1][k]) < 2e-3, k
+
+
+def test_spsedt_bf16_train_step_runs_and_tracks_f32(pkg, golden_dir):
+    """SP-SEDT (config C4 shape family: patch backbone + self-supervised decoder queries + feature loss) through the eager
+    train step in bf16: finite, and within the stated bf16 bound (3e-2) of the f32 loss of the same step"""
+    A, runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import train_step, build_optimizer
+    g = np.load(os.path.join(golden_dir, 'g4_spsedt.npz'))
+    B, P = 2, 10
+    x = torch.randn(B, 1, 496, 64, generator=torch.Generator().manual_seed(8)).cuda()
+    patches = torch.randn(B, P, 1, 128, 64, generator=torch.Generator().manual_seed(9)).cuda()
+    mask = torch.zeros(B, 496, 64, dtype=torch.bool).cuda()
+    targets = [{'labels': torch.zeros(P, dtype=torch.int64).cuda(), 'boxes': torch.from_numpy(g['target_boxes'][i]).cuda()}
+               for i in range(B)]
+    losses = {}
+    for mode in ('f32', 'bf16'):
+        runtime.set_compute_dtype(mode)
+        runtime.manual_seed(1)
+        model, crit = _build(sedt, 6, 20, dec_at=False, self_sup=True, lr_backbone=0.0, dropout=0.0)
+        _seed_load(model, 404).cuda().train()
+        crit.cuda()
+        opt = build_optimizer(model)
+        torch.manual_seed(0)                     # the Bernoulli query mask of SPSEDT.forward
+        l, ld = train_step(model, crit, opt, (x, mask), targets, slice(B), slice(B), max_norm=0.1, patches=patches)
+        losses[mode] = float(l)
+        assert all(torch.isfinite(v).all() for v in ld.values())
+        assert all(torch.isfinite(p).all() for p in model.parameters())
+    runtime.set_compute_dtype('f32')
+    assert abs(losses['bf16'] - losses['f32']) < 3e-2 * abs(losses['f32']), losses
