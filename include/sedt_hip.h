@@ -132,6 +132,18 @@ typedef struct SedtReduceJob {
 } SedtReduceJob;
 int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, void* stream);
 
+/* ------------------------------------------------------------------ linear layers with N <= 16 outputs (the SEDT heads,
+ * sedt/sedt.py:36-38, 90-95, 398-409): direct kernels on the f32 MASTER weight w[N][K] (no packing).
+ * fwd: y[m][n] = act(x[m] . w[n] + bias[n]); y is f32 (out_f32) or the compute dtype.
+ * bwd: g[M][N] f32 is the gradient of y; with act != NONE the derivative is folded in from ysaved (= y, f32, same ld as g).
+ *      gx (compute dtype, optional; masked by mask > 0 when given) = g' w; dw[N][K], db[N] (optional) = g'^T x, column sums. */
+int sedt_skinny_linear_fwd(const void* x, int64_t ldx, const float* w, const float* bias, void* y, int64_t ldy, int M, int N,
+                           int K, int act, int out_f32, int dtype, void* stream);
+size_t sedt_skinny_linear_bwd_scratch(int K); /* bytes of `scratch` (row-slice partial sums) when dw is requested */
+int sedt_skinny_linear_bwd(const float* g, const float* ysaved, int64_t ldg, const float* w, const void* x, int64_t ldx,
+                           const void* mask, int64_t ldm, void* gx, int64_t ldo, float* dw, float* db, float* scratch, int M, int N,
+                           int K, int act, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ elementwise / reductions */
 /* out[c] = sum_r in[r*ld + c]   (in: compute dtype or f32 if in_f32), out f32 */
 int sedt_colsum(const void* in, int64_t ld, int rows, int cols, int in_f32, int dtype, float* out,

@@ -65,11 +65,17 @@ class LinearFn(Function):
         dgrad epilogue here instead of a separate pass in the producer's backward)"""
         x = _as(x, dt)
         ctx.relu_input = relu_input
+        ctx.dt, ctx.act, ctx.out_f32 = dt, act, out_f32
+        ctx.has_bias = bias is not None
+        # heads with a handful of outputs (class 11, box 2, audio tag 10): direct kernels on the master weight
+        ctx.skinny = ops.skinny_ok(weight.shape[0], weight.shape[1]) and out_f32 and weight.is_contiguous()
+        if ctx.skinny:
+            y = ops.skinny_linear_fwd(dt, x, weight, bias, act, True)
+            ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
+            return y
         wf, ctx.wb = _prep_linear(dt, weight, ctx.needs_input_grad[0])
         y = ops.linear(dt, x, wf, bias=bias, act=act, out_f32=out_f32)
-        ctx.dt, ctx.act, ctx.out_f32 = dt, act, out_f32
         ctx.save_for_backward(x, weight, y if act != ACT_NONE else None)
-        ctx.has_bias = bias is not None
         return y
 
     @staticmethod
@@ -77,6 +83,11 @@ class LinearFn(Function):
         x, weight, y = ctx.saved_tensors
         dt = ctx.dt
         gy = gy.contiguous()
+        if ctx.skinny:
+            gx, gw, gb = ops.skinny_linear_bwd(dt, gy.float() if gy.dtype != torch.float32 else gy, y, weight, x, ctx.act,
+                                               mask=x if ctx.relu_input else None, need_gx=ctx.needs_input_grad[0],
+                                               need_gw=ctx.needs_input_grad[1], need_gb=ctx.has_bias and ctx.needs_input_grad[2])
+            return gx, gw, gb, None, None, None, None
         if ctx.act == ACT_SIGMOID:
             gy = ops.sigmoid_grad(gy.float() if gy.dtype != torch.float32 else gy, y.float() if y.dtype != torch.float32 else y)
         elif ctx.act == ACT_RELU:

@@ -74,6 +74,9 @@ SIGNATURES = {
     'sedt_wgrad_reduce': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sedt_wgrad_reduce_bias': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'sedt_multi_wgrad_reduce': (_i, [C.POINTER(SedtReduceJob), _i, _vp]),
+    'sedt_skinny_linear_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
+    'sedt_skinny_linear_bwd_scratch': (_sz, [_i]),
+    'sedt_skinny_linear_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'sedt_colsum': (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'sedt_colsum_scratch': (_sz, [_i, _i]),
     'sedt_dropout_grad': (_i, [_vp, _i64, _vp, _i64, _i, _i, _f, _u32, _vp, _i, _vp]),

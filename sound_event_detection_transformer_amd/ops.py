@@ -179,6 +179,41 @@ def linear(dtype, x, w, out=None, *, bias=None, out_f32=False, **ep):
     return out
 
 
+def skinny_ok(N, K):
+    """envelope of the direct small-N linear kernels (csrc/skinny.hip)"""
+    return N <= 16 and K % 64 == 0 and K <= 1024
+
+
+def skinny_linear_fwd(dtype, x, w, bias=None, act=ACT_NONE, out_f32=False):
+    """y = act(x @ w^T + b) for N <= 16 output features straight from the f32 master weight (no packing)"""
+    _dev_check(x, w)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.dtype == torch.float32 and w.is_contiguous() and x.stride(1) == 1
+    y = torch.empty((M, N), device=x.device, dtype=torch.float32 if out_f32 else TORCH_DTYPE[dtype])
+    L.check(L.load().sedt_skinny_linear_fwd(_p(x), x.stride(0), _p(w), _p(bias), _p(y), y.stride(0), M, N, K, act, int(out_f32), dtype,
+                                            L.stream_ptr()), 'skinny_linear_fwd')
+    return y
+
+
+def skinny_linear_bwd(dtype, g, ysaved, w, x, act=ACT_NONE, mask=None, need_gx=True, need_gw=True, need_gb=True):
+    """(gx, dW, db) of skinny_linear_fwd; g f32 [M,N]; ysaved = the f32 output when act != NONE"""
+    M, K = x.shape
+    N = w.shape[0]
+    assert g.dtype == torch.float32 and g.is_contiguous() and (ysaved is None or (ysaved.dtype == torch.float32 and ysaved.is_contiguous()))
+    gx = torch.empty((M, K), device=x.device, dtype=TORCH_DTYPE[dtype]) if need_gx else None
+    dw = torch.empty((N, K), device=x.device, dtype=torch.float32) if need_gw else None
+    db = torch.empty((N,), device=x.device, dtype=torch.float32) if (need_gb and need_gw) else None
+    lib = L.load()
+    scratch = torch.empty((lib.sedt_skinny_linear_bwd_scratch(K) // 4,), device=x.device, dtype=torch.float32) if need_gw else None
+    L.check(lib.sedt_skinny_linear_bwd(_p(g), _p(ysaved), g.stride(0), _p(w), _p(x), x.stride(0), _p(mask),
+                                       mask.stride(0) if mask is not None else 0, _p(gx), K, _p(dw), _p(db), _p(scratch), M, N, K, act,
+                                       dtype, L.stream_ptr()), 'skinny_linear_bwd')
+    if need_gb and not need_gw:
+        db = g.sum(0) if act == ACT_NONE else (g * ysaved * (1 - ysaved)).sum(0) if act == ACT_SIGMOID else (g * (ysaved > 0)).sum(0)
+    return gx, dw, db
+
+
 def linear_group(dtype, items):
     """several independent ``linear`` calls (each item: (x, w, kwargs of linear)) as one launch when the kernel allows it
     (sedt_igemm_group) - the q / k / v projections of an attention block, or their three dgrads.  Returns the outputs."""

@@ -418,3 +418,32 @@ def test_igemm_co_matches_separate_launches(ops):
         assert torch.isfinite(b.float()).all()
         assert torch.equal(a, b)
     assert outs['co'][0].abs().sum() > 0 and all(o.abs().sum() > 0 for o in outs['co'][1:])
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+@pytest.mark.parametrize('M,N,K,act', [(2112, 11, 256, 'none'), (2112, 2, 256, 'sigmoid'), (64, 10, 256, 'none'),
+                                       (333, 16, 128, 'relu'), (17, 1, 64, 'sigmoid')])
+def test_skinny_linear_fwd_bwd(ops, dt, M, N, K, act):
+    """direct small-N head kernels (csrc/skinny.hip) vs torch: y, dx (with and without the relu-input mask), dW, db"""
+    ACT = {'none': ops.ACT_NONE, 'sigmoid': ops.ACT_SIGMOID, 'relu': ops.ACT_RELU}[act]
+    fn = {'none': lambda t: t, 'sigmoid': torch.sigmoid, 'relu': F.relu}[act]
+    assert ops.skinny_ok(N, K)
+    x, w, b, g = randn(M, K), randn(N, K) / math.sqrt(K), randn(N), randn(M, N)
+    xr = rnd(x, dt).requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = fn(xr @ wr.t() + br)
+    yr.backward(g)
+    xd = dev(x, dt)
+    y = ops.skinny_linear_fwd(dt, xd, w.cuda(), b.cuda(), ACT, out_f32=True)
+    close(y, yr.detach(), dt, bf16_tol=1e-5 if dt == BF16 else 2e-2)      # f32 math on bf16-rounded inputs: exact to rounding
+    gx, gw, gb = ops.skinny_linear_bwd(dt, g.cuda(), y if act != 'none' else None, w.cuda(), xd, ACT)
+    close(gx, xr.grad, dt)
+    close(gw, wr.grad, dt, bf16_tol=1e-4)
+    close(gb, br.grad, dt, bf16_tol=1e-4)
+    # relu-input mask on dx (x is the saved post-relu activation of the previous layer)
+    gx2, _, _ = ops.skinny_linear_bwd(dt, g.cuda(), y if act != 'none' else None, w.cuda(), xd, ACT, mask=xd, need_gw=False, need_gb=False)
+    close(gx2, xr.grad * (rnd(x, dt) > 0), dt)
+    # bf16-typed output variant
+    y2 = ops.skinny_linear_fwd(dt, xd, w.cuda(), b.cuda(), ACT, out_f32=False)
+    assert y2.dtype == TD[dt]
+    close(y2, yr.detach(), dt)
