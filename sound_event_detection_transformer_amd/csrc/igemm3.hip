@@ -27,7 +27,10 @@ __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_read
 // added through LDS in the epilogue).  The 8-wave form gives a 128x128 tile - 64 flop per byte fetched from L2 instead of
 // 43 for 64x128 - enough waves to hide latency when a problem has only one workgroup per CU (M = 8192, N = 512).
 // CONV: gathered A operand (tap walk); false = plain row-major A, whose per-K-tile bookkeeping is ONE scalar add.
-template <int BM, int BN, int S, int NW, bool CONV>
+// PP (8 waves only): "ping-pong" - the second wave group runs its MFMAs half a stage late, i.e. while the first group reads
+// its fragments and issues the next LDS-DMA, and reads its own fragments while the first group's MFMAs run: with one
+// workgroup per CU (128x128 tiles at M = 8192, N = 512) nothing else overlaps the LDS phase with the MFMA phase.
+template <int BM, int BN, int S, int NW, bool CONV, int PP = 0>
 __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int bx) {
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int STAGE_BYTES = (BM + BN) * ROWB;
@@ -154,21 +157,23 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     }
   };
 
-  auto issue = [&](const int stage) {      // called with literal stages only: folds to immediates after inlining
+  // one LDS-DMA piece of the tile at the current K position: pieces 0..GA-1 are A rows, GA..GA+GB-1 are B rows
+  auto issue_piece = [&](const int stage, const int i) {      // literal stage / piece only: folds to immediates
     unsigned char* st = smem + stage * STAGE_BYTES;
     const unsigned kb2 = (unsigned)(k0 * 2);
-    const unsigned koff = CONV ? (unsigned)(c0 * 2) : kb2;      // (an out-of-range a_cur stays out of range: c0 * 2 < 2^31)
-#pragma unroll
-    for (int i = 0; i < GA; ++i) {
+    if (i < GA) {
+      const unsigned koff = CONV ? (unsigned)(c0 * 2) : kb2;    // (an out-of-range a_cur stays out of range: c0 * 2 < 2^31)
       unsigned voff = a_cur[i] + koff;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(st + ((i * NW + wave) * 8) * ROWB), 16, voff, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < GB; ++i) {
+    } else {
       // (a local, not the expression, as the builtin argument: clang's host pass otherwise drops the kernel stub)
-      unsigned bv = b_off[i] + kb2;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(st + (BM + (i * NW + wave) * 8) * ROWB), 16, bv, 0, 0, 0);
+      unsigned bv = b_off[i - GA] + kb2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(st + (BM + ((i - GA) * NW + wave) * 8) * ROWB), 16, bv, 0, 0, 0);
     }
+  };
+  auto issue = [&](const int stage) {
+#pragma unroll
+    for (int i = 0; i < GA + GB; ++i) issue_piece(stage, i);
     advance();
   };
 
@@ -225,10 +230,61 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     load_frags(stage);
     mfma_all();
   };
-
   // ---- S-stage pipeline, unrolled by the ring depth (stage indices are literals after unrolling).  A wave waits only for
   //      its own oldest tile: (S-2) later tiles x G DMA instructions may stay in flight.
   constexpr int G = GA + GB;
+  if constexpr (PP) {
+    // Ping-pong: every stage is two barrier-delimited segments - "load" (fragment reads of tile s, LDS-DMA issue of tile
+    // s+S-1) and "math" (the MFMAs of tile s) - and the second wave group runs ONE BARRIER behind the first, so on every
+    // SIMD one wave is in its math segment while the other is in its load segment.  Same instruction stream for both
+    // groups (the skew is one extra barrier before the loop for group 1, after it for group 0).  Ordering rules:
+    //   RAW  tile s+1 is waited for (own DMA pieces, counted vmcnt) at the END of the load segment of tile s: that is
+    //        before the barrier preceding the first group's reads of tile s+1 for both groups;
+    // (Issuing the LDS-DMA pieces between the MFMAs of the math segment instead was measured 3-15 % slower.)
+    //   WAR  the buffer of tile s-1 is restaged in the load segment of tile s; the last reads of it (group 1, load segment
+    //        of s-1) retired before the barrier ending that segment (lgkmcnt(0)), which precedes the first group's issue.
+    static_assert(NW == 8 && S >= 2, "ping-pong needs two wave groups and a ring");
+#pragma unroll
+    for (int s0 = 0; s0 < S - 1; ++s0)
+      if (s0 < nkb) issue(s0);
+    if (nkb >= S - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (kgrp == 1) __builtin_amdgcn_s_barrier();
+    int it = 0;
+    for (; it + 2 * S - 1 <= nkb; it += S) {
+#pragma unroll
+      for (int ph = 0; ph < S; ++ph) {
+        __builtin_amdgcn_s_barrier();
+        load_frags(ph);
+        issue((ph + S - 1) % S);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");      // tile s+1 complete (own pieces)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+        mfma_all();
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+    for (; it < nkb; it += S) {
+#pragma unroll
+      for (int ph = 0; ph < S; ++ph) {
+        if (it + ph < nkb) {
+          const bool more = it + ph + S - 1 < nkb;
+          __builtin_amdgcn_s_barrier();
+          load_frags(ph);
+          if (more) issue((ph + S - 1) % S);
+          if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_s_setprio(1);
+          mfma_all();
+          __builtin_amdgcn_s_setprio(0);
+        }
+      }
+    }
+    if (kgrp == 0) __builtin_amdgcn_s_barrier();
+  } else {
   if constexpr (S == 1) {
     // single K tile (K = 64: the 64 -> 256 convolutions of layer1): no ring, half the LDS, twice the resident workgroups -
     // these problems are pure HBM streams and only occupancy hides their latency
@@ -271,6 +327,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       __builtin_amdgcn_s_barrier();
       compute(ph);
     }
+  }
   __builtin_amdgcn_s_barrier();
 
   // ---- epilogue through LDS (identical to igemm2)
@@ -357,10 +414,10 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   }
 }
 
-template <int BM, int BN, int S, int NW = 4>
+template <int BM, int BN, int S, int NW = 4, int PP = 0>
 __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int bx) {
-  if (p.conv) igemm3_impl<BM, BN, S, NW, true>(p, a_bytes, b_bytes, bx);      // uniform branch: two specialised programs
-  else igemm3_impl<BM, BN, S, NW, false>(p, a_bytes, b_bytes, bx);
+  if (p.conv) igemm3_impl<BM, BN, S, NW, true, PP>(p, a_bytes, b_bytes, bx);      // uniform branch: two specialised programs
+  else igemm3_impl<BM, BN, S, NW, false, PP>(p, a_bytes, b_bytes, bx);
 }
 
 template <int BM, int BN, int S>
@@ -368,18 +425,18 @@ __global__ __launch_bounds__(256) void igemm3_kernel(const SedtIgemm p, const un
   igemm3_body<BM, BN, S>(p, a_bytes, b_bytes, blockIdx.x);
 }
 
-template <int BM, int BN, int S>
+template <int BM, int BN, int S, int PP = 0>
 __global__ __launch_bounds__(512) void igemm3_w8_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes) {
-  igemm3_body<BM, BN, S, 8>(p, a_bytes, b_bytes, blockIdx.x);
+  igemm3_body<BM, BN, S, 8, PP>(p, a_bytes, b_bytes, blockIdx.x);
 }
 
-template <int BM, int BN, int S>
+template <int BM, int BN, int S, int PP = 0>
 static int launch3_w8(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
   constexpr size_t ring = (size_t)S * (BM + BN) * ROWB;
   constexpr size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);
   constexpr size_t lds = ring > ctile ? ring : ctile;
   static bool attr_set = false;
-  auto kern = igemm3_w8_kernel<BM, BN, S>;
+  auto kern = igemm3_w8_kernel<BM, BN, S, PP>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
@@ -575,6 +632,21 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
   }
   // measured (tools/tune_igemm.py, SEDT_IGEMM3_NW): the 64x128 tile runs 2-14 % faster with 8 waves (two groups splitting the
   // k16 steps) at every shape that selects it; 128x128 / 128x64 with 8 waves are experiment-only (SEDT_IGEMM3_NW=8)
+  static int pp_env = -1;
+  if (pp_env < 0) {
+    const char* e = getenv("SEDT_IGEMM3_PP");
+    pp_env = e ? atoi(e) : 1;
+  }
+  if (!plan3.on && co_group == nullptr && nw_env != 4 && pp_env) {
+#define SEDT_PP(BM_, BN_)                                                                                   \
+  if (bm == BM_ && bn == BN_) {                                                                             \
+    return S >= 3 ? launch3_w8<BM_, BN_, 3, 1>(p, a_bytes, b_bytes, st) : launch3_w8<BM_, BN_, 2, 1>(p, a_bytes, b_bytes, st); \
+  }
+    SEDT_PP(64, 128)
+    SEDT_PP(128, 128)
+    SEDT_PP(128, 64)
+#undef SEDT_PP
+  }
   if (!plan3.on && co_group == nullptr && nw_env != 4) {
     if (bm == 64 && bn == 128) return S >= 3 ? launch3_w8<64, 128, 3>(p, a_bytes, b_bytes, st) : launch3_w8<64, 128, 2>(p, a_bytes, b_bytes, st);
     if (nw_env == 8 && bm == 128 && bn == 128)

@@ -447,3 +447,32 @@ def test_skinny_linear_fwd_bwd(ops, dt, M, N, K, act):
     y2 = ops.skinny_linear_fwd(dt, xd, w.cuda(), b.cuda(), ACT, out_f32=False)
     assert y2.dtype == TD[dt]
     close(y2, yr.detach(), dt)
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+def test_pack_plan_layouts(dt):
+    """one-launch weight packing (vectorized and scalar tiles) vs torch permutes: forward [Co][taps][Ci], dgrad [Ci][taps][Co] * bn scale"""
+    from sound_event_detection_transformer_amd.packing import PackPlan
+    shapes = [(64, 64, 1), (256, 64, 1), (72, 136, 1), (64, 64, 3), (40, 96, 3), (512, 512, 3), (11, 256, 1), (256, 20, 1), (24, 12, 3)]
+    convs, linears = [], []
+    for co, ci, k in shapes:
+        w = torch.nn.Parameter(randn(co, ci, k, k).cuda())
+        bn = tuple(t.cuda() for t in (torch.rand(co, generator=G) + 0.5, randn(co), randn(co), torch.rand(co, generator=G) + 0.5))
+        convs.append((w, bn))
+    for n, k in [(256, 256), (2048, 256), (10, 256), (256, 2048)]:
+        linears.append(torch.nn.Parameter(randn(n, k).cuda()))
+    plan = PackPlan(dt, torch.device('cuda'), convs, linears)
+    with plan:
+        for w, bn in convs:
+            wf, wb, sc, bi = plan.table[w.data_ptr()]
+            co, ci, k = w.shape[0], w.shape[1], w.shape[2]
+            scale = (bn[0] * torch.rsqrt(bn[3] + 1e-5)).cpu()
+            ref_f = w.detach().cpu().permute(0, 2, 3, 1).reshape(co, k * k * ci)
+            ref_b = (w.detach().cpu() * scale[:, None, None, None]).permute(1, 2, 3, 0).reshape(ci, k * k * co)
+            close(wf, rnd(ref_f, dt), dt, f32_tol=1e-6, bf16_tol=1e-6)
+            close(wb, ref_b, dt, f32_tol=1e-6, bf16_tol=8e-3)
+            close(sc, scale, F32, f32_tol=1e-5)
+        for w in linears:
+            wf, wb, _, _ = plan.table[w.data_ptr()]
+            close(wf, rnd(w.detach().cpu(), dt), dt, f32_tol=1e-6, bf16_tol=1e-6)
+            close(wb, w.detach().cpu().t(), dt, f32_tol=1e-6, bf16_tol=8e-3)
