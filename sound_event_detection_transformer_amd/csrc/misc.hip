@@ -86,30 +86,53 @@ __global__ __launch_bounds__(256) void multi_wgrad_reduce_kernel(const ReduceJob
   const long per = (long)J.R * J.taps * J.Ci;
   if (J.colsum_slab) {
     // column sums over the split slices: the fused bias gradient of a wgrad, or (per == 0, splitk = partial rows) the
-    // gamma/beta reduction of a LayerNorm backward riding in the same launch
-    const long e = (long)blk * 256 + threadIdx.x;
-    if (e < J.R) {
+    // gamma/beta reduction of a LayerNorm backward riding in the same launch.  The first ceil(R / 64) blocks of the job take
+    // 64 columns each; the slices are dealt to 4 thread groups x 4 independent sums (a LayerNorm job has up to 512 slices:
+    // one thread walking them alone was the tail of the whole launch), combined in a fixed order.
+    __shared__ float csum[4][64];
+    const int col = blk * 64 + (threadIdx.x & 63), zg = threadIdx.x >> 6;
+    if (blk * 64 < J.R) {
       float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-      int z = 0;
-      for (; z + 4 <= J.splitk; z += 4) {
-        b0 += J.colsum_slab[(long)z * J.R + e];
-        b1 += J.colsum_slab[(long)(z + 1) * J.R + e];
-        b2 += J.colsum_slab[(long)(z + 2) * J.R + e];
-        b3 += J.colsum_slab[(long)(z + 3) * J.R + e];
+      if (col < J.R) {
+        const float* cp = J.colsum_slab + col;
+        int z = zg;
+        for (; z + 12 < J.splitk; z += 16) {
+          b0 += cp[(long)z * J.R];
+          b1 += cp[(long)(z + 4) * J.R];
+          b2 += cp[(long)(z + 8) * J.R];
+          b3 += cp[(long)(z + 12) * J.R];
+        }
+        for (; z < J.splitk; z += 4) b0 += cp[(long)z * J.R];
       }
-      for (; z < J.splitk; ++z) b0 += J.colsum_slab[(long)z * J.R + e];
-      J.bias_out[e] = (b0 + b1) + (b2 + b3);
+      csum[zg][threadIdx.x & 63] = (b0 + b1) + (b2 + b3);
+      __syncthreads();
+      if (zg == 0 && col < J.R) J.bias_out[col] = (csum[0][col & 63] + csum[1][col & 63]) + (csum[2][col & 63] + csum[3][col & 63]);
     }
   }
   const int mode = reduce_job_mode(J);
   if (mode == 0) {
     const long e = ((long)blk * 256 + threadIdx.x) * 4;
     if (e >= per) return;
-    float4 s = *reinterpret_cast<const float4*>(J.slab + e);
-    for (int z = 1; z < J.splitk; ++z) {
-      const float4 a = *reinterpret_cast<const float4*>(J.slab + (long)z * per + e);
-      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    // four independent partial sums: the slices are read as parallel streams, not as one dependent chain of loads
+    const float* sp = J.slab + e;
+    float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, s3 = s1;
+    int z = 1;
+    for (; z + 4 <= J.splitk; z += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(sp + (long)z * per);
+      const float4 b = *reinterpret_cast<const float4*>(sp + (long)(z + 1) * per);
+      const float4 c = *reinterpret_cast<const float4*>(sp + (long)(z + 2) * per);
+      const float4 d = *reinterpret_cast<const float4*>(sp + (long)(z + 3) * per);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+      s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+      s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+      s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
     }
+    for (; z < J.splitk; ++z) {
+      const float4 a = *reinterpret_cast<const float4*>(sp + (long)z * per);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+    float4 s = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                           (s0.w + s1.w) + (s2.w + s3.w));
     if (J.rowscale) {
       const float sc = J.rowscale[e / J.Ci];
       s.x *= sc; s.y *= sc; s.z *= sc; s.w *= sc;
@@ -122,19 +145,34 @@ __global__ __launch_bounds__(256) void multi_wgrad_reduce_kernel(const ReduceJob
     const int n = J.taps * 64;
     const float sc = J.rowscale ? J.rowscale[r] : 1.f;
     const long rbase = (long)r * J.taps * J.Ci;
-    for (int i = threadIdx.x; i < n; i += 256) {
-      const int tap = i >> 6, c = i & 63;
-      const long e = rbase + (long)tap * J.Ci + c0 + c;
-      float v = 0.f;
-      for (int z = 0; z < J.splitk; ++z) v += J.slab[(long)z * per + e];
-      tile[tap][c] = v * sc;
+    for (int i = threadIdx.x; i < n / 4; i += 256) {          // float4 along the channel run of one tap, two slice streams
+      const int tap = i >> 4, c = (i & 15) * 4;
+      const float* sp = J.slab + rbase + (long)tap * J.Ci + c0 + c;
+      float4 v = *reinterpret_cast<const float4*>(sp), u = make_float4(0.f, 0.f, 0.f, 0.f);
+      int z = 1;
+      for (; z + 2 <= J.splitk; z += 2) {
+        const float4 a = *reinterpret_cast<const float4*>(sp + (long)z * per);
+        const float4 b = *reinterpret_cast<const float4*>(sp + (long)(z + 1) * per);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        u.x += b.x; u.y += b.y; u.z += b.z; u.w += b.w;
+      }
+      if (z < J.splitk) {
+        const float4 a = *reinterpret_cast<const float4*>(sp + (long)z * per);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      tile[tap][c] = (v.x + u.x) * sc; tile[tap][c + 1] = (v.y + u.y) * sc;
+      tile[tap][c + 2] = (v.z + u.z) * sc; tile[tap][c + 3] = (v.w + u.w) * sc;
     }
     __syncthreads();
-    float* o = J.out + ((long)r * J.Ci + c0) * J.taps;
+    float* o = J.out + ((long)r * J.Ci + c0) * J.taps;      // 64 * taps contiguous floats, 16-byte aligned (64 * taps * 4 bytes per chunk)
     if (J.taps == 9) {                               // compile-time divisor for the 3x3 case
-      for (int i = threadIdx.x; i < n; i += 256) {
-        const int c = i / 9, tap = i - c * 9;
-        o[i] = tile[tap][c];
+      for (int i = threadIdx.x; i < n / 4; i += 256) {
+        float4 q;
+        { const int k = 4 * i, c = k / 9, tap = k - c * 9; q.x = tile[tap][c]; }
+        { const int k = 4 * i + 1, c = k / 9, tap = k - c * 9; q.y = tile[tap][c]; }
+        { const int k = 4 * i + 2, c = k / 9, tap = k - c * 9; q.z = tile[tap][c]; }
+        { const int k = 4 * i + 3, c = k / 9, tap = k - c * 9; q.w = tile[tap][c]; }
+        *reinterpret_cast<float4*>(o + 4 * i) = q;
       }
     } else {
       for (int i = threadIdx.x; i < n; i += 256) {
@@ -1006,7 +1044,7 @@ extern "C" int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, voi
     SEDT_REQUIRE((jobs[i].colsum_slab == nullptr) == (jobs[i].bias_out == nullptr), "multi_wgrad_reduce: job %d colsum/bias", i);
     a.j[i].blk0 = blk;
     int nb = reduce_job_blocks(jobs[i]);
-    if (jobs[i].colsum_slab) nb = std::max(nb, (jobs[i].R + 255) / 256);   // the bias sums ride on the first blocks
+    if (jobs[i].colsum_slab) nb = std::max(nb, (jobs[i].R + 63) / 64);   // the bias sums ride on the first blocks
     blk += nb;
   }
   hipLaunchKernelGGL(multi_wgrad_reduce_kernel, dim3(blk), dim3(256), 0, S(stream), a);
