@@ -566,6 +566,9 @@ extern "C" int sedt_igemm_splitk(int M, int N, int K, int dtype) {
   int maxs = nkb / 4 > 1 ? nkb / 4 : 1;
   if (s > maxs) s = maxs;
   if (s > 128) s = 128;
+  // one or two output tiles under a very long K (the stem: 64 x 128 over 512 k pixels) is a pure HBM stream: only many
+  // resident workgroups hide its latency, and its slabs are tiny
+  if (tiles <= 2) s = maxs < 512 ? maxs : 512;
   if (s < 1) s = 1;
   // K-slice mapping (bf16 grouped launches, csrc/wgrad3_body.h): with a split factor that is a multiple of 8, XCD x works
   // on K slice x of EVERY output tile, so each private 4 MB L2 fetches 1/8 of both operands instead of one operand in

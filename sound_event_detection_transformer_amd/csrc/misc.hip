@@ -32,26 +32,6 @@ static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); 
 static inline unsigned nblk(long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
 
 // ------------------------------------------------------------------ wgrad split-K reduce
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, int R, int taps, int Ci,
-                                    const float* __restrict__ rowscale, float* __restrict__ out,
-                                    const float* __restrict__ colsum_slab, float* __restrict__ bias_out) {
-  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long per = (long)R * taps * Ci;
-  if (colsum_slab && e < R) {
-    float b = 0.f;
-    for (int z = 0; z < splitk; ++z) b += colsum_slab[(long)z * R + e];
-    bias_out[e] = b;
-  }
-  if (e >= per) return;
-  int c = (int)(e % Ci);
-  long rt = e / Ci;
-  int tap = (int)(rt % taps);
-  int r = (int)(rt / taps);
-  float s = 0.f;
-  for (int z = 0; z < splitk; ++z) s += slab[(long)z * per + e];
-  if (rowscale) s *= rowscale[r];
-  out[((long)r * Ci + c) * taps + tap] = s;
-}
 
 struct ReduceJobs {
   int n;
@@ -61,8 +41,11 @@ struct ReduceJobs {
 // blocks of one job: taps == 1 (and 4 | Ci): 1024 consecutive elements per block, float4 per thread;
 // taps > 1 and 64 | Ci: one (row, 64-channel chunk) with all its taps per block - the [tap][c] -> [c][tap] transposition
 // goes through LDS so that slab reads and gradient writes are both contiguous runs; otherwise 256 scalar elements.
+// (taps == 1 with many slices - a tiny output under a very long K, e.g. the stem: mode 3 = 256 elements per block, the
+// slices dealt to 4 thread groups.)  The wide modes need 16-byte aligned slabs / outputs.
 __host__ __device__ inline int reduce_job_mode(const SedtReduceJob& J) {
-  if (J.taps == 1 && (J.Ci & 3) == 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(J.slab) | reinterpret_cast<uintptr_t>(J.out)) & 15) return 2;
+  if (J.taps == 1 && (J.Ci & 3) == 0) return J.splitk >= 16 ? 3 : 0;
   if (J.taps > 1 && J.taps <= 9 && (J.Ci & 63) == 0) return 1;
   return 2;
 }
@@ -71,7 +54,7 @@ __host__ __device__ inline int reduce_job_blocks(const SedtReduceJob& J) {
   const int mode = reduce_job_mode(J);
   if (mode == 0) return (int)((per + 1023) / 1024);
   if (mode == 1) return J.R * (J.Ci / 64);
-  return (int)((per + 255) / 256);
+  return (int)((per + 255) / 256);       // modes 2 and 3
 }
 
 __global__ __launch_bounds__(256) void multi_wgrad_reduce_kernel(const ReduceJobs jobs) {
@@ -110,7 +93,37 @@ __global__ __launch_bounds__(256) void multi_wgrad_reduce_kernel(const ReduceJob
     }
   }
   const int mode = reduce_job_mode(J);
-  if (mode == 0) {
+  if (mode == 3) {
+    __shared__ float4 zsum[4][64];
+    const int q = threadIdx.x & 63, zg = threadIdx.x >> 6;
+    const long e = ((long)blk * 64 + q) * 4;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (e < per) {
+      const float* sp = J.slab + e;
+      int z = zg;
+      for (; z + 4 < J.splitk; z += 8) {
+        const float4 a = *reinterpret_cast<const float4*>(sp + (long)z * per);
+        const float4 b = *reinterpret_cast<const float4*>(sp + (long)(z + 4) * per);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+      }
+      if (z < J.splitk) {
+        const float4 a = *reinterpret_cast<const float4*>(sp + (long)z * per);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+      }
+    }
+    zsum[zg][q] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (zg == 0 && e < per) {
+      const float4 a = zsum[0][q], b = zsum[1][q], c = zsum[2][q], d = zsum[3][q];
+      float4 s = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+      if (J.rowscale) {
+        const float sc = J.rowscale[e / J.Ci];
+        s.x *= sc; s.y *= sc; s.z *= sc; s.w *= sc;
+      }
+      *reinterpret_cast<float4*>(J.out + e) = s;
+    }
+  } else if (mode == 0) {
     const long e = ((long)blk * 256 + threadIdx.x) * 4;
     if (e >= per) return;
     // four independent partial sums: the slices are read as parallel streams, not as one dependent chain of loads
@@ -774,14 +787,16 @@ extern "C" int sedt_version(void) { return 1; }
   else if ((dtype) == SEDT_BF16) { CALL_BF16; }                \
   else { set_error("unsupported dtype %d", (int)(dtype)); return 1; }
 
+extern "C" int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, void* stream);
+
 extern "C" int sedt_wgrad_reduce_bias(const float* slab, int splitk, int R, int taps, int Ci, const float* rowscale,
                                       float* out, const float* colsum_slab, float* bias_out, void* stream) {
   SEDT_REQUIRE(slab && out && splitk >= 1, "wgrad_reduce: bad args");
   SEDT_REQUIRE((colsum_slab == nullptr) == (bias_out == nullptr), "wgrad_reduce: colsum_slab and bias_out go together");
-  long n = (long)R * taps * Ci;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(n)), dim3(256), 0, S(stream), slab, splitk, R, taps, Ci, rowscale, out,
-                     colsum_slab, bias_out);
-  return check_launch("wgrad_reduce");
+  SedtReduceJob j = {};
+  j.slab = slab; j.out = out; j.rowscale = rowscale; j.colsum_slab = colsum_slab; j.bias_out = bias_out;
+  j.splitk = splitk; j.R = R; j.taps = taps; j.Ci = Ci;
+  return sedt_multi_wgrad_reduce(&j, 1, stream);      // one job of the grouped kernel (vector / LDS-transposing paths)
 }
 
 extern "C" int sedt_wgrad_reduce(const float* slab, int splitk, int R, int taps, int Ci, const float* rowscale,
