@@ -170,6 +170,13 @@ int sedt_layernorm_bwd(const void* dy, const void* dy2, const void* x, const flo
                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* scratch,
                        size_t scratch_bytes, int rows, int D, int dtype, void* stream);
 size_t sedt_layernorm_bwd_scratch(int rows, int D);
+/* same, with a second output dx_drop = dropout-backward of dx under (drop_p, seed): the gradient entering the sub-layer
+ * whose dropped output fed this LayerNorm (post-norm layers, reference transformer.py:186-189) - saves the separate
+ * sedt_dropout_grad launch.  dx_drop may be NULL. */
+int sedt_layernorm_bwd_drop(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean,
+                            const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* scratch,
+                            size_t scratch_bytes, int rows, int D, void* dx_drop, float drop_p, uint32_t seed,
+                            const uint32_t* seed_ptr, int dtype, void* stream);
 /* second stage of sedt_layernorm_bwd on its own (call sedt_layernorm_bwd with dgamma = dbeta = NULL first): reduces the
  * per-workgroup partial sums in `scratch` to dgamma / dbeta.  Lets a caller move the parameter-gradient half off the
  * critical path of the backward pass (another stream). */

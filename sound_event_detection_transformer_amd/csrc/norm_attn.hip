@@ -52,7 +52,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const T* __restrict__ dres, T* __restrict__ dx,
-                                                     float* __restrict__ partial, int rows) {
+                                                     float* __restrict__ partial, int rows, T* __restrict__ dx_drop,
+                                                     uint32_t thresh, float inv_keep, uint32_t seed,
+                                                     const uint32_t* __restrict__ seed_ptr) {
   constexpr int D = VPT * 64;
   typedef VecT<T, VPT> V;                       // one 8/16-byte access per lane and tensor
   __shared__ float red[4][2 * D];
@@ -92,6 +94,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       out.v[i] = (T)o;
     }
     *reinterpret_cast<V*>(dx + base) = out;
+    if (dx_drop) {
+      // second output: dx through the dropout mask of the sub-layer whose output fed this LayerNorm (element index =
+      // row * D + column, the convention of the GEMM epilogue that dropped it and of dropout_grad_kernel)
+      const uint32_t sd = eff_seed(seed, seed_ptr);
+      V od;
+#pragma unroll
+      for (int i = 0; i < VPT; ++i)
+        od.v[i] = drop_keep(sd, (uint64_t)(base + i), thresh) ? (T)((float)out.v[i] * inv_keep) : (T)0.f;
+      *reinterpret_cast<V*>(dx_drop + base) = od;
+    }
   }
 #pragma unroll
   for (int i = 0; i < VPT; ++i) { red[wave][lane * VPT + i] = dg[i]; red[wave][D + lane * VPT + i] = db[i]; }
@@ -405,14 +417,30 @@ extern "C" int sedt_layernorm_fwd(const void* x, const float* gamma, const float
 
 extern "C" size_t sedt_layernorm_bwd_scratch(int rows, int D) { return (size_t)ln_bwd_blocks(rows) * 2 * D * sizeof(float); }
 
+extern "C" int sedt_layernorm_bwd_drop(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean,
+                                       const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                       float* scratch, size_t scratch_bytes, int rows, int D, void* dx_drop, float drop_p,
+                                       uint32_t seed, const uint32_t* seed_ptr, int dtype, void* stream);
+
 extern "C" int sedt_layernorm_bwd(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean,
                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* scratch,
                                   size_t scratch_bytes, int rows, int D, int dtype, void* stream) {
+  return sedt_layernorm_bwd_drop(dy, dy2, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, scratch_bytes, rows, D, nullptr,
+                                 0.f, 0u, nullptr, dtype, stream);
+}
+
+extern "C" int sedt_layernorm_bwd_drop(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean,
+                                       const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                       float* scratch, size_t scratch_bytes, int rows, int D, void* dx_drop, float drop_p,
+                                       uint32_t seed, const uint32_t* seed_ptr, int dtype, void* stream) {
   SEDT_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
+  SEDT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "layernorm_bwd: drop_p out of range");
+  const uint32_t th = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+  const float ik = 1.f / (1.f - drop_p);
   SEDT_REQUIRE(scratch && scratch_bytes >= sedt_layernorm_bwd_scratch(rows, D), "layernorm_bwd: scratch too small");
   int nb = ln_bwd_blocks(rows);
   dim3 grid(nb), block(256);
-#define A_(T) grid, block, 0, S(stream), (const T*)dy, (const T*)dy2, (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, scratch, rows
+#define A_(T) grid, block, 0, S(stream), (const T*)dy, (const T*)dy2, (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, scratch, rows, (T*)dx_drop, th, ik, seed, seed_ptr
   if (dtype == SEDT_F32 && D == 256) hipLaunchKernelGGL((ln_bwd_kernel<float, 4>), A_(float));
   else if (dtype == SEDT_F32 && D == 512) hipLaunchKernelGGL((ln_bwd_kernel<float, 8>), A_(float));
   else if (dtype == SEDT_BF16 && D == 256) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 4>), A_(bf16_t));

@@ -168,14 +168,24 @@ def _mha_fwd(dt, q_in, k_in, v_in, same_qk, w_in, b_in, w_out, b_out, res, B, H,
     return out, saved
 
 
-def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, batch=None):
-    """g_out = grad wrt the block output (the residual branch is the caller's business).
+def _drop_args(s, device):
+    """(p, seed, seed_ptr) of the dropout on a block's output, for ops.layernorm_bwd(drop=...)"""
+    p = s['p']
+    return (p, s['seeds'][1], runtime.seed_ptr(device) if p > 0 else None)
+
+
+def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, batch=None, g_dropped=None):
+    """g_out = grad wrt the block output (the residual branch is the caller's business); g_dropped = the same gradient
+    already through the output dropout (ops.layernorm_bwd(drop=...)).
     returns g_q_in, g_k_in, g_v_in, d_in_proj_weight, d_in_proj_bias, d_out_w, d_out_b"""
     B, H, Lq, Lk = s['dims']
     E = w_in.shape[1]
     p = s['p']
     sp = runtime.seed_ptr(g_out.device) if p > 0 else None
-    g1 = ops.dropout_grad(dt, g_out, p, s['seeds'][1], sp) if p > 0 else g_out
+    if g_dropped is not None:
+        g1 = g_dropped
+    else:
+        g1 = ops.dropout_grad(dt, g_out, p, s['seeds'][1], sp) if p > 0 else g_out
     d_bo = torch.empty((E,), device=g_out.device, dtype=torch.float32)
     d_wo = ops.linear_wgrad(dt, g1, s['ctxv'], bias_out=d_bo, batch=batch)
     g_ctx = ops.linear(dt, g1, s['wb_o'])
@@ -223,10 +233,13 @@ def _ffn_fwd(dt, x_in, w1, b1, w2, b2, res, p, seeds, train=True):
     return out, dict(x_in=x_in, h=h, p=p, seeds=seeds, wb1=wb1, wb2=wb2)
 
 
-def _ffn_bwd(dt, s, g_out, w1, w2, res_for_gx=None, batch=None):
+def _ffn_bwd(dt, s, g_out, w1, w2, res_for_gx=None, batch=None, g_dropped=None):
     """returns g_x_in (+ res_for_gx), dW1, db1, dW2, db2"""
     p = s['p']
-    g2 = ops.dropout_grad(dt, g_out, p, s['seeds'][1], runtime.seed_ptr(g_out.device)) if p > 0 else g_out
+    if g_dropped is not None:
+        g2 = g_dropped
+    else:
+        g2 = ops.dropout_grad(dt, g_out, p, s['seeds'][1], runtime.seed_ptr(g_out.device)) if p > 0 else g_out
     d_b2 = torch.empty((g2.shape[1],), device=g2.device, dtype=torch.float32)
     d_w2 = ops.linear_wgrad(dt, g2, s['h'], bias_out=d_b2, batch=batch)
     # d_hidden = (g2 @ W2) * [h > 0] / (1-p): h = drop(relu(.)) is positive exactly where kept and active
@@ -287,10 +300,13 @@ class EncoderLayerFn(Function):
             # LN1 fed xn (to V) and xn+pos (to Q,K): both gradients land on xn
             gx, d_g1, d_be1 = ops.layernorm_bwd(dt, g_v, sv['x'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gx1, batch=rb)
         else:
-            g_t2, d_g2, d_be2 = ops.layernorm_bwd(dt, gx2, sv['t2'], g2, sv['m2'], sv['r2'], batch=rb)
-            g_x1, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], g_t2, w1, w2, res_for_gx=g_t2, batch=rb)
-            g_t, d_g1, d_be1 = ops.layernorm_bwd(dt, g_x1, sv['t'], g1, sv['m1'], sv['r1'], batch=rb)
-            g_qk, _, g_v, d_win, d_bin, d_wo, d_bo = _mha_bwd(dt, sv['mha'], g_t, w_in, w_o, batch=rb)
+            dev = gx2.device
+            g_t2, d_g2, d_be2, g_t2d = ops.layernorm_bwd(dt, gx2, sv['t2'], g2, sv['m2'], sv['r2'], batch=rb,
+                                                         drop=_drop_args(sv['ffn'], dev))
+            g_x1, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], g_t2, w1, w2, res_for_gx=g_t2, batch=rb, g_dropped=g_t2d)
+            g_t, d_g1, d_be1, g_td = ops.layernorm_bwd(dt, g_x1, sv['t'], g1, sv['m1'], sv['r1'], batch=rb,
+                                                       drop=_drop_args(sv['mha'], dev))
+            g_qk, _, g_v, d_win, d_bin, d_wo, d_bo = _mha_bwd(dt, sv['mha'], g_t, w_in, w_o, batch=rb, g_dropped=g_td)
             gx = ops.add(dt, ops.add(dt, g_qk, g_v), g_t)
         rb.flush()
         ctx.sv = None
@@ -353,15 +369,19 @@ class DecoderLayerFn(Function):
             gtgt, d_g1, d_be1 = ops.layernorm_bwd(dt, g_vs, sv['tgt'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gt1, batch=rb)
             g_qpos = ops.add(dt, g_qpos, g_qk)
         else:
-            g_f, d_g3, d_be3 = ops.layernorm_bwd(dt, gt3, sv['f'], g3, sv['m3'], sv['r3'], batch=rb)
-            g_t2, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], g_f, w1, w2, res_for_gx=g_f, batch=rb)
-            g_c, d_g2, d_be2 = ops.layernorm_bwd(dt, g_t2, sv['c'], g2, sv['m2'], sv['r2'], batch=rb)
-            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], g_c, cw_in, cw_o, batch=rb)
+            dev = gt3.device
+            g_f, d_g3, d_be3, g_fd = ops.layernorm_bwd(dt, gt3, sv['f'], g3, sv['m3'], sv['r3'], batch=rb,
+                                                       drop=_drop_args(sv['ffn'], dev))
+            g_t2, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], g_f, w1, w2, res_for_gx=g_f, batch=rb, g_dropped=g_fd)
+            g_c, d_g2, d_be2, g_cd = ops.layernorm_bwd(dt, g_t2, sv['c'], g2, sv['m2'], sv['r2'], batch=rb,
+                                                       drop=_drop_args(sv['ca'], dev))
+            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], g_c, cw_in, cw_o, batch=rb, g_dropped=g_cd)
             g_t1 = ops.add(dt, g_q, g_c)                     # query path + residual
             g_qpos = g_q
             g_mem_pos, g_mem = g_k, g_v
-            g_a, d_g1, d_be1 = ops.layernorm_bwd(dt, g_t1, sv['a'], g1, sv['m1'], sv['r1'], batch=rb)
-            g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], g_a, sw_in, sw_o, batch=rb)
+            g_a, d_g1, d_be1, g_ad = ops.layernorm_bwd(dt, g_t1, sv['a'], g1, sv['m1'], sv['r1'], batch=rb,
+                                                       drop=_drop_args(sv['sa'], dev))
+            g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], g_a, sw_in, sw_o, batch=rb, g_dropped=g_ad)
             gtgt = ops.add(dt, ops.add(dt, g_qk, g_vs), g_a)
             g_qpos = ops.add(dt, g_qpos, g_qk)
         rb.flush()

@@ -6,6 +6,7 @@ allocator.  No arithmetic happens in torch here; torch is device memory + stream
 """
 import ctypes as C
 
+import os
 import torch
 
 from . import lib as L
@@ -453,9 +454,11 @@ def layernorm_fwd(dtype, x, gamma, beta, add_t=None):
     return y, y2, mean, rstd
 
 
-def layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2=None, dres=None, want_param_grads=True, batch=None):
-    """batch (a ReduceBatch inside runtime.async_wgrad): the gamma/beta reduction - which only feeds the optimizer - is
-    deferred to batch.flush() and runs with the layer's weight gradients on the side stream"""
+def layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2=None, dres=None, want_param_grads=True, batch=None, drop=None):
+    """batch (a ReduceBatch): the gamma/beta reduction - which only feeds the optimizer - is deferred to batch.flush() and
+    rides in the layer's split-K reduction launch.
+    drop = (p, seed, seed_ptr): also returns dx passed through that dropout mask (the gradient entering the sub-layer whose
+    dropped output fed this LayerNorm) as a 4th result - one launch instead of layernorm_bwd + dropout_grad"""
     lib = L.load()
     rows, D = x.shape
     dx = torch.empty_like(x)
@@ -463,17 +466,24 @@ def layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2=None, dres=None, want_par
     db = torch.empty((D,), device=x.device, dtype=torch.float32) if want_param_grads else None
     nb = lib.sedt_layernorm_bwd_scratch(rows, D)
     scratch = torch.empty((nb // 4,), device=x.device, dtype=torch.float32)
-    from . import runtime
-    if want_param_grads and batch is not None:
-        # dx now; the gamma/beta reduction of the per-workgroup partials only feeds the optimizer: it rides in the layer's
-        # split-K reduction launch (batch.flush()) as one more job
-        L.check(lib.sedt_layernorm_bwd(_p(dy), _p(dy2), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), None, None,
-                                       _p(scratch), nb, rows, D, dtype, L.stream_ptr()), 'layernorm_bwd')
+    dxd, p_, seed_, sp_ = None, 0.0, 0, None
+    if drop is not None and drop[0] > 0:
+        p_, seed_, sp_ = drop
+        if os.environ.get('SEDT_LN_DROP_FUSE', '1') == '0':        # A/B switch: separate dropout_grad launch
+            dx, dg, db = layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2, dres, want_param_grads, batch)
+            return dx, dg, db, dropout_grad(dtype, dx, p_, seed_, sp_)
+        dxd = torch.empty_like(x)
+    deferred = want_param_grads and batch is not None
+    L.check(lib.sedt_layernorm_bwd_drop(_p(dy), _p(dy2), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
+                                        None if deferred else _p(dg), None if deferred else _p(db), _p(scratch), nb, rows, D,
+                                        _p(dxd), p_, seed_ & 0xffffffff, _p(sp_), dtype, L.stream_ptr()), 'layernorm_bwd')
+    if deferred:
+        # the gamma/beta reduction of the per-workgroup partials rides in batch.flush() as one more job
         dgb = torch.empty((2 * D,), device=x.device, dtype=torch.float32)
         batch.add_colsum(scratch, nb // (2 * D * 4), 2 * D, dgb)
-        return dx, dgb[:D], dgb[D:]
-    L.check(lib.sedt_layernorm_bwd(_p(dy), _p(dy2), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dg), _p(db),
-                                   _p(scratch), nb, rows, D, dtype, L.stream_ptr()), 'layernorm_bwd')
+        dg, db = dgb[:D], dgb[D:]
+    if drop is not None:
+        return dx, dg, db, (dxd if dxd is not None else dx)
     return dx, dg, db
 
 

@@ -476,3 +476,21 @@ def test_pack_plan_layouts(dt):
             wf, wb, _, _ = plan.table[w.data_ptr()]
             close(wf, rnd(w.detach().cpu(), dt), dt, f32_tol=1e-6, bf16_tol=1e-6)
             close(wb, w.detach().cpu().t(), dt, f32_tol=1e-6, bf16_tol=8e-3)
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+def test_layernorm_bwd_with_fused_dropout_grad(ops, dt):
+    """second output of layernorm_bwd(drop=...) == dropout_grad(dx) with the same (p, seed): bit-identical"""
+    rows, D = 700, 256
+    x, dy, gam = randn(rows, D), randn(rows, D), torch.rand(D, generator=G) + 0.5
+    xd, dyd = dev(x, dt), dev(dy, dt)
+    y, _, mean, rstd = ops.layernorm_fwd(dt, xd, gam.cuda(), torch.zeros(D).cuda())
+    dx0, dg0, db0 = ops.layernorm_bwd(dt, dyd, xd, gam.cuda(), mean, rstd)
+    dx, dg, db, dxd = ops.layernorm_bwd(dt, dyd, xd, gam.cuda(), mean, rstd, drop=(0.1, 1234, None))
+    assert torch.equal(dx, dx0) and torch.equal(dg, dg0) and torch.equal(db, db0)
+    ref = ops.dropout_grad(dt, dx, 0.1, 1234)
+    assert torch.equal(dxd, ref)
+    kept = (dxd != 0).float().mean().item()
+    assert 0.85 < kept < 0.95
+    # p = 0: the extra result is dx itself
+    assert ops.layernorm_bwd(dt, dyd, xd, gam.cuda(), mean, rstd, drop=(0.0, 0, None))[3] is not None
