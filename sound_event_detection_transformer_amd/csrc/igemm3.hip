@@ -623,7 +623,9 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
     // re-tuned after the 8-wave / lean-bookkeeping changes (full step, SEDT_IGEMM3_STAGES sweep: 2 everywhere 8881,
     // old rule "3 when K >= 1024 and <= 3 workgroups per CU" 9447, 3 everywhere 9590, 4 9457 clips/s): two tiles in flight
     // pay at every depth that has them
-    S = p.K >= 3 * BK2 ? 3 : 2;
+    // (per-shape sweep of the step's launches, bench.py --dump-igemm: K = 256 problems and the N = 64, K = 576 layer1 3x3
+    // convolution - few K tiles, fixed per-workgroup costs dominate - prefer the occupancy of the 2-stage ring)
+    S = (p.K >= 5 * BK2 && !(p.N <= 64 && p.K <= 9 * BK2)) ? 3 : 2;
   }
   static int nw_env = -1;
   if (nw_env < 0) {

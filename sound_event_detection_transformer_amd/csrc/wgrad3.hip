@@ -51,6 +51,9 @@ static bool wgrad3_conv_ok(const SedtIgemm& p) {
 }
 
 int wgrad2_envelope(const SedtIgemm& p, long* a_bytes, long* b_bytes);   // wgrad2.hip
+bool wgrad4_ok(const SedtIgemm& p);                                        // wgrad4.hip: 128x128 ping-pong kernel
+int launch_wgrad4(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st);
+int launch_wgrad4_group(WgradGroup& g, hipStream_t st);
 
 // 0 = launched, -1 = some problem is outside the lean kernel's envelope (caller launches them one by one)
 int wgrad3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
@@ -80,23 +83,37 @@ int wgrad3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
     attr_set = true;
   }
   for (int base = 0; base < njobs; base += WG_MAXG) {
-    WgradGroup g;
-    g.n = std::min(WG_MAXG, njobs - base);
+    WgradGroup g, gw;                 // the 64x64 program, and the large problems that take the 128x128 ping-pong kernel
+    g.n = gw.n = 0;
+    const int n = std::min(WG_MAXG, njobs - base);
     int blk = 0;
-    for (int i = 0; i < g.n; ++i) {
-      const SedtIgemm& p = jobs[base + i];
-      wgrad2_envelope(p, &ab[i], &bb[i]);
+    for (int j = 0; j < n; ++j) {
+      const SedtIgemm& p = jobs[base + j];
+      long a, b;
+      wgrad2_envelope(p, &a, &b);
+      if (wgrad4_ok(p)) {
+        const int i = gw.n++;
+        gw.p[i] = p;
+        gw.a_bytes[i] = (unsigned)a;
+        gw.b_bytes[i] = (unsigned)b;
+        continue;
+      }
+      const int i = g.n++;
       g.p[i] = p;
-      g.a_bytes[i] = (unsigned)ab[i];
-      g.b_bytes[i] = (unsigned)bb[i];
+      g.a_bytes[i] = (unsigned)a;
+      g.b_bytes[i] = (unsigned)b;
       g.nwg[i] = ((p.N + 63) / 64) * ((p.M + 63) / 64);
       g.nmajor[i] = (p.N > p.M ? 1 : 0) + ((p.splitk >= 8 && p.splitk % 8 == 0) ? 2 : 0);
       g.blk0[i] = blk;
       blk += (g.nwg[i] * (p.splitk > 1 ? p.splitk : 1) + 7) / 8 * 8;      // ranges start on multiples of 8 (XCD = id & 7)
     }
-    g.blk0[g.n] = blk;
-    hipLaunchKernelGGL(wgrad3_group_kernel, dim3(blk), dim3(256), lds, st, g);
-    if (int r = check_launch("wgrad3_group")) return r;
+    if (gw.n > 0)
+      if (int r = launch_wgrad4_group(gw, st)) return r;
+    if (g.n > 0) {
+      g.blk0[g.n] = blk;
+      hipLaunchKernelGGL(wgrad3_group_kernel, dim3(blk), dim3(256), lds, st, g);
+      if (int r = check_launch("wgrad3_group")) return r;
+    }
   }
   return 0;
 }
@@ -133,6 +150,7 @@ int wgrad3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream
   }
   if (!on) return -1;
   if (!wgrad3_conv_ok(p)) return -1;
+  if (wgrad4_ok(p)) return launch_wgrad4(p, a_bytes, b_bytes, st);
   int bn = 64;
   if (wide == 1) {   // measured on the full step: the wide tile does not pay (fewer, longer workgroups); opt-in only
     // a 16-byte chunk never straddles a tap (Ci % 8 == 0), so the wide tile needs nothing beyond N % 128 == 0

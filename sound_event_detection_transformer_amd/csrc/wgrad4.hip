@@ -1,0 +1,355 @@
+// wgrad4.hip - the 128x128, 8-wave "ping-pong" weight-gradient GEMM for the large problems (layer3/4, FFN: Cout, taps*Cin >= 256).
+//
+// Same data path as wgrad3 ([pixel][channel] images of dY and X by LDS-DMA into an XOR-swizzled ring, k-contiguous MFMA
+// fragments by ds_read_b64_tr_b16, split-K slabs), with the two things that made the forward GEMM (igemm3.hip, PP) faster
+// at these sizes:
+//   * a 128x128 output tile: 64 flop per byte moved L2 -> LDS instead of 32 for 64x64 (the LDS-DMA path, ~27 B/clk/CU,
+//     is what bounds these kernels);
+//   * two groups of four waves that each own the whole tile but only two of the four k16 steps of a 64-pixel K tile, and
+//     run ONE BARRIER apart: on every SIMD one wave is in its "load" segment (transposing fragment reads + the LDS-DMA
+//     issue of a later tile) while the other is in its "math" segment (8 MFMAs).  Ordering rules as in igemm3.hip:
+//     a tile is waited for (counted vmcnt) at the end of the load segment of the tile before it; a buffer is restaged
+//     one stage after its last reads, which retired (lgkmcnt(0)) before the barrier that ended their segment.
+// Envelope: bf16, M % 128 == 0, N % 128 == 0, M >= 256, N >= 256, no fused bias sums, wgrad3's conv condition.
+#include <stdlib.h>
+#include <algorithm>
+#include "wgrad3_body.h"
+
+namespace sedt {
+
+template <bool CONV>
+__device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int nmajor,
+                                            const int bx, const int by) {
+  constexpr int BM = 128, BN = 128, BKP = 64, NW = 8, S = 3;
+  constexpr int IMG_ROWB = 256;                       // image row: 128 channels of bf16
+  constexpr int IMG_BYTES = BKP * IMG_ROWB;           // 16 KB per operand per stage
+  constexpr int STAGE_BYTES = 2 * IMG_BYTES;
+  constexpr int CPR = 16, RPI = 4;                    // 16-byte chunks per image row, rows per DMA instruction
+  constexpr int GA = BKP / RPI / NW, GB = GA;         // 2 + 2 DMA instructions per wave per tile
+  constexpr int G = GA + GB;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = w3_uniform(t >> 6);
+  const int kgrp = wave >> 2;
+  const int wm = ((wave & 3) >> 1) * 64, wn = (wave & 1) * 64;
+
+  const int ntn = p.N / BN, ntm = p.M / BM;
+  const int nwg = ntn * ntm;
+  int vid;
+  {
+    const int b = bx, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  int m0, n0;
+  if (nmajor & 1) { n0 = (vid / ntm) * BN; m0 = (vid % ntm) * BM; }
+  else { m0 = (vid / ntn) * BM; n0 = (vid % ntn) * BN; }
+
+  const int nkb_total = (p.K + BKP - 1) / BKP;
+  int kb_begin = 0, kb_end = nkb_total;
+  if (p.splitk > 1) {
+    const int per = (nkb_total + p.splitk - 1) / p.splitk;
+    kb_begin = by * per;
+    kb_end = min(nkb_total, kb_begin + per);
+  }
+  const int nkb = max(0, kb_end - kb_begin);
+
+  __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, a_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, b_bytes, 0x00020000);
+
+  // ---- DMA lanes: instruction `instr` covers image rows [instr*4, +4) x 16 chunks; the XOR swizzle acts on the low three
+  //      chunk bits (inside each 128-byte half row), the physical chunk a lane writes holds logical chunk lchunk
+  const int drow = lane / CPR, pchunk = lane % CPR;
+  unsigned a_poff[GA];
+  int a_trow[GA];
+  const unsigned a_step = (unsigned)(BKP * p.lda * 2);
+#pragma unroll
+  for (int i = 0; i < GA; ++i) {
+    const int trow = (i * NW + wave) * RPI + drow;
+    const int lchunk = (pchunk & ~7) | ((pchunk & 7) ^ w3_swz(trow));
+    a_trow[i] = trow;
+    a_poff[i] = (unsigned)((((long)kb_begin * BKP + trow) * p.lda + m0 + lchunk * 8) * 2);
+  }
+  unsigned b_poff[GB];
+  int b_ho[GB], b_hoff[GB], b_trow[GB];
+  bool b_wok[GB];
+  const int step_h = CONV ? BKP / p.Wo : 0;
+  const unsigned b_step = CONV ? (unsigned)((long)step_h * p.sh * p.Wi * p.ldb * 2) : (unsigned)(BKP * p.ldb * 2);
+  const unsigned b_wrap = CONV ? (unsigned)(((long)p.Hi * p.Wi - (long)p.Ho * p.sh * p.Wi) * p.ldb * 2) : 0u;
+#pragma unroll
+  for (int i = 0; i < GB; ++i) {
+    const int trow = (i * NW + wave) * RPI + drow;
+    const int lchunk = (pchunk & ~7) | ((pchunk & 7) ^ w3_swz(trow));
+    const int j = n0 + lchunk * 8;
+    b_trow[i] = trow;
+    bool ok = true;
+    long off;
+    if (CONV) {
+      const int tap = j / p.Ci, c = j - tap * p.Ci;
+      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+      const int pix = kb_begin * BKP + trow;
+      const int HoWo = p.Ho * p.Wo;
+      const int n = pix / HoWo, rem = pix - n * HoWo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      const int wi = wo * p.sw - p.pw + kw * p.dw;
+      b_ho[i] = ho;
+      b_hoff[i] = kh * p.dh - p.ph;
+      ok = (unsigned)wi < (unsigned)p.Wi;
+      off = ((((long)n * p.Hi + ho * p.sh + b_hoff[i]) * p.Wi + wi) * p.ldb + c) * 2;
+    } else {
+      b_ho[i] = 0; b_hoff[i] = 0;
+      off = (((long)kb_begin * BKP + trow) * p.ldb + j) * 2;
+    }
+    b_wok[i] = ok;
+    b_poff[i] = (unsigned)off;
+  }
+
+  int kbase = kb_begin * BKP;      // first pixel of the tile about to be issued (uniform)
+  auto issue = [&](const int stage) {
+    unsigned char* st = smem + stage * STAGE_BYTES;
+    const int left = p.K - kbase;
+    const bool full = left >= BKP;
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+      unsigned voff = (full || a_trow[i] < left) ? a_poff[i] : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(st + ((i * NW + wave) * RPI) * IMG_ROWB), 16, voff, 0, 0, 0);
+      a_poff[i] += a_step;
+    }
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      unsigned voff = OOB;
+      bool ok = b_wok[i] && (full || b_trow[i] < left);
+      if (CONV) ok = ok && (unsigned)(b_ho[i] * p.sh + b_hoff[i]) < (unsigned)p.Hi;
+      if (ok) voff = b_poff[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(st + IMG_BYTES + ((i * NW + wave) * RPI) * IMG_ROWB), 16, voff, 0, 0,
+                                               0);
+      b_poff[i] += b_step;
+      if (CONV) {
+        b_ho[i] += step_h;
+        if (b_ho[i] >= p.Ho) { b_ho[i] -= p.Ho; b_poff[i] += b_wrap; }
+      }
+    }
+    kbase += BKP;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- transposing fragment reads of this wave's two k16 steps: per-thread constant offsets inside a stage
+  const int grp = lane >> 4, s16 = lane & 15;
+  const int src_pix = (grp >> 1) * 8 + (s16 >> 2);
+  int a_rd[2][2][2], b_rd[2][2][2];            // [k16 step][32-wide sub-tile][half]
+#pragma unroll
+  for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int pixrow = (2 * kgrp + kq) * 16 + src_pix + 4 * h2;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int a_ch = wm + j * 32 + (grp & 1) * 16 + (s16 & 3) * 4;
+        const int b_ch = wn + j * 32 + (grp & 1) * 16 + (s16 & 3) * 4;
+        const int a8 = a_ch >> 3, b8 = b_ch >> 3;
+        const int aphys = (a8 & ~7) | ((a8 & 7) ^ w3_swz(pixrow));
+        const int bphys = (b8 & ~7) | ((b8 & 7) ^ w3_swz(pixrow));
+        a_rd[kq][j][h2] = pixrow * IMG_ROWB + aphys * 16 + ((a_ch >> 2) & 1) * 8;
+        b_rd[kq][j][h2] = IMG_BYTES + pixrow * IMG_ROWB + bphys * 16 + ((b_ch >> 2) & 1) * 8;
+      }
+    }
+  auto tr = [&](const unsigned char* ptr) -> w3_s16x4 { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((w3_lds_s16x4*)ptr); };
+  w3_s16x8 fa[2][2], fb[2][2];
+  auto load_frags = [&](const int stage) {
+    const unsigned char* st = smem + stage * STAGE_BYTES;
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const w3_s16x4 a0 = tr(st + a_rd[kq][j][0]), a1 = tr(st + a_rd[kq][j][1]);
+        fa[kq][j] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const w3_s16x4 b0 = tr(st + b_rd[kq][j][0]), b1 = tr(st + b_rd[kq][j][1]);
+        fb[kq][j] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+  };
+  auto mfma_all = [&]() {
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kq][i]), __builtin_bit_cast(bf16x8, fb[kq][j]),
+                                                              acc[i][j], 0, 0, 0);
+  };
+
+  // ---- ping-pong ring (see igemm3.hip): load segment | barrier | math segment, group 1 one barrier behind group 0
+#pragma unroll
+  for (int s0 = 0; s0 < S - 1; ++s0)
+    if (s0 < nkb) issue(s0);
+  if (nkb >= S - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (kgrp == 1) __builtin_amdgcn_s_barrier();
+  int it = 0;
+  for (; it + 2 * S - 1 <= nkb; it += S) {
+#pragma unroll
+    for (int ph = 0; ph < S; ++ph) {
+      __builtin_amdgcn_s_barrier();
+      load_frags(ph);
+      issue((ph + S - 1) % S);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+      mfma_all();
+      __builtin_amdgcn_s_setprio(0);
+    }
+  }
+  for (; it < nkb; it += S) {
+#pragma unroll
+    for (int ph = 0; ph < S; ++ph) {
+      if (it + ph < nkb) {
+        const bool more = it + ph + S - 1 < nkb;
+        __builtin_amdgcn_s_barrier();
+        load_frags(ph);
+        if (more) issue((ph + S - 1) % S);
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+        mfma_all();
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  }
+  if (kgrp == 0) __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: the two groups' halves of the K sum meet in LDS, then 16-byte rows go to the slab / gradient
+  constexpr int CP = BN + 4;
+  float* Cs = reinterpret_cast<float*>(smem);
+  const int frow = lane & 31, fhalf = lane >> 5;
+  if (kgrp == 0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+          Cs[row * CP + wn + j * 32 + frow] = acc[i][j][r];
+        }
+  }
+  __syncthreads();
+  if (kgrp == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
+          Cs[row * CP + wn + j * 32 + frow] += acc[i][j][r];
+        }
+  }
+  __syncthreads();
+  float* out = p.splitk > 1 ? p.slab + (long)by * p.M * p.N : reinterpret_cast<float*>(p.C);
+  const long ldo = p.splitk > 1 ? p.N : p.ldc;
+#pragma unroll
+  for (int c = 0; c < BM * (BN / 4) / (NW * 64); ++c) {
+    const int u = t + c * NW * 64;
+    const int trow = u / (BN / 4), cc = (u % (BN / 4)) * 4;
+    *reinterpret_cast<float4*>(out + (long)(m0 + trow) * ldo + n0 + cc) = *reinterpret_cast<const float4*>(Cs + trow * CP + cc);
+  }
+}
+
+__device__ __forceinline__ void wgrad4_body(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int nmajor,
+                                            const int bx, const int by) {
+  if (p.conv) wgrad4_impl<true>(p, a_bytes, b_bytes, nmajor, bx, by);
+  else wgrad4_impl<false>(p, a_bytes, b_bytes, nmajor, bx, by);
+}
+
+__global__ __launch_bounds__(512) void wgrad4_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes,
+                                                     const int nmajor) {
+  wgrad4_body(p, a_bytes, b_bytes, nmajor, blockIdx.x, blockIdx.y);
+}
+
+__global__ __launch_bounds__(512) void wgrad4_group_kernel(const WgradGroup g) {
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < g.n && b >= g.blk0[i + 1]) ++i;
+  const int local = b - g.blk0[i];
+  const int nwg = g.nwg[i], sk = g.p[i].splitk > 1 ? g.p[i].splitk : 1;
+  if (local >= nwg * sk) return;                       // padding workgroups (problem ranges start on multiples of 8)
+  wgrad4_body(g.p[i], g.a_bytes[i], g.b_bytes[i], g.nmajor[i], local % nwg, local / nwg);
+}
+
+constexpr size_t WG4_LDS = (size_t)3 * 2 * 64 * 256;      // 96 KB ring >= the 128 x 132 f32 epilogue tile (66 KB)
+
+// shape part of the envelope (sedt_igemm_splitk sizes the split for the 128x128 tiling when this holds)
+bool wgrad4_shape_ok(int M, int N) {
+  static int mn = -1;
+  if (mn < 0) {
+    const char* e = getenv("SEDT_WGRAD4_MIN");
+    mn = e ? atoi(e) : 256;     // full-step sweep: 512 -> 6.32, 256 -> 6.27, 128 -> 6.30 ms
+  }
+  return M >= mn && N >= mn && (M % 128) == 0 && (N % 128) == 0;
+}
+
+bool wgrad4_ok(const SedtIgemm& p) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("SEDT_WGRAD_V4");
+    on = (e && e[0] == '0') ? 0 : 1;
+  }
+  return on && p.trans && wgrad4_shape_ok(p.M, p.N) && p.colsum_out == nullptr && p.out_f32 &&
+         (p.splitk > 1 ? p.slab != nullptr : ((p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0)) &&
+         (reinterpret_cast<uintptr_t>(p.slab) & 15) == 0;
+}
+
+template <typename K>
+static int wg4_attr(K kern, const char* what) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG4_LDS);
+  if (e != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
+    return 1;
+  }
+  return 0;
+}
+
+int launch_wgrad4(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (wg4_attr(wgrad4_kernel, "wgrad4")) return 1;
+    attr_set = true;
+  }
+  const int nwg = (p.N / 128) * (p.M / 128);
+  hipLaunchKernelGGL(wgrad4_kernel, dim3(nwg, p.splitk > 1 ? p.splitk : 1), dim3(512), WG4_LDS, st, p, a_bytes, b_bytes,
+                     p.N > p.M ? 1 : 0);
+  return check_launch("wgrad4");
+}
+
+// launches the (already validated, all wgrad4_ok) problems of g as one grouped kernel; nwg / blk0 are filled here
+int launch_wgrad4_group(WgradGroup& g, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (wg4_attr(wgrad4_group_kernel, "wgrad4 group")) return 1;
+    attr_set = true;
+  }
+  int blk = 0;
+  for (int i = 0; i < g.n; ++i) {
+    const SedtIgemm& p = g.p[i];
+    g.nwg[i] = (p.N / 128) * (p.M / 128);
+    g.nmajor[i] = p.N > p.M ? 1 : 0;
+    g.blk0[i] = blk;
+    blk += (g.nwg[i] * (p.splitk > 1 ? p.splitk : 1) + 7) / 8 * 8;
+  }
+  g.blk0[g.n] = blk;
+  hipLaunchKernelGGL(wgrad4_group_kernel, dim3(blk), dim3(512), WG4_LDS, st, g);
+  return check_launch("wgrad4_group");
+}
+
+}  // namespace sedt

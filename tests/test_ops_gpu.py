@@ -396,7 +396,7 @@ def test_igemm_co_matches_separate_launches(ops):
     # main problem: a plain GEMM with K = 128 -> the 64x64 2-stage kernel, the configuration that can carry riders
     xm = torch.randn(4096, 128, device='cuda').bfloat16()
     wm = (torch.randn(64, 128, device='cuda') / 11.0).bfloat16()
-    riders = [problem(32, 4, 256, 256, 3, 1, 1, 1), problem(32, 4, 512, 128, 1, 1, 0, 1), problem(16, 8, 64, 64, 3, 1, 1, 1)]
+    riders = [problem(32, 4, 256, 128, 3, 1, 1, 1), problem(32, 4, 512, 128, 1, 1, 0, 1), problem(16, 8, 64, 64, 3, 1, 1, 1)]
     outs = {}
     for mode in ('separate', 'co'):
         dx = torch.zeros((4096, 64), device='cuda', dtype=torch.bfloat16)
@@ -494,3 +494,27 @@ def test_layernorm_bwd_with_fused_dropout_grad(ops, dt):
     assert 0.85 < kept < 0.95
     # p = 0: the extra result is dx itself
     assert ops.layernorm_bwd(dt, dyd, xd, gam.cuda(), mean, rstd, drop=(0.0, 0, None))[3] is not None
+
+
+@pytest.mark.parametrize('dt', [F32, BF16])
+@pytest.mark.parametrize('cfg', [(32, 4, 128, 512, 3, 1, 2, 2, 5), (16, 4, 512, 640, 1, 1, 0, 1, 7), (17, 4, 640, 512, 1, 1, 0, 1, 3)])
+def test_wgrad_large_tiles(ops, dt, cfg):
+    """weight gradients with Cout, taps*Cin >= 512: the 128x128 ping-pong kernel (csrc/wgrad4.hip) in bf16 mode -
+    layer4-like dilated 3x3 and 1x1 problems, K a multiple of the 64-pixel tile or not, every split-K slice count the library picks"""
+    Hi, Wi, Ci, Co, k, s, pd, dl, B = cfg
+    g = ops.ConvGeom(Hi, Wi, Ci, Co, k, s, pd, dl)
+    x, gy = randn(B, Ci, Hi, Wi), randn(B, Co, g.Ho, g.Wo)
+    w = torch.zeros(Co, Ci, k, k, requires_grad=True)
+    F.conv2d(rnd(x, dt), w, stride=s, padding=pd, dilation=dl).backward(rnd(gy, dt))
+    xd, gyd = dev(_nhwc(x).reshape(-1, Ci), dt), dev(_nhwc(gy).reshape(-1, Co), dt)
+    dw = ops.wgrad(dt, gyd, xd, B, g)
+    close(dw, w.grad, dt, bf16_tol=2e-3)          # same bf16-rounded inputs, f32 accumulation: only summation order differs
+    # the grouped launch (one wide + one small problem) gives the same numbers
+    rb = ops.ReduceBatch()
+    dw2 = ops.wgrad(dt, gyd, xd, B, g, batch=rb)
+    g1 = ops.ConvGeom(Hi, Wi, Ci, 64, 1, 1, 0, 1)
+    gy1 = randn(B * Hi * Wi, 64)
+    dw1 = ops.wgrad(dt, dev(gy1, dt), xd, B, g1, batch=rb)
+    rb.flush()
+    assert torch.equal(dw2, dw)
+    close(dw1.view(64, Ci), rnd(gy1, dt).t() @ rnd(_nhwc(x).reshape(-1, Ci), dt), dt)
