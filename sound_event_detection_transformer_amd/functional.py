@@ -295,8 +295,9 @@ class EncoderLayerFn(Function):
         rb = ops.ReduceBatch()
         if cfg['pre_norm']:
             g_x1n, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], gx2, w1, w2, batch=rb)
-            gx1, d_g2, d_be2 = ops.layernorm_bwd(dt, g_x1n, sv['x1'], g2, sv['m2'], sv['r2'], dres=gx2, batch=rb)
-            g_qk, _, g_v, d_win, d_bin, d_wo, d_bo = _mha_bwd(dt, sv['mha'], gx1, w_in, w_o, batch=rb)
+            gx1, d_g2, d_be2, gx1d = ops.layernorm_bwd(dt, g_x1n, sv['x1'], g2, sv['m2'], sv['r2'], dres=gx2, batch=rb,
+                                                       drop=_drop_args(sv['mha'], gx2.device))
+            g_qk, _, g_v, d_win, d_bin, d_wo, d_bo = _mha_bwd(dt, sv['mha'], gx1, w_in, w_o, batch=rb, g_dropped=gx1d)
             # LN1 fed xn (to V) and xn+pos (to Q,K): both gradients land on xn
             gx, d_g1, d_be1 = ops.layernorm_bwd(dt, g_v, sv['x'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gx1, batch=rb)
         else:
@@ -359,13 +360,15 @@ class DecoderLayerFn(Function):
         rb = ops.ReduceBatch()
         if cfg['pre_norm']:
             g_t2n, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], gt3, w1, w2, batch=rb)
-            gt2, d_g3, d_be3 = ops.layernorm_bwd(dt, g_t2n, sv['t2'], g3, sv['m3'], sv['r3'], dres=gt3, batch=rb)
-            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], gt2, cw_in, cw_o, batch=rb)
+            gt2, d_g3, d_be3, gt2d = ops.layernorm_bwd(dt, g_t2n, sv['t2'], g3, sv['m3'], sv['r3'], dres=gt3, batch=rb,
+                                                       drop=_drop_args(sv['ca'], gt3.device))
+            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], gt2, cw_in, cw_o, batch=rb, g_dropped=gt2d)
             # LN2 outputs: t1n (unused on its own) and t1n + qpos (cross-attn query)
-            gt1, d_g2, d_be2 = ops.layernorm_bwd(dt, g_q, sv['t1'], g2, sv['m2'], sv['r2'], dres=gt2, batch=rb)
+            gt1, d_g2, d_be2, gt1d = ops.layernorm_bwd(dt, g_q, sv['t1'], g2, sv['m2'], sv['r2'], dres=gt2, batch=rb,
+                                                       drop=_drop_args(sv['sa'], gt3.device))
             g_qpos = g_q
             g_mem_pos, g_mem = g_k, g_v
-            g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], gt1, sw_in, sw_o, batch=rb)
+            g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], gt1, sw_in, sw_o, batch=rb, g_dropped=gt1d)
             gtgt, d_g1, d_be1 = ops.layernorm_bwd(dt, g_vs, sv['tgt'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gt1, batch=rb)
             g_qpos = ops.add(dt, g_qpos, g_qk)
         else:
