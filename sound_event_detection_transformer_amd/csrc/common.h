@@ -50,6 +50,21 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint64_t idx, uint32_t 
   const uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xffffu);
   return bits >= thresh;
 }
+// keep-decisions of 8 consecutive elements base .. base+7 (base % 8 == 0) as a bit mask - the same decisions as drop_keep, with
+// the part of the hash that depends only on (seed, high index word) computed once instead of four times
+__device__ __forceinline__ uint32_t drop_keep8(uint32_t seed, uint64_t base, uint32_t thresh) {
+  const uint64_t h0 = base >> 1;                       // hash index of elements base, base+1; +1, +2, +3 for the next pairs
+  const uint32_t hi = (uint32_t)(h0 >> 32), lo = (uint32_t)h0;      // lo % 4 == 0: lo + 3 does not carry into hi
+  const uint32_t inner = mix32(seed ^ (hi * 0x9E3779B9U) ^ 0x85ebca6bU);
+  uint32_t m = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t h = mix32((lo + q) ^ inner);
+    m |= ((h & 0xffffu) >= thresh ? 1u : 0u) << (2 * q);
+    m |= ((h >> 16) >= thresh ? 1u : 0u) << (2 * q + 1);
+  }
+  return m;
+}
 __device__ __forceinline__ uint32_t eff_seed(uint32_t seed, const uint32_t* seed_ptr) {
   return seed + (seed_ptr ? *seed_ptr : 0u);
 }

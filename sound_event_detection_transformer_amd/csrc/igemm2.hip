@@ -297,7 +297,12 @@ int igemm2_try(const SedtIgemm& p, hipStream_t st) {
     // once K is deep and enough tiles remain to fill the chip; everything else prefers the 64x64 tile's occupancy
     // (with the 8-wave form of that tile - igemm3.hip - the tile-count condition of the 4-wave kernel no longer applies)
     // (a grouped launch - igemm3_planning() - runs on the 64x64 program: worth it for the launch-bound decoder-sized problems)
-    if ((p.N % 128) == 0 && p.K >= 512 && !(igemm3_planning() && p.M <= 1024)) bn = 128;
+    static int mink = -1;
+    if (mink < 0) {
+      const char* e = getenv("SEDT_IGEMM_BN128_MINK");
+      mink = e ? atoi(e) : 512;
+    }
+    if ((p.N % 128) == 0 && p.K >= mink && !(igemm3_planning() && p.M <= 1024)) bn = 128;
     // the ping-pong 8-wave kernel makes the 128x128 tile (one workgroup per CU) pay where the K loop is long enough to
     // amortise its exposed prologue / epilogue and the tiles still cover the chip: layer4 conv1 fwd / conv2 / conv3 dgrad
     if (bn == 128 && p.K >= 2048 && (long)((p.M + 127) / 128) * (p.N / 128) >= 256 && !igemm3_planning()) bm = 128;

@@ -74,7 +74,11 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     const int u = t + c * NT;
     const int row = m0 + u / CPR, col = n0 + (u % CPR) * 8;
     if (row < p.M && col < p.N) {
-      if (resT) res_pf[c] = *reinterpret_cast<const bf16x8*>(resT + (long)(p.res_mod > 0 ? (row % p.res_mod) : row) * p.ldr + col);
+      if (resT) {
+        int rrow = row;
+        if (p.res_mod > 0) rrow = row % p.res_mod;          // uniform branch: the common case pays no integer division
+        res_pf[c] = *reinterpret_cast<const bf16x8*>(resT + (long)rrow * p.ldr + col);
+      }
       if (maskT) mask_pf[c] = *reinterpret_cast<const bf16x8*>(maskT + (long)row * p.ldm + col);
     }
   }
@@ -103,8 +107,8 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       // pitch - so "lane base + wave-uniform tap delta" holds for strided dgrads too (tsub = pitch/s in elements).
       off = ((long)n * p.Hi * p.Wi) * p.lda + ((long)hb * p.Wi + wb) * tsub + swz;
       if (row < p.M)
-        for (int tp = 0; tp < taps; ++tp) {
-          const int kh = tp / p.KW, kw = tp - kh * p.KW;
+        for (int tp = 0, kh = 0, kw = 0; tp < taps; ++tp, ++kw) {      // (kh, kw) walk without a division per tap
+          if (kw == p.KW) { kw = 0; ++kh; }
           int hi = hb + sg * kh * p.dh, wi = wb + sg * kw * p.dw;
           bool ok = hi >= 0 && wi >= 0;
           if (p.transposed) {
@@ -364,41 +368,62 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   const uint32_t thresh = drop_threshold(p.drop_p);
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
   bf16_t* outT = reinterpret_cast<bf16_t*>(p.C);
+  // a thread's chunks all sit in the same 8 columns (NT is a multiple of the chunks per row): per-column operands once.
+  // The K <= 256 problems are instruction-issue bound in this epilogue (PMC: 17 VALU per MFMA), so it is kept lean.
+  static_assert(NT % CPR == 0, "column of a thread's chunks must not depend on the chunk");
+  const int ccol = n0 + (t % CPR) * 8;
+  const bool col_ok = ccol < p.N;
+  float sc8[8], bi8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sc8[e] = 1.f; bi8[e] = 0.f; }
+  if (col_ok && p.scale) {
+    const float4 s0 = *reinterpret_cast<const float4*>(p.scale + ccol), s1 = *reinterpret_cast<const float4*>(p.scale + ccol + 4);
+    sc8[0] = s0.x; sc8[1] = s0.y; sc8[2] = s0.z; sc8[3] = s0.w; sc8[4] = s1.x; sc8[5] = s1.y; sc8[6] = s1.z; sc8[7] = s1.w;
+  }
+  if (col_ok && p.bias) {
+    const float4 s0 = *reinterpret_cast<const float4*>(p.bias + ccol), s1 = *reinterpret_cast<const float4*>(p.bias + ccol + 4);
+    bi8[0] = s0.x; bi8[1] = s0.y; bi8[2] = s0.z; bi8[3] = s0.w; bi8[4] = s1.x; bi8[5] = s1.y; bi8[6] = s1.z; bi8[7] = s1.w;
+  }
+  const bool affine = p.scale != nullptr || p.bias != nullptr;
+  const bool relu_pre = !p.act_post_res && p.act == SEDT_ACT_RELU, relu_post = p.act_post_res && p.act == SEDT_ACT_RELU;
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int u = t + c * NT;
     const int trow = u / CPR, cc = (u % CPR) * 8;
     const int row = m0 + trow, col = n0 + cc;
-    if (row >= p.M || col >= p.N) continue;
+    if (row >= p.M || !col_ok) continue;
     float v[8];
     {
       const float4 x0 = *reinterpret_cast<const float4*>(Cs + trow * CP + cc);
       const float4 x1 = *reinterpret_cast<const float4*>(Cs + trow * CP + cc + 4);
       v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
     }
-    if (p.scale) {
-      const float4 s0 = *reinterpret_cast<const float4*>(p.scale + col), s1 = *reinterpret_cast<const float4*>(p.scale + col + 4);
-      v[0] *= s0.x; v[1] *= s0.y; v[2] *= s0.z; v[3] *= s0.w; v[4] *= s1.x; v[5] *= s1.y; v[6] *= s1.z; v[7] *= s1.w;
+    if (affine) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc8[e], bi8[e]);
     }
-    if (p.bias) {
-      const float4 s0 = *reinterpret_cast<const float4*>(p.bias + col), s1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
-      v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w; v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
-    }
-    if (!p.act_post_res && p.act == SEDT_ACT_RELU) {
+    if (relu_pre) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
     if (p.drop_p > 0.f) {
-      const uint64_t base = (uint64_t)row * (uint64_t)p.N + col;
+      // drop_keep of 8 consecutive elements: the (seed, high word) part of the hash once, one outer hash per pair
+      const uint64_t h0 = ((uint64_t)row * (uint64_t)p.N + col) >> 1;
+      const uint32_t lo = (uint32_t)h0;
+      const uint32_t inner = mix32(seed ^ ((uint32_t)(h0 >> 32) * 0x9E3779B9U) ^ 0x85ebca6bU);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = drop_keep(seed, base + e, thresh) ? v[e] * inv_keep : 0.f;
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t h = mix32((lo + q) ^ inner);
+        v[2 * q] = (h & 0xffffu) >= thresh ? v[2 * q] * inv_keep : 0.f;
+        v[2 * q + 1] = (h >> 16) >= thresh ? v[2 * q + 1] * inv_keep : 0.f;
+      }
     }
     if (resT) {
       const bf16x8 rv = res_pf[c];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
     }
-    if (p.act_post_res && p.act == SEDT_ACT_RELU) {
+    if (relu_post) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
@@ -407,9 +432,13 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ((float)mv[e] > 0.f) ? v[e] : 0.f;
     }
+    if (p.alpha != 1.f) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+    }
     bf16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)(v[e] * p.alpha);
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
     *reinterpret_cast<bf16x8*>(outT + (long)row * p.ldc + col) = o;
   }
 }
@@ -639,7 +668,13 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
     const char* e = getenv("SEDT_IGEMM3_PP");
     pp_env = e ? atoi(e) : 1;
   }
-  if (!plan3.on && co_group == nullptr && nw_env != 4 && pp_env) {
+  static int w4k = -1;          // experiment: below this K the 64x128 tile runs on the 4-wave kernel (32 MFMAs per wave and tile)
+  if (w4k < 0) {
+    const char* e = getenv("SEDT_IGEMM3_W4_BELOW_K");
+    w4k = e ? atoi(e) : 0;
+  }
+  const bool force4 = p.K < w4k;
+  if (!plan3.on && co_group == nullptr && nw_env != 4 && pp_env && !force4) {
 #define SEDT_PP(BM_, BN_)                                                                                   \
   if (bm == BM_ && bn == BN_) {                                                                             \
     return S >= 3 ? launch3_w8<BM_, BN_, 3, 1>(p, a_bytes, b_bytes, st) : launch3_w8<BM_, BN_, 2, 1>(p, a_bytes, b_bytes, st); \
@@ -649,7 +684,7 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
     SEDT_PP(128, 64)
 #undef SEDT_PP
   }
-  if (!plan3.on && co_group == nullptr && nw_env != 4) {
+  if (!plan3.on && co_group == nullptr && nw_env != 4 && !force4) {
     if (bm == 64 && bn == 128) return S >= 3 ? launch3_w8<64, 128, 3>(p, a_bytes, b_bytes, st) : launch3_w8<64, 128, 2>(p, a_bytes, b_bytes, st);
     if (nw_env == 8 && bm == 128 && bn == 128)
       return S >= 3 ? launch3_w8<128, 128, 3>(p, a_bytes, b_bytes, st) : launch3_w8<128, 128, 2>(p, a_bytes, b_bytes, st);

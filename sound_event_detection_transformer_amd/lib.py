@@ -8,6 +8,8 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libsedt_hip.so')
+if os.environ.get('SEDT_LIB_AB'):          # developer A/B runs: another build of the same library (tools/README.md)
+    LIB_PATH = os.environ['SEDT_LIB_AB']
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
