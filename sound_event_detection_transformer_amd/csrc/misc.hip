@@ -310,14 +310,24 @@ __global__ void stem_prep_kernel(const float* w0, const float* b0, const float* 
 template <typename T>
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x, T* __restrict__ col, int B, int H, int W,
                                                           int Ho, int Wo) {
-  const int npix = B * Ho * Wo;
-  const int pix = blockIdx.x * 16 + (threadIdx.x >> 4), chunk = threadIdx.x & 15;
-  if (pix >= npix) return;
-  const int wo = pix % Wo, r = pix / Wo;
-  const int ho = r % Ho, b = r / Ho;
+  // grid (ceil(Wo / 16), Ho, B).  The seven input rows of this output row go to LDS first (coalesced, zero-padded by 3 on
+  // every side): the 4-byte tap gathers straight from global memory were what bounded the kernel (one scattered load
+  // instruction per tap), the column stores are 16/32 bytes per thread.
+  extern __shared__ float rows[];                     // [7][W + 6]
+  const int P = W + 6;
+  const int ho = blockIdx.y, b = blockIdx.z;
+  const float* xb = x + (long)b * H * W;
+  for (int i = threadIdx.x; i < 7 * P; i += 256) {
+    const int kh = i / P, j = i - kh * P;
+    const int hi = 2 * ho - 3 + kh, wi = j - 3;
+    rows[i] = ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) ? xb[hi * W + wi] : 0.f;
+  }
+  __syncthreads();
+  const int wo = blockIdx.x * 16 + (threadIdx.x >> 4), chunk = threadIdx.x & 15;
+  if (wo >= Wo) return;
+  const int pix = (b * Ho + ho) * Wo + wo;
   const int k0 = chunk * 8;
   const bool ind = k0 >= 64;
-  const float* xb = x + (long)b * H * W;
   VecT<T, 8> out;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -326,7 +336,8 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
     if (tap < 49) {
       const int kh = tap / 7, kw = tap - kh * 7;
       const int hi = 2 * ho - 3 + kh, wi = 2 * wo - 3 + kw;
-      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = ind ? 1.f : xb[hi * W + wi];
+      if (ind) v = ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) ? 1.f : 0.f;
+      else v = rows[kh * P + 2 * wo + kw];
     }
     out.v[e] = (T)v;
   }
@@ -362,13 +373,13 @@ __global__ void stem_conv0_grad_kernel(const float* G, const float* w1, float* d
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ idx,
                                                           int B, int H, int W, int C, int Ho, int Wo) {
+  // grid (ceil(Wo * C/VEC / 256), Ho, B): one division (by the channel-chunk count) per thread instead of six
   const int CV = C / VEC;
-  const long e = (long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (long)B * Ho * Wo * CV) return;
-  const int c = (int)(e % CV) * VEC;
-  const int pix = (int)(e / CV);
-  const int wo = pix % Wo, r = pix / Wo;
-  const int ho = r % Ho, b = r / Ho;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= Wo * CV) return;
+  const int wo = e / CV, c = (e - wo * CV) * VEC;
+  const int ho = blockIdx.y, b = blockIdx.z;
+  const int pix = (b * Ho + ho) * Wo + wo;
   float best[VEC];
   uint8_t bi[VEC];
 #pragma unroll
@@ -403,14 +414,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 template <typename T, int VEC>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, const T* __restrict__ relu_src,
                                    T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
+  // grid (ceil(W * C/VEC / 256), H, B): row and clip from the block index (the kernel was VALU-bound on its divisions)
   const int CV = C / VEC;
-  long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long n = (long)B * H * W * CV;
-  if (e >= n) return;
-  const int c = (int)(e % CV) * VEC;
-  const int ipix = (int)(e / CV);
-  const int wi = ipix % W, r = ipix / W;
-  const int hi = r % H, b = r / H;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= W * CV) return;
+  const int wi = e / CV, c = (e - wi * CV) * VEC;
+  const int hi = blockIdx.y, b = blockIdx.z;
   float s[VEC];
 #pragma unroll
   for (int v = 0; v < VEC; ++v) s[v] = 0.f;
@@ -904,10 +913,13 @@ extern "C" int sedt_stem_im2col(const float* x, void* col, int B, int H, int W, 
   int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const long npix = (long)B * Ho * Wo;
   SEDT_REQUIRE(npix * 128 < (1L << 31) * 16 && npix < (1L << 31) - 16, "stem_im2col: too many pixels for 32-bit indexing");
-  const unsigned nb = (unsigned)((npix + 15) / 16);
+  SEDT_REQUIRE(Ho <= 65535 && B <= 65535, "stem_im2col: Ho / B exceed the grid limits");
+  SEDT_REQUIRE(W <= 2042, "stem_im2col: W = %d too wide for the row staging buffer", W);
+  const dim3 grid((unsigned)((Wo + 15) / 16), (unsigned)Ho, (unsigned)B);
+  const size_t lds = (size_t)7 * (W + 6) * sizeof(float);
   BY_DTYPE(dtype,
-           hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(nb), dim3(256), 0, S(stream), x, (float*)col, B, H, W, Ho, Wo),
-           hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(nb), dim3(256), 0, S(stream), x, (bf16_t*)col, B, H, W, Ho, Wo));
+           hipLaunchKernelGGL(stem_im2col_kernel<float>, grid, dim3(256), lds, S(stream), x, (float*)col, B, H, W, Ho, Wo),
+           hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, grid, dim3(256), lds, S(stream), x, (bf16_t*)col, B, H, W, Ho, Wo));
   return check_launch("stem_im2col");
 }
 
@@ -919,16 +931,18 @@ extern "C" int sedt_stem_conv0_grad(const float* G, const float* w1, float* dw0,
 extern "C" int sedt_maxpool_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, int dtype, void* stream) {
   int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-  SEDT_REQUIRE((long)B * H * W < (1L << 31), "maxpool_fwd: too many pixels for 32-bit indexing");
+  SEDT_REQUIRE((long)B * H * W < (1L << 31) && H <= 65535 && B <= 65535, "maxpool_fwd: too many pixels for 32-bit indexing / the grid");
   if (dtype == SEDT_BF16) {
     SEDT_REQUIRE(C % 8 == 0 && al(x, 16) && al(y, 16) && al(idx, 8), "maxpool_fwd: needs C %% 8 == 0 and 16-byte aligned tensors");
-    long n = (long)B * Ho * Wo * (C / 8);
-    hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 8>), dim3(nblk(n)), dim3(256), 0, S(stream), (const bf16_t*)x, (bf16_t*)y, idx,
+    const int bs = std::min(256, (Wo * (C / 8) + 63) / 64 * 64);        // a row of 16 pixels x 8 chunks fills only two waves
+    const dim3 grid(nblk((long)Wo * (C / 8), bs), (unsigned)Ho, (unsigned)B);
+    hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t, 8>), grid, dim3(bs), 0, S(stream), (const bf16_t*)x, (bf16_t*)y, idx,
                        B, H, W, C, Ho, Wo);
   } else if (dtype == SEDT_F32) {
     SEDT_REQUIRE(C % 4 == 0 && al(x, 16) && al(y, 16) && al(idx, 4), "maxpool_fwd: needs C %% 4 == 0 and 16-byte aligned tensors");
-    long n = (long)B * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL((maxpool_fwd_kernel<float, 4>), dim3(nblk(n)), dim3(256), 0, S(stream), (const float*)x, (float*)y, idx, B,
+    const int bs = std::min(256, (Wo * (C / 4) + 63) / 64 * 64);        // a row of 16 pixels x 8 chunks fills only two waves
+    const dim3 grid(nblk((long)Wo * (C / 4), bs), (unsigned)Ho, (unsigned)B);
+    hipLaunchKernelGGL((maxpool_fwd_kernel<float, 4>), grid, dim3(bs), 0, S(stream), (const float*)x, (float*)y, idx, B,
                        H, W, C, Ho, Wo);
   } else {
     set_error("maxpool_fwd: unsupported dtype %d", dtype);
@@ -941,17 +955,20 @@ extern "C" int sedt_maxpool_bwd(const void* dy, const uint8_t* idx, const void* 
                                 int C, int dtype, void* stream) {
   int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  SEDT_REQUIRE((long)B * H * W < (1L << 31) && H <= 65535 && B <= 65535, "maxpool_bwd: too many pixels for 32-bit indexing / the grid");
   if (dtype == SEDT_BF16) {
     SEDT_REQUIRE(C % 8 == 0 && al(dy) && al(dx) && (!relu_src || al(relu_src)) && (reinterpret_cast<uintptr_t>(idx) & 7) == 0,
                  "maxpool_bwd: needs C %% 8 == 0 and 16-byte aligned tensors");
-    long n = (long)B * H * W * (C / 8);
-    hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8>), dim3(nblk(n)), dim3(256), 0, S(stream), (const bf16_t*)dy, idx,
+    const int bs = std::min(256, (W * (C / 8) + 63) / 64 * 64);
+    const dim3 grid(nblk((long)W * (C / 8), bs), (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8>), grid, dim3(bs), 0, S(stream), (const bf16_t*)dy, idx,
                        (const bf16_t*)relu_src, (bf16_t*)dx, B, H, W, C, Ho, Wo);
   } else if (dtype == SEDT_F32) {
     SEDT_REQUIRE(C % 4 == 0 && al(dy) && al(dx) && (!relu_src || al(relu_src)) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0,
                  "maxpool_bwd: needs C %% 4 == 0 and 16-byte aligned tensors");
-    long n = (long)B * H * W * (C / 4);
-    hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4>), dim3(nblk(n)), dim3(256), 0, S(stream), (const float*)dy, idx,
+    const int bs = std::min(256, (W * (C / 4) + 63) / 64 * 64);
+    const dim3 grid(nblk((long)W * (C / 4), bs), (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4>), grid, dim3(bs), 0, S(stream), (const float*)dy, idx,
                        (const float*)relu_src, (float*)dx, B, H, W, C, Ho, Wo);
   } else {
     set_error("unsupported dtype %d", dtype);
