@@ -336,8 +336,14 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
 
   // ---- epilogue through LDS (identical to igemm2)
   constexpr int CP = BN + 4;
+  // 8 waves: the two groups hold the two halves of the K sum.  When the ring has room for two staging tiles each group
+  // writes its own and the chunk loop adds them (one phase, one barrier); otherwise the second group adds into the first
+  // group's tile in a second phase.
+  constexpr bool TWO_CS = NW == 8 && (size_t)S * (BM + BN) * ROWB >= (size_t)2 * BM * CP * sizeof(float);
   float* Cs = reinterpret_cast<float*>(smem);
-  if (NW == 4 || kgrp == 0) {
+  float* Cs2 = Cs + BM * CP;
+  if (NW == 4 || kgrp == 0 || TWO_CS) {
+    float* dst = (TWO_CS && kgrp == 1) ? Cs2 : Cs;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -345,11 +351,11 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fhalf;
-          Cs[row * CP + wn + j * 32 + frow] = acc[i][j][r];
+          dst[row * CP + wn + j * 32 + frow] = acc[i][j][r];
         }
   }
   __syncthreads();
-  if (NW == 8) {                     // second wave group: add its half of the K sum
+  if (NW == 8 && !TWO_CS) {                     // second wave group: add its half of the K sum
     if (kgrp == 1) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -397,6 +403,11 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       const float4 x0 = *reinterpret_cast<const float4*>(Cs + trow * CP + cc);
       const float4 x1 = *reinterpret_cast<const float4*>(Cs + trow * CP + cc + 4);
       v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+      if (TWO_CS) {
+        const float4 y0 = *reinterpret_cast<const float4*>(Cs2 + trow * CP + cc);
+        const float4 y1 = *reinterpret_cast<const float4*>(Cs2 + trow * CP + cc + 4);
+        v[0] += y0.x; v[1] += y0.y; v[2] += y0.z; v[3] += y0.w; v[4] += y1.x; v[5] += y1.y; v[6] += y1.z; v[7] += y1.w;
+      }
     }
     if (affine) {
 #pragma unroll
