@@ -174,7 +174,7 @@ def _drop_args(s, device):
     return (p, s['seeds'][1], runtime.seed_ptr(device) if p > 0 else None)
 
 
-def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, batch=None, g_dropped=None):
+def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, batch=None, g_dropped=None, kv_fused=False):
     """g_out = grad wrt the block output (the residual branch is the caller's business); g_dropped = the same gradient
     already through the output dropout (ops.layernorm_bwd(drop=...)).
     returns g_q_in, g_k_in, g_v_in, d_in_proj_weight, d_in_proj_bias, d_out_w, d_out_b"""
@@ -193,10 +193,16 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, b
     if s['same_qk']:
         dqk = torch.empty((B * Lq, 2 * E), device=g_out.device, dtype=td)
         dq, dk = dqk[:, :E], dqk[:, E:]
+        dv = torch.empty((B * Lk, E), device=g_out.device, dtype=td)
+    elif kv_fused:
+        # key and value inputs are the same tensor up to a constant: dK | dV side by side, one dgrad GEMM over K = 2E
+        dq = torch.empty((B * Lq, E), device=g_out.device, dtype=td)
+        dkv = torch.empty((B * Lk, 2 * E), device=g_out.device, dtype=td)
+        dk, dv = dkv[:, :E], dkv[:, E:]
     else:
         dq = torch.empty((B * Lq, E), device=g_out.device, dtype=td)
         dk = torch.empty((B * Lk, E), device=g_out.device, dtype=td)
-    dv = torch.empty((B * Lk, E), device=g_out.device, dtype=td)
+        dv = torch.empty((B * Lk, E), device=g_out.device, dtype=td)
     ops.attention_bwd(dt, s['q'], s['k'], s['v'], s['ctxv'], g_ctx, s['lse'], B, H, Lq, Lk, dq, dk, dv, s['kpm'], s['amask'],
                       p, s['seeds'][0], sp)
     d_win = torch.empty((3 * E, E), device=g_out.device, dtype=torch.float32)
@@ -213,10 +219,12 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, b
         ops.linear_wgrad(dt, dk, s['k_in'], out=d_win[E:2 * E], bias_out=d_bin[E:2 * E], batch=batch)
         if need_q:
             dgrads.append(('q', dq, wb[:, :E]))
-        if need_k:
+        if need_k and not kv_fused:
             dgrads.append(('k', dk, wb[:, E:2 * E]))
     ops.linear_wgrad(dt, dv, s['v_in'], out=d_win[2 * E:], bias_out=d_bin[2 * E:], batch=batch)
-    if need_v:
+    if kv_fused and not s['same_qk']:
+        dgrads.append(('v', dkv, wb[:, E:]))              # grad wrt the shared key/value source, returned in the value slot
+    elif need_v:
         dgrads.append(('v', dv, wb[:, 2 * E:]))
     if dgrads:
         got = dict(zip([n for n, _, _ in dgrads], ops.linear_group(dt, [(g, w, {}) for _, g, w in dgrads])))
@@ -362,7 +370,8 @@ class DecoderLayerFn(Function):
             g_t2n, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], gt3, w1, w2, batch=rb)
             gt2, d_g3, d_be3, gt2d = ops.layernorm_bwd(dt, g_t2n, sv['t2'], g3, sv['m3'], sv['r3'], dres=gt3, batch=rb,
                                                        drop=_drop_args(sv['ca'], gt3.device))
-            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], gt2, cw_in, cw_o, batch=rb, g_dropped=gt2d)
+            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], gt2, cw_in, cw_o, batch=rb, g_dropped=gt2d,
+                                                                   kv_fused=cfg.get('kv_fused', False))
             # LN2 outputs: t1n (unused on its own) and t1n + qpos (cross-attn query)
             gt1, d_g2, d_be2, gt1d = ops.layernorm_bwd(dt, g_q, sv['t1'], g2, sv['m2'], sv['r2'], dres=gt2, batch=rb,
                                                        drop=_drop_args(sv['sa'], gt3.device))
@@ -378,7 +387,8 @@ class DecoderLayerFn(Function):
             g_t2, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], g_f, w1, w2, res_for_gx=g_f, batch=rb, g_dropped=g_fd)
             g_c, d_g2, d_be2, g_cd = ops.layernorm_bwd(dt, g_t2, sv['c'], g2, sv['m2'], sv['r2'], batch=rb,
                                                        drop=_drop_args(sv['ca'], dev))
-            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], g_c, cw_in, cw_o, batch=rb, g_dropped=g_cd)
+            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], g_c, cw_in, cw_o, batch=rb, g_dropped=g_cd,
+                                                                   kv_fused=cfg.get('kv_fused', False))
             g_t1 = ops.add(dt, g_q, g_c)                     # query path + residual
             g_qpos = g_q
             g_mem_pos, g_mem = g_k, g_v

@@ -86,8 +86,10 @@ class TransformerDecoderLayer(nn.Module):
                 self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                 self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.norm3.weight, self.norm3.bias)
 
-    def forward_tokens(self, tgt, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask=None):
-        cfg = dict(dt=runtime.compute_dtype(), B=B, S=S, Q=Q, H=self.nhead, dropout=self.p, training=self.training,
+    def forward_tokens(self, tgt, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask=None, kv_fused=False):
+        """kv_fused: mem_pos is mem + a constant (the decoder's own sine position add): the key and value input gradients
+        of the cross-attention are returned as ONE tensor on `mem` (one K = 2E GEMM) and nothing on `mem_pos`"""
+        cfg = dict(kv_fused=kv_fused, dt=runtime.compute_dtype(), B=B, S=S, Q=Q, H=self.nhead, dropout=self.p, training=self.training,
                    pre_norm=self.normalize_before)
         return Fn.DecoderLayerFn.apply(tgt, mem, mem_pos, qpos, kpm, tgt_mask, cfg, *self.params())
 
@@ -127,7 +129,7 @@ class TransformerDecoder(nn.Module):
         out = tgt
         outs = []
         for layer in self.layers:
-            out = layer.forward_tokens(out, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask)
+            out = layer.forward_tokens(out, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask, kv_fused=not pos.requires_grad)
             outs.append(out)
         d = out.shape[1]
         if self.return_intermediate:
