@@ -222,6 +222,10 @@ int sedt_maxpool_fwd(const void* x, void* y, uint8_t* idx, int B, int H, int W, 
 /* dx = (sum of dy routed by idx) * (relu_src > 0 if relu_src) */
 int sedt_maxpool_bwd(const void* dy, const uint8_t* idx, const void* relu_src, void* dx, int B, int H, int W, int C,
                      int dtype, void* stream);
+/* same with the ReLU mask taken from the pooled output y (NHWC at the pooled resolution; the selected element passed the
+ * ReLU exactly when y > 0): pass relu_src = NULL.  Reads a quarter of the bytes and the un-pooled activation need not be kept. */
+int sedt_maxpool_bwd_y(const void* dy, const uint8_t* idx, const void* relu_src, const void* y, void* dx, int B, int H, int W,
+                       int C, int dtype, void* stream);
 /* global average pool over NHWC pixels: out[b][c] = mean_p x[b][p][c] (f32 out) */
 int sedt_avgpool(const void* x, float* out, int B, int P, int C, int dtype, void* stream);
 

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 // thread = one input pixel x VEC consecutive channels (16 bytes of dy / relu_src / dx at a time when C % VEC == 0)
 template <typename T, int VEC>
 __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, const T* __restrict__ relu_src,
-                                   T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
+                                   const T* __restrict__ y, T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
   // grid (ceil(W * C/VEC / 256), H, B): row and clip from the block index (the kernel was VALU-bound on its divisions)
   const int CV = C / VEC;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -438,9 +438,20 @@ __global__ void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __re
           *reinterpret_cast<const typename std::conditional<sizeof(T) * VEC == 16, uint4, uint2>::type*>(dy + o);
       *reinterpret_cast<typename std::conditional<VEC == 8, uint2, uint32_t>::type*>(iv) =
           *reinterpret_cast<const typename std::conditional<VEC == 8, uint2, uint32_t>::type*>(idx + o);
+      if (y) {
+        // ReLU mask of the pooled tensor's producer, taken from the pooled OUTPUT: the selected element is the window
+        // maximum, so it passed the ReLU exactly when y > 0 (a quarter of the bytes of the full-resolution mask source)
+        T yv[VEC];
+        *reinterpret_cast<typename std::conditional<sizeof(T) * VEC == 16, uint4, uint2>::type*>(yv) =
+            *reinterpret_cast<const typename std::conditional<sizeof(T) * VEC == 16, uint4, uint2>::type*>(y + o);
 #pragma unroll
-      for (int v = 0; v < VEC; ++v)
-        if (iv[v] == kh * 3 + kw) s[v] += (float)gv[v];
+        for (int v = 0; v < VEC; ++v)
+          if (iv[v] == kh * 3 + kw && (float)yv[v] > 0.f) s[v] += (float)gv[v];
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+          if (iv[v] == kh * 3 + kw) s[v] += (float)gv[v];
+      }
     }
   }
   const long xo = (((long)b * H + hi) * W + wi) * C + c;
@@ -951,8 +962,16 @@ extern "C" int sedt_maxpool_fwd(const void* x, void* y, uint8_t* idx, int B, int
   return check_launch("maxpool_fwd");
 }
 
+extern "C" int sedt_maxpool_bwd_y(const void* dy, const uint8_t* idx, const void* relu_src, const void* y, void* dx, int B, int H,
+                                  int W, int C, int dtype, void* stream);
+
 extern "C" int sedt_maxpool_bwd(const void* dy, const uint8_t* idx, const void* relu_src, void* dx, int B, int H, int W,
                                 int C, int dtype, void* stream) {
+  return sedt_maxpool_bwd_y(dy, idx, relu_src, nullptr, dx, B, H, W, C, dtype, stream);
+}
+
+extern "C" int sedt_maxpool_bwd_y(const void* dy, const uint8_t* idx, const void* relu_src, const void* y, void* dx, int B, int H,
+                                  int W, int C, int dtype, void* stream) {
   int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   SEDT_REQUIRE((long)B * H * W < (1L << 31) && H <= 65535 && B <= 65535, "maxpool_bwd: too many pixels for 32-bit indexing / the grid");
@@ -962,14 +981,14 @@ extern "C" int sedt_maxpool_bwd(const void* dy, const uint8_t* idx, const void* 
     const int bs = std::min(256, (W * (C / 8) + 63) / 64 * 64);
     const dim3 grid(nblk((long)W * (C / 8), bs), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t, 8>), grid, dim3(bs), 0, S(stream), (const bf16_t*)dy, idx,
-                       (const bf16_t*)relu_src, (bf16_t*)dx, B, H, W, C, Ho, Wo);
+                       (const bf16_t*)relu_src, (const bf16_t*)y, (bf16_t*)dx, B, H, W, C, Ho, Wo);
   } else if (dtype == SEDT_F32) {
     SEDT_REQUIRE(C % 4 == 0 && al(dy) && al(dx) && (!relu_src || al(relu_src)) && (reinterpret_cast<uintptr_t>(idx) & 3) == 0,
                  "maxpool_bwd: needs C %% 4 == 0 and 16-byte aligned tensors");
     const int bs = std::min(256, (W * (C / 4) + 63) / 64 * 64);
     const dim3 grid(nblk((long)W * (C / 4), bs), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL((maxpool_bwd_kernel<float, 4>), grid, dim3(bs), 0, S(stream), (const float*)dy, idx,
-                       (const float*)relu_src, (float*)dx, B, H, W, C, Ho, Wo);
+                       (const float*)relu_src, (const float*)y, (float*)dx, B, H, W, C, Ho, Wo);
   } else {
     set_error("unsupported dtype %d", dtype);
     return 1;

@@ -425,17 +425,18 @@ class StemFn(Function):
         s1 = ops.linear(dt, col, wcat, scale=sc, bias=bi, act=ACT_RELU)
         pool, idx, Hp, Wp = ops.maxpool_fwd(dt, s1, B, Ho, Wo, 64)
         ctx.dt, ctx.dims = dt, (B, Ho, Wo)
-        ctx.save_for_backward(col, s1, idx, sc, w1)
+        ctx.save_for_backward(col, pool, idx, sc, w1)          # (the un-pooled activation s1 is not kept: see backward)
         ctx.mark_non_differentiable(idx)
         ctx.out_hw = (Hp, Wp)
         return pool
 
     @staticmethod
     def backward(ctx, g):
-        col, s1, idx, sc, w1 = ctx.saved_tensors
+        col, pool, idx, sc, w1 = ctx.saved_tensors
         dt = ctx.dt
         B, Ho, Wo = ctx.dims
-        gs = ops.maxpool_bwd(dt, _as(g, dt), idx, s1, B, Ho, Wo, 64)          # routed by argmax, masked by the stem ReLU
+        # routed by argmax, masked by the stem ReLU: the selected element is the window maximum = the pooled value
+        gs = ops.maxpool_bwd(dt, _as(g, dt), idx, None, B, Ho, Wo, 64, y=pool)
         G = ops.wgrad(dt, gs, col, gs.shape[0], ConvGeom(1, 1, 128, 64), rowscale=sc).view(64, 128)
         dw0, db0 = ops.stem_conv0_grad(G, w1)
         return None, dw0, db0, None, None, None, None, None, None

@@ -104,6 +104,7 @@ SIGNATURES = {
     'sedt_stem_conv0_grad': (_i, [_vp, _vp, _vp, _vp, _vp]),
     'sedt_maxpool_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'sedt_maxpool_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'sedt_maxpool_bwd_y': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'sedt_avgpool': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'sedt_sumsq': (_i, [_vp, _i64, _vp, _vp, _sz, _i, _vp]),
     'sedt_sumsq_scratch': (_sz, [_i64]),

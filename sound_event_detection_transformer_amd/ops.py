@@ -573,9 +573,12 @@ def maxpool_fwd(dtype, x, B, H, W, Cch):
     return y, idx, Ho, Wo
 
 
-def maxpool_bwd(dtype, dy, idx, relu_src, B, H, W, Cch):
+def maxpool_bwd(dtype, dy, idx, relu_src, B, H, W, Cch, y=None):
+    """dx of the 3x3/s2 max-pool, optionally through the ReLU that produced the pooled tensor: relu_src = that tensor at
+    full resolution, or (cheaper) y = the pooled output itself"""
     dx = torch.empty((B * H * W, Cch), device=dy.device, dtype=dy.dtype)
-    L.check(L.load().sedt_maxpool_bwd(_p(dy), _p(idx), _p(relu_src), _p(dx), B, H, W, Cch, dtype, L.stream_ptr()), 'maxpool_bwd')
+    L.check(L.load().sedt_maxpool_bwd_y(_p(dy), _p(idx), _p(relu_src), _p(y), _p(dx), B, H, W, Cch, dtype, L.stream_ptr()),
+            'maxpool_bwd')
     return dx
 
 

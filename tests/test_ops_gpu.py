@@ -261,6 +261,13 @@ def test_maxpool(ops, dt):
     else:   # bf16 ties may route the gradient to another tap of equal value: allow a small mismatch fraction
         frac = ((dx.float().cpu() - _nhwc(ref).reshape(-1, Cc)).abs() > 1e-2).float().mean().item()
         assert frac < 0.02
+    # the ReLU mask taken from the pooled output (stem path): pool(relu(x)) backward == maxpool_bwd(..., y=pooled) bit for bit
+    xp = dev(_nhwc(F.relu(x)).reshape(-1, Cc), dt)
+    y2, idx2, _, _ = ops.maxpool_fwd(dt, xp, B, H, W, Cc)
+    gyd = dev(_nhwc(gy).reshape(-1, Cc), dt)
+    a = ops.maxpool_bwd(dt, gyd, idx2, xp, B, H, W, Cc)
+    b = ops.maxpool_bwd(dt, gyd, idx2, None, B, H, W, Cc, y=y2)
+    assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize('dt', [F32, BF16])
