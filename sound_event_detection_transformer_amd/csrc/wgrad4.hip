@@ -10,7 +10,7 @@
 //     issue of a later tile) while the other is in its "math" segment (8 MFMAs).  Ordering rules as in igemm3.hip:
 //     a tile is waited for (counted vmcnt) at the end of the load segment of the tile before it; a buffer is restaged
 //     one stage after its last reads, which retired (lgkmcnt(0)) before the barrier that ended their segment.
-// Envelope: bf16, M % 128 == 0, N % 128 == 0, M >= 256, N >= 256, no fused bias sums, wgrad3's conv condition.
+// Envelope: bf16, M % 128 == 0, N % 128 == 0, M >= 256, N >= 256, wgrad3's conv condition; fused bias sums opt-in.
 #include <stdlib.h>
 #include <algorithm>
 #include "wgrad3_body.h"
@@ -185,6 +185,22 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
                                                               acc[i][j], 0, 0, 0);
   };
 
+  // optional bias gradient (column sums of dY) by the column-tile-0 workgroups: thread = (channel, pixel quarter), summed
+  // from the dY image in the load segment of either group (all 512 threads take part, each in its own group's segment)
+  const bool do_colsum = p.colsum_out != nullptr && n0 == 0;
+  float bsum = 0.f;
+  const int cs_ch = t & 127, cs_q = t >> 7;
+  auto colsum_tile = [&](const int stage) {
+    const unsigned char* st = smem + stage * STAGE_BYTES;
+    const int c8 = cs_ch >> 3;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int pixrow = cs_q * 16 + r;
+      const int phys = (c8 & ~7) | ((c8 & 7) ^ w3_swz(pixrow));
+      bsum += (float)*reinterpret_cast<const bf16_t*>(st + pixrow * IMG_ROWB + phys * 16 + (cs_ch & 7) * 2);
+    }
+  };
+
   // ---- ping-pong ring (see igemm3.hip): load segment | barrier | math segment, group 1 one barrier behind group 0
 #pragma unroll
   for (int s0 = 0; s0 < S - 1; ++s0)
@@ -198,6 +214,7 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
     for (int ph = 0; ph < S; ++ph) {
       __builtin_amdgcn_s_barrier();
       load_frags(ph);
+      if (do_colsum) colsum_tile(ph);
       issue((ph + S - 1) % S);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -214,6 +231,7 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
         const bool more = it + ph + S - 1 < nkb;
         __builtin_amdgcn_s_barrier();
         load_frags(ph);
+        if (do_colsum) colsum_tile(ph);
         if (more) issue((ph + S - 1) % S);
         if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -227,6 +245,15 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
   }
   if (kgrp == 0) __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_s_barrier();
+
+  if (do_colsum) {
+    float* red = reinterpret_cast<float*>(smem);
+    red[t] = bsum;
+    __syncthreads();
+    if (t < 128)
+      p.colsum_out[(long)(p.splitk > 1 ? by : 0) * p.M + m0 + t] = (red[t] + red[t + 128]) + (red[t + 256] + red[t + 384]);
+    __syncthreads();
+  }
 
   // ---- epilogue: the two groups' halves of the K sum meet in LDS, then 16-byte rows go to the slab / gradient
   constexpr int CP = BN + 4;
@@ -305,7 +332,14 @@ bool wgrad4_ok(const SedtIgemm& p) {
     const char* e = getenv("SEDT_WGRAD_V4");
     on = (e && e[0] == '0') ? 0 : 1;
   }
-  return on && p.trans && wgrad4_shape_ok(p.M, p.N) && p.colsum_out == nullptr && p.out_f32 &&
+  // problems with a fused bias gradient are the transformer linears: measured on the full step they are better off in the
+  // 64x64 grouped launch with the rest of their layer (6.05 vs 6.10-6.13 ms); SEDT_WGRAD4_BIAS=1 sends them here (tests do)
+  static int with_bias = -1;
+  if (with_bias < 0) {
+    const char* e = getenv("SEDT_WGRAD4_BIAS");
+    with_bias = (e && e[0] == '1') ? 1 : 0;
+  }
+  return on && p.trans && wgrad4_shape_ok(p.M, p.N) && (p.colsum_out == nullptr || with_bias) && p.out_f32 &&
          (p.splitk > 1 ? p.slab != nullptr : ((p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0)) &&
          (reinterpret_cast<uintptr_t>(p.slab) & 15) == 0;
 }

@@ -516,6 +516,11 @@ def test_wgrad_large_tiles(ops, dt, cfg):
     xd, gyd = dev(_nhwc(x).reshape(-1, Ci), dt), dev(_nhwc(gy).reshape(-1, Co), dt)
     dw = ops.wgrad(dt, gyd, xd, B, g)
     close(dw, w.grad, dt, bf16_tol=2e-3)          # same bf16-rounded inputs, f32 accumulation: only summation order differs
+    # with the bias gradient (column sums of dY) fused into the same launch
+    db = torch.empty(Co, device='cuda', dtype=torch.float32)
+    dwb = ops.wgrad(dt, gyd, xd, B, g, bias_out=db)
+    assert torch.equal(dwb, dw)
+    close(db, rnd(gy, dt).sum((0, 2, 3)), dt, bf16_tol=1e-4)
     # the grouped launch (one wide + one small problem) gives the same numbers
     rb = ops.ReduceBatch()
     dw2 = ops.wgrad(dt, gyd, xd, B, g, batch=rb)
