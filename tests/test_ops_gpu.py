@@ -519,7 +519,7 @@ def test_wgrad_large_tiles(ops, dt, cfg):
     # with the bias gradient (column sums of dY) fused into the same launch
     db = torch.empty(Co, device='cuda', dtype=torch.float32)
     dwb = ops.wgrad(dt, gyd, xd, B, g, bias_out=db)
-    assert torch.equal(dwb, dw)
+    close(dwb, w.grad, dt, bf16_tol=2e-3)          # (same kernel as dw only under SEDT_WGRAD4_BIAS=1)
     close(db, rnd(gy, dt).sum((0, 2, 3)), dt, bf16_tol=1e-4)
     # the grouped launch (one wide + one small problem) gives the same numbers
     rb = ops.ReduceBatch()
