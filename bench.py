@@ -197,7 +197,7 @@ def main():
         avg_s = tot_ms / 1e3 / max(n, 1)
         peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
         ach = flops_launch / avg_s / 1e12
-        roof = {"bound": "mfma", "kernel": "sedt::igemm3_kernel + sedt::wgrad3_kernel (MFMA implicit-GEMM family: every conv/linear fwd, dgrad, wgrad launch)", "achieved": round(ach, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
+        roof = {"bound": "mfma", "kernel": "sedt::igemm3_kernel / igemm3_w8_kernel + sedt::wgrad3_kernel / wgrad4_kernel (MFMA implicit-GEMM family: every conv/linear fwd, dgrad, wgrad launch)", "achieved": round(ach, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
                 "frac": round(ach / (peak / 1e12), 4), "traffic": None, "launches_per_step": n,
                 "avg_launch_us": round(avg_s * 1e6, 2), "igemm_ms_per_step": round(tot_ms, 3),
                 "algorithmic_flop_per_launch": flops_launch}
