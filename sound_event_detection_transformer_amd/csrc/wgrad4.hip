@@ -17,6 +17,13 @@
 
 namespace sedt {
 
+// XOR swizzle of the 16-byte chunk index (4 bits: 16 chunks per 256-byte image row).  A transposing read serves 32 lanes per
+// LDS cycle: four consecutive pixel rows x one 64-byte quarter row each - and with 256-byte rows every row starts at bank 0,
+// so the four rows must sit in four different quarters: chunk bits 3:2 ^= row bits 1:0.  (The first version re-used wgrad3's
+// 128-byte-row swizzle on the low three chunk bits: rows r and r+1 shared a quarter, 49 % of the LDS cycles were bank
+// conflicts by SQ_LDS_BANK_CONFLICT.)
+__device__ __forceinline__ int w4_swz(int row) { return (row & 3) << 2; }
+
 template <bool CONV>
 __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int nmajor,
                                             const int bx, const int by) {
@@ -57,8 +64,8 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, b_bytes, 0x00020000);
 
-  // ---- DMA lanes: instruction `instr` covers image rows [instr*4, +4) x 16 chunks; the XOR swizzle acts on the low three
-  //      chunk bits (inside each 128-byte half row), the physical chunk a lane writes holds logical chunk lchunk
+  // ---- DMA lanes: instruction `instr` covers image rows [instr*4, +4) x 16 chunks; the physical chunk a lane writes holds
+  //      logical chunk lchunk = pchunk ^ w4_swz(row)
   const int drow = lane / CPR, pchunk = lane % CPR;
   unsigned a_poff[GA];
   int a_trow[GA];
@@ -66,7 +73,7 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
 #pragma unroll
   for (int i = 0; i < GA; ++i) {
     const int trow = (i * NW + wave) * RPI + drow;
-    const int lchunk = (pchunk & ~7) | ((pchunk & 7) ^ w3_swz(trow));
+    const int lchunk = pchunk ^ w4_swz(trow);
     a_trow[i] = trow;
     a_poff[i] = (unsigned)((((long)kb_begin * BKP + trow) * p.lda + m0 + lchunk * 8) * 2);
   }
@@ -79,7 +86,7 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
 #pragma unroll
   for (int i = 0; i < GB; ++i) {
     const int trow = (i * NW + wave) * RPI + drow;
-    const int lchunk = (pchunk & ~7) | ((pchunk & 7) ^ w3_swz(trow));
+    const int lchunk = pchunk ^ w4_swz(trow);
     const int j = n0 + lchunk * 8;
     b_trow[i] = trow;
     bool ok = true;
@@ -154,8 +161,7 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
         const int a_ch = wm + j * 32 + (grp & 1) * 16 + (s16 & 3) * 4;
         const int b_ch = wn + j * 32 + (grp & 1) * 16 + (s16 & 3) * 4;
         const int a8 = a_ch >> 3, b8 = b_ch >> 3;
-        const int aphys = (a8 & ~7) | ((a8 & 7) ^ w3_swz(pixrow));
-        const int bphys = (b8 & ~7) | ((b8 & 7) ^ w3_swz(pixrow));
+        const int aphys = a8 ^ w4_swz(pixrow), bphys = b8 ^ w4_swz(pixrow);
         a_rd[kq][j][h2] = pixrow * IMG_ROWB + aphys * 16 + ((a_ch >> 2) & 1) * 8;
         b_rd[kq][j][h2] = IMG_BYTES + pixrow * IMG_ROWB + bphys * 16 + ((b_ch >> 2) & 1) * 8;
       }
@@ -196,7 +202,7 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int pixrow = cs_q * 16 + r;
-      const int phys = (c8 & ~7) | ((c8 & 7) ^ w3_swz(pixrow));
+      const int phys = c8 ^ w4_swz(pixrow);
       bsum += (float)*reinterpret_cast<const bf16_t*>(st + pixrow * IMG_ROWB + phys * 16 + (cs_ch & 7) * 2);
     }
   };
