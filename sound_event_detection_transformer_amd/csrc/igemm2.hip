@@ -165,10 +165,10 @@ __global__ __launch_bounds__(256) void igemm2_kernel(const SedtIgemm p, const un
     // tiles issued after `it` and still allowed in flight: min(STAGES-2, nkb-1-it)
     if (it + STAGES - 2 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * G) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     compute(it, (it + STAGES - 1 < nkb) ? it + STAGES - 1 : -1);
   }
-  __builtin_amdgcn_s_barrier();   // everyone is done reading the ring: reuse it for the C tile
+  lds_barrier();   // everyone is done reading the ring: reuse it for the C tile
 
   // ---- epilogue through LDS: f32 tile [BM][BN + 4]
   constexpr int CP = BN + 4;

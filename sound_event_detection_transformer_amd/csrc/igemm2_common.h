@@ -29,4 +29,14 @@ __device__ __forceinline__ long gather_pix2(const Geom2& g, int n, int ho, int w
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+// Workgroup barrier that first retires this wave's outstanding LDS operations.  A bare s_barrier orders nothing in LDS: the
+// compiler may schedule it ABOVE the lgkmcnt wait of the last fragment reads (their consumers are MFMAs, not memory
+// operations), and then another wave that passed the barrier can overwrite the buffer - the f32 staging tile of the epilogue
+// aliases the ring - before those reads have executed.  Seen on the single-stage K = 64 kernel: sporadic wrong elements, found
+// by the bit-reproducibility test of the full-size step.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
 }  // namespace sedt

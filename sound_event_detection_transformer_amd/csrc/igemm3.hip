@@ -253,17 +253,17 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       if (s0 < nkb) issue(s0);
     if (nkb >= S - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (kgrp == 1) __builtin_amdgcn_s_barrier();
+    if (kgrp == 1) lds_barrier();
     int it = 0;
     for (; it + 2 * S - 1 <= nkb; it += S) {
 #pragma unroll
       for (int ph = 0; ph < S; ++ph) {
-        __builtin_amdgcn_s_barrier();
+        lds_barrier();
         load_frags(ph);
         issue((ph + S - 1) % S);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");      // tile s+1 complete (own pieces)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        lds_barrier();
         __builtin_amdgcn_s_setprio(1);
         mfma_all();
         __builtin_amdgcn_s_setprio(0);
@@ -274,27 +274,27 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       for (int ph = 0; ph < S; ++ph) {
         if (it + ph < nkb) {
           const bool more = it + ph + S - 1 < nkb;
-          __builtin_amdgcn_s_barrier();
+          lds_barrier();
           load_frags(ph);
           if (more) issue((ph + S - 1) % S);
           if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
+          lds_barrier();
           __builtin_amdgcn_s_setprio(1);
           mfma_all();
           __builtin_amdgcn_s_setprio(0);
         }
       }
     }
-    if (kgrp == 0) __builtin_amdgcn_s_barrier();
+    if (kgrp == 0) lds_barrier();
   } else {
   if constexpr (S == 1) {
     // single K tile (K = 64: the 64 -> 256 convolutions of layer1): no ring, half the LDS, twice the resident workgroups -
     // these problems are pure HBM streams and only occupancy hides their latency
     issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     compute(0);
   }
 #pragma unroll
@@ -306,7 +306,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
 #pragma unroll
     for (int ph = 0; ph < S; ++ph) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S >= 2 ? S - 2 : 0) * G) : "memory");
-      __builtin_amdgcn_s_barrier();
+      lds_barrier();
       load_frags(ph);
       issue((ph + S - 1) % S);
       mfma_all();
@@ -318,7 +318,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       const bool more = it + ph + S - 1 < nkb;
       if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S >= 2 ? S - 2 : 0) * G) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      lds_barrier();
       load_frags(ph);
       if (more) issue((ph + S - 1) % S);
       mfma_all();
@@ -328,11 +328,11 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   for (int ph = 0; ph < S - 1; ++ph)
     if (it + ph < nkb) {                     // tail: already issued, nothing left to prefetch
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      lds_barrier();
       compute(ph);
     }
   }
-  __builtin_amdgcn_s_barrier();
+  lds_barrier();
 
   // ---- epilogue through LDS (identical to igemm2)
   constexpr int CP = BN + 4;

@@ -157,13 +157,13 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(const SedtIgemm p, const un
   for (int it = 0; it < nkb; ++it) {
     if (it + STAGES - 2 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * G) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     if (it + STAGES - 1 < nkb) issue(kb_begin + it + STAGES - 1);
     compute(kb_begin + it);
     if (do_colsum) colsum_tile(kb_begin + it);
   }
   if (do_colsum) {
-    __builtin_amdgcn_s_barrier();                      // ring no longer read: reuse it for the 4-way reduction
+    lds_barrier();                      // ring no longer read: reuse it for the 4-way reduction
     float* red = reinterpret_cast<float*>(smem);
     red[t] = bsum;
     __syncthreads();

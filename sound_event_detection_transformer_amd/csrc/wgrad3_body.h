@@ -216,7 +216,7 @@ __device__ __forceinline__ void wgrad3_impl(const SedtIgemm& p, const unsigned a
       const bool more = it + ph + WS - 1 < nkb;
       if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((WS - 2) * G) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      lds_barrier();
       if (more) issue((ph + WS - 1) % WS);
       compute(ph);
       if (do_colsum) colsum_tile(ph);
@@ -226,12 +226,12 @@ __device__ __forceinline__ void wgrad3_impl(const SedtIgemm& p, const unsigned a
   for (int ph = 0; ph < WS - 1; ++ph)
     if (it + ph < nkb) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      lds_barrier();
       compute(ph);
       if (do_colsum) colsum_tile(ph);
     }
   if (do_colsum) {
-    __builtin_amdgcn_s_barrier();
+    lds_barrier();
     float* red = reinterpret_cast<float*>(smem);
     red[t] = bsum;
     __syncthreads();

@@ -213,18 +213,18 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
     if (s0 < nkb) issue(s0);
   if (nkb >= S - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (kgrp == 1) __builtin_amdgcn_s_barrier();
+  if (kgrp == 1) lds_barrier();
   int it = 0;
   for (; it + 2 * S - 1 <= nkb; it += S) {
 #pragma unroll
     for (int ph = 0; ph < S; ++ph) {
-      __builtin_amdgcn_s_barrier();
+      lds_barrier();
       load_frags(ph);
       if (do_colsum) colsum_tile(ph);
       issue((ph + S - 1) % S);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      lds_barrier();
       __builtin_amdgcn_s_setprio(1);
       mfma_all();
       __builtin_amdgcn_s_setprio(0);
@@ -235,22 +235,22 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
     for (int ph = 0; ph < S; ++ph) {
       if (it + ph < nkb) {
         const bool more = it + ph + S - 1 < nkb;
-        __builtin_amdgcn_s_barrier();
+        lds_barrier();
         load_frags(ph);
         if (do_colsum) colsum_tile(ph);
         if (more) issue((ph + S - 1) % S);
         if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * G) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        lds_barrier();
         __builtin_amdgcn_s_setprio(1);
         mfma_all();
         __builtin_amdgcn_s_setprio(0);
       }
     }
   }
-  if (kgrp == 0) __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_s_barrier();
+  if (kgrp == 0) lds_barrier();
+  lds_barrier();
 
   if (do_colsum) {
     float* red = reinterpret_cast<float*>(smem);

@@ -403,3 +403,44 @@ def test_spsedt_bf16_train_step_runs_and_tracks_f32(pkg, golden_dir):
         assert all(torch.isfinite(p).all() for p in model.parameters())
     runtime.set_compute_dtype('f32')
     assert abs(losses['bf16'] - losses['f32']) < 3e-2 * abs(losses['f32']), losses
+
+
+def test_full_size_step_is_deterministic_and_trains(pkg):
+    """BASELINE size (C2: B = 64, 10 s @ 64 mel, E = 3, Q = 10, bf16, the one-graph step): size-independent properties -
+    two independently captured steppers fed the same batches end with BIT-IDENTICAL parameters (no atomics anywhere in the
+    path: split-K slabs, column sums and the gradient norm are summed in fixed orders), every loss is finite, parameters
+    move, and repeating one batch drives its loss down"""
+    A, runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import build_optimizer, GraphedTrainStep
+    runtime.set_compute_dtype('bf16')
+    B = 64
+    gen = torch.Generator().manual_seed(11)
+    batches = [(torch.randn(B, 1, 500, 64, generator=gen).cuda(), synthetic_targets(B, 300 + i, 10)) for i in range(2)]
+    finals, curves = [], []
+    for run in range(2):
+        model, crit = _build(sedt, 3, 10, dropout=0.0, dec_at=True)
+        _seed_load(model, 2020).cuda().train()
+        crit.cuda()
+        opt = build_optimizer(model)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        stepper = GraphedTrainStep(model, crit, opt, batches[0][0], batches[0][1], None, slice(B), warmup=2)
+        model.load_state_dict(sd0)
+        opt._m.zero_(); opt._v.zero_(); opt._step_t.zero_()
+        losses = []
+        for it in range(6):
+            xb, tb = batches[0] if it != 2 else batches[1]          # one different batch in between
+            l, _ = stepper(xb, tb)
+            losses.append(float(l))
+        torch.cuda.synchronize()
+        curves.append(losses)
+        finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+        if run == 0:
+            moved = max((finals[0][k].float() - sd0[k].float()).abs().max().item() for k in sd0 if sd0[k].dtype.is_floating_point)
+            assert moved > 0
+    runtime.set_compute_dtype('f32')
+    assert all(np.isfinite(c).all() for c in curves)
+    assert curves[0] == curves[1]
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+    same = [curves[0][i] for i in (0, 1, 3, 4, 5)]               # the repeated batch
+    assert same[-1] < same[0]

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Is the graphed train step bit-reproducible?  Same weights, same batch: losses / outputs of repeated runs."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sound_event_detection_transformer_amd import runtime
+from sound_event_detection_transformer_amd.sedt import build_model, default_args
+from sound_event_detection_transformer_amd.engine import build_optimizer, GraphedTrainStep
+from sound_event_detection_transformer_amd.utilities.synthetic import seeded_state_dict, synthetic_batch
+
+runtime.set_compute_dtype('bf16')
+dev = torch.device('cuda:0')
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+model, crit, _ = build_model(default_args(enc_layers=3, num_queries=10, dec_at=True, dropout=0.0))
+model.load_state_dict(seeded_state_dict(model.state_dict(), 2020))
+model.to(dev).train(); crit.to(dev)
+x, targets = synthetic_batch(B, 500, 2020, dev)
+model.eval()
+with torch.no_grad():
+    o1 = model(x); o2 = model(x)
+print('eval forward bit-identical:', {k: bool(torch.equal(o1[k], o2[k])) for k in ('pred_logits', 'pred_boxes')})
+model.train()
+opt = build_optimizer(model)
+sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+st = GraphedTrainStep(model, crit, opt, x, targets, None, slice(B), warmup=2)
+for rep in range(3):
+    model.load_state_dict(sd0); opt._m.zero_(); opt._v.zero_(); opt._step_t.zero_()
+    l, d = st(x, targets)
+    torch.cuda.synchronize()
+    print(rep, float(l), {k: round(float(v), 6) for k, v in list(d.items())[:6]})
+    p = torch.cat([v.detach().float().flatten() for v in model.parameters()])
+    print('   param checksum', float(p.double().sum()), float(p.double().abs().sum()))
