@@ -10,10 +10,13 @@ from sound_event_detection_transformer_amd.utilities.synthetic import seeded_sta
 runtime.set_compute_dtype('bf16')
 dev = torch.device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-model, crit, _ = build_model(default_args(enc_layers=3, num_queries=10, dec_at=True, dropout=0.0))
+E = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+Q = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+T = int(sys.argv[4]) if len(sys.argv) > 4 else 500
+model, crit, _ = build_model(default_args(enc_layers=E, dec_layers=(6 if E == 6 else 3), num_queries=Q, dec_at=True, dropout=0.0))
 model.load_state_dict(seeded_state_dict(model.state_dict(), 2020))
 model.to(dev).train(); crit.to(dev)
-x, targets = synthetic_batch(B, 500, 2020, dev)
+x, targets = synthetic_batch(B, T, 2020, dev)
 model.eval()
 with torch.no_grad():
     o1 = model(x); o2 = model(x)
