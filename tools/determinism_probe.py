@@ -13,7 +13,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 E = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 Q = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 T = int(sys.argv[4]) if len(sys.argv) > 4 else 500
-model, crit, _ = build_model(default_args(enc_layers=E, dec_layers=(6 if E == 6 else 3), num_queries=Q, dec_at=True, dropout=0.0))
+model, crit, _ = build_model(default_args(enc_layers=E, dec_layers=(6 if E == 6 else 3), num_queries=Q, dec_at=True, dropout=float(os.environ.get('DROPOUT', '0'))))
 model.load_state_dict(seeded_state_dict(model.state_dict(), 2020))
 model.to(dev).train(); crit.to(dev)
 x, targets = synthetic_batch(B, T, 2020, dev)
@@ -25,8 +25,9 @@ model.train()
 opt = build_optimizer(model)
 sd0 = {k: v.clone() for k, v in model.state_dict().items()}
 st = GraphedTrainStep(model, crit, opt, x, targets, None, slice(B), warmup=2)
-for rep in range(3):
+for rep in range(int(os.environ.get("REPS", "3"))):
     model.load_state_dict(sd0); opt._m.zero_(); opt._v.zero_(); opt._step_t.zero_()
+    runtime.seed_ptr(dev).zero_()                      # same dropout masks on every repeat
     l, d = st(x, targets)
     torch.cuda.synchronize()
     print(rep, float(l), {k: round(float(v), 6) for k, v in list(d.items())[:6]})
