@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __r
     const float inv = 1.f / sum;
     if (hf == 0 && qi < Lq) lse[((long)b * H + h) * Lq + qi] = m + __logf(sum);
     const uint64_t rowbase = ((uint64_t)bh * Lq + qi) * Lk;
+    const uint32_t d_hi = (uint32_t)(rowbase >> 33), d_inner = drop_inner(sd, d_hi);      // seed half of the dropout hash, once per row
     // pass 2: O = dropout(P) V, scores recomputed tile by tile (two MFMAs per tile - cheaper than keeping them)
     f32x16 oacc;
 #pragma unroll
@@ -151,13 +152,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __r
       for (int u = 0; u < 2; ++u) {
         float pv[8];
 #pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
-          float p = __expf(st[8 * u + s8] - m) * inv;
-          if (thresh) {
-            const int key = kt * 32 + crow(8 * u + s8, hf);
-            p = drop_keep(sd, rowbase + key, thresh) ? p * inv_keep : 0.f;
+        for (int s4 = 0; s4 < 2; ++s4) {                  // a lane's keys come in runs of four: two hashes per run
+          uint32_t keep = 0xfu;
+          if (thresh) keep = drop_keep4(d_inner, d_hi, sd, rowbase + (kt * 32 + crow(8 * u + 4 * s4, hf)), thresh);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float p = __expf(st[8 * u + 4 * s4 + e] - m) * inv;
+            pv[4 * s4 + e] = (keep >> e & 1u) ? (thresh ? p * inv_keep : p) : 0.f;
           }
-          pv[s8] = p;
         }
         oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(pv), frag_cols_tr(Vi, kt * 32 + 16 * u, lane), oacc, 0, 0, 0);
       }
@@ -221,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_mfma_kernel(const bf16_t* __r
     const int qi = q0 + (lane & 31);
     const float lq = Ls[qi], dlq = De[qi];
     const uint64_t rowbase = ((uint64_t)bh * Lq + qi) * Lk;
+    const uint32_t d_hi = (uint32_t)(rowbase >> 33), d_inner = drop_inner(sd, d_hi);
     f32x16 dqa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqa[r] = 0.f;
@@ -243,6 +246,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_mfma_kernel(const bf16_t* __r
           const int key0 = kt * 32 + 16 * u + 8 * g2 + 4 * hf;
           const float4 kb = *reinterpret_cast<const float4*>(Kb + key0);
           const float kbv[4] = {kb.x, kb.y, kb.z, kb.w};
+          uint32_t keep = 0xfu;
+          if (thresh) keep = drop_keep4(d_inner, d_hi, sd, rowbase + key0, thresh);      // four consecutive keys: two hashes
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 8 * u + 4 * g2 + e, key = key0 + e;
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_mfma_kernel(const bf16_t* __r
             if (AMASK) { if (qi < Lq && key < Lk) sc += amask[(long)qi * Lk + key]; }
             const float p = __expf(sc - lq);
             float g = dp[r];
-            if (thresh) g = drop_keep(sd, rowbase + key, thresh) ? g * inv_keep : 0.f;
+            if (thresh) g = (keep >> e & 1u) ? g * inv_keep : 0.f;
             ds[4 * g2 + e] = (qi < Lq) ? p * (g - dlq) : 0.f;
           }
         }
@@ -268,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_mfma_kernel(const bf16_t* __r
   for (int k0 = wave * 32; k0 < Lk; k0 += nwave * 32) {
     const int kj = k0 + (lane & 31);                    // this lane's key
     const float kbj = Kb[kj];
+    const uint32_t k_hi = (uint32_t)((((uint64_t)bh * Lq) * Lk) >> 33), k_inner = drop_inner(sd, k_hi);   // seed half of the dropout hash
     f32x16 dkt, dvt;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dkt[r] = 0.f; dvt[r] = 0.f; }
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_mfma_kernel(const bf16_t* __r
             float p = (qr < Lq) ? __expf(sc - lv[e]) : 0.f;
             float g = dp[r], pk = p;
             if (thresh) {
-              const bool keep = drop_keep(sd, ((uint64_t)bh * Lq + qr) * Lk + kj, thresh);
+              const bool keep = drop_keep_in(k_inner, k_hi, sd, ((uint64_t)bh * Lq + qr) * Lk + kj, thresh);
               g = keep ? g * inv_keep : 0.f;
               pk = keep ? p * inv_keep : 0.f;
             }

@@ -50,6 +50,33 @@ __device__ __forceinline__ bool drop_keep(uint32_t seed, uint64_t idx, uint32_t 
   const uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xffffu);
   return bits >= thresh;
 }
+// The same decisions as drop_keep with the seed-only half of the hash taken out of the inner loops (the attention kernels
+// draw one decision per probability and were VALU-bound on this hash: 100 VALU per MFMA by PMC).
+// drop_inner: the (seed, high index word) part; valid for every element whose hash index idx >> 1 has that high word.
+__device__ __forceinline__ uint32_t drop_inner(uint32_t seed, uint32_t hi) { return mix32(seed ^ (hi * 0x9E3779B9U) ^ 0x85ebca6bU); }
+__device__ __forceinline__ bool drop_keep_in(uint32_t inner, uint32_t inner_hi, uint32_t seed, uint64_t idx, uint32_t thresh) {
+  const uint64_t hidx = idx >> 1;
+  const uint32_t hi = (uint32_t)(hidx >> 32);
+  const uint32_t in = hi == inner_hi ? inner : drop_inner(seed, hi);          // (never taken below 2^33 elements)
+  const uint32_t h = mix32((uint32_t)hidx ^ in);
+  const uint32_t bits = (idx & 1) ? (h >> 16) : (h & 0xffffu);
+  return bits >= thresh;
+}
+// four consecutive elements idx0 .. idx0+3: bit e of the result = keep(idx0 + e).  Two hashes when idx0 is even.
+__device__ __forceinline__ uint32_t drop_keep4(uint32_t inner, uint32_t inner_hi, uint32_t seed, uint64_t idx0, uint32_t thresh) {
+  if (idx0 & 1) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m |= (drop_keep_in(inner, inner_hi, seed, idx0 + e, thresh) ? 1u : 0u) << e;
+    return m;
+  }
+  const uint64_t h0 = idx0 >> 1, h1 = h0 + 1;
+  const uint32_t in0 = (uint32_t)(h0 >> 32) == inner_hi ? inner : drop_inner(seed, (uint32_t)(h0 >> 32));
+  const uint32_t in1 = (uint32_t)(h1 >> 32) == inner_hi ? inner : drop_inner(seed, (uint32_t)(h1 >> 32));
+  const uint32_t ha = mix32((uint32_t)h0 ^ in0), hb = mix32((uint32_t)h1 ^ in1);
+  return ((ha & 0xffffu) >= thresh ? 1u : 0u) | ((ha >> 16) >= thresh ? 2u : 0u) | ((hb & 0xffffu) >= thresh ? 4u : 0u) |
+         ((hb >> 16) >= thresh ? 8u : 0u);
+}
 // keep-decisions of 8 consecutive elements base .. base+7 (base % 8 == 0) as a bit mask - the same decisions as drop_keep, with
 // the part of the hash that depends only on (seed, high index word) computed once instead of four times
 __device__ __forceinline__ uint32_t drop_keep8(uint32_t seed, uint64_t base, uint32_t thresh) {
