@@ -1,0 +1,60 @@
+"""Seeded INPUTS of the fixtures G9-G12, shared by make_golden.py (which feeds them to the reference) and by the tests
+(which feed them to the oracle / the HIP path).  Data only: no reference code, no expected values."""
+import torch
+
+from oracle.criterion_oracle import synthetic_targets
+
+
+def clip_input(b, t, seed):
+    return torch.randn(b, 1, t, 64, generator=torch.Generator().manual_seed(seed))
+
+
+def g9_inputs():
+    g = torch.Generator().manual_seed(91)
+    B, Q = 6, 10
+    outputs = {'pred_logits': torch.randn(B, Q, 11, generator=g) * 2, 'pred_boxes': torch.rand(B, Q, 2, generator=g) * 0.6 + 0.2,
+               'at': torch.rand(B, 10, generator=g),
+               'aux_outputs': [{'pred_logits': torch.randn(B, Q, 11, generator=g) * 2,
+                                'pred_boxes': torch.rand(B, Q, 2, generator=g) * 0.6 + 0.2} for _ in range(2)]}
+    return outputs, synthetic_targets(B, 92, 10), B, Q
+
+
+def g10_inputs():
+    g = torch.Generator().manual_seed(101)
+    B, Q, C = 5, 10, 10
+    outputs = {'pred_logits': torch.randn(B, Q, C + 1, generator=g) * 2.5, 'pred_boxes': torch.rand(B, Q, 2, generator=g) * 0.5 + 0.1}
+    tags = (torch.rand(B, C, generator=g) > 0.5).long()
+    sizes = torch.tensor([10.0, 10.0, 7.5, 10.0, 4.0])
+    return outputs, tags, sizes
+
+
+def g11_inputs():
+    g = torch.Generator().manual_seed(111)
+    B, Q, C = 8, 20, 10
+    logits = torch.randn(B, Q, C + 1, generator=g) * 3
+    logits[..., -1] -= 1.0
+    tea = {'pred_logits': logits, 'pred_boxes': torch.stack([torch.rand(B, Q, generator=g) * 0.7 + 0.15,
+                                                             torch.rand(B, Q, generator=g) * 0.4], -1),
+           'at': torch.rand(B, C, generator=g)}
+    tea['pred_boxes'][0, :5, 1] = 0.01                   # shorter than 0.2 / 10 s: dropped
+    thr = torch.rand(C, generator=g) * 0.25 + 0.3
+    return tea, thr, B
+
+
+SEMI = dict(n_strong=2, n_weak=2, n_unl=4, T=496, thr=0.115, seed_w=2021, seed_x=71, seed_t=72)
+
+
+def semi_batch():
+    c = SEMI
+    B = c['n_strong'] + c['n_weak'] + c['n_unl']
+    x_t = clip_input(B, c['T'], c['seed_x'])
+    x_s = x_t.clone()
+    x_s[c['n_strong'] + c['n_weak']:] += 0.1 * clip_input(c['n_unl'], c['T'], c['seed_x'] + 1)    # student view of the unlabelled clips
+    targets = synthetic_targets(B, c['seed_t'], 10)
+    for t in targets[c['n_strong']:]:
+        t['boxes'] = torch.zeros(0, 2)
+    for t in targets[c['n_strong'] + c['n_weak']:]:
+        t['labels'] = torch.zeros(0, dtype=torch.int64)
+    return x_t, x_s, targets
+
+

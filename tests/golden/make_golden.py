@@ -35,6 +35,8 @@ sys.path.insert(0, ROOT)
 
 from oracle import sedt_oracle as O              # noqa: E402
 from oracle.criterion_oracle import synthetic_targets  # noqa: E402
+sys.path.insert(0, HERE)
+from inputs import g9_inputs as _g9_inputs, g10_inputs as _g10_inputs, g11_inputs as _g11_inputs, SEMI, semi_batch as _semi_batch  # noqa: E402
 
 
 # ----------------------------------------------------------------------------- shim
@@ -85,6 +87,34 @@ def install_torchvision_shim():
     for name, mod in (('torchvision', tv), ('torchvision.models', models), ('torchvision.models._utils', mutils),
                       ('torchvision.ops', ops), ('torchvision.ops.boxes', boxes)):
         sys.modules[name] = mod
+
+
+class _AbsentModule(types.ModuleType):
+    """placeholder for third-party modules the reference imports at module level but that this image lacks (librosa,
+    soundfile, dcase_util, sed_eval, psds_eval, torchvision.transforms).  It only lets ``import engine`` /
+    ``import utilities.BoxTransforms`` succeed; NOTHING computed for a fixture comes from it (ApplyLog, the one transform
+    that calls librosa, is never run: see oracle/transforms_oracle.py)."""
+
+    def __getattr__(self, k):
+        if k.startswith('__'):
+            raise AttributeError(k)
+        return type(k, (), {})
+
+
+def import_reference_engine():
+    """reference engine.py / utilities.mixup / utilities.BoxTransforms (after import_reference())"""
+    for name in ('librosa', 'soundfile', 'dcase_util', 'dcase_util.data', 'sed_eval', 'psds_eval', 'torchvision.transforms'):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:
+                sys.modules[name] = _AbsentModule(name)
+    sys.modules['torchvision'].transforms = sys.modules['torchvision.transforms']
+    import engine as rengine
+    import utilities.mixup as rmixup
+    import utilities.BoxTransforms as rbt
+    rengine.to_cuda_if_available = lambda *a: a[0] if len(a) == 1 else list(a)
+    return rengine, rmixup, rbt
 
 
 def import_reference():
@@ -348,12 +378,262 @@ def g6_posenc(out, rsedt):
     print('G6 ok')
 
 
+class recorded_rand(object):
+    """context: torch.rand draws from a seeded generator and every draw is recorded (matcher.py:116 calls torch.rand)"""
+
+    def __init__(self, seed):
+        self.g, self.draws = torch.Generator().manual_seed(seed), []
+
+    def __enter__(self):
+        self.orig = torch.rand
+
+        def fake(*a, **k):
+            r = self.orig(*a, generator=self.g, **k)
+            self.draws.append(r.clone())
+            return r
+        torch.rand = fake
+        return self
+
+    def __exit__(self, *e):
+        torch.rand = self.orig
+        return False
+
+
+def _pad_rows(rows, width, fill):
+    out = np.full((len(rows), width), fill, dtype=np.float32)
+    for i, r in enumerate(rows):
+        r = np.asarray(r, dtype=np.float32).reshape(-1)
+        out[i, :len(r)] = r
+    return out
+
+
+def g9_criterion_variants(out, rsedt):
+    """G9: fine_tune re-matching (two epsilons, +/- normalize) and the focal-loss branches, on fixed outputs/targets."""
+    _, criterion, _ = rsedt.build_model(ref_args())
+    outputs, targets, B, Q = _g9_inputs()
+    res = {}
+    cases = {'ft': dict(fine_tune=True, normalize=False, fl=False, eps=1.0),
+             'ft_eps3': dict(fine_tune=True, normalize=False, fl=False, eps=3.0),
+             'ft_norm_eps3': dict(fine_tune=True, normalize=True, fl=False, eps=3.0),
+             'fl': dict(fine_tune=False, normalize=False, fl=True, eps=1.0),
+             'fl_ft_eps3': dict(fine_tune=True, normalize=False, fl=True, eps=3.0)}
+    for name, c in cases.items():
+        criterion.matcher.epsilon = c['eps']
+        with recorded_rand(900 + len(name)) as rr:
+            loss_dict, indices = criterion(outputs, targets, None, slice(B), c['fine_tune'], c['normalize'], c['fl'])
+        for k, v in loss_dict.items():
+            res[f'{name}_loss_{k}'] = np.float32(v.item())
+        res[f'{name}_src'] = _pad_rows([npy(i) for i, _ in indices], 2 * Q, -1)
+        res[f'{name}_tgt'] = _pad_rows([npy(j) for _, j in indices], 2 * Q, -1)
+        res[f'{name}_rand'] = _pad_rows([npy(r) for r in rr.draws], Q, -1) if rr.draws else np.zeros((0, Q), np.float32)
+    # weak+strong split with focal loss (loss_weak -> weak_focal_loss)
+    t2 = [dict(t) for t in targets]
+    for t in t2[4:]:
+        t['boxes'] = torch.zeros(0, 2)
+    criterion.matcher.epsilon = 1.0
+    loss_dict, _ = criterion(outputs, t2, slice(4, 6), slice(4), False, False, True)
+    for k, v in loss_dict.items():
+        res[f'fl_ws_loss_{k}'] = np.float32(v.item())
+    # mixup-style targets with 'ratio' (positional coefficients, matcher.py:130-131)
+    g = torch.Generator().manual_seed(93)
+    t3 = [dict(t) for t in targets]
+    for t in t3[:3]:
+        t['ratio'] = torch.rand(len(t['labels']), generator=g) * 0.8 + 0.1
+    loss_dict, _ = criterion(outputs, t3, None, slice(B), False, False, False)
+    for k, v in loss_dict.items():
+        res[f'ratio_loss_{k}'] = np.float32(v.item())
+    res['ratio_values'] = _pad_rows([npy(t['ratio']) if 'ratio' in t else [] for t in t3], 9, -1)
+    np.savez_compressed(os.path.join(out, 'g9_criterion_variants.npz'), **res)
+    print('G9 ok', len(res))
+
+
+def g10_postprocess(out, rsedt):
+    """G10: PostProcess for every fusion mode, with and without tags, seconds and is_semi boxes."""
+    pp = rsedt.PostProcess()
+    outputs, tags, sizes = _g10_inputs()
+    res = {}
+    for name, kw in (('none', dict(audio_tags=None)), ('m1', dict(audio_tags=tags, at_m=1)), ('m2', dict(audio_tags=tags, at_m=2)),
+                     ('m3', dict(audio_tags=tags, at_m=3)), ('m2_t03', dict(audio_tags=tags, at_m=2, threshold=0.3)),
+                     ('semi', dict(audio_tags=tags, at_m=1, is_semi=True, threshold=None))):
+        r = pp({k: v.clone() for k, v in outputs.items()}, sizes, **kw)
+        res[f'{name}_scores'] = np.stack([npy(x['scores']) for x in r])
+        res[f'{name}_labels'] = np.stack([npy(x['labels']) for x in r])
+        res[f'{name}_boxes'] = np.stack([npy(x['boxes']) for x in r])
+    np.savez_compressed(os.path.join(out, 'g10_postprocess.npz'), **res)
+    print('G10 ok')
+
+
+def g11_pseudo_labels(out, rsedt, rengine):
+    """G11: engine.get_pseudo_labels on fixed teacher outputs (class-wise thresholds, min length, same-class overlap removal)."""
+    from collections import Counter
+    tea, thr, B = _g11_inputs()
+    sizes = torch.full((B,), 10.0)
+    res = {}
+    for name, kw in (('nms', dict()), ('raw', dict(del_overlap=False))):
+        targets = [{'labels': torch.zeros(0, dtype=torch.int64), 'boxes': torch.zeros(0, 2), 'orig_size': torch.tensor(10.0)}
+                   for _ in range(B)]
+        cnt = Counter()
+        got = rengine.get_pseudo_labels({k: v.clone() for k, v in tea.items()}, {'bbox': rsedt.PostProcess()}, sizes, targets, cnt,
+                                        classwise_threshold=thr, **kw)
+        res[f'{name}_count'] = np.array([len(t['labels']) for t in got])
+        res[f'{name}_labels'] = _pad_rows([npy(t['labels']) for t in got], 20, -1)
+        res[f'{name}_centre'] = _pad_rows([npy(t['boxes'][:, 0]) for t in got], 20, -1)
+        res[f'{name}_length'] = _pad_rows([npy(t['boxes'][:, 1]) for t in got], 20, -1)
+        res[f'{name}_counter'] = np.array([cnt.get(c, 0) for c in range(10)])
+    np.savez_compressed(os.path.join(out, 'g11_pseudo_labels.npz'), **res)
+    print('G11 ok', res['nms_count'], res['raw_count'])
+
+
+def g12_semi_step(out, rsedt, rengine, ru):
+    """G12: one iteration of the reference's engine.semi_train (mean teacher, E=6, Q=20+1, mixup off): once with the
+    optimizer step withheld (losses + every gradient norm), once complete (parameter and EMA-shadow deltas)."""
+    import utilities.utils as rutils
+    c = SEMI
+    res = {}
+    ns, nw, nu = c['n_strong'], c['n_weak'], c['n_unl']
+    masks = dict(mask_strong=slice(ns), mask_weak=slice(ns, ns + nw), mask_label=slice(ns + nw), mask_unlabel=slice(ns + nw, ns + nw + nu))
+    for mode in ('grads', 'step'):
+        args = ref_args(enc_layers=6, num_queries=20, dropout=0.0)
+        model, criterion, post = rsedt.build_model(args)
+        seeded_load(model, c['seed_w'])
+        model.train()
+        ema = rutils.EMA(model, 0.9)
+        ema.register()
+        g = torch.Generator().manual_seed(5)
+        for n in ema.shadow:                                  # a teacher that differs from the student
+            ema.shadow[n] = ema.shadow[n] + 0.02 * ema.shadow[n].abs().mean() * torch.randn(ema.shadow[n].shape, generator=g)
+        shadow0 = {n: v.clone() for n, v in ema.shadow.items()}
+        groups = [{"params": [p for n, p in model.named_parameters() if "backbone" not in n and p.requires_grad]},
+                  {"params": [p for n, p in model.named_parameters() if "backbone" in n and p.requires_grad], "lr": 1e-4}]
+        opt = torch.optim.AdamW(groups, lr=1e-4, weight_decay=1e-4)
+        x_t, x_s, targets = _semi_batch()
+        nt = lambda x: ru.NestedTensor(x, torch.zeros(x.shape[0], x.shape[2], x.shape[3], dtype=torch.bool))
+        loader = [((nt(x_t), nt(x_s)), targets)]
+        before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+        thr = torch.full((10,), c['thr'])
+        value, counter = rengine.semi_train(loader, model, ema, criterion, opt, 0, 2 if mode == 'grads' else 1, 1, post,
+                                            max_norm=0.1, classwise_threshold=thr, **masks)
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+        if mode == 'grads':
+            res['total'] = np.float32(value)
+            res['gradnames'] = np.array(names)
+            res['gradnorm'] = np.array([dict(model.named_parameters())[n].grad.norm().item() for n in names], np.float32)
+            res['pseudo_counter'] = np.array([counter.get(k, 0) for k in range(10)])
+            res['pseudo_count'] = np.array([len(t['labels']) for t in targets[masks['mask_unlabel']]])
+            res['pseudo_labels'] = _pad_rows([npy(t['labels']) for t in targets[masks['mask_unlabel']]], 20, -1)
+            res['pseudo_centre'] = _pad_rows([npy(t['boxes'][:, 0]) for t in targets[masks['mask_unlabel']]], 20, -1)
+            res['pseudo_length'] = _pad_rows([npy(t['boxes'][:, 1]) for t in targets[masks['mask_unlabel']]], 20, -1)
+        else:
+            res['step_total'] = np.float32(value)
+            res['step_delta'] = np.array([(dict(model.named_parameters())[n].detach() - before[n]).norm().item() for n in names],
+                                         np.float32)
+            # semi_train updated the shadow AFTER the optimizer step: shadow1 = 0.9 shadow0 + 0.1 p_new
+            res['ema_delta'] = np.array([(ema.shadow[n] - shadow0[n]).norm().item() for n in names], np.float32)
+    np.savez_compressed(os.path.join(out, 'g12_semi_step.npz'), **res)
+    print('G12 ok total', res['total'], 'pseudo', res['pseudo_count'])
+
+
+def g13_transforms_mixup(out, rmixup, rbt):
+    """G13: the reference's own transform classes (PadOrTrunc, TimeMask, FreqMask(mean), FreqShift, Normalize - NOT ApplyLog,
+    which is librosa) with np.random seeded, the parameters they drew, and mixup_data / mixup_label_unlabel with their
+    Beta / shuffle draws."""
+    import utilities.Scaler as rscaler
+    res = {}
+    rng = np.random.RandomState(131)
+    db = (rng.randn(3, 470, 64) * 12 - 40).astype(np.float64)          # log-mel-like clips, shorter than 496 frames
+    db[2] = (rng.randn(520, 64) * 12 - 40)[:470]
+    long_clip = (rng.randn(520, 64) * 12 - 40)
+    sc = rscaler.Scaler()
+    mean = rng.randn(64) * 3 - 40
+    sc.load_state_dict({'mean_': mean.tolist(), 'mean_of_square_': (mean ** 2 + rng.rand(64) * 100 + 60).tolist()})
+    res['scaler_mean'], res['scaler_std'] = sc.mean_.astype(np.float64), sc.std_.astype(np.float64)
+    res['in_db'] = db.astype(np.float32)
+    res['in_long'] = long_clip.astype(np.float32)
+    outs, params = [], []
+    for i, clip in enumerate(list(db) + [long_clip]):
+        np.random.seed(1000 + i)
+        x = rbt.pad_trunc_seq(clip.astype(np.float32).copy(), 496)
+        tm, fm, fs = rbt.TimeMask(p=0.6), rbt.FreqMask(fill_mode="mean", p=0.6), rbt.FreqShift(p=0.6)
+        x = tm.transform_data(x)
+        x = fm.transform_data(x)
+        x = fs.transform_data(x)
+        t = rbt.ToTensor(unsqueeze_axis=0).transform_data(x)
+        y = rbt.Normalize(sc).transform_data(t)
+        outs.append(npy(y))
+        params.append([float(tm.parameters['apply']), tm.parameters['t'], tm.parameters['t0'], float(fm.parameters['apply']),
+                       fm.parameters['f'], fm.parameters['f0'], float(fs.parameters['apply']), float(fs.parameters['shift_size'])])
+    res['out'] = np.stack(outs)
+    res['params'] = np.asarray(params, np.float64)
+    # ---- mixup_data (labelled batch: 3 strong + 3 weak) and mixup_label_unlabel
+    import utilities.utils as rutils
+    g = torch.Generator().manual_seed(132)
+    B = 6
+    x = torch.randn(B, 1, 32, 8, generator=g)
+    tg = synthetic_targets(B, 133, 10)
+    for t in tg[3:]:
+        t['boxes'] = torch.zeros(0, 2)
+    np.random.seed(77)
+    lam = np.random.beta(1, 1)
+    idx = np.asarray(list(range(B)))
+    np.random.shuffle(idx)
+    np.random.seed(77)
+    nt = rutils.NestedTensor(x.clone(), torch.zeros(B, 32, 8, dtype=torch.bool))
+    xm, ym, ms, mw = rmixup.mixup_data(nt, [dict(t) for t in tg], slice(3), slice(3, 6), mix_up_ratio=0.67, alpha=1)
+    res['mix_lam'], res['mix_index'] = np.float64(lam), idx
+    res['mix_x'] = npy(xm.tensors)
+    res['mix_masks'] = np.array([ms.stop, mw.start, mw.stop])
+    res['mix_nlabels'] = np.array([len(t['labels']) for t in ym])
+    res['mix_nboxes'] = np.array([len(t['boxes']) for t in ym])
+    res['mix_labels'] = _pad_rows([npy(t['labels']) for t in ym], 20, -1)
+    res['mix_ratio'] = _pad_rows([npy(t['ratio']) if 'ratio' in t else [] for t in ym], 20, -1)
+    res['mix_centre'] = _pad_rows([npy(t['boxes'].reshape(-1, 2)[:, 0]) for t in ym], 20, -1)
+    # label/unlabel mixing
+    x1, x2 = torch.randn(4, 1, 32, 8, generator=g), torch.randn(4, 1, 32, 8, generator=g)
+    y1, y2 = synthetic_targets(4, 134, 10), synthetic_targets(4, 135, 10)
+    np.random.seed(78)
+    lam2 = np.random.beta(1, 1)
+    np.random.seed(78)
+    n1 = rutils.NestedTensor(x1.clone(), None)
+    n2 = rutils.NestedTensor(x2.clone(), None)
+    xo, yo = rmixup.mixup_label_unlabel(n1, n2, [dict(t) for t in y1], [dict(t) for t in y2], alpha=1)
+    res['lu_lam'] = np.float64(lam2)
+    res['lu_x'] = npy(xo.tensors)
+    res['lu_nlabels'] = np.array([len(t['labels']) for t in yo])
+    res['lu_labels'] = _pad_rows([npy(t['labels']) for t in yo], 20, -1)
+    res['lu_ratio'] = _pad_rows([npy(t['ratio']) if 'ratio' in t else [] for t in yo], 20, -1)
+    np.savez_compressed(os.path.join(out, 'g13_transforms_mixup.npz'), **res)
+    print('G13 ok', res['params'][:, [0, 3, 6]].tolist(), res['mix_nlabels'], res['lu_nlabels'])
+
+
 if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default='', help='comma list of fixtures to (re)generate, e.g. g9,g12 (default: all)')
+    ap.add_argument('--out', default=HERE)
+    cli = ap.parse_args()
+    want = set(w for w in cli.only.split(',') if w)
+    on = lambda k: not want or k in want
     torch.set_num_threads(8)
-    out = HERE
-    g1_transformer(out)
+    out = cli.out
+    if on('g1'):
+        g1_transformer(out)
     rsedt, ru = import_reference()
-    g6_posenc(out, rsedt)
-    g5_criterion(out, rsedt)
-    g2_g3_sedt(out, rsedt)
-    g4_spsedt(out, rsedt)
+    if on('g6'):
+        g6_posenc(out, rsedt)
+    if on('g5'):
+        g5_criterion(out, rsedt)
+    if on('g2'):
+        g2_g3_sedt(out, rsedt)
+    if on('g4'):
+        g4_spsedt(out, rsedt)
+    if on('g9'):
+        g9_criterion_variants(out, rsedt)
+    if on('g10'):
+        g10_postprocess(out, rsedt)
+    if want & {'g11', 'g12', 'g13'} or not want:
+        rengine, rmixup, rbt = import_reference_engine()
+        if on('g11'):
+            g11_pseudo_labels(out, rsedt, rengine)
+        if on('g13'):
+            g13_transforms_mixup(out, rmixup, rbt)
+        if on('g12'):
+            g12_semi_step(out, rsedt, rengine, ru)
