@@ -13,16 +13,23 @@
  * FMA chains); SEDT_BF16 = throughput mode (bf16 operands, f32 accumulate,
  * v_mfma_f32_32x32x16_bf16).  Parameters and gradients are always f32.
  *
+ * Binding: the library is built with plain `hipcc -shared` and bound with ctypes (sound_event_detection_transformer_amd/
+ * lib.py mirrors every prototype below); no torch headers are involved - torch only supplies device pointers and streams.
+ *
  * Reference interface each group replaces (file:line under the reference repo):
- *   sedt_igemm / sedt_layernorm_* / sedt_attention_*   - the torch operators below
- *        torch.nn.Conv2d/Linear/LayerNorm/MultiheadAttention at sedt/transformer.py:160-165,
- *        183-204, 220-233, 248-284, sedt/sedt.py:36, 88-92, 398-409, torchvision Bottleneck
- *        (sedt/backbone.py:98-100)
- *   sedt_backbone_*      - Backbone / BackboneBase.forward + autograd      sedt/backbone.py:56-113
- *   sedt_encoder_* / sedt_decoder_*  - TransformerEncoder/Decoder(+Layer)  sedt/transformer.py:90-297
- *   sedt_posenc          - PositionEmbeddingSine.forward                   sedt/position_encoding.py:27-47
- *   sedt_heads_*         - class/bbox/audio-tag heads                      sedt/sedt.py:90-95, 398-409
- *   sedt_adamw_clip      - clip_grad_norm_ + AdamW.step                    engine.py:77-80
+ *   sedt_igemm / sedt_igemm_group / sedt_wgrad_group / sedt_multi_wgrad_reduce / sedt_skinny_linear_*
+ *        torch.nn.Conv2d / Linear forward + autograd: sedt/transformer.py:160-165, 183-204, 220-233, 248-284,
+ *        sedt/sedt.py:36, 88-92, 398-409, torchvision Bottleneck convs behind sedt/backbone.py:98-100
+ *   sedt_bn_fold / sedt_multi_bn_fold / sedt_pack_conv / sedt_multi_pack      FrozenBatchNorm2d     sedt/backbone.py:17-53
+ *   sedt_stem_* / sedt_maxpool_* / sedt_avgpool / sedt_mask_resize            Backbone.forward      sedt/backbone.py:56-113
+ *   sedt_layernorm_* / sedt_attention_* / sedt_add / sedt_dropout_grad        TransformerEncoder/DecoderLayer  sedt/transformer.py:155-297
+ *   sedt_posenc                                                               PositionEmbeddingSine sedt/position_encoding.py:27-47
+ *   sedt_match_targets / sedt_hungarian_batch                                 HungarianMatcher      sedt/matcher.py:41-133
+ *   sedt_set_criterion(_bwd) / sedt_feature_loss                              SetCriterion          sedt/sedt.py:134-352
+ *   sedt_postprocess / sedt_pseudo_labels                                     PostProcess, get_pseudo_labels  sedt/sedt.py:355-396, engine.py:300-348
+ *   sedt_multi_sumsq / sedt_multi_adamw / sedt_adamw_clip                     clip_grad_norm_ + AdamW.step  engine.py:77-80
+ *   sedt_multi_ema                                                            EMA.update            utilities/utils.py:62-67
+ *   sedt_multi_gather                                                         DDP gradient buckets  train_spsedt.py:157-158
  */
 #ifndef SEDT_HIP_H
 #define SEDT_HIP_H
@@ -324,18 +331,49 @@ typedef struct SedtCriterion {
   int32_t layer_of[SEDT_CRIT_MAXL];
   float w_ce[SEDT_CRIT_MAXL], w_bbox[SEDT_CRIT_MAXL], w_giou[SEDT_CRIT_MAXL];
   float w_weak;
+  /* focal-loss variant (sedt/sedt.py:176, 211-218, 412-433; train_ss_sedt.py --focal_loss): fl != 0 replaces the weighted
+   * cross-entropy by sigmoid_focal_loss over the C+1 logits (pos_weight = empty_weight) and the audio-tag BCE by
+   * weak_focal_loss (sum over classes, mean over clips); alpha_fl < 0 disables the alpha_t factor (config.py:71-72). */
+  int32_t fl;
+  float alpha_fl, gamma_fl;
+  /* optional device word: set to 1 (never cleared here) when the weighted total is not finite - the reference aborts on
+   * such a loss (engine.py:70-73, 167-169); a graphed step polls this word instead of synchronising every step */
+  int32_t* nonfinite;
 } SedtCriterion;
 int sedt_set_criterion(const SedtCriterion* args, void* stream);
 int sedt_set_criterion_bwd(const SedtCriterion* args, const float* g, float* glogits, float* gboxes, float* gat,
                            void* stream);
 
-/* ------------------------------------------------------------------ device-side matching (sedt/matcher.py:60-95)
+/* ------------------------------------------------------------------ SP-SEDT feature-reconstruction loss (sedt/sedt.py:263-283)
+ * For dense layer d, strong clip b, query q matched to patch tidx (wbox > 0):
+ *   row = sum_f (normalize(pred[layer_of[d]][b][q])[f] - normalize(gt[b*P + tidx])[f])^2,   normalize = x / max(|x|_2, 1e-12)
+ *   out[d] = sum over matched rows / num_boxes.  dpred receives d out[d] / d pred (unweighted; zero rows where unmatched).
+ * pred / dpred [L][B][Q][F] f32, gt [B*P][F] f32 (treated as a constant: the SP-SEDT backbone is frozen,
+ * train_spsedt.py:50), wbox / tidx [L][ns][Q] as written by sedt_match_targets, num_boxes [1] device scalar.
+ * rowloss [L*ns*Q] scratch.  Deterministic (fixed summation order).  sedt_scale_rows: x[l][...] *= g[l] + gtot[0]*w[l]. */
+int sedt_feature_loss(const float* pred, const float* gt, const float* wbox, const float* tidx, const float* num_boxes,
+                      const int32_t* layer_of, int L, int B, int ns, int Q, int P, int F, float* rowloss, float* out,
+                      float* dpred, void* stream);
+int sedt_scale_layers(float* x, const float* g, const float* gtot, const float* w, int L, int64_t per_layer, void* stream);
+/* out[0] = sum_i x[i] (one workgroup, fixed order): num_boxes = sum of the final layer's box weights (sedt.py:322-324) */
+int sedt_sum_f32(const float* x, int n, float* out, void* stream);
+
+/* ------------------------------------------------------------------ device-side matching (sedt/matcher.py:41-133)
  * The Hungarian assignment of every (decoder layer, strong clip) and the dense targets sedt_set_criterion reads, in one
  * launch and without leaving the device (one wave per problem; Q <= 63 queries, <= 63 targets per clip).
  * Targets arrive concatenated over the batch: lab_cat[lab_off[b] .. lab_off[b+1]) = labels of clip b (all B clips; for a
  * strong clip the first n_b labels belong to its n_b boxes), box_cat[box_off[b] .. box_off[b+1]) = (centre, length) of
- * the events of strong clip b < ns, ratio_cat (optional) aligned with lab_cat.  Cost = w_bbox*L1 + w_class*(-p[class])
- * - w_giou*GIoU; same optimum and tie-breaking as sedt_hungarian_batch.
+ * the events of strong clip b < ns, ratio_cat (optional) aligned with lab_cat.  Cost = w_bbox*L1 + w_class*cost_class
+ * - w_giou*GIoU with cost_class = -softmax(logits)[class] (fl == 0) or the focal matching cost of matcher.py:73-78
+ * (fl != 0); same optimum and tie-breaking as sedt_hungarian_batch.
+ * Coefficients (matcher.py:124-132): normalize != 0: 1 / (number of queries matched to the same target); else with
+ * ratio_cat: the k-th matched query of a clip (ascending query index) takes ratio[k] - POSITIONAL, as the reference
+ * assigns them; else 1.
+ * fine_tune != 0 (matcher.py:99-121; dense layer 0 only, aux layers keep the plain assignment as sedt.py:340 does): with
+ * the localisation cost w_bbox*L1 - w_giou*GIoU, a Hungarian pair survives only if the query's closest target is nearer
+ * than epsilon; every other query whose closest target is nearer than epsilon is matched to that target unless
+ * u > alpha * n_gt / Q, u = ft_rand[b*Q + k] for the k-th such query of clip b (ascending query index; the reference
+ * draws torch.rand in that order) or, when ft_rand is null, a counter hash of (ft_seed + *seed_ptr, b, k).
  * Outputs: tc/coef/wbox/tidx [L][ns][Q], tbox [L][ns][Q][2], tgt_len [B], gt_weak [n_lab][C] (may be null),
  * assign [L][ns][Q] int32 (may be null): index of the matched target within its clip or -1.
  * max_targets: capacity per clip the caller guarantees (LDS sizing; box_off differences must not exceed it). */
@@ -358,8 +396,31 @@ typedef struct SedtMatch {
   int32_t L, B, ns, Q, C, n_lab, max_targets;
   int32_t layer_of[SEDT_CRIT_MAXL];
   float w_class, w_bbox, w_giou;
+  int32_t fl, fine_tune, normalize;
+  float alpha_fl, gamma_fl, epsilon, alpha;
+  const float* ft_rand;     /* [ns][Q] or null */
+  uint32_t ft_seed;
+  const uint32_t* seed_ptr; /* or null */
 } SedtMatch;
 int sedt_match_targets(const SedtMatch* args, void* stream);
+
+/* ------------------------------------------------------------------ PostProcess + pseudo labels on the device
+ * sedt_postprocess (sedt/sedt.py:355-396): softmax over the C+1 logits of every query; optional fusion with clip-level
+ * tags (tags [B][C] as f32 0/1, at_m 1/2/3 exactly as the reference: at_m 2/3 lift the best query of every class to
+ * `threshold`, at_m 1/2 multiply the class scores by the tags); scores [B][Q] = max class score, labels [B][Q] (int64) =
+ * its class (first maximum), boxes_out [B][Q][2] = (onset, offset) * sizes[b], or the (centre, length) input when is_semi.
+ *
+ * sedt_pseudo_labels (engine.py:300-348, get_pseudo_labels): tags = at >= thr[class]; PostProcess(at_m = 1, is_semi); an
+ * event survives when score >= thr[label] and length > min_len; per clip the survivors are ordered by descending score
+ * (ties: lower query first) and, with del_overlap, an event is dropped when an already kept event of the same class
+ * overlaps it in time.  Results are written in the flat layout sedt_match_targets reads: lab_cat / box_cat compacted
+ * over the clips in kept order, lab_off / box_off [B+1], counter[C] += kept events per class (int32; pseudo_labels_counter
+ * of the reference).  cap = capacity of lab_cat / box_cat in events.  at may be null (no tag gating). */
+int sedt_postprocess(const float* logits, const float* boxes, const float* tags, const float* sizes, int B, int Q, int C,
+                     int at_m, float threshold, int is_semi, float* scores, int64_t* labels, float* boxes_out, void* stream);
+int sedt_pseudo_labels(const float* logits, const float* boxes, const float* at, const float* thr, float min_len, int B,
+                       int Q, int C, int del_overlap, int64_t* lab_cat, float* box_cat, int32_t* lab_off, int32_t* box_off,
+                       int32_t* counter, int cap, void* stream);
 
 /* ------------------------------------------------------------------ host-side matching (sedt/matcher.py:95)
  * HOST pointers.  cost [nlayers][nclips][Q][Nt] f32; clip b owns columns [col_off[b], col_off[b]+ncols[b]).

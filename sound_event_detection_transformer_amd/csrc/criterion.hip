@@ -76,13 +76,37 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
       const long di = ((long)d * ns + b) * Q + q;
       const int tc = (int)a.tc[di];
       const float coef = a.coef[di], wb = a.wbox[di];
-      float se = 0.f;
-      for (int c = 0; c < C1; ++c) se += __expf(x[c] - m);
-      const float lse = m + __logf(se);
-      const float w = a.empty_weight[tc];
-      l_ce += w * (lse - x[tc]) * coef * inv_nb;
-      const float gscale = coef * w * inv_nb;
-      for (int c = 0; c < C1; ++c) gx[c] = gscale * (__expf(x[c] - lse) - (c == tc ? 1.f : 0.f));
+      if (a.fl) {
+        // sigmoid focal loss over the C+1 logits, one-hot target at tc (sedt.py:211-218, 412-422)
+        float row = 0.f;
+        const float ks = coef * inv_nb;
+        for (int c = 0; c < C1; ++c) {
+          const float xv = x[c], p = 1.f / (1.f + __expf(-xv));
+          const float sp_pos = fmaxf(xv, 0.f) + log1pf(__expf(-fabsf(xv)));     // softplus(x)  = -log(1 - p)
+          const float sp_neg = sp_pos - xv;                                     // softplus(-x) = -log p
+          float ce, mod, dce, dmod, at;
+          if (c == tc) {
+            const float w = a.empty_weight[c];
+            ce = w * sp_neg; dce = -w * (1.f - p); mod = 1.f - p; dmod = -p * (1.f - p); at = a.alpha_fl;
+          } else {
+            ce = sp_pos; dce = p; mod = p; dmod = p * (1.f - p); at = 1.f - a.alpha_fl;
+          }
+          if (a.alpha_fl < 0.f) at = 1.f;
+          const float mg = a.gamma_fl == 1.f ? mod : powf(mod, a.gamma_fl);
+          const float dmg = a.gamma_fl == 1.f ? 1.f : a.gamma_fl * powf(mod, a.gamma_fl - 1.f);
+          row += at * ce * mg;
+          gx[c] = ks * at * (dce * mg + ce * dmg * dmod);
+        }
+        l_ce += row * ks;
+      } else {
+        float se = 0.f;
+        for (int c = 0; c < C1; ++c) se += __expf(x[c] - m);
+        const float lse = m + __logf(se);
+        const float w = a.empty_weight[tc];
+        l_ce += w * (lse - x[tc]) * coef * inv_nb;
+        const float gscale = coef * w * inv_nb;
+        for (int c = 0; c < C1; ++c) gx[c] = gscale * (__expf(x[c] - lse) - (c == tc ? 1.f : 0.f));
+      }
       if (d == 0 && wb > 0.f) {
         n_cnt += 1.f;
         if (amax == tc) n_hit += 1.f;
@@ -154,8 +178,19 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
       float g = 0.f;
       if (r < n) {
         const float p = a.at[r], y = a.gt_weak[r];
-        weak += -(y * fmaxf(__logf(p), -100.f) + (1.f - y) * fmaxf(__logf(1.f - p), -100.f)) / (float)n;
-        g = (p - y) / fmaxf(p * (1.f - p), 1e-12f) / (float)n;
+        const float ce = -(y * fmaxf(__logf(p), -100.f) + (1.f - y) * fmaxf(__logf(1.f - p), -100.f));
+        const float dce = (p - y) / fmaxf(p * (1.f - p), 1e-12f);
+        if (a.fl) {                             // weak_focal_loss (sedt.py:425-433): sum over classes, mean over clips
+          const float mod = 1.f - (p * y + (1.f - p) * (1.f - y)), dmod = 1.f - 2.f * y;
+          const float at = a.alpha_fl < 0.f ? 1.f : a.alpha_fl * y + (1.f - a.alpha_fl) * (1.f - y);
+          const float mg = a.gamma_fl == 1.f ? mod : powf(mod, a.gamma_fl);
+          const float dmg = a.gamma_fl == 1.f ? 1.f : a.gamma_fl * powf(mod, a.gamma_fl - 1.f);
+          weak += at * ce * mg / (float)a.n_lab;
+          g = at * (dce * mg + ce * dmg * dmod) / (float)a.n_lab;
+        } else {
+          weak += ce / (float)n;
+          g = dce / (float)n;
+        }
       }
       a.dat[r] = g;
     }
@@ -165,6 +200,7 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
   if (t == 0) {
     a.out[SLOT_WEAK] = weak;
     a.out[4 * L + 3] = total;                   // weighted total
+    if (a.nonfinite && !(fabsf(total) <= 3.0e38f)) *a.nonfinite = 1;      // NaN or inf (engine.py:70-73)
   }
 }
 
@@ -274,16 +310,26 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
   const int d = blockIdx.x / ns, b = blockIdx.x % ns;
   const int ml = a.layer_of[d];
   const int bo = a.box_off[b], n = a.box_off[b + 1] - bo, lo = a.lab_off[b];
-  float* prob = lds;                       // [Q][C1]
+  float* prob = lds;                       // [Q][C1]: class part of the matching cost per (query, class)
   float* cst = lds + Q * C1;               // [Q][n]
-  // softmax rows
+  float* loc = cst + Q * a.max_targets;    // [Q][n] localisation-only cost (fine_tune)
+  const bool main_ft = a.fine_tune && d == 0;
   if (lane < Q) {
     const float* x = a.logits + (((long)ml * B + b) * Q + lane) * C1;
-    float m = -INFINITY;
-    for (int c = 0; c < C1; ++c) m = fmaxf(m, x[c]);
-    float se = 0.f;
-    for (int c = 0; c < C1; ++c) se += expf(x[c] - m);
-    for (int c = 0; c < C1; ++c) prob[lane * C1 + c] = expf(x[c] - m) / se;
+    if (a.fl) {                            // matcher.py:73-78: focal cost on sigmoid probabilities
+      for (int c = 0; c < C1; ++c) {
+        const float p = 1.f / (1.f + expf(-x[c]));
+        const float neg = (1.f - a.alpha_fl) * powf(p, a.gamma_fl) * (-logf(1.f - p + 1e-8f));
+        const float pos = a.alpha_fl * powf(1.f - p, a.gamma_fl) * (-logf(p + 1e-8f));
+        prob[lane * C1 + c] = pos - neg;
+      }
+    } else {                               // -softmax probability
+      float m = -INFINITY;
+      for (int c = 0; c < C1; ++c) m = fmaxf(m, x[c]);
+      float se = 0.f;
+      for (int c = 0; c < C1; ++c) se += expf(x[c] - m);
+      for (int c = 0; c < C1; ++c) prob[lane * C1 + c] = -(expf(x[c] - m) / se);
+    }
   }
   __syncthreads();
   for (int i = lane; i < Q * n; i += 64) {
@@ -296,8 +342,9 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
     const float uni = (e1 - s1) + (e2 - s2) - inter;
     const float hull = fmaxf(fmaxf(e1, e2) - fminf(s1, s2), 0.f);
     const float giou = inter / uni - (hull - uni) / hull;
-    const float cost_class = -prob[q * C1 + (int)a.lab_cat[lo + t]];
+    const float cost_class = prob[q * C1 + (int)a.lab_cat[lo + t]];
     cst[q * n + t] = a.w_bbox * cost_bbox + a.w_class * cost_class - a.w_giou * giou;
+    if (main_ft) loc[q * n + t] = a.w_bbox * cost_bbox - a.w_giou * giou;
   }
   __syncthreads();
   // assignment: target index matched to query `lane`, or -1
@@ -323,11 +370,44 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
       if (lane < Q) asg = tmp[lane];
     }
   }
+  // ---- coefficients (matcher.py:124-132) and the fine-tune re-matching (matcher.py:99-121; dense layer 0 only)
+  float cf = 1.f;
+  if (main_ft && n > 0) {
+    float nc = INFINITY;
+    int nt = 0;
+    if (lane < Q)
+      for (int t = 0; t < n; ++t) {
+        const float v = loc[lane * n + t];
+        if (v < nc) { nc = v; nt = t; }                       // first minimum, as torch.min on the CPU
+      }
+    const bool hung = lane < Q && asg >= 0;
+    const bool close = lane < Q && nc < a.epsilon;
+    const int n_gt = __popcll(__ballot(hung));
+    const bool extra = close && !hung;
+    const unsigned long long em = __ballot(extra);
+    const int k = __popcll(em & ((1ull << lane) - 1ull));
+    float u = 0.f;
+    if (extra) {
+      if (a.ft_rand) u = a.ft_rand[b * Q + k];
+      else u = (float)(rng32(eff_seed(a.ft_seed, a.seed_ptr), (uint64_t)b * 64 + k) >> 8) * (1.f / 16777216.f);
+    }
+    const float keep_p = (float)((double)a.alpha * (double)n_gt / (double)Q);
+    asg = (hung && close) ? asg : ((extra && !(u > keep_p)) ? nt : -1);
+    if (a.normalize) {
+      int cnt = 0;
+      for (int j = 0; j < Q; ++j) cnt += (__shfl(asg, j, 64) == asg) ? 1 : 0;
+      cf = 1.f / (float)max(cnt, 1);
+    }
+  } else if (!(a.normalize && d == 0) && a.ratio_cat) {       // (normalize reaches the final layer only: sedt.py:320 vs :340)
+    // POSITIONAL: the k-th matched query of the clip (ascending query index) takes ratio[k]
+    const unsigned long long mm = __ballot(lane < Q && asg >= 0);
+    cf = a.ratio_cat[lo + __popcll(mm & ((1ull << lane) - 1ull))];
+  }
   if (lane < Q) {
     const long di = ((long)d * ns + b) * Q + lane;
     const bool hit = asg >= 0;
     const int t = hit ? asg : 0;
-    const float ratio = (hit && a.ratio_cat) ? a.ratio_cat[lo + t] : 1.f;
+    const float ratio = hit ? cf : 1.f;
     a.tc[di] = hit ? (float)a.lab_cat[lo + t] : (float)C;
     a.coef[di] = ratio;
     a.wbox[di] = hit ? ratio : 0.f;
@@ -377,7 +457,8 @@ extern "C" int sedt_match_targets(const SedtMatch* args, void* stream) {
   SEDT_REQUIRE(a.logits && a.boxes && a.lab_cat && a.lab_off && a.box_cat && a.box_off && a.tc && a.coef && a.wbox && a.tbox &&
                    a.tidx && a.tgt_len,
                "match_targets: null pointer");
-  const size_t lds = std::max((size_t)a.Q * (a.C + 1 + a.max_targets), (size_t)64 * (a.C + 1)) * sizeof(float);
+  SEDT_REQUIRE(!(a.fine_tune && a.ratio_cat && !a.normalize), "match_targets: fine_tune with mixup ratios is undefined in the reference (matcher.py:130)");
+  const size_t lds = std::max((size_t)a.Q * (a.C + 1 + 2 * a.max_targets), (size_t)64 * (a.C + 1)) * sizeof(float);
   hipLaunchKernelGGL(match_targets_kernel, dim3(a.L * a.ns + 1), dim3(64), lds, reinterpret_cast<hipStream_t>(stream), a);
   return check_launch("match_targets");
 }

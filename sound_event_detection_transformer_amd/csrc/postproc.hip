@@ -1,0 +1,336 @@
+// postproc.hip - the small device-side pieces around the model that keep the semi-supervised (mean-teacher) step and the
+// SP-SEDT pre-training step free of device->host copies:
+//   * postprocess_kernel     PostProcess.forward                       reference sedt/sedt.py:355-396
+//   * pseudo_labels_kernel   engine.get_pseudo_labels                  reference engine.py:300-348
+//   * feature_loss_kernel    SetCriterion.loss_feature (+ gradient)    reference sedt/sedt.py:263-283
+// All of it is byte/latency-sized work (a few thousand rows); the kernels are organised so that every result is
+// deterministic (fixed orders, no floating-point atomics) and lands in the flat layouts the matching / loss kernels read.
+#include <algorithm>
+#include "common.h"
+
+namespace sedt {
+
+// class scores of one query after the optional tag fusion; returns (best score, first best class)
+//   prob[c] for c < C lives in registers of the calling lane (C <= 63 handled with a loop over a local array bound)
+#define SEDT_PP_MAXC 64
+
+// ---------------------------------------------------------------------------------------------------------------------
+// one wave per clip, lane = query (Q <= 64)
+__global__ __launch_bounds__(64) void postprocess_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+                                                         const float* __restrict__ tags, const float* __restrict__ sizes, int Q,
+                                                         int C, int at_m, float threshold, int is_semi, float* __restrict__ scores,
+                                                         int64_t* __restrict__ labels, float* __restrict__ boxes_out) {
+  extern __shared__ float lds[];              // [Q][C] class probabilities of the clip
+  const int b = blockIdx.x, lane = threadIdx.x, C1 = C + 1;
+  float* prob = lds;
+  if (lane < Q) {
+    const float* x = logits + ((long)b * Q + lane) * C1;
+    float m = -INFINITY;
+    for (int c = 0; c < C1; ++c) m = fmaxf(m, x[c]);
+    float se = 0.f;
+    for (int c = 0; c < C1; ++c) se += expf(x[c] - m);
+    for (int c = 0; c < C; ++c) prob[lane * C + c] = expf(x[c] - m) / se;
+  }
+  __syncthreads();
+  if (tags) {
+    if (at_m == 2 || at_m == 3) {
+      // per class: the query with the highest probability (first maximum) is lifted to `threshold` if it is below
+      for (int c = 0; c < C; ++c) {
+        float v = lane < Q ? prob[lane * C + c] : -INFINITY;
+        int q = lane < Q ? lane : 64;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ov = __shfl_xor(v, o, 64);
+          const int oq = __shfl_xor(q, o, 64);
+          if (ov > v || (ov == v && oq < q)) { v = ov; q = oq; }
+        }
+        const bool lift = v < threshold && (at_m == 2 || tags[(long)b * C + c] != 0.f);
+        if (lift && lane == q) prob[q * C + c] = threshold;
+      }
+      __syncthreads();
+    }
+    if ((at_m == 1 || at_m == 2) && lane < Q)
+      for (int c = 0; c < C; ++c) prob[lane * C + c] *= tags[(long)b * C + c];
+  }
+  if (lane < Q) {
+    float best = -INFINITY;
+    int bc = 0;
+    for (int c = 0; c < C; ++c) {
+      const float v = prob[lane * C + c];
+      if (v > best) { best = v; bc = c; }
+    }
+    const long r = (long)b * Q + lane;
+    scores[r] = best;
+    labels[r] = bc;
+    const float c0 = boxes[2 * r], l0 = boxes[2 * r + 1];
+    if (is_semi) {
+      boxes_out[2 * r] = c0;
+      boxes_out[2 * r + 1] = l0;
+    } else {
+      const float sz = sizes[b];
+      boxes_out[2 * r] = (c0 - l0 / 2) * sz;
+      boxes_out[2 * r + 1] = (c0 + l0 / 2) * sz;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ONE workgroup of 16 waves; wave w handles clips w, w+16, ...: scores -> filter -> order -> greedy same-class overlap
+// removal, results staged in LDS; then clip offsets (serial prefix over <= a few hundred clips) and the compaction.
+__global__ __launch_bounds__(1024) void pseudo_labels_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+                                                             const float* __restrict__ at, const float* __restrict__ thr,
+                                                             float min_len, int B, int Q, int C, int del_overlap,
+                                                             int64_t* __restrict__ lab_cat, float* __restrict__ box_cat,
+                                                             int32_t* __restrict__ lab_off, int32_t* __restrict__ box_off,
+                                                             int32_t* __restrict__ counter, int cap) {
+  extern __shared__ float lds[];
+  int* cnt = reinterpret_cast<int*>(lds);                 // [B] kept events per clip
+  int* off = cnt + B;                                     // [B+1]
+  int* s_lab = off + B + 1;                               // [B][Q] staged labels in kept order
+  float* s_box = reinterpret_cast<float*>(s_lab + B * Q); // [B][Q][2]
+  int* hist = reinterpret_cast<int*>(s_box + 2 * B * Q);  // [C]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, C1 = C + 1;
+  for (int c = threadIdx.x; c < C; c += 1024) hist[c] = 0;
+  __syncthreads();
+  for (int b = wave; b < B; b += 16) {
+    float score = -INFINITY, cen = 0.f, len = 0.f;
+    int label = 0;
+    if (lane < Q) {
+      const float* x = logits + ((long)b * Q + lane) * C1;
+      float m = -INFINITY;
+      for (int c = 0; c < C1; ++c) m = fmaxf(m, x[c]);
+      float se = 0.f;
+      for (int c = 0; c < C1; ++c) se += expf(x[c] - m);
+      for (int c = 0; c < C; ++c) {
+        float v = expf(x[c] - m) / se;
+        if (at) v *= (at[(long)b * C + c] >= thr[c]) ? 1.f : 0.f;        // clip-level tag gate (PostProcess at_m = 1)
+        if (v > score) { score = v; label = c; }
+      }
+      cen = boxes[2 * ((long)b * Q + lane)];
+      len = boxes[2 * ((long)b * Q + lane) + 1];
+    }
+    const bool ok = lane < Q && score >= thr[label] && len > min_len;
+    // rank among the survivors: descending score, ties -> lower query index
+    int rank = 0;
+    for (int j = 0; j < Q; ++j) {
+      const float sj = __shfl(score, j, 64);
+      const bool okj = __shfl((int)ok, j, 64) != 0;
+      if (okj && (sj > score || (sj == score && j < lane))) ++rank;
+    }
+    const unsigned long long okm = __ballot(ok);
+    const int nok = __popcll(okm);
+    if (!del_overlap) rank = __popcll(okm & ((1ull << lane) - 1ull));   // engine.py:317-319: survivors in query order
+    // greedy pass in rank order: an event is dropped when a kept one of the same class overlaps it
+    const float on = cen - len / 2, offt = cen + len / 2;
+    bool kept = false;
+    int out_pos = 0, nkept = 0;
+    for (int r = 0; r < nok; ++r) {
+      const unsigned long long who = __ballot(ok && rank == r);          // exactly one lane
+      const int src = __ffsll((long long)who) - 1;
+      const float on_r = __shfl(on, src, 64), off_r = __shfl(offt, src, 64);
+      const int lab_r = __shfl(label, src, 64);
+      bool clash = false;
+      if (del_overlap && kept && label == lab_r) {
+        const float shared = fmaxf(fminf(off_r, offt) - fmaxf(on_r, on), 0.f);
+        clash = shared != 0.f;
+      }
+      const bool drop = __ballot(clash) != 0ull;
+      if (!drop) {
+        if (lane == src) { kept = true; out_pos = nkept; }
+        ++nkept;
+      }
+    }
+    if (kept) {
+      s_lab[b * Q + out_pos] = label;
+      s_box[2 * (b * Q + out_pos)] = cen;
+      s_box[2 * (b * Q + out_pos) + 1] = len;
+      if (del_overlap) atomicAdd(&hist[label], 1);                       // integer LDS atomics: order-independent (engine.py:346)
+    }
+    if (lane == 0) cnt[b] = nkept;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int o = 0;
+    for (int b = 0; b < B; ++b) {
+      off[b] = o;
+      o += cnt[b];
+    }
+    off[B] = o;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b <= B; b += 1024) {
+    const int o = min(off[b], cap);
+    lab_off[b] = o;
+    box_off[b] = o;
+  }
+  for (int i = threadIdx.x; i < B * Q; i += 1024) {
+    const int b = i / Q, j = i - b * Q;
+    if (j < cnt[b] && off[b] + j < cap) {
+      lab_cat[off[b] + j] = s_lab[i];
+      box_cat[2 * (off[b] + j)] = s_box[2 * i];
+      box_cat[2 * (off[b] + j) + 1] = s_box[2 * i + 1];
+    }
+  }
+  if (counter)
+    for (int c = threadIdx.x; c < C; c += 1024) counter[c] += hist[c];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// feature-reconstruction loss: one wave per (dense layer, strong clip, query) row of F features
+__global__ __launch_bounds__(256) void feature_loss_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                           const float* __restrict__ wbox, const float* __restrict__ tidx,
+                                                           const float* __restrict__ num_boxes,
+                                                           int lay0, int lay1, int lay2, int lay3, int lay4, int lay5, int lay6, int lay7,
+                                                           int L, int B, int ns, int Q, int P, int F, float* __restrict__ rowloss,
+                                                           float* __restrict__ dpred) {
+  const int lays[8] = {lay0, lay1, lay2, lay3, lay4, lay5, lay6, lay7};
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);           // over [L][B][Q] of the MODEL's layout
+  if (row >= (long)L * B * Q) return;
+  const int ml = (int)(row / ((long)B * Q));
+  const int rem = (int)(row - (long)ml * B * Q);
+  const int b = rem / Q, q = rem - b * Q;
+  int d = -1;
+  for (int i = 0; i < L; ++i)
+    if (lays[i] == ml) d = i;
+  float4* g4 = reinterpret_cast<float4*>(dpred + row * F);
+  const long di = ((long)d * ns + b) * Q + q;
+  const bool live = d >= 0 && b < ns && wbox[di] > 0.f;
+  if (!live) {
+    for (int i = lane; i < F / 4; i += 64) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d >= 0 && b < ns && lane == 0) rowloss[di] = 0.f;
+    return;
+  }
+  const float4* s4 = reinterpret_cast<const float4*>(pred + row * F);
+  const float4* t4 = reinterpret_cast<const float4*>(gt + ((long)b * P + (int)tidx[di]) * F);
+  float ss = 0.f, tt = 0.f, st = 0.f;
+  for (int i = lane; i < F / 4; i += 64) {
+    const float4 s = s4[i], t = t4[i];
+    ss += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+    tt += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+    st += s.x * t.x + s.y * t.y + s.z * t.z + s.w * t.w;
+  }
+  ss = wave_sum(ss); tt = wave_sum(tt); st = wave_sum(st);
+  const float ns_ = fmaxf(sqrtf(ss), 1e-12f), nt_ = fmaxf(sqrtf(tt), 1e-12f);       // F.normalize eps
+  const float inv_nb = 1.f / num_boxes[0];
+  // |s/ns - t/nt|^2 = ss/ns^2 + tt/nt^2 - 2 st/(ns nt)
+  const float cosv = st / (ns_ * nt_);
+  if (lane == 0) rowloss[di] = (ss / (ns_ * ns_) + tt / (nt_ * nt_) - 2.f * cosv) * inv_nb;
+  // d/ds = 2/ns * (s/ns * (ss/ns^2 ... ) ...): with sn = s/ns (|sn| = 1 unless clamped): 2/ns * (sn - tn - sn * (sn . (sn - tn)))
+  const float a = ss / (ns_ * ns_);                    // sn . sn  (1, or < 1 when the norm was clamped)
+  const float proj = a - cosv;                         // sn . (sn - tn)
+  const float clampd = sqrtf(ss) < 1e-12f ? 0.f : 1.f; // clamped norm: the max() has zero derivative w.r.t. s
+  const float k = 2.f * inv_nb / ns_;
+  for (int i = lane; i < F / 4; i += 64) {
+    const float4 s = s4[i], t = t4[i];
+    float4 g;
+    g.x = k * ((s.x / ns_ - t.x / nt_) - clampd * proj * (s.x / ns_));
+    g.y = k * ((s.y / ns_ - t.y / nt_) - clampd * proj * (s.y / ns_));
+    g.z = k * ((s.z / ns_ - t.z / nt_) - clampd * proj * (s.z / ns_));
+    g.w = k * ((s.w / ns_ - t.w / nt_) - clampd * proj * (s.w / ns_));
+    g4[i] = g;
+  }
+}
+
+// out[d] = sum of rowloss[d][ns*Q] in a fixed order (one workgroup per dense layer)
+__global__ __launch_bounds__(256) void feature_loss_reduce_kernel(const float* __restrict__ rowloss, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  const float* r = rowloss + (long)blockIdx.x * n;
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) v += r[i];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sum_f32_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float v = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) v += x[i];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// x[l][i] *= g[l] + gtot[0] * w[l]
+__global__ __launch_bounds__(256) void scale_layers_kernel(float* __restrict__ x, const float* __restrict__ g,
+                                                           const float* __restrict__ gtot, const float* __restrict__ w,
+                                                           long per_layer4) {
+  const int l = blockIdx.y;
+  const float k = (g ? g[l] : 0.f) + (gtot ? gtot[0] * w[l] : 0.f);
+  float4* p = reinterpret_cast<float4*>(x) + (long)l * per_layer4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_layer4; i += (long)gridDim.x * 256) {
+    float4 v = p[i];
+    v.x *= k; v.y *= k; v.z *= k; v.w *= k;
+    p[i] = v;
+  }
+}
+
+}  // namespace sedt
+
+extern "C" int sedt_postprocess(const float* logits, const float* boxes, const float* tags, const float* sizes, int B, int Q,
+                                int C, int at_m, float threshold, int is_semi, float* scores, int64_t* labels, float* boxes_out,
+                                void* stream) {
+  using namespace sedt;
+  SEDT_REQUIRE(logits && boxes && scores && labels && boxes_out, "postprocess: null pointer");
+  SEDT_REQUIRE(B >= 0 && Q >= 1 && Q <= 64 && C >= 1 && C < SEDT_PP_MAXC, "postprocess: B=%d Q=%d (<=64) C=%d (<64)", B, Q, C);
+  SEDT_REQUIRE(is_semi || sizes, "postprocess: target sizes are needed unless is_semi");
+  SEDT_REQUIRE(!tags || (at_m >= 1 && at_m <= 3), "postprocess: at_m=%d (1..3)", at_m);
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(postprocess_kernel, dim3(B), dim3(64), (size_t)Q * C * sizeof(float), reinterpret_cast<hipStream_t>(stream),
+                     logits, boxes, tags, sizes, Q, C, at_m, threshold, is_semi, scores, labels, boxes_out);
+  return check_launch("postprocess");
+}
+
+extern "C" int sedt_pseudo_labels(const float* logits, const float* boxes, const float* at, const float* thr, float min_len, int B,
+                                  int Q, int C, int del_overlap, int64_t* lab_cat, float* box_cat, int32_t* lab_off,
+                                  int32_t* box_off, int32_t* counter, int cap, void* stream) {
+  using namespace sedt;
+  SEDT_REQUIRE(logits && boxes && thr && lab_cat && box_cat && lab_off && box_off, "pseudo_labels: null pointer");
+  SEDT_REQUIRE(B >= 1 && Q >= 1 && Q <= 64 && C >= 1 && C < SEDT_PP_MAXC, "pseudo_labels: B=%d Q=%d (<=64) C=%d (<64)", B, Q, C);
+  const size_t lds = ((size_t)2 * B + 1 + (size_t)3 * B * Q + C) * 4;
+  SEDT_REQUIRE(lds <= 150 * 1024, "pseudo_labels: B*Q = %d is too large for one workgroup's LDS", B * Q);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pseudo_labels_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(pseudo_labels_kernel, dim3(1), dim3(1024), lds, reinterpret_cast<hipStream_t>(stream), logits, boxes, at, thr,
+                     min_len, B, Q, C, del_overlap, lab_cat, box_cat, lab_off, box_off, counter, cap);
+  return check_launch("pseudo_labels");
+}
+
+extern "C" int sedt_feature_loss(const float* pred, const float* gt, const float* wbox, const float* tidx, const float* num_boxes,
+                                 const int32_t* layer_of, int L, int B, int ns, int Q, int P, int F, float* rowloss, float* out,
+                                 float* dpred, void* stream) {
+  using namespace sedt;
+  SEDT_REQUIRE(pred && gt && wbox && tidx && num_boxes && layer_of && rowloss && out && dpred, "feature_loss: null pointer");
+  SEDT_REQUIRE(L >= 1 && L <= SEDT_CRIT_MAXL && F % 4 == 0 && ns <= B && P >= 1, "feature_loss: L=%d F=%d ns=%d B=%d P=%d", L, F, ns, B, P);
+  int lay[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  for (int i = 0; i < L; ++i) lay[i] = layer_of[i];          // HOST array (like SedtCriterion.layer_of)
+  const long rows = (long)L * B * Q;
+  hipLaunchKernelGGL(feature_loss_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pred,
+                     gt, wbox, tidx, num_boxes, lay[0], lay[1], lay[2], lay[3], lay[4], lay[5], lay[6], lay[7],
+                     L, B, ns, Q, P, F, rowloss, dpred);
+  hipLaunchKernelGGL(feature_loss_reduce_kernel, dim3(L), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rowloss, ns * Q, out);
+  return check_launch("feature_loss");
+}
+
+extern "C" int sedt_scale_layers(float* x, const float* g, const float* gtot, const float* w, int L, int64_t per_layer, void* stream) {
+  using namespace sedt;
+  SEDT_REQUIRE(x && (g || gtot) && (!gtot || w), "scale_layers: null pointer");
+  SEDT_REQUIRE(per_layer % 4 == 0 && L >= 1, "scale_layers: per_layer=%ld must be a multiple of 4", (long)per_layer);
+  const long n4 = per_layer / 4;
+  const unsigned gx = (unsigned)std::min<long>((n4 + 255) / 256, 2048 / L + 1);
+  hipLaunchKernelGGL(scale_layers_kernel, dim3(gx, L), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, g, gtot, w, n4);
+  return check_launch("scale_layers");
+}
+
+extern "C" int sedt_sum_f32(const float* x, int n, float* out, void* stream) {
+  using namespace sedt;
+  SEDT_REQUIRE(x && out && n >= 0, "sum_f32: bad arguments");
+  hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, n, out);
+  return check_launch("sum_f32");
+}

@@ -51,14 +51,18 @@ class SedtCriterion(C.Structure):
                                            'num_boxes', 'empty_weight', 'dlogits', 'dboxes', 'dboxes2', 'dat', 'out')] + \
                [(n, C.c_int32) for n in ('L', 'B', 'ns', 'Q', 'C', 'n_lab', 'Bat')] + \
                [('layer_of', C.c_int32 * CRIT_MAXL), ('w_ce', C.c_float * CRIT_MAXL), ('w_bbox', C.c_float * CRIT_MAXL),
-                ('w_giou', C.c_float * CRIT_MAXL), ('w_weak', C.c_float)]
+                ('w_giou', C.c_float * CRIT_MAXL), ('w_weak', C.c_float), ('fl', C.c_int32), ('alpha_fl', C.c_float),
+                ('gamma_fl', C.c_float), ('nonfinite', C.c_void_p)]
 
 
 class SedtMatch(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('logits', 'boxes', 'lab_cat', 'lab_off', 'box_cat', 'box_off', 'ratio_cat', 'tc',
                                            'coef', 'wbox', 'tbox', 'tidx', 'tgt_len', 'gt_weak', 'assign')] + \
                [(n, C.c_int32) for n in ('L', 'B', 'ns', 'Q', 'C', 'n_lab', 'max_targets')] + \
-               [('layer_of', C.c_int32 * CRIT_MAXL), ('w_class', C.c_float), ('w_bbox', C.c_float), ('w_giou', C.c_float)]
+               [('layer_of', C.c_int32 * CRIT_MAXL), ('w_class', C.c_float), ('w_bbox', C.c_float), ('w_giou', C.c_float),
+                ('fl', C.c_int32), ('fine_tune', C.c_int32), ('normalize', C.c_int32), ('alpha_fl', C.c_float),
+                ('gamma_fl', C.c_float), ('epsilon', C.c_float), ('alpha', C.c_float), ('ft_rand', C.c_void_p),
+                ('ft_seed', C.c_uint32), ('seed_ptr', C.c_void_p)]
 
 
 MAX_REDUCE_JOBS = 40
@@ -117,6 +121,11 @@ SIGNATURES = {
     'sedt_set_criterion': (_i, [C.POINTER(SedtCriterion), _vp]),
     'sedt_set_criterion_bwd': (_i, [C.POINTER(SedtCriterion), _vp, _vp, _vp, _vp, _vp]),
     'sedt_match_targets': (_i, [C.POINTER(SedtMatch), _vp]),
+    'sedt_feature_loss': (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'sedt_scale_layers': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp]),
+    'sedt_sum_f32': (_i, [_vp, _i, _vp, _vp]),
+    'sedt_postprocess': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    'sedt_pseudo_labels': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'sedt_hungarian_batch': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sedt_adamw_clip': (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _f, _i, _vp]),
 }

@@ -601,10 +601,12 @@ def adamw_clip(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, weight_deca
                                      weight_decay, step, L.stream_ptr()), 'adamw_clip')
 
 
-def set_criterion(logits, boxes, at, dense, empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak):
+def set_criterion(logits, boxes, at, dense, empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak, fl=False, alpha_fl=0.5,
+                  gamma_fl=1.0, nonfinite=None):
     """device half of SetCriterion in one launch (csrc/criterion.hip).  logits [L,B,Q,C+1], boxes [L,B,Q,2], at [Bat,C] or
-    None - all f32 contiguous; dense = SetCriterion.dense_views(...).  Returns (out[4L+5], state); state feeds
-    set_criterion_bwd."""
+    None - all f32 contiguous; dense = SetCriterion.dense_views(...).  fl: the focal-loss variant (sedt.py:176, 211-218).
+    nonfinite: optional int32 device word set to 1 when the weighted total is NaN/inf.  Returns (out[4L+5], state); state
+    feeds set_criterion_bwd."""
     _dev_check(logits, boxes)
     Lh, B, Q, C1 = logits.shape
     assert logits.dtype == torch.float32 and boxes.dtype == torch.float32 and logits.is_contiguous() and boxes.is_contiguous()
@@ -630,6 +632,10 @@ def set_criterion(logits, boxes, at, dense, empty_weight, layer_of, w_ce, w_bbox
     for i in range(Lh):
         a.layer_of[i], a.w_ce[i], a.w_bbox[i], a.w_giou[i] = layer_of[i], w_ce[i], w_bbox[i], w_giou[i]
     a.w_weak = w_weak
+    a.fl, a.alpha_fl, a.gamma_fl = int(bool(fl)), alpha_fl, gamma_fl
+    if nonfinite is not None:
+        assert nonfinite.dtype == torch.int32 and nonfinite.is_cuda
+        a.nonfinite = nonfinite.data_ptr()
     L.check(L.load().sedt_set_criterion(a, L.stream_ptr()), 'set_criterion')
     return out, (a, dl, db, db2, dat)
 
@@ -644,10 +650,13 @@ def set_criterion_bwd(state, g):
     return gl, gb, gat
 
 
-def match_targets(logits, boxes, tables, dense, layer_of, w_class, w_bbox, w_giou, max_targets, assign=None):
+def match_targets(logits, boxes, tables, dense, layer_of, w_class, w_bbox, w_giou, max_targets, assign=None, fl=False,
+                  fine_tune=False, normalize=False, epsilon=1.0, alpha=1.0, alpha_fl=0.5, gamma_fl=1.0, ft_rand=None, ft_seed=0,
+                  seed_ptr=None):
     """device-side Hungarian matching + dense targets in one launch (csrc/criterion.hip).  tables: dict with lab_cat (int64),
     lab_off (int32 [B+1]), box_cat (f32 [N,2]), box_off (int32 [ns+1]), ratio_cat (f32 or None); dense: the views of
-    SetCriterion.dense_views, written in place."""
+    SetCriterion.dense_views, written in place.  fl / fine_tune / normalize: the matcher variants of matcher.py:73-78,
+    99-121, 124-132 (ft_rand [ns,Q] f32 injects the uniforms of the fine-tune branch; else a counter hash of ft_seed)."""
     _dev_check(logits, boxes)
     Lh, B, Q, C1 = logits.shape
     assert logits.dtype == torch.float32 and boxes.dtype == torch.float32 and logits.is_contiguous() and boxes.is_contiguous()
@@ -673,4 +682,83 @@ def match_targets(logits, boxes, tables, dense, layer_of, w_class, w_bbox, w_gio
     for i in range(Lh):
         a.layer_of[i] = layer_of[i]
     a.w_class, a.w_bbox, a.w_giou = w_class, w_bbox, w_giou
+    a.fl, a.fine_tune, a.normalize = int(bool(fl)), int(bool(fine_tune)), int(bool(normalize))
+    a.alpha_fl, a.gamma_fl, a.epsilon, a.alpha = alpha_fl, gamma_fl, epsilon, alpha
+    if ft_rand is not None:
+        assert ft_rand.dtype == torch.float32 and ft_rand.is_cuda and ft_rand.is_contiguous() and ft_rand.numel() >= dense['ns'] * Q
+        a.ft_rand = ft_rand.data_ptr()
+    a.ft_seed = ft_seed & 0xffffffff
+    if seed_ptr is not None:
+        a.seed_ptr = seed_ptr.data_ptr()
     L.check(L.load().sedt_match_targets(a, L.stream_ptr()), 'match_targets')
+
+
+def sum_f32(x, out=None):
+    """out[0] = sum(x) in a fixed order (one small launch)"""
+    x = x.contiguous()
+    assert x.dtype == torch.float32 and x.is_cuda
+    if out is None:
+        out = torch.empty(1, device=x.device, dtype=torch.float32)
+    L.check(L.load().sedt_sum_f32(_p(x), x.numel(), _p(out), L.stream_ptr()), 'sum_f32')
+    return out
+
+
+def feature_loss(pred, gt, dense, layer_of, num_boxes):
+    """SP-SEDT feature-reconstruction loss (sedt.py:263-283) of every decoder layer in one launch.  pred [L,B,Q,F] f32,
+    gt [B*P,F] f32.  Returns (loss[L], dpred [L,B,Q,F] = d loss[d] / d pred, unweighted)."""
+    _dev_check(pred, gt)
+    Lh, B, Q, F = pred.shape
+    assert pred.dtype == torch.float32 and gt.dtype == torch.float32 and pred.is_contiguous() and gt.is_contiguous()
+    ns = dense['ns']
+    P = gt.shape[0] // max(ns, 1)
+    assert gt.shape == (ns * P, F) and dense['L'] == Lh and num_boxes.numel() == 1
+    dpred = torch.empty_like(pred)
+    rowloss = torch.empty(Lh * ns * Q, device=pred.device, dtype=torch.float32)
+    out = torch.empty(Lh, device=pred.device, dtype=torch.float32)
+    lay = (C.c_int32 * Lh)(*layer_of)
+    L.check(L.load().sedt_feature_loss(_p(pred), _p(gt), _p(dense['wbox']), _p(dense['tidx']), _p(num_boxes), lay, Lh, B, ns, Q, P, F,
+                                       _p(rowloss), _p(out), _p(dpred), L.stream_ptr()), 'feature_loss')
+    return out, dpred
+
+
+def scale_layers(x, g, gtot, w):
+    """in place: x[l] *= g[l] + gtot[0] * w[l]   (x [L, ...] f32; g, w [L]; gtot [1])"""
+    Lh = x.shape[0]
+    per = x.numel() // Lh
+    L.check(L.load().sedt_scale_layers(_p(x), _p(g), _p(gtot), _p(w), Lh, per, L.stream_ptr()), 'scale_layers')
+    return x
+
+
+def postprocess(logits, boxes, sizes=None, tags=None, at_m=2, is_semi=False, threshold=0.5):
+    """PostProcess.forward on the device (sedt.py:355-396): (scores [B,Q], labels [B,Q] int64, boxes [B,Q,2])"""
+    _dev_check(logits, boxes)
+    B, Q, C1 = logits.shape
+    logits, boxes = logits.detach().float().contiguous(), boxes.detach().float().contiguous()
+    tg = None if tags is None else tags.to(device=logits.device, dtype=torch.float32).contiguous()
+    sz = None if sizes is None else sizes.to(device=logits.device, dtype=torch.float32).reshape(-1).contiguous()
+    scores = torch.empty((B, Q), device=logits.device, dtype=torch.float32)
+    labels = torch.empty((B, Q), device=logits.device, dtype=torch.int64)
+    out = torch.empty((B, Q, 2), device=logits.device, dtype=torch.float32)
+    L.check(L.load().sedt_postprocess(_p(logits), _p(boxes), _p(tg), _p(sz), B, Q, C1 - 1, at_m, 0.0 if threshold is None else float(threshold),
+                                      int(bool(is_semi)), _p(scores), _p(labels), _p(out), L.stream_ptr()), 'postprocess')
+    return scores, labels, out
+
+
+def pseudo_labels(logits, boxes, at, thr, min_len, tables, counter=None, del_overlap=True):
+    """engine.get_pseudo_labels on the device (engine.py:300-348): fills the flat target tables (dict with lab_cat int64,
+    box_cat f32 [N,2], lab_off / box_off int32 [B+1]) that match_targets reads; counter int32 [C] accumulates the kept events
+    per class."""
+    _dev_check(logits, boxes, thr)
+    B, Q, C1 = logits.shape
+    logits, boxes = logits.detach().float().contiguous(), boxes.detach().float().contiguous()
+    at = None if at is None else at.detach().float().contiguous()
+    assert thr.dtype == torch.float32 and thr.numel() == C1 - 1 and thr.is_contiguous()
+    assert tables['lab_cat'].dtype == torch.int64 and tables['box_cat'].dtype == torch.float32
+    assert tables['lab_off'].dtype == torch.int32 and tables['box_off'].dtype == torch.int32
+    assert tables['lab_off'].numel() >= B + 1 and tables['box_off'].numel() >= B + 1
+    cap = min(tables['lab_cat'].numel(), tables['box_cat'].numel() // 2)
+    if counter is not None:
+        assert counter.dtype == torch.int32 and counter.numel() >= C1 - 1 and counter.is_cuda
+    L.check(L.load().sedt_pseudo_labels(_p(logits), _p(boxes), _p(at), _p(thr), float(min_len), B, Q, C1 - 1, int(bool(del_overlap)),
+                                        _p(tables['lab_cat']), _p(tables['box_cat']), _p(tables['lab_off']), _p(tables['box_off']),
+                                        _p(counter), cap, L.stream_ptr()), 'pseudo_labels')

@@ -21,16 +21,24 @@ class HungarianMatcher(nn.Module):
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
 
     @torch.no_grad()
-    def cost_matrices(self, logits, boxes, tgt_ids, tgt_bbox):
-        """logits [L,B,Q,C+1], boxes [L,B,Q,2], targets concatenated over the batch -> [L,B,Q,Nt]"""
-        prob = logits.float().softmax(-1)
-        cost_class = -prob[..., tgt_ids]
+    def cost_matrices(self, logits, boxes, tgt_ids, tgt_bbox, fl=False, with_loc=False, alpha_fl=0.5, gamma_fl=1.0):
+        """logits [L,B,Q,C+1], boxes [L,B,Q,2], targets concatenated over the batch -> (cost [L,B,Q,Nt], loc or None).
+        fl: the focal matching cost on sigmoid probabilities (matcher.py:73-78); loc = the localisation-only part
+        cost_bbox * L1 - cost_giou * GIoU that the fine-tune re-matching thresholds (matcher.py:99-104)."""
+        if fl:
+            p = logits.float().sigmoid()
+            neg = (1 - alpha_fl) * p ** gamma_fl * (-(1 - p + 1e-8).log())
+            pos = alpha_fl * (1 - p) ** gamma_fl * (-(p + 1e-8).log())
+            cost_class = pos[..., tgt_ids] - neg[..., tgt_ids]
+        else:
+            cost_class = -logits.float().softmax(-1)[..., tgt_ids]
         c, l = boxes[..., 0].float(), boxes[..., 1].float()
         tc, tl = tgt_bbox[:, 0], tgt_bbox[:, 1]
         s1, e1, s2, e2 = c - l / 2, c + l / 2, tc - tl / 2, tc + tl / 2
         cost_bbox = (s1[..., None] - s2).abs() + (e1[..., None] - e2).abs()      # y extents (0,1) cancel
         giou = interval_giou_pairwise(c.reshape(-1), l.reshape(-1), tc, tl).view(*c.shape, -1)
-        return self.cost_bbox * cost_bbox + self.cost_class * cost_class - self.cost_giou * giou
+        cost = self.cost_bbox * cost_bbox + self.cost_class * cost_class - self.cost_giou * giou
+        return cost, (self.cost_bbox * cost_bbox - self.cost_giou * giou) if with_loc else None
 
     @torch.no_grad()
     def match_layers(self, logits, boxes, targets):
@@ -43,7 +51,7 @@ class HungarianMatcher(nn.Module):
             return [[(e, e) for _ in range(B)] for _ in range(L)]
         tgt_ids = torch.cat([v["labels"][:len(v["boxes"])] for v in targets]).to(dev)
         tgt_bbox = torch.cat([v["boxes"] for v in targets]).to(dev).float()
-        C = self.cost_matrices(logits, boxes, tgt_ids, tgt_bbox).cpu()          # the one device->host sync
+        C = self.cost_matrices(logits, boxes, tgt_ids, tgt_bbox)[0].cpu()       # the one device->host sync
         out = []
         for l in range(L):
             per, off = [], 0
@@ -69,9 +77,10 @@ class HungarianMatcher(nn.Module):
 
     @torch.no_grad()
     def forward(self, outputs, targets, fine_tune=False, normalize=False, fl=False):
-        """reference-compatible single-layer interface: (indices, coefficients)"""
+        """reference-compatible single-layer interface: (indices, coefficients).  The fine_tune / fl variants live in
+        SetCriterion.prepare / prepare_device (they need the loss-side bookkeeping); this entry covers the plain matching."""
         if fine_tune or fl:
-            raise NotImplementedError('fine_tune re-matching / focal costs (matcher.py:73-78, 99-121) are not built')
+            raise NotImplementedError('call SetCriterion(outputs, targets, ..., fine_tune=, fl=): the variants are implemented there')
         idx = self.match_layers(outputs["pred_logits"][None], outputs["pred_boxes"][None], targets)[0]
         return idx, self.coefficients(idx, targets, normalize)
 

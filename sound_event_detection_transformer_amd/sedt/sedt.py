@@ -214,16 +214,20 @@ class TargetTables(object):
         return self
 
 
+ALPHA_FL, GAMMA_FL = 0.5, 1.0          # reference config.py:71-72 (focal-loss constants)
+
+
 class _CriterionFn(torch.autograd.Function):
     """autograd node around ops.set_criterion / set_criterion_bwd: forward computes the loss vector and every per-term
     gradient; backward combines them with the gradient that reached the vector (weighted total and/or single entries)."""
 
     @staticmethod
-    def forward(ctx, logits_all, boxes_all, at, dense, empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak):
+    def forward(ctx, logits_all, boxes_all, at, dense, empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak, fl, nonfinite):
         from .. import ops
         out, ctx.state = ops.set_criterion(logits_all.detach().float().contiguous(), boxes_all.detach().float().contiguous(),
                                            None if at is None else at.detach().float().contiguous(), dense,
-                                           empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak)
+                                           empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak, fl=fl, alpha_fl=ALPHA_FL,
+                                           gamma_fl=GAMMA_FL, nonfinite=nonfinite)
         ctx.dts = (logits_all.dtype, boxes_all.dtype, None if at is None else at.dtype)
         return out
 
@@ -232,16 +236,43 @@ class _CriterionFn(torch.autograd.Function):
         from .. import ops
         gl, gb, gat = ops.set_criterion_bwd(ctx.state, g)
         return (gl.to(ctx.dts[0]), gb.to(ctx.dts[1]), None if gat is None else gat.to(ctx.dts[2]),
-                None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
+
+
+class _FeatureLossFn(torch.autograd.Function):
+    """SP-SEDT feature reconstruction (sedt.py:263-283) of all decoder layers: out[:L] = loss_feature per dense layer,
+    out[L] = their weighted sum.  The forward launch also leaves the unweighted gradient; backward scales it per layer."""
+
+    @staticmethod
+    def forward(ctx, pred_all, gt, dense, layer_of, num_boxes, wvec):
+        from .. import ops
+        loss, ctx.dpred = ops.feature_loss(pred_all.detach().float().contiguous(), gt.detach().float().contiguous(), dense,
+                                           layer_of, num_boxes)
+        ctx.wvec, ctx.dt = wvec, pred_all.dtype
+        L = loss.numel()
+        out = torch.empty(L + 1, device=loss.device, dtype=torch.float32)
+        out[:L] = loss
+        out[L] = torch.dot(loss, wvec)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import ops
+        g = g.contiguous().float()
+        L = g.numel() - 1
+        d = ops.scale_layers(ctx.dpred, g[:L], g[L:], ctx.wvec)
+        ctx.dpred = None
+        return d.to(ctx.dt), None, None, None, None, None
 
 
 class SetCriterion(nn.Module):
-    """reference sedt.py:134-352 (fl=False, fine_tune=False): same loss names, weights and normalisation.
+    """reference sedt.py:134-352: same loss names, weights, normalisation, fine_tune / normalize / fl switches.
 
-    Host-side by design (north star), but organised for the GPU it feeds: ``prepare`` builds the matching costs of ALL
-    decoder layers on the device, brings them to the host in ONE copy, solves every assignment in one C++ call
-    (sedt_hungarian_batch) and uploads dense, fixed-shape target tensors in ONE copy; ``compute`` is then pure
-    fixed-shape device math (no gathers, no per-layer loops), which also makes it capturable in a HIP graph."""
+    ``forward`` keeps the reference's host-side API (list-of-dict targets; north star: matching on the host) but is
+    organised for the GPU it feeds: ``prepare`` builds the matching costs of ALL decoder layers on the device, brings them
+    to the host in ONE copy, solves every assignment in one C++ call (sedt_hungarian_batch) and uploads dense, fixed-shape
+    target tensors in ONE copy; ``compute`` is then one fused launch for every loss and gradient.  ``prepare_device`` is
+    the same preparation without leaving the device (sedt_match_targets), which lets a whole step live in one HIP graph."""
 
     def __init__(self, num_classes, matcher, weight_dict, eos_coef, losses):
         super().__init__()
@@ -252,10 +283,14 @@ class SetCriterion(nn.Module):
         self.register_buffer('empty_weight', empty_weight)
         self.last_total = None
         self._wvec = {}
+        self.nonfinite = None                     # optional int32 device word (engine: polled instead of a sync per step)
 
     # ------------------------------------------------------------------ host part
     @torch.no_grad()
-    def prepare(self, outputs, targets, weak_mask=None, strong_mask=None, normalize=False):
+    def prepare(self, outputs, targets, weak_mask=None, strong_mask=None, normalize=False, fine_tune=False, fl=False,
+                ft_rand=None):
+        """ft_rand: optional list (one entry per strong clip) of the uniforms the fine-tune branch consumes, in the order the
+        reference draws them (matcher.py:116); default: torch.rand."""
         import numpy as np
         from .. import lib as L_
         if strong_mask is None or strong_mask.start not in (None, 0) or strong_mask.step not in (None, 1):
@@ -274,12 +309,18 @@ class SetCriterion(nn.Module):
         n_lab = max(n_lab, ns)
         lab_sizes = [int(len(targets[i]['labels'])) for i in range(n_lab)]
         has_ratio = any('ratio' in t for t in targets[:n_lab])
+        if fine_tune and has_ratio and not normalize:
+            raise ValueError('fine_tune with mixup ratios is undefined in the reference (matcher.py:130: shapes mismatch)')
+        if fine_tune and (Nt == 0 or min(sizes) == 0):
+            raise ValueError('fine_tune needs at least one event in every strong clip (matcher.py:103 takes a min over them)')
         parts = []
         if Nt > 0:
             tgt_ids = torch.cat([t['labels'][:len(t['boxes'])] for t in st]).to(dev)
             tgt_bbox = torch.cat([t['boxes'].reshape(-1, 2) for t in st]).to(dev).float()
-            cost = self.matcher.cost_matrices(logits, boxes, tgt_ids, tgt_bbox)
+            cost, loc = self.matcher.cost_matrices(logits, boxes, tgt_ids, tgt_bbox, fl=fl, with_loc=fine_tune)
             parts += [cost.flatten(), tgt_bbox.flatten()]
+            if fine_tune:
+                parts.append(loc[0].flatten())
         lab_all = torch.cat([targets[i]['labels'] for i in range(n_lab)]).to(dev).float() if sum(lab_sizes) else None
         if lab_all is not None:
             parts.append(lab_all)
@@ -290,13 +331,30 @@ class SetCriterion(nn.Module):
         o = 0
         assign = -np.ones((L, ns, Q), np.int32)
         tb = np.zeros((Nt, 2), np.float32)
+        off = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32) if ns else np.zeros(0, np.int32)
+        extra0 = np.zeros((ns, Q), bool)              # fine_tune: queries added beyond the Hungarian pairs (final layer)
         if Nt > 0:
             cost_h = np.ascontiguousarray(host[o:o + L * ns * Q * Nt]); o += L * ns * Q * Nt
             tb = host[o:o + 2 * Nt].reshape(Nt, 2); o += 2 * Nt
-            off = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int32)
             nc = np.asarray(sizes, np.int32)
             L_.check(L_.load().sedt_hungarian_batch(cost_h.ctypes.data, L, ns, Q, Nt, off.ctypes.data, nc.ctypes.data,
                                                     assign.ctypes.data), 'hungarian_batch')
+            if fine_tune:                             # matcher.py:99-121 on the final layer's assignment
+                loc_h = host[o:o + ns * Q * Nt].reshape(ns, Q, Nt); o += ns * Q * Nt
+                m = self.matcher
+                for b, n in enumerate(sizes):
+                    cl = loc_h[b][:, off[b]:off[b] + n]
+                    near_t, near_c = cl.argmin(1), cl.min(1)
+                    hung = assign[0, b] >= 0
+                    close = near_c < np.float32(m.epsilon)
+                    extra = np.nonzero(close & ~hung)[0]
+                    u = (np.asarray(ft_rand[b], np.float32)[:len(extra)] if ft_rand is not None
+                         else torch.rand(len(extra)).numpy())
+                    add = extra[~(u > np.float32(m.alpha * int(hung.sum()) / Q))]
+                    new = np.where(hung & close, assign[0, b], -1)
+                    new[add] = near_t[add]
+                    assign[0, b] = new
+                    extra0[b, add] = True
         nl = sum(lab_sizes)
         lab_h = host[o:o + nl].astype(np.int64); o += nl
         ratio_h = host[o:o + nl] if has_ratio else np.ones(nl, np.float32)
@@ -305,19 +363,26 @@ class SetCriterion(nn.Module):
         nmax = max(max(sizes) if sizes else 0, 1)
         lab_pad = np.full((ns, nmax), self.num_classes, np.int64)
         box_pad = np.full((ns, nmax, 2), 0.5, np.float32)
-        rat_pad = np.ones((ns, nmax), np.float32)
+        rat_pos = np.ones((ns, max(Q, 1)), np.float32)       # ratio[k] for the k-th matched query (POSITIONAL, matcher.py:130)
         bo = 0
         for b, n in enumerate(sizes):
             lab_pad[b, :n] = lab_h[lab_off[b]:lab_off[b] + n]
             box_pad[b, :n] = tb[bo:bo + n]
-            rat_pad[b, :n] = ratio_h[lab_off[b]:lab_off[b] + n]
+            r = ratio_h[lab_off[b]:lab_off[b + 1]][:Q]
+            rat_pos[b, :len(r)] = r
             bo += n
         matched = assign >= 0
         a = np.clip(assign, 0, None)
         bi = np.arange(ns)[None, :, None]
+        kth = np.clip(np.cumsum(matched, axis=2) - 1, 0, None)
+        cf = rat_pos[bi, kth] if has_ratio else np.ones((L, ns, Q), np.float32)
+        if normalize:                                         # final layer only (sedt.py:320 vs :340): 1 / #queries per target
+            cnt = (a[0][:, :, None] == a[0][:, None, :]) & matched[0][:, :, None] & matched[0][:, None, :]
+            cf = cf.copy()
+            cf[0] = 1.0 / np.maximum(cnt.sum(2), 1)
         tc = np.where(matched, lab_pad[bi, a], self.num_classes).astype(np.float32)
-        coef = np.where(matched, rat_pad[bi, a], 1.0).astype(np.float32)          # CE weight of every query
-        wbox = np.where(matched, rat_pad[bi, a], 0.0).astype(np.float32)          # box-loss weight (0 = unmatched)
+        coef = np.where(matched, cf, 1.0).astype(np.float32)          # CE weight of every query
+        wbox = np.where(matched, cf, 0.0).astype(np.float32)          # box-loss weight (0 = unmatched)
         tbox = np.where(matched[..., None], box_pad[bi, a], 0.5).astype(np.float32)
         num_boxes = float(wbox[0].sum())
         C = self.num_classes
@@ -331,8 +396,12 @@ class SetCriterion(nn.Module):
                                gt_weak.ravel(), tgt_len, np.asarray([num_boxes], np.float32)])
         d = torch.from_numpy(pack).to(dev, non_blocking=True)                       # the ONE host->device copy
         dense = self.dense_views(d, (L, ns, Q, n_lab, C, len(targets)))
-        idx0 = [(torch.from_numpy(np.nonzero(matched[0, b])[0].astype(np.int64)),
-                 torch.from_numpy(assign[0, b][matched[0, b]].astype(np.int64))) for b in range(ns)]
+        idx0 = []
+        for b in range(ns):                           # reference order: surviving Hungarian pairs, then the added queries
+            first = np.nonzero(matched[0, b] & ~extra0[b])[0]
+            second = np.nonzero(extra0[b])[0]
+            qs = np.concatenate([first, second]).astype(np.int64)
+            idx0.append((torch.from_numpy(qs), torch.from_numpy(assign[0, b][qs].astype(np.int64))))
         return dense, idx0
 
     @staticmethod
@@ -350,10 +419,11 @@ class SetCriterion(nn.Module):
                 'num_boxes': d[-1:], 'ns': ns, 'n_lab': n_lab, 'L': L, '_pack': d, '_meta': meta}
 
     # ------------------------------------------------------------------ device matching (no host round trip)
-    def prepare_device(self, outputs, tables, pack=None, assign=None):
+    def prepare_device(self, outputs, tables, pack=None, assign=None, normalize=False, fine_tune=False, fl=False, ft_rand=None):
         """same result as ``prepare`` (dense targets of all decoder layers), but the assignment problems are solved ON the
         device (ops.match_targets: one wave per problem) from the flat target tables of ``TargetTables`` - no device->host
-        copy, no host work that depends on model outputs, so the whole train step can be captured in ONE HIP graph."""
+        copy, no host work that depends on model outputs, so the whole train step can be captured in ONE HIP graph.
+        ft_rand: optional f32 [ns, Q] device tensor of injected uniforms (default: a counter hash, fresh per replay)."""
         from .. import ops
         if '_stacked' not in outputs:
             raise RuntimeError('prepare_device needs the stacked head outputs (model built with aux_loss=True)')
@@ -363,11 +433,14 @@ class SetCriterion(nn.Module):
         if pack is None:
             pack = torch.zeros(self.dense_numel(meta), device=logits_all.device, dtype=torch.float32)
         dense = self.dense_views(pack, meta)
-        dense['num_boxes'] = None                   # the loss kernel sums the final layer's box weights itself
         m = self.matcher
+        seed_ptr = runtime.seed_ptr(logits_all.device) if (fine_tune and ft_rand is None) else None
         ops.match_targets(logits_all.detach().float().contiguous(), boxes_all.detach().float().contiguous(), tables.as_dict(),
                           dense, [L - 1] + list(range(L - 1)), float(m.cost_class), float(m.cost_bbox), float(m.cost_giou),
-                          tables.max_targets, assign=assign)
+                          tables.max_targets, assign=assign, fl=fl, fine_tune=fine_tune, normalize=normalize,
+                          epsilon=float(m.epsilon), alpha=float(m.alpha), alpha_fl=ALPHA_FL, gamma_fl=GAMMA_FL, ft_rand=ft_rand,
+                          ft_seed=runtime.next_seed() if (fine_tune and ft_rand is None) else 0, seed_ptr=seed_ptr)
+        dense['num_boxes'] = ops.sum_f32(dense['wbox'][0], out=dense['num_boxes'])   # sum of the final layer's coefficients
         return dense
 
     @staticmethod
@@ -379,27 +452,35 @@ class SetCriterion(nn.Module):
     def _weights(self, name, L):
         return [float(self.weight_dict.get(name if d == 0 else f'{name}_{d - 1}', 0.0)) for d in range(L)]
 
-    def _compute_fused(self, outputs, dense):
-        """all losses + their gradients in ONE launch (csrc/criterion.hip) when the model handed over its stacked head
-        outputs; the dict returned has the same keys / values as the op-by-op path below."""
-        logits_all, boxes_all = outputs['_stacked']
+    def _dev_const(self, key, values, device):
+        k = (key, str(device))
+        if k not in self._wvec:                       # uploaded once, then reused (graph-capture safe)
+            self._wvec[k] = torch.tensor(values, device=device, dtype=torch.float32)
+        return self._wvec[k]
+
+    def _compute_fused(self, outputs, dense, fl=False):
+        """all losses + their gradients in ONE launch (csrc/criterion.hip) - plus one for the SP-SEDT feature loss; the dict
+        returned has the same keys / values as the reference's."""
+        if '_stacked' in outputs:
+            logits_all, boxes_all = outputs['_stacked']
+        else:                                          # a hand-made output dict: stack [final, aux_0, ...] -> model order
+            layers = list(outputs.get('aux_outputs', [])) + [outputs]
+            logits_all = torch.stack([o['pred_logits'] for o in layers])
+            boxes_all = torch.stack([o['pred_boxes'] for o in layers])
         L = dense['L']
+        layer_of = [L - 1] + list(range(L - 1))
         at = outputs['at'] if ('weak' in self.losses and 'at' in outputs) else None
         if at is not None and at.dim() == 1:
             at = at[None]
         zero = [0.0] * L
-        ew = self.empty_weight
-        if ew.device != logits_all.device or ew.dtype != torch.float32:      # criterion left on the CPU: upload once
-            key = ('ew', str(logits_all.device))
-            if key not in self._wvec:
-                self._wvec[key] = ew.detach().to(logits_all.device, torch.float32)
-            ew = self._wvec[key]
+        dev = logits_all.device
+        ew = self._dev_const('ew', self.empty_weight.detach().float().tolist(), dev)
         vec = _CriterionFn.apply(
-            logits_all, boxes_all, at, dense, ew, [L - 1] + list(range(L - 1)),
+            logits_all, boxes_all, at, dense, ew, layer_of,
             self._weights('loss_ce', L) if 'labels' in self.losses else zero,
             self._weights('loss_bbox', L) if 'boxes' in self.losses else zero,
             self._weights('loss_giou', L) if 'boxes' in self.losses else zero,
-            float(self.weight_dict.get('loss_weak', 0.0)) if at is not None else 0.0)
+            float(self.weight_dict.get('loss_weak', 0.0)) if at is not None else 0.0, fl, self.nonfinite)
         out = {}
         names = []
         if 'labels' in self.losses:
@@ -415,13 +496,35 @@ class SetCriterion(nn.Module):
                 out[k if d == 0 else f'{k}_{d - 1}'] = v.detach() if slot == 3 else v
         if at is not None:
             out['loss_weak'] = vec[4 * L + 2]
-        self.last_total = vec[4 * L + 3]
+        total = vec[4 * L + 3]
+        if 'feature' in self.losses:
+            if '_stacked_feature' in outputs:
+                feats = outputs['_stacked_feature']
+            else:
+                feats = torch.stack([o['pred_feature'] for o in list(outputs.get('aux_outputs', [])) + [outputs]])
+            wv = self._dev_const(('wfeat', L), self._weights('loss_feature', L), dev)
+            nb = dense['num_boxes'] if dense.get('num_boxes') is not None else None
+            if nb is None:
+                from .. import ops
+                nb = ops.sum_f32(dense['wbox'][0])
+            fv = _FeatureLossFn.apply(feats, outputs['gt_feature'], dense, layer_of, nb, wv)
+            for d in range(L):
+                out['loss_feature' if d == 0 else f'loss_feature_{d - 1}'] = fv[d]
+            total = total + fv[L]
+        self.last_total = total
         return out
 
-    def compute(self, outputs, dense):
-        if '_stacked' in outputs and outputs['pred_logits'].is_cuda and 'feature' not in self.losses \
-                and outputs['_stacked'][0].shape[0] == dense['L'] <= 8 and 8 * outputs['pred_logits'].shape[0] <= 8192:
-            return self._compute_fused(outputs, dense)
+    def compute(self, outputs, dense, fl=False):
+        if outputs['pred_logits'].is_cuda:
+            L, B = dense['L'], outputs['pred_logits'].shape[0]
+            if L > 8 or L * B > 8192:
+                raise NotImplementedError(f'fused criterion handles up to 8 decoder layers and L*B <= 8192 (got {L}, {B})')
+            return self._compute_fused(outputs, dense, fl)
+        return self._compute_host(outputs, dense, fl)
+
+    def _compute_host(self, outputs, dense, fl=False):
+        """the same losses with torch ops on HOST tensors - only for exercising the matching / target logic without a GPU
+        (tests/test_criterion_cpu.py); GPU tensors always take the fused kernels"""
         layers = [outputs] + list(outputs.get('aux_outputs', []))
         L, ns, nb = dense['L'], dense['ns'], dense['num_boxes']
         if nb is None:
@@ -434,8 +537,17 @@ class SetCriterion(nn.Module):
         vec = {}
         tc = dense['tc'].long()
         if 'labels' in self.losses:
-            ce = F.cross_entropy(logits.reshape(-1, C1), tc.reshape(-1), self.empty_weight.to(logits.device),
-                                 reduction='none').view(L, -1)
+            if fl:
+                onehot = F.one_hot(tc, C1).float()
+                p = logits.sigmoid()
+                ce = F.binary_cross_entropy_with_logits(logits, onehot, pos_weight=self.empty_weight.to(logits.device), reduction='none')
+                ce = ce * (1 - (p * onehot + (1 - p) * (1 - onehot))) ** GAMMA_FL
+                if ALPHA_FL >= 0:
+                    ce = ce * (ALPHA_FL * onehot + (1 - ALPHA_FL) * (1 - onehot))
+                ce = ce.sum(-1).view(L, -1)
+            else:
+                ce = F.cross_entropy(logits.reshape(-1, C1), tc.reshape(-1), self.empty_weight.to(logits.device),
+                                     reduction='none').view(L, -1)
             vec['loss_ce'] = (ce * dense['coef'].view(L, -1)).sum(1) / nb
             with torch.no_grad():
                 m = (dense['wbox'][0] > 0)
@@ -468,54 +580,44 @@ class SetCriterion(nn.Module):
             for li in range(L):
                 out[k if li == 0 else f'{k}_{li - 1}'] = v[li]
         if 'weak' in self.losses and 'at' in outputs:
-            out['loss_weak'] = F.binary_cross_entropy(outputs['at'][:dense['n_lab']].float(), dense['gt_weak'])
+            pw, gw = outputs['at'][:dense['n_lab']].float(), dense['gt_weak']
+            if fl:
+                ce = F.binary_cross_entropy(pw, gw, reduction='none') * (1 - (pw * gw + (1 - pw) * (1 - gw))) ** GAMMA_FL
+                if ALPHA_FL >= 0:
+                    ce = ce * (ALPHA_FL * gw + (1 - ALPHA_FL) * (1 - gw))
+                out['loss_weak'] = ce.sum(1).mean()
+            else:
+                out['loss_weak'] = F.binary_cross_entropy(pw, gw)
         wd = self.weight_dict
         total = None
         for k, v in vec.items():
             wts = [wd.get(k if li == 0 else f'{k}_{li - 1}', 0.0) for li in range(L)]
             if any(wts):
-                key = (k, L, str(v.device))
-                if key not in self._wvec:                     # uploaded once, then reused (graph-capture safe)
-                    self._wvec[key] = torch.tensor(wts, device=v.device, dtype=v.dtype)
-                term = (v * self._wvec[key]).sum()
+                term = (v * torch.tensor(wts, device=v.device, dtype=v.dtype)).sum()
                 total = term if total is None else total + term
         if 'loss_weak' in out and wd.get('loss_weak', 0.0):
             total = out['loss_weak'] * wd['loss_weak'] + (total if total is not None else 0.0)
         self.last_total = total
         return out
 
-    def forward(self, outputs, targets, weak_mask=None, strong_mask=None, fine_tune=False, normalize=False, fl=False):
-        if fine_tune or fl:
-            raise NotImplementedError('fine_tune / focal-loss branches (sedt.py:176,211-218; matcher.py:99-121) are not built')
-        dense, idx0 = self.prepare(outputs, targets, weak_mask, strong_mask, normalize)
-        return self.compute(outputs, dense), idx0
+    def forward(self, outputs, targets, weak_mask=None, strong_mask=None, fine_tune=False, normalize=False, fl=False,
+                ft_rand=None):
+        dense, idx0 = self.prepare(outputs, targets, weak_mask, strong_mask, normalize, fine_tune, fl, ft_rand)
+        return self.compute(outputs, dense, fl), idx0
 
 
 class PostProcess(nn.Module):
-    """reference sedt.py:355-396: logits/boxes -> per-clip scores, labels, (onset, offset) in seconds"""
+    """reference sedt.py:355-396: logits/boxes -> per-clip scores, labels, (onset, offset) in seconds - one launch
+    (sedt_postprocess) for the whole batch and every fusion mode; the list of per-clip dicts the reference returns is a
+    list of views into the batched results."""
+
+    @torch.no_grad()
+    def batched(self, outputs, target_sizes, audio_tags=None, at_m=2, is_semi=False, threshold=0.5):
+        from .. import ops
+        return ops.postprocess(outputs['pred_logits'], outputs['pred_boxes'], None if is_semi else target_sizes, audio_tags, at_m,
+                               is_semi, threshold)
 
     @torch.no_grad()
     def forward(self, outputs, target_sizes, audio_tags=None, at_m=2, is_semi=False, threshold=0.5):
-        out_logits, out_bbox = outputs['pred_logits'], outputs['pred_boxes']
-        bs, num_q, _ = out_logits.shape
-        prob = F.softmax(out_logits.float(), -1)
-        if audio_tags is not None:
-            cls = prob[..., :-1]
-            at = audio_tags.to(prob.device).float()
-            if at_m in (2, 3):
-                best_q = cls.argmax(1)                                          # (B, C): query with the max prob per class
-                best = cls.gather(1, best_q[:, None, :])[:, 0, :]
-                lift = best < threshold
-                if at_m == 3:
-                    lift = lift & at.bool()
-                raised = torch.where(lift, torch.full_like(best, threshold), best)
-                cls = cls.scatter(1, best_q[:, None, :], raised[:, None, :])
-            if at_m in (1, 2):
-                cls = cls * at[:, None, :]
-            prob = torch.cat([cls, prob[..., -1:]], dim=-1)
-        scores, labels = prob[..., :-1].max(-1)
-        if not is_semi:
-            boxes = box_ops.box_cxcywh_to_se(out_bbox.float()) * target_sizes.to(out_bbox.device).float().view(-1, 1, 1)
-        else:
-            boxes = out_bbox
+        scores, labels, boxes = self.batched(outputs, target_sizes, audio_tags, at_m, is_semi, threshold)
         return [{'scores': s, 'labels': l, 'boxes': b} for s, l, b in zip(scores, labels, boxes)]

@@ -68,6 +68,8 @@ class SPSEDT(SEDT):
             if self.aux_loss:
                 out['aux_outputs'] = [{'pred_logits': a, 'pred_boxes': b, 'pred_feature': c, 'gt_feature': gt}
                                       for a, b, c in zip(outputs_class[:-1], outputs_coord[:-1], outputs_feature[:-1])]
+                out['_stacked'] = (outputs_class, outputs_coord)      # all decoder layers, for the fused criterion kernels
+                out['_stacked_feature'] = outputs_feature
         else:
             out = {'pred_logits': outputs_class[-1], 'pred_boxes': outputs_coord[-1]}
             if self.aux_loss:

@@ -77,3 +77,57 @@ def test_ema_host_loop_matches_reference_formula():
     assert torch.equal(m.weight.data, ema.shadow['weight'])
     ema.restore()
     assert torch.equal(m.weight.data, w0 + 1.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# G9: the fine_tune / normalize / focal-loss / ratio variants of the product's host criterion path (CPU tensors)
+import sys                                                                             # noqa: E402
+
+import pytest                                                                          # noqa: E402
+
+from conftest import GOLDEN                                                            # noqa: E402
+
+sys.path.insert(0, GOLDEN)
+import inputs as GI                                                                    # noqa: E402
+
+G9_CASES = {'ft': (True, False, False, 1.0), 'ft_eps3': (True, False, False, 3.0), 'ft_norm_eps3': (True, True, False, 3.0),
+            'fl': (False, False, True, 1.0), 'fl_ft_eps3': (True, False, True, 3.0)}
+
+
+def _rows(a):
+    return [r[r >= 0] for r in a]
+
+
+@pytest.mark.parametrize('name', list(G9_CASES))
+def test_g9_variants_host_path(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, 'g9_criterion_variants.npz'))
+    ft, norm, fl, eps = G9_CASES[name]
+    crit = _crit()
+    crit.matcher.epsilon = eps
+    outputs, targets, B, Q = GI.g9_inputs()
+    ld, idx = crit(outputs, targets, None, slice(B), ft, norm, fl, ft_rand=_rows(g[f'{name}_rand']) if ft else None)
+    for b, (i, j) in enumerate(idx):
+        np.testing.assert_array_equal(i.numpy(), _rows(g[f'{name}_src'])[b])
+        np.testing.assert_array_equal(j.numpy(), _rows(g[f'{name}_tgt'])[b])
+    assert set(ld) == {k[len(name) + 6:] for k in g.files if k.startswith(f'{name}_loss_')}
+    for k, v in ld.items():
+        assert abs(v.item() - float(g[f'{name}_loss_{k}'])) <= 2e-5 * max(1.0, abs(v.item())), k
+
+
+def test_g9_focal_weak_and_positional_ratio_host_path(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'g9_criterion_variants.npz'))
+    crit = _crit()
+    outputs, targets, B, Q = GI.g9_inputs()
+    t2 = [dict(t) for t in targets]
+    for t in t2[4:]:
+        t['boxes'] = torch.zeros(0, 2)
+    ld, _ = crit(outputs, t2, slice(4, 6), slice(4), False, False, True)
+    for k, v in ld.items():
+        assert abs(v.item() - float(g[f'fl_ws_loss_{k}'])) <= 2e-5 * max(1.0, abs(v.item())), k
+    t3 = [dict(t) for t in targets]
+    for t, r in zip(t3, _rows(g['ratio_values'])):
+        if len(r):
+            t['ratio'] = torch.from_numpy(r.copy())
+    ld, _ = crit(outputs, t3, None, slice(B))
+    for k, v in ld.items():
+        assert abs(v.item() - float(g[f'ratio_loss_{k}'])) <= 2e-5 * max(1.0, abs(v.item())), k
