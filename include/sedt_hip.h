@@ -350,11 +350,14 @@ int sedt_set_criterion_bwd(const SedtCriterion* args, const float* g, float* glo
  *   out[d] = sum over matched rows / num_boxes.  dpred receives d out[d] / d pred (unweighted; zero rows where unmatched).
  * pred / dpred [L][B][Q][F] f32, gt [B*P][F] f32 (treated as a constant: the SP-SEDT backbone is frozen,
  * train_spsedt.py:50), wbox / tidx [L][ns][Q] as written by sedt_match_targets, num_boxes [1] device scalar.
- * rowloss [L*ns*Q] scratch.  Deterministic (fixed summation order).  sedt_scale_rows: x[l][...] *= g[l] + gtot[0]*w[l]. */
+ * rowloss [L*ns*Q] scratch.  Deterministic (fixed summation order).  sedt_scale_layers: x[l][...] *= g[d] + gtot[0]*w[d] with d = idx[l] (idx = inverse of layer_of: dpred is in the model's
+ * layer order, the loss vector in dense order). */
 int sedt_feature_loss(const float* pred, const float* gt, const float* wbox, const float* tidx, const float* num_boxes,
-                      const int32_t* layer_of, int L, int B, int ns, int Q, int P, int F, float* rowloss, float* out,
-                      float* dpred, void* stream);
-int sedt_scale_layers(float* x, const float* g, const float* gtot, const float* w, int L, int64_t per_layer, void* stream);
+                      const int32_t* layer_of /* host [L] */, const float* w /* device [L] or null */, int L, int B, int ns,
+                      int Q, int P, int F, float* rowloss, float* out /* [L+1]: out[L] = sum_d w[d] out[d] */, float* dpred,
+                      void* stream);
+int sedt_scale_layers(float* x, const float* g, const float* gtot, const float* w, const int32_t* idx /* host [L] or null */,
+                      int L, int64_t per_layer, void* stream);
 /* out[0] = sum_i x[i] (one workgroup, fixed order): num_boxes = sum of the final layer's box weights (sedt.py:322-324) */
 int sedt_sum_f32(const float* x, int n, float* out, void* stream);
 

@@ -251,7 +251,7 @@ __device__ int wave_lsa(int n, int m, F cost) {
   int p = 0, way = 0;             // lane j: row matched to column j; predecessor column on the alternating path
   for (int i = 1; i <= n; ++i) {
     if (lane == 0) p = i;
-    int j0 = 0;
+    int j0 = 0, guard = 0;
     double minv = INF;
     bool used = false, in_rows = false;
     do {
@@ -277,13 +277,15 @@ __device__ int wave_lsa(int n, int m, F cost) {
       if (in_rows) u += delta;
       if (used) v -= delta; else minv -= delta;
       j0 = bj;
-    } while (__shfl(p, j0, 64) != 0);
+    } while (j0 < 64 && __shfl(p, j0, 64) != 0 && ++guard <= m + 1);
+    if (j0 >= 64) j0 = 0;         // (unreachable with finite costs)
+    guard = 0;
     do {                          // augment along the path
       const int j1 = __shfl(way, j0, 64);
       const int pj1 = __shfl(p, j1, 64);
       if (lane == j0) p = pj1;
       j0 = j1;
-    } while (j0);
+    } while (j0 && ++guard <= m + 1);
   }
   return p;
 }
@@ -343,8 +345,14 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
     const float hull = fmaxf(fmaxf(e1, e2) - fminf(s1, s2), 0.f);
     const float giou = inter / uni - (hull - uni) / hull;
     const float cost_class = prob[q * C1 + (int)a.lab_cat[lo + t]];
-    cst[q * n + t] = a.w_bbox * cost_bbox + a.w_class * cost_class - a.w_giou * giou;
-    if (main_ft) loc[q * n + t] = a.w_bbox * cost_bbox - a.w_giou * giou;
+    // a non-finite cost (diverged model outputs) must not stall the augmenting-path search: it becomes a huge finite cost,
+    // the losses computed afterwards are NaN/inf anyway and raise the criterion's non-finite flag
+    const float cv = a.w_bbox * cost_bbox + a.w_class * cost_class - a.w_giou * giou;
+    cst[q * n + t] = fabsf(cv) <= 1e30f ? cv : 1e30f;
+    if (main_ft) {
+      const float lv = a.w_bbox * cost_bbox - a.w_giou * giou;
+      loc[q * n + t] = fabsf(lv) <= 1e30f ? lv : 1e30f;
+    }
   }
   __syncthreads();
   // assignment: target index matched to query `lane`, or -1

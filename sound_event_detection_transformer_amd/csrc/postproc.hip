@@ -232,16 +232,24 @@ __global__ __launch_bounds__(256) void feature_loss_kernel(const float* __restri
   }
 }
 
-// out[d] = sum of rowloss[d][ns*Q] in a fixed order (one workgroup per dense layer)
-__global__ __launch_bounds__(256) void feature_loss_reduce_kernel(const float* __restrict__ rowloss, int n, float* __restrict__ out) {
+// out[d] = sum of rowloss[d][ns*Q] in a fixed order for every dense layer d, out[L] = sum_d w[d] * out[d] (one workgroup)
+__global__ __launch_bounds__(256) void feature_loss_reduce_kernel(const float* __restrict__ rowloss, int n, int L,
+                                                                  const float* __restrict__ w, float* __restrict__ out) {
   __shared__ float red[4];
-  const float* r = rowloss + (long)blockIdx.x * n;
-  float v = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) v += r[i];
-  v = wave_sum(v);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  float tot = 0.f;
+  for (int d = 0; d < L; ++d) {
+    const float* r = rowloss + (long)d * n;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) v += r[i];
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float s = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) out[d] = s;
+    tot += (w ? w[d] : 0.f) * s;
+  }
+  if (threadIdx.x == 0) out[L] = tot;
 }
 
 __global__ __launch_bounds__(256) void sum_f32_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
@@ -254,12 +262,13 @@ __global__ __launch_bounds__(256) void sum_f32_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// x[l][i] *= g[l] + gtot[0] * w[l]
+// x[l][i] *= g[d] + gtot[0] * w[d],  d = idx[l]
+struct LayerIdx { int v[8]; };
 __global__ __launch_bounds__(256) void scale_layers_kernel(float* __restrict__ x, const float* __restrict__ g,
                                                            const float* __restrict__ gtot, const float* __restrict__ w,
-                                                           long per_layer4) {
-  const int l = blockIdx.y;
-  const float k = (g ? g[l] : 0.f) + (gtot ? gtot[0] * w[l] : 0.f);
+                                                           long per_layer4, LayerIdx idx) {
+  const int l = blockIdx.y, d = idx.v[l];
+  const float k = (g ? g[d] : 0.f) + (gtot ? gtot[0] * w[d] : 0.f);
   float4* p = reinterpret_cast<float4*>(x) + (long)l * per_layer4;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < per_layer4; i += (long)gridDim.x * 256) {
     float4 v = p[i];
@@ -303,8 +312,8 @@ extern "C" int sedt_pseudo_labels(const float* logits, const float* boxes, const
 }
 
 extern "C" int sedt_feature_loss(const float* pred, const float* gt, const float* wbox, const float* tidx, const float* num_boxes,
-                                 const int32_t* layer_of, int L, int B, int ns, int Q, int P, int F, float* rowloss, float* out,
-                                 float* dpred, void* stream) {
+                                 const int32_t* layer_of, const float* w, int L, int B, int ns, int Q, int P, int F, float* rowloss,
+                                 float* out, float* dpred, void* stream) {
   using namespace sedt;
   SEDT_REQUIRE(pred && gt && wbox && tidx && num_boxes && layer_of && rowloss && out && dpred, "feature_loss: null pointer");
   SEDT_REQUIRE(L >= 1 && L <= SEDT_CRIT_MAXL && F % 4 == 0 && ns <= B && P >= 1, "feature_loss: L=%d F=%d ns=%d B=%d P=%d", L, F, ns, B, P);
@@ -314,17 +323,20 @@ extern "C" int sedt_feature_loss(const float* pred, const float* gt, const float
   hipLaunchKernelGGL(feature_loss_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pred,
                      gt, wbox, tidx, num_boxes, lay[0], lay[1], lay[2], lay[3], lay[4], lay[5], lay[6], lay[7],
                      L, B, ns, Q, P, F, rowloss, dpred);
-  hipLaunchKernelGGL(feature_loss_reduce_kernel, dim3(L), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rowloss, ns * Q, out);
+  hipLaunchKernelGGL(feature_loss_reduce_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rowloss, ns * Q, L, w, out);
   return check_launch("feature_loss");
 }
 
-extern "C" int sedt_scale_layers(float* x, const float* g, const float* gtot, const float* w, int L, int64_t per_layer, void* stream) {
+extern "C" int sedt_scale_layers(float* x, const float* g, const float* gtot, const float* w, const int32_t* idx, int L,
+                                 int64_t per_layer, void* stream) {
   using namespace sedt;
   SEDT_REQUIRE(x && (g || gtot) && (!gtot || w), "scale_layers: null pointer");
-  SEDT_REQUIRE(per_layer % 4 == 0 && L >= 1, "scale_layers: per_layer=%ld must be a multiple of 4", (long)per_layer);
+  SEDT_REQUIRE(per_layer % 4 == 0 && L >= 1 && L <= 8, "scale_layers: per_layer=%ld must be a multiple of 4, L=%d <= 8", (long)per_layer, L);
   const long n4 = per_layer / 4;
   const unsigned gx = (unsigned)std::min<long>((n4 + 255) / 256, 2048 / L + 1);
-  hipLaunchKernelGGL(scale_layers_kernel, dim3(gx, L), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, g, gtot, w, n4);
+  LayerIdx li;
+  for (int l = 0; l < 8; ++l) li.v[l] = (idx && l < L) ? idx[l] : l;          // idx: HOST array, or null = identity
+  hipLaunchKernelGGL(scale_layers_kernel, dim3(gx, L), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, g, gtot, w, n4, li);
   return check_launch("scale_layers");
 }
 

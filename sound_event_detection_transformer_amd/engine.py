@@ -38,7 +38,7 @@ _step_streams = {}
 
 
 def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None, mask_strong=None, max_norm=0.1,
-               normalize=False, check_finite=True, patches=None, allreduce=False):
+               normalize=False, check_finite=True, patches=None, allreduce=False, fine_tune=False, fl=False):
     """forward -> SetCriterion -> weighted sum over weight_dict -> backward -> clip_grad_norm_(max_norm) -> step ->
     zero_grad.  Raises on a non-finite loss (the reference calls sys.exit(1), engine.py:70-73).
 
@@ -57,11 +57,11 @@ def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             out = train_step(model, criterion, optimizer, batch_input, targets, mask_weak, mask_strong, max_norm, normalize,
-                             check_finite, patches, allreduce)
+                             check_finite, patches, allreduce, fine_tune, fl)
         cur.wait_stream(side)
         return out
     outputs = model(batch_input, patches) if patches is not None else model(batch_input)
-    loss_dict, _ = criterion(outputs, targets, mask_weak, mask_strong, False, normalize)
+    loss_dict, _ = criterion(outputs, targets, mask_weak, mask_strong, fine_tune, normalize, fl)
     wd = criterion.weight_dict
     losses = getattr(criterion, 'last_total', None)      # the same weighted sum, pre-reduced as one dot product
     if losses is None:
@@ -100,7 +100,47 @@ def build_optimizer(model, lr=1e-4, lr_backbone=1e-4, weight_decay=1e-4, fused=T
     return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay)
 
 
-class GraphedTrainStep(object):
+def _snapshot(model, optimizer, ema=None):
+    """parameters + optimizer moments (+ EMA shadow) before the warm-up steps of a capture; _restore puts them back, so that
+    constructing a graphed stepper leaves the training state untouched"""
+    snap = {'p': [p.detach().clone() for p in model.parameters()], 'o': optimizer.snapshot()}
+    if ema is not None:
+        snap['e'] = {n: v.clone() for n, v in ema.shadow.items()}
+    return snap
+
+
+@torch.no_grad()
+def _restore(model, optimizer, snap, ema=None):
+    for p, v in zip(model.parameters(), snap['p']):
+        p.copy_(v)
+    optimizer.restore(snap['o'])
+    if ema is not None:
+        for n, v in snap['e'].items():
+            ema.shadow[n].copy_(v)
+
+
+class _GraphedBase(object):
+    """what every graphed stepper shares: the optimizer's private chunk tables, the learning-rate refresh before each
+    replay, and the device-side non-finite-loss word (reference engine.py:70-73 / 167-169 abort on such a loss)."""
+    check_every = 50
+
+    def _init_common(self, criterion, optimizer, dev):
+        self._tabname = f'graph{id(self)}'
+        self._calls = 0
+        self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
+        criterion.nonfinite = self.nonfinite
+
+    def _before_replay(self):
+        self.optimizer.refresh_hyperparams(self._tabname)      # StepLR / param_group['lr'] edits reach the captured upload
+
+    def _after_replay(self, check_finite):
+        self._calls += 1
+        if check_finite or (self.check_every and self._calls % self.check_every == 0):
+            if self.nonfinite.item():                          # one 4-byte copy every `check_every` steps
+                raise FloatingPointError('Loss is not finite, stopping training (device flag raised by the criterion kernel)')
+
+
+class GraphedTrainStep(_GraphedBase):
     """The training step as HIP graphs.
 
     device_matching=True (default): ONE graph holds the whole step - model forward, the Hungarian matching of every
@@ -111,19 +151,32 @@ class GraphedTrainStep(object):
     device_matching=False: the reference's split - graph A (forward), SetCriterion.prepare on the host (one D2H copy,
     batched C++ Hungarian, one H2D copy), graph B (loss + backward + optimizer).
 
+    SP-SEDT (``example_patches`` given): the patches are a second static input, the query-patch mask is drawn inside the graph,
+    the feature-reconstruction loss runs in its own fused kernel (reference engine.py:56-59, sedt/spsedt.py:34-91).
+
+    ``fine_tune`` / ``normalize`` / ``fl``: the criterion variants of the reference's second training stage
+    (train_sedt.py:309) - device matching only.
+
+    Constructing one runs ``warmup`` eager steps (lazy initialisation of kernels, buffers, optimizer state) and then RESTORES
+    parameters, optimizer moments and step count: the training state is the same before and after.  ``__call__`` returns
+    the graph's static loss tensors (overwritten by the next call: ``.item()`` / ``.clone()`` what you keep).  A non-finite
+    loss raises - checked on the host every ``check_every`` calls through a device flag (or at once with check_finite=True).
+
     Before constructing one, drop every tensor that still carries an autograd graph of an earlier EAGER backward on the
     default stream (loss dicts, model outputs): live AccumulateGrad nodes of another stream invalidate the capture of the
     backward (PyTorch warns 'AccumulateGrad node's stream does not match'; ROCm then faults in hipStreamEndCapture).
 
     Shapes are static: every batch must have the batch size, clip length and strong/weak split it was captured with (and,
     for the host split, the same per-clip target counts).  Dropout masks change on each replay through the device-side
-    seed word (runtime.bump_seed); the Adam step count lives on the device too.
+    seed word (runtime.bump_seed); the Adam step count lives on the device too.  The optimizer's learning rates are re-read
+    before every replay.  Eager ``optimizer.step()`` calls between replays are safe (the graph owns its pointer tables).
 
-    Data parallel (world > 1): gradients are packed into ONE flat f32 buffer and averaged with RCCL between the backward
-    graph and an optimizer graph.  With a SEDT backbone the backward is cut after layer3 (overlap_allreduce=True): the
-    first graph ends with the gradients of everything above the cut (transformer, heads, layer4, layer3 = 90 % of the
-    bytes) packed into the head of the flat buffer, their all-reduce is launched asynchronously, and a second graph runs
-    the backward of layer2 / layer1 / stem meanwhile; the small tail is reduced after it.
+    Data parallel (world > 1): parameters are broadcast from rank 0 at construction; gradients are packed into ONE flat f32
+    buffer and averaged with RCCL between the backward graph and an optimizer graph.  With a SEDT backbone the backward is
+    cut after layer3 (overlap_allreduce=True): the first graph ends with the gradients of everything above the cut
+    (transformer, heads, layer4, layer3 = 90 % of the bytes) packed into the head of the flat buffer, their all-reduce is
+    launched asynchronously, and a second graph runs the backward of layer2 / layer1 / stem meanwhile; the small tail is
+    reduced after it.
 
     Two alternatives for the weight gradients are implemented and measured slower than the default (a layer's wgrads as ONE
     grouped launch on the main stream): async_wgrad=True issues them as a parallel branch of the graph (ROCm 7.2 pays
@@ -132,14 +185,18 @@ class GraphedTrainStep(object):
 
     def __init__(self, model, criterion, optimizer, example_input, example_targets, mask_weak=None, mask_strong=None,
                  max_norm=0.1, normalize=False, warmup=3, device_matching=True, max_targets=32, async_wgrad=False,
-                 overlap_allreduce=True, coschedule=False, data_parallel=None):
+                 overlap_allreduce=True, coschedule=False, data_parallel=None, example_patches=None, fine_tune=False, fl=False,
+                 ft_rand=None):
         import gc
         from . import runtime
         from .sedt import TargetTables
         if not isinstance(optimizer, FusedAdamW):
             raise RuntimeError('GraphedTrainStep needs FusedAdamW (device-side step count, one pointer table)')
+        if (fine_tune or fl) and not device_matching:
+            raise NotImplementedError('fine_tune / fl are built for the device-matching graph')
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.mw, self.ms, self.max_norm, self.normalize = mask_weak, mask_strong, max_norm, normalize
+        self.fine_tune, self.fl, self.ft_rand = fine_tune, fl, ft_rand
         self.runtime = runtime
         self.async_wgrad = async_wgrad
         self.coschedule = coschedule and not async_wgrad
@@ -152,8 +209,11 @@ class GraphedTrainStep(object):
         self.dp = (self.world > 1) if data_parallel is None else bool(data_parallel)
         if self.dp and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
             raise RuntimeError('data_parallel=True needs an initialised torch.distributed process group')
+        net = getattr(model, 'module', model)
+        if self.world > 1:
+            broadcast_parameters(net)                         # replicas start identical (DDP does the same at wrap time)
+            runtime.seed_for_rank(torch.distributed.get_rank())   # ... but drop different elements (seeds are baked at capture)
         if self.dp and overlap_allreduce and device_matching:
-            net = getattr(model, 'module', model)
             body = getattr(getattr(net, 'backbone', [None])[0], 'body', None) if hasattr(net, 'backbone') else None
             if body is not None and hasattr(body, 'stage_out') and optimizer._static is None:
                 tail = [p for n, p in body.named_parameters() if p.requires_grad and (n.startswith('conv0.') or n.startswith('layer2.'))]
@@ -162,15 +222,23 @@ class GraphedTrainStep(object):
                     self.cut_body = body
         dev = example_input.device
         self.dev = dev
+        self._init_common(criterion, optimizer, dev)
         self.static_x = example_input.clone()
+        self.static_patches = None if example_patches is None else example_patches.clone()
+        snap = _snapshot(net, optimizer)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), optimizer.table_set(self._tabname):
             for _ in range(warmup):                          # eager steps: lazy inits (LDS attributes, optimizer state)
-                train_step(model, criterion, optimizer, self.static_x, example_targets, mask_weak, mask_strong, max_norm,
-                           normalize, check_finite=False, allreduce=True)
+                if device_matching:
+                    self._eager_device_step(example_targets, max_targets)
+                else:
+                    train_step(model, criterion, optimizer, self.static_x, example_targets, mask_weak, mask_strong, max_norm,
+                               normalize, check_finite=False, allreduce=True, patches=self.static_patches)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        _restore(net, optimizer, snap)
+        self.nonfinite.zero_()
         criterion.last_total = None      # drop the warm-up autograd graphs (their AccumulateGrad nodes belong to `side`)
         if self.cut_body is not None:
             self.cut_body.keep_stage_out = True              # the capture below needs the layer2 output as the cut tensor
@@ -181,46 +249,77 @@ class GraphedTrainStep(object):
         self.device_matching = device_matching
         self.g_fwd = torch.cuda.CUDAGraph()
         self.g_bwd = self.g_opt = self.g_low = None
-        if device_matching:
-            if mask_strong is None or mask_strong.start not in (None, 0) or mask_strong.step not in (None, 1):
-                raise NotImplementedError('strong_mask must be slice(0, n)')
-            B = len(example_targets)
-            ns = len(example_targets[mask_strong])
-            n_lab = mask_weak.stop if mask_weak is not None else mask_strong.stop
-            self.tables = TargetTables(B, ns, n_lab, dev, max_targets=max_targets,
-                                       with_ratio=any('ratio' in t for t in example_targets)).load(example_targets)
-            with torch.cuda.graph(self.g_fwd):
-                self.static_out = model(self.static_x)
-                self.static_dense = criterion.prepare_device(self.static_out, self.tables)
-                if self.cut_body is None:
+        with optimizer.table_set(self._tabname):
+            if device_matching:
+                self.tables = self._make_tables(example_targets, max_targets)
+                with torch.cuda.graph(self.g_fwd):
+                    self.static_out = self._forward()
+                    self.static_dense = criterion.prepare_device(self.static_out, self.tables, normalize=normalize,
+                                                                 fine_tune=fine_tune, fl=fl, ft_rand=ft_rand)
+                    if self.cut_body is None:
+                        self._backward_and_step()
+                    else:
+                        self._backward_above_cut()
+                if self.cut_body is not None:
+                    self.g_low = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.g_low, pool=self.g_fwd.pool()):
+                        self._backward_below_cut()
+            else:
+                with torch.cuda.graph(self.g_fwd):
+                    self.static_out = self._forward()
+                dense, _ = criterion.prepare(self.static_out, example_targets, mask_weak, mask_strong, normalize)
+                self.meta = dense['_meta']
+                self.static_pack = dense['_pack'].clone()
+                self.static_dense = criterion.dense_views(self.static_pack, self.meta)
+                self.g_bwd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
                     self._backward_and_step()
-                else:
-                    self._backward_above_cut()
-            if self.cut_body is not None:
-                self.g_low = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_low, pool=self.g_fwd.pool()):
-                    self._backward_below_cut()
-        else:
-            with torch.cuda.graph(self.g_fwd):
-                self.static_out = model(self.static_x)
-            dense, _ = criterion.prepare(self.static_out, example_targets, mask_weak, mask_strong, normalize)
-            self.meta = dense['_meta']
-            self.static_pack = dense['_pack'].clone()
-            self.static_dense = criterion.dense_views(self.static_pack, self.meta)
-            self.g_bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
-                self._backward_and_step()
-        if self.dp:
-            # data parallel: ONE RCCL all-reduce of the flat gradient buffer between the graphs, then the fused
-            # clip + AdamW reads the averaged gradients from the flat buffer
-            self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt, pool=self.g_fwd.pool()):
-                optimizer.step(max_norm=max_norm, from_flat=True)
+            if self.dp:
+                # data parallel: ONE RCCL all-reduce of the flat gradient buffer between the graphs, then the fused
+                # clip + AdamW reads the averaged gradients from the flat buffer
+                self.g_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_opt, pool=self.g_fwd.pool()):
+                    optimizer.step(max_norm=max_norm, from_flat=True)
         torch.cuda.synchronize()
+
+    # ------------------------------------------------------------------ pieces
+    def _make_tables(self, example_targets, max_targets):
+        from .sedt import TargetTables
+        if self.ms is None or self.ms.start not in (None, 0) or self.ms.step not in (None, 1):
+            raise NotImplementedError('strong_mask must be slice(0, n)')
+        B = len(example_targets)
+        ns = len(example_targets[self.ms])
+        n_lab = self.mw.stop if self.mw is not None else self.ms.stop
+        return TargetTables(B, ns, n_lab, self.dev, max_targets=max_targets,
+                            with_ratio=any('ratio' in t for t in example_targets)).load(example_targets)
+
+    def _forward(self):
+        if self.static_patches is not None:
+            mask = torch.zeros(self.static_x.shape[0], self.static_x.shape[2], self.static_x.shape[3], dtype=torch.bool, device=self.dev)
+            return self.model((self.static_x, mask), self.static_patches)
+        return self.model(self.static_x)
+
+    def _eager_device_step(self, targets, max_targets):
+        """one un-captured step through exactly the code the capture will run (device matching, fused losses)"""
+        tables = self._make_tables(targets, max_targets)
+        out = self._forward()
+        dense = self.criterion.prepare_device(out, tables, normalize=self.normalize, fine_tune=self.fine_tune, fl=self.fl,
+                                              ft_rand=self.ft_rand)
+        self.criterion.compute(out, dense, self.fl)
+        total = self.criterion.last_total
+        self.criterion.last_total = None
+        total.backward()
+        if self.dp:
+            flat = self.optimizer.gather_grads()
+            allreduce_mean(flat)
+            self.optimizer.step(max_norm=self.max_norm, from_flat=True)
+        else:
+            self.optimizer.step(max_norm=self.max_norm)
+        self.optimizer.zero_grad(set_to_none=True)
 
     def _backward_above_cut(self):
         """loss + backward down to the output of layer2; gradients of all parameters above -> head of the flat buffer"""
-        self.static_losses = self.criterion.compute(self.static_out, self.static_dense)
+        self.static_losses = self.criterion.compute(self.static_out, self.static_dense, self.fl)
         self.static_total = self.criterion.last_total
         head, self._tail = self.optimizer.head_tail_params()
         self._cut = self.cut_body.stage_out[1]
@@ -239,7 +338,7 @@ class GraphedTrainStep(object):
         self.flat_tail = self.optimizer.gather_grads('tail')
 
     def _backward_and_step(self):
-        self.static_losses = self.criterion.compute(self.static_out, self.static_dense)
+        self.static_losses = self.criterion.compute(self.static_out, self.static_dense, self.fl)
         self.static_total = self.criterion.last_total
         # weight gradients ride in the spare workgroup slots of the dgrad chain's launches; drained on exit
         with self.runtime.async_wgrad(self.async_wgrad), ops.coschedule(self.coschedule):
@@ -249,9 +348,12 @@ class GraphedTrainStep(object):
         else:
             self.flat_g = self.optimizer.gather_grads()      # all gradients -> one flat buffer (one launch)
 
-    def __call__(self, batch_input, targets, check_finite=False):
+    def __call__(self, batch_input, targets, check_finite=False, patches=None):
         self.static_x.copy_(batch_input, non_blocking=True)
+        if self.static_patches is not None:
+            self.static_patches.copy_(patches, non_blocking=True)
         self.runtime.bump_seed(self.dev)
+        self._before_replay()
         if self.device_matching:
             self.tables.load(targets)
             self.g_fwd.replay()
@@ -272,8 +374,246 @@ class GraphedTrainStep(object):
         elif self.g_opt is not None:
             allreduce_mean(self.flat_g)
             self.g_opt.replay()
-        if check_finite:
-            v = self.static_total.item()
-            if not math.isfinite(v):
-                raise FloatingPointError(f'Loss is {v}, stopping training')
+        self._after_replay(check_finite)
         return self.static_total, self.static_losses
+
+
+def broadcast_parameters(model, src=0):
+    """every rank starts from rank ``src``'s parameters and buffers (what DistributedDataParallel does when it wraps a
+    model, reference train_spsedt.py:157-158)"""
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() < 2:
+        return
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            if dist.get_backend() == 'nccl' or not t.is_cuda:
+                dist.broadcast(t, src)
+            else:                                             # gloo in this image has no GPU tensors: stage through the host
+                h = t.cpu()
+                dist.broadcast(h, src)
+                t.copy_(h)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Mean-teacher (semi-supervised) step - counterpart of the per-batch body of reference engine.semi_train (engine.py:117-181)
+# ---------------------------------------------------------------------------------------------------------------------
+def _tensors(x):
+    return x.tensors if hasattr(x, 'tensors') else x
+
+
+def pseudo_label_tables(tea_outputs, classwise_threshold, orig_size, tables, counter=None, del_overlap=True):
+    """engine.py:300-348 without leaving the device: teacher outputs -> the flat target tables (sedt.TargetTables) that the
+    on-device matching reads.  ``orig_size``: clip duration in seconds (the minimum event length is 0.2 / orig_size)."""
+    ops.pseudo_labels(tea_outputs['pred_logits'], tea_outputs['pred_boxes'], tea_outputs.get('at'), classwise_threshold,
+                      0.2 / float(orig_size), tables.as_dict(), counter, del_overlap)
+    return tables
+
+
+@torch.no_grad()
+def get_pseudo_labels(tea_outputs, postprocessor, orig_unlabel_target_sizes, target_unlabeled, pseudo_labels_counter,
+                      threshold=0.5, del_overlap=True, classwise_threshold=None):
+    """the reference's signature and return value (engine.py:300-348: the list of target dicts with 'labels' / 'boxes'
+    replaced by the pseudo events, the Counter updated) - computed by ONE kernel (sedt_pseudo_labels) and ONE device->host
+    copy (clip offsets + class counts)."""
+    from .sedt import TargetTables
+    logits = tea_outputs['pred_logits']
+    B, Q, C1 = logits.shape
+    dev = logits.device
+    thr = classwise_threshold.to(device=dev, dtype=torch.float32).contiguous()
+    tables = TargetTables(B, B, B, dev, max_targets=Q)
+    counter = torch.zeros(C1 - 1, dtype=torch.int32, device=dev)
+    pseudo_label_tables(tea_outputs, thr, orig_unlabel_target_sizes[0].item(), tables, counter, del_overlap)
+    host = torch.cat([tables.off[:B + 1], counter]).cpu().numpy()
+    off, cnt = host[:B + 1], host[B + 1:]
+    for i in range(B):
+        target_unlabeled[i]['labels'] = tables.lab_cat[off[i]:off[i + 1]].clone()
+        target_unlabeled[i]['boxes'] = tables.box_cat[off[i]:off[i + 1]].clone()
+    if del_overlap and pseudo_labels_counter is not None:
+        pseudo_labels_counter.update({int(c): int(n) for c, n in enumerate(cnt) if n})
+    return target_unlabeled
+
+
+def semi_train_step(model, ema, criterion, optimizer, batch_input_teacher, batch_input_student, targets, mask_strong, mask_weak,
+                    mask_label, mask_unlabel, classwise_threshold, fine_tune=False, normalize=False, fl=False, max_norm=0.1,
+                    counter=None, check_finite=True, do_step=True, do_ema=True, mix_up_ratio=0):
+    """one iteration of the reference's semi_train (engine.py:117-181): supervised loss on the labelled part -> teacher
+    (EMA weights swapped in, no grad) on the unlabelled part -> pseudo labels -> student on the augmented unlabelled part ->
+    ONE backward over both graphs -> clip / AdamW -> EMA update.  Returns (sup dict, unsup dict, total, pseudo targets)."""
+    if mix_up_ratio:
+        raise NotImplementedError('mixup inside the semi step: apply utilities.mixup.mixup_data / mixup_label_unlabel around it')
+    dev = _tensors(batch_input_teacher).device
+    if dev.type == 'cuda' and torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev):
+        key = str(dev)
+        if key not in _step_streams:
+            _step_streams[key] = torch.cuda.Stream(device=dev)
+        side, cur = _step_streams[key], torch.cuda.current_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            out = semi_train_step(model, ema, criterion, optimizer, batch_input_teacher, batch_input_student, targets, mask_strong,
+                                  mask_weak, mask_label, mask_unlabel, classwise_threshold, fine_tune, normalize, fl, max_norm,
+                                  counter, check_finite, do_step, do_ema, mix_up_ratio)
+        cur.wait_stream(side)
+        return out
+    xt, xs = _tensors(batch_input_teacher), _tensors(batch_input_student)
+    wd = criterion.weight_dict
+    sup, _ = criterion(model(xt[mask_label]), targets[mask_label], mask_weak, mask_strong, fine_tune, normalize, fl)
+    sup_total = criterion.last_total
+    unl = [dict(t) for t in targets[mask_unlabel]]
+    ema.apply_shadow()
+    with torch.no_grad():
+        tea = model(xt[mask_unlabel])
+        sizes = torch.stack([t['orig_size'] for t in unl], dim=0)
+        pseudo = get_pseudo_labels(tea, None, sizes, unl, counter, classwise_threshold=classwise_threshold)
+    ema.restore()
+    x_u = xs[mask_unlabel]
+    unsup, _ = criterion(model(x_u), pseudo, None, slice(x_u.shape[0]), fine_tune, normalize, fl)
+    total = sup_total + criterion.last_total
+    criterion.last_total = None
+    if check_finite and not math.isfinite(total.item()):
+        raise FloatingPointError('Loss is infinite, stopping training')
+    total.backward()
+    if do_step:
+        if isinstance(optimizer, FusedAdamW):
+            optimizer.step(max_norm=max_norm)
+        else:
+            if max_norm > 0:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+            optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+    if do_ema:
+        ema.update()
+    return ({k: v.detach() for k, v in sup.items()}, {k: v.detach() for k, v in unsup.items()}, total.detach(), pseudo)
+
+
+class GraphedSemiStep(_GraphedBase):
+    """The mean-teacher step (reference engine.py:117-181) as ONE HIP graph: labelled forward + device matching + fused
+    loss, teacher forward through the EMA weights (no grad), pseudo labels written by ``sedt_pseudo_labels`` straight into the
+    flat target tables, student forward on the augmented unlabelled clips, device matching against those tables, one
+    backward over both autograd graphs, fused clip + AdamW, fused EMA update.  No device->host copy anywhere.
+
+    Live parameters without re-capture: ``EMA.apply_shadow`` / ``restore`` swap ``param.data`` between two FIXED
+    sets of tensors (the student parameters, updated in place by the optimizer, and the EMA shadow, updated in place by
+    ``EMA.update``).  The graph is captured over both pointer sets - each forward prepares its weights through the plan of the
+    pointer set it sees (packing.PlanSet) - so replays always read the current student / teacher values.  Loading a
+    state_dict copies INTO those tensors and is seen as well; only re-allocating parameters needs a new stepper.
+
+    The thresholds (``classwise_threshold``, f32 [C] on the device) are read by the graph on every replay: update them in
+    place (``stepper.threshold.copy_(...)``) when the driver adjusts them per epoch (train_ss_sedt.py:207).
+    ``counter`` (int32 [C]) accumulates the pseudo events per class like the reference's pseudo_labels_counter."""
+
+    def __init__(self, model, ema, criterion, optimizer, x_teacher, x_student, targets, mask_strong, mask_weak, mask_label,
+                 mask_unlabel, classwise_threshold, orig_size=10.0, fine_tune=False, normalize=False, fl=False, max_norm=0.1,
+                 warmup=2, max_targets=32, accumulating_ema_steps=1):
+        import gc
+        from . import runtime
+        from .sedt import TargetTables
+        if not isinstance(optimizer, FusedAdamW):
+            raise RuntimeError('GraphedSemiStep needs FusedAdamW')
+        if accumulating_ema_steps != 1:
+            raise NotImplementedError('the EMA update is part of the graph: every step (accumlating_ema_steps = 1)')
+        self.model, self.ema, self.criterion, self.optimizer, self.runtime = model, ema, criterion, optimizer, runtime
+        self.ms, self.mw, self.ml, self.mu = mask_strong, mask_weak, mask_label, mask_unlabel
+        self.flags = dict(normalize=normalize, fine_tune=fine_tune, fl=fl)
+        self.fl, self.max_norm, self.orig_size = fl, max_norm, orig_size
+        xt, xs = _tensors(x_teacher), _tensors(x_student)
+        dev = xt.device
+        self.dev = dev
+        self._init_common(criterion, optimizer, dev)
+        dist = torch.distributed
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.dp = self.world > 1
+        if self.dp:
+            broadcast_parameters(model)
+            with torch.no_grad():
+                for n, p in model.named_parameters():         # the teacher starts identical on every rank too
+                    if n in ema.shadow:
+                        h = ema.shadow[n] if dist.get_backend() == 'nccl' else ema.shadow[n].cpu()
+                        dist.broadcast(h, 0)
+                        ema.shadow[n].copy_(h)
+            runtime.seed_for_rank(dist.get_rank())
+        self.x_lab = xt[mask_label].clone()
+        self.x_tea = xt[mask_unlabel].clone()
+        self.x_stu = xs[mask_unlabel].clone()
+        self.threshold = classwise_threshold.to(device=dev, dtype=torch.float32).clone()
+        lab_t = targets[mask_label]
+        n_l, n_u = self.x_lab.shape[0], self.x_stu.shape[0]
+        ns = len(lab_t[mask_strong])
+        n_lab = mask_weak.stop if mask_weak is not None else mask_strong.stop
+        Q = model.num_queries
+        self.counter = torch.zeros(criterion.num_classes, dtype=torch.int32, device=dev)
+        self.tab_l = TargetTables(n_l, ns, n_lab, dev, max_targets=max_targets,
+                                  with_ratio=any('ratio' in t for t in lab_t)).load(lab_t)
+        self.tab_u = TargetTables(n_u, n_u, n_u, dev, max_targets=max(Q, 1))
+        snap = _snapshot(model, optimizer, ema)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), optimizer.table_set(self._tabname):
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        _restore(model, optimizer, snap, ema)
+        self.nonfinite.zero_()
+        self.counter.zero_()
+        criterion.last_total = None
+        optimizer.zero_grad(set_to_none=True)
+        gc.collect()
+        if self.dp:
+            optimizer.enable_flat_grads()
+        self.graph = torch.cuda.CUDAGraph()
+        self.g_opt = None
+        with optimizer.table_set(self._tabname):
+            with torch.cuda.graph(self.graph):
+                self._body(part='fwd_bwd' if self.dp else 'all')
+            if self.dp:                                       # data parallel: RCCL all-reduce of the flat gradients in between
+                self.g_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_opt, pool=self.graph.pool()):
+                    self._body(part='update')
+        torch.cuda.synchronize()
+
+    def _body(self, part='all'):
+        if part == 'update':
+            self.optimizer.step(max_norm=self.max_norm, from_flat=True)
+            self.ema.update()
+            return
+        crit, model = self.criterion, self.model
+        out_l = model(self.x_lab)
+        self.sup = crit.compute(out_l, crit.prepare_device(out_l, self.tab_l, **self.flags), self.fl)
+        total_l = crit.last_total
+        self.ema.apply_shadow()
+        try:
+            with torch.no_grad():
+                tea = model(self.x_tea)
+        finally:
+            self.ema.restore()
+        pseudo_label_tables(tea, self.threshold, self.orig_size, self.tab_u, self.counter)
+        out_s = model(self.x_stu)
+        self.unsup = crit.compute(out_s, crit.prepare_device(out_s, self.tab_u, **self.flags), self.fl)
+        self.total = total_l + crit.last_total
+        crit.last_total = None
+        self.total.backward()
+        if part == 'fwd_bwd':
+            self.flat_g = self.optimizer.gather_grads()
+            return
+        if self.dp:                                           # (eager warm-up of the data-parallel schedule)
+            allreduce_mean(self.optimizer.gather_grads())
+            self.optimizer.step(max_norm=self.max_norm, from_flat=True)
+        else:
+            self.optimizer.step(max_norm=self.max_norm)
+        self.optimizer.zero_grad(set_to_none=True)
+        self.ema.update()
+
+    def __call__(self, x_teacher, x_student, targets, check_finite=False):
+        xt, xs = _tensors(x_teacher), _tensors(x_student)
+        self.x_lab.copy_(xt[self.ml], non_blocking=True)
+        self.x_tea.copy_(xt[self.mu], non_blocking=True)
+        self.x_stu.copy_(xs[self.mu], non_blocking=True)
+        self.tab_l.load(targets[self.ml])
+        self.runtime.bump_seed(self.dev)
+        self._before_replay()
+        self.graph.replay()
+        if self.g_opt is not None:
+            allreduce_mean(self.flat_g)
+            self.g_opt.replay()
+        self._after_replay(check_finite)
+        return self.total, self.sup, self.unsup

@@ -703,9 +703,10 @@ def sum_f32(x, out=None):
     return out
 
 
-def feature_loss(pred, gt, dense, layer_of, num_boxes):
+def feature_loss(pred, gt, dense, layer_of, num_boxes, w=None):
     """SP-SEDT feature-reconstruction loss (sedt.py:263-283) of every decoder layer in one launch.  pred [L,B,Q,F] f32,
-    gt [B*P,F] f32.  Returns (loss[L], dpred [L,B,Q,F] = d loss[d] / d pred, unweighted)."""
+    gt [B*P,F] f32, w [L] f32 layer weights.  Returns (out[L+1]: loss per dense layer + their weighted sum,
+    dpred [L,B,Q,F] = d loss[d] / d pred, unweighted)."""
     _dev_check(pred, gt)
     Lh, B, Q, F = pred.shape
     assert pred.dtype == torch.float32 and gt.dtype == torch.float32 and pred.is_contiguous() and gt.is_contiguous()
@@ -714,18 +715,19 @@ def feature_loss(pred, gt, dense, layer_of, num_boxes):
     assert gt.shape == (ns * P, F) and dense['L'] == Lh and num_boxes.numel() == 1
     dpred = torch.empty_like(pred)
     rowloss = torch.empty(Lh * ns * Q, device=pred.device, dtype=torch.float32)
-    out = torch.empty(Lh, device=pred.device, dtype=torch.float32)
+    out = torch.empty(Lh + 1, device=pred.device, dtype=torch.float32)
     lay = (C.c_int32 * Lh)(*layer_of)
-    L.check(L.load().sedt_feature_loss(_p(pred), _p(gt), _p(dense['wbox']), _p(dense['tidx']), _p(num_boxes), lay, Lh, B, ns, Q, P, F,
+    L.check(L.load().sedt_feature_loss(_p(pred), _p(gt), _p(dense['wbox']), _p(dense['tidx']), _p(num_boxes), lay, _p(w), Lh, B, ns, Q, P, F,
                                        _p(rowloss), _p(out), _p(dpred), L.stream_ptr()), 'feature_loss')
     return out, dpred
 
 
-def scale_layers(x, g, gtot, w):
-    """in place: x[l] *= g[l] + gtot[0] * w[l]   (x [L, ...] f32; g, w [L]; gtot [1])"""
+def scale_layers(x, g, gtot, w, idx=None):
+    """in place: x[l] *= g[d] + gtot[0] * w[d], d = idx[l] (identity when None)   (x [L, ...] f32; g, w [L]; gtot [1])"""
     Lh = x.shape[0]
     per = x.numel() // Lh
-    L.check(L.load().sedt_scale_layers(_p(x), _p(g), _p(gtot), _p(w), Lh, per, L.stream_ptr()), 'scale_layers')
+    ia = None if idx is None else (C.c_int32 * Lh)(*idx)
+    L.check(L.load().sedt_scale_layers(_p(x), _p(g), _p(gtot), _p(w), ia, Lh, per, L.stream_ptr()), 'scale_layers')
     return x
 
 

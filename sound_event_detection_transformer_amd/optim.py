@@ -16,6 +16,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step = 0
         self._static = None
         self._tail_ids = set()
+        self._tabset = 'eager'
+        self._sets = {}
 
     def set_tail_params(self, params):
         """put these parameters LAST in the flat state / gradient layout (call before the first step).  The data-parallel
@@ -60,14 +62,55 @@ class FusedAdamW(torch.optim.Optimizer):
         so_b = np.asarray(state_off, np.uint64) * 4
         self._tab['m'] = np.uint64(self._m.data_ptr()) + so_b
         self._tab['v'] = np.uint64(self._v.data_ptr()) + so_b
-        self._dev_tab = torch.empty(self._tab.nbytes, dtype=torch.uint8, device=dev)
         self._partial = torch.empty(len(owner), device=dev)
         self._sumsq = torch.zeros(1, device=dev)
         self._step_t = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side step count (graph-replay safe)
-        self._host_tab = torch.empty(self._tab.nbytes, dtype=torch.uint8).pin_memory()
         self._state_off_b = so_b
         self._flat_g = None
+        self._dev = dev
         self._static = True
+        self._sets = {}
+        self._use_set(self._tabset)
+        pending, self._pending_state = getattr(self, '_pending_state', None), None
+        if pending is not None:
+            self.load_state_dict(pending)
+
+    # ---- chunk tables: one pinned + one device copy PER USER.  The eager path owns the set 'eager'; every captured HIP
+    # graph owns its own (``table_set(name)``): a captured upload re-reads its pinned buffer at every replay, so nothing else
+    # may ever write other pointers into it (an eager step between replays used to do exactly that).
+    def _use_set(self, name):
+        if self._static is None:
+            self._tabset = name
+            return
+        if name not in self._sets:
+            nb = self._tab.nbytes
+            self._sets[name] = dict(host=torch.empty(nb, dtype=torch.uint8).pin_memory(),
+                                    dev=torch.empty(nb, dtype=torch.uint8, device=self._dev), ghost=None, gdev=None, hyper=None)
+        self._tabset = name
+        st = self._sets[name]
+        self._host_tab, self._dev_tab = st['host'], st['dev']
+        if self._flat_g is not None:
+            if st['ghost'] is None:
+                st['ghost'] = torch.empty(self._tab.nbytes, dtype=torch.uint8).pin_memory()
+                st['gdev'] = torch.empty(self._tab.nbytes, dtype=torch.uint8, device=self._dev)
+            self._host_gtab, self._dev_gtab = st['ghost'], st['gdev']
+
+    def table_set(self, name):
+        """context manager: inside it, step()/gather_grads() use the chunk tables called ``name`` (created on first use)"""
+        opt = self
+
+        class _Ctx(object):
+            def __enter__(self_c):
+                self_c.prev = opt._tabset
+                if opt._static is None:
+                    opt._build()
+                opt._use_set(name)
+                return opt
+
+            def __exit__(self_c, *a):
+                opt._use_set(self_c.prev)
+                return False
+        return _Ctx()
 
     # ---- data-parallel support: all gradients in ONE flat buffer -> one RCCL all-reduce -> update from the flat buffer
     def enable_flat_grads(self):
@@ -76,8 +119,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if self._flat_g is None:
             self._flat_g = torch.zeros_like(self._m)
             self._gtab = self._tab.copy()
-            self._dev_gtab = torch.empty_like(self._dev_tab)
-            self._host_gtab = torch.empty(self._tab.nbytes, dtype=torch.uint8).pin_memory()
+            self._use_set(self._tabset)
         return self._flat_g
 
     def head_tail_params(self):
@@ -131,6 +173,7 @@ class FusedAdamW(torch.optim.Optimizer):
         t['lr'] = lrs[self._gi][self._owner]
         t['wd'] = wds[self._gi][self._owner]
         self._host_tab.numpy()[:] = t.view(np.uint8)
+        self._sets[self._tabset]['hyper'] = (lrs.tobytes(), wds.tobytes())
         self._dev_tab.copy_(self._host_tab, non_blocking=True)
         self._step += 1
         self._step_t.add_(1)
@@ -142,13 +185,102 @@ class FusedAdamW(torch.optim.Optimizer):
         L.check(lib.sedt_multi_adamw(L.p(self._dev_tab), n, L.p(self._sumsq), float(max_norm), g0['betas'][0], g0['betas'][1],
                                      g0['eps'], L.p(self._step_t), L.stream_ptr()), 'multi_adamw')
 
-    def refresh_hyperparams(self):
-        """re-read lr / weight_decay of the param groups into the pinned chunk table (a captured graph re-uploads it)"""
+    def refresh_hyperparams(self, name=None):
+        """re-read lr / weight_decay of the param groups into the pinned chunk table of set ``name`` (a captured graph
+        re-uploads that table on every replay: engine.GraphedTrainStep calls this before each replay, so a StepLR /
+        cosine schedule / manual ``param_group['lr']`` change reaches the graphed step).  The pinned buffer is rewritten only
+        when a value changed, after waiting for the device (the previous replay's upload may still be reading it)."""
+        name = self._tabset if name is None else name
+        st = self._sets.get(name)
+        if st is None:
+            return False
         lrs = np.asarray([g['lr'] for g in self.param_groups], np.float32)
         wds = np.asarray([g['weight_decay'] for g in self.param_groups], np.float32)
-        self._tab['lr'] = lrs[self._gi][self._owner]
-        self._tab['wd'] = wds[self._gi][self._owner]
-        self._host_tab.numpy()[:] = self._tab.view(np.uint8)
+        key = (lrs.tobytes(), wds.tobytes())
+        if st['hyper'] == key:
+            return False
+        torch.cuda.synchronize(self._dev)
+        tab = np.frombuffer(st['host'].numpy(), dtype=_DT)
+        tab['lr'] = lrs[self._gi][self._owner]
+        tab['wd'] = wds[self._gi][self._owner]
+        st['hyper'] = key
+        return True
+
+    # ---- checkpointing in torch.optim.AdamW's layout (reference train_sedt.py:272-283, 318-320 saves / restores it)
+    def state_dict(self):
+        """{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} exactly as torch.optim.AdamW writes it
+        (parameter indices in param-group order), so checkpoints move freely between this optimizer and the reference's."""
+        groups, index, i = [], {}, 0
+        for g in self.param_groups:
+            ids = []
+            for p in g['params']:
+                index[id(p)] = i
+                ids.append(i)
+                i += 1
+            groups.append({**{k: v for k, v in g.items() if k != 'params'}, 'params': ids})
+        state = {}
+        if self._static is not None:
+            step = float(self._step_t.item())
+            if step > 0 or self._step > 0:
+                off = 0
+                for p in self._ps:
+                    k = p.numel()
+                    state[index[id(p)]] = {'step': torch.tensor(step), 'exp_avg': self._m[off:off + k].view_as(p).clone(),
+                                           'exp_avg_sq': self._v[off:off + k].view_as(p).clone()}
+                    off += (k + 3) // 4 * 4
+        return {'state': state, 'param_groups': groups}
+
+    def load_state_dict(self, sd):
+        if len(sd['param_groups']) != len(self.param_groups):
+            raise ValueError('loaded state dict has a different number of parameter groups')
+        for g, sg in zip(self.param_groups, sd['param_groups']):
+            if len(g['params']) != len(sg['params']):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+            g.update({k: v for k, v in sg.items() if k != 'params'})
+        if self._static is None:
+            self._pending_state = sd                  # applied as soon as the flat state exists (needs GPU parameters)
+            if all(p.is_cuda for g in self.param_groups for p in g['params'] if p.requires_grad):
+                self._build()
+            return
+        index, i = {}, 0
+        for g in self.param_groups:
+            for p in g['params']:
+                index[id(p)] = i
+                i += 1
+        st = sd['state']
+        steps = set()
+        off = 0
+        with torch.no_grad():
+            for p in self._ps:
+                k = p.numel()
+                e = st.get(index[id(p)], st.get(str(index[id(p)])))
+                if e is None:
+                    self._m[off:off + k].zero_()
+                    self._v[off:off + k].zero_()
+                else:
+                    self._m[off:off + k].copy_(e['exp_avg'].reshape(-1))
+                    self._v[off:off + k].copy_(e['exp_avg_sq'].reshape(-1))
+                    steps.add(int(float(e['step'])))
+                off += (k + 3) // 4 * 4
+        if len(steps) > 1:
+            raise ValueError(f'FusedAdamW keeps ONE step count for all parameters; the checkpoint has {sorted(steps)}')
+        n = steps.pop() if steps else 0
+        self._step = n
+        self._step_t.fill_(n)
+        for stt in self._sets.values():
+            stt['hyper'] = None
+
+    def snapshot(self):
+        """(moments, step counts) - restore() puts them back; used around the warm-up steps of a graph capture"""
+        if self._static is None:
+            self._build()
+        return (self._m.clone(), self._v.clone(), self._step_t.clone(), self._step)
+
+    def restore(self, snap):
+        self._m.copy_(snap[0])
+        self._v.copy_(snap[1])
+        self._step_t.copy_(snap[2])
+        self._step = snap[3]
 
     def grad_norm(self):
         """global gradient norm of the last clipped step (device tensor)"""

@@ -109,10 +109,14 @@ class PackPlan(object):
         self._host_pk = torch.empty(max(self._pk.nbytes, 8), dtype=torch.uint8).pin_memory()
         self._last = None
 
-    def run(self):
+    def pointer_key(self):
+        """the live parameter / buffer pointers this plan would read now (changes under EMA.apply_shadow, load_state_dict)"""
         wp = np.fromiter((w.data_ptr() for w in self._params), np.uint64, len(self._params))
         bp = np.asarray([[t.data_ptr() for t in bn] for bn in self._bn_tensors], np.uint64).reshape(-1, 4)
-        key = (wp.tobytes(), bp.tobytes())
+        return wp, bp, (wp.tobytes(), bp.tobytes())
+
+    def run(self, key3=None):
+        wp, bp, key = key3 if key3 is not None else self.pointer_key()
         if key != self._last:
             self._pk['w'] = wp[self._pk_owner]
             self._host_pk.numpy()[:self._pk.nbytes] = self._pk.view(np.uint8)
@@ -136,4 +140,42 @@ class PackPlan(object):
 
     def __exit__(self, *a):
         _active.remove(self)
+        return False
+
+
+class PlanSet(object):
+    """One PackPlan PER SET OF PARAMETER POINTERS.  A model whose ``param.data`` is swapped between the student weights and
+    the EMA shadow (EMA.apply_shadow / restore, reference utilities/utils.py:69-81) alternates between two pointer sets; each
+    gets its own plan - own packed-weight buffers, own pinned + device job tables - so that HIP graphs captured over either
+    set stay valid (a captured host->device table upload re-reads its pinned buffer on every replay: the buffer must never
+    be rewritten with the other set's pointers).  ``factory()`` builds a fresh plan of the model's structure."""
+    MAX = 6
+
+    def __init__(self, factory):
+        self.factory = factory
+        self.plans = [factory()]
+        self._cur = None
+
+    def current(self):
+        key3 = self.plans[0].pointer_key()
+        for p in self.plans:
+            if p._last is None or p._last == key3[2]:
+                self._key3 = key3
+                return p
+        if len(self.plans) >= self.MAX:
+            raise RuntimeError(f'more than {self.MAX} distinct parameter-pointer sets seen by one model: parameters are being '
+                               'reallocated every step (update them in place, or swap between fixed tensors)')
+        self.plans.append(self.factory())
+        self._key3 = key3
+        return self.plans[-1]
+
+    def __enter__(self):
+        self._cur = self.current()
+        self._cur.run(self._key3)
+        _active.append(self._cur)
+        return self._cur
+
+    def __exit__(self, *a):
+        _active.remove(self._cur)
+        self._cur = None
         return False

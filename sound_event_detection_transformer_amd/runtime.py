@@ -23,6 +23,12 @@ def manual_seed(seed):
     _state['seed'] = int(seed) & 0x7fffffff
 
 
+def seed_for_rank(rank):
+    """data parallel: every rank draws its own dropout masks (the reference's DDP processes do: independent torch RNG
+    streams); call once per process before capturing / running steps"""
+    _state['seed'] = (_state['seed'] + 0x9E3779B1 * (int(rank) + 1)) & 0x7fffffff if rank else _state['seed']
+
+
 def next_seed():
     """a fresh 32-bit seed per dropout site per forward (the kernels hash (seed, element index))"""
     _state['seed'] = (_state['seed'] * 1103515245 + 12345) & 0x7fffffff

@@ -80,32 +80,36 @@ class SEDT(nn.Module):
             self.query_embed = nn.Embedding(num_queries, hidden_dim)
 
     def pack_plan(self):
-        """the model's PackPlan (two launches prepare every weight / FrozenBN of the forward), cached per dtype/device"""
+        """the model's weight-preparation plans (two launches prepare every weight / FrozenBN of a forward), cached per
+        dtype/device; one plan per parameter-pointer set (packing.PlanSet), so student / EMA-teacher forwards - eager or
+        captured in HIP graphs - never share job tables"""
         dt, dev = runtime.compute_dtype(), self.query_embed.weight.device
         key = (dt, str(dev))
         plans = self.__dict__.setdefault('_plans', {})
         if key not in plans:
-            body = self.backbone[0].body
-            convs = []
-            bn_only = [(body.conv1.weight, body.bn1.tensors())]        # 7x7 stem: only its FrozenBN fold is needed
-            for layer in (body.layer1, body.layer2, body.layer3, body.layer4):
-                for b in layer:
-                    convs += [(b.conv1.weight, b.bn1.tensors()), (b.conv2.weight, b.bn2.tensors()), (b.conv3.weight, b.bn3.tensors())]
-                    if b.downsample is not None:
-                        convs.append((b.downsample[0].weight, b.downsample[1].tensors()))
-            lin = [self.input_proj.weight.view(self.input_proj.out_channels, self.input_proj.in_channels)]
-            for l in self.transformer.encoder.layers:
-                lin += [l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.linear1.weight, l.linear2.weight]
-            for l in self.transformer.decoder.layers:
-                lin += [l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.multihead_attn.in_proj_weight,
-                        l.multihead_attn.out_proj.weight, l.linear1.weight, l.linear2.weight]
-            lin += [self.class_embed.weight] + [m.weight for m in self.bbox_embed.layers]
-            for name in ('weak_class_embed', 'patch2query'):
-                if hasattr(self, name):
-                    lin.append(getattr(self, name).weight)
-            if hasattr(self, 'feature_align'):
-                lin += [m.weight for m in self.feature_align.layers]
-            plans[key] = packing.PackPlan(dt, dev, convs, lin, bn_only)
+            def factory():
+                body = self.backbone[0].body
+                convs = []
+                bn_only = [(body.conv1.weight, body.bn1.tensors())]        # 7x7 stem: only its FrozenBN fold is needed
+                for layer in (body.layer1, body.layer2, body.layer3, body.layer4):
+                    for b in layer:
+                        convs += [(b.conv1.weight, b.bn1.tensors()), (b.conv2.weight, b.bn2.tensors()), (b.conv3.weight, b.bn3.tensors())]
+                        if b.downsample is not None:
+                            convs.append((b.downsample[0].weight, b.downsample[1].tensors()))
+                lin = [self.input_proj.weight]          # (Co, Ci, 1, 1): the Parameter itself, so pointer swaps are seen
+                for l in self.transformer.encoder.layers:
+                    lin += [l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.linear1.weight, l.linear2.weight]
+                for l in self.transformer.decoder.layers:
+                    lin += [l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.multihead_attn.in_proj_weight,
+                            l.multihead_attn.out_proj.weight, l.linear1.weight, l.linear2.weight]
+                lin += [self.class_embed.weight] + [m.weight for m in self.bbox_embed.layers]
+                for name in ('weak_class_embed', 'patch2query'):
+                    if hasattr(self, name):
+                        lin.append(getattr(self, name).weight)
+                if hasattr(self, 'feature_align'):
+                    lin += [m.weight for m in self.feature_align.layers]
+                return packing.PackPlan(dt, dev, convs, lin, bn_only)
+            plans[key] = packing.PlanSet(factory)
         return plans[key]
 
     def forward(self, samples):
@@ -206,8 +210,8 @@ class TargetTables(object):
         if nb:
             self.box_cat[:nb].copy_(torch.cat([targets[b]['boxes'].reshape(-1, 2).float() for b in range(ns)]), non_blocking=True)
         if self.ratio_cat is not None and nl:
-            self.ratio_cat[:nl].copy_(torch.cat([t['ratio'].detach().float().reshape(-1) if 'ratio' in t else
-                                                 torch.ones(n, device=t['labels'].device) for t, n in zip(targets, nlab)]),
+            self.ratio_cat[:nl].copy_(torch.cat([t['ratio'].detach().float().reshape(-1).to(self.dev) if 'ratio' in t else
+                                                 torch.ones(n, device=self.dev) for t, n in zip(targets, nlab)]),
                                       non_blocking=True)
         elif any('ratio' in t for t in targets):
             raise ValueError('targets carry pseudo-label ratios: build TargetTables(with_ratio=True)')
@@ -246,13 +250,13 @@ class _FeatureLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred_all, gt, dense, layer_of, num_boxes, wvec):
         from .. import ops
-        loss, ctx.dpred = ops.feature_loss(pred_all.detach().float().contiguous(), gt.detach().float().contiguous(), dense,
-                                           layer_of, num_boxes)
+        out, ctx.dpred = ops.feature_loss(pred_all.detach().float().contiguous(), gt.detach().float().contiguous(), dense,
+                                          layer_of, num_boxes, wvec)
         ctx.wvec, ctx.dt = wvec, pred_all.dtype
-        L = loss.numel()
-        out = torch.empty(L + 1, device=loss.device, dtype=torch.float32)
-        out[:L] = loss
-        out[L] = torch.dot(loss, wvec)
+        inv = [0] * len(layer_of)
+        for d, ml in enumerate(layer_of):
+            inv[ml] = d
+        ctx.inv = inv                                  # dpred is in the model's layer order, the loss vector in dense order
         return out
 
     @staticmethod
@@ -260,7 +264,7 @@ class _FeatureLossFn(torch.autograd.Function):
         from .. import ops
         g = g.contiguous().float()
         L = g.numel() - 1
-        d = ops.scale_layers(ctx.dpred, g[:L], g[L:], ctx.wvec)
+        d = ops.scale_layers(ctx.dpred, g[:L], g[L:], ctx.wvec, ctx.inv)
         ctx.dpred = None
         return d.to(ctx.dt), None, None, None, None, None
 
@@ -325,8 +329,8 @@ class SetCriterion(nn.Module):
         if lab_all is not None:
             parts.append(lab_all)
         if has_ratio:
-            parts.append(torch.cat([targets[i]['ratio'].detach().float() if 'ratio' in targets[i] else
-                                    torch.ones(lab_sizes[i]) for i in range(n_lab)]).to(dev))
+            parts.append(torch.cat([targets[i]['ratio'].detach().float().to(dev) if 'ratio' in targets[i] else
+                                    torch.ones(lab_sizes[i], device=dev) for i in range(n_lab)]))
         host = torch.cat(parts).cpu().numpy() if parts else np.zeros(0, np.float32)   # the ONE device->host copy
         o = 0
         assign = -np.ones((L, ns, Q), np.int32)

@@ -35,6 +35,9 @@ class SPSEDT(SEDT):
 
     def _forward_sp(self, samples, patches, query_mask=None):
         dev = self.query_embed.weight.device
+        if any(p.requires_grad for p in self.backbone.parameters()):
+            # gt_feature is computed without autograd (the reference's recipe freezes the backbone: train_spsedt.py:50)
+            raise NotImplementedError('SP-SEDT on the HIP path needs a frozen backbone (lr_backbone = 0)')
         bnp = patches.shape[1]
         samples = NestedTensor(samples[0].to(dev), samples[1].to(dev))
         patches = patches.to(dev)

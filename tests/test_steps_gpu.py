@@ -1,0 +1,458 @@
+"""GPU: the configurations beyond the plain supervised step - C5 mean-teacher step (reference engine.py:97-196), C4 SP-SEDT
+pre-training step (engine.py:56-59 + sedt/spsedt.py) as HIP graphs, C3 at its size - against the reference's own numbers
+(fixtures G12 / G4, f32 mode, golden size) and, at the BASELINE sizes, through size-independent properties
+(graph == eager, bit-reproducibility, finite losses, training progress, live-parameter rule).
+
+Tolerances: f32 parity mode - total loss 1e-3, gradient norms 2e-3, AdamW deltas 2e-2 (as G3/G7); index work exact."""
+import os
+import sys
+from collections import Counter
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+sys.path.insert(0, GOLDEN)
+import inputs as GI                                                                    # noqa: E402
+from oracle import sedt_oracle as O                                                    # noqa: E402
+from oracle import semi_oracle as S                                                    # noqa: E402
+from oracle.criterion_oracle import synthetic_targets                                  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(got, ref):
+    got = torch.as_tensor(got).float().cpu()
+    ref = torch.as_tensor(ref).float().cpu()
+    return ((got - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
+
+
+def _rows(a):
+    return [r[r >= 0] for r in a]
+
+
+@pytest.fixture(scope='module')
+def pkg():
+    from sound_event_detection_transformer_amd import runtime, sedt
+    assert torch.cuda.is_available()
+    return runtime, sedt
+
+
+def _cuda_targets(targets):
+    return [{k: v.cuda() for k, v in t.items()} for t in targets]
+
+
+def _semi_masks():
+    c = GI.SEMI
+    ns, nw, nu = c['n_strong'], c['n_weak'], c['n_unl']
+    return dict(mask_strong=slice(ns), mask_weak=slice(ns, ns + nw), mask_label=slice(ns + nw), mask_unlabel=slice(ns + nw, ns + nw + nu))
+
+
+def _golden_shadow():
+    """the perturbed teacher of fixture G12, keyed by parameter name (drawn in the oracle's = the reference's parameter order)"""
+    c = GI.SEMI
+    om = O.build_oracle_model(10, 20, 6, 3, True, True, True, dropout=0.0)
+    om.load_state_dict(O.seeded_state_dict(om.state_dict(), c['seed_w']))
+    ema = S.EMA(om, 0.9)
+    ema.register()
+    gen = torch.Generator().manual_seed(5)
+    for n in ema.shadow:
+        ema.shadow[n] = ema.shadow[n] + 0.02 * ema.shadow[n].abs().mean() * torch.randn(ema.shadow[n].shape, generator=gen)
+    return ema.shadow
+
+
+def _semi_model(sedt, dropout=0.0, seed=None, decay=0.9):
+    from sound_event_detection_transformer_amd.engine import build_optimizer
+    from sound_event_detection_transformer_amd.utilities.utils import EMA
+    c = GI.SEMI
+    model, crit, _ = sedt.build_model(sedt.default_args(enc_layers=6, num_queries=20, dropout=dropout))
+    model.load_state_dict(O.seeded_state_dict(model.state_dict(), c['seed_w'] if seed is None else seed))
+    model.cuda().train()
+    crit.cuda()
+    ema = EMA(model, decay)
+    ema.register()
+    opt = build_optimizer(model)
+    return model, crit, ema, opt
+
+
+def test_g12_mean_teacher_step_f32(pkg, golden_dir):
+    """one semi_train iteration on the HIP path == the reference's (fixture G12): total loss, pseudo labels, every gradient
+    norm; then the complete iteration: AdamW parameter deltas and EMA shadow deltas"""
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import semi_train_step
+    runtime.set_compute_dtype('f32')
+    g = np.load(os.path.join(golden_dir, 'g12_semi_step.npz'))
+    c = GI.SEMI
+    thr = torch.full((10,), c['thr']).cuda()
+    shadow = _golden_shadow()
+    x_t, x_s, targets = GI.semi_batch()
+    for mode in ('grads', 'step'):
+        model, crit, ema, opt = _semi_model(sedt)
+        for n in ema.shadow:
+            ema.shadow[n].copy_(shadow[n])
+        before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+        shadow0 = {n: v.clone() for n, v in ema.shadow.items()}
+        cnt = Counter()
+        sup, unsup, total, pseudo = semi_train_step(model, ema, crit, opt, x_t.cuda(), x_s.cuda(), _cuda_targets(targets),
+                                                    classwise_threshold=thr, counter=cnt, do_step=(mode == 'step'),
+                                                    do_ema=(mode == 'step'), **_semi_masks())
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+        params = dict(model.named_parameters())
+        if mode == 'grads':
+            assert abs(total.item() - float(g['total'])) < 1e-3 * abs(float(g['total']))
+            np.testing.assert_array_equal([len(t['labels']) for t in pseudo], g['pseudo_count'])
+            for b, t in enumerate(pseudo):
+                np.testing.assert_array_equal(t['labels'].cpu().numpy(), _rows(g['pseudo_labels'])[b].astype(np.int64))
+                np.testing.assert_allclose(t['boxes'][:, 0].cpu().numpy(), _rows(g['pseudo_centre'])[b], rtol=1e-3)
+            np.testing.assert_array_equal([cnt.get(k, 0) for k in range(10)], g['pseudo_counter'])
+            assert names == [str(n) for n in g['gradnames']]
+            gn = np.array([params[n].grad.norm().item() for n in names], np.float32)
+            bad = [(n, a, b) for n, a, b in zip(names, gn, g['gradnorm']) if abs(a - b) > 2e-3 * b + 1e-6]
+            assert not bad, bad[:10]
+        else:
+            assert abs(total.item() - float(g['step_total'])) < 1e-3 * abs(float(g['step_total']))
+            delta = np.array([(params[n].detach() - before[n]).norm().item() for n in names], np.float32)
+            np.testing.assert_allclose(delta, g['step_delta'], rtol=2e-2, atol=1e-7)
+            ed = np.array([(ema.shadow[n] - shadow0[n]).norm().item() for n in names], np.float32)
+            np.testing.assert_allclose(ed, g['ema_delta'], rtol=2e-3, atol=1e-7)
+
+
+def _rand_semi_batch(seed, n_strong, n_weak, n_unl, T=496):
+    gen = torch.Generator().manual_seed(seed)
+    B = n_strong + n_weak + n_unl
+    x_t = torch.randn(B, 1, T, 64, generator=gen)
+    x_s = x_t.clone()
+    x_s[n_strong + n_weak:] += 0.1 * torch.randn(n_unl, 1, T, 64, generator=gen)
+    t = synthetic_targets(B, seed + 1, 10)
+    for tt in t[n_strong:]:
+        tt['boxes'] = torch.zeros(0, 2)
+    for tt in t[n_strong + n_weak:]:
+        tt['labels'] = torch.zeros(0, dtype=torch.int64)
+    return x_t.cuda(), x_s.cuda(), _cuda_targets(t)
+
+
+def test_graphed_semi_step_matches_eager_and_follows_live_parameters(pkg):
+    """GraphedSemiStep (ONE graph: 3 forwards, device pseudo labels, device matching, backward, AdamW, EMA) reproduces the
+    eager semi_train_step on changing batches; constructing it leaves the training state untouched; and - SURVEY H5 - a
+    state_dict loaded AFTER the capture (student) and new teacher weights (in place) are what the next replay uses"""
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import semi_train_step, GraphedSemiStep
+    runtime.set_compute_dtype('bf16')
+    masks = dict(mask_strong=slice(2), mask_weak=slice(2, 4), mask_label=slice(4), mask_unlabel=slice(4, 8))
+    thr = torch.full((10,), 0.115).cuda()
+    batches = [_rand_semi_batch(500 + i, 2, 2, 4) for i in range(3)]
+    other = O.seeded_state_dict(sedt.build_model(sedt.default_args(enc_layers=6, num_queries=20))[0].state_dict(), 77)
+    res = {}
+    for mode in ('eager', 'graph'):
+        model, crit, ema, opt = _semi_model(sedt)
+        with torch.no_grad():
+            for n in ema.shadow:
+                ema.shadow[n].mul_(1.01)
+        if mode == 'graph':
+            sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+            sh0 = {k: v.clone() for k, v in ema.shadow.items()}
+            stepper = GraphedSemiStep(model, ema, crit, opt, batches[0][0], batches[0][1], batches[0][2],
+                                      classwise_threshold=thr, **masks)
+            for k, v in model.state_dict().items():                       # capture + warm-up restored everything
+                assert torch.equal(v, sd0[k]), k
+            for k, v in ema.shadow.items():
+                assert torch.equal(v, sh0[k]), k
+            assert opt._step_t.item() == 0 and float(opt._m.abs().max()) == 0.0
+        losses = []
+        for i, (xt, xs, tg) in enumerate(batches):
+            if i == 2:                                                    # live-parameter rule: new weights, same tensors
+                model.load_state_dict(other)
+                with torch.no_grad():
+                    for n in ema.shadow:
+                        ema.shadow[n].mul_(0.97)
+            if mode == 'eager':
+                _, _, total, _ = semi_train_step(model, ema, crit, opt, xt, xs, tg, classwise_threshold=thr, **masks)
+            else:
+                total, _, _ = stepper(xt, xs, tg)
+            losses.append(float(total))
+        res[mode] = (losses, {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()},
+                     {k: v.detach().float().cpu().clone() for k, v in ema.shadow.items()})
+    runtime.set_compute_dtype('f32')
+    np.testing.assert_allclose(res['graph'][0], res['eager'][0], rtol=1e-3)
+    assert abs(res['eager'][0][2] - res['eager'][0][1]) > 1e-3 * abs(res['eager'][0][1])      # the new weights changed the loss
+    for k in res['eager'][1]:
+        assert rel(res['graph'][1][k], res['eager'][1][k]) < 2e-3, k
+    for k in res['eager'][2]:
+        assert rel(res['graph'][2][k], res['eager'][2][k]) < 2e-3, k
+
+
+def test_c5_full_size_semi_step_properties(pkg):
+    """BASELINE config C5 at its size (DCASE geometry, E=6, Q=20, 16 synthetic + 16 weak + 32 unlabelled clips, teacher and
+    student views, bf16, dropout on): two independently captured steppers fed the same batches end bit-identical, losses
+    finite, the pseudo-label counter grows, parameters and the EMA teacher move"""
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import GraphedSemiStep
+    runtime.set_compute_dtype('bf16')
+    masks = dict(mask_strong=slice(16), mask_weak=slice(16, 32), mask_label=slice(32), mask_unlabel=slice(32, 64))
+    thr = torch.full((10,), 0.1).cuda()
+    batches = [_rand_semi_batch(900 + i, 16, 16, 32) for i in range(2)]
+    finals, curves, counts = [], [], []
+    for run in range(2):
+        runtime.manual_seed(4242)
+        model, crit, ema, opt = _semi_model(sedt, dropout=0.1, decay=0.9996)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        sh0 = {k: v.clone() for k, v in ema.shadow.items()}
+        stepper = GraphedSemiStep(model, ema, crit, opt, batches[0][0], batches[0][1], batches[0][2], classwise_threshold=thr, **masks)
+        losses = []
+        for it in range(4):
+            xt, xs, tg = batches[it % 2]
+            total, sup, unsup = stepper(xt, xs, tg, check_finite=True)
+            losses.append(float(total))
+        torch.cuda.synchronize()
+        curves.append(losses)
+        counts.append(stepper.counter.cpu().numpy().copy())
+        finals.append(({k: v.detach().clone() for k, v in model.state_dict().items()}, {k: v.clone() for k, v in ema.shadow.items()}))
+        if run == 0:
+            assert max((finals[0][0][k].float() - sd0[k].float()).abs().max().item() for k in sd0 if sd0[k].dtype.is_floating_point) > 0
+            assert max((finals[0][1][k] - sh0[k]).abs().max().item() for k in sh0) > 0
+    runtime.set_compute_dtype('f32')
+    assert np.isfinite(curves).all() and curves[0] == curves[1]
+    assert counts[0].sum() > 0 and (counts[0] == counts[1]).all()
+    for k in finals[0][0]:
+        assert torch.equal(finals[0][0][k], finals[1][0][k]), k
+    for k in finals[0][1]:
+        assert torch.equal(finals[0][1][k], finals[1][1][k]), k
+
+
+# ------------------------------------------------------------------------------------------------ C4: SP-SEDT
+def _sp_model(sedt, seed=404, dropout=0.0, mask_ratio=None):
+    from sound_event_detection_transformer_amd.engine import build_optimizer
+    model, crit, _ = sedt.build_model(sedt.default_args(enc_layers=6, num_queries=20, dec_at=False, self_sup=True, lr_backbone=0.0,
+                                                        dropout=dropout))
+    model.load_state_dict(O.seeded_state_dict(model.state_dict(), seed))
+    model.cuda().train()
+    if mask_ratio is not None:
+        model.mask_ratio = mask_ratio
+    crit.cuda()
+    return model, crit, build_optimizer(model)
+
+
+def _sp_batch(seed, B, P=10):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 1, 496, 64, generator=gen)
+    patches = torch.randn(B, P, 1, 128, 64, generator=gen)
+    targets = []
+    for _ in range(B):
+        l = torch.rand(P, generator=gen) * 0.3 + 0.05
+        c = l / 2 + torch.rand(P, generator=gen) * (1 - l)
+        targets.append({'labels': torch.zeros(P, dtype=torch.int64), 'boxes': torch.stack([c, l], -1)})
+    return x.cuda(), patches.cuda(), _cuda_targets(targets)
+
+
+def test_g4_spsedt_fused_losses_f32(pkg, golden_dir):
+    """the SP-SEDT losses of fixture G4 - incl. loss_feature of every decoder layer and pred_feature itself - from the fused
+    kernels, with the matching solved on the host AND on the device"""
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.sedt import TargetTables
+    runtime.set_compute_dtype('f32')
+    g = np.load(os.path.join(golden_dir, 'g4_spsedt.npz'))
+    model, crit, _ = _sp_model(sedt)
+    B, P = 2, 10
+    x = torch.randn(B, 1, 496, 64, generator=torch.Generator().manual_seed(8)).cuda()
+    patches = torch.randn(B, P, 1, 128, 64, generator=torch.Generator().manual_seed(9)).cuda()
+    mask = torch.zeros(B, 496, 64, dtype=torch.bool).cuda()
+    targets = _cuda_targets([{'labels': torch.zeros(P, dtype=torch.int64), 'boxes': torch.from_numpy(g['target_boxes'][i])} for i in range(B)])
+    o = model((x, mask), patches, query_mask=torch.from_numpy(g['train_query_mask']))
+    pf = o['pred_feature'].detach().float().flatten().cpu()
+    idx = torch.linspace(0, pf.numel() - 1, 256).long()
+    dig = torch.cat([pf.mean()[None], pf.abs().mean()[None], pf[idx]])
+    assert rel(dig[1:], g['train_pred_feature'][1:]) < 1e-3
+    ld, _ = crit(o, targets, slice(B), slice(B))
+    keys = {k[11:] for k in g.files if k.startswith('train_loss_')}
+    assert set(ld) == keys
+    for k, v in ld.items():
+        assert abs(v.item() - float(g[f'train_loss_{k}'])) < 1e-3 * max(1.0, abs(v.item())), k
+    assert abs(crit.last_total.item() - float(g['train_total'])) < 1e-3 * abs(float(g['train_total']))
+    tables = TargetTables(B, B, B, torch.device('cuda'), max_targets=16).load(targets)
+    ld2 = crit.compute(o, crit.prepare_device(o, tables))
+    for k, v in ld2.items():
+        assert abs(v.item() - float(g[f'train_loss_{k}'])) < 1e-3 * max(1.0, abs(v.item())), k
+
+
+def test_graphed_spsedt_step_matches_eager(pkg):
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import train_step, GraphedTrainStep
+    runtime.set_compute_dtype('bf16')
+    B = 4
+    batches = [_sp_batch(700 + i, B) for i in range(3)]
+    res = {}
+    for mode in ('eager', 'graph'):
+        model, crit, opt = _sp_model(sedt, mask_ratio=-1.0)            # rand > -1: every query keeps its patch (deterministic)
+        if mode == 'graph':
+            stepper = GraphedTrainStep(model, crit, opt, batches[0][0], batches[0][2], slice(B), slice(B), warmup=2,
+                                       example_patches=batches[0][1])
+        losses = []
+        for x, p, t in batches:
+            if mode == 'eager':
+                mask = torch.zeros(B, 496, 64, dtype=torch.bool, device='cuda')
+                l, _ = train_step(model, crit, opt, (x, mask), t, slice(B), slice(B), max_norm=0.1, patches=p)
+            else:
+                l, _ = stepper(x, t, patches=p)
+            losses.append(float(l))
+        res[mode] = (losses, {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()})
+    runtime.set_compute_dtype('f32')
+    np.testing.assert_allclose(res['graph'][0], res['eager'][0], rtol=1e-3)
+    for k in res['eager'][1]:
+        assert rel(res['graph'][1][k], res['eager'][1][k]) < 2e-3, k
+
+
+def test_c4_full_size_spsedt_step_properties(pkg):
+    """BASELINE config C4 per rank (B = 200 clips + 2000 patches, E=6, Q=20, backbone frozen, bf16, dropout on): the graphed
+    step runs, is finite, trains, and only head / transformer parameters receive updates"""
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import GraphedTrainStep
+    runtime.set_compute_dtype('bf16')
+    B = 200
+    x, p, t = _sp_batch(800, B)
+    model, crit, opt = _sp_model(sedt, dropout=0.1)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    stepper = GraphedTrainStep(model, crit, opt, x, t, slice(B), slice(B), warmup=1, example_patches=p)
+    losses = []
+    for it in range(5):
+        l, ld = stepper(x, t, patches=p, check_finite=True)
+        losses.append(float(l))
+    torch.cuda.synchronize()
+    runtime.set_compute_dtype('f32')
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    assert float(ld['loss_feature']) > 0
+    for k, v in model.state_dict().items():
+        if 'backbone' in k:
+            assert torch.equal(v, sd0[k]), k
+    assert any(not torch.equal(v, sd0[k]) for k, v in model.state_dict().items() if 'transformer' in k)
+
+
+# ------------------------------------------------------------------------------------------------ C3 at its size
+def test_c3_full_size_step_properties(pkg):
+    """BASELINE config C3 (DCASE geometry T = 496, E=6, Q=20, B = 32 = 16 strong + 16 weak): graph == eager at dropout 0 on
+    the first step, then finite + bit-reproducible training"""
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import train_step, build_optimizer, GraphedTrainStep
+    runtime.set_compute_dtype('bf16')
+    B, ns = 32, 16
+
+    def batch(seed):
+        x = torch.randn(B, 1, 496, 64, generator=torch.Generator().manual_seed(seed)).cuda()
+        t = synthetic_targets(B, seed + 100, 10)
+        for tt in t[ns:]:
+            tt['boxes'] = torch.zeros(0, 2)
+        return x, _cuda_targets(t)
+    batches = [batch(40 + i) for i in range(2)]
+    out = {}
+    for mode in ('eager', 'graph', 'graph2'):
+        model, crit, _ = sedt.build_model(sedt.default_args(enc_layers=6, num_queries=20, dropout=0.0))
+        model.load_state_dict(O.seeded_state_dict(model.state_dict(), 5))
+        model.cuda().train()
+        crit.cuda()
+        opt = build_optimizer(model)
+        if mode != 'eager':
+            stepper = GraphedTrainStep(model, crit, opt, batches[0][0], batches[0][1], slice(ns, B), slice(ns), warmup=1)
+        losses = []
+        for xb, tb in batches:
+            if mode == 'eager':
+                l, _ = train_step(model, crit, opt, xb, tb, slice(ns, B), slice(ns), max_norm=0.1)
+            else:
+                l, _ = stepper(xb, tb, check_finite=True)
+            losses.append(float(l))
+        out[mode] = (losses, {k: v.detach().clone() for k, v in model.state_dict().items()})
+    runtime.set_compute_dtype('f32')
+    np.testing.assert_allclose(out['graph'][0], out['eager'][0], rtol=1e-3)
+    assert out['graph'][0] == out['graph2'][0]
+    for k in out['graph'][1]:
+        assert torch.equal(out['graph'][1][k], out['graph2'][1][k]), k
+        assert rel(out['graph'][1][k], out['eager'][1][k]) < 2e-3, k
+
+
+# ------------------------------------------------------------------------------------------------ optimizer / graph hygiene
+def test_fused_adamw_state_dict_round_trip_and_reference_layout(pkg):
+    """FusedAdamW.state_dict() is torch.optim.AdamW's layout: save -> load into a fresh optimizer -> identical next step;
+    and it loads into torch.optim.AdamW (a reference checkpoint's optimizer state) and back"""
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import train_step, build_optimizer
+    runtime.set_compute_dtype('bf16')
+    B = 2
+    x = torch.randn(B, 1, 500, 64, generator=torch.Generator().manual_seed(6)).cuda()
+    t = _cuda_targets(synthetic_targets(B, 70, 10))
+
+    def fresh():
+        model, crit, _ = sedt.build_model(sedt.default_args(dropout=0.0))
+        model.load_state_dict(O.seeded_state_dict(model.state_dict(), 5))
+        model.cuda().train()
+        return model, crit.cuda(), build_optimizer(model)
+    model, crit, opt = fresh()
+    for _ in range(2):
+        train_step(model, crit, opt, x, t, None, slice(B))
+    sd_model = {k: v.clone() for k, v in model.state_dict().items()}
+    sd_opt = opt.state_dict()
+    n_train = sum(1 for p in model.parameters() if p.requires_grad)
+    assert len(sd_opt['state']) == n_train and len(sd_opt['param_groups']) == 2
+    e = sd_opt['state'][0]
+    assert set(e) == {'step', 'exp_avg', 'exp_avg_sq'} and float(e['step']) == 2.0
+    train_step(model, crit, opt, x, t, None, slice(B))
+    want = {k: v.clone() for k, v in model.state_dict().items()}
+    # resume in a fresh process-alike: new model + new optimizer
+    model2, crit2, opt2 = fresh()
+    model2.load_state_dict(sd_model)
+    opt2.load_state_dict(sd_opt)
+    train_step(model2, crit2, opt2, x, t, None, slice(B))
+    for k, v in model2.state_dict().items():
+        assert torch.equal(v, want[k]), k
+    # the layout is torch's: round trip through torch.optim.AdamW
+    groups = [{"params": [p for n, p in model2.named_parameters() if "backbone" not in n and p.requires_grad]},
+              {"params": [p for n, p in model2.named_parameters() if "backbone" in n and p.requires_grad], "lr": 1e-4}]
+    ref_opt = torch.optim.AdamW(groups, lr=1e-4, weight_decay=1e-4)
+    ref_opt.load_state_dict(sd_opt)
+    back = ref_opt.state_dict()
+    assert float(back['state'][0]['step']) == 2.0
+    opt3 = build_optimizer(model2)
+    opt3.load_state_dict(back)
+    m3 = opt3.state_dict()
+    for i in sd_opt['state']:
+        assert torch.equal(m3['state'][i]['exp_avg'], sd_opt['state'][i]['exp_avg'])
+        assert torch.equal(m3['state'][i]['exp_avg_sq'], sd_opt['state'][i]['exp_avg_sq'])
+    runtime.set_compute_dtype('f32')
+
+
+def test_graph_sees_lr_changes_and_survives_eager_steps(pkg):
+    """(1) a learning-rate change after capture reaches the replayed optimizer; (2) an eager step between replays
+    (which rewrites the optimizer's eager pointer table) does not corrupt the graph's table"""
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import train_step, build_optimizer, GraphedTrainStep
+    runtime.set_compute_dtype('bf16')
+    B = 2
+    x = torch.randn(B, 1, 500, 64, generator=torch.Generator().manual_seed(6)).cuda()
+    t = _cuda_targets(synthetic_targets(B, 70, 10))
+    res = {}
+    for mode in ('graph', 'eager'):
+        model, crit, _ = sedt.build_model(sedt.default_args(dropout=0.0))
+        model.load_state_dict(O.seeded_state_dict(model.state_dict(), 5))
+        model.cuda().train()
+        crit.cuda()
+        opt = build_optimizer(model)
+        if mode == 'graph':
+            stepper = GraphedTrainStep(model, crit, opt, x, t, None, slice(B), warmup=1)
+        seq = []
+        for i in range(4):
+            if i == 2:
+                for gq in opt.param_groups:
+                    gq['lr'] = gq['lr'] * 0.1                      # StepLR-style decay (train_sedt.py:271)
+            if mode == 'graph' and i != 1:
+                stepper(x, t)
+            else:
+                train_step(model, crit, opt, x, t, None, slice(B))      # step 1 of the graph run is an EAGER step
+            seq.append({k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()})
+        res[mode] = seq
+    runtime.set_compute_dtype('f32')
+    for i in range(4):
+        for k in res['eager'][i]:
+            assert rel(res['graph'][i][k], res['eager'][i][k]) < 2e-3, (i, k)
+    k = 'transformer.encoder.layers.0.linear1.weight'
+    d12 = (res['graph'][1][k] - res['graph'][0][k]).abs().mean().item()
+    d23 = (res['graph'][2][k] - res['graph'][1][k]).abs().mean().item()
+    assert d23 < 0.5 * d12                                            # the smaller learning rate took effect in the replay
