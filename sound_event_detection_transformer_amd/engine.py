@@ -555,7 +555,10 @@ class GraphedSemiStep(_GraphedBase):
         _restore(model, optimizer, snap, ema)
         self.nonfinite.zero_()
         self.counter.zero_()
+        # drop every handle on the warm-up autograd graphs: their AccumulateGrad nodes belong to `side`; kept alive, the
+        # captured backward would accumulate the two forwards' gradients on that stream, outside the capture's ordering
         criterion.last_total = None
+        self.sup = self.unsup = self.total = None
         optimizer.zero_grad(set_to_none=True)
         gc.collect()
         if self.dp:

@@ -4,6 +4,7 @@ import torch
 from .lib import F32, BF16
 
 _state = {'dtype': F32, 'seed': 0x5EDD0000}
+_seed_tensors = {}
 
 
 def set_compute_dtype(name):
@@ -20,7 +21,10 @@ def torch_dtype():
 
 
 def manual_seed(seed):
+    """restart the dropout mask sequence: the host-side per-site seeds AND the device-side replay counters"""
     _state['seed'] = int(seed) & 0x7fffffff
+    for t in _seed_tensors.values():
+        t.zero_()
 
 
 def seed_for_rank(rank):
@@ -33,9 +37,6 @@ def next_seed():
     """a fresh 32-bit seed per dropout site per forward (the kernels hash (seed, element index))"""
     _state['seed'] = (_state['seed'] * 1103515245 + 12345) & 0x7fffffff
     return _state['seed']
-
-
-_seed_tensors = {}
 
 
 def seed_ptr(device):

@@ -457,9 +457,11 @@ class SetCriterion(nn.Module):
         return [float(self.weight_dict.get(name if d == 0 else f'{name}_{d - 1}', 0.0)) for d in range(L)]
 
     def _dev_const(self, key, values, device):
+        """small f32 constant on the device, uploaded once and then reused (graph-capture safe); values: list or callable"""
         k = (key, str(device))
-        if k not in self._wvec:                       # uploaded once, then reused (graph-capture safe)
-            self._wvec[k] = torch.tensor(values, device=device, dtype=torch.float32)
+        if k not in self._wvec:
+            v = values() if callable(values) else values
+            self._wvec[k] = torch.as_tensor(v, dtype=torch.float32).to(device)
         return self._wvec[k]
 
     def _compute_fused(self, outputs, dense, fl=False):
@@ -478,7 +480,7 @@ class SetCriterion(nn.Module):
             at = at[None]
         zero = [0.0] * L
         dev = logits_all.device
-        ew = self._dev_const('ew', self.empty_weight.detach().float().tolist(), dev)
+        ew = self._dev_const('ew', lambda: self.empty_weight.detach().float().cpu(), dev)
         vec = _CriterionFn.apply(
             logits_all, boxes_all, at, dense, ew, layer_of,
             self._weights('loss_ce', L) if 'labels' in self.losses else zero,

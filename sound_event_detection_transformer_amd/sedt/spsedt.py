@@ -49,17 +49,18 @@ class SPSEDT(SEDT):
         gt = ops.avgpool(runtime.compute_dtype(), pf.permute(0, 2, 3, 1).reshape(BP * ph * pw, C), BP, ph * pw, C)
         pq = self.patch2query(gt).float().view(bs, bnp, 1, -1).repeat(1, 1, self.num_queries // self.num_patches, 1) \
             .flatten(1, 2).permute(1, 0, 2).contiguous()                     # (Q, B, d)
-        idx = torch.randperm(self.num_queries) if self.query_shuffle else torch.arange(self.num_queries)
         start = 1 if self.dec_at else 0
         if self.training:
+            qe = self.query_embed.weight[start:, :]
+            if self.query_shuffle:                                          # spsedt.py:60: the queries are permuted
+                qe = qe[torch.randperm(self.num_queries, device=dev)]
             if query_mask is None:
                 query_mask = (torch.rand(self.num_queries, bs, 1, device=dev) > self.mask_ratio).float()
-            dec_in = self.query_embed.weight[start:, :].unsqueeze(1).repeat(1, bs, 1)[idx]
-            dec_in = dec_in + (pq * query_mask.to(dev) + dec_in)             # spsedt.py:66-67: 2*query + patch*mask
+            dec_in = (qe * 2).unsqueeze(1) + pq * query_mask.to(dev)        # spsedt.py:66-67: 2*query + patch*mask
             am = self.attention_mask
         else:
             nq = bnp * self.num_queries // self.num_patches
-            dec_in = pq + self.query_embed.weight[start:nq, :].unsqueeze(1).repeat(1, bs, 1)
+            dec_in = pq + self.query_embed.weight[start:nq, :].unsqueeze(1)
             am = self.attention_mask[:nq, :nq]
         hs, memory = self.transformer(self.input_proj(src), mask, dec_in, pos[-1], decoder_mask=am)
         outputs_class = self.class_embed(hs, out_f32=True)
