@@ -1,87 +1,373 @@
 #!/usr/bin/env python3
-"""Headline benchmark: SEDT training throughput (audio clips/s) on synthetic URBAN-SED-shaped batches.
+"""Headline benchmark: SEDT training throughput (audio clips/s) on synthetic batches, one process per GPU.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c4|c5] [--dtype bf16|f32]
 
-A step = one full training step of BASELINE.json configs[1] (URBAN-SED SEDT, enc_layers=3, dec_at, num_queries=10,
-B=64 per GPU, bf16): forward on the HIP path, Hungarian matching + SetCriterion (on the device inside the step's HIP
-graph by default; --host-matching keeps the reference's host-side matching), backward on the HIP path,
-clip_grad_norm_(0.1), AdamW - with dropout 0.1 active.  Inputs are resident in HBM before the timed region.
-Prints ONE JSON line (rank 0) with the `roofline` (dominant kernel: the MFMA implicit GEMM, timed live with HIP events
-on the launch stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores, bounded sample) objects.
+N > 1 without a launcher: this script starts N ranks ITSELF (``python -m torch.distributed.run`` as a child process,
+before the parent touches the GPU) and relays rank 0's JSON line.  Under a launcher (WORLD_SIZE set) it is one rank;
+``--gpus`` must equal WORLD_SIZE.
+
+A step = one full training step of the chosen BASELINE.json configuration, as HIP graphs, inputs resident in HBM:
+  c2 (default, the metric's config): URBAN-SED SEDT E=3 dec_at Q=10 B=64/GPU bf16 - forward, on-device Hungarian matching +
+      SetCriterion, backward, clip 0.1, AdamW, dropout 0.1
+  c3: DCASE SEDT E=6 Q=20, B=32 = 16 strong + 16 weak clips
+  c4: SP-SEDT pre-training E=6 Q=20, 10 patches per clip, B=200/GPU, backbone frozen, feature-reconstruction loss
+  c5: mean-teacher step E=6 Q=20: 32 labelled (16+16) + 32 unlabelled clips through teacher (no grad) and student
+Prints ONE JSON line (rank 0): clips/s over all ranks, `roofline` (whole-step MFMA roofline from HIP events on the launch
+stream + the GEMM family replayed alone + PMC traffic from profiles/), `kernels` (per-kernel MFMA utilisation / HBM GB/s
+for the north-star kernels, timed live with HIP events), `cpu_baseline` (the CPU oracle on this box's host cores).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_CLIP_FWD_BWD = 27.37e9      # SURVEY.md 8(d), C2 geometry, 2*MAC, wgrad skipped for frozen conv1+layer1
-MFMA_PEAK_BF16 = 2.5e15              # dense bf16 MFMA peak, MI355X_MICROARCH.md
-MFMA_PEAK_F32 = 157.3e12
+# algorithmic work per clip, fwd + bwd, 2*MAC, wgrad skipped for frozen tensors
+FLOP_PER_CLIP = {'c2': 27.37e9, 'c3': 30.00e9, 'c4': 35.63e9}
+FLOP_C5_STEP_64 = (32 * 30.00 + 32 * 10.33 + 32 * 30.00) * 1e9      # labelled fwd+bwd, teacher fwd, student fwd+bwd
+MFMA_PEAK = {'bf16': 2.5e15, 'f32': 157.3e12}                          # dense peaks, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
 
 
-def synthetic_batch(B, T, seed, device):
-    from sound_event_detection_transformer_amd.utilities.synthetic import synthetic_batch as sb
-    return sb(B, T, seed, device)
-
-
-def cpu_baseline(batch=8, steps=2):
-    """the CPU oracle (pure PyTorch restatement of the reference path) on this box's host cores"""
-    from oracle import sedt_oracle as O
-    from oracle.criterion_oracle import build_oracle_criterion
-    cores = torch.get_num_threads()
-    model = O.build_oracle_model(10, 10, 3, 3, True, True, True, dropout=0.1)
-    model.load_state_dict(O.seeded_state_dict(model.state_dict(), 2020))
-    model.train()
-    crit = build_oracle_criterion(10, 3, True, True)
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-4)
-    x, targets = synthetic_batch(batch, 500, 2020, None)
-
-    def step():
-        ld, _ = crit(model(x), targets, None, slice(batch))
-        loss = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
-        opt.step()
-        opt.zero_grad()
-    step()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    dt = time.perf_counter() - t0
-    return {"value": round(batch * steps / dt, 3), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} full train steps of the CPU oracle at B={batch} (same model/config, f32, dropout on), 1 warm-up"}
-
-
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c4', 'c5'])
+    ap.add_argument('--batch', type=int, default=None, help='clips per GPU (default: the config\'s own)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernels', action='store_true', help='skip the per-kernel report')
     ap.add_argument('--dump-igemm', default=None, help='write per-launch igemm timings (json) to this path')
     ap.add_argument('--host-matching', action='store_true',
-                    help='solve the Hungarian matching on the host between two HIP graphs (the reference split) instead of on the device')
-    ap.add_argument('--coschedule', action='store_true', help='let weight-gradient GEMMs ride in the spare workgroup slots of the\n'
-                    'dgrad launches instead of one grouped launch per layer (measured slightly slower)')
-    ap.add_argument('--async-wgrad', action='store_true',
-                    help='issue the weight-gradient GEMMs as a parallel branch of the step graph (second stream); measured slower than the\n'
-                         'single-stream graph on ROCm 7.2: cross-queue dependencies cost 50-100 us each')
-    ap.add_argument('--no-graph', action='store_true', help='issue every kernel from Python instead of replaying HIP graphs')
-    ap.add_argument('--model-only', action='store_true', help='time fwd+bwd of the model with a fixed differentiable loss')
-    args = ap.parse_args()
+                    help='c2/c3: solve the Hungarian matching on the host between two HIP graphs (the reference split)')
+    ap.add_argument('--no-graph', action='store_true', help='c2/c3: issue every kernel from Python instead of replaying HIP graphs')
+    ap.add_argument('--model-only', action='store_true', help='c2: time fwd+bwd of the model with a fixed differentiable loss')
+    ap.add_argument('--no-overlap', action='store_true', help='data parallel: one all-reduce after the backward (no cut)')
+    return ap.parse_args()
 
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """N > 1 and no launcher: start the ranks as a CHILD process tree before this process makes any GPU call"""
+    import torch
+    have = torch.cuda.device_count()              # (does not initialise the GPU on this image)
+    if have < args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but only {have} GPU(s) visible', file=sys.stderr)
+        return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def host_cores():
+    """cores this process may really use: physical cores, capped by the affinity mask and the cgroup CPU quota"""
+    n = os.cpu_count() or 1
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False) or n
+    except Exception:
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, p = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(budget_s=25.0):
+    """the CPU oracle (pure-PyTorch restatement of the reference path, pinned to the reference by tests/golden) on this box's
+    host cores: BASELINE.md section 3 - C1 (B=4) and B=64, threads = usable physical cores, full step and fwd+bwd only."""
+    import torch
+    from oracle import sedt_oracle as O
+    from oracle.criterion_oracle import build_oracle_criterion
+    from sound_event_detection_transformer_amd.utilities.synthetic import synthetic_batch
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    model = O.build_oracle_model(10, 10, 3, 3, True, True, True, dropout=0.1)
+    model.load_state_dict(O.seeded_state_dict(model.state_dict(), 2020))
+    model.train()
+    crit = build_oracle_criterion(10, 3, True, True)
+    groups = [{"params": [p for n, p in model.named_parameters() if "backbone" not in n and p.requires_grad]},
+              {"params": [p for n, p in model.named_parameters() if "backbone" in n and p.requires_grad], "lr": 1e-4}]
+    opt = torch.optim.AdamW(groups, lr=1e-4, weight_decay=1e-4)
+
+    def run(batch, max_steps, budget, full=True):
+        x, targets = synthetic_batch(batch, 500, 2020, None)
+
+        def step():
+            ld, _ = crit(model(x), targets, None, slice(batch))
+            loss = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+            loss.backward()
+            if full:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+                opt.step()
+            opt.zero_grad()
+        step()                                   # warm-up
+        n, t0 = 0, time.perf_counter()
+        while n < max_steps and (n == 0 or time.perf_counter() - t0 < budget):
+            step()
+            n += 1
+        return batch * n / (time.perf_counter() - t0), n
+    c1, n1 = run(4, 5, budget_s * 0.15)
+    b64, n64 = run(64, 5, budget_s * 0.55)
+    fb, nfb = run(64, 2, budget_s * 0.2, full=False)
+    return {"value": round(b64, 3), "unit": "clips/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
+            "c1_b4_clips_per_s": round(c1, 3), "b64_fwd_bwd_only_clips_per_s": round(fb, 3),
+            "sample": f"CPU oracle, URBAN-SED SEDT E=3 Q=10 dec_at, f32, dropout on, torch.set_num_threads({cores}): "
+                      f"1 warm-up + {n64} full train steps at B=64 (value), 1+{n1} at B=4 (BASELINE config C1), "
+                      f"1+{nfb} fwd+bwd-only at B=64"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def build_workload(args, dev, rank, world):
+    """returns (step callable, clips per step per rank, flop per step per rank, description, graphed flag, extras)"""
+    import torch
+    from sound_event_detection_transformer_amd import runtime
+    from sound_event_detection_transformer_amd.sedt import build_model, default_args
+    from sound_event_detection_transformer_amd.engine import build_optimizer, GraphedTrainStep, GraphedSemiStep, train_step
+    from sound_event_detection_transformer_amd.utilities.synthetic import seeded_state_dict, synthetic_batch, synthetic_targets
+    from sound_event_detection_transformer_amd.utilities.utils import EMA
+    cfg = args.config
+    seed = 2020 + rank
+
+    def to_dev(ts):
+        return [{k: v.to(dev) for k, v in t.items()} for t in ts]
+    extras = {}
+    if cfg in ('c2', 'c3'):
+        E, Q, T = (3, 10, 500) if cfg == 'c2' else (6, 20, 496)
+        B = args.batch or (64 if cfg == 'c2' else 32)
+        ns = B if cfg == 'c2' else B // 2
+        model, criterion, _ = build_model(default_args(enc_layers=E, num_queries=Q, dec_at=True, dropout=0.1))
+        model.load_state_dict(seeded_state_dict(model.state_dict(), 2020))
+        model.to(dev).train()
+        criterion.to(dev)
+        opt = build_optimizer(model)
+        x, targets = synthetic_batch(B, T, seed, dev)
+        for t in targets[ns:]:
+            t['boxes'] = torch.zeros(0, 2, device=dev)
+        wm = slice(ns, B) if ns < B else None
+        net = model
+        if world > 1 and args.no_graph:
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False,
+                                                            gradient_as_bucket_view=True)
+        graphed = not (args.no_graph or args.model_only)
+        if graphed:
+            g = GraphedTrainStep(net, criterion, opt, x, targets, wm, slice(ns), max_norm=0.1, device_matching=not args.host_matching,
+                                 overlap_allreduce=not args.no_overlap)
+            extras['stepper'] = g
+
+            def step():
+                g(x, targets)
+        elif args.model_only:
+            def step():
+                o = net(x)
+                loss = o['pred_logits'].square().mean() + o['pred_boxes'].mean() + o['at'].mean() + \
+                    sum(a['pred_logits'].square().mean() + a['pred_boxes'].mean() for a in o['aux_outputs'])
+                loss.backward()
+                opt.zero_grad(set_to_none=True)
+        else:
+            def step():
+                train_step(net, criterion, opt, x, targets, wm, slice(ns), max_norm=0.1)
+        extras.update(model=model, criterion=criterion, opt=opt, x=x, targets=targets, wm=wm, ns=ns, net=net)
+        what = (f"{'URBAN-SED' if cfg == 'c2' else 'DCASE2019'} SEDT enc_layers={E} dec_at num_queries={Q} B={B}/GPU"
+                f"{'' if cfg == 'c2' else f' ({ns} strong + {B - ns} weak)'}, 10 s @ 64-mel (B,1,{T},64), full train step: fwd + "
+                f"Hungarian matching ({'host' if (args.host_matching or args.no_graph) else 'device'}) + SetCriterion + bwd + clip 0.1 + "
+                f"AdamW, dropout 0.1" + (" [model-only timing]" if args.model_only else ""))
+        return step, B, FLOP_PER_CLIP[cfg] * B, what, graphed, extras
+    if cfg == 'c4':
+        B, P = args.batch or 200, 10
+        model, criterion, _ = build_model(default_args(enc_layers=6, num_queries=20, dec_at=False, self_sup=True, lr_backbone=0.0,
+                                                       dropout=0.1))
+        model.load_state_dict(seeded_state_dict(model.state_dict(), 2020))
+        model.to(dev).train()
+        criterion.to(dev)
+        opt = build_optimizer(model)
+        gen = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, 1, 496, 64, generator=gen).to(dev)
+        patches = torch.randn(B, P, 1, 128, 64, generator=gen).to(dev)
+        targets = []
+        for _ in range(B):                       # one box per patch, label 0 (DataLoad.py:57-77)
+            l = (torch.randn(P, generator=gen) * 0.26 + 0.2).clamp(0.05, 0.799)
+            c = l / 2 + torch.rand(P, generator=gen) * (1 - l)
+            targets.append({'labels': torch.zeros(P, dtype=torch.int64), 'boxes': torch.stack([c, l], -1)})
+        targets = to_dev(targets)
+        g = GraphedTrainStep(model, criterion, opt, x, targets, slice(B), slice(B), max_norm=0.1, example_patches=patches,
+                             overlap_allreduce=False)
+        extras.update(stepper=g, model=model)
+
+        def step():
+            g(x, targets, patches=patches)
+        what = (f"SP-SEDT self-sup pre-training (feature_recon, num_patches=10) enc_layers=6 num_queries=20 B={B}/GPU + {B * P} patches "
+                f"(1,128,64), backbone frozen, full step: clip + patch backbone fwd, transformer fwd/bwd, device matching, "
+                f"CE/L1/GIoU/feature losses, clip 0.1 + AdamW, dropout 0.1")
+        return step, B, FLOP_PER_CLIP['c4'] * B, what, True, extras
+    # c5
+    n_s = n_w = (args.batch // 4) if args.batch else 16
+    n_u = 2 * n_s
+    B = n_s + n_w + n_u
+    model, criterion, _ = build_model(default_args(enc_layers=6, num_queries=20, dec_at=True, dropout=0.1))
+    model.load_state_dict(seeded_state_dict(model.state_dict(), 2020))
+    model.to(dev).train()
+    criterion.to(dev)
+    ema = EMA(model, 0.9996)
+    ema.register()
+    opt = build_optimizer(model)
+    gen = torch.Generator().manual_seed(seed)
+    x_t = torch.randn(B, 1, 496, 64, generator=gen)
+    x_s = x_t.clone()
+    x_s[n_s + n_w:] += 0.1 * torch.randn(n_u, 1, 496, 64, generator=gen)     # the student's augmented view of the unlabelled clips
+    x_t, x_s = x_t.to(dev), x_s.to(dev)
+    targets = synthetic_targets(B, seed + 1, 10)
+    for t in targets[n_s:]:
+        t['boxes'] = torch.zeros(0, 2)
+    for t in targets[n_s + n_w:]:
+        t['labels'] = torch.zeros(0, dtype=torch.int64)
+    targets = to_dev(targets)
+    thr = torch.full((10,), 0.1, device=dev)          # (random-init teacher: a low threshold keeps pseudo events alive)
+    g = GraphedSemiStep(model, ema, criterion, opt, x_t, x_s, targets, slice(n_s), slice(n_s, n_s + n_w), slice(n_s + n_w),
+                        slice(n_s + n_w, B), thr)
+    extras.update(stepper=g, model=model)
+
+    def step():
+        g(x_t, x_s, targets)
+    what = (f"semi-supervised mean-teacher step (train_ss_sedt.py) enc_layers=6 num_queries=20 per GPU: {n_s} synthetic + {n_w} weak "
+            f"labelled clips fwd/bwd, {n_u} unlabelled clips through the EMA teacher (no grad) -> device pseudo labels -> student "
+            f"fwd/bwd on the augmented view, one backward, clip 0.1 + AdamW + EMA update, dropout 0.1, mixup off")
+    return step, B, FLOP_C5_STEP_64 * B / 64.0, what, True, extras
+
+
+def kernel_report(dtype, dev):
+    """north_star's per-kernel figures, timed live with HIP events at the C2 shapes: MFMA utilisation of the attention core,
+    the encoder self-attention block, the FFN GEMMs and the layer4 3x3 conv; HBM GB/s of LayerNorm and the fused AdamW."""
+    import torch
+    from sound_event_detection_transformer_amd import ops, lib as L
+    from sound_event_detection_transformer_amd.optim import FusedAdamW
+    dt = L.BF16 if dtype == 'bf16' else L.F32
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    es = 2 if dtype == 'bf16' else 4
+    peak = MFMA_PEAK[dtype]
+    B, S, E, H, FF = 64, 128, 256, 8, 2048
+    M = B * S
+    g = torch.Generator().manual_seed(1)
+
+    def rnd(*shape, scale=1.0, dtype_=None):
+        return (torch.randn(*shape, generator=g) * scale).to(device=dev, dtype=dtype_ or td)
+
+    def timeit(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+    out = []
+    x, pos = rnd(M, E), rnd(M, E, scale=0.5)
+    gam, bet = rnd(E, dtype_=torch.float32), rnd(E, dtype_=torch.float32)
+    w_in, b_in = rnd(3 * E, E, scale=0.06), rnd(3 * E, dtype_=torch.float32)
+    w_o, b_o = rnd(E, E, scale=0.06), rnd(E, dtype_=torch.float32)
+    w1, b1 = rnd(FF, E, scale=0.06), rnd(FF, dtype_=torch.float32)
+    w2, b2 = rnd(E, FF, scale=0.02), rnd(E, dtype_=torch.float32)
+    q, k, v = rnd(M, E), rnd(M, E), rnd(M, E)
+
+    def mf(name, flop, t, note=''):
+        out.append({"kernel": name, "us": round(t * 1e6, 2), "achieved": round(flop / t / 1e12, 1), "unit": "TFLOP/s",
+                    "peak": peak / 1e12, "frac": round(flop / t / peak, 4), "bound": "mfma", "note": note})
+
+    def hb(name, nbytes, t, note=''):
+        out.append({"kernel": name, "us": round(t * 1e6, 2), "achieved": round(nbytes / t / 1e9, 1), "unit": "GB/s",
+                    "peak": HBM_PEAK / 1e9, "frac": round(nbytes / t / HBM_PEAK, 4), "bound": "hbm", "note": note})
+    t = timeit(lambda: ops.attention_fwd(dt, q, k, v, B, H, S, S, None, None, 0.1, 7, None))
+    mf("attention core fwd (sedt_attention_fwd: 512 heads x 128x128x32, dropout 0.1)", 4.0 * S * S * 32 * B * H, t)
+
+    def block():
+        xn, xnp, _, _ = ops.layernorm_fwd(dt, x, gam, bet, add_t=pos)
+        qk, vv = ops.linear_group(dt, [(xnp, w_in[:2 * E], dict(bias=b_in[:2 * E])), (xn, w_in[2 * E:], dict(bias=b_in[2 * E:]))])
+        ctx, _ = ops.attention_fwd(dt, qk[:, :E], qk[:, E:], vv, B, H, S, S, None, None, 0.1, 7, None)
+        return ops.linear(dt, ctx, w_o, bias=b_o, drop_p=0.1, seed=3, res=x, ldr=x.stride(0))
+    t = timeit(block)
+    mf("encoder self-attn block fwd (LN1 + pos -> QKV -> attention -> out-proj + dropout + residual)", 83.9e6 * B, t,
+       "4 launches today; north_star target >= 0.60")
+
+    def ffn():
+        h = ops.linear(dt, x, w1, bias=b1, act=L.ACT_RELU, drop_p=0.1, seed=5)
+        return ops.linear(dt, h, w2, bias=b2, drop_p=0.1, seed=6, res=x, ldr=x.stride(0))
+    t = timeit(ffn)
+    mf("encoder FFN fwd (linear1 + ReLU + dropout, linear2 + dropout + residual)", 2.0 * 2 * M * E * FF, t)
+    xin = rnd(B * 32 * 4, 512)
+    wc = rnd(512, 9 * 512, scale=0.02)
+    sc, bi = rnd(512, dtype_=torch.float32), rnd(512, dtype_=torch.float32)
+    geo = ops.ConvGeom(32, 4, 512, 512, 3, 1, 2, 2)
+    t = timeit(lambda: ops.conv_fwd(dt, xin, B, geo, wc, scale=sc, bias=bi, act=L.ACT_RELU))
+    mf("layer4 3x3 dilated conv fwd (implicit GEMM 8192 x 512 x 4608, FrozenBN + ReLU epilogue)", 2.0 * M * 512 * 4608, t)
+    t = timeit(lambda: ops.layernorm_fwd(dt, x, gam, bet))
+    hb("LayerNorm fwd 8192 x 256 (sedt_layernorm_fwd)", 2.0 * M * E * es, t)
+    n = 32579869
+    p = torch.nn.Parameter(torch.zeros(n, device=dev))
+    p.grad = torch.full((n,), 1e-3, device=dev)
+    opt = FusedAdamW([p], lr=1e-4, weight_decay=1e-4)
+    t = timeit(lambda: opt.step(max_norm=0.1), reps=10)
+    hb("clip + AdamW over 32.58 M parameters (sedt_multi_sumsq + sedt_multi_adamw)", 32.0 * n, t,
+       "sumsq reads g (4 B), adamw reads p,g,m,v and writes p,m,v (28 B) per parameter")
+    return out
+
+
+def pmc_traffic(config):
+    """HBM-side bytes per step from the committed PMC profile of this config (profiles/r02_pmc_<config>.json), or None"""
+    path = os.path.join(ROOT, 'profiles', f'r02_pmc_{config}.json')
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} does not match WORLD_SIZE {world}', file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -92,42 +378,9 @@ def main():
     torch.cuda.set_device(dev)
 
     from sound_event_detection_transformer_amd import runtime, ops
-    from sound_event_detection_transformer_amd.sedt import build_model, default_args
-    from sound_event_detection_transformer_amd.engine import train_step, build_optimizer
-    from sound_event_detection_transformer_amd.utilities.synthetic import seeded_state_dict
-
     runtime.set_compute_dtype(args.dtype)
     torch.manual_seed(2020)
-    model, criterion, _ = build_model(default_args(enc_layers=3, num_queries=10, dec_at=True, dropout=0.1))
-    model.load_state_dict(seeded_state_dict(model.state_dict(), 2020))
-    model.to(dev).train()
-    criterion.to(dev)
-    net = model
-    if world > 1 and args.no_graph:
-        # eager path: torch DDP (bucketed RCCL all-reduce overlapped with backward)
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
-                                                        gradient_as_bucket_view=True)
-    opt = build_optimizer(model)
-    B = args.batch
-    x, targets = synthetic_batch(B, 500, 2020 + rank, dev)
-
-    from sound_event_detection_transformer_amd.engine import GraphedTrainStep
-    graphed = None
-    if not args.no_graph and not args.model_only:
-        graphed = GraphedTrainStep(net, criterion, opt, x, targets, None, slice(B), max_norm=0.1,
-                                   device_matching=not args.host_matching, async_wgrad=args.async_wgrad, coschedule=args.coschedule)
-
-    def step():
-        if graphed is not None and ops.PROFILE is None:
-            graphed(x, targets)
-        elif args.model_only:
-            o = net(x)
-            loss = o['pred_logits'].square().mean() + o['pred_boxes'].mean() + o['at'].mean() + \
-                sum(a['pred_logits'].square().mean() + a['pred_boxes'].mean() for a in o['aux_outputs'])
-            loss.backward()
-            opt.zero_grad(set_to_none=True)
-        else:
-            train_step(net, criterion, opt, x, targets, None, slice(B), max_norm=0.1)
+    step, clips, flop_step, what, graphed, ex = build_workload(args, dev, rank, world)
 
     def barrier():
         if world > 1:
@@ -137,85 +390,125 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     for _ in range(args.steps):
         step()
+    e1.record()
     barrier()
     elapsed = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1) / args.steps           # HIP events on the stream the step's graphs are launched on
+    per_rank = [elapsed]
+    rccl_world = 1
     if world > 1:
+        dist = torch.distributed
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = t.item()
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(v) for v in allt]
+        elapsed = max(per_rank)
+        rccl_world = dist.get_world_size() if dist.get_backend() == 'nccl' else 0
 
-    # ---- roofline of the dominant kernel family: ONE extra (eager) step records the argument block of every GEMM launch and
-    #      keeps its operands alive; the launches are then replayed back to back on the launch stream between two HIP events
-    #      (queueing ~300 launches takes less host time than they run, so the stream never starves): elapsed / launches = the
-    #      average GEMM launch duration, comparable with rocprofv3's per-kernel averages of the graphed step.
-    roof = None
-    if rank != 0 and world > 1 and args.no_graph:
-        ops.PROFILE = []                      # eager DDP: the extra step contains collectives, every rank must take part
-        step()
+    # ---- exposed communication: the same step without the data-parallel schedule (local gradients only), same process
+    exposed = None
+    if world > 1 and graphed and args.config in ('c2', 'c3') and 'stepper' in ex:
+        from sound_event_detection_transformer_amd.engine import GraphedTrainStep
+        loc = GraphedTrainStep(ex['net'], ex['criterion'], ex['opt'], ex['x'], ex['targets'], ex['wm'], slice(ex['ns']), max_norm=0.1,
+                               data_parallel=False)
+        for _ in range(3):
+            loc(ex['x'], ex['targets'])
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            loc(ex['x'], ex['targets'])
         torch.cuda.synchronize()
-        ops.PROFILE = None
-    if rank == 0:
-        import ctypes
-        from sound_event_detection_transformer_amd import lib as L_
-        ops.PROFILE = []
-        step()
-        torch.cuda.synchronize()
-        rec = ops.PROFILE
-        ops.PROFILE = None
-        n = len(rec)
-        lib = L_.load()
+        local_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        exposed = {"local_step_ms": round(local_ms, 3), "exposed_comm_ms": round(elapsed / args.steps * 1e3 - local_ms, 3)}
 
-        def replay():
-            for a, dt_, _, _ in rec:
-                L_.check(lib.sedt_igemm(ctypes.byref(a), dt_, L_.stream_ptr()), 'sedt_igemm')
-        replay()
-        torch.cuda.synchronize()
-        reps = 3
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            replay()
-        e1.record()
-        torch.cuda.synchronize()
-        tot_ms = e0.elapsed_time(e1) / reps
-        if args.dump_igemm:
-            per = []
-            for a, dt_, sh, _ in rec:
-                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s0.record()
-                for _ in range(5):
+    # ---- GEMM family alone (c2/c3, rank 0): ONE extra eager step records the argument block of every GEMM launch, which are
+    #      then replayed back to back on the launch stream between two HIP events
+    gemm = None
+    if args.config in ('c2', 'c3') and not args.model_only:
+        if rank != 0 and world > 1 and args.no_graph:
+            ops.PROFILE = []                      # eager DDP: the extra step contains collectives, every rank must take part
+            from sound_event_detection_transformer_amd.engine import train_step
+            train_step(ex['net'], ex['criterion'], ex['opt'], ex['x'], ex['targets'], ex['wm'], slice(ex['ns']), max_norm=0.1)
+            torch.cuda.synchronize()
+            ops.PROFILE = None
+        if rank == 0:
+            import ctypes
+            from sound_event_detection_transformer_amd import lib as L_
+            from sound_event_detection_transformer_amd.engine import train_step
+            ops.PROFILE = []
+            train_step(ex['net'], ex['criterion'], ex['opt'], ex['x'], ex['targets'], ex['wm'], slice(ex['ns']), max_norm=0.1)
+            torch.cuda.synchronize()
+            rec = ops.PROFILE
+            ops.PROFILE = None
+            n = len(rec)
+            lib = L_.load()
+
+            def replay():
+                for a, dt_, _, _ in rec:
                     L_.check(lib.sedt_igemm(ctypes.byref(a), dt_, L_.stream_ptr()), 'sedt_igemm')
-                s1.record()
-                torch.cuda.synchronize()
-                per.append({'ms': s0.elapsed_time(s1) / 5, 'shape': sh})
-            with open(args.dump_igemm, 'w') as f:
-                json.dump(per, f)
-        flops_launch = FLOP_PER_CLIP_FWD_BWD * B / max(n, 1)
-        avg_s = tot_ms / 1e3 / max(n, 1)
-        peak = MFMA_PEAK_BF16 if args.dtype == 'bf16' else MFMA_PEAK_F32
-        ach = flops_launch / avg_s / 1e12
-        roof = {"bound": "mfma", "kernel": "sedt::igemm3_kernel / igemm3_w8_kernel + sedt::wgrad3_kernel / wgrad4_kernel (MFMA implicit-GEMM family: every conv/linear fwd, dgrad, wgrad launch)", "achieved": round(ach, 2), "peak": peak / 1e12, "unit": "TFLOP/s",
-                "frac": round(ach / (peak / 1e12), 4), "traffic": None, "launches_per_step": n,
-                "avg_launch_us": round(avg_s * 1e6, 2), "igemm_ms_per_step": round(tot_ms, 3),
-                "algorithmic_flop_per_launch": flops_launch}
-        del rec
+            replay()
+            torch.cuda.synchronize()
+            reps = 3
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            for _ in range(reps):
+                replay()
+            g1.record()
+            torch.cuda.synchronize()
+            tot_ms = g0.elapsed_time(g1) / reps
+            if args.dump_igemm:
+                per = []
+                for a, dt_, sh, _ in rec:
+                    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s0.record()
+                    for _ in range(5):
+                        L_.check(lib.sedt_igemm(ctypes.byref(a), dt_, L_.stream_ptr()), 'sedt_igemm')
+                    s1.record()
+                    torch.cuda.synchronize()
+                    per.append({'ms': s0.elapsed_time(s1) / 5, 'shape': sh})
+                with open(args.dump_igemm, 'w') as f:
+                    json.dump(per, f)
+            gemm = {"launches_per_step": n, "ms_per_step_replayed_alone": round(tot_ms, 3),
+                    "avg_launch_us": round(tot_ms * 1e3 / max(n, 1), 2),
+                    "achieved_tflops": round(flop_step / (tot_ms * 1e-3) / 1e12, 1),
+                    "frac": round(flop_step / (tot_ms * 1e-3) / MFMA_PEAK[args.dtype], 4),
+                    "note": "every conv/linear fwd, dgrad and wgrad launch of one step issued back to back (eager, ungrouped); "
+                            "the same family inside the step graph is ~15 % faster (profiles/)"}
+            del rec
 
     if rank == 0:
+        peak = MFMA_PEAK[args.dtype]
+        ach = flop_step / (dev_ms * 1e-3)
+        traffic = pmc_traffic(args.config)
+        roof = {"bound": "mfma",
+                "kernel": "whole training-step graph (>= 99 % of its algorithmic flops are the MFMA implicit-GEMM family "
+                          "sedt::igemm3* / wgrad3/4*; see gemm_family and kernels)",
+                "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": None if traffic is None else traffic.get('hbm_bytes_per_step'),
+                "traffic_source": None if traffic is None else traffic.get('source'),
+                "algorithmic_flop_per_launch": flop_step, "launch": "one step = one replay of the step's HIP graph(s)",
+                "avg_launch_ms_hip_events": round(dev_ms, 4), "gemm_family": gemm}
+        kernels = None
+        if not args.no_kernels and args.config == 'c2':
+            try:
+                kernels = kernel_report(args.dtype, dev)
+            except Exception as e:                                   # the report must never cost the headline number
+                kernels = [{"error": repr(e)}]
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
-        value = world * B * args.steps / elapsed
-        out = {"metric": "audio clips/sec training throughput (B=64, 10s@64-mel)", "value": round(value, 2),
+        value = world * clips * args.steps / elapsed
+        out = {"metric": f"audio clips/sec training throughput (B={clips}, 10s@64-mel)", "value": round(value, 2),
                "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": "URBAN-SED SEDT enc_layers=3 dec_at num_queries=10 B=64/GPU, 10 s @ 64-mel "
-                                      "(B,1,500,64), full train step: fwd + Hungarian matching (" + ("host" if (args.host_matching or args.no_graph) else "device") +
-                                      ") + SetCriterion + bwd + clip 0.1 + AdamW, dropout 0.1"
-                                      + (" [model-only timing]" if args.model_only else ""),
-                          "global_batch": world * B, "parallelism": f"dp{world}"},
-               "roofline": roof, "cpu_baseline": cpu, "hip_graph": graphed is not None}
+               "config": {"workload": what, "name": args.config, "global_batch": world * clips, "parallelism": f"dp{world}"},
+               "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "hip_graph": graphed,
+               "rccl_world": rccl_world, "ms_per_step_per_rank": [round(v / args.steps * 1e3, 3) for v in per_rank],
+               "exposed_comm": exposed}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -25,7 +25,7 @@ def _worker(rank, world, port, out):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from sound_event_detection_transformer_amd.engine import allreduce_mean
     from sound_event_detection_transformer_amd.sedt import build_model, default_args
-    from bench import synthetic_batch
+    from sound_event_detection_transformer_amd.utilities.synthetic import synthetic_batch
     crit = build_model(default_args())[1]
     B, Q = 4, 10
     x, targets = synthetic_batch(B, 500, 2020 + rank, None)                  # different data on every rank
@@ -54,3 +54,18 @@ def test_flat_gradient_mean_allreduce_gloo_world2(tmp_path):
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     r = torch.load(out)
     assert r['ok'] and r['differ'] and r['x_differ'], r
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """bench.py --gpus N must never print an N-GPU line from fewer ranks: under a launcher WORLD_SIZE has to equal --gpus; without
+    one it starts the ranks itself and fails when the GPUs are not there (this container has none)"""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, 'bench.py')
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '1'], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and 'does not match WORLD_SIZE' in r.stderr and not r.stdout.strip()
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '1'], env=env, capture_output=True, text=True)
+        assert r.returncode == 2 and 'GPU(s) visible' in r.stderr and not r.stdout.strip()
