@@ -35,6 +35,9 @@ def allreduce_mean(flat, async_op=False):
 
 
 _step_streams = {}
+# capture mode: only THIS thread's unsafe calls invalidate a capture.  With the default ("global") the RCCL watchdog thread of
+# an initialised process group - it polls events with hipEventQuery - sporadically kills a capture in progress.
+_CAPTURE = dict(capture_error_mode='thread_local')
 
 
 def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None, mask_strong=None, max_norm=0.1,
@@ -252,7 +255,7 @@ class GraphedTrainStep(_GraphedBase):
         with optimizer.table_set(self._tabname):
             if device_matching:
                 self.tables = self._make_tables(example_targets, max_targets)
-                with torch.cuda.graph(self.g_fwd):
+                with torch.cuda.graph(self.g_fwd, **_CAPTURE):
                     self.static_out = self._forward()
                     self.static_dense = criterion.prepare_device(self.static_out, self.tables, normalize=normalize,
                                                                  fine_tune=fine_tune, fl=fl, ft_rand=ft_rand)
@@ -262,23 +265,23 @@ class GraphedTrainStep(_GraphedBase):
                         self._backward_above_cut()
                 if self.cut_body is not None:
                     self.g_low = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.g_low, pool=self.g_fwd.pool()):
+                    with torch.cuda.graph(self.g_low, pool=self.g_fwd.pool(), **_CAPTURE):
                         self._backward_below_cut()
             else:
-                with torch.cuda.graph(self.g_fwd):
+                with torch.cuda.graph(self.g_fwd, **_CAPTURE):
                     self.static_out = self._forward()
                 dense, _ = criterion.prepare(self.static_out, example_targets, mask_weak, mask_strong, normalize)
                 self.meta = dense['_meta']
                 self.static_pack = dense['_pack'].clone()
                 self.static_dense = criterion.dense_views(self.static_pack, self.meta)
                 self.g_bwd = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool()):
+                with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), **_CAPTURE):
                     self._backward_and_step()
             if self.dp:
                 # data parallel: ONE RCCL all-reduce of the flat gradient buffer between the graphs, then the fused
                 # clip + AdamW reads the averaged gradients from the flat buffer
                 self.g_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_opt, pool=self.g_fwd.pool()):
+                with torch.cuda.graph(self.g_opt, pool=self.g_fwd.pool(), **_CAPTURE):
                     optimizer.step(max_norm=max_norm, from_flat=True)
         torch.cuda.synchronize()
 
@@ -566,11 +569,11 @@ class GraphedSemiStep(_GraphedBase):
         self.graph = torch.cuda.CUDAGraph()
         self.g_opt = None
         with optimizer.table_set(self._tabname):
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, **_CAPTURE):
                 self._body(part='fwd_bwd' if self.dp else 'all')
             if self.dp:                                       # data parallel: RCCL all-reduce of the flat gradients in between
                 self.g_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_opt, pool=self.graph.pool()):
+                with torch.cuda.graph(self.g_opt, pool=self.graph.pool(), **_CAPTURE):
                     self._body(part='update')
         torch.cuda.synchronize()
 
