@@ -195,7 +195,7 @@ def test_sedt_against_oracle_bf16_and_f32_b4(pkg):
         ref = oracle(x)
     model, _ = _build(sedt, 3, 10)
     _seed_load(model, 31).cuda().eval()
-    for mode, tol in (('f32', 1e-3), ('bf16', 5e-2)):
+    for mode, tol in (('f32', 1e-3), ('bf16', 4.5e-2)):       # bf16: ~3x the measured error (tests/test_parity_depth_gpu.py)
         runtime.set_compute_dtype(mode)
         with torch.no_grad():
             o = model(x.cuda())
