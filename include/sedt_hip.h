@@ -425,6 +425,23 @@ int sedt_pseudo_labels(const float* logits, const float* boxes, const float* at,
                        int Q, int C, int del_overlap, int64_t* lab_cat, float* box_cat, int32_t* lab_off, int32_t* box_off,
                        int32_t* counter, int cap, void* stream);
 
+/* ------------------------------------------------------------------ input side on the device (utilities/BoxTransforms.py,
+ * utilities/mixup.py)
+ * sedt_box_transform: the per-clip feature transforms composed as get_transforms does (BoxTransforms.py:454-490):
+ *   ApplyLog (librosa.amplitude_to_db: 10 log10(max(1e-10, x^2)), clamped at clip-max - 80 dB; apply_log = 0 skips it)
+ *   -> PadOrTrunc to `frames` rows (zero rows appended) -> TimeMask (rows [tm_t0, tm_t0 + tm_t) zeroed)
+ *   -> FreqMask (bands [fm_f0, fm_f0 + fm_f) := their mean over the clip when fill_mean, else fill_const; only if fm_on)
+ *   -> FreqShift (np.roll by fs_shift bands, wrapped bands zeroed) -> (x - mean[band]) / std[band] in float64 (Scaler.normalize;
+ *   mean/std may be null: no normalisation).  The random parameters are drawn by the caller exactly as the reference's
+ *   transform classes draw them; aug = B records of 8 int32 {nframes_raw, tm_t, tm_t0, fm_f, fm_f0, fm_on, fs_shift, 0}.
+ *   amp [B][raw_stride][F] f32 (rows >= nframes_raw ignored), out [B][1][frames][F] f32.  One workgroup per clip, the clip
+ *   stays in LDS between the passes (frames * F * 4 bytes <= 160 KB).
+ * sedt_mixup: out[i] = lam * x1[src1] + (1 - lam) * x2[src2] (mode 0), x1[src1] (1) or x2[src2] (2); jobs = n_out records
+ *   {int32 src1, src2, mode; float lam} (mixup.py:35, 142: the label bookkeeping stays on the host). */
+int sedt_box_transform(const float* amp, int64_t raw_stride, const void* aug, const double* mean, const double* stdv, int B,
+                       int frames, int F, int apply_log, int fill_mean, float fill_const, float* out, void* stream);
+int sedt_mixup(const float* x1, const float* x2, const void* jobs, int n_out, int64_t clip_elems, float* out, void* stream);
+
 /* ------------------------------------------------------------------ host-side matching (sedt/matcher.py:95)
  * HOST pointers.  cost [nlayers][nclips][Q][Nt] f32; clip b owns columns [col_off[b], col_off[b]+ncols[b]).
  * assign [nlayers][nclips][Q]: index (within the clip) of the target matched to query q, or -1.

@@ -1,0 +1,163 @@
+// input.hip - the input side of the training step on the device:
+//   * box_transform_kernel  the per-clip feature transforms of reference utilities/BoxTransforms.py composed as
+//                           get_transforms does (:454-490): ApplyLog (librosa.amplitude_to_db, :55-67) -> PadOrTrunc (:70-117)
+//                           -> TimeMask (:363-395) -> FreqMask(fill "mean" or constant, :398-425) -> FreqShift (:428-451)
+//                           -> ToTensor (add the channel axis, f32) -> Normalize (Scaler.normalize, Scaler.py:102-108)
+//   * mixup_kernel          the feature half of utilities/mixup.py:13-196 (lam * x1 + (1 - lam) * x2, or one of the two)
+// One workgroup per clip: the clip (frames x 64 mel, <= 127 KB as f32) lives in LDS between the passes, so HBM sees one read
+// of the raw amplitudes and one write of the normalised features.  Random parameters are drawn on the HOST exactly as the
+// reference draws them (np.random, same order) and arrive as integers: the kernel is deterministic.
+#include <algorithm>
+#include "common.h"
+
+namespace sedt {
+
+struct ClipAug {               // mirrors utilities/transforms.py:_AUG (8 x int32 per clip)
+  int32_t nframes_raw;         // frames of the raw clip (rows of amp actually present)
+  int32_t tm_t, tm_t0;         // time mask: rows [t0, t0 + t) are zeroed (t = 0: off)
+  int32_t fm_f, fm_f0;         // frequency mask: mel bands [f0, f0 + f) are overwritten (f = 0 with fm_on = 0: off)
+  int32_t fm_on;               // 1 = apply (f may be 0: numpy then writes nothing)
+  int32_t fs_shift;            // frequency shift in bands (0 = off)
+  int32_t pad_;
+};
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float m = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+  return m;
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];          // fixed order
+  return s;
+}
+
+// amp [B][raw_stride][F] f32 mel amplitudes (rows >= nframes_raw are ignored), out [B][1][frames][F] f32
+__global__ __launch_bounds__(1024) void box_transform_kernel(const float* __restrict__ amp, long raw_stride, const ClipAug* __restrict__ aug,
+                                                             const double* __restrict__ mean, const double* __restrict__ stdv,
+                                                             int frames, int F, int apply_log, int fill_mean, float fill_const,
+                                                             float* __restrict__ out) {
+  extern __shared__ float lds[];
+  float* clip = lds;                              // [frames][F]
+  float* red = lds + (long)frames * F;            // [16]
+  const int b = blockIdx.x, t = threadIdx.x;
+  const ClipAug a = aug[b];
+  const float* src = amp + (long)b * raw_stride * F;
+  const int nraw = a.nframes_raw;
+  // ---- pass 1: amplitude -> dB (10 log10(max(1e-10, x^2)), reference value 1.0), clip maximum over ALL raw frames
+  float mx = -INFINITY;
+  for (long i = t; i < (long)nraw * F; i += 1024) {
+    const float x = src[i];
+    const float v = apply_log ? 10.f * log10f(fmaxf(1e-10f, x * x)) : x;
+    mx = fmaxf(mx, v);
+    if (i < (long)frames * F) clip[i] = v;
+  }
+  for (long i = (long)nraw * F + t; i < (long)frames * F; i += 1024) clip[i] = 0.f;        // PadOrTrunc: zero rows appended
+  mx = block_max(mx, red);
+  __syncthreads();
+  const float floor_db = mx - 80.f;               // top_db = 80
+  const int keep = min(nraw, frames);
+  // ---- pass 2 (LDS): top_db clamp on the real rows, then the time mask
+  for (long i = t; i < (long)frames * F; i += 1024) {
+    const int r = (int)(i / F);
+    float v = clip[i];
+    if (apply_log && r < keep) v = fmaxf(v, floor_db);
+    if (r >= a.tm_t0 && r < a.tm_t0 + a.tm_t) v = 0.f;
+    clip[i] = v;
+  }
+  __syncthreads();
+  // ---- frequency mask: the bands [f0, f0 + f) take their mean over the whole (padded, time-masked) clip
+  if (a.fm_on && a.fm_f > 0) {
+    float fill = fill_const;
+    if (fill_mean) {
+      float s = 0.f;
+      for (long i = t; i < (long)frames * a.fm_f; i += 1024) {
+        const int r = (int)(i / a.fm_f), c = a.fm_f0 + (int)(i - (long)r * a.fm_f);
+        s += clip[(long)r * F + c];
+      }
+      s = block_sum(s, red);
+      fill = s / (float)((long)frames * a.fm_f);
+      __syncthreads();
+    }
+    for (long i = t; i < (long)frames * a.fm_f; i += 1024) {
+      const int r = (int)(i / a.fm_f), c = a.fm_f0 + (int)(i - (long)r * a.fm_f);
+      clip[(long)r * F + c] = fill;
+    }
+    __syncthreads();
+  }
+  // ---- frequency shift (np.roll along mel, wrapped bands zeroed) + normalisation (float64 like Scaler.normalize), store
+  float* dst = out + (long)b * frames * F;
+  const int sh = a.fs_shift;
+  for (long i = t; i < (long)frames * F; i += 1024) {
+    const int r = (int)(i / F), c = (int)(i - (long)r * F);
+    const int cs = c - sh;                         // out[c] = in[c - shift]
+    const float v = (cs >= 0 && cs < F) ? clip[(long)r * F + cs] : 0.f;
+    dst[i] = mean ? (float)(((double)v - mean[c]) / stdv[c]) : v;
+  }
+}
+
+struct MixJob {                // mirrors utilities/mixup.py (4 x int32 + 1 float per output clip)
+  int32_t src1, src2;          // rows of x1 / x2
+  int32_t mode;                // 0: lam * x1[src1] + (1 - lam) * x2[src2], 1: x1[src1], 2: x2[src2]
+  float lam;
+};
+
+__global__ __launch_bounds__(256) void mixup_kernel(const float* __restrict__ x1, const float* __restrict__ x2,
+                                                    const MixJob* __restrict__ jobs, long clip4, float* __restrict__ out) {
+  const MixJob j = jobs[blockIdx.y];
+  const float4* a = reinterpret_cast<const float4*>(x1) + (long)j.src1 * clip4;
+  const float4* b = reinterpret_cast<const float4*>(x2) + (long)j.src2 * clip4;
+  float4* o = reinterpret_cast<float4*>(out) + (long)blockIdx.y * clip4;
+  const float l = j.lam, m = 1.f - j.lam;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < clip4; i += (long)gridDim.x * 256) {
+    float4 v;
+    if (j.mode == 1) v = a[i];
+    else if (j.mode == 2) v = b[i];
+    else {
+      const float4 p = a[i], q = b[i];
+      v.x = l * p.x + m * q.x; v.y = l * p.y + m * q.y; v.z = l * p.z + m * q.z; v.w = l * p.w + m * q.w;
+    }
+    o[i] = v;
+  }
+}
+
+}  // namespace sedt
+
+extern "C" int sedt_box_transform(const float* amp, int64_t raw_stride, const void* aug, const double* mean, const double* stdv,
+                                  int B, int frames, int F, int apply_log, int fill_mean, float fill_const, float* out, void* stream) {
+  using namespace sedt;
+  SEDT_REQUIRE(amp && aug && out, "box_transform: null pointer");
+  SEDT_REQUIRE((mean == nullptr) == (stdv == nullptr), "box_transform: mean and std go together");
+  SEDT_REQUIRE(B >= 0 && frames >= 1 && F >= 1 && raw_stride >= 1, "box_transform: B=%d frames=%d F=%d", B, frames, F);
+  const size_t lds = ((size_t)frames * F + 16) * sizeof(float);
+  SEDT_REQUIRE(lds <= 160 * 1024, "box_transform: a clip of %d x %d f32 does not fit the 160 KB LDS", frames, F);
+  if (B == 0) return 0;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(box_transform_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(box_transform_kernel, dim3(B), dim3(1024), lds, reinterpret_cast<hipStream_t>(stream), amp, (long)raw_stride,
+                     reinterpret_cast<const ClipAug*>(aug), mean, stdv, frames, F, apply_log, fill_mean, fill_const, out);
+  return check_launch("box_transform");
+}
+
+extern "C" int sedt_mixup(const float* x1, const float* x2, const void* jobs, int n_out, int64_t clip_elems, float* out, void* stream) {
+  using namespace sedt;
+  SEDT_REQUIRE(x1 && x2 && jobs && out, "mixup: null pointer");
+  SEDT_REQUIRE(clip_elems % 4 == 0 && n_out >= 0, "mixup: clip size %ld must be a multiple of 4", (long)clip_elems);
+  if (n_out == 0) return 0;
+  const long c4 = clip_elems / 4;
+  const unsigned gx = (unsigned)std::min<long>((c4 + 255) / 256, 64);
+  hipLaunchKernelGGL(mixup_kernel, dim3(gx, n_out), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x1, x2,
+                     reinterpret_cast<const MixJob*>(jobs), c4, out);
+  return check_launch("mixup");
+}

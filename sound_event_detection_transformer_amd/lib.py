@@ -124,6 +124,8 @@ SIGNATURES = {
     'sedt_feature_loss': (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'sedt_scale_layers': (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i64, _vp]),
     'sedt_sum_f32': (_i, [_vp, _i, _vp, _vp]),
+    'sedt_box_transform': (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    'sedt_mixup': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),
     'sedt_postprocess': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     'sedt_pseudo_labels': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'sedt_hungarian_batch': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -1,0 +1,162 @@
+"""GPU: the input side on the device - the fused feature-transform kernel, mixup and the prefetcher -
+against what the REFERENCE's own transform classes / mixup functions produced (fixture G13) and, for the librosa part
+(amplitude_to_db: third party, parity unpinned), against its restated published algorithm in oracle/transforms_oracle.py.
+Tolerance: 2e-6 relative + 2e-5 absolute on normalised features (f32 log / mean differ by an ulp); labels, ratios, masks exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import transforms_oracle as TO
+from oracle.criterion_oracle import synthetic_targets
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(a):
+    return [r[r >= 0] for r in a]
+
+
+def _params_from_golden(p, nraw, frames=496, F=64):
+    from sound_event_detection_transformer_amd.utilities.transforms import _AUG
+    r = np.zeros((), _AUG)
+    r['nframes_raw'] = nraw
+    if p[0]:
+        r['tm_t'], r['tm_t0'] = int(p[1] * frames), int(p[2] * frames)
+    if p[3]:
+        r['fm_on'], r['fm_f'], r['fm_f0'] = 1, int(p[4] * F), int(p[5] * F)
+    if p[6]:
+        r['fs_shift'] = int(p[7])
+    return r
+
+
+def test_g13_transform_kernel_matches_reference_classes(golden_dir):
+    from sound_event_detection_transformer_amd.utilities.transforms import DeviceBoxTransform
+    g = np.load(os.path.join(golden_dir, 'g13_transforms_mixup.npz'))
+    clips = list(g['in_db']) + [g['in_long']]                     # three 470-frame clips (padded) + one 520-frame clip (truncated)
+    tf = DeviceBoxTransform(496, g['scaler_mean'], g['scaler_std'], True, True, True, apply_log=False)
+    params = np.stack([_params_from_golden(g['params'][i], len(c)) for i, c in enumerate(clips)])
+    out = tf(clips, params=params)
+    assert out.shape == (4, 1, 496, 64) and out.dtype == torch.float32
+    np.testing.assert_allclose(out.cpu().numpy(), g['out'], rtol=2e-6, atol=2e-5)
+    # the host-side draws consume np.random exactly like the reference's TimeMask / FreqMask / FreqShift objects
+    tf.tm, tf.fm, tf.fs = (0.0, 0.1, 0.6), (0.03, 0.4, 0.6), (0.6, 4, 0, 2)          # the probabilities fixture G13 used
+    for i, c in enumerate(clips):
+        np.random.seed(1000 + i)
+        assert tf.draw(len(c)) == params[i]
+
+
+def test_full_pipeline_with_log_matches_oracle():
+    from sound_event_detection_transformer_amd.utilities.transforms import DeviceBoxTransform
+    rng = np.random.RandomState(3)
+    clips = [np.abs(rng.randn(n, 64)).astype(np.float32) * 10 ** rng.uniform(-3, 1) for n in (431, 496, 520, 300)]
+    clips[1][:40] = 0.0                                           # silence: exercises amin and the 80 dB floor
+    mean, std = rng.randn(64) * 3 - 30, rng.rand(64) * 5 + 8
+    tf = DeviceBoxTransform(496, mean, std, True, True, True)
+    np.random.seed(5)
+    params = np.stack([tf.draw(len(c)) for c in clips])
+    out = tf(clips, params=params).cpu().numpy()
+    for i, c in enumerate(clips):
+        p = params[i]
+        ref = TO.box_transform(c.astype(np.float32), 496, mean, std, (p['tm_t'] > 0, p['tm_t'] / 496 + 1e-9, p['tm_t0'] / 496 + 1e-9),
+                               (bool(p['fm_on']), p['fm_f'] / 64 + 1e-9, p['fm_f0'] / 64 + 1e-9), (p['fs_shift'] != 0, int(p['fs_shift'])))
+        np.testing.assert_allclose(out[i], ref, rtol=2e-5, atol=2e-4)
+    assert (params['tm_t'] > 0).any() and params['fm_on'].any() and (params['fs_shift'] != 0).any()
+
+
+def test_device_resident_input_and_no_augmentation():
+    from sound_event_detection_transformer_amd.utilities.transforms import DeviceBoxTransform
+    x = torch.rand(3, 496, 64, device='cuda') + 0.1
+    tf = DeviceBoxTransform(496, apply_log=True)
+    y = tf(x)
+    ref = np.stack([TO.amplitude_to_db(c.T).T for c in x.cpu().numpy()])[:, None]
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-5, atol=1e-4)
+
+
+def test_g13_mixup_matches_reference(golden_dir):
+    from sound_event_detection_transformer_amd.utilities import mixup as M
+    from sound_event_detection_transformer_amd.utilities.utils import NestedTensor
+    g = np.load(os.path.join(golden_dir, 'g13_transforms_mixup.npz'))
+    gen = torch.Generator().manual_seed(132)
+    B = 6
+    x = torch.randn(B, 1, 32, 8, generator=gen)
+    tg = synthetic_targets(B, 133, 10)
+    for t in tg[3:]:
+        t['boxes'] = torch.zeros(0, 2)
+    tg = [{k: v.cuda() for k, v in t.items()} for t in tg]
+    np.random.seed(77)
+    nt = NestedTensor(x.cuda(), torch.zeros(B, 32, 8, dtype=torch.bool, device='cuda'))
+    xm, ym, ms, mw = M.mixup_data(nt, [dict(t) for t in tg], slice(3), slice(3, 6), mix_up_ratio=0.67, alpha=1)
+    assert xm is nt
+    np.testing.assert_allclose(xm.tensors.cpu().numpy(), g['mix_x'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal([ms.stop, mw.start, mw.stop], g['mix_masks'])
+    np.testing.assert_array_equal([len(t['labels']) for t in ym], g['mix_nlabels'])
+    np.testing.assert_array_equal([len(t['boxes']) for t in ym], g['mix_nboxes'])
+    for b, t in enumerate(ym):
+        np.testing.assert_array_equal(t['labels'].cpu().numpy(), _rows(g['mix_labels'])[b])
+        r = t['ratio'].cpu().numpy() if 'ratio' in t else np.zeros(0, np.float32)
+        np.testing.assert_allclose(r, _rows(g['mix_ratio'])[b], rtol=1e-6)
+    x1, x2 = torch.randn(4, 1, 32, 8, generator=gen), torch.randn(4, 1, 32, 8, generator=gen)
+    y1 = [{k: v.cuda() for k, v in t.items()} for t in synthetic_targets(4, 134, 10)]
+    y2 = [{k: v.cuda() for k, v in t.items()} for t in synthetic_targets(4, 135, 10)]
+    np.random.seed(78)
+    xo, yo = M.mixup_label_unlabel(x1.cuda(), x2.cuda(), y1, y2, alpha=1)
+    np.testing.assert_allclose(xo.cpu().numpy(), g['lu_x'], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal([len(t['labels']) for t in yo], g['lu_nlabels'])
+    for b, t in enumerate(yo):
+        np.testing.assert_array_equal(t['labels'].cpu().numpy(), _rows(g['lu_labels'])[b])
+        r = t['ratio'].cpu().numpy() if 'ratio' in t else np.zeros(0, np.float32)
+        np.testing.assert_allclose(r, _rows(g['lu_ratio'])[b], rtol=1e-6)
+
+
+def test_mixed_batch_through_the_criterion():
+    """a mixed batch (ratios, changed strong/weak split) goes straight into the reference-API criterion on the device"""
+    from sound_event_detection_transformer_amd.utilities import mixup as M
+    from sound_event_detection_transformer_amd.sedt import build_model, default_args
+    crit = build_model(default_args())[1].cuda()
+    gen = torch.Generator().manual_seed(7)
+    B, Q = 8, 10
+    x = torch.randn(B, 1, 32, 8, generator=gen).cuda()
+    tg = synthetic_targets(B, 9, 10)
+    for t in tg[4:]:
+        t['boxes'] = torch.zeros(0, 2)
+    tg = [{k: v.cuda() for k, v in t.items()} for t in tg]
+    np.random.seed(3)
+    xm, ym, ms, mw = M.mixup_data(x, tg, slice(4), slice(4, 8), mix_up_ratio=0.5, alpha=1)
+    n = xm.shape[0]
+    la = torch.randn(3, n, Q, 11, generator=gen).cuda()
+    ba = (torch.rand(3, n, Q, 2, generator=gen) * 0.8 + 0.1).cuda()
+    o = {'pred_logits': la[-1], 'pred_boxes': ba[-1], 'at': torch.rand(n, 10, generator=gen).cuda(),
+         'aux_outputs': [{'pred_logits': a, 'pred_boxes': b} for a, b in zip(la[:-1], ba[:-1])], '_stacked': (la, ba)}
+    ld, _ = crit(o, ym, mw, ms)
+    assert all(torch.isfinite(v).all() for v in ld.values()) and any('ratio' in t for t in ym)
+
+
+def test_prefetcher_overlaps_and_preserves_batches():
+    from sound_event_detection_transformer_amd.utilities.prefetch import DevicePrefetcher
+    from sound_event_detection_transformer_amd.utilities.transforms import DeviceBoxTransform
+    rng = np.random.RandomState(0)
+    tf = DeviceBoxTransform(496, rng.randn(64) - 30, rng.rand(64) + 8)
+    batches = []
+    for i in range(4):
+        clips = [np.abs(rng.randn(rng.randint(400, 520), 64)).astype(np.float32) for _ in range(3)]
+        tg = synthetic_targets(3, 20 + i, 10)
+        batches.append((clips, tg))
+    want = [tf(c).cpu() for c, _ in batches]
+    pf = DevicePrefetcher(batches, transform=tf)
+    got = []
+    for inp, tgt in pf:
+        assert inp.is_cuda and tgt[0]['labels'].is_cuda
+        got.append((inp.cpu(), tgt))
+    assert len(got) == 4
+    for (a, tg), b, (_, tref) in zip(got, want, batches):
+        assert torch.equal(a, b)
+        assert all(torch.equal(x['labels'].cpu(), y['labels']) for x, y in zip(tg, tref))
+    assert pf.next() == (None, None)
+    # tensors / NestedTensor batches (the reference's usage) go through the pinned path too
+    from sound_event_detection_transformer_amd.utilities.utils import NestedTensor
+    nb = [(NestedTensor(torch.randn(2, 1, 496, 64), torch.zeros(2, 496, 64, dtype=torch.bool)), synthetic_targets(2, 5, 10)) for _ in range(3)]
+    pf = DevicePrefetcher(nb)
+    for (inp, tgt), (ref, _) in zip(pf, nb):
+        assert torch.equal(inp.tensors.cpu(), ref.tensors) and inp.mask.is_cuda
