@@ -119,11 +119,16 @@ def test_mixed_batch_through_the_criterion():
     B, Q = 8, 10
     x = torch.randn(B, 1, 32, 8, generator=gen).cuda()
     tg = synthetic_targets(B, 9, 10)
+    for i, t in enumerate(tg):                                   # one event per clip, all classes different: pairs are mixable
+        t['labels'], t['boxes'] = torch.tensor([i]), t['boxes'][:1]
     for t in tg[4:]:
         t['boxes'] = torch.zeros(0, 2)
     tg = [{k: v.cuda() for k, v in t.items()} for t in tg]
-    np.random.seed(3)
-    xm, ym, ms, mw = M.mixup_data(x, tg, slice(4), slice(4, 8), mix_up_ratio=0.5, alpha=1)
+    for seed in range(20):                                       # a draw in which at least one pair really gets mixed
+        np.random.seed(seed)
+        xm, ym, ms, mw = M.mixup_data(x, [dict(t) for t in tg], slice(4), slice(4, 8), mix_up_ratio=0.5, alpha=1)
+        if any('ratio' in t for t in ym):
+            break
     n = xm.shape[0]
     la = torch.randn(3, n, Q, 11, generator=gen).cuda()
     ba = (torch.rand(3, n, Q, 2, generator=gen) * 0.8 + 0.1).cuda()
