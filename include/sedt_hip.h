@@ -425,6 +425,20 @@ int sedt_pseudo_labels(const float* logits, const float* boxes, const float* at,
                        int Q, int C, int del_overlap, int64_t* lab_cat, float* box_cat, int32_t* lab_off, int32_t* box_off,
                        int32_t* counter, int cap, void* stream);
 
+/* ------------------------------------------------------------------ fused head of the pre-norm encoder layer
+ * (sedt/transformer.py:196-199): xn = LayerNorm1(x); q = k = (xn + pos) Wqk^T + b; v = xn Wv^T + b;
+ * ctx = dropout(softmax(q k^T / sqrt(32) + key padding)) v - LayerNorm, the three projections and the attention core in ONE
+ * launch (workgroup = clip x pair of heads; the normalised slab stays in registers as MFMA A fragments, weights stream from
+ * L2 as B fragments, Q/K/V go straight into the LDS images of the attention core).  x, pos, ctx [B*S][256] bf16 contiguous,
+ * w_in [768][256] bf16 (packed in_proj_weight), b_in [768] f32, lse [B][8][S].  Training by-products (all or none): xn, xnp
+ * [B*S][256] bf16, mean / rstd [B*S] f32, qk [B*S][512] bf16 (q | k), v [B*S][256] bf16 - what sedt_layernorm_bwd,
+ * sedt_attention_bwd and the weight-gradient GEMMs read.  Dropout hash identical to sedt_attention_fwd (same seed -> same
+ * mask in sedt_attention_bwd).  Envelope: bf16, D = 256, H = 8, S <= 128. */
+int sedt_encoder_attn_fwd(const void* x, const void* pos, const float* gamma, const float* beta, const void* w_in,
+                          const float* b_in, void* ctx, float* lse, void* xn, void* xnp, float* mean, float* rstd, void* qk,
+                          void* v, const uint8_t* kpm, int B, int S, int D, int H, float drop_p, uint32_t seed,
+                          const uint32_t* seed_ptr, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ input side on the device (utilities/BoxTransforms.py,
  * utilities/mixup.py)
  * sedt_box_transform: the per-clip feature transforms composed as get_transforms does (BoxTransforms.py:454-490):

@@ -14,6 +14,7 @@
 //
 // Probabilities never touch HBM: backward recomputes them from the saved log-sum-exp; the dropout mask is the counter
 // hash of ((b*H+h)*Lq + q)*Lk + k, identical in forward and backward (and to the f32 reference kernels).
+#include <stdlib.h>
 #include "common.h"
 
 namespace sedt {
@@ -169,6 +170,213 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __r
       const int qr = q0 + crow(r, hf);
       if (qr < Lq) o[((long)b * Lq + qr) * ldo + h * AD + (lane & 31)] = (bf16_t)oacc[r];
     }
+  }
+}
+
+// ============================================================================================ fused encoder block head
+// Pre-norm encoder self-attention up to the context (reference sedt/transformer.py:196-199):
+//     xn = LayerNorm1(x);  q = k = (xn + pos) Wqk^T + b;  v = xn Wv^T + b;  ctx = softmax(q k^T / sqrt(32) + key mask) dropout . v
+// ONE launch instead of LayerNorm, the grouped Q|K / V projection GEMMs and the attention core: a workgroup = (clip, pair of
+// heads), 8 waves = 4 slabs of 32 tokens x 2 heads.  A wave keeps its 32 x 256 slab of x in registers IN MFMA A-FRAGMENT
+// LAYOUT (lane = token row, 16 chunks of 8 channels: 64 VGPRs), normalises it there (row statistics: in-lane sums + one
+// cross-half shuffle), streams the 3 x 32 weight rows of its head from L2 as B fragments (16 bytes per lane per k-step) and
+// accumulates the Q, K, V tiles (3 x 16 MFMAs).  The tiles go to the [token][32] bf16 LDS images of the attention core
+// (the same code as attn_fwd_mfma_kernel from there on), so Q, K, V and the normalised activations never travel through HBM
+// in a no-grad forward.  TRAIN additionally writes what the (unfused) backward kernels read: xn, xn + pos, the LayerNorm row
+// statistics, q | k and v (coalesced 16-byte copies out of the LDS images).
+// Envelope: d_model 256, 8 heads of 32, S <= 128 tokens, bf16.
+constexpr int EF_D = 256, EF_S = 128, EF_IMG = EF_S * AROW;
+
+template <bool TRAIN>
+__global__ __launch_bounds__(512) void enc_attn_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ pos,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const bf16_t* __restrict__ w_in, const float* __restrict__ b_in,
+                                                             bf16_t* __restrict__ ctx, float* __restrict__ lse,
+                                                             bf16_t* __restrict__ xn_out, bf16_t* __restrict__ xnp_out,
+                                                             float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                             bf16_t* __restrict__ qk_out, bf16_t* __restrict__ v_out,
+                                                             const uint8_t* __restrict__ kpm, int S, float scale, uint32_t thresh,
+                                                             float inv_keep, uint32_t seed, const uint32_t* seed_ptr, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Kimg = smem;                         // [2 heads][128][32] bf16
+  unsigned char* Vimg = Kimg + 2 * EF_IMG;
+  unsigned char* Qimg = Vimg + 2 * EF_IMG;
+  float* Kb = reinterpret_cast<float*>(Qimg + 2 * EF_IMG);     // [128] additive key bias
+  float* Gs = Kb + EF_S;                              // gamma [256]
+  float* Bs = Gs + EF_D;                              // beta  [256]
+  const int b = blockIdx.x >> 2, hp = blockIdx.x & 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = wave >> 2, slab = wave & 3, head = hp * 2 + hh, hf = lane >> 5;
+  for (int i = tid; i < EF_D; i += 512) { Gs[i] = gamma[i]; Bs[i] = beta[i]; }
+  stage_key_bias(Kb, kpm ? kpm + (long)b * S : nullptr, S, EF_S, tid, 512);
+  // ---- this lane's half row of x: token `row`, channels 16 j + 8 hf + [0, 8) for j = 0..15
+  const int row = slab * 32 + (lane & 31);
+  const bool live = row < S;
+  const long grow = (long)b * S + row;
+  // row statistics in one pass over the slab (shifted sums: no cancellation when |mean| >> std); the slab is re-read from
+  // L1/L2 in the projection loop instead of being held in 64 registers (the kernel would spill)
+  const bf16_t* xrow = x + grow * EF_D + 8 * hf;
+  float shift = live ? (float)x[grow * EF_D] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (live) v = *reinterpret_cast<const bf16x8*>(xrow + 16 * j);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = (float)v[e] - shift; s1 += d; s2 += d * d; }
+  }
+  s1 += __shfl_xor(s1, 32, 64);
+  s2 += __shfl_xor(s2, 32, 64);
+  const float dm = s1 * (1.f / EF_D);
+  const float mu = live ? shift + dm : 0.f;
+  const float rs = rsqrtf(fmaxf(s2 * (1.f / EF_D) - dm * dm, 0.f) + 1e-5f);
+  const bool writer = TRAIN && hp == 0 && hh == 0;      // one wave per slab of the clip writes the shared by-products
+  if (writer && live && hf == 0) { mean_out[grow] = mu; rstd_out[grow] = rs; }
+  __syncthreads();                                      // gamma / beta / key bias staged
+  // ---- projections: Q, K from xn + pos, V from xn; weight rows n = head*32 + (lane & 31) of the q / k / v blocks
+  f32x16 aq, ak, av;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aq[r] = 0.f; ak[r] = 0.f; av[r] = 0.f; }
+  const bf16_t* wq = w_in + (long)(head * AD + (lane & 31)) * EF_D + 8 * hf;
+  const bf16_t* wk = wq + (long)EF_D * EF_D;
+  const bf16_t* wv = wk + (long)EF_D * EF_D;
+#pragma unroll
+  for (int j = 0; j < ((dbg & 1) ? 0 : 16); ++j) {
+    const int c0 = 16 * j + 8 * hf;
+    const bf16x8 bq = *reinterpret_cast<const bf16x8*>(wq + 16 * j);
+    const bf16x8 bk = *reinterpret_cast<const bf16x8*>(wk + 16 * j);
+    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(wv + 16 * j);
+    bf16x8 pz = {0, 0, 0, 0, 0, 0, 0, 0}, xv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (live) {
+      pz = *reinterpret_cast<const bf16x8*>(pos + grow * EF_D + c0);
+      xv = *reinterpret_cast<const bf16x8*>(xrow + 16 * j);
+    }
+    const float4 g0 = *reinterpret_cast<const float4*>(Gs + c0), g1 = *reinterpret_cast<const float4*>(Gs + c0 + 4);
+    const float4 e0 = *reinterpret_cast<const float4*>(Bs + c0), e1 = *reinterpret_cast<const float4*>(Bs + c0 + 4);
+    const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    const float ev[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+    bf16x8 an, ap;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float o = ((float)xv[e] - mu) * rs * gv[e] + ev[e];
+      an[e] = (bf16_t)o;
+      ap[e] = (bf16_t)(o + (float)pz[e]);
+    }
+    if (writer && live) {
+      *reinterpret_cast<bf16x8*>(xn_out + grow * EF_D + c0) = an;
+      *reinterpret_cast<bf16x8*>(xnp_out + grow * EF_D + c0) = ap;
+    }
+    aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bq, aq, 0, 0, 0);
+    ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bk, ak, 0, 0, 0);
+    av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(an, bv, av, 0, 0, 0);
+    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // bound how far the weight / pos loads are hoisted (registers)
+  }
+  // ---- bias, bf16, into the LDS images of this head: accumulator register r of half hf <-> token slab*32 + crow(r, hf)
+  {
+    const float biq = b_in[head * AD + (lane & 31)], bik = b_in[EF_D + head * AD + (lane & 31)],
+                biv = b_in[2 * EF_D + head * AD + (lane & 31)];
+    bf16_t* Qh = reinterpret_cast<bf16_t*>(Qimg + hh * EF_IMG);
+    bf16_t* Kh = reinterpret_cast<bf16_t*>(Kimg + hh * EF_IMG);
+    bf16_t* Vh = reinterpret_cast<bf16_t*>(Vimg + hh * EF_IMG);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = slab * 32 + crow(r, hf);
+      Qh[t * AD + (lane & 31)] = (bf16_t)(aq[r] + biq);
+      Kh[t * AD + (lane & 31)] = (bf16_t)(ak[r] + bik);
+      Vh[t * AD + (lane & 31)] = (bf16_t)(av[r] + biv);
+    }
+  }
+  __syncthreads();
+  if (TRAIN) {
+    // q | k -> qk_out [B*S][512], v -> v_out [B*S][256]: one 16-byte chunk per thread and image (128 rows x 4 chunks)
+    const int r = tid >> 2, c = tid & 3;
+    if (r < S) {
+      const long g = (long)b * S + r;
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int hd = hp * 2 + h2;
+        *reinterpret_cast<uint4*>(qk_out + g * (2 * EF_D) + hd * AD + c * 8) = *reinterpret_cast<const uint4*>(Qimg + h2 * EF_IMG + r * AROW + c * 16);
+        *reinterpret_cast<uint4*>(qk_out + g * (2 * EF_D) + EF_D + hd * AD + c * 8) = *reinterpret_cast<const uint4*>(Kimg + h2 * EF_IMG + r * AROW + c * 16);
+        *reinterpret_cast<uint4*>(v_out + g * EF_D + hd * AD + c * 8) = *reinterpret_cast<const uint4*>(Vimg + h2 * EF_IMG + r * AROW + c * 16);
+      }
+    }
+  }
+  // ---- attention core of (head, query slab): identical to attn_fwd_mfma_kernel<4, false>
+  const unsigned char* Ki = Kimg + hh * EF_IMG;
+  const unsigned char* Vi = Vimg + hh * EF_IMG;
+  const unsigned char* Qi = Qimg + hh * EF_IMG;
+  const uint32_t sd = eff_seed(seed, seed_ptr);
+  const int q0 = slab * 32, qi = q0 + (lane & 31), bh = b * 8 + head;
+  if (q0 >= S || (dbg & 2)) return;
+  const bf16x8 qf0 = frag_rows(Qi, q0, 0, lane), qf1 = frag_rows(Qi, q0, 1, lane);
+  auto score_tile = [&](int kt, f32x16& st) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ki, kt * 32, 0, lane), qf0, st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rows(Ki, kt * 32, 1, lane), qf1, st, 0, 0, 0);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float4 kb = *reinterpret_cast<const float4*>(Kb + kt * 32 + 8 * g4 + 4 * hf);
+      st[4 * g4 + 0] = st[4 * g4 + 0] * scale + kb.x;
+      st[4 * g4 + 1] = st[4 * g4 + 1] * scale + kb.y;
+      st[4 * g4 + 2] = st[4 * g4 + 2] * scale + kb.z;
+      st[4 * g4 + 3] = st[4 * g4 + 3] * scale + kb.w;
+    }
+  };
+  float m = -INFINITY, ssum = 0.f;
+#pragma unroll 1
+  for (int kt = 0; kt < 4; ++kt) {
+    f32x16 st;
+    score_tile(kt, st);
+    float tm = st[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, st[r]);
+    const float mn = fmaxf(m, tm);
+    if (mn > -INFINITY) {
+      float ts = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ts += __expf(st[r] - mn);
+      ssum = ssum * __expf(m - mn) + ts;
+      m = mn;
+    }
+  }
+  {
+    const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(ssum, 32, 64);
+    const float M = fmaxf(m, m2);
+    ssum = (m > -INFINITY ? ssum * __expf(m - M) : 0.f) + (m2 > -INFINITY ? s2 * __expf(m2 - M) : 0.f);
+    m = M;
+  }
+  const float inv = 1.f / ssum;
+  if (hf == 0 && qi < S) lse[((long)b * 8 + head) * S + qi] = m + __logf(ssum);
+  const uint64_t rowbase = ((uint64_t)bh * S + qi) * S;
+  const uint32_t d_hi = (uint32_t)(rowbase >> 33), d_inner = drop_inner(sd, d_hi);
+  f32x16 oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+#pragma unroll 1
+  for (int kt = 0; kt < 4; ++kt) {
+    f32x16 st;
+    score_tile(kt, st);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float pv[8];
+#pragma unroll
+      for (int s4 = 0; s4 < 2; ++s4) {
+        uint32_t keep = 0xfu;
+        if (thresh) keep = drop_keep4(d_inner, d_hi, sd, rowbase + (kt * 32 + crow(8 * u + 4 * s4, hf)), thresh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = __expf(st[8 * u + 4 * s4 + e] - m) * inv;
+          pv[4 * s4 + e] = (keep >> e & 1u) ? (thresh ? p * inv_keep : p) : 0.f;
+        }
+      }
+      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(pv), frag_cols_tr(Vi, kt * 32 + 16 * u, lane), oacc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int qr = q0 + crow(r, hf);
+    if (qr < S) ctx[((long)b * S + qr) * EF_D + head * AD + (lane & 31)] = (bf16_t)oacc[r];
   }
 }
 
@@ -380,6 +588,32 @@ int attn_fwd_mfma_try(const void* q, int64_t ldq, const void* k, int64_t ldk, co
   return check_launch("attention_fwd_mfma");
 }
 
+int enc_attn_fused_launch(const void* x, const void* pos, const float* gamma, const float* beta, const void* w_in, const float* b_in,
+                          void* ctx, float* lse, void* xn, void* xnp, float* mean, float* rstd, void* qk, void* v, const uint8_t* kpm,
+                          int B, int S, float drop_p, uint32_t seed, const uint32_t* seed_ptr, hipStream_t st) {
+  const size_t lds = (size_t)6 * EF_IMG + (size_t)(EF_S + 2 * EF_D) * sizeof(float);
+  const float scale = 1.f / sqrtf((float)AD);
+  const uint32_t th = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+  const float ik = 1.f / (1.f - drop_p);
+  const bool train = xn != nullptr;
+  static const int dbg = getenv("SEDT_ENC_DBG") ? atoi(getenv("SEDT_ENC_DBG")) : 0;      // developer timing switch (1: no projections, 2: no attention)
+  dim3 grid(B * 4), block(512);
+  if (train) {
+    static bool done = false;
+    if (set_attr_once(enc_attn_fused_kernel<true>, done, 64 * 1024, "enc_attn_fused")) return 1;
+    hipLaunchKernelGGL(enc_attn_fused_kernel<true>, grid, block, lds, st, (const bf16_t*)x, (const bf16_t*)pos, gamma, beta,
+                       (const bf16_t*)w_in, b_in, (bf16_t*)ctx, lse, (bf16_t*)xn, (bf16_t*)xnp, mean, rstd, (bf16_t*)qk, (bf16_t*)v, kpm,
+                       S, scale, th, ik, seed, seed_ptr, dbg);
+  } else {
+    static bool done = false;
+    if (set_attr_once(enc_attn_fused_kernel<false>, done, 64 * 1024, "enc_attn_fused")) return 1;
+    hipLaunchKernelGGL(enc_attn_fused_kernel<false>, grid, block, lds, st, (const bf16_t*)x, (const bf16_t*)pos, gamma, beta,
+                       (const bf16_t*)w_in, b_in, (bf16_t*)ctx, lse, (bf16_t*)nullptr, (bf16_t*)nullptr, (float*)nullptr, (float*)nullptr,
+                       (bf16_t*)nullptr, (bf16_t*)nullptr, kpm, S, scale, th, ik, seed, seed_ptr, dbg);
+  }
+  return check_launch("enc_attn_fused");
+}
+
 template <int NTQ>
 static int launch_bwd_q(int ntk, dim3 grid, dim3 block, size_t lds, hipStream_t st, const void* q, int64_t ldq, const void* k,
                         int64_t ldk, const void* v, int64_t ldv, const void* o, int64_t ldo, const void* dout, int64_t lddo,
@@ -435,3 +669,22 @@ int attn_bwd_mfma_try(const void* q, int64_t ldq, const void* k, int64_t ldk, co
 }
 
 }  // namespace sedt
+
+// LayerNorm1 + (Q | K | V) projections + attention core of a pre-norm encoder layer in one launch (bf16, d_model 256, 8 heads,
+// S <= 128).  xn .. v may be null together (no-grad forward: nothing but ctx / lse is written).
+extern "C" int sedt_encoder_attn_fwd(const void* x, const void* pos, const float* gamma, const float* beta, const void* w_in,
+                                     const float* b_in, void* ctx, float* lse, void* xn, void* xnp, float* mean, float* rstd,
+                                     void* qk, void* v, const uint8_t* kpm, int B, int S, int D, int H, float drop_p, uint32_t seed,
+                                     const uint32_t* seed_ptr, int dtype, void* stream) {
+  using namespace sedt;
+  SEDT_REQUIRE(x && pos && gamma && beta && w_in && b_in && ctx && lse, "encoder_attn_fwd: null pointer");
+  SEDT_REQUIRE(dtype == SEDT_BF16 && D == EF_D && H == 8 && S >= 1 && S <= EF_S && B >= 1,
+               "encoder_attn_fwd: envelope is bf16, d_model 256, 8 heads, S <= 128 (got dtype %d D %d H %d S %d)", dtype, D, H, S);
+  const bool any = xn || xnp || mean || rstd || qk || v, all = xn && xnp && mean && rstd && qk && v;
+  SEDT_REQUIRE(any == all, "encoder_attn_fwd: the training by-products (xn, xnp, mean, rstd, qk, v) go together");
+  SEDT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "encoder_attn_fwd: drop_p out of range");
+  SEDT_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(w_in) |
+                 reinterpret_cast<uintptr_t>(ctx)) & 15) == 0, "encoder_attn_fwd: 16-byte aligned tensors required");
+  return enc_attn_fused_launch(x, pos, gamma, beta, w_in, b_in, ctx, lse, xn, xnp, mean, rstd, qk, v, kpm, B, S, drop_p, seed, seed_ptr,
+                               reinterpret_cast<hipStream_t>(stream));
+}

@@ -278,9 +278,25 @@ class EncoderLayerFn(Function):
         pos = _as(pos, dt)
         sv = {}
         tr = any(ctx.needs_input_grad)
-        if cfg['pre_norm']:
+        if cfg['pre_norm'] and ops.FUSED_ENC and ops.encoder_attn_ok(dt, x.shape[1], H, S, amask) and x.is_contiguous() and pos.is_contiguous():
+            # LayerNorm1 + Q|K|V projections + attention core in ONE launch (csrc/attn_mfma.hip); the by-products the unfused
+            # backward kernels read are written only when a backward will follow
+            wf, wb_in = _prep_linear(dt, w_in, tr)
+            wf_o, wb_o = _prep_linear(dt, w_o, tr)
+            sp = runtime.seed_ptr(x.device) if p > 0 else None
+            ctxv, lse, by = ops.encoder_attn_fwd(dt, x, pos, g1, be1, wf, b_in, B, S, H, kpm, p, seeds[0], sp, train=tr)
+            x1 = ops.linear(dt, ctxv, wf_o, bias=b_o, drop_p=p, seed=seeds[1], seed_ptr=sp, res=x, ldr=x.stride(0))
+            if tr:
+                xn, xnp, m1, r1, qk, v = by
+                E = x.shape[1]
+                sv['mha'] = dict(wb_in=wb_in, wb_o=wb_o, q_in=xnp, k_in=xnp, v_in=xn, same_qk=True, qk=qk, q=qk[:, :E], k=qk[:, E:], v=v,
+                                 ctxv=ctxv, lse=lse, dims=(B, H, S, S), kpm=kpm, amask=None, p=p, seeds=seeds[0:2])
+            else:
+                m1 = r1 = None
+        elif cfg['pre_norm']:
             xn, xnp, m1, r1 = ops.layernorm_fwd(dt, x, g1, be1, add_t=pos)
             x1, sv['mha'] = _mha_fwd(dt, xnp, xnp, xn, True, w_in, b_in, w_o, b_o, x, B, H, S, S, kpm, amask, p, seeds[0:2], tr)
+        if cfg['pre_norm']:
             x1n, _, m2, r2 = ops.layernorm_fwd(dt, x1, g2, be2)
             x2, sv['ffn'] = _ffn_fwd(dt, x1n, w1, b1, w2, b2, x1, p, seeds[2:4], tr)
             sv.update(x=x, x1=x1, m1=m1, r1=r1, m2=m2, r2=r2)

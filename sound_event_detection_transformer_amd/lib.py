@@ -99,6 +99,8 @@ SIGNATURES = {
                                 _vp, _i, _vp]),
     'sedt_attention_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp,
                                 _i64, _vp, _i64, _i, _i, _i, _i, _f, _u32, _vp, _i, _vp]),
+    'sedt_encoder_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u32,
+                               _vp, _i, _vp]),
     'sedt_posenc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'sedt_mask_resize': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'sedt_bn_fold': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

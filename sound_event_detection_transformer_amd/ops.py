@@ -507,6 +507,40 @@ def attention_bwd(dtype, q, k, v, o, do, lse, B, H, Lq, Lk, dq, dk, dv, kpm=None
     return dq, dk, dv
 
 
+# The fused encoder head is correct (tests/test_ops_gpu.py) but, as measured on the MI355X, not yet faster
+# than the three launches it replaces: its projection phase loads fragment-shaped operands (32 rows x 32 B per wave
+# instruction) straight from L2 and is bound by the texture-address path (20 of its 38 us).  Opt in with SEDT_FUSED_ENC=1.
+FUSED_ENC = os.environ.get('SEDT_FUSED_ENC', '0') == '1'
+
+
+def encoder_attn_ok(dtype, D, H, S, amask):
+    """envelope of the fused LayerNorm + QKV + attention kernel (csrc/attn_mfma.hip: enc_attn_fused_kernel)"""
+    return dtype == BF16 and D == 256 and H == 8 and S <= 128 and amask is None
+
+
+def encoder_attn_fwd(dtype, x, pos, gamma, beta, w_in, b_in, B, S, H, kpm=None, drop_p=0.0, seed=0, seed_ptr=None, train=True):
+    """pre-norm encoder self-attention up to the context in ONE launch.  x, pos [B*S, 256] bf16 contiguous; w_in [768, 256]
+    bf16 (packed in_proj_weight); returns (ctx, lse, saved) with saved = (xn, xnp, mean, rstd, qk, v) when train else None"""
+    _dev_check(x, pos, w_in)
+    M, D = x.shape
+    assert x.is_contiguous() and pos.is_contiguous() and w_in.is_contiguous() and pos.shape == x.shape and M == B * S
+    ctx = torch.empty((M, D), device=x.device, dtype=x.dtype)
+    lse = torch.empty((B, H, S), device=x.device, dtype=torch.float32)
+    saved = None
+    if train:
+        xn, xnp = torch.empty_like(x), torch.empty_like(x)
+        mean = torch.empty((M,), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        qk = torch.empty((M, 2 * D), device=x.device, dtype=x.dtype)
+        v = torch.empty((M, D), device=x.device, dtype=x.dtype)
+        saved = (xn, xnp, mean, rstd, qk, v)
+    s = saved if saved is not None else (None,) * 6
+    L.check(L.load().sedt_encoder_attn_fwd(_p(x), _p(pos), _p(gamma), _p(beta), _p(w_in), _p(b_in), _p(ctx), _p(lse), _p(s[0]), _p(s[1]),
+                                           _p(s[2]), _p(s[3]), _p(s[4]), _p(s[5]), _p(kpm), B, S, D, H, drop_p, seed & 0xffffffff,
+                                           _p(seed_ptr), dtype, L.stream_ptr()), 'encoder_attn_fwd')
+    return ctx, lse, saved
+
+
 def posenc(dtype, mask_u8, D):
     B, H, W = mask_u8.shape
     pos = torch.empty((B, H * W, D), device=mask_u8.device, dtype=TORCH_DTYPE[dtype])

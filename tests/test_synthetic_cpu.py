@@ -21,3 +21,21 @@ def test_synthetic_targets_identical():
             assert ta.keys() == tb.keys()
             for k in ta:
                 assert torch.equal(ta[k], tb[k])
+
+
+def test_transform_parameter_draws_follow_the_reference_order(golden_dir=None):
+    """host logic of the device feature transform (no GPU): np.random is consumed exactly like the reference's TimeMask /
+    FreqMask / FreqShift objects do (fixture G13 recorded what they drew after np.random.seed(1000 + i))"""
+    import os
+    import numpy as np
+    from conftest import GOLDEN
+    from sound_event_detection_transformer_amd.utilities.transforms import DeviceBoxTransform
+    g = np.load(os.path.join(GOLDEN, 'g13_transforms_mixup.npz'))
+    tf = DeviceBoxTransform(496, time_mask=True, freq_mask=True, freq_shift=True, device='cpu',
+                            tm=(0.0, 0.1, 0.6), fm=(0.03, 0.4, 0.6), fs=(0.6, 4, 0, 2))
+    for i, p in enumerate(g['params']):
+        np.random.seed(1000 + i)
+        r = tf.draw(470)
+        assert (r['tm_t'], r['tm_t0']) == ((int(p[1] * 496), int(p[2] * 496)) if p[0] else (0, 0))
+        assert (r['fm_on'], r['fm_f'], r['fm_f0']) == ((1, int(p[4] * 64), int(p[5] * 64)) if p[3] else (0, 0, 0))
+        assert r['fs_shift'] == (int(p[7]) if p[6] else 0)

@@ -1,0 +1,28 @@
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from sound_event_detection_transformer_amd import ops, lib as L
+dt = L.BF16
+B, S, E, H = 64, 128, 256, 8
+M = B * S
+g = torch.Generator().manual_seed(1)
+rnd = lambda *s, sc=1.0, d=torch.bfloat16: (torch.randn(*s, generator=g) * sc).to('cuda', d)
+x, pos = rnd(M, E), rnd(M, E, sc=0.5)
+gam, bet = rnd(E, d=torch.float32), rnd(E, d=torch.float32)
+w_in, b_in = rnd(3 * E, E, sc=0.06), rnd(3 * E, d=torch.float32)
+def timeit(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        for _ in range(reps): fn()
+    gr.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): gr.replay()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (5 * reps) * 1e3
+p = float(os.environ.get('P', '0.1'))
+print('dbg', os.environ.get('SEDT_ENC_DBG'), 'p', p, 'fused nograd us', round(timeit(lambda: ops.encoder_attn_fwd(dt, x, pos, gam, bet, w_in, b_in, B, S, H, None, p, 7, None, train=False)), 2),
+      'train us', round(timeit(lambda: ops.encoder_attn_fwd(dt, x, pos, gam, bet, w_in, b_in, B, S, H, None, p, 7, None, train=True)), 2))
+q, k, v = rnd(M, E), rnd(M, E), rnd(M, E)
+print('attention_fwd us', round(timeit(lambda: ops.attention_fwd(dt, q, k, v, B, H, S, S, None, None, p, 7, None)), 2))
