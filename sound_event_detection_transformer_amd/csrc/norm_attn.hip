@@ -24,26 +24,34 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      T* __restrict__ y, T* __restrict__ y2, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int rows) {
   constexpr int D = VPT * 64;
+  typedef VecT<T, VPT> V;                       // one 8/16-byte access per lane and tensor (scalar bf16 accesses halve the rate)
+  typedef VecT<float, VPT> VF;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * 4 + wave;
   if (row >= rows) return;
   const long base = (long)row * D + lane * VPT;
+  const V vx = *reinterpret_cast<const V*>(x + base);
+  V va;
+  if (y2) va = *reinterpret_cast<const V*>(add + base);
+  const VF vg = *reinterpret_cast<const VF*>(gamma + lane * VPT), vb = *reinterpret_cast<const VF*>(beta + lane * VPT);
   float v[VPT];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < VPT; ++i) { v[i] = (float)x[base + i]; s += v[i]; }
+  for (int i = 0; i < VPT; ++i) { v[i] = (float)vx.v[i]; s += v[i]; }
   const float mu = wave_sum(s) * (1.f / D);
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) { float d = v[i] - mu; q += d * d; }
   const float rs = rsqrtf(wave_sum(q) * (1.f / D) + 1e-5f);
+  V vy, vy2;
 #pragma unroll
   for (int i = 0; i < VPT; ++i) {
-    const int c = lane * VPT + i;
-    float o = (v[i] - mu) * rs * gamma[c] + beta[c];
-    y[base + i] = (T)o;
-    if (y2) y2[base + i] = (T)(o + (float)add[base + i]);
+    float o = (v[i] - mu) * rs * vg.v[i] + vb.v[i];
+    vy.v[i] = (T)o;
+    if (y2) vy2.v[i] = (T)(o + (float)va.v[i]);
   }
+  *reinterpret_cast<V*>(y + base) = vy;
+  if (y2) *reinterpret_cast<V*>(y2 + base) = vy2;
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 

@@ -35,6 +35,18 @@ def allreduce_mean(flat, async_op=False):
 
 
 _step_streams = {}
+
+
+def train_stream(dev):
+    """THE stream training work of a device runs on - eager steps, the warm-up steps of a capture and the captures themselves.
+    A parameter's gradient accumulator (autograd's AccumulateGrad node) is tied to the stream of the forward that created it and
+    lives as long as any autograd graph referencing it; if a later backward runs on another stream, autograd executes the
+    accumulation of a second gradient (a parameter used by two forward passes, as in the mean-teacher step) on the OLD stream -
+    outside a capture in progress on the new one, i.e. with garbage at replay.  One stream for everything removes the case."""
+    key = str(dev)
+    if key not in _step_streams:
+        _step_streams[key] = torch.cuda.Stream(device=dev)
+    return _step_streams[key]
 # capture mode: only THIS thread's unsafe calls invalidate a capture.  With the default ("global") the RCCL watchdog thread of
 # an initialised process group - it polls events with hipEventQuery - sporadically kills a capture in progress.
 _CAPTURE = dict(capture_error_mode='thread_local')
@@ -53,10 +65,7 @@ def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None
         batch_input, (tuple, list)) else (batch_input[0] if len(batch_input) and torch.is_tensor(batch_input[0]) else None))
     dev = first.device if torch.is_tensor(first) else None
     if dev is not None and dev.type == 'cuda' and torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev):
-        key = str(dev)
-        if key not in _step_streams:
-            _step_streams[key] = torch.cuda.Stream(device=dev)
-        side, cur = _step_streams[key], torch.cuda.current_stream(dev)
+        side, cur = train_stream(dev), torch.cuda.current_stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             out = train_step(model, criterion, optimizer, batch_input, targets, mask_weak, mask_strong, max_norm, normalize,
@@ -229,7 +238,8 @@ class GraphedTrainStep(_GraphedBase):
         self.static_x = example_input.clone()
         self.static_patches = None if example_patches is None else example_patches.clone()
         snap = _snapshot(net, optimizer)
-        side = torch.cuda.Stream()
+        side = train_stream(dev)
+        self._capture = dict(stream=side, **_CAPTURE)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), optimizer.table_set(self._tabname):
             for _ in range(warmup):                          # eager steps: lazy inits (LDS attributes, optimizer state)
@@ -255,7 +265,7 @@ class GraphedTrainStep(_GraphedBase):
         with optimizer.table_set(self._tabname):
             if device_matching:
                 self.tables = self._make_tables(example_targets, max_targets)
-                with torch.cuda.graph(self.g_fwd, **_CAPTURE):
+                with torch.cuda.graph(self.g_fwd, **self._capture):
                     self.static_out = self._forward()
                     self.static_dense = criterion.prepare_device(self.static_out, self.tables, normalize=normalize,
                                                                  fine_tune=fine_tune, fl=fl, ft_rand=ft_rand)
@@ -265,23 +275,23 @@ class GraphedTrainStep(_GraphedBase):
                         self._backward_above_cut()
                 if self.cut_body is not None:
                     self.g_low = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.g_low, pool=self.g_fwd.pool(), **_CAPTURE):
+                    with torch.cuda.graph(self.g_low, pool=self.g_fwd.pool(), **self._capture):
                         self._backward_below_cut()
             else:
-                with torch.cuda.graph(self.g_fwd, **_CAPTURE):
+                with torch.cuda.graph(self.g_fwd, **self._capture):
                     self.static_out = self._forward()
                 dense, _ = criterion.prepare(self.static_out, example_targets, mask_weak, mask_strong, normalize)
                 self.meta = dense['_meta']
                 self.static_pack = dense['_pack'].clone()
                 self.static_dense = criterion.dense_views(self.static_pack, self.meta)
                 self.g_bwd = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), **_CAPTURE):
+                with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), **self._capture):
                     self._backward_and_step()
             if self.dp:
                 # data parallel: ONE RCCL all-reduce of the flat gradient buffer between the graphs, then the fused
                 # clip + AdamW reads the averaged gradients from the flat buffer
                 self.g_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_opt, pool=self.g_fwd.pool(), **_CAPTURE):
+                with torch.cuda.graph(self.g_opt, pool=self.g_fwd.pool(), **self._capture):
                     optimizer.step(max_norm=max_norm, from_flat=True)
         torch.cuda.synchronize()
 
@@ -446,10 +456,7 @@ def semi_train_step(model, ema, criterion, optimizer, batch_input_teacher, batch
         raise NotImplementedError('mixup inside the semi step: apply utilities.mixup.mixup_data / mixup_label_unlabel around it')
     dev = _tensors(batch_input_teacher).device
     if dev.type == 'cuda' and torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev):
-        key = str(dev)
-        if key not in _step_streams:
-            _step_streams[key] = torch.cuda.Stream(device=dev)
-        side, cur = _step_streams[key], torch.cuda.current_stream(dev)
+        side, cur = train_stream(dev), torch.cuda.current_stream(dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             out = semi_train_step(model, ema, criterion, optimizer, batch_input_teacher, batch_input_student, targets, mask_strong,
@@ -548,7 +555,8 @@ class GraphedSemiStep(_GraphedBase):
                                   with_ratio=any('ratio' in t for t in lab_t)).load(lab_t)
         self.tab_u = TargetTables(n_u, n_u, n_u, dev, max_targets=max(Q, 1))
         snap = _snapshot(model, optimizer, ema)
-        side = torch.cuda.Stream()
+        side = train_stream(dev)
+        self._capture = dict(stream=side, **_CAPTURE)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), optimizer.table_set(self._tabname):
             for _ in range(warmup):
@@ -569,11 +577,11 @@ class GraphedSemiStep(_GraphedBase):
         self.graph = torch.cuda.CUDAGraph()
         self.g_opt = None
         with optimizer.table_set(self._tabname):
-            with torch.cuda.graph(self.graph, **_CAPTURE):
+            with torch.cuda.graph(self.graph, **self._capture):
                 self._body(part='fwd_bwd' if self.dp else 'all')
             if self.dp:                                       # data parallel: RCCL all-reduce of the flat gradients in between
                 self.g_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.g_opt, pool=self.graph.pool(), **_CAPTURE):
+                with torch.cuda.graph(self.g_opt, pool=self.graph.pool(), **self._capture):
                     self._body(part='update')
         torch.cuda.synchronize()
 

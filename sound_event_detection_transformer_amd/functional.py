@@ -122,6 +122,43 @@ class LayerNormFn(Function):
         return dx, dg, db, None
 
 
+class StackViewFn(Function):
+    """the decoder layers write their outputs straight into consecutive row ranges of ONE buffer (DecoderLayerFn, cfg['out']);
+    this node hands that buffer to the shared LayerNorm as a single [n*R, D] tensor - the torch.cat without the copy.
+    Backward: the row ranges of the incoming gradient (views)."""
+
+    @staticmethod
+    def forward(ctx, buf, *outs):
+        R = outs[0].shape[0]
+        for i, o in enumerate(outs):
+            if o.data_ptr() != buf.data_ptr() + i * R * buf.shape[1] * buf.element_size() or o.shape != outs[0].shape:
+                raise RuntimeError('StackViewFn: the layer outputs are not the row ranges of the stacking buffer')
+        ctx.R, ctx.n = R, len(outs)
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        return (None,) + tuple(g[i * ctx.R:(i + 1) * ctx.R] for i in range(ctx.n))
+
+
+class BroadcastRowsFn(Function):
+    """out[b*Q + q] = table[q] in the compute dtype (the decoder's query position embedding for every clip); backward = the
+    column sums of the gradient seen as [B, Q*C] (one launch instead of an expand/reshape copy forward and a strided
+    reduction backward)"""
+
+    @staticmethod
+    def forward(ctx, table, zeros, B, dt):
+        ctx.dt, ctx.B, ctx.shape = dt, B, tuple(table.shape)
+        return ops.add(dt, zeros, _as(table.detach(), dt), table.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        Q, C = ctx.shape
+        g = _as(g, ctx.dt)
+        return ops.colsum(ctx.dt, g.view(ctx.B, Q * C)).view(Q, C), None, None, None
+
+
 class CastFn(Function):
     """x in the compute dtype; the gradient is cast back to x's dtype (one conversion however many consumers x has)"""
 
@@ -232,12 +269,12 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, b
     return g_q, g_k, g_v, d_win, d_bin, d_wo, d_bo
 
 
-def _ffn_fwd(dt, x_in, w1, b1, w2, b2, res, p, seeds, train=True):
+def _ffn_fwd(dt, x_in, w1, b1, w2, b2, res, p, seeds, train=True, out=None):
     sp = runtime.seed_ptr(x_in.device) if p > 0 else None
     wf1, wb1 = _prep_linear(dt, w1, train)
     wf2, wb2 = _prep_linear(dt, w2, train)
     h = ops.linear(dt, x_in, wf1, bias=b1, act=ACT_RELU, drop_p=p, seed=seeds[0], seed_ptr=sp)
-    out = ops.linear(dt, h, wf2, bias=b2, drop_p=p, seed=seeds[1], seed_ptr=sp, res=res, ldr=res.stride(0))
+    out = ops.linear(dt, h, wf2, out, bias=b2, drop_p=p, seed=seeds[1], seed_ptr=sp, res=res, ldr=res.stride(0))
     return out, dict(x_in=x_in, h=h, p=p, seeds=seeds, wb1=wb1, wb2=wb2)
 
 
@@ -360,7 +397,7 @@ class DecoderLayerFn(Function):
             t1n, t1np, m2, r2 = ops.layernorm_fwd(dt, t1, g2, be2, add_t=qpos)
             t2, sv['ca'] = _mha_fwd(dt, t1np, mem_pos, mem, False, cw_in, cb_in, cw_o, cb_o, t1, B, H, Q, S, kpm, None, p, seeds[2:4], tr)
             t2n, _, m3, r3 = ops.layernorm_fwd(dt, t2, g3, be3)
-            t3, sv['ffn'] = _ffn_fwd(dt, t2n, w1, b1, w2, b2, t2, p, seeds[4:6], tr)
+            t3, sv['ffn'] = _ffn_fwd(dt, t2n, w1, b1, w2, b2, t2, p, seeds[4:6], tr, out=cfg.get('out'))
             sv.update(tgt=tgt, t1=t1, t2=t2, m1=m1, r1=r1, m2=m2, r2=r2, m3=m3, r3=r3)
         else:
             tp = ops.add(dt, tgt, qpos)

@@ -443,12 +443,16 @@ def sigmoid_grad(g, s):
     return out
 
 
-def layernorm_fwd(dtype, x, gamma, beta, add_t=None):
+def layernorm_fwd(dtype, x, gamma, beta, add_t=None, out=None):
+    """out = (y, mean, rstd) preallocated (contiguous row ranges of larger buffers are fine)"""
     rows, D = x.shape
-    y = torch.empty_like(x)
     y2 = torch.empty_like(x) if add_t is not None else None
-    mean = torch.empty((rows,), device=x.device, dtype=torch.float32)
-    rstd = torch.empty_like(mean)
+    if out is not None:
+        y, mean, rstd = out
+    else:
+        y = torch.empty_like(x)
+        mean = torch.empty((rows,), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
     L.check(L.load().sedt_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(add_t), _p(y), _p(y2), _p(mean), _p(rstd), rows, D,
                                         dtype, L.stream_ptr()), 'layernorm_fwd')
     return y, y2, mean, rstd

@@ -127,9 +127,10 @@ class SEDT(nn.Module):
         out = {}
         hs, memory = self.transformer(self.input_proj(src), mask, self.query_embed.weight, pos[-1], enc_at_embed=None)
         if self.dec_at:
-            ev = hs[:, :, 1:, :]
-            outputs_class = self.class_embed(ev, out_f32=True)
-            outputs_coord = self.bbox_embed(ev, final_act=ACT_SIGMOID, out_f32=True)
+            # the heads run over ALL Q+1 queries and the (tiny, f32) outputs are sliced - slicing hs[:, :, 1:] first costs a
+            # strided copy of the activations forward and a scatter backward; query 0's event outputs are simply unused
+            outputs_class = self.class_embed(hs, out_f32=True)[:, :, 1:, :]
+            outputs_coord = self.bbox_embed(hs, final_act=ACT_SIGMOID, out_f32=True)[:, :, 1:, :]
             at = self.weak_class_embed(hs[-1, :, 0, :], act=ACT_SIGMOID, out_f32=True).squeeze()
             out['at'] = at
         else:

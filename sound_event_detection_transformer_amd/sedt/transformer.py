@@ -86,11 +86,11 @@ class TransformerDecoderLayer(nn.Module):
                 self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                 self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.norm3.weight, self.norm3.bias)
 
-    def forward_tokens(self, tgt, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask=None, kv_fused=False):
+    def forward_tokens(self, tgt, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask=None, kv_fused=False, out=None):
         """kv_fused: mem_pos is mem + a constant (the decoder's own sine position add): the key and value input gradients
         of the cross-attention are returned as ONE tensor on `mem` (one K = 2E GEMM) and nothing on `mem_pos`"""
         cfg = dict(kv_fused=kv_fused, dt=runtime.compute_dtype(), B=B, S=S, Q=Q, H=self.nhead, dropout=self.p, training=self.training,
-                   pre_norm=self.normalize_before)
+                   pre_norm=self.normalize_before, out=out)
         return Fn.DecoderLayerFn.apply(tgt, mem, mem_pos, qpos, kpm, tgt_mask, cfg, *self.params())
 
 
@@ -128,14 +128,18 @@ class TransformerDecoder(nn.Module):
         qpos = Fn.CastFn.apply(qpos, dt)                       # once for all layers (their gradients add up in the compute dtype)
         out = tgt
         outs = []
-        for layer in self.layers:
-            out = layer.forward_tokens(out, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask, kv_fused=not pos.requires_grad)
+        R, d, n = tgt.shape[0], tgt.shape[1], len(self.layers)
+        # pre-norm layers end in a GEMM (FFN linear2 + residual): it writes straight into its row range of ONE buffer, so the
+        # shared LayerNorm of every layer's output (transformer.py:134-147) is ONE call over all rows without a torch.cat
+        stack = (torch.empty((n * R, d), device=tgt.device, dtype=runtime.torch_dtype())
+                 if (self.return_intermediate and n > 1 and all(l.normalize_before for l in self.layers)) else None)
+        for li, layer in enumerate(self.layers):
+            out = layer.forward_tokens(out, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask, kv_fused=not pos.requires_grad,
+                                       out=None if stack is None else stack[li * R:(li + 1) * R])
             outs.append(out)
-        d = out.shape[1]
         if self.return_intermediate:
-            # the shared LayerNorm of every layer's output (transformer.py:134-147) as ONE call over the stacked rows
-            stacked = torch.cat(outs) if len(outs) > 1 else outs[0]
-            return Fn.LayerNormFn.apply(stacked, self.norm.weight, self.norm.bias, dt).view(len(outs), B, Q, d)
+            stacked = Fn.StackViewFn.apply(stack, *outs) if stack is not None else (torch.cat(outs) if n > 1 else outs[0])
+            return Fn.LayerNormFn.apply(stacked, self.norm.weight, self.norm.bias, dt).view(n, B, Q, d)
         return Fn.LayerNormFn.apply(out, self.norm.weight, self.norm.bias, dt).view(1, B, Q, d)
 
 
@@ -172,13 +176,16 @@ class Transformer(nn.Module):
         x = _tokens(src)
         pos = _tokens(pos_embed)
         kpm = _u8(mask.flatten(1))
+        tgt = None
         if self.self_sup:
             Q = query_embed.shape[0]
             qpos = query_embed.permute(1, 0, 2).reshape(B * Q, C)
         else:
             Q = query_embed.shape[0]
-            qpos = query_embed.unsqueeze(0).expand(B, Q, C).reshape(B * Q, C)
-        tgt = torch.zeros((B * Q, C), device=src.device, dtype=runtime.torch_dtype())
+            tgt = torch.zeros((B * Q, C), device=src.device, dtype=runtime.torch_dtype())
+            qpos = Fn.BroadcastRowsFn.apply(query_embed, tgt, B, dt)        # (Q,C) -> [B*Q, C] in the compute dtype, one launch
+        if tgt is None:
+            tgt = torch.zeros((B * Q, C), device=src.device, dtype=runtime.torch_dtype())
         memory = self.encoder.forward_tokens(x, pos, kpm, B, S)
         tmask = decoder_mask.float().contiguous() if (self.self_sup and decoder_mask is not None) else None
         hs = self.decoder.forward_tokens(tgt, memory, pos, qpos, kpm, B, S, Q, tmask)

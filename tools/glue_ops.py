@@ -19,12 +19,26 @@ model.to(dev).train()
 criterion.to(dev)
 opt = build_optimizer(model)
 x, targets = synthetic_batch(64, 500, 2020, dev)
+device_path = len(sys.argv) > 1 and sys.argv[1] == 'device'      # the code a graphed step captures (device matching)
+if device_path:
+    from sound_event_detection_transformer_amd.engine import GraphedTrainStep
+    g = GraphedTrainStep(model, criterion, opt, x, targets, None, slice(64), max_norm=0.1, warmup=1)
+
+    def one():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            g._eager_device_step(targets, 32)
+        torch.cuda.current_stream().wait_stream(side)
+else:
+    def one():
+        train_step(model, criterion, opt, x, targets, None, slice(64), max_norm=0.1)
 for _ in range(2):
-    train_step(model, criterion, opt, x, targets, None, slice(64), max_norm=0.1)
+    one()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
-    train_step(model, criterion, opt, x, targets, None, slice(64), max_norm=0.1)
+    one()
     torch.cuda.synchronize()
 agg = collections.Counter()
 tim = collections.Counter()
