@@ -495,6 +495,16 @@ def semi_train_step(model, ema, criterion, optimizer, batch_input_teacher, batch
     return ({k: v.detach() for k, v in sup.items()}, {k: v.detach() for k, v in unsup.items()}, total.detach(), pseudo)
 
 
+def _slice_outputs(out, sl):
+    """the clips `sl` of a model output dict (stacked head outputs included)"""
+    o = {k: v[sl] for k, v in out.items() if torch.is_tensor(v)}
+    if 'aux_outputs' in out:
+        o['aux_outputs'] = [{k: v[sl] for k, v in a.items()} for a in out['aux_outputs']]
+    if '_stacked' in out:
+        o['_stacked'] = tuple(t[:, sl] for t in out['_stacked'])
+    return o
+
+
 class GraphedSemiStep(_GraphedBase):
     """The mean-teacher step (reference engine.py:117-181) as ONE HIP graph: labelled forward + device matching + fused
     loss, teacher forward through the EMA weights (no grad), pseudo labels written by ``sedt_pseudo_labels`` straight into the
@@ -513,7 +523,7 @@ class GraphedSemiStep(_GraphedBase):
 
     def __init__(self, model, ema, criterion, optimizer, x_teacher, x_student, targets, mask_strong, mask_weak, mask_label,
                  mask_unlabel, classwise_threshold, orig_size=10.0, fine_tune=False, normalize=False, fl=False, max_norm=0.1,
-                 warmup=2, max_targets=32, accumulating_ema_steps=1):
+                 warmup=2, max_targets=32, accumulating_ema_steps=1, fuse_student_forwards=True):
         import gc
         from . import runtime
         from .sedt import TargetTables
@@ -525,6 +535,10 @@ class GraphedSemiStep(_GraphedBase):
         self.ms, self.mw, self.ml, self.mu = mask_strong, mask_weak, mask_label, mask_unlabel
         self.flags = dict(normalize=normalize, fine_tune=fine_tune, fl=fl)
         self.fl, self.max_norm, self.orig_size = fl, max_norm, orig_size
+        # the labelled clips and the unlabelled (student view) clips go through the student weights: ONE forward over their
+        # concatenation instead of two (clips are independent end to end - FrozenBatchNorm, per-clip attention - so every clip's
+        # outputs are what its own forward gives; the GEMMs see twice the rows, the step half the launches)
+        self.fuse = fuse_student_forwards
         xt, xs = _tensors(x_teacher), _tensors(x_student)
         dev = xt.device
         self.dev = dev
@@ -541,9 +555,10 @@ class GraphedSemiStep(_GraphedBase):
                         dist.broadcast(h, 0)
                         ema.shadow[n].copy_(h)
             runtime.seed_for_rank(dist.get_rank())
-        self.x_lab = xt[mask_label].clone()
+        n_lab_clips = xt[mask_label].shape[0]
+        self.x_cat = torch.cat([xt[mask_label], xs[mask_unlabel]])          # static input of the student forward(s)
+        self.x_lab, self.x_stu = self.x_cat[:n_lab_clips], self.x_cat[n_lab_clips:]
         self.x_tea = xt[mask_unlabel].clone()
-        self.x_stu = xs[mask_unlabel].clone()
         self.threshold = classwise_threshold.to(device=dev, dtype=torch.float32).clone()
         lab_t = targets[mask_label]
         n_l, n_u = self.x_lab.shape[0], self.x_stu.shape[0]
@@ -591,9 +606,10 @@ class GraphedSemiStep(_GraphedBase):
             self.ema.update()
             return
         crit, model = self.criterion, self.model
-        out_l = model(self.x_lab)
-        self.sup = crit.compute(out_l, crit.prepare_device(out_l, self.tab_l, **self.flags), self.fl)
-        total_l = crit.last_total
+        if not self.fuse:
+            out_l = model(self.x_lab)
+            self.sup = crit.compute(out_l, crit.prepare_device(out_l, self.tab_l, **self.flags), self.fl)
+            total_l = crit.last_total
         self.ema.apply_shadow()
         try:
             with torch.no_grad():
@@ -601,7 +617,14 @@ class GraphedSemiStep(_GraphedBase):
         finally:
             self.ema.restore()
         pseudo_label_tables(tea, self.threshold, self.orig_size, self.tab_u, self.counter)
-        out_s = model(self.x_stu)
+        if self.fuse:
+            out = model(self.x_cat)
+            n = self.x_lab.shape[0]
+            out_l, out_s = _slice_outputs(out, slice(0, n)), _slice_outputs(out, slice(n, None))
+            self.sup = crit.compute(out_l, crit.prepare_device(out_l, self.tab_l, **self.flags), self.fl)
+            total_l = crit.last_total
+        else:
+            out_s = model(self.x_stu)
         self.unsup = crit.compute(out_s, crit.prepare_device(out_s, self.tab_u, **self.flags), self.fl)
         self.total = total_l + crit.last_total
         crit.last_total = None
