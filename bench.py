@@ -341,9 +341,9 @@ def kernel_report(dtype, dev):
             return ops.linear(dt, ctx, w_o, bias=b_o, drop_p=0.1, seed=3, res=x, ldr=x.stride(0))
         t = timeit(lambda: fused(True))
         mf("encoder self-attn block fwd, FUSED head (LN1+QKV+attention in one launch, by-products for backward written) + out-proj",
-           83.9e6 * B, t, "2 launches; what the training step runs")
+           83.9e6 * B, t, "2 launches; opt-in (SEDT_FUSED_ENC=1): slower than the 4-launch form today, DESIGN.md 4")
         t = timeit(lambda: fused(False))
-        mf("encoder self-attn block fwd, FUSED head, no-grad form (teacher / eval) + out-proj", 83.9e6 * B, t, "2 launches")
+        mf("encoder self-attn block fwd, FUSED head, no-grad form (teacher / eval) + out-proj", 83.9e6 * B, t, "2 launches; opt-in")
         t = timeit(lambda: ops.encoder_attn_fwd(dt, x, pos, gam, bet, w_in, b_in, B, S, H, None, 0.1, 7, None, train=False))
         mf("  fused head alone, no-grad (sedt_encoder_attn_fwd)", (83.9e6 - 16.8e6) * B, t)
     xn0, xnp0, _, _ = ops.layernorm_fwd(dt, x, gam, bet, add_t=pos)
@@ -443,17 +443,21 @@ def main():
     exposed = None
     if world > 1 and graphed and args.config in ('c2', 'c3') and 'stepper' in ex:
         from sound_event_detection_transformer_amd.engine import GraphedTrainStep
-        loc = GraphedTrainStep(ex['net'], ex['criterion'], ex['opt'], ex['x'], ex['targets'], ex['wm'], slice(ex['ns']), max_norm=0.1,
-                               data_parallel=False)
-        for _ in range(3):
-            loc(ex['x'], ex['targets'])
+        try:                                   # a diagnostic after the timed region: never allowed to cost the result line
+            loc = GraphedTrainStep(ex['net'], ex['criterion'], ex['opt'], ex['x'], ex['targets'], ex['wm'], slice(ex['ns']),
+                                   max_norm=0.1, data_parallel=False)
+            for _ in range(3):
+                loc(ex['x'], ex['targets'])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                loc(ex['x'], ex['targets'])
+            torch.cuda.synchronize()
+            local_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            exposed = {"local_step_ms": round(local_ms, 3), "exposed_comm_ms": round(elapsed / args.steps * 1e3 - local_ms, 3)}
+        except Exception as e:                 # noqa: BLE001
+            exposed = {"error": repr(e)[:200]}
         barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            loc(ex['x'], ex['targets'])
-        torch.cuda.synchronize()
-        local_ms = (time.perf_counter() - t1) / args.steps * 1e3
-        exposed = {"local_step_ms": round(local_ms, 3), "exposed_comm_ms": round(elapsed / args.steps * 1e3 - local_ms, 3)}
 
     # ---- GEMM family alone (c2/c3, rank 0): ONE extra eager step records the argument block of every GEMM launch, which are
     #      then replayed back to back on the launch stream between two HIP events

@@ -305,7 +305,14 @@ int igemm2_try(const SedtIgemm& p, hipStream_t st) {
     if ((p.N % 128) == 0 && p.K >= mink && !(igemm3_planning() && p.M <= 1024)) bn = 128;
     // the ping-pong 8-wave kernel makes the 128x128 tile (one workgroup per CU) pay where the K loop is long enough to
     // amortise its exposed prologue / epilogue and the tiles still cover the chip: layer4 conv1 fwd / conv2 / conv3 dgrad
-    if (bn == 128 && p.K >= 2048 && (long)((p.M + 127) / 128) * (p.N / 128) >= 256 && !igemm3_planning()) bm = 128;
+    static int bm128k = -1, bm128t = -1;
+    if (bm128k < 0) {
+      const char* e = getenv("SEDT_IGEMM_BM128_MINK");
+      bm128k = e ? atoi(e) : 2048;
+      e = getenv("SEDT_IGEMM_BM128_MINTILES");
+      bm128t = e ? atoi(e) : 256;
+    }
+    if (bn == 128 && p.K >= bm128k && (long)((p.M + 127) / 128) * (p.N / 128) >= bm128t && !igemm3_planning()) bm = 128;
   }
   {   // the lean-issue kernel takes the common cases
     int r3 = igemm3_try(p, (unsigned)a_bytes, (unsigned)b_bytes, bm, bn, st);
