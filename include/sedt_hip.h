@@ -222,6 +222,17 @@ int sedt_pack_conv(const float* w, int Cout, int Cin, int taps, const float* bns
  * col[B*Ho*Wo][128] = [x taps | 0 | in-bounds indicators | 0]. */
 int sedt_stem_prep(const float* w0, const float* b0, const float* w1, void* wcat, int dtype, void* stream);
 int sedt_stem_im2col(const float* x, void* col, int B, int H, int W, int dtype, void* stream);
+/* The whole stem in one launch (bf16, W = 64 mel bands): conv0 o conv1 7x7/s2 o FrozenBN (scale, bias) o ReLU o max-pool 3x3/s2
+ * (sedt/backbone.py:98-111 + torchvision stem) from x f32 [B][H][64] to pool bf16 [B*Hp*16][64] + argmax bytes idx (may be
+ * null); wcat = sedt_stem_prep's bf16 [64][128]; s1_out (optional, tests): the un-pooled activation [B*Ho*32][64]. */
+int sedt_stem_pool_fwd(const float* x, const void* wcat, const float* scale, const float* bias, void* pool, uint8_t* idx,
+                       void* s1_out, int B, int H, int W, void* stream);
+/* weight gradient of the folded stem convolution from the POOLED gradient g (max-pool backward through the ReLU evaluated on
+ * the fly): slab f32 [nslab][64][128] partial sums in wcat's layout, nslab = sedt_stem_pool_wgrad_slabs(B, H); reduce with
+ * sedt_wgrad_reduce_bias(slab, nslab, 64, 1, 128, bn_scale, G, ...) and feed G to sedt_stem_conv0_grad */
+int sedt_stem_pool_wgrad_slabs(int B, int H);
+int sedt_stem_pool_wgrad(const float* x, const void* g, const uint8_t* idx, const void* pool, float* slab, int nslab, int B, int H,
+                         int W, void* stream);
 /* dw0[c] = sum w1[co,c,tap]*G[co][tap], db0[c] = sum w1[co,c,tap]*G[co][64+tap]; G f32 [64][128] */
 int sedt_stem_conv0_grad(const float* G, const float* w1, float* dw0, float* db0, void* stream);
 /* 3x3 stride-2 pad-1 max pooling over NHWC; idx (uint8 argmax tap) saved for backward */

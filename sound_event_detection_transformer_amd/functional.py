@@ -473,8 +473,18 @@ class StemFn(Function):
         B, _, H, W = x.shape
         x = x.contiguous().float()
         wcat = ops.stem_prep(dt, w0, b0, w1)
-        col, Ho, Wo = ops.stem_im2col(dt, x, B, H, W)
         _, _, sc, bi = _prep_conv(dt, w1, (bnw, bnb, bnrm, bnrv))
+        ctx.direct = ops.stem_pool_ok(dt, W)
+        if ctx.direct:
+            # ONE launch from the spectrogram to the pooled activation (csrc/stem.hip): neither the im2col matrix nor the
+            # un-pooled activation exists; the backward needs x, the pooled output and the argmax bytes only
+            pool, idx, Hp, Wp = ops.stem_pool_fwd(x, wcat, sc, bi, B, H, W, want_idx=any(ctx.needs_input_grad))
+            ctx.dt, ctx.dims = dt, (B, H, W)
+            if idx is not None:
+                ctx.save_for_backward(x, pool, idx, sc, w1)
+            ctx.out_hw = (Hp, Wp)
+            return pool
+        col, Ho, Wo = ops.stem_im2col(dt, x, B, H, W)
         s1 = ops.linear(dt, col, wcat, scale=sc, bias=bi, act=ACT_RELU)
         pool, idx, Hp, Wp = ops.maxpool_fwd(dt, s1, B, Ho, Wo, 64)
         ctx.dt, ctx.dims = dt, (B, Ho, Wo)
@@ -487,6 +497,11 @@ class StemFn(Function):
     def backward(ctx, g):
         col, pool, idx, sc, w1 = ctx.saved_tensors
         dt = ctx.dt
+        if ctx.direct:
+            B, H, W = ctx.dims
+            G = ops.stem_pool_wgrad(col, _as(g, dt).contiguous(), idx, pool, sc, B, H, W)       # (col = x here)
+            dw0, db0 = ops.stem_conv0_grad(G, w1)
+            return None, dw0, db0, None, None, None, None, None, None
         B, Ho, Wo = ctx.dims
         # routed by argmax, masked by the stem ReLU: the selected element is the window maximum = the pooled value
         gs = ops.maxpool_bwd(dt, _as(g, dt), idx, None, B, Ho, Wo, 64, y=pool)

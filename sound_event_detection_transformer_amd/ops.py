@@ -514,6 +514,7 @@ def attention_bwd(dtype, q, k, v, o, do, lse, B, H, Lq, Lk, dq, dk, dv, kpm=None
 # The fused encoder head is correct (tests/test_ops_gpu.py) but, as measured on the MI355X, not yet faster
 # than the three launches it replaces: its projection phase loads fragment-shaped operands (32 rows x 32 B per wave
 # instruction) straight from L2 and is bound by the texture-address path (20 of its 38 us).  Opt in with SEDT_FUSED_ENC=1.
+STEM_DIRECT = os.environ.get('SEDT_STEM_DIRECT', '1') != '0'     # one-launch stem forward / backward (stem.hip)
 FUSED_ENC = os.environ.get('SEDT_FUSED_ENC', '0') == '1'
 
 
@@ -592,6 +593,34 @@ def stem_im2col(dtype, x, B, H, W):
     col = torch.empty((B * Ho * Wo, 128), device=x.device, dtype=TORCH_DTYPE[dtype])
     L.check(L.load().sedt_stem_im2col(_p(x), _p(col), B, H, W, dtype, L.stream_ptr()), 'stem_im2col')
     return col, Ho, Wo
+
+
+def stem_pool_ok(dtype, W):
+    """the one-launch stem (conv0 o conv1 o FrozenBN o ReLU o max-pool) exists for the bf16 mode and 64 mel bands"""
+    return dtype == BF16 and W == 64 and STEM_DIRECT
+
+
+def stem_pool_fwd(x, wcat, scale, bias, B, H, W, want_idx=True, want_s1=False):
+    """x f32 [B][H][64] -> (pool bf16 [B*Hp*16, 64], idx uint8 or None, Hp, Wp[, s1 bf16 [B*Ho*32, 64]])"""
+    Ho = (H - 1) // 2 + 1
+    Hp, Wp = (Ho - 1) // 2 + 1, 16
+    pool = torch.empty((B * Hp * Wp, 64), device=x.device, dtype=torch.bfloat16)
+    idx = torch.empty((B * Hp * Wp, 64), device=x.device, dtype=torch.uint8) if want_idx else None
+    s1 = torch.empty((B * Ho * 32, 64), device=x.device, dtype=torch.bfloat16) if want_s1 else None
+    L.check(L.load().sedt_stem_pool_fwd(_p(x), _p(wcat), _p(scale), _p(bias), _p(pool), _p(idx), _p(s1), B, H, W, L.stream_ptr()),
+            'stem_pool_fwd')
+    return (pool, idx, Hp, Wp, s1) if want_s1 else (pool, idx, Hp, Wp)
+
+
+def stem_pool_wgrad(x, g, idx, pool, rowscale, B, H, W):
+    """G f32 [64][128] (wcat's layout) = bn_scale[co] * sum over pixels of maxpool_bwd(g)[pixel][co] * patch[pixel][k]"""
+    lib = L.load()
+    ns = lib.sedt_stem_pool_wgrad_slabs(B, H)
+    slab = torch.empty((ns, 64, 128), device=x.device, dtype=torch.float32)
+    G = torch.empty((64, 128), device=x.device, dtype=torch.float32)
+    L.check(lib.sedt_stem_pool_wgrad(_p(x), _p(g), _p(idx), _p(pool), _p(slab), ns, B, H, W, L.stream_ptr()), 'stem_pool_wgrad')
+    L.check(lib.sedt_wgrad_reduce_bias(_p(slab), ns, 64, 1, 128, _p(rowscale), _p(G), None, None, L.stream_ptr()), 'wgrad_reduce')
+    return G
 
 
 def stem_conv0_grad(G, w1):

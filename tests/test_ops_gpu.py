@@ -3,6 +3,7 @@
 Tolerances: f32 mode rtol 2e-4 (exact-f32 MFMA, different summation order); bf16 mode compares
 against the f32 reference evaluated on bf16-rounded inputs with 2e-2 of the output scale."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -294,6 +295,67 @@ def test_stem(ops, dt, H, W):
     dw0, db0 = ops.stem_conv0_grad(Gm.contiguous(), w1.cuda())
     close(dw0, w0.grad, dt)
     close(db0, b0.grad, dt)
+
+
+@pytest.mark.parametrize('B,H', [(2, 500), (3, 496), (5, 128), (2, 37), (1, 9)])
+def test_stem_one_launch_forward_and_backward(ops, B, H):
+    """csrc/stem.hip: conv0 o conv1 o FrozenBN o ReLU o max-pool in one launch, and the conv0 gradients from the pooled gradient
+    in one launch + reduce, against plain PyTorch f32 (bf16-rounded operands) and against the unfused HIP chain"""
+    dt, W = BF16, 64
+    x = randn(B, 1, H, W)
+    w0, b0 = (randn(3, 1, 1, 1) * 0.5).requires_grad_(True), (randn(3) * 0.5).requires_grad_(True)
+    w1 = randn(64, 3, 7, 7) / math.sqrt(147)
+    sc, bi = torch.rand(64, generator=G) + 0.5, randn(64) * 0.1
+    pre = F.conv2d(F.conv2d(x, w0, b0), w1, stride=2, padding=3)
+    s1_ref = F.relu(pre * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1))
+    xd = x.cuda().contiguous()
+    wcat = ops.stem_prep(dt, w0.detach().cuda(), b0.detach().cuda(), w1.cuda())
+    pool, idx, Hp, Wp, s1 = ops.stem_pool_fwd(xd, wcat, sc.cuda(), bi.cuda(), B, H, W, want_s1=True)
+    Ho = (H - 1) // 2 + 1
+    assert (Hp, Wp) == ((Ho - 1) // 2 + 1, 16)
+    close(s1, _nhwc(s1_ref).reshape(-1, 64).detach(), dt)
+    # the pooling half is exact given the un-pooled tile the kernel itself produced (values, argmax bytes, first-maximum rule)
+    p2, i2, _, _ = ops.maxpool_fwd(dt, s1, B, Ho, 32, 64)
+    assert torch.equal(pool, p2) and torch.equal(idx, i2)
+    # without the argmax bytes (no-grad form): same pooled values
+    p3, i3, _, _ = ops.stem_pool_fwd(xd, wcat, sc.cuda(), bi.cuda(), B, H, W, want_idx=False)
+    assert i3 is None and torch.equal(p3, pool)
+    # ---- backward: conv0 gradients from the pooled gradient
+    gy = randn(B, 64, Hp, Wp)
+    gyd = dev(_nhwc(gy).reshape(-1, 64), dt)
+    Gd = ops.stem_pool_wgrad(xd, gyd, idx, pool, sc.cuda(), B, H, W)
+    # unfused HIP chain on the same tensors: max-pool backward through the ReLU, then the GEMM weight gradient
+    col, _, _ = ops.stem_im2col(dt, xd, B, H, W)
+    gs = ops.maxpool_bwd(dt, gyd, idx, None, B, Ho, 32, 64, y=pool)
+    Gu = ops.linear_wgrad(dt, gs, col) * sc.cuda().view(-1, 1)
+    close(Gd, Gu.float().cpu(), F32, f32_tol=2e-3)                       # same bf16 products, different summation order
+    assert torch.equal(Gd[:, 49:64], torch.zeros_like(Gd[:, 49:64])) and torch.equal(Gd[:, 113:], torch.zeros_like(Gd[:, 113:]))
+    dw0, db0 = ops.stem_conv0_grad(Gd, w1.cuda())
+    # independent reference for the gradient matrix: the kernel's own argmax bytes route the pooled gradient on the CPU (which
+    # window element a bf16 near-tie selects is the forward's business and is pinned above; a torch max_pool2d reference re-decides
+    # the ties and moves whole +- terms: 10 % of the matrix scale), then einsum against unfolded bf16-rounded patches
+    gp = rnd(gy, dt).permute(0, 2, 3, 1) * (pool.float().cpu().view(B, Hp, Wp, 64) > 0)
+    code = idx.cpu().view(B, Hp, Wp, 64).long()
+    gs_ref = torch.zeros(B, Ho, 32, 64)
+    hh, ww = torch.arange(Hp).view(1, Hp, 1, 1), torch.arange(Wp).view(1, 1, Wp, 1)
+    ho, wo = (2 * hh - 1 + code // 3), (2 * ww - 1 + code % 3)
+    bb_ = torch.arange(B).view(B, 1, 1, 1).expand_as(code)
+    cc_ = torch.arange(64).view(1, 1, 1, 64).expand_as(code)
+    gs_ref.index_put_((bb_.reshape(-1), ho.reshape(-1), wo.reshape(-1), cc_.reshape(-1)), gp.reshape(-1), accumulate=True)
+    gs_ref = rnd(gs_ref, dt).permute(0, 3, 1, 2).reshape(B, 64, -1)
+    patches = F.unfold(rnd(x, dt), 7, padding=3, stride=2)                   # [B, 49, Ho*Wo]
+    inb = F.unfold(torch.ones_like(x), 7, padding=3, stride=2)
+    Gx = torch.einsum('bcp,btp->ct', gs_ref, patches) * sc.view(-1, 1)
+    Gi = torch.einsum('bcp,btp->ct', gs_ref, inb) * sc.view(-1, 1)
+    close(Gd[:, :49], Gx, dt)
+    close(Gd[:, 64:113], Gi, dt)
+    w1v = w1.view(64, 3, 49)
+    for got, Gref in ((dw0.view(3), Gx), (db0, Gi)):
+        ref = torch.einsum('oct,ot->c', w1v, Gref)
+        scale = torch.einsum('oct,ot->c', w1v.abs(), Gref.abs()).max().item()
+        assert (got.cpu() - ref).abs().max().item() < 2e-2 * scale
+    # bit-reproducible
+    assert torch.equal(ops.stem_pool_wgrad(xd, gyd, idx, pool, sc.cuda(), B, H, W), Gd)
 
 
 @pytest.mark.parametrize('dt', [F32, BF16])
@@ -599,3 +661,19 @@ def test_fused_encoder_attention_head_matches_unfused_chain(ops, B, S, padded, p
     # no-grad form: same context, nothing else written
     nctx, nlse, none = ops.encoder_attn_fwd(BF16, x, pos, gam, bet, w_in, b_in, B, S, H, kpm, p, 77, None, train=False)
     assert none is None and torch.equal(nctx, fctx) and torch.equal(nlse, flse)
+
+
+def test_previous_generation_kernels_still_pass_the_same_parity_tests():
+    """igemm2 / wgrad2 / wgrad3 are the envelope fallbacks of the current GEMM generation (igemm3 / wgrad4): with the newer kernels
+    switched off (the library reads the switches once per process, hence the child process) the same conv / linear parity
+    tests must pass through them"""
+    import subprocess
+    import sys
+    env = dict(os.environ, SEDT_IGEMM_V3='0', SEDT_WGRAD_V4='0', SEDT_WGRAD_V3='0')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_ops_gpu.py'), '-q', '-x', '-m', 'gpu', '-k',
+                        'test_linear_epilogues or test_conv_fwd_dgrad_wgrad or test_linear_wgrad_and_colsum or test_wgrad_large_tiles '
+                        'or test_linear_tiles_and_strided_views'],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert ' passed' in r.stdout
