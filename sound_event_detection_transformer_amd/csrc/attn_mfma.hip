@@ -185,7 +185,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __r
 // in a no-grad forward.  TRAIN additionally writes what the (unfused) backward kernels read: xn, xn + pos, the LayerNorm row
 // statistics, q | k and v (coalesced 16-byte copies out of the LDS images).
 // Envelope: d_model 256, 8 heads of 32, S <= 128 tokens, bf16.
+// sum over the 32 lanes of each half wave, returned in every lane: DPP row shifts + row_bcast:15 (VALU rate; five
+// ds_bpermute round trips per sum - what __shfl_xor compiles to - made the LayerNorm statistics the longest part of the kernel)
+__device__ __forceinline__ float halfwave_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));   // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));   // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));   // row_shr:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, true));   // row_bcast:15 into rows 1, 3
+  const float lo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+  const float hi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  return (threadIdx.x & 32) ? hi : lo;
+}
+
 constexpr int EF_D = 256, EF_S = 128, EF_IMG = EF_S * AROW;
+constexpr int EF_AP = 128 * 2 + 16;          // row pitch of the staged half images (272 B: conflict-free 16-byte fragment reads)
 
 template <bool TRAIN>
 __global__ __launch_bounds__(512) void enc_attn_fused_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ pos,
@@ -198,79 +212,116 @@ __global__ __launch_bounds__(512) void enc_attn_fused_kernel(const bf16_t* __res
                                                              const uint8_t* __restrict__ kpm, int S, float scale, uint32_t thresh,
                                                              float inv_keep, uint32_t seed, const uint32_t* seed_ptr, int dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // projection phase: An | Ap (normalised activation halves, [128 tokens][128 channels], 272-byte rows) | Wl (the head pair's
+  // 192 weight rows, same shape) - all filled with fully coalesced 16-byte accesses and read back as MFMA fragments with
+  // ds_read_b128 (the first version loaded fragment-shaped operands - 32 rows x 32 B per wave instruction - straight from
+  // L2 and was bound by the texture-address path: 20 of its 38 us).  The attention images alias that area afterwards.
+  unsigned char* An = smem;
+  unsigned char* Ap = An + EF_S * EF_AP;
+  unsigned char* Wl = Ap + EF_S * EF_AP;
+  float* Kb = reinterpret_cast<float*>(Wl + 192 * EF_AP);      // [128] additive key bias (lives through both phases)
   unsigned char* Kimg = smem;                         // [2 heads][128][32] bf16
   unsigned char* Vimg = Kimg + 2 * EF_IMG;
   unsigned char* Qimg = Vimg + 2 * EF_IMG;
-  float* Kb = reinterpret_cast<float*>(Qimg + 2 * EF_IMG);     // [128] additive key bias
-  float* Gs = Kb + EF_S;                              // gamma [256]
-  float* Bs = Gs + EF_D;                              // beta  [256]
   const int b = blockIdx.x >> 2, hp = blockIdx.x & 3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int hh = wave >> 2, slab = wave & 3, head = hp * 2 + hh, hf = lane >> 5;
-  for (int i = tid; i < EF_D; i += 512) { Gs[i] = gamma[i]; Bs[i] = beta[i]; }
   stage_key_bias(Kb, kpm ? kpm + (long)b * S : nullptr, S, EF_S, tid, 512);
-  // ---- this lane's half row of x: token `row`, channels 16 j + 8 hf + [0, 8) for j = 0..15
-  const int row = slab * 32 + (lane & 31);
-  const bool live = row < S;
-  const long grow = (long)b * S + row;
-  // row statistics in one pass over the slab (shifted sums: no cancellation when |mean| >> std); the slab is re-read from
-  // L1/L2 in the projection loop instead of being held in 64 registers (the kernel would spill)
-  const bf16_t* xrow = x + grow * EF_D + 8 * hf;
-  float shift = live ? (float)x[grow * EF_D] : 0.f;
-  float s1 = 0.f, s2 = 0.f;
+  // ---- the clip's x (and pos) tile in registers: thread <-> column chunk cc (8 channels) of rows rb + 16 i
+  const int cc = tid & 31, rb = tid >> 5;
+  bf16x8 xv[8], pz[8];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (live) v = *reinterpret_cast<const bf16x8*>(xrow + 16 * j);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { const float d = (float)v[e] - shift; s1 += d; s2 += d * d; }
+  for (int i = 0; i < 8; ++i) {
+    const int row = rb + 16 * i;
+    const long o = ((long)b * S + row) * EF_D + cc * 8;
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    xv[i] = row < S ? *reinterpret_cast<const bf16x8*>(x + o) : z;
+    pz[i] = row < S ? *reinterpret_cast<const bf16x8*>(pos + o) : z;
   }
-  s1 += __shfl_xor(s1, 32, 64);
-  s2 += __shfl_xor(s2, 32, 64);
-  const float dm = s1 * (1.f / EF_D);
-  const float mu = live ? shift + dm : 0.f;
-  const float rs = rsqrtf(fmaxf(s2 * (1.f / EF_D) - dm * dm, 0.f) + 1e-5f);
-  const bool writer = TRAIN && hp == 0 && hh == 0;      // one wave per slab of the clip writes the shared by-products
-  if (writer && live && hf == 0) { mean_out[grow] = mu; rstd_out[grow] = rs; }
-  __syncthreads();                                      // gamma / beta / key bias staged
-  // ---- projections: Q, K from xn + pos, V from xn; weight rows n = head*32 + (lane & 31) of the q / k / v blocks
-  f32x16 aq, ak, av;
+  // first half of the weight rows (global row of staged row r: q / k / v block r >> 6, rows hp*64 + (r & 63))
+  auto wsrc = [&](int q, int half) {
+    const int id = tid + 512 * q, r = id >> 4, wc = id & 15;
+    return w_in + ((long)(r >> 6) * EF_D + hp * 64 + (r & 63)) * EF_D + half * 128 + wc * 8;
+  };
+  uint4 wreg[6];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { aq[r] = 0.f; ak[r] = 0.f; av[r] = 0.f; }
-  const bf16_t* wq = w_in + (long)(head * AD + (lane & 31)) * EF_D + 8 * hf;
-  const bf16_t* wk = wq + (long)EF_D * EF_D;
-  const bf16_t* wv = wk + (long)EF_D * EF_D;
+  for (int q = 0; q < 6; ++q) wreg[q] = *reinterpret_cast<const uint4*>(wsrc(q, 0));
+  float gv[8], ev[8];
 #pragma unroll
-  for (int j = 0; j < ((dbg & 1) ? 0 : 16); ++j) {
-    const int c0 = 16 * j + 8 * hf;
-    const bf16x8 bq = *reinterpret_cast<const bf16x8*>(wq + 16 * j);
-    const bf16x8 bk = *reinterpret_cast<const bf16x8*>(wk + 16 * j);
-    const bf16x8 bv = *reinterpret_cast<const bf16x8*>(wv + 16 * j);
-    bf16x8 pz = {0, 0, 0, 0, 0, 0, 0, 0}, xv = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (live) {
-      pz = *reinterpret_cast<const bf16x8*>(pos + grow * EF_D + c0);
-      xv = *reinterpret_cast<const bf16x8*>(xrow + 16 * j);
-    }
-    const float4 g0 = *reinterpret_cast<const float4*>(Gs + c0), g1 = *reinterpret_cast<const float4*>(Gs + c0 + 4);
-    const float4 e0 = *reinterpret_cast<const float4*>(Bs + c0), e1 = *reinterpret_cast<const float4*>(Bs + c0 + 4);
-    const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-    const float ev[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+  for (int e = 0; e < 8; ++e) { gv[e] = gamma[cc * 8 + e]; ev[e] = beta[cc * 8 + e]; }
+  // ---- LayerNorm in registers: a row's 32 chunks sit in the 32 lanes of a half wave (two-pass mean / variance)
+  const bool writer = TRAIN && hp == 0;                 // one workgroup of the clip writes the shared by-products
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = rb + 16 * i;
+    float s1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1 += (float)xv[i][e];
+    s1 = halfwave_sum(s1);
+    const float mu = s1 * (1.f / EF_D);
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = (float)xv[i][e] - mu; s2 += d * d; }
+    s2 = halfwave_sum(s2);
+    const float rs = rsqrtf(s2 * (1.f / EF_D) + 1e-5f);
     bf16x8 an, ap;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float o = ((float)xv[e] - mu) * rs * gv[e] + ev[e];
-      an[e] = (bf16_t)o;
-      ap[e] = (bf16_t)(o + (float)pz[e]);
+      const float o = ((float)xv[i][e] - mu) * rs * gv[e] + ev[e];
+      an[e] = row < S ? (bf16_t)o : (bf16_t)0.f;
+      ap[e] = row < S ? (bf16_t)(o + (float)pz[i][e]) : (bf16_t)0.f;
     }
-    if (writer && live) {
-      *reinterpret_cast<bf16x8*>(xn_out + grow * EF_D + c0) = an;
-      *reinterpret_cast<bf16x8*>(xnp_out + grow * EF_D + c0) = ap;
+    xv[i] = an;
+    pz[i] = ap;
+    if (writer && row < S) {
+      const long g = (long)b * S + row;
+      *reinterpret_cast<bf16x8*>(xn_out + g * EF_D + cc * 8) = an;
+      *reinterpret_cast<bf16x8*>(xnp_out + g * EF_D + cc * 8) = ap;
+      if (cc == 0) { mean_out[g] = mu; rstd_out[g] = rs; }
     }
-    aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bq, aq, 0, 0, 0);
-    ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap, bk, ak, 0, 0, 0);
-    av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(an, bv, av, 0, 0, 0);
-    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // bound how far the weight / pos loads are hoisted (registers)
   }
+  // ---- projections: Q, K from xn + pos, V from xn, in two K halves of 128 channels
+  f32x16 aq, ak, av;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aq[r] = 0.f; ak[r] = 0.f; av[r] = 0.f; }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();                          // the first half's fragments are read
+    if ((cc >> 4) == half) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        *reinterpret_cast<bf16x8*>(An + (rb + 16 * i) * EF_AP + (cc & 15) * 16) = xv[i];
+        *reinterpret_cast<bf16x8*>(Ap + (rb + 16 * i) * EF_AP + (cc & 15) * 16) = pz[i];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const int id = tid + 512 * q;
+      *reinterpret_cast<uint4*>(Wl + (id >> 4) * EF_AP + (id & 15) * 16) = wreg[q];
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q) wreg[q] = *reinterpret_cast<const uint4*>(wsrc(q, 1));      // in flight under the MFMAs
+    }
+    if (!(dbg & 1)) {
+      const unsigned char* arow = Ap + (slab * 32 + (lane & 31)) * EF_AP + 16 * hf;
+      const unsigned char* nrow = An + (slab * 32 + (lane & 31)) * EF_AP + 16 * hf;
+      const unsigned char* wrow = Wl + (hh * 32 + (lane & 31)) * EF_AP + 16 * hf;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 apf = *reinterpret_cast<const bf16x8*>(arow + 32 * ks);
+        const bf16x8 anf = *reinterpret_cast<const bf16x8*>(nrow + 32 * ks);
+        const bf16x8 bq = *reinterpret_cast<const bf16x8*>(wrow + 32 * ks);
+        const bf16x8 bk = *reinterpret_cast<const bf16x8*>(wrow + 64 * EF_AP + 32 * ks);
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(wrow + 128 * EF_AP + 32 * ks);
+        aq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apf, bq, aq, 0, 0, 0);
+        ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apf, bk, ak, 0, 0, 0);
+        av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(anf, bv, av, 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                                      // every fragment is read: the staging area becomes the Q / K / V images
   // ---- bias, bf16, into the LDS images of this head: accumulator register r of half hf <-> token slab*32 + crow(r, hf)
   {
     const float biq = b_in[head * AD + (lane & 31)], bik = b_in[EF_D + head * AD + (lane & 31)],
@@ -591,7 +642,7 @@ int attn_fwd_mfma_try(const void* q, int64_t ldq, const void* k, int64_t ldk, co
 int enc_attn_fused_launch(const void* x, const void* pos, const float* gamma, const float* beta, const void* w_in, const float* b_in,
                           void* ctx, float* lse, void* xn, void* xnp, float* mean, float* rstd, void* qk, void* v, const uint8_t* kpm,
                           int B, int S, float drop_p, uint32_t seed, const uint32_t* seed_ptr, hipStream_t st) {
-  const size_t lds = (size_t)6 * EF_IMG + (size_t)(EF_S + 2 * EF_D) * sizeof(float);
+  const size_t lds = (size_t)(2 * EF_S + 192) * EF_AP + (size_t)EF_S * sizeof(float);       // 122368 B: one workgroup per CU
   const float scale = 1.f / sqrtf((float)AD);
   const uint32_t th = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
   const float ik = 1.f / (1.f - drop_p);
@@ -600,13 +651,13 @@ int enc_attn_fused_launch(const void* x, const void* pos, const float* gamma, co
   dim3 grid(B * 4), block(512);
   if (train) {
     static bool done = false;
-    if (set_attr_once(enc_attn_fused_kernel<true>, done, 64 * 1024, "enc_attn_fused")) return 1;
+    if (set_attr_once(enc_attn_fused_kernel<true>, done, 128 * 1024, "enc_attn_fused")) return 1;
     hipLaunchKernelGGL(enc_attn_fused_kernel<true>, grid, block, lds, st, (const bf16_t*)x, (const bf16_t*)pos, gamma, beta,
                        (const bf16_t*)w_in, b_in, (bf16_t*)ctx, lse, (bf16_t*)xn, (bf16_t*)xnp, mean, rstd, (bf16_t*)qk, (bf16_t*)v, kpm,
                        S, scale, th, ik, seed, seed_ptr, dbg);
   } else {
     static bool done = false;
-    if (set_attr_once(enc_attn_fused_kernel<false>, done, 64 * 1024, "enc_attn_fused")) return 1;
+    if (set_attr_once(enc_attn_fused_kernel<false>, done, 128 * 1024, "enc_attn_fused")) return 1;
     hipLaunchKernelGGL(enc_attn_fused_kernel<false>, grid, block, lds, st, (const bf16_t*)x, (const bf16_t*)pos, gamma, beta,
                        (const bf16_t*)w_in, b_in, (bf16_t*)ctx, lse, (bf16_t*)nullptr, (bf16_t*)nullptr, (float*)nullptr, (float*)nullptr,
                        (bf16_t*)nullptr, (bf16_t*)nullptr, kpm, S, scale, th, ik, seed, seed_ptr, dbg);

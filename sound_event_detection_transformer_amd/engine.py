@@ -1,6 +1,7 @@
 """The per-batch body of the reference's ``engine.train`` loop (engine.py:56-80) as one function."""
 import math
 
+import os
 import torch
 
 from . import ops
@@ -211,7 +212,7 @@ class GraphedTrainStep(_GraphedBase):
         self.fine_tune, self.fl, self.ft_rand = fine_tune, fl, ft_rand
         self.runtime = runtime
         self.async_wgrad = async_wgrad
-        self.coschedule = coschedule and not async_wgrad
+        self.coschedule = (coschedule or os.environ.get('SEDT_COSCHEDULE', '0') == '1') and not async_wgrad
         self.world = torch.distributed.get_world_size() if (torch.distributed.is_available()
                                                             and torch.distributed.is_initialized()) else 1
         # data-parallel overlap: parameters whose gradients come last (stem conv0 + layer2) go to the tail of the flat layout

@@ -98,6 +98,8 @@ class WgradPool(object):
         self.dtype = dtype
 
     def take(self, main_tiles):
+        if NO_RIDE:
+            return []
         room = max(self.SLOTS - main_tiles, 512)
         out = []
         while self.gemms and len(out) < self.MAX_RIDERS:
@@ -514,6 +516,7 @@ def attention_bwd(dtype, q, k, v, o, do, lse, B, H, Lq, Lk, dq, dk, dv, kpm=None
 # The fused encoder head is correct (tests/test_ops_gpu.py) but, as measured on the MI355X, not yet faster
 # than the three launches it replaces: its projection phase loads fragment-shaped operands (32 rows x 32 B per wave
 # instruction) straight from L2 and is bound by the texture-address path (20 of its 38 us).  Opt in with SEDT_FUSED_ENC=1.
+NO_RIDE = os.environ.get('SEDT_CO_NORIDE', '0') == '1'      # experiment: park all wgrads until the end of the backward, no riders
 STEM_DIRECT = os.environ.get('SEDT_STEM_DIRECT', '1') != '0'     # one-launch stem forward / backward (stem.hip)
 FUSED_ENC = os.environ.get('SEDT_FUSED_ENC', '0') == '1'
 
