@@ -513,11 +513,11 @@ def attention_bwd(dtype, q, k, v, o, do, lse, B, H, Lq, Lk, dq, dk, dv, kpm=None
     return dq, dk, dv
 
 
-# The fused encoder head is correct (tests/test_ops_gpu.py) but, as measured on the MI355X, not yet faster
-# than the three launches it replaces: its projection phase loads fragment-shaped operands (32 rows x 32 B per wave
-# instruction) straight from L2 and is bound by the texture-address path (20 of its 38 us).  Opt in with SEDT_FUSED_ENC=1.
 NO_RIDE = os.environ.get('SEDT_CO_NORIDE', '0') == '1'      # experiment: park all wgrads until the end of the backward, no riders
 STEM_DIRECT = os.environ.get('SEDT_STEM_DIRECT', '1') != '0'     # one-launch stem forward / backward (stem.hip)
+# The fused encoder head (LN1 + QKV + attention in one launch) is correct (tests/test_ops_gpu.py) and, as measured on the
+# MI355X, level with the three launches it replaces (30.6 vs 32.7 us no-grad, 32.2 in training form) but not ahead: one
+# workgroup per CU runs its phases strictly in sequence.  Opt in with SEDT_FUSED_ENC=1.
 FUSED_ENC = os.environ.get('SEDT_FUSED_ENC', '0') == '1'
 
 
