@@ -4,7 +4,7 @@
   matrix-core busy share (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): rocprofv3 sums GRBM_GUI_ACTIVE over the 8
   XCDs; calibrated on the layer4 3x3 conv: 1.18 M MFMAs x 32 cycles over 1024 SIMDs), VALU instructions per MFMA.
 usage: pmc_step_summary.py <gpurun_out/prof_<tag>> <profiles/rNN_step_c2.csv> <profiles/rNN_pmc_c2.json>
-Steps are split at the stem_im2col launch (one per forward of the supervised step)."""
+Steps are split at the stem forward launch (stem_pool_fwd, or stem_im2col in builds before the one-launch stem: one per forward of the supervised step)."""
 import collections
 import csv
 import glob
@@ -23,7 +23,7 @@ def short(n):
 
 def last_step(rows, key):
     rows = sorted(rows, key=key)
-    marks = [i for i, r in enumerate(rows) if 'stem_im2col' in r['Kernel_Name']]
+    marks = [i for i, r in enumerate(rows) if 'stem_im2col' in r['Kernel_Name'] or 'stem_pool_fwd' in r['Kernel_Name']]
     return rows[marks[-2]:marks[-1]]
 
 
