@@ -467,6 +467,13 @@ int sedt_box_transform(const float* amp, int64_t raw_stride, const void* aug, co
                        int frames, int F, int apply_log, int fill_mean, float fill_const, float* out, void* stream);
 int sedt_mixup(const float* x1, const float* x2, const void* jobs, int n_out, int64_t clip_elems, float* out, void* stream);
 
+/* SP-SEDT query patches (utilities/BoxTransforms.py:315-360, Query.transform_label; boxes from DataLoad.py:57-77 are turned into
+ * row ranges on the host): for each of n_patches jobs {clip, s_idx, e_idx, 0} (int32 x 4, device memory) crop rows [s_idx, e_idx)
+ * of data f32 [B][T][F], min-max normalise, quantise to 8 bits, resize to 128 rows with Pillow's bilinear resampling arithmetic,
+ * de-normalise -> out f32 [n_patches][128][F], bit-identical to the reference pipeline; fixed != 0: copy the 128 rows as they are
+ * (fixed_patch_size). */
+int sedt_query_patches(const float* data, int B, int T, int F, const void* jobs, int n_patches, int fixed, float* out, void* stream);
+
 /* ------------------------------------------------------------------ host-side matching (sedt/matcher.py:95)
  * HOST pointers.  cost [nlayers][nclips][Q][Nt] f32; clip b owns columns [col_off[b], col_off[b]+ncols[b]).
  * assign [nlayers][nclips][Q]: index (within the clip) of the target matched to query q, or -1.

@@ -129,7 +129,103 @@ __global__ __launch_bounds__(256) void mixup_kernel(const float* __restrict__ x1
   }
 }
 
+// ---- SP-SEDT query patches (reference utilities/BoxTransforms.py:315-360, Query.transform_label): crop rows [s, e) of a
+// transformed clip, min-max normalise to [0, 1], quantise to 8 bits (torchvision ToPILImage: x 255, truncated), resize to 128
+// rows with PIL's bilinear resampling, back to float (/ 255) and de-normalise.  Only the vertical pass of Pillow's
+// ImagingResample runs (the mel axis keeps its 64 bands): triangle filter of support 1 stretched by the scale when shrinking,
+// double-precision weights normalised per output row, rounded to 22-bit fixed point, int32 accumulation with a half-unit
+// bias, clipped to [0, 255] (Resample.c).  The float steps use explicitly rounded intrinsics so nothing is contracted into
+// an FMA: the result is bit-identical to the reference pipeline.  One workgroup per patch, the 8-bit crop lives in LDS.
+struct PatchJob {              // mirrors utilities/transforms.py (4 x int32 per patch)
+  int32_t clip, s_idx, e_idx, pad_;
+};
+
+__global__ __launch_bounds__(1024) void query_patch_kernel(const float* __restrict__ data, int T, int F, const PatchJob* __restrict__ jobs,
+                                                           int fixed, float* __restrict__ out) {
+  // HIP's __fmul_rn / __fadd_rn are inline functions compiled with contraction allowed: after inlining the backend still fuses
+  // them into one FMA (an ulp off the reference's separately rounded mul and add).  Plain operators under this pragma carry no
+  // contract flag.
+#pragma clang fp contract(off)
+  extern __shared__ unsigned char code[];            // [h][F] uint8, then 32 floats of reduction scratch (4-byte aligned)
+  const PatchJob j = jobs[blockIdx.x];
+  const int t = threadIdx.x, h = j.e_idx - j.s_idx;
+  const float* src = data + ((long)j.clip * T + j.s_idx) * F;
+  float* dst = out + (long)blockIdx.x * 128 * F;
+  if (fixed) {                                       // fixed_patch_size: the 128 rows as they are
+    for (int i = t; i < 128 * F; i += 1024) dst[i] = src[i];
+    return;
+  }
+  float* red = reinterpret_cast<float*>(code + (((long)h * F + 15) & ~15L));
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = t; i < h * F; i += 1024) {
+    const float v = src[i];
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+  mx = block_max(mx, red);
+  mn = -block_max(-mn, red);
+  const float range = mx - mn;
+  for (int i = t; i < h * F; i += 1024)
+    code[i] = (unsigned char)(int)(((src[i] - mn) / range) * 255.f);
+  __syncthreads();
+  const double scale = (double)h / 128.0;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 1.0 * filterscale, ss = 1.0 / filterscale;
+  for (int i = t; i < 128 * F; i += 1024) {
+    const int yy = i / F, col = i - yy * F;
+    int q;
+    if (h == 128) {
+      q = code[i];                                   // same size: Pillow copies
+    } else {
+      const double center = (yy + 0.5) * scale;
+      int ymin = (int)(center - support + 0.5);
+      if (ymin < 0) ymin = 0;
+      int ymax = (int)(center + support + 0.5);
+      if (ymax > h) ymax = h;
+      ymax -= ymin;
+      double ww = 0.0;
+      for (int y = 0; y < ymax; ++y) {
+        double x = ((double)(y + ymin) - center + 0.5) * ss;
+        x = x < 0.0 ? -x : x;
+        ww += x < 1.0 ? 1.0 - x : 0.0;
+      }
+      int acc = 1 << 21;
+      for (int y = 0; y < ymax; ++y) {
+        double x = ((double)(y + ymin) - center + 0.5) * ss;
+        x = x < 0.0 ? -x : x;
+        double w = x < 1.0 ? 1.0 - x : 0.0;
+        if (ww != 0.0) w = w / ww;
+        const double kq = w * 4194304.0;
+        acc += (int)code[(ymin + y) * F + col] * (int)(0.5 + kq);
+      }
+      q = acc >> 22;
+      q = q < 0 ? 0 : (q > 255 ? 255 : q);
+    }
+    const float back = (float)q / 255.f;
+    const float scaled = back * range;
+    dst[i] = scaled + mn;
+  }
+}
+
 }  // namespace sedt
+
+extern "C" int sedt_query_patches(const float* data, int B, int T, int F, const void* jobs, int n_patches, int fixed, float* out,
+                                  void* stream) {
+  using namespace sedt;
+  SEDT_REQUIRE(data && jobs && out, "query_patches: null pointer");
+  SEDT_REQUIRE(B >= 1 && T >= 1 && F >= 1 && n_patches >= 0, "query_patches: B=%d T=%d F=%d n=%d", B, T, F, n_patches);
+  const size_t lds = (((size_t)T * F + 15) & ~(size_t)15) + 32 * sizeof(float);
+  SEDT_REQUIRE(lds <= 160 * 1024, "query_patches: a crop of up to %d x %d bytes does not fit the 160 KB LDS", T, F);
+  if (n_patches == 0) return 0;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(query_patch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL(query_patch_kernel, dim3(n_patches), dim3(1024), lds, reinterpret_cast<hipStream_t>(stream), data, T, F,
+                     reinterpret_cast<const PatchJob*>(jobs), fixed, out);
+  return check_launch("query_patches");
+}
 
 extern "C" int sedt_box_transform(const float* amp, int64_t raw_stride, const void* aug, const double* mean, const double* stdv,
                                   int B, int frames, int F, int apply_log, int fill_mean, float fill_const, float* out, void* stream) {

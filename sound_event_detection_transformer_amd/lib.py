@@ -131,6 +131,7 @@ SIGNATURES = {
     'sedt_sum_f32': (_i, [_vp, _i, _vp, _vp]),
     'sedt_box_transform': (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     'sedt_mixup': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    'sedt_query_patches': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     'sedt_postprocess': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     'sedt_pseudo_labels': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'sedt_hungarian_batch': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),

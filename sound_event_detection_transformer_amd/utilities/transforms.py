@@ -85,3 +85,70 @@ class DeviceBoxTransform(object):
         L.check(L.load().sedt_box_transform(L.p(amp), stride, L.p(aug), L.p(self.mean), L.p(self.std), B, self.frames, self.F,
                                             int(self.apply_log), 1, 0.0, L.p(out), L.stream_ptr()), 'box_transform')
         return out
+
+
+# ------------------------------------------------------------------------------------------------ SP-SEDT query patches
+_JOB = np.dtype([('clip', np.int32), ('s_idx', np.int32), ('e_idx', np.int32), ('pad', np.int32)])
+
+
+def random_patch_boxes(t, num_patches, mu=0.2, sigma=0.26, fixed_patch_size=False):
+    """the (centre, length) patch boxes of one clip of ``t`` frames, drawn with np.random in the reference's order
+    (data_utils/DataLoad.py:57-77, DataLoadDf.get_random_patch: 5 P normal lengths filtered to [0.05, 0.8), then one integer
+    centre per kept length)"""
+    if fixed_patch_size:
+        l = np.asarray([128 / t] * num_patches)
+    else:
+        l = mu + sigma * np.random.randn(5 * num_patches)
+        l = l[[0.05 <= i < 0.8 for i in l]][:num_patches]
+    c = [np.random.randint(int(t * i / 2) + 1, int(t * (1 - i / 2))) / t for i in l]
+    s, e = (c - l / 2) * t, (c + l / 2) * t
+    s = [int(i) for i in s]
+    e = [i + 128 for i in s] if fixed_patch_size else [int(i) for i in e]
+    return [[(i + j) / (2 * t), (j - i) / t] for i, j in zip(s, e)]
+
+
+class DeviceQuery(object):
+    """reference utilities/BoxTransforms.py:315-360 (``Query``, the last transform of the SP-SEDT pipeline) for a whole batch in
+    ONE launch: every box of every clip is cropped from the transformed clip, min-max normalised, quantised to 8 bits, resized
+    to (128, F) with Pillow's bilinear arithmetic and de-normalised - bit-identical to the reference's PIL round trip
+    (sedt_query_patches).  The row range of a box is computed on the host exactly as the reference does (float32 box values,
+    ``int(s * t)``)."""
+
+    def __init__(self, fixed_patch_size=False):
+        self.fixed = bool(fixed_patch_size)
+
+    def rows(self, box, t):
+        c, l = np.float32(box[0]), np.float32(box[1])
+        s, e = c - l / 2, c + l / 2
+        s_idx, e_idx = int(s * t), int(e * t)
+        if self.fixed:
+            e_idx = min(t, s_idx + 128)
+            s_idx = e_idx - 128
+        elif s_idx >= e_idx:                                   # make sure the patch is not empty
+            s_idx, e_idx = max(0, s_idx - 1), min(t, e_idx + 1)
+        return s_idx, e_idx
+
+    def __call__(self, data, boxes):
+        """data (B, 1, T, F) f32 on the GPU (output of DeviceBoxTransform), boxes: per clip a (P, 2) array / tensor of (centre,
+        length).  Returns patches (B, P, 1, 128, F) f32 - what the reference's collate stacks from ``label['patches']``."""
+        if not data.is_cuda:
+            raise RuntimeError('DeviceQuery runs on the MI355X HIP path only (no CPU fallback)')
+        B, _, T, F = data.shape
+        data = data.contiguous().float()
+        P = len(boxes[0])
+        jobs = np.zeros((B * P,), _JOB)
+        k = 0
+        for b in range(B):
+            bx = boxes[b].detach().cpu().numpy() if torch.is_tensor(boxes[b]) else np.asarray(boxes[b])
+            assert len(bx) == P, 'every clip carries the same number of patch boxes'
+            for box in bx.astype(np.float32):
+                s, e = self.rows(box, T)
+                if not (0 <= s < e <= T) or (self.fixed and e - s != 128):
+                    raise ValueError(f'patch box {box.tolist()} gives rows [{s}, {e}) outside a clip of {T} frames')
+                jobs[k] = (b, s, e, 0)
+                k += 1
+        jd = torch.from_numpy(jobs.view(np.int32)).to(data.device, non_blocking=True)
+        out = torch.empty((B, P, 1, 128, F), device=data.device, dtype=torch.float32)
+        L.check(L.load().sedt_query_patches(data.data_ptr(), B, T, F, jd.data_ptr(), B * P, int(self.fixed), out.data_ptr(),
+                                            L.stream_ptr()), 'query_patches')
+        return out

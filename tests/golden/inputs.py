@@ -58,3 +58,14 @@ def semi_batch():
     return x_t, x_s, targets
 
 
+
+
+QUERY = dict(T=496, num_patches=10, seeds=(501, 502), short_clip_T=96)
+
+
+def query_clips():
+    """normalised (1, T, 64) clips the SP-SEDT patch cropper works on: two full-length clips and a short one (its longest
+    boxes are UP-sampled to 128 frames)"""
+    c = QUERY
+    return [clip_input(1, c['T'], c['seeds'][0])[0] * 1.7 - 0.3, clip_input(1, c['T'], c['seeds'][1])[0] * 0.6 + 2.0,
+            clip_input(1, c['short_clip_T'], 503)[0]]

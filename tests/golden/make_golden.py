@@ -605,6 +605,90 @@ def g13_transforms_mixup(out, rmixup, rbt):
     print('G13 ok', res['params'][:, [0, 3, 6]].tolist(), res['mix_nlabels'], res['lu_nlabels'])
 
 
+def install_pil_transforms_shim(rbt):
+    """torchvision.transforms is absent from this image; Query (BoxTransforms.py:315-330) composes ToPILImage -> Resize((128, 64))
+    -> ToTensor.  These stand-ins restate torchvision's documented behaviour of exactly those three calls on a (1, H, W) float
+    tensor over the REAL Pillow (``pic.mul(255).byte()`` -> mode 'L' image; ``img.resize(size[::-1], BILINEAR)``; uint8 -> float
+    / 255): the resampling arithmetic in the fixture is Pillow's own, the three wrapper lines are the unpinned part."""
+    from PIL import Image
+
+    class Compose(object):
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class ToPILImage(object):
+        def __call__(self, pic):
+            assert pic.dim() == 3 and pic.shape[0] == 1
+            return Image.fromarray(pic.mul(255).byte().numpy()[0], mode='L')
+
+    class Resize(object):
+        def __init__(self, size):
+            self.size = size
+
+        def __call__(self, img):
+            return img.resize(tuple(self.size[::-1]), Image.BILINEAR)
+
+    class ToTensor(object):
+        def __call__(self, img):
+            a = np.array(img, np.uint8, copy=True)
+            return torch.from_numpy(a).view(a.shape[0], a.shape[1], 1).permute(2, 0, 1).contiguous().float().div(255)
+
+    tv = types.ModuleType('torchvision.transforms')
+    tv.Compose, tv.ToPILImage, tv.Resize, tv.ToTensor = Compose, ToPILImage, Resize, ToTensor
+    rbt.transforms = tv
+
+
+def g14_query_patches(out, rbt):
+    """G14: the reference's own SP-SEDT patch pipeline - DataLoadDf.get_random_patch (DataLoad.py:57-77) draws the boxes,
+    Query.transform_label (BoxTransforms.py:332-360) crops / min-max normalises / resizes through Pillow / de-normalises.
+    Stored per patch: the crop rows, (min, max), the resized uint8 image (the float patch is code / 255 * (max - min) + min,
+    re-formed by the tests) and an f32 digest of the reference's float output."""
+    import data_utils.DataLoad as rdl
+    from inputs import QUERY, query_clips
+    install_pil_transforms_shim(rbt)
+    res = {}
+    for ci, data in enumerate(query_clips()):
+        t = data.shape[1]
+        for mode, fixed in (('free', False), ('fixed', True)):
+            if fixed and t < 128:
+                continue
+            fake = types.SimpleNamespace(fixed_patch_size=fixed, num_patches=QUERY['num_patches'], mu=0.2, sigma=0.26)
+            np.random.seed(900 + 10 * ci + int(fixed))
+            boxes = rdl.DataLoadDf.get_random_patch(fake, np.zeros((t, 64), np.float32))
+            label = {'patches': None, 'boxes': torch.tensor(boxes, dtype=torch.float32)}
+            _, lab = rbt.Query(fixed).transform_label((data.clone(), label))
+            patches = lab['patches']
+            assert patches.shape == (QUERY['num_patches'], 1, 128, 64), patches.shape
+            key = f'c{ci}_{mode}'
+            res[key + '_boxes'] = np.asarray(boxes, np.float64)
+            res[key + '_sum'] = np.asarray([float(p.double().sum()) for p in patches])
+            res[key + '_sample'] = npy(patches[:, 0, ::16, ::8])
+            if fixed:
+                continue
+            rows, mm, codes = [], [], []
+            for b, p in zip(label['boxes'], patches):
+                c, l = b.numpy()
+                s, e = c - l / 2, c + l / 2
+                s_idx, e_idx = int(s * t), int(e * t)
+                if s_idx >= e_idx:
+                    s_idx, e_idx = max(0, s_idx - 1), min(t, e_idx + 1)
+                crop = data[:, s_idx:e_idx, :]
+                mn, mx = crop.min(), crop.max()
+                code = torch.round((p[0] - mn) / (mx - mn) * 255).to(torch.uint8)
+                assert torch.equal(code.float().div(255) * (mx - mn) + mn, p[0]), 'code does not reproduce the reference patch'
+                rows.append([s_idx, e_idx])
+                mm.append([float(mn), float(mx)])
+                codes.append(code.numpy())
+            res[key + '_rows'], res[key + '_minmax'], res[key + '_code'] = np.asarray(rows), np.asarray(mm, np.float32), np.stack(codes)
+    np.savez_compressed(os.path.join(out, 'g14_query_patches.npz'), **res)
+    print('G14 ok', {k: v.shape for k, v in res.items() if k.endswith('_rows')}, res['c2_free_rows'][:, 1] - res['c2_free_rows'][:, 0])
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='', help='comma list of fixtures to (re)generate, e.g. g9,g12 (default: all)')
@@ -629,8 +713,10 @@ if __name__ == '__main__':
         g9_criterion_variants(out, rsedt)
     if on('g10'):
         g10_postprocess(out, rsedt)
-    if want & {'g11', 'g12', 'g13'} or not want:
+    if want & {'g11', 'g12', 'g13', 'g14'} or not want:
         rengine, rmixup, rbt = import_reference_engine()
+        if on('g14'):
+            g14_query_patches(out, rbt)
         if on('g11'):
             g11_pseudo_labels(out, rsedt, rengine)
         if on('g13'):

@@ -210,3 +210,38 @@ def test_g13_mixup(golden_dir):
         np.testing.assert_array_equal(t['labels'].numpy(), _rows(g['lu_labels'])[b])
         r = t['ratio'].numpy() if 'ratio' in t else np.zeros(0, np.float32)
         np.testing.assert_allclose(r, _rows(g['lu_ratio'])[b], rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------- G14 SP-SEDT query patches
+def test_g14_query_patches_oracle_matches_reference_and_pillow():
+    """the oracle's restatement of DataLoadDf.get_random_patch + Query.transform_label against the fixture the reference's own
+    code produced (boxes bit-exact, resized uint8 images bit-exact, float patches bit-exact), and its restatement of Pillow's
+    bilinear resampling against the real Pillow on sizes that shrink, keep and enlarge"""
+    from oracle import transforms_oracle as T
+    from golden.inputs import QUERY, query_clips
+    g = np.load(os.path.join(GOLDEN, 'g14_query_patches.npz'))
+    for ci, data in enumerate(query_clips()):
+        t = data.shape[1]
+        for mode, fixed in (('free', False), ('fixed', True)):
+            key = f'c{ci}_{mode}'
+            if key + '_boxes' not in g.files:
+                assert fixed and t < 128
+                continue
+            np.random.seed(900 + 10 * ci + int(fixed))
+            boxes = T.random_patch_boxes(t, QUERY['num_patches'], fixed_patch_size=fixed)
+            assert np.array_equal(np.asarray(boxes, np.float64), g[key + '_boxes'])
+            b32 = np.asarray(boxes, np.float32)
+            patches, codes, mm = T.query_patches(data.numpy(), b32, fixed)
+            assert patches.shape == (QUERY['num_patches'], 1, 128, 64)
+            assert np.array_equal(patches[:, 0, ::16, ::8], g[key + '_sample'])
+            np.testing.assert_allclose([p.astype(np.float64).sum() for p in patches], g[key + '_sum'], rtol=1e-12)
+            if not fixed:
+                assert np.array_equal(np.asarray([T.patch_rows(b, t) for b in b32]), g[key + '_rows'])
+                assert np.array_equal(codes, g[key + '_code'])
+                assert np.array_equal(np.asarray(mm, np.float32), g[key + '_minmax'])
+    from PIL import Image
+    rng = np.random.RandomState(5)
+    for h in (1, 2, 3, 7, 25, 64, 127, 128, 129, 200, 397, 496):
+        img = rng.randint(0, 256, (h, 64)).astype(np.uint8)
+        ref = np.array(Image.fromarray(img, mode='L').resize((64, 128), Image.BILINEAR))
+        assert np.array_equal(T.pil_resize_rows(img, 128), ref), h
