@@ -222,6 +222,12 @@ int sedt_pack_conv(const float* w, int Cout, int Cin, int taps, const float* bns
  * col[B*Ho*Wo][128] = [x taps | 0 | in-bounds indicators | 0]. */
 int sedt_stem_prep(const float* w0, const float* b0, const float* w1, void* wcat, int dtype, void* stream);
 int sedt_stem_im2col(const float* x, void* col, int B, int H, int W, int dtype, void* stream);
+/* Direct 3x3 convolution, stride 1, pad 1, over NHWC bf16 tokens x [B*H*W][C] with C = 64 channels in and out on a W = 16 wide
+ * map (conv2 of the layer1 Bottlenecks, torchvision resnet50 behind sedt/backbone.py:98-111): y = act(conv(x, w) * scale + bias),
+ * or, with flip = 1 and w = the dgrad pack [Cin][taps][Cout] (BN scale folded in), the input gradient masked by (mask > 0).
+ * w: bf16 [64 out][9 taps][64 in]; scale / bias / mask may be null; relu: 0 / 1. */
+int sedt_conv3x3_c64(const void* x, const void* w, int flip, const float* scale, const float* bias, int relu, const void* mask, void* y,
+                     int B, int H, int W, int C, void* stream);
 /* The whole stem in one launch (bf16, W = 64 mel bands): conv0 o conv1 7x7/s2 o FrozenBN (scale, bias) o ReLU o max-pool 3x3/s2
  * (sedt/backbone.py:98-111 + torchvision stem) from x f32 [B][H][64] to pool bf16 [B*Hp*16][64] + argmax bytes idx (may be
  * null); wcat = sedt_stem_prep's bf16 [64][128]; s1_out (optional, tests): the un-pooled activation [B*Ho*32][64]. */

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsedt_hip.so')
-SOURCES = ['igemm.hip', 'igemm2.hip', 'igemm3.hip', 'wgrad2.hip', 'wgrad3.hip', 'wgrad4.hip', 'misc.hip', 'stem.hip', 'norm_attn.hip', 'attn_mfma.hip', 'criterion.hip', 'postproc.hip', 'input.hip', 'skinny.hip', 'host.cpp']
+SOURCES = ['igemm.hip', 'igemm2.hip', 'igemm3.hip', 'wgrad2.hip', 'wgrad3.hip', 'wgrad4.hip', 'misc.hip', 'stem.hip', 'conv3x3_c64.hip', 'norm_attn.hip', 'attn_mfma.hip', 'criterion.hip', 'postproc.hip', 'input.hip', 'skinny.hip', 'host.cpp']
 
 
 def _stale():

@@ -108,6 +108,7 @@ SIGNATURES = {
     'sedt_stem_prep': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     'sedt_stem_im2col': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'sedt_stem_conv0_grad': (_i, [_vp, _vp, _vp, _vp, _vp]),
+    'sedt_conv3x3_c64': (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     'sedt_stem_pool_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'sedt_stem_pool_wgrad_slabs': (_i, [_i, _i]),
     'sedt_stem_pool_wgrad': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -240,11 +240,28 @@ def linear_group(dtype, items):
     return outs
 
 
+def _conv3_c64_ok(dtype, t, g, ep, out):
+    """envelope of the direct 3x3 kernel (csrc/conv3x3_c64.hip): the layer1 conv2 geometry, plain epilogues"""
+    return (CONV3_DIRECT and PROFILE is None and dtype == BF16 and g.Ci == 64 and g.Co == 64 and g.KH == 3 and g.KW == 3
+            and g.sh == 1 and g.sw == 1 and g.ph == 1 and g.pw == 1 and g.dh == 1 and g.dw == 1 and g.Wi == 16
+            and t.stride(0) == 64 and out.stride(0) == 64 and set(ep) <= {'scale', 'bias', 'act', 'mask', 'ldm', 'tile'}
+            and ep.get('act', 0) in (0, ACT_RELU) and tuple(ep.get('tile', (0, 0))) == (0, 0)
+            and (ep.get('mask') is None or (ep.get('ldm', 64) == 64 and ep.get('act', 0) == 0)))
+
+
+def _conv3_c64(t, B, g, w, flip, out, ep):
+    L.check(L.load().sedt_conv3x3_c64(_p(t), _p(w), flip, _p(ep.get('scale')), _p(ep.get('bias')), 1 if ep.get('act', 0) == ACT_RELU else 0,
+                                      _p(ep.get('mask')), _p(out), B, g.Hi, g.Wi, 64, L.stream_ptr()), 'conv3x3_c64')
+    return out
+
+
 def conv_fwd(dtype, x, B, g, wf, out=None, **ep):
     """NHWC conv forward: x [B*Hi*Wi, Ci] (row stride = x.stride(0)), wf packed [Co][taps][Ci]"""
     M = B * g.Ho * g.Wo
     if out is None:
         out = torch.empty((M, g.Co), device=x.device, dtype=TORCH_DTYPE[dtype])
+    if _conv3_c64_ok(dtype, x, g, ep, out):
+        return _conv3_c64(x, B, g, wf, 0, out, ep)
     conv = None if g.plain else _geom_tuple(g)
     igemm(dtype, M, g.Co, g.taps * g.Ci, x, x.stride(0), wf, g.taps * g.Ci, out, out.stride(0), conv=conv, **ep)
     return out
@@ -255,6 +272,8 @@ def conv_dgrad(dtype, dy, B, g, wb, out=None, **ep):
     M = B * g.Hi * g.Wi
     if out is None:
         out = torch.empty((M, g.Ci), device=dy.device, dtype=TORCH_DTYPE[dtype])
+    if _conv3_c64_ok(dtype, dy, g, ep, out) and 'scale' not in ep and 'bias' not in ep:
+        return _conv3_c64(dy, B, g, wb, 1, out, ep)       # the input gradient of a stride-1 3x3 conv is the same conv, taps flipped
     conv = None if g.plain else _geom_tuple(g, transposed=True)
     igemm(dtype, M, g.Ci, g.taps * g.Co, dy, dy.stride(0), wb, g.taps * g.Co, out, out.stride(0), conv=conv,
           transposed=0 if g.plain else 1, **ep)
@@ -514,6 +533,7 @@ def attention_bwd(dtype, q, k, v, o, do, lse, B, H, Lq, Lk, dq, dk, dv, kpm=None
 
 
 NO_RIDE = os.environ.get('SEDT_CO_NORIDE', '0') == '1'      # experiment: park all wgrads until the end of the backward, no riders
+CONV3_DIRECT = os.environ.get('SEDT_CONV3_DIRECT', '1') != '0'   # direct 3x3 kernel for the layer1 conv2 geometry (conv3x3_c64.hip)
 STEM_DIRECT = os.environ.get('SEDT_STEM_DIRECT', '1') != '0'     # one-launch stem forward / backward (stem.hip)
 # The fused encoder head (LN1 + QKV + attention in one launch) is correct (tests/test_ops_gpu.py) and, as measured on the
 # MI355X, level with the three launches it replaces (30.6 vs 32.7 us no-grad, 32.2 in training form) but not ahead: one

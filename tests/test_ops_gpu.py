@@ -94,6 +94,10 @@ def _nhwc(x_nchw):
     return x_nchw.permute(0, 2, 3, 1).contiguous()
 
 
+def _nchw(tok, B, H, W):
+    return tok.view(B, H, W, -1).permute(0, 3, 1, 2)
+
+
 @pytest.mark.parametrize('dt', [F32, BF16])
 @pytest.mark.parametrize('cfg', CONVS)
 def test_conv_fwd_dgrad_wgrad(ops, dt, cfg):
@@ -677,3 +681,41 @@ def test_previous_generation_kernels_still_pass_the_same_parity_tests():
                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert ' passed' in r.stdout
+
+
+@pytest.mark.parametrize('B,H', [(2, 125), (3, 124), (1, 16), (2, 7), (5, 33)])
+def test_direct_conv3x3_c64_forward_and_dgrad(ops, B, H):
+    """csrc/conv3x3_c64.hip (layer1 conv2 geometry: 64 -> 64 channels, 16-wide map) against F.conv2d and against the implicit-GEMM
+    kernel it replaces, forward (FrozenBN scale / bias + ReLU) and input gradient (taps flipped, ReLU mask of the consumer)"""
+    dt, W, C = BF16, 16, 64
+    g = ops.ConvGeom(H, W, C, C, 3, 1, 1, 1)
+    x = randn(B, C, H, W)
+    w = randn(C, C, 3, 3) / math.sqrt(C * 9)
+    sc, bi = torch.rand(C, generator=G) + 0.5, randn(C) * 0.1
+    xd = dev(_nhwc(x).reshape(-1, C), dt)
+    wf, wb = ops.pack_conv(dt, w.cuda(), sc.cuda())
+    assert ops.CONV3_DIRECT
+    y = ops.conv_fwd(dt, xd, B, g, wf, scale=sc.cuda(), bias=bi.cuda(), act=ops.ACT_RELU)
+    ref = F.relu(F.conv2d(rnd(x, dt), rnd(w, dt), padding=1) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1))
+    close(y, _nhwc(ref).reshape(-1, C), dt)
+    y0 = ops.conv_fwd(dt, xd, B, g, wf)                                    # no epilogue operands at all
+    close(y0, _nhwc(F.conv2d(rnd(x, dt), rnd(w, dt), padding=1)).reshape(-1, C), dt)
+    gy = randn(B, C, H, W)
+    gyd = dev(_nhwc(gy).reshape(-1, C), dt)
+    msrc = dev(_nhwc(randn(B, C, H, W)).reshape(-1, C), dt)
+    dx = ops.conv_dgrad(dt, gyd, B, g, wb, mask=msrc, ldm=C)
+    wsc = rnd(w * sc.view(-1, 1, 1, 1), dt)                                 # the dgrad pack carries the BN scale
+    refdx = F.conv_transpose2d(rnd(gy, dt), wsc, padding=1) * (_nchw(msrc.float().cpu(), B, H, W) > 0)
+    close(dx, _nhwc(refdx).reshape(-1, C), dt)
+    dx0 = ops.conv_dgrad(dt, gyd, B, g, wb)
+    close(dx0, _nhwc(F.conv_transpose2d(rnd(gy, dt), wsc, padding=1)).reshape(-1, C), dt)
+    # against the implicit GEMM on the same operands: same bf16 products, f32 accumulation in a different order
+    ops.CONV3_DIRECT = False
+    try:
+        yi = ops.conv_fwd(dt, xd, B, g, wf, scale=sc.cuda(), bias=bi.cuda(), act=ops.ACT_RELU)
+        dxi = ops.conv_dgrad(dt, gyd, B, g, wb, mask=msrc, ldm=C)
+    finally:
+        ops.CONV3_DIRECT = True
+    assert (y.float() - yi.float()).abs().max().item() <= 2e-2 * yi.float().abs().max().item()
+    assert (dx.float() - dxi.float()).abs().max().item() <= 2e-2 * dxi.float().abs().max().item()
+    assert torch.equal(ops.conv_fwd(dt, xd, B, g, wf, scale=sc.cuda(), bias=bi.cuda(), act=ops.ACT_RELU), y)     # reproducible
