@@ -120,6 +120,10 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const bf16_t* __restri
   }
 }
 
+// (Measured and dropped: the same kernel with all 72 weight fragments in registers - 288 of the unified 512 - and 4 waves per
+//  workgroup: no LDS traffic for B at all, but one wave per SIMD cannot hide the A-fragment and epilogue latencies: 24.0 us
+//  forward / 29.6 us dgrad against 17.7 / 21.5 us for this version.)
+
 }  // namespace sedt
 
 extern "C" int sedt_conv3x3_c64(const void* x, const void* w, int flip, const float* scale, const float* bias, int relu,
