@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic work per clip, fwd + bwd, 2*MAC, wgrad skipped for frozen tensors
-FLOP_PER_CLIP = {'c2': 27.37e9, 'c3': 30.00e9, 'c4': 35.63e9}
+FLOP_PER_CLIP = {'c2': 27.37e9, 'c3': 30.00e9, 'c4': 35.63e9, 'eval': 9.458e9}      # SURVEY.md 8(d); eval = C2 forward only
 FLOP_C5_STEP_64 = (32 * 30.00 + 32 * 10.33 + 32 * 30.00) * 1e9      # labelled fwd+bwd, teacher fwd, student fwd+bwd
 MFMA_PEAK = {'bf16': 2.5e15, 'f32': 157.3e12}                          # dense peaks, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
@@ -40,7 +40,9 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c4', 'c5'])
+    ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c4', 'c5', 'eval'],
+                    help="BASELINE.json configuration (default c2 = the headline metric); 'eval' = the validation body of "
+                         "engine.get_sedt_predictions at the C2 shape (an extra, not a BASELINE metric)")
     ap.add_argument('--batch', type=int, default=None, help='clips per GPU (default: the config\'s own)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -206,6 +208,24 @@ def build_workload(args, dev, rank, world):
                 f"Hungarian matching ({'host' if (args.host_matching or args.no_graph) else 'device'}) + SetCriterion + bwd + clip 0.1 + "
                 f"AdamW, dropout 0.1" + (" [model-only timing]" if args.model_only else ""))
         return step, B, FLOP_PER_CLIP[cfg] * B, what, graphed, extras
+    if cfg == 'eval':
+        from sound_event_detection_transformer_amd.engine import GraphedPredictStep
+        B = args.batch or 64
+        model, criterion, post = build_model(default_args(enc_layers=3, num_queries=10, dec_at=True, dropout=0.1))
+        model.load_state_dict(seeded_state_dict(model.state_dict(), 2020))
+        model.to(dev).eval()
+        criterion.to(dev)
+        x, targets = synthetic_batch(B, 500, seed, dev)
+        for t in targets:
+            t['orig_size'] = torch.tensor(10.0, device=dev)
+        g = GraphedPredictStep(model, criterion, post['bbox'], x, targets, fusion_strategy=(1,))
+        extras.update(stepper=g, model=model)
+
+        def step():
+            g(x, targets)
+        what = (f"validation body of engine.get_sedt_predictions, URBAN-SED SEDT enc_layers=3 dec_at num_queries=10 B={B}/GPU: no-grad "
+                f"forward + device matching + SetCriterion (logged losses) + audio tags + PostProcess (fusion strategy 1), one HIP graph")
+        return step, B, FLOP_PER_CLIP['eval'] * B, what, True, extras
     if cfg == 'c4':
         B, P = args.batch or 200, 10
         model, criterion, _ = build_model(default_args(enc_layers=6, num_queries=20, dec_at=False, self_sup=True, lr_backbone=0.0,
@@ -538,7 +558,8 @@ def main():
                 kernels = [{"error": repr(e)}]
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
         value = world * clips * args.steps / elapsed
-        out = {"metric": f"audio clips/sec training throughput (B={clips}, 10s@64-mel)", "value": round(value, 2),
+        kind = "inference (validation step)" if args.config == 'eval' else "training"
+        out = {"metric": f"audio clips/sec {kind} throughput (B={clips}, 10s@64-mel)", "value": round(value, 2),
                "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

@@ -415,6 +415,70 @@ def _tensors(x):
     return x.tensors if hasattr(x, 'tensors') else x
 
 
+# ---------------------------------------------------------------------------------------------------- validation / prediction
+def predict_step(model, criterion, postprocessor, batch_input, targets, fusion_strategy=(1,), at=True, threshold=0.5):
+    """The per-batch body of reference engine.get_sedt_predictions (engine.py:244-285) on the device: no-grad forward, the
+    losses the reference logs (criterion with strong_mask = the whole batch), the thresholded audio tags, and
+    ``postprocessors['bbox']`` once per fusion strategy.  Returns (loss_dict, audio_tags or None, {at_m: (scores [B,Q], labels
+    [B,Q], boxes [B,Q,2] in seconds)}); the host-side decoding into event lists (decoder.decode_strong, pandas) stays the
+    caller's, as in the reference."""
+    with torch.no_grad():
+        outputs = model(batch_input)
+        B = outputs['pred_logits'].shape[0]
+        loss_dict, _ = criterion(outputs, targets, None, slice(B))
+        sizes = torch.stack([t['orig_size'] for t in targets], dim=0)
+        audio_tags = (outputs['at'] > 0.5).long() if at else None
+        if at:
+            assert 'at' in outputs
+        results = {m: postprocessor.batched(outputs, sizes, audio_tags=audio_tags, at_m=m, threshold=threshold) for m in fusion_strategy}
+    return loss_dict, audio_tags, results
+
+
+class GraphedPredictStep(object):
+    """predict_step as ONE HIP graph (forward, device Hungarian matching + fused losses for the logged validation losses, audio
+    tags, PostProcess for every fusion strategy): per batch the host refreshes the static input / target tables and replays;
+    the outputs are static tensors (overwritten by the next call).  Shapes are static like GraphedTrainStep's.  Weight packs
+    follow parameter-pointer swaps (an EMA teacher evaluated through ``ema.apply_shadow()`` gets its own pack plan)."""
+
+    def __init__(self, model, criterion, postprocessor, example_input, example_targets, fusion_strategy=(1,), at=True, threshold=0.5,
+                 max_targets=32, warmup=2):
+        from .sedt import TargetTables
+        self.model, self.criterion, self.post = model, criterion, postprocessor
+        self.fusion, self.at, self.threshold = tuple(fusion_strategy), at, threshold
+        dev = example_input.device
+        self.static_x = example_input.clone()
+        B = len(example_targets)
+        self.tables = TargetTables(B, B, B, dev, max_targets=max_targets, with_ratio=False).load(example_targets)
+        self.sizes = torch.stack([t['orig_size'] for t in example_targets], dim=0).to(dev).float().clone()
+        stream = train_stream(dev)
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream().wait_stream(stream)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=stream, **_CAPTURE):
+            self.out = self._body()
+        torch.cuda.synchronize()
+
+    def _body(self):
+        with torch.no_grad():
+            outputs = self.model(self.static_x)
+            dense = self.criterion.prepare_device(outputs, self.tables)
+            losses = self.criterion.compute(outputs, dense)
+            tags = (outputs['at'] > 0.5).long() if self.at else None
+            res = {m: self.post.batched(outputs, self.sizes, audio_tags=tags, at_m=m, threshold=self.threshold) for m in self.fusion}
+        return losses, tags, res
+
+    def __call__(self, batch_input, targets):
+        self.static_x.copy_(batch_input, non_blocking=True)
+        self.tables.load(targets)
+        self.sizes.copy_(torch.stack([t['orig_size'] for t in targets], dim=0), non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+
 def pseudo_label_tables(tea_outputs, classwise_threshold, orig_size, tables, counter=None, del_overlap=True):
     """engine.py:300-348 without leaving the device: teacher outputs -> the flat target tables (sedt.TargetTables) that the
     on-device matching reads.  ``orig_size``: clip duration in seconds (the minimum event length is 0.2 / orig_size)."""

@@ -456,3 +456,55 @@ def test_graph_sees_lr_changes_and_survives_eager_steps(pkg):
     d12 = (res['graph'][1][k] - res['graph'][0][k]).abs().mean().item()
     d23 = (res['graph'][2][k] - res['graph'][1][k]).abs().mean().item()
     assert d23 < 0.5 * d12                                            # the smaller learning rate took effect in the replay
+
+
+def test_predict_step_eager_and_graphed(pkg):
+    """the per-batch body of engine.get_sedt_predictions (engine.py:244-285): losses as the criterion gives them for the same
+    outputs, audio tags, PostProcess per fusion strategy equal to the oracle's PostProcess on the model's own outputs; the graphed
+    form returns the same tensors and follows new batches"""
+    runtime, sedt = pkg
+    from oracle.criterion_oracle import PostProcess as OraclePost
+    from sound_event_detection_transformer_amd.engine import predict_step, GraphedPredictStep
+    runtime.set_compute_dtype('f32')
+    runtime.manual_seed(5)
+    B = 6
+    model, crit, post = sedt.build_model(sedt.default_args(dropout=0.0))
+    model.load_state_dict(O.seeded_state_dict(model.state_dict(), 2020))
+    model.cuda().eval()
+    crit.cuda()
+    batches = []
+    for s in (41, 42):
+        x = torch.randn(B, 1, 500, 64, generator=torch.Generator().manual_seed(s)).cuda()
+        tg = synthetic_targets(B, s + 100, 10)
+        for i, t in enumerate(tg):
+            t['orig_size'] = torch.tensor(10.0 - 0.5 * i)
+        batches.append((x, _cuda_targets(tg)))
+    fusion = (1, 2, 3)
+    x, tg = batches[0]
+    losses, tags, res = predict_step(model, crit, post['bbox'], x, tg, fusion_strategy=fusion)
+    with torch.no_grad():
+        out = model(x)
+        ld, _ = crit(out, tg, None, slice(B))
+    for k in ld:
+        assert rel(losses[k], ld[k]) < 1e-6, k
+    assert torch.equal(tags, (out['at'] > 0.5).long())
+    cpu_out = {k: out[k].float().cpu() for k in ('pred_logits', 'pred_boxes')}
+    sizes = torch.stack([t['orig_size'] for t in tg]).cpu()
+    for m in fusion:
+        ref = OraclePost()(cpu_out, sizes, audio_tags=tags.cpu(), at_m=m)
+        sc, lb, bx = res[m]
+        for b in range(B):
+            assert torch.equal(lb[b].cpu(), ref[b]['labels'])
+            assert rel(sc[b], ref[b]['scores']) < 1e-5 and rel(bx[b], ref[b]['boxes']) < 1e-5
+    g = GraphedPredictStep(model, crit, post['bbox'], x, tg, fusion_strategy=fusion)
+    for xb, tb in batches[::-1] + batches:
+        gl, gt, gr = g(xb, tb)
+        el, et, er = predict_step(model, crit, post['bbox'], xb, tb, fusion_strategy=fusion)
+        torch.cuda.synchronize()
+        assert torch.equal(gt, et)
+        for k in el:
+            assert rel(gl[k], el[k]) < 1e-5, k
+        for m in fusion:
+            assert torch.equal(gr[m][1], er[m][1])
+            assert rel(gr[m][0], er[m][0]) < 1e-5 and rel(gr[m][2], er[m][2]) < 1e-5
+    runtime.set_compute_dtype('bf16')
