@@ -136,17 +136,27 @@ class DeviceQuery(object):
         B, _, T, F = data.shape
         data = data.contiguous().float()
         P = len(boxes[0])
+        bx = np.stack([(b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)).astype(np.float32) for b in boxes])
+        assert bx.shape == (B, P, 2), 'every clip carries the same number of (centre, length) patch boxes'
+        # the whole batch at once, in the float32 arithmetic of rows() (= the reference's box.numpy() scalars)
+        c, l = bx[..., 0], bx[..., 1]
+        half = l / np.float32(2)
+        s_idx = ((c - half) * np.float32(T)).astype(np.int64)
+        e_idx = ((c + half) * np.float32(T)).astype(np.int64)
+        if self.fixed:
+            e_idx = np.minimum(T, s_idx + 128)
+            s_idx = e_idx - 128
+        else:
+            empty = s_idx >= e_idx                                      # make sure the patch is not empty
+            s_idx = np.where(empty, np.maximum(0, s_idx - 1), s_idx)
+            e_idx = np.where(empty, np.minimum(T, e_idx + 1), e_idx)
+        bad = ~((0 <= s_idx) & (s_idx < e_idx) & (e_idx <= T)) | (self.fixed & (e_idx - s_idx != 128))
+        if bad.any():
+            b, k = np.argwhere(bad)[0]
+            raise ValueError(f'patch box {bx[b, k].tolist()} gives rows [{s_idx[b, k]}, {e_idx[b, k]}) outside a clip of {T} frames')
         jobs = np.zeros((B * P,), _JOB)
-        k = 0
-        for b in range(B):
-            bx = boxes[b].detach().cpu().numpy() if torch.is_tensor(boxes[b]) else np.asarray(boxes[b])
-            assert len(bx) == P, 'every clip carries the same number of patch boxes'
-            for box in bx.astype(np.float32):
-                s, e = self.rows(box, T)
-                if not (0 <= s < e <= T) or (self.fixed and e - s != 128):
-                    raise ValueError(f'patch box {box.tolist()} gives rows [{s}, {e}) outside a clip of {T} frames')
-                jobs[k] = (b, s, e, 0)
-                k += 1
+        jobs['clip'] = np.repeat(np.arange(B, dtype=np.int32), P)
+        jobs['s_idx'], jobs['e_idx'] = s_idx.reshape(-1), e_idx.reshape(-1)
         jd = torch.from_numpy(jobs.view(np.int32)).to(data.device, non_blocking=True)
         out = torch.empty((B, P, 1, 128, F), device=data.device, dtype=torch.float32)
         L.check(L.load().sedt_query_patches(data.data_ptr(), B, T, F, jd.data_ptr(), B * P, int(self.fixed), out.data_ptr(),
