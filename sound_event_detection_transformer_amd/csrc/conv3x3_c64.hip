@@ -25,6 +25,8 @@ constexpr int C3_WL = 9 * C3_C * C3_PP;                       // 82944 B
 constexpr int C3_CHUNKS = C3_HR * C3_HW * 8;                  // 2592 16-byte chunks per halo tile
 constexpr int C3_PRE = (C3_CHUNKS + 511) / 512;               // 6 per thread
 
+typedef int c3_i4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ int c3_crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, int flip,
@@ -78,16 +80,30 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const bf16_t* __restri
     f32x16 acc0, acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    // The 16 lanes of a DPP row are the 16 pixels of one image row, so the fragments of the left / right taps (kw = 0, 2) are
+    // the centre tap's fragment shifted by one lane (row_shr:1 / row_shl:1; the lane shifted in from outside the row reads
+    // zero = the convolution's zero padding): one LDS read per (kh, k16 step) instead of three.
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int kh = tap / 3, kw = tap - kh * 3;
+    for (int kh = 0; kh < 3; ++kh) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(abase + (kh * C3_HW + kw) * C3_PP + ks * 32);
-        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bbase + (tap * C3_C) * C3_PP + ks * 32);
-        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(bbase + (tap * C3_C + 32) * C3_PP + ks * 32);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b1, acc1, 0, 0, 0);
+        const bf16x8 ac = *reinterpret_cast<const bf16x8*>(abase + (kh * C3_HW + 1) * C3_PP + ks * 32);
+        const c3_i4 ci = __builtin_bit_cast(c3_i4, ac);
+        c3_i4 li, ri;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          li[q] = __builtin_amdgcn_update_dpp(0, ci[q], 0x111, 0xf, 0xf, true);       // row_shr:1 -> pixel column c - 1
+          ri[q] = __builtin_amdgcn_update_dpp(0, ci[q], 0x101, 0xf, 0xf, true);       // row_shl:1 -> pixel column c + 1
+        }
+        const bf16x8 av[3] = {__builtin_bit_cast(bf16x8, li), ac, __builtin_bit_cast(bf16x8, ri)};
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = kh * 3 + kw;
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(bbase + (tap * C3_C) * C3_PP + ks * 32);
+          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(bbase + (tap * C3_C + 32) * C3_PP + ks * 32);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kw], b0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[kw], b1, acc1, 0, 0, 0);
+        }
       }
     }
     __syncthreads();                                  // every wave is done with the halo: it becomes the output stage

@@ -16,7 +16,7 @@ def timeit(fn, reps=10):
     for _ in range(5): gr.replay()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / (5 * reps) * 1e3
-B = 64
+B = int(os.environ.get("B", "64"))
 for name, Hi, Wi, C in (('l1.conv2 3x3 64->64  M=128000', 125, 16, 64),):
     gm = ops.ConvGeom(Hi, Wi, C, C, 3, 1, 1, 1)
     x = torch.randn(B * Hi * Wi, C, generator=g).to('cuda', torch.bfloat16)
