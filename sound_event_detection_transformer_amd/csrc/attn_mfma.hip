@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __r
   unsigned char* Vi = Ki + LkP * AROW;
   unsigned char* Qi = Vi + LkP * AROW;
   float* Kb = reinterpret_cast<float*>(Qi + LqP * AROW);
+  float* Rs = Kb + LkP;                                // [waves][32] 1 / row-sum strips
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = blockDim.x, nwave = nthr >> 6;
   stage_image(Ki, k + (long)b * Lk * ldk + h * AD, ldk, Lk, LkP, tid, nthr);
@@ -113,35 +114,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __r
         }
       }
     };
-    // pass 1: softmax statistics, one tile at a time (running max / rescaled sum), so only one tile is live in registers
-    float m = -INFINITY, sum = 0.f;
+    // pass 1: the row maximum only (no exponentials: v_exp_f32 is quarter rate, and the first version of this kernel paid
+    // it twice per score - once for the row sum here, once for the probabilities below)
+    float m = -INFINITY;
 #pragma unroll 1
     for (int kt = 0; kt < NT; ++kt) {
       f32x16 st;
       score_tile(kt, st);
-      float tm = st[0];
 #pragma unroll
-      for (int r = 1; r < 16; ++r) tm = fmaxf(tm, st[r]);
-      const float mn = fmaxf(m, tm);
-      if (mn > -INFINITY) {
-        float ts = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ts += __expf(st[r] - mn);
-        sum = sum * __expf(m - mn) + ts;
-        m = mn;
-      }
+      for (int r = 0; r < 16; ++r) m = fmaxf(m, st[r]);
     }
-    {
-      const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(sum, 32, 64);
-      const float M = fmaxf(m, m2);
-      sum = (m > -INFINITY ? sum * __expf(m - M) : 0.f) + (m2 > -INFINITY ? s2 * __expf(m2 - M) : 0.f);
-      m = M;
-    }
-    const float inv = 1.f / sum;
-    if (hf == 0 && qi < Lq) lse[((long)b * H + h) * Lq + qi] = m + __logf(sum);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float ms = m > -INFINITY ? m : 0.f;             // a fully masked row: every exp(-inf - 0) = 0, sum 0, output NaN as torch
     const uint64_t rowbase = ((uint64_t)bh * Lq + qi) * Lk;
     const uint32_t d_hi = (uint32_t)(rowbase >> 33), d_inner = drop_inner(sd, d_hi);      // seed half of the dropout hash, once per row
-    // pass 2: O = dropout(P) V, scores recomputed tile by tile (two MFMAs per tile - cheaper than keeping them)
+    // pass 2: O = dropout(exp(S - max)) V with the row sum gathered on the way (before dropout), scores recomputed tile by
+    // tile (two MFMAs per tile - cheaper than keeping them); the 1 / sum goes onto the output rows at the end
+    float sum = 0.f;
     f32x16 oacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
@@ -158,13 +147,27 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_mfma_kernel(const bf16_t* __r
           if (thresh) keep = drop_keep4(d_inner, d_hi, sd, rowbase + (kt * 32 + crow(8 * u + 4 * s4, hf)), thresh);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float p = __expf(st[8 * u + 4 * s4 + e] - m) * inv;
+            const float p = __expf(st[8 * u + 4 * s4 + e] - ms);
+            sum += p;
             pv[4 * s4 + e] = (keep >> e & 1u) ? (thresh ? p * inv_keep : p) : 0.f;
           }
         }
         oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(pv), frag_cols_tr(Vi, kt * 32 + 16 * u, lane), oacc, 0, 0, 0);
       }
     }
+    sum += __shfl_xor(sum, 32, 64);
+    if (hf == 0 && qi < Lq) lse[((long)b * H + h) * Lq + qi] = m + __logf(sum);
+    // 1 / sum is per QUERY = per lane here, but per accumulator ROW in oacc (lane <-> dim): through this wave's 32-float LDS strip
+    float* strip = Rs + wave * 32;
+    if (hf == 0) strip[lane] = 1.f / sum;
+    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the strip is written (same wave reads it back)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float4 iv = *reinterpret_cast<const float4*>(strip + 8 * g4 + 4 * hf);
+      oacc[4 * g4 + 0] *= iv.x; oacc[4 * g4 + 1] *= iv.y; oacc[4 * g4 + 2] *= iv.z; oacc[4 * g4 + 3] *= iv.w;
+    }
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qr = q0 + crow(r, hf);
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(512) void enc_attn_fused_kernel(const bf16_t* __res
   unsigned char* Ap = An + EF_S * EF_AP;
   unsigned char* Wl = Ap + EF_S * EF_AP;
   float* Kb = reinterpret_cast<float*>(Wl + 192 * EF_AP);      // [128] additive key bias (lives through both phases)
+  float* Rs = Kb + EF_S;                              // [8 waves][32] 1 / row-sum strips
   unsigned char* Kimg = smem;                         // [2 heads][128][32] bf16
   unsigned char* Vimg = Kimg + 2 * EF_IMG;
   unsigned char* Qimg = Vimg + 2 * EF_IMG;
@@ -374,33 +378,20 @@ __global__ __launch_bounds__(512) void enc_attn_fused_kernel(const bf16_t* __res
       st[4 * g4 + 3] = st[4 * g4 + 3] * scale + kb.w;
     }
   };
-  float m = -INFINITY, ssum = 0.f;
+  // (as attn_fwd_mfma_kernel: row maximum first, probabilities + row sum in one pass, 1 / sum on the output rows at the end)
+  float m = -INFINITY;
 #pragma unroll 1
   for (int kt = 0; kt < 4; ++kt) {
     f32x16 st;
     score_tile(kt, st);
-    float tm = st[0];
 #pragma unroll
-    for (int r = 1; r < 16; ++r) tm = fmaxf(tm, st[r]);
-    const float mn = fmaxf(m, tm);
-    if (mn > -INFINITY) {
-      float ts = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ts += __expf(st[r] - mn);
-      ssum = ssum * __expf(m - mn) + ts;
-      m = mn;
-    }
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, st[r]);
   }
-  {
-    const float m2 = __shfl_xor(m, 32, 64), s2 = __shfl_xor(ssum, 32, 64);
-    const float M = fmaxf(m, m2);
-    ssum = (m > -INFINITY ? ssum * __expf(m - M) : 0.f) + (m2 > -INFINITY ? s2 * __expf(m2 - M) : 0.f);
-    m = M;
-  }
-  const float inv = 1.f / ssum;
-  if (hf == 0 && qi < S) lse[((long)b * 8 + head) * S + qi] = m + __logf(ssum);
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  const float ms = m > -INFINITY ? m : 0.f;
   const uint64_t rowbase = ((uint64_t)bh * S + qi) * S;
   const uint32_t d_hi = (uint32_t)(rowbase >> 33), d_inner = drop_inner(sd, d_hi);
+  float ssum = 0.f;
   f32x16 oacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
@@ -417,12 +408,24 @@ __global__ __launch_bounds__(512) void enc_attn_fused_kernel(const bf16_t* __res
         if (thresh) keep = drop_keep4(d_inner, d_hi, sd, rowbase + (kt * 32 + crow(8 * u + 4 * s4, hf)), thresh);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float p = __expf(st[8 * u + 4 * s4 + e] - m) * inv;
+          const float p = __expf(st[8 * u + 4 * s4 + e] - ms);
+          ssum += p;
           pv[4 * s4 + e] = (keep >> e & 1u) ? (thresh ? p * inv_keep : p) : 0.f;
         }
       }
       oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(pv), frag_cols_tr(Vi, kt * 32 + 16 * u, lane), oacc, 0, 0, 0);
     }
+  }
+  ssum += __shfl_xor(ssum, 32, 64);
+  if (hf == 0 && qi < S) lse[((long)b * 8 + head) * S + qi] = m + __logf(ssum);
+  float* strip = Rs + wave * 32;
+  if (hf == 0) strip[lane] = 1.f / ssum;
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const float4 iv = *reinterpret_cast<const float4*>(strip + 8 * g4 + 4 * hf);
+    oacc[4 * g4 + 0] *= iv.x; oacc[4 * g4 + 1] *= iv.y; oacc[4 * g4 + 2] *= iv.z; oacc[4 * g4 + 3] *= iv.w;
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -612,8 +615,8 @@ int attn_fwd_mfma_try(const void* q, int64_t ldq, const void* k, int64_t ldk, co
   if (Lk > 32 * AMAXT || Lq > 32 * AMAXT) return -1;
   if (!aligned_ok(q, ldq) || !aligned_ok(k, ldk) || !aligned_ok(v, ldv)) return -1;
   const int nt = (Lk + 31) / 32, LqP = (Lq + 31) & ~31;
-  const size_t lds = (size_t)(2 * nt * 32 + LqP) * AROW + (size_t)nt * 32 * sizeof(float);
   const int nwave = 4;     // all four waves stage K/V/Q; waves beyond the query tiles then idle
+  const size_t lds = (size_t)(2 * nt * 32 + LqP) * AROW + (size_t)(nt * 32 + nwave * 32) * sizeof(float);
   const float scale = 1.f / sqrtf((float)AD);
   const uint32_t th = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
   const float ik = 1.f / (1.f - drop_p);
@@ -642,7 +645,7 @@ int attn_fwd_mfma_try(const void* q, int64_t ldq, const void* k, int64_t ldk, co
 int enc_attn_fused_launch(const void* x, const void* pos, const float* gamma, const float* beta, const void* w_in, const float* b_in,
                           void* ctx, float* lse, void* xn, void* xnp, float* mean, float* rstd, void* qk, void* v, const uint8_t* kpm,
                           int B, int S, float drop_p, uint32_t seed, const uint32_t* seed_ptr, hipStream_t st) {
-  const size_t lds = (size_t)(2 * EF_S + 192) * EF_AP + (size_t)EF_S * sizeof(float);       // 122368 B: one workgroup per CU
+  const size_t lds = (size_t)(2 * EF_S + 192) * EF_AP + (size_t)(EF_S + 8 * 32) * sizeof(float);       // 123392 B: one workgroup per CU
   const float scale = 1.f / sqrtf((float)AD);
   const uint32_t th = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
   const float ik = 1.f / (1.f - drop_p);

@@ -150,13 +150,32 @@ def test_b64_forward_f32_matches_oracle_on_sampled_clips(pkg):
         assert rel(a['pred_boxes'][pick], ref['aux_outputs'][i]['pred_boxes']) < 1e-3
 
 
-# measured on this build (printed by the test): pred_logits 1.45e-2, pred_boxes 9.7e-3, at 7.0e-3, total loss 6.2e-4, the worst
-# relative gradient-norm error 6.7e-2 (backbone.0.body.conv0.bias, the end of the longest backward chain), median 2.8e-3.
-# Bounds = about 3x those.
-BF16_BOUNDS = {'pred_logits': 4.5e-2, 'pred_boxes': 3e-2, 'at': 2.2e-2, 'loss': 3e-3, 'gradnorm': 0.2, 'gradnorm_median': 1e-2}
+# measured on this build (printed by the test): pred_logits 1.5e-2, pred_boxes 1.0e-2, at 4.8e-3, total loss 6e-5 .. 6e-4; gradient
+# norms under the smooth surrogate loss: median 2e-3 .. 4e-3, worst 1.5e-2 .. 7e-2 (conv0, the end of the longest backward chain).
+# Bounds = about 3x the larger observations.
+BF16_BOUNDS = {'pred_logits': 4.5e-2, 'pred_boxes': 3e-2, 'at': 2.2e-2, 'loss': 3e-3, 'gradnorm': 0.2, 'gradnorm_median': 1.2e-2}
+
+
+def _smooth_loss(o):
+    """a kink-free scalar of every model output (all decoder layers): what the gradient comparison below differentiates"""
+    t = o['pred_logits'].float().square().mean() + 3.0 * o['pred_boxes'].float().square().mean() + o['at'].float().square().mean()
+    for i, a in enumerate(o['aux_outputs']):
+        t = t + (0.5 + 0.25 * i) * (a['pred_logits'].float().square().mean() + 3.0 * a['pred_boxes'].float().square().mean())
+    return t
 
 
 def test_bf16_mode_error_is_measured_and_bounded(pkg, golden_dir, capsys):
+    """bf16 throughput mode against the f32 reference, measured and printed:
+    * eval outputs against fixture G2 (the reference's own numbers);
+    * the training loss against fixture G3 with the Hungarian ASSIGNMENT taken from the f32-mode forward of the same model (pinned
+      to the reference's by G2/G3): at random init several queries predict nearly the same event, so matching costs are
+      near-tied and a last-bit change upstream may swap two queries - a legitimate answer to a tie, not an arithmetic error;
+    * per-parameter gradient norms against the f32 MODE of this library (itself within 2e-3 of the reference's, G3) under a
+      SMOOTH surrogate loss.  SetCriterion's own gradient has kinks exactly where a random-init model sits (L1 sign at
+      pred = target, the clamps of the 1-D GIoU with boxes hanging over the clip start): a 1e-2 forward difference flips a few
+      of its +-1 entries and moves every gradient norm by 5-25 % although nothing is wrong - the first form of this test
+      (criterion gradients against G3) passed or failed with the f32 summation ORDER of an unrelated kernel.  The criterion's
+      backward kernel is pinned separately in f32 (G3, G5, G9) where such flips cannot happen."""
     runtime, sedt, ops = pkg
     g = np.load(os.path.join(golden_dir, 'g2_g3_sedt.npz'))
     B = 2
@@ -169,19 +188,31 @@ def test_bf16_mode_error_is_measured_and_bounded(pkg, golden_dir, capsys):
         o = model(x.cuda())
     errs = {k: rel(o[k], g[f'urban_eval_{k}']) for k in ('pred_logits', 'pred_boxes', 'at')}
     model.train()
-    ld, _ = crit(model(x.cuda()), synthetic_targets(B, 99, 10), None, slice(B))
-    total = crit.last_total
-    total.backward()
+    tg = [{k: v.cuda() for k, v in t.items()} for t in synthetic_targets(B, 99, 10)]
     runtime.set_compute_dtype('f32')
+    with torch.no_grad():
+        dense, _ = crit.prepare(model(x.cuda()), tg, None, slice(B))
+    model.zero_grad(set_to_none=True)
+    _smooth_loss(model(x.cuda())).backward()
+    ref_gn = {n: p.grad.norm().item() for n, p in model.named_parameters() if p.grad is not None}
+    runtime.set_compute_dtype('bf16')
+    with torch.no_grad():
+        crit.compute(model(x.cuda()), dense)
+    total = crit.last_total
     errs['loss'] = abs(total.item() - float(g['urban_train_total'])) / abs(float(g['urban_train_total']))
-    names = [str(n) for n in g['urban_train_gradnames']]
+    model.zero_grad(set_to_none=True)
+    _smooth_loss(model(x.cuda())).backward()
+    runtime.set_compute_dtype('f32')
+    names = [n for n in ref_gn if ref_gn[n] > 0]
     params = dict(model.named_parameters())
     gn = np.array([params[n].grad.norm().item() for n in names])
-    relg = np.abs(gn - g['urban_train_gradnorm']) / (g['urban_train_gradnorm'] + 1e-9)
+    rg = np.array([ref_gn[n] for n in names])
+    relg = np.abs(gn - rg) / (rg + 1e-12)
     errs['gradnorm'] = float(relg.max())
     errs['gradnorm_median'] = float(np.median(relg))
     worst = names[int(relg.argmax())]
     with capsys.disabled():
-        print('\\n[bf16 vs reference f32, fixture G2/G3] ' + ', '.join(f'{k}={v:.3e}' for k, v in errs.items()) + f' (worst grad: {worst})')
+        print('\n[bf16 vs f32: outputs / loss against fixtures G2 / G3, gradient norms against the f32 mode under a smooth loss] '
+              + ', '.join(f'{k}={v:.3e}' for k, v in errs.items()) + f' (worst grad: {worst})')
     for k, bound in BF16_BOUNDS.items():
         assert errs[k] < bound, (k, errs[k], bound)
