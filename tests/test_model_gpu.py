@@ -205,33 +205,50 @@ def test_sedt_against_oracle_bf16_and_f32_b4(pkg):
     runtime.set_compute_dtype('f32')
 
 
+def _smooth_loss(o):
+    """a kink-free scalar of every model output: SetCriterion's own gradient has +-1 entries (L1 sign, GIoU clamps) that flip
+    on 1e-2 forward differences at a random-init operating point, which makes cross-precision comparisons of ITS gradients a
+    coin flip (see tests/test_parity_depth_gpu.py); the criterion backward is pinned in f32"""
+    t = o['pred_logits'].float().square().mean() + 3.0 * o['pred_boxes'].float().square().mean() + o['at'].float().square().mean()
+    for i, a in enumerate(o['aux_outputs']):
+        t = t + (0.5 + 0.25 * i) * (a['pred_logits'].float().square().mean() + 3.0 * a['pred_boxes'].float().square().mean())
+    return t
+
+
 def test_bf16_train_step_grads_close_to_oracle(pkg):
-    """bf16 throughput mode: loss and gradient norms track the f32 oracle (loose, stated: loss 3e-2, grad norms 15 %)"""
+    """bf16 throughput mode against the f32 CPU oracle: the criterion's total loss (continuous: 3e-2) and, under a smooth
+    surrogate loss, every parameter's gradient norm (10 %; measured 2-4 % worst, 0.2 % median)"""
     A, runtime, sedt = pkg
     B = 4
     oracle = _seed_load(O.build_oracle_model(10, 10, 3, 3, True, True, True, dropout=0.0), 77).train()
     crit_o = build_oracle_criterion(10, 3, True, True)
     x = torch.randn(B, 1, 500, 64, generator=torch.Generator().manual_seed(6))
     targets = synthetic_targets(B, 3, 10)
-    ld, _ = crit_o(oracle(x), targets, None, slice(B))
+    oo = oracle(x)
+    ld, _ = crit_o(oo, targets, None, slice(B))
     tot_o = sum(ld[k] * crit_o.weight_dict[k] for k in ld if k in crit_o.weight_dict)
-    tot_o.backward()
+    _smooth_loss(oo).backward()
     model, crit = _build(sedt, 3, 10)
     _seed_load(model, 77).cuda().train()
     runtime.set_compute_dtype('bf16')
-    ld, _ = crit(model(x.cuda()), targets, None, slice(B))
+    out = model(x.cuda())
+    ld, _ = crit(out, targets, None, slice(B))
     tot = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
-    tot.backward()
+    tot.backward()                                                # the criterion's own backward runs and stays finite
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert torch.isfinite(p.grad).all(), n
+    model.zero_grad(set_to_none=True)
+    _smooth_loss(model(x.cuda())).backward()
     runtime.set_compute_dtype('f32')
     assert abs(tot.item() - tot_o.item()) < 3e-2 * abs(tot_o.item())
     po = dict(oracle.named_parameters())
     worst = 0.0
     for n, p in model.named_parameters():
-        if p.requires_grad:
+        if p.requires_grad and po[n].grad is not None and po[n].grad.norm().item() > 0:
             a, b = p.grad.norm().item(), po[n].grad.norm().item()
-            worst = max(worst, abs(a - b) / (b + 1e-6))
-            assert torch.isfinite(p.grad).all(), n
-    assert worst < 0.15, worst
+            worst = max(worst, abs(a - b) / b)
+    assert worst < 0.10, worst
 
 
 def test_dropout_train_mode_runs_and_is_seeded(pkg):
