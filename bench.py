@@ -383,6 +383,33 @@ def kernel_report(dtype, dev):
     geo = ops.ConvGeom(32, 4, 512, 512, 3, 1, 2, 2)
     t = timeit(lambda: ops.conv_fwd(dt, xin, B, geo, wc, scale=sc, bias=bi, act=L.ACT_RELU))
     mf("layer4 3x3 dilated conv fwd (implicit GEMM 8192 x 512 x 4608, FrozenBN + ReLU epilogue)", 2.0 * M * 512 * 4608, t)
+    # layer1 conv2: the direct 3x3 kernel (conv3x3_c64.hip) and its input gradient
+    g1 = ops.ConvGeom(125, 16, 64, 64, 3, 1, 1, 1)
+    x1 = rnd(B * 125 * 16, 64)
+    w1c = rnd(64, 64, 3, 3, scale=0.04, dtype_=torch.float32)
+    sc1, bi1 = rnd(64, dtype_=torch.float32).abs() + 0.5, rnd(64, dtype_=torch.float32)
+    wf1, wb1 = ops.pack_conv(dt, w1c, sc1)
+    y1 = torch.empty_like(x1)
+    t = timeit(lambda: ops.conv_fwd(dt, x1, B, g1, wf1, out=y1, scale=sc1, bias=bi1, act=L.ACT_RELU))
+    mf("layer1 3x3 conv fwd (direct kernel, 128000 x 64 x 576, FrozenBN + ReLU)", 2.0 * B * 125 * 16 * 64 * 576, t,
+       "halo tile + all nine taps in LDS; the implicit GEMM it replaced: 25 us")
+    t = timeit(lambda: ops.conv_dgrad(dt, x1, B, g1, wb1, out=y1, mask=x1, ldm=64))
+    mf("layer1 3x3 conv input gradient (direct kernel, taps flipped, ReLU mask)", 2.0 * B * 125 * 16 * 64 * 576, t,
+       "the implicit GEMM it replaced: 37 us")
+    # the stem in one launch each way (stem.hip): bytes = f32 input + pooled bf16 output + argmax bytes
+    if ops.stem_pool_ok(dt, 64):
+        xs = torch.randn(B, 1, 500, 64, device=dev)
+        w0, b0 = torch.randn(3, 1, 1, 1, device=dev), torch.randn(3, device=dev)
+        ws1 = torch.randn(64, 3, 7, 7, device=dev) / 12
+        wcat = ops.stem_prep(dt, w0, b0, ws1)
+        pool, idx, Hp, Wp = ops.stem_pool_fwd(xs, wcat, sc1, bi1, B, 500, 64)
+        gpool = torch.randn_like(pool)
+        t = timeit(lambda: ops.stem_pool_fwd(xs, wcat, sc1, bi1, B, 500, 64))
+        hb("stem forward, one launch (conv0 o conv1 7x7/s2 o FrozenBN o ReLU o max-pool)", xs.numel() * 4.0 + pool.numel() * 3.0, t,
+           "VALU-bound (epilogue + pooling), not HBM-bound; the im2col -> GEMM -> pool chain it replaced: 110 us")
+        t = timeit(lambda: ops.stem_pool_wgrad(xs, gpool, idx, pool, sc1, B, 500, 64))
+        hb("stem backward, one launch + reduce (conv0 gradients from the pooled gradient)", xs.numel() * 4.0 + pool.numel() * 5.0, t,
+           "the max-pool backward -> weight-gradient GEMM chain it replaced: 122 us")
     t = timeit(lambda: ops.layernorm_fwd(dt, x, gam, bet))
     hb("LayerNorm fwd 8192 x 256 (sedt_layernorm_fwd)", 2.0 * M * E * es, t)
     n = 32579869
