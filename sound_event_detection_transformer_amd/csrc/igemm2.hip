@@ -302,7 +302,16 @@ int igemm2_try(const SedtIgemm& p, hipStream_t st) {
       const char* e = getenv("SEDT_IGEMM_BN128_MINK");
       mink = e ? atoi(e) : 512;
     }
-    if ((p.N % 128) == 0 && p.K >= mink && !(igemm3_planning() && p.M <= 1024)) bn = 128;
+    static int bn128t = -1;
+    if (bn128t < 0) {
+      const char* e = getenv("SEDT_IGEMM_BN128_MINTILES");
+      bn128t = e ? atoi(e) : 250;
+    }
+    // below 250 tiles of 64x128 the 64x64 tile covers more of the chip: the B = 32 configurations have M = 3968 rows, i.e. 124
+    // tiles of 64x128 at N = 256 (measured, tools/dev/sweep_c3.sh: C3 4.97 -> 4.88 ms, C5 8.71 -> 8.61 ms, C2 - exactly 256 tiles -
+    // unchanged; a threshold of 300 costs C2 0.2 %)
+    const long t128 = (long)((p.M + 63) / 64) * (p.N / 128);
+    if ((p.N % 128) == 0 && p.K >= mink && !(igemm3_planning() && p.M <= 1024) && (t128 >= bn128t || p.M <= 1024)) bn = 128;
     // the ping-pong 8-wave kernel makes the 128x128 tile (one workgroup per CU) pay where the K loop is long enough to
     // amortise its exposed prologue / epilogue and the tiles still cover the chip: layer4 conv1 fwd / conv2 / conv3 dgrad
     static int bm128k = -1, bm128t = -1;
