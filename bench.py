@@ -186,8 +186,27 @@ def build_workload(args, dev, rank, world):
                                                             gradient_as_bucket_view=True)
         graphed = not (args.no_graph or args.model_only)
         if graphed:
-            g = GraphedTrainStep(net, criterion, opt, x, targets, wm, slice(ns), max_norm=0.1, device_matching=not args.host_matching,
-                                 overlap_allreduce=not args.no_overlap)
+            g, err = None, None
+            try:
+                g = GraphedTrainStep(net, criterion, opt, x, targets, wm, slice(ns), max_norm=0.1, device_matching=not args.host_matching,
+                                     overlap_allreduce=not args.no_overlap)
+            except Exception as e:                      # noqa: BLE001
+                if world == 1:
+                    raise
+                err = repr(e)[:300]
+            if world > 1:
+                # every rank must take the same path: if the captured data-parallel schedule could not be built on ANY rank (its
+                # first execution on real multi-GPU hardware is the driver's scaling run), all ranks fall back to the eager step
+                # under torch DDP rather than lose the measurement
+                flag = torch.tensor([0 if g is None else 1], device=dev, dtype=torch.int32)
+                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    g = None
+                    graphed = False
+                    extras['graph_fallback'] = err or 'another rank failed to build the graphed data-parallel step'
+                    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False,
+                                                                    gradient_as_bucket_view=True)
+        if graphed:
             extras['stepper'] = g
 
             def step():
@@ -205,7 +224,7 @@ def build_workload(args, dev, rank, world):
         extras.update(model=model, criterion=criterion, opt=opt, x=x, targets=targets, wm=wm, ns=ns, net=net)
         what = (f"{'URBAN-SED' if cfg == 'c2' else 'DCASE2019'} SEDT enc_layers={E} dec_at num_queries={Q} B={B}/GPU"
                 f"{'' if cfg == 'c2' else f' ({ns} strong + {B - ns} weak)'}, 10 s @ 64-mel (B,1,{T},64), full train step: fwd + "
-                f"Hungarian matching ({'host' if (args.host_matching or args.no_graph) else 'device'}) + SetCriterion + bwd + clip 0.1 + "
+                f"Hungarian matching ({'host' if (args.host_matching or not graphed) else 'device'}) + SetCriterion + bwd + clip 0.1 + "
                 f"AdamW, dropout 0.1" + (" [model-only timing]" if args.model_only else ""))
         return step, B, FLOP_PER_CLIP[cfg] * B, what, graphed, extras
     if cfg == 'eval':
@@ -510,7 +529,7 @@ def main():
     #      then replayed back to back on the launch stream between two HIP events
     gemm = None
     if args.config in ('c2', 'c3') and not args.model_only:
-        if rank != 0 and world > 1 and args.no_graph:
+        if rank != 0 and world > 1 and not graphed:
             ops.PROFILE = []                      # eager DDP: the extra step contains collectives, every rank must take part
             from sound_event_detection_transformer_amd.engine import train_step
             train_step(ex['net'], ex['criterion'], ex['opt'], ex['x'], ex['targets'], ex['wm'], slice(ex['ns']), max_norm=0.1)
@@ -594,6 +613,8 @@ def main():
                "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "hip_graph": graphed,
                "rccl_world": rccl_world, "ms_per_step_per_rank": [round(v / args.steps * 1e3, 3) for v in per_rank],
                "exposed_comm": exposed}
+        if ex.get('graph_fallback'):
+            out["graph_fallback"] = ex['graph_fallback']
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
