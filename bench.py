@@ -182,8 +182,10 @@ def build_workload(args, dev, rank, world):
         wm = slice(ns, B) if ns < B else None
         net = model
         if world > 1 and args.no_graph:
-            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False,
-                                                            gradient_as_bucket_view=True)
+            from sound_event_detection_transformer_amd.engine import train_stream
+            with torch.cuda.stream(train_stream(dev)):
+                net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False,
+                                                                gradient_as_bucket_view=True)
         graphed = not (args.no_graph or args.model_only)
         if graphed:
             g, err = None, None
@@ -204,8 +206,10 @@ def build_workload(args, dev, rank, world):
                     g = None
                     graphed = False
                     extras['graph_fallback'] = err or 'another rank failed to build the graphed data-parallel step'
-                    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False,
-                                                                    gradient_as_bucket_view=True)
+                    from sound_event_detection_transformer_amd.engine import train_stream
+                    with torch.cuda.stream(train_stream(dev)):
+                        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False,
+                                                                        gradient_as_bucket_view=True)
         if graphed:
             extras['stepper'] = g
 

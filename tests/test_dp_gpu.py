@@ -182,3 +182,56 @@ def test_rccl_schedule_on_one_gpu_matches_single_process_step(tmp_path):
     assert ra['finite'] and rb['finite']
     d = (ra['vec'] - rb['vec']).abs().max().item()
     assert d <= 1e-6 * max(1.0, rb['vec'].abs().max().item()), d
+
+
+def _ddp_worker(rank, port, out, ddp):
+    """eager train_step with the model wrapped in torch DistributedDataParallel over RCCL (world size 1) - the path bench.py
+    falls back to when the graphed data-parallel schedule cannot be built - against the same eager steps without the wrapper"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from sound_event_detection_transformer_amd import runtime
+    from sound_event_detection_transformer_amd.sedt import build_model, default_args
+    from sound_event_detection_transformer_amd.engine import build_optimizer, train_step, train_stream
+    from sound_event_detection_transformer_amd.utilities.synthetic import seeded_state_dict, synthetic_batch
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    if ddp:
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    runtime.set_compute_dtype('bf16')
+    runtime.manual_seed(4)
+    model, crit, _ = build_model(default_args(dropout=0.0))
+    model.load_state_dict(seeded_state_dict(model.state_dict(), 3))
+    model.to(dev).train()
+    crit.to(dev)
+    opt = build_optimizer(model)
+    net = model
+    if ddp:
+        with torch.cuda.stream(train_stream(dev)):          # DDP's AccumulateGrad hooks belong to the stream the steps run on
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], broadcast_buffers=False, gradient_as_bucket_view=True)
+    B = 2
+    losses = []
+    for i in range(3):
+        x, t = synthetic_batch(B, 500, 300 + 10 * i, dev)
+        total, ld = train_step(net, crit, opt, x, t, None, slice(B), max_norm=0.1)
+        losses.append(float(total))
+    torch.cuda.synchronize()
+    vec = torch.cat([p.detach().flatten().float().cpu() for p in model.parameters() if p.requires_grad])
+    torch.save({'vec': vec, 'losses': losses}, out)
+    if ddp:
+        dist.destroy_process_group()
+
+
+def test_eager_step_under_torch_ddp_matches_plain_eager_step(tmp_path):
+    a, b = str(tmp_path / 'ddp.pt'), str(tmp_path / 'plain.pt')
+    mp.spawn(_ddp_worker, args=(_free_port(), a, True), nprocs=1, join=True)
+    mp.spawn(_ddp_worker, args=(_free_port(), b, False), nprocs=1, join=True)
+    ra, rb = torch.load(a), torch.load(b)
+    # the first step sees identical parameters: identical losses; later steps differ by what bf16 training makes of a different
+    # f32 summation order in the global gradient norm (bucket views vs per-parameter gradients): bounded, not bit-equal
+    assert abs(ra['losses'][0] - rb['losses'][0]) <= 1e-6 * abs(rb['losses'][0]), (ra['losses'], rb['losses'])
+    assert all(abs(x - y) <= 1e-2 * abs(y) for x, y in zip(ra['losses'], rb['losses'])), (ra['losses'], rb['losses'])
+    assert torch.isfinite(ra['vec']).all()
+    v0 = _initial_vec()
+    ua, ub = ra['vec'] - v0, rb['vec'] - v0
+    assert ub.norm().item() > 0
+    assert (ua - ub).norm().item() <= 0.1 * ub.norm().item(), ((ua - ub).norm().item(), ub.norm().item())
