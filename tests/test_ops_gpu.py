@@ -301,7 +301,7 @@ def test_stem(ops, dt, H, W):
     close(db0, b0.grad, dt)
 
 
-@pytest.mark.parametrize('B,H', [(2, 500), (3, 496), (5, 128), (2, 37), (1, 9)])
+@pytest.mark.parametrize('B,H', [(2, 500), (3, 496), (5, 128), (2, 37), (1, 9), (20, 500)])   # the last: 2-3 tiles per persistent workgroup
 def test_stem_one_launch_forward_and_backward(ops, B, H):
     """csrc/stem.hip: conv0 o conv1 o FrozenBN o ReLU o max-pool in one launch, and the conv0 gradients from the pooled gradient
     in one launch + reduce, against plain PyTorch f32 (bf16-rounded operands) and against the unfused HIP chain"""
@@ -683,7 +683,7 @@ def test_previous_generation_kernels_still_pass_the_same_parity_tests():
     assert ' passed' in r.stdout
 
 
-@pytest.mark.parametrize('B,H', [(2, 125), (3, 124), (1, 16), (2, 7), (5, 33)])
+@pytest.mark.parametrize('B,H', [(2, 125), (3, 124), (1, 16), (2, 7), (5, 33), (70, 125), (300, 32)])   # the last two: 3 tiles per persistent workgroup
 def test_direct_conv3x3_c64_forward_and_dgrad(ops, B, H):
     """csrc/conv3x3_c64.hip (layer1 conv2 geometry: 64 -> 64 channels, 16-wide map) against F.conv2d and against the implicit-GEMM
     kernel it replaces, forward (FrozenBN scale / bias + ReLU) and input gradient (taps flipped, ReLU mask of the consumer)"""
