@@ -167,13 +167,23 @@ class EMA(object):
 # ------------------------------------------------------------------------------------------------ one semi_train iteration
 def semi_step(model, ema, criterion, optimizer, x_teacher, x_student, targets, mask_strong, mask_weak, mask_label,
               mask_unlabel, classwise_threshold, fine_tune=False, normalize=False, fl=False, max_norm=0.1, do_step=True,
-              counter=None):
-    """engine.py:117-181 for one batch (mixup off).  x_teacher / x_student: (B,1,T,F) views of the same clips (the
-    student's unlabelled part carries the extra augmentation).  Returns (sup dict, unsup dict, total, pseudo targets)."""
+              counter=None, mix_up_ratio=0, mix_draws=None, trace=None):
+    """engine.py:117-181 for one batch.  x_teacher / x_student: (B,1,T,F) views of the same clips (the student's unlabelled
+    part carries the extra augmentation).  mix_up_ratio > 0 (engine.py:128-133, 150-153): the labelled part goes through
+    mixup_data, the student's unlabelled view and the pseudo labels through mixup_label_unlabel (mixed with the ALREADY MIXED
+    labelled batch, as the reference passes it on); mix_draws = (lam of mixup_data, its shuffled index, lam of
+    mixup_label_unlabel) - what np.random gave the reference.  trace (dict, optional) receives what the two mixups returned.
+    Returns (sup dict, unsup dict, total, pseudo targets as fed to the student's criterion)."""
     counter = Counter() if counter is None else counter
     post = PostProcess()
     wd = criterion.weight_dict
-    sup, _ = criterion(model(x_teacher[mask_label]), targets[mask_label], mask_weak, mask_strong, fine_tune, normalize, fl)
+    x_lab, t_lab = x_teacher[mask_label], targets[mask_label]
+    if mix_up_ratio > 0:
+        x_lab, t_lab, mask_strong, mask_weak = mixup_data(x_lab, t_lab, mask_strong, mask_weak, mix_draws[0], mix_draws[1],
+                                                          mix_up_ratio=mix_up_ratio)
+        if trace is not None:
+            trace['md'] = (x_lab, t_lab, mask_strong, mask_weak)
+    sup, _ = criterion(model(x_lab), t_lab, mask_weak, mask_strong, fine_tune, normalize, fl)
     sup_total = sum(sup[k] * wd[k] for k in sup if k in wd)
     unl = [dict(t) for t in targets[mask_unlabel]]
     ema.apply_shadow()
@@ -183,6 +193,12 @@ def semi_step(model, ema, criterion, optimizer, x_teacher, x_student, targets, m
         pseudo = get_pseudo_labels(tea, post, sizes, unl, counter, classwise_threshold)
     ema.restore()
     xs = x_student[mask_unlabel]
+    if mix_up_ratio > 0:
+        if trace is not None:
+            trace['pseudo'] = [dict(t) for t in pseudo]
+        xs, pseudo = mixup_label_unlabel(x_lab, xs, t_lab, pseudo, mix_draws[2])
+        if trace is not None:
+            trace['lu'] = (xs, pseudo)
     unsup, _ = criterion(model(xs), pseudo, None, slice(xs.shape[0]), fine_tune, normalize, fl)
     unsup_total = sum(unsup[k] * wd[k] for k in unsup if k in wd)
     total = sup_total + unsup_total
@@ -194,3 +210,22 @@ def semi_step(model, ema, criterion, optimizer, x_teacher, x_student, targets, m
         optimizer.zero_grad()
         ema.update()
     return sup, unsup, total, pseudo
+
+
+def train_step_mix(model, criterion, optimizer, x, targets, mask_strong, mask_weak, mix_up_ratio, mix_draws, max_norm=0.1,
+                   do_step=True, trace=None):
+    """engine.py:47-80 for one batch with mix-up: mixup_data (draws passed in) -> forward -> criterion with the masks mixup_data
+    returned -> backward -> clip / step"""
+    x, targets, ms, mw = mixup_data(x, targets, mask_strong, mask_weak, mix_draws[0], mix_draws[1], mix_up_ratio=mix_up_ratio)
+    if trace is not None:
+        trace['md'] = (x, targets, ms, mw)
+    loss_dict, _ = criterion(model(x), targets, mw, ms)
+    wd = criterion.weight_dict
+    total = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+    total.backward()
+    if do_step:
+        if max_norm > 0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+        optimizer.step()
+        optimizer.zero_grad()
+    return loss_dict, total

@@ -58,6 +58,49 @@ def semi_batch():
     return x_t, x_s, targets
 
 
+# G15: the same mean-teacher iteration with mix-up on (train_ss_sedt.py --mix_up_ratio 0.6) and a supervised mix-up step.
+# 5 strong + 5 weak labelled clips: mixup_data mixes int(10 * 0.6) = 6 clips (five strong and one weak one),
+# mixup_label_unlabel the first int(10 * 0.5) = 5 unlabelled clips with the (already mixed) strong ones.
+SEMI_MIX = dict(n_strong=5, n_weak=5, n_unl=6, T=496, thr=0.115, seed_w=2023, seed_x=151, seed_t=152, np_seed=0, ratio=0.6)
+SUP_MIX = dict(n_strong=5, n_weak=5, T=496, seed_w=2024, seed_x=161, seed_t=162, np_seed=3, ratio=0.6)
+
+
+def sparse_targets(batch, seed, num_classes=10):
+    """1-3 short events per clip: two such clips usually mix without a same-class overlap (mixup.py:84-93 abandons those)"""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(batch):
+        n = int(torch.randint(1, 4, (1,), generator=g).item())
+        l = torch.rand(n, generator=g) * 0.13 + 0.02
+        c = l / 2 + torch.rand(n, generator=g) * (1 - l)
+        out.append({'labels': torch.randint(0, num_classes, (n,), generator=g), 'boxes': torch.stack([c, l], dim=-1),
+                    'orig_size': torch.tensor(10.0)})
+    return out
+
+
+def semi_mix_batch():
+    c = SEMI_MIX
+    nl = c['n_strong'] + c['n_weak']
+    B = nl + c['n_unl']
+    x_t = clip_input(B, c['T'], c['seed_x'])
+    x_s = x_t.clone()
+    x_s[nl:] += 0.1 * clip_input(c['n_unl'], c['T'], c['seed_x'] + 1)
+    targets = sparse_targets(B, c['seed_t'])
+    for t in targets[c['n_strong']:]:
+        t['boxes'] = torch.zeros(0, 2)
+    for t in targets[nl:]:
+        t['labels'] = torch.zeros(0, dtype=torch.int64)
+    return x_t, x_s, targets
+
+
+def sup_mix_batch():
+    c = SUP_MIX
+    B = c['n_strong'] + c['n_weak']
+    x = clip_input(B, c['T'], c['seed_x'])
+    targets = sparse_targets(B, c['seed_t'])
+    for t in targets[c['n_strong']:]:
+        t['boxes'] = torch.zeros(0, 2)
+    return x, targets
 
 
 QUERY = dict(T=496, num_patches=10, seeds=(501, 502), short_clip_T=96)

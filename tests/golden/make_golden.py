@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 from oracle import sedt_oracle as O              # noqa: E402
 from oracle.criterion_oracle import synthetic_targets  # noqa: E402
 sys.path.insert(0, HERE)
-from inputs import g9_inputs as _g9_inputs, g10_inputs as _g10_inputs, g11_inputs as _g11_inputs, SEMI, semi_batch as _semi_batch  # noqa: E402
+from inputs import g9_inputs as _g9_inputs, g10_inputs as _g10_inputs, g11_inputs as _g11_inputs, SEMI, semi_batch as _semi_batch, SEMI_MIX, SUP_MIX, semi_mix_batch as _semi_mix_batch, sup_mix_batch as _sup_mix_batch  # noqa: E402
 
 
 # ----------------------------------------------------------------------------- shim
@@ -533,6 +533,126 @@ def g12_semi_step(out, rsedt, rengine, ru):
     print('G12 ok total', res['total'], 'pseudo', res['pseudo_count'])
 
 
+class _HostPrefetcher(object):
+    """engine.train pulls its batches through DataLoad.data_prefetcher, which opens a CUDA stream; on the CPU the same
+    iteration protocol (next() -> (input, target), then (None, None)) without the stream"""
+
+    def __init__(self, loader):
+        self.it = iter(loader)
+
+    def next(self):
+        try:
+            return next(self.it)
+        except StopIteration:
+            return None, None
+
+
+def _target_rows(res, key, targets):
+    res[f'{key}_nlabels'] = np.array([len(t['labels']) for t in targets])
+    res[f'{key}_nboxes'] = np.array([len(t['boxes']) for t in targets])
+    res[f'{key}_labels'] = _pad_rows([npy(t['labels']) for t in targets], 24, -1)
+    res[f'{key}_centre'] = _pad_rows([npy(t['boxes'].reshape(-1, 2)[:, 0]) for t in targets], 24, -1)
+    res[f'{key}_length'] = _pad_rows([npy(t['boxes'].reshape(-1, 2)[:, 1]) for t in targets], 24, -1)
+    res[f'{key}_ratio'] = _pad_rows([npy(t['ratio']) if 'ratio' in t else [] for t in targets], 24, -1)
+
+
+def g15_mixup_steps(out, rsedt, rengine, rmixup, ru):
+    """G15: (a) one iteration of the reference's engine.semi_train with mix_up_ratio = 0.6 (train_ss_sedt.py's recipe): np.random
+    seeded, so mixup_data's Beta draw + shuffle and mixup_label_unlabel's Beta draw are reproducible; recorded: what the two
+    mixups returned (the calls are observed, not replaced), the total loss, every gradient norm, and - second run - the
+    parameter / EMA deltas of the complete iteration.  (b) one iteration of engine.train with mix_up_ratio = 0.6 on a 5 strong +
+    5 weak batch where the mixing moves a clip across the strong / weak boundary."""
+    import utilities.utils as rutils
+    res = {}
+    # ------------------------------------------------------------------ (a) mean teacher
+    c = SEMI_MIX
+    ns, nw, nu = c['n_strong'], c['n_weak'], c['n_unl']
+    masks = dict(mask_strong=slice(ns), mask_weak=slice(ns, ns + nw), mask_label=slice(ns + nw), mask_unlabel=slice(ns + nw, ns + nw + nu))
+    seen = {}
+    real_md, real_lu = rmixup.mixup_data, rmixup.mixup_label_unlabel
+
+    def spy_md(x, y, *a, **k):
+        r = real_md(x, y, *a, **k)
+        seen['md'] = (r[0].tensors.clone(), [dict(t) for t in r[1]], r[2], r[3])
+        return r
+
+    def spy_lu(x1, x2, y1, y2, *a, **k):
+        seen['pseudo'] = [dict(t) for t in y2]
+        r = real_lu(x1, x2, y1, y2, *a, **k)
+        seen['lu'] = (r[0].tensors.clone(), [dict(t) for t in r[1]])
+        return r
+
+    rengine.mixup_data, rengine.mixup_label_unlabel = spy_md, spy_lu
+    try:
+        for mode in ('grads', 'step'):
+            args = ref_args(enc_layers=6, num_queries=20, dropout=0.0)
+            model, criterion, post = rsedt.build_model(args)
+            seeded_load(model, c['seed_w'])
+            model.train()
+            ema = rutils.EMA(model, 0.9)
+            ema.register()
+            g = torch.Generator().manual_seed(5)
+            for n in ema.shadow:
+                ema.shadow[n] = ema.shadow[n] + 0.02 * ema.shadow[n].abs().mean() * torch.randn(ema.shadow[n].shape, generator=g)
+            shadow0 = {n: v.clone() for n, v in ema.shadow.items()}
+            groups = [{"params": [p for n, p in model.named_parameters() if "backbone" not in n and p.requires_grad]},
+                      {"params": [p for n, p in model.named_parameters() if "backbone" in n and p.requires_grad], "lr": 1e-4}]
+            opt = torch.optim.AdamW(groups, lr=1e-4, weight_decay=1e-4)
+            x_t, x_s, targets = _semi_mix_batch()
+            nt = lambda x: ru.NestedTensor(x, torch.zeros(x.shape[0], x.shape[2], x.shape[3], dtype=torch.bool))
+            loader = [((nt(x_t), nt(x_s)), targets)]
+            before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+            thr = torch.full((10,), c['thr'])
+            np.random.seed(c['np_seed'])
+            value, counter = rengine.semi_train(loader, model, ema, criterion, opt, 0, 2 if mode == 'grads' else 1, 1, post,
+                                                max_norm=0.1, classwise_threshold=thr, mix_up_ratio=c['ratio'], **masks)
+            names = [n for n, p in model.named_parameters() if p.requires_grad]
+            if mode == 'grads':
+                res['semi_total'] = np.float32(value)
+                res['semi_gradnames'] = np.array(names)
+                res['semi_gradnorm'] = np.array([dict(model.named_parameters())[n].grad.norm().item() for n in names], np.float32)
+                res['semi_counter'] = np.array([counter.get(k, 0) for k in range(10)])
+                res['semi_md_split'] = np.array([seen['md'][2].stop, seen['md'][3].start, seen['md'][3].stop])
+                res['semi_md_x_digest'] = np.stack([digest(seen['md'][0][i], 16) for i in range(ns + nw)])
+                _target_rows(res, 'semi_md', seen['md'][1])
+                _target_rows(res, 'semi_pseudo', seen['pseudo'])
+                res['semi_lu_x_digest'] = np.stack([digest(seen['lu'][0][i], 16) for i in range(nu)])
+                _target_rows(res, 'semi_lu', seen['lu'][1])
+            else:
+                res['semi_step_total'] = np.float32(value)
+                res['semi_step_delta'] = np.array([(dict(model.named_parameters())[n].detach() - before[n]).norm().item() for n in names],
+                                                  np.float32)
+                res['semi_ema_delta'] = np.array([(ema.shadow[n] - shadow0[n]).norm().item() for n in names], np.float32)
+        # ------------------------------------------------------------------ (b) supervised step with mix-up (engine.train)
+        c = SUP_MIX
+        ns, nw = c['n_strong'], c['n_weak']
+        rengine.data_prefetcher = _HostPrefetcher
+        args = ref_args(enc_layers=3, num_queries=20, dropout=0.0)
+        model, criterion, post = rsedt.build_model(args)
+        seeded_load(model, c['seed_w'])
+        model.train()
+        groups = [{"params": [p for n, p in model.named_parameters() if "backbone" not in n and p.requires_grad]},
+                  {"params": [p for n, p in model.named_parameters() if "backbone" in n and p.requires_grad], "lr": 1e-4}]
+        opt = torch.optim.AdamW(groups, lr=1e-4, weight_decay=1e-4)
+        x, targets = _sup_mix_batch()
+        loader = [(ru.NestedTensor(x, torch.zeros(x.shape[0], x.shape[2], x.shape[3], dtype=torch.bool)), targets)]
+        np.random.seed(c['np_seed'])
+        value = rengine.train(loader, model, criterion, opt, 0, 2, mask_weak=slice(ns, ns + nw), mask_strong=slice(ns), max_norm=0.1,
+                              mix_up_ratio=c['ratio'])
+        names = [n for n, p in model.named_parameters() if p.requires_grad]
+        res['sup_total'] = np.float32(value)
+        res['sup_gradnames'] = np.array(names)
+        res['sup_gradnorm'] = np.array([dict(model.named_parameters())[n].grad.norm().item() for n in names], np.float32)
+        res['sup_md_split'] = np.array([seen['md'][2].stop, seen['md'][3].start, seen['md'][3].stop])
+        res['sup_md_x_digest'] = np.stack([digest(seen['md'][0][i], 16) for i in range(ns + nw)])
+        _target_rows(res, 'sup_md', seen['md'][1])
+    finally:
+        rengine.mixup_data, rengine.mixup_label_unlabel = real_md, real_lu
+    np.savez_compressed(os.path.join(out, 'g15_mixup_steps.npz'), **res)
+    print('G15 ok semi total', res['semi_total'], 'split', res['semi_md_split'], 'pseudo', res['semi_pseudo_nlabels'], 'mixed unl',
+          res['semi_lu_nlabels'], '| sup total', res['sup_total'], 'split', res['sup_md_split'])
+
+
 def g13_transforms_mixup(out, rmixup, rbt):
     """G13: the reference's own transform classes (PadOrTrunc, TimeMask, FreqMask(mean), FreqShift, Normalize - NOT ApplyLog,
     which is librosa) with np.random seeded, the parameters they drew, and mixup_data / mixup_label_unlabel with their
@@ -713,7 +833,7 @@ if __name__ == '__main__':
         g9_criterion_variants(out, rsedt)
     if on('g10'):
         g10_postprocess(out, rsedt)
-    if want & {'g11', 'g12', 'g13', 'g14'} or not want:
+    if want & {'g11', 'g12', 'g13', 'g14', 'g15'} or not want:
         rengine, rmixup, rbt = import_reference_engine()
         if on('g14'):
             g14_query_patches(out, rbt)
@@ -723,3 +843,5 @@ if __name__ == '__main__':
             g13_transforms_mixup(out, rmixup, rbt)
         if on('g12'):
             g12_semi_step(out, rsedt, rengine, ru)
+        if on('g15'):
+            g15_mixup_steps(out, rsedt, rengine, rmixup, ru)

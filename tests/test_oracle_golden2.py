@@ -159,6 +159,98 @@ def test_g12_semi_step(golden_dir):
     np.testing.assert_allclose(ed, g['ema_delta'], rtol=1e-4, atol=1e-7)
 
 
+def _check_target_rows(g, key, targets, exact=True):
+    np.testing.assert_array_equal([len(t['labels']) for t in targets], g[f'{key}_nlabels'])
+    np.testing.assert_array_equal([len(t['boxes']) for t in targets], g[f'{key}_nboxes'])
+    for b, t in enumerate(targets):
+        np.testing.assert_array_equal(t['labels'].numpy(), _rows(g[f'{key}_labels'])[b])
+        cmp = np.testing.assert_array_equal if exact else (lambda a, b_: np.testing.assert_allclose(a, b_, rtol=1e-5))
+        cmp(t['boxes'].reshape(-1, 2)[:, 0].numpy(), _rows(g[f'{key}_centre'])[b])
+        cmp(t['boxes'].reshape(-1, 2)[:, 1].numpy(), _rows(g[f'{key}_length'])[b])
+        r = t['ratio'].numpy() if 'ratio' in t else np.zeros(0, np.float32)
+        np.testing.assert_allclose(r, _rows(g[f'{key}_ratio'])[b], rtol=1e-6)
+
+
+def _digest(t, n=16):
+    t = t.detach().float().flatten()
+    idx = torch.linspace(0, t.numel() - 1, n).long()
+    return np.concatenate([[t.mean().item(), t.abs().mean().item()], t[idx].numpy()]).astype(np.float32)
+
+
+def mix_draws(np_seed, bs):
+    """what np.random hands the reference's two mixups when seeded with np_seed before the iteration: mixup_data draws a Beta
+    weight and shuffles arange(bs) (mixup.py:22-29), mixup_label_unlabel another Beta weight (mixup.py:141)"""
+    np.random.seed(np_seed)
+    lam1 = float(np.random.beta(1, 1))
+    idx = np.asarray(list(range(bs)))
+    np.random.shuffle(idx)
+    lam2 = float(np.random.beta(1, 1))
+    return lam1, idx, lam2
+
+
+def test_g15_semi_step_with_mixup(golden_dir):
+    """the oracle's mean-teacher iteration with mix-up == the reference's engine.semi_train(mix_up_ratio=0.6): what both mixups
+    return (labels / boxes / ratios exact, features to rounding), the pseudo labels in between, total loss, gradient norms"""
+    g = np.load(os.path.join(golden_dir, 'g15_mixup_steps.npz'))
+    torch.set_num_threads(8)
+    c = GI.SEMI_MIX
+    ns, nw, nu = c['n_strong'], c['n_weak'], c['n_unl']
+    model = O.build_oracle_model(10, 20, 6, 3, True, True, True, dropout=0.0)
+    model.load_state_dict(O.seeded_state_dict(model.state_dict(), c['seed_w']))
+    model.train()
+    ema = S.EMA(model, 0.9)
+    ema.register()
+    gen = torch.Generator().manual_seed(5)
+    for n in ema.shadow:
+        ema.shadow[n] = ema.shadow[n] + 0.02 * ema.shadow[n].abs().mean() * torch.randn(ema.shadow[n].shape, generator=gen)
+    masks = dict(mask_strong=slice(ns), mask_weak=slice(ns, ns + nw), mask_label=slice(ns + nw), mask_unlabel=slice(ns + nw, ns + nw + nu))
+    x_t, x_s, targets = GI.semi_mix_batch()
+    trace = {}
+    sup, unsup, total, pseudo = S.semi_step(model, ema, build_oracle_criterion(10, 3, True, True), None, x_t, x_s, targets,
+                                            classwise_threshold=torch.full((10,), c['thr']), do_step=False, mix_up_ratio=c['ratio'],
+                                            mix_draws=mix_draws(c['np_seed'], ns + nw), trace=trace, **masks)
+    md = trace['md']
+    np.testing.assert_array_equal([md[2].stop, md[3].start, md[3].stop], g['semi_md_split'])
+    _check_target_rows(g, 'semi_md', md[1])
+    _check_target_rows(g, 'semi_pseudo', trace['pseudo'], exact=False)
+    _check_target_rows(g, 'semi_lu', trace['lu'][1], exact=False)
+    np.testing.assert_allclose(np.stack([_digest(md[0][i]) for i in range(ns + nw)]), g['semi_md_x_digest'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.stack([_digest(trace['lu'][0][i]) for i in range(nu)]), g['semi_lu_x_digest'], rtol=1e-5, atol=1e-6)
+    assert abs(total.item() - float(g['semi_total'])) <= 2e-5 * abs(float(g['semi_total']))
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert names == list(g['semi_gradnames'])
+    gn = np.array([dict(model.named_parameters())[n].grad.norm().item() for n in names], np.float32)
+    np.testing.assert_allclose(gn, g['semi_gradnorm'], rtol=2e-3, atol=1e-6)
+    # the fixture exercises what it is meant to: mixed strong clips, a mixed weak clip, abandoned and mixed unlabelled clips
+    assert (g['semi_md_ratio'][:ns] >= 0).any() and (g['semi_md_ratio'][ns:] >= 0).any()
+    assert (g['semi_lu_ratio'] >= 0).any(1).sum() >= 2 and (g['semi_lu_nlabels'][:5] == g['semi_pseudo_nlabels'][:5]).any()
+
+
+def test_g15_supervised_step_with_mixup(golden_dir):
+    """engine.train(mix_up_ratio=0.6): the mixing moves a weak clip into the strong part (split 5|5 -> 6|4)"""
+    g = np.load(os.path.join(golden_dir, 'g15_mixup_steps.npz'))
+    torch.set_num_threads(8)
+    c = GI.SUP_MIX
+    ns, nw = c['n_strong'], c['n_weak']
+    model = O.build_oracle_model(10, 20, 3, 3, True, True, True, dropout=0.0)
+    model.load_state_dict(O.seeded_state_dict(model.state_dict(), c['seed_w']))
+    model.train()
+    x, targets = GI.sup_mix_batch()
+    trace = {}
+    ld, total = S.train_step_mix(model, build_oracle_criterion(10, 3, True, True), None, x, targets, slice(ns), slice(ns, ns + nw),
+                                 c['ratio'], mix_draws(c['np_seed'], ns + nw)[:2], do_step=False, trace=trace)
+    md = trace['md']
+    np.testing.assert_array_equal([md[2].stop, md[3].start, md[3].stop], g['sup_md_split'])
+    assert md[2].stop != ns
+    _check_target_rows(g, 'sup_md', md[1])
+    np.testing.assert_allclose(np.stack([_digest(md[0][i]) for i in range(ns + nw)]), g['sup_md_x_digest'], rtol=1e-5, atol=1e-6)
+    assert abs(total.item() - float(g['sup_total'])) <= 2e-5 * abs(float(g['sup_total']))
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert names == list(g['sup_gradnames'])
+    gn = np.array([dict(model.named_parameters())[n].grad.norm().item() for n in names], np.float32)
+    np.testing.assert_allclose(gn, g['sup_gradnorm'], rtol=2e-3, atol=1e-6)
+
+
 def test_g13_transforms(golden_dir):
     g = np.load(os.path.join(golden_dir, 'g13_transforms_mixup.npz'))
     clips = list(g['in_db']) + [g['in_long']]
