@@ -53,6 +53,8 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='c2/c3: issue every kernel from Python instead of replaying HIP graphs')
     ap.add_argument('--model-only', action='store_true', help='c2: time fwd+bwd of the model with a fixed differentiable loss')
     ap.add_argument('--no-overlap', action='store_true', help='data parallel: one all-reduce after the backward (no cut)')
+    ap.add_argument('--mix-up-ratio', type=float, default=None,
+                    help='mix-up inside the step (engine.py:50-53, 128-133, 150-153); default: 0.6 for c5 (its recipe), off for c2/c3')
     return ap.parse_args()
 
 
@@ -176,9 +178,11 @@ def build_workload(args, dev, rank, world):
         model.to(dev).train()
         criterion.to(dev)
         opt = build_optimizer(model)
-        x, targets = synthetic_batch(B, T, seed, dev)
+        mix = args.mix_up_ratio or 0.0
+        x, targets = synthetic_batch(B, T, seed, dev if not mix else torch.device('cpu'))
+        x = x.to(dev)
         for t in targets[ns:]:
-            t['boxes'] = torch.zeros(0, 2, device=dev)
+            t['boxes'] = torch.zeros(0, 2, device=t['labels'].device)
         wm = slice(ns, B) if ns < B else None
         net = model
         if world > 1 and args.no_graph:
@@ -191,7 +195,7 @@ def build_workload(args, dev, rank, world):
             g, err = None, None
             try:
                 g = GraphedTrainStep(net, criterion, opt, x, targets, wm, slice(ns), max_norm=0.1, device_matching=not args.host_matching,
-                                     overlap_allreduce=not args.no_overlap)
+                                     overlap_allreduce=not args.no_overlap, mix_up_ratio=mix)
             except Exception as e:                      # noqa: BLE001
                 if world == 1:
                     raise
@@ -224,12 +228,12 @@ def build_workload(args, dev, rank, world):
                 opt.zero_grad(set_to_none=True)
         else:
             def step():
-                train_step(net, criterion, opt, x, targets, wm, slice(ns), max_norm=0.1)
+                train_step(net, criterion, opt, x, targets, wm, slice(ns), max_norm=0.1, mix_up_ratio=mix)
         extras.update(model=model, criterion=criterion, opt=opt, x=x, targets=targets, wm=wm, ns=ns, net=net)
         what = (f"{'URBAN-SED' if cfg == 'c2' else 'DCASE2019'} SEDT enc_layers={E} dec_at num_queries={Q} B={B}/GPU"
                 f"{'' if cfg == 'c2' else f' ({ns} strong + {B - ns} weak)'}, 10 s @ 64-mel (B,1,{T},64), full train step: fwd + "
                 f"Hungarian matching ({'host' if (args.host_matching or not graphed) else 'device'}) + SetCriterion + bwd + clip 0.1 + "
-                f"AdamW, dropout 0.1" + (" [model-only timing]" if args.model_only else ""))
+                f"AdamW, dropout 0.1" + (f", mixup {mix} inside the step" if mix else "") + (" [model-only timing]" if args.model_only else ""))
         return step, B, FLOP_PER_CLIP[cfg] * B, what, graphed, extras
     if cfg == 'eval':
         from sound_event_detection_transformer_amd.engine import GraphedPredictStep
@@ -297,17 +301,24 @@ def build_workload(args, dev, rank, world):
         t['boxes'] = torch.zeros(0, 2)
     for t in targets[n_s + n_w:]:
         t['labels'] = torch.zeros(0, dtype=torch.int64)
-    targets = to_dev(targets)
+    mix = args.mix_up_ratio if args.mix_up_ratio is not None else 0.6        # train_ss_sedt.py's recipe (README.md:134)
+    if not mix:
+        targets = to_dev(targets)                     # (with mix-up the targets stay on the host: its label half is host work)
     thr = torch.full((10,), 0.1, device=dev)          # (random-init teacher: a low threshold keeps pseudo events alive)
+    import numpy as np
+    np.random.seed(seed)
     g = GraphedSemiStep(model, ema, criterion, opt, x_t, x_s, targets, slice(n_s), slice(n_s, n_s + n_w), slice(n_s + n_w),
-                        slice(n_s + n_w, B), thr)
+                        slice(n_s + n_w, B), thr, mix_up_ratio=mix)
     extras.update(stepper=g, model=model)
 
     def step():
         g(x_t, x_s, targets)
     what = (f"semi-supervised mean-teacher step (train_ss_sedt.py) enc_layers=6 num_queries=20 per GPU: {n_s} synthetic + {n_w} weak "
             f"labelled clips fwd/bwd, {n_u} unlabelled clips through the EMA teacher (no grad) -> device pseudo labels -> student "
-            f"fwd/bwd on the augmented view, one backward, clip 0.1 + AdamW + EMA update, dropout 0.1, mixup off")
+            f"fwd/bwd on the augmented view, one backward, clip 0.1 + AdamW + EMA update, dropout 0.1, " +
+            (f"mixup {mix} inside the step (mixup_data on the labelled clips, mixup_label_unlabel of the student view with the "
+             f"pseudo labels: np.random draws + label plan on the host per step, feature mixing + label merge in the graph)"
+             if mix else "mixup off"))
     return step, B, FLOP_C5_STEP_64 * B / 64.0, what, True, extras
 
 

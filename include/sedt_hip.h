@@ -356,6 +356,10 @@ typedef struct SedtCriterion {
   /* optional device word: set to 1 (never cleared here) when the weighted total is not finite - the reference aborts on
    * such a loss (engine.py:70-73, 167-169); a graphed step polls this word instead of synchronising every step */
   int32_t* nonfinite;
+  /* optional device words {ns, n_lab} that override the two fields above as the NUMBER of strong / labelled clips of this batch
+   * (utilities/mixup.py:13-127 returns a new strong | weak split for every batch); ns / n_lab then are the capacities = the
+   * strides of the dense tables.  Lets a captured step take batches of any split. */
+  const int32_t* split;
 } SedtCriterion;
 int sedt_set_criterion(const SedtCriterion* args, void* stream);
 int sedt_set_criterion_bwd(const SedtCriterion* args, const float* g, float* glogits, float* gboxes, float* gat,
@@ -421,6 +425,8 @@ typedef struct SedtMatch {
   const float* ft_rand;     /* [ns][Q] or null */
   uint32_t ft_seed;
   const uint32_t* seed_ptr; /* or null */
+  const int32_t* split;     /* or null: device {ns, n_lab} of this batch, see SedtCriterion.split (box_off then has ns + 1
+                               entries for the capacity ns; clips >= split[0] get "no target" rows) */
 } SedtMatch;
 int sedt_match_targets(const SedtMatch* args, void* stream);
 
@@ -472,6 +478,20 @@ int sedt_encoder_attn_fwd(const void* x, const void* pos, const float* gamma, co
 int sedt_box_transform(const float* amp, int64_t raw_stride, const void* aug, const double* mean, const double* stdv, int B,
                        int frames, int F, int apply_log, int fill_mean, float fill_const, float* out, void* stream);
 int sedt_mixup(const float* x1, const float* x2, const void* jobs, int n_out, int64_t clip_elems, float* out, void* stream);
+/* sedt_mixup_targets: the LABEL half of mixup_label_unlabel (utilities/mixup.py:129-196; call site engine.py:150-153, between the
+ * teacher and the student forward of semi_train) without leaving the device.  Set 1 = the labelled targets (flat tables as
+ * sedt_match_targets reads them: lab1/lab_off1 [B1+1], box1/box_off1 [ns1+1], optional ratio1 aligned with lab1, optional split1 =
+ * device {ns, n_lab}), set 2 = the pseudo targets sedt_pseudo_labels wrote (all B2 clips with boxes).  For clip i < mix_num:
+ * more than max_events events together -> the pseudo target if it has events, else the labelled one; otherwise labels / boxes
+ * concatenated (labelled first) with ratio lam[0] for the labelled and lam[1] (= 1 - lam as the host rounds it) for the pseudo
+ * labels, unless two events of one class overlap in time -> the labelled target (and clip) replaces the unlabelled one.
+ * Clips >= mix_num keep their pseudo target.  Outputs: merged tables (capacity cap events), ratio_out (1 where the reference has no
+ * 'ratio'), jobs = B2 sedt_mixup records {i, i, mode, lam} producing the matching features from (x1 = labelled, x2 = unlabelled). */
+int sedt_mixup_targets(const int64_t* lab1, const int32_t* lab_off1, const float* box1, const int32_t* box_off1, const float* ratio1,
+                       const int32_t* split1, int B1, int ns1, const int64_t* lab2, const int32_t* lab_off2, const float* box2,
+                       const int32_t* box_off2, int B2, const float* lam, int mix_num, int max_events, int64_t* lab_out,
+                       int32_t* lab_off_out, float* box_out, int32_t* box_off_out, float* ratio_out, int cap, void* jobs,
+                       void* stream);
 
 /* SP-SEDT query patches (utilities/BoxTransforms.py:315-360, Query.transform_label; boxes from DataLoad.py:57-77 are turned into
  * row ranges on the host): for each of n_patches jobs {clip, s_idx, e_idx, 0} (int32 x 4, device memory) crop rows [s_idx, e_idx)

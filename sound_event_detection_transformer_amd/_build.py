@@ -1,38 +1,63 @@
-"""Build libsedt_hip.so (gfx950) in-tree with hipcc.  Cross-compiles without a GPU."""
+"""Build libsedt_hip.so (gfx950) in-tree with hipcc.  Cross-compiles without a GPU.
+
+One object per source file (cached under build/obj, recompiled when the source or any header is newer), compiled in
+parallel, then one link: editing a kernel costs the compile of its own file, not of the library."""
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsedt_hip.so')
-SOURCES = ['igemm.hip', 'igemm2.hip', 'igemm3.hip', 'wgrad2.hip', 'wgrad3.hip', 'wgrad4.hip', 'misc.hip', 'stem.hip', 'conv3x3_c64.hip', 'norm_attn.hip', 'attn_mfma.hip', 'criterion.hip', 'postproc.hip', 'input.hip', 'skinny.hip', 'host.cpp']
+OBJ = os.path.join(HERE, '..', 'build', 'obj')
+SOURCES = ['igemm.hip', 'igemm2.hip', 'igemm3.hip', 'wgrad2.hip', 'wgrad3.hip', 'wgrad4.hip', 'misc.hip', 'stem.hip', 'conv3x3_c64.hip',
+           'norm_attn.hip', 'attn_mfma.hip', 'criterion.hip', 'postproc.hip', 'input.hip', 'skinny.hip', 'host.cpp']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-failed']
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    return hs + [os.path.join(HERE, '..', 'include', 'sedt_hip.h'), os.path.abspath(__file__)]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'sedt_hip.h')]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
+def build(force=False, verbose=False, jobs=None):
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    objs = [os.path.join(OBJ, s + '.o') for s in SOURCES]
+    heads = _headers()
+    todo = [(s, o) for s, o in zip(srcs, objs) if force or _newer(o, [s] + heads)]
+    if not todo and not _newer(LIB, objs):
+        return LIB
     if not os.path.exists(hipcc):
         raise RuntimeError('hipcc not found: cannot build libsedt_hip.so')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-pass-failed',
-           *[os.path.join(CSRC, s) for s in SOURCES], '-o', LIB + '.tmp']
-    if verbose:
-        print(' '.join(cmd))
+    os.makedirs(OBJ, exist_ok=True)
+
+    def compile_one(so):
+        cmd = [hipcc, *FLAGS, '-c', so[0], '-o', so[1]]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed on {so[0]}:\n' + r.stdout + r.stderr)
+
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIB + '.tmp']
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError('hipcc failed:\n' + r.stdout + r.stderr)
+        raise RuntimeError('link failed:\n' + r.stdout + r.stderr)
     os.replace(LIB + '.tmp', LIB)
     return LIB
 
 
 if __name__ == '__main__':
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force='--force' in sys.argv, verbose=True))

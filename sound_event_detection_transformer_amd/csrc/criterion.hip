@@ -37,6 +37,10 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
   __shared__ int card[SEDT_CRIT_MAXCARD];      // predicted-event count of every (dense layer, clip): integer LDS atomics
   const int t = threadIdx.x;
   const int L = a.L, B = a.B, ns = a.ns, Q = a.Q, C1 = a.C + 1, C = a.C;
+  // strong / labelled clip counts as DATA (mix-up moves clips across the strong | weak boundary per batch): a.ns / a.n_lab
+  // stay the strides and capacities of the dense tables
+  const int ns_eff = a.split ? min(a.split[0], ns) : ns;
+  const int n_lab_eff = a.split ? min(a.split[1], a.n_lab) : a.n_lab;
   float nb;
   if (a.num_boxes) nb = a.num_boxes[0];
   else {                                        // num_boxes = sum of the box weights of the final layer (sedt.py:330)
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
       for (int c = 0; c < C1; ++c)
         if (x[c] > m) { m = x[c]; amax = c; }
       if (amax != C) atomicAdd(&card[d * B + b], 1);
-      if (b >= ns) {                            // not strongly labelled: no CE / box loss, zero grads
+      if (b >= ns_eff) {                        // not strongly labelled: no CE / box loss, zero grads
         for (int c = 0; c < C1; ++c) gx[c] = 0.f;
         gbx[0] = 0.f; gbx[1] = 0.f;
         gbx2[0] = 0.f; gbx2[1] = 0.f;
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
   // ---------------- audio-tag BCE (mean over n_lab x C), torch semantics: log clamped at -100, grad denominator >= 1e-12
   float weak = 0.f;
   if (a.at) {
-    const int n = a.n_lab * C;
+    const int n = n_lab_eff * C;
     for (int r = t; r < a.Bat * C; r += 1024) {
       float g = 0.f;
       if (r < n) {
@@ -185,8 +189,8 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
           const float at = a.alpha_fl < 0.f ? 1.f : a.alpha_fl * y + (1.f - a.alpha_fl) * (1.f - y);
           const float mg = a.gamma_fl == 1.f ? mod : powf(mod, a.gamma_fl);
           const float dmg = a.gamma_fl == 1.f ? 1.f : a.gamma_fl * powf(mod, a.gamma_fl - 1.f);
-          weak += at * ce * mg / (float)a.n_lab;
-          g = at * (dce * mg + ce * dmg * dmod) / (float)a.n_lab;
+          weak += at * ce * mg / (float)n_lab_eff;
+          g = at * (dce * mg + ce * dmg * dmod) / (float)n_lab_eff;
         } else {
           weak += ce / (float)n;
           g = dce / (float)n;
@@ -294,6 +298,8 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
   const int L = a.L, B = a.B, ns = a.ns, Q = a.Q, C = a.C, C1 = a.C + 1;
+  const int ns_eff = a.split ? min(a.split[0], ns) : ns;          // (see set_criterion_kernel: the split as data)
+  const int n_lab_eff = a.split ? min(a.split[1], a.n_lab) : a.n_lab;
   if ((int)blockIdx.x == L * ns) {
     // ---- bookkeeping block: per-clip target counts (cardinality) and the clip-level tag targets (sedt.py:199-209)
     float* row = lds + lane * (C + 1);          // this lane's tag row lives in LDS until it is complete
@@ -302,7 +308,8 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
       a.tgt_len[b] = (float)n;
       if (a.gt_weak && b < a.n_lab) {
         for (int c = 0; c < C; ++c) row[c] = 0.f;
-        for (int j = 0; j < n; ++j) row[a.lab_cat[o + j]] += a.ratio_cat ? a.ratio_cat[o + j] : 1.f;
+        if (b < n_lab_eff)
+          for (int j = 0; j < n; ++j) row[a.lab_cat[o + j]] += a.ratio_cat ? a.ratio_cat[o + j] : 1.f;
         float* g = a.gt_weak + (long)b * C;
         for (int c = 0; c < C; ++c) g[c] = fminf(fmaxf(row[c], 0.f), 1.f);
       }
@@ -311,6 +318,14 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
   }
   const int d = blockIdx.x / ns, b = blockIdx.x % ns;
   const int ml = a.layer_of[d];
+  if (b >= ns_eff) {                       // beyond this batch's strong part: "no target" rows, zero box weight
+    if (lane < Q) {
+      const long di = ((long)d * ns + b) * Q + lane;
+      a.tc[di] = (float)C; a.coef[di] = 1.f; a.wbox[di] = 0.f; a.tbox[2 * di] = 0.5f; a.tbox[2 * di + 1] = 0.5f; a.tidx[di] = 0.f;
+      if (a.assign) a.assign[di] = -1;
+    }
+    return;
+  }
   const int bo = a.box_off[b], n = a.box_off[b + 1] - bo, lo = a.lab_off[b];
   float* prob = lds;                       // [Q][C1]: class part of the matching cost per (query, class)
   float* cst = lds + Q * C1;               // [Q][n]

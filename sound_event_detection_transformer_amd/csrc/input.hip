@@ -129,6 +129,97 @@ __global__ __launch_bounds__(256) void mixup_kernel(const float* __restrict__ x1
   }
 }
 
+// ---- label half of mixup_label_unlabel (reference utilities/mixup.py:129-196) on the device.  In the mean-teacher step the
+// pseudo labels of the unlabelled clips are produced ON the device between the teacher and the student forward
+// (pseudo_labels_kernel), so the merge with the labelled targets cannot be planned on the host without a device->host copy in
+// the middle of the step.  One workgroup, one wave per unlabelled clip i (round robin):
+//   i < mix_num:  n1 + n2 > max_events -> the pseudo target (if it has events) else the labelled one;
+//                 else candidate = labels1 ++ labels2, boxes1 ++ boxes2, ratio = lam x len(labels1) ++ (1-lam) x len(labels2);
+//                 two events of one class overlapping in time (sorted by onset: end[k] < onset[k+1] violated; evaluated pair-wise
+//                 in the reference's f32 arithmetic) -> abandoned: the labelled clip and its target replace the unlabelled one;
+//   i >= mix_num: the pseudo target unchanged.
+// Outputs: the merged targets in the flat layout match_targets_kernel reads (every clip counts as strong), and the MixJob records
+// that make mixup_kernel produce the matching features (mode 0 mix, 1 labelled clip, 2 unlabelled clip).
+struct MixTargets {
+  const int64_t* lab1; const int32_t* lab_off1; const float* box1; const int32_t* box_off1; const float* ratio1; const int32_t* split1;
+  const int64_t* lab2; const int32_t* lab_off2; const float* box2; const int32_t* box_off2;
+  const float* lam;              // device {lam, 1 - lam} as the host rounded them to f32
+  int64_t* lab_out; int32_t* lab_off_out; float* box_out; int32_t* box_off_out; float* ratio_out;
+  MixJob* jobs;
+  int32_t B1, ns1, B2, mix_num, max_events, cap;
+};
+
+__global__ __launch_bounds__(1024) void mixup_targets_kernel(const MixTargets a) {
+  extern __shared__ int sm[];                 // [B2] decision, [B2+1] label offsets, [B2+1] box offsets
+  int* dec = sm;
+  int* lo = sm + a.B2;
+  int* bo = lo + a.B2 + 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int ns1 = a.split1 ? min(a.split1[0], a.ns1) : a.ns1;
+  for (int i = wave; i < a.B2; i += nw) {
+    const int l2o = a.lab_off2[i], nl2 = a.lab_off2[i + 1] - l2o, b2o = a.box_off2[i], nb2 = a.box_off2[i + 1] - b2o;
+    int d = 2, nl = nl2, nb = nb2;
+    if (i < a.mix_num && i < a.B1) {
+      const int l1o = a.lab_off1[i], nl1 = a.lab_off1[i + 1] - l1o;
+      const int b1o = i < ns1 ? a.box_off1[i] : 0, nb1 = i < ns1 ? a.box_off1[i + 1] - b1o : 0;
+      if (nb1 + nb2 > a.max_events) {
+        if (nb2 == 0) { d = 1; nl = nl1; nb = nb1; }
+      } else {
+        const int n = nb1 + nb2;                     // candidate boxes; box j carries label j of the concatenated LABEL list
+        bool clash = false;
+        for (int j = lane; j < n; j += 64) {
+          const float cj = j < nb1 ? a.box1[2 * (b1o + j)] : a.box2[2 * (b2o + j - nb1)];
+          const float lj = j < nb1 ? a.box1[2 * (b1o + j) + 1] : a.box2[2 * (b2o + j - nb1) + 1];
+          const long ej = j < nl1 ? a.lab1[l1o + j] : a.lab2[l2o + j - nl1];
+          const float sj = cj - lj / 2, tj = cj + lj / 2;
+          for (int k = 0; k < j; ++k) {
+            const long ek = k < nl1 ? a.lab1[l1o + k] : a.lab2[l2o + k - nl1];
+            if (ek != ej) continue;
+            const float ck = k < nb1 ? a.box1[2 * (b1o + k)] : a.box2[2 * (b2o + k - nb1)];
+            const float lk = k < nb1 ? a.box1[2 * (b1o + k) + 1] : a.box2[2 * (b2o + k - nb1) + 1];
+            const float sk = ck - lk / 2, tk = ck + lk / 2;
+            if (!(tj < sk) && !(tk < sj)) clash = true;
+          }
+        }
+        if (__any(clash)) { d = 1; nl = nl1; nb = nb1; }
+        else { d = 0; nl = nl1 + nl2; nb = n; }
+      }
+    }
+    if (lane == 0) { dec[i] = d; lo[i + 1] = nl; bo[i + 1] = nb; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lo[0] = 0; bo[0] = 0;
+    for (int i = 0; i < a.B2; ++i) { lo[i + 1] += lo[i]; bo[i + 1] += bo[i]; }
+  }
+  __syncthreads();
+  const bool fits = lo[a.B2] <= a.cap && bo[a.B2] <= a.cap;      // (capacity = B2 * max_targets >= max_events per clip: always)
+  for (int i = threadIdx.x; i <= a.B2; i += blockDim.x) {
+    a.lab_off_out[i] = fits ? lo[i] : 0;
+    a.box_off_out[i] = fits ? bo[i] : 0;
+  }
+  const float lam = a.lam[0], lam1 = a.lam[1];
+  for (int i = wave; i < a.B2; i += nw) {
+    const int d = dec[i];
+    if (lane == 0) a.jobs[i] = MixJob{i, i, d, d == 0 ? lam : 0.f};
+    if (!fits) continue;
+    const int l2o = a.lab_off2[i], nl2 = a.lab_off2[i + 1] - l2o, b2o = a.box_off2[i], nb2 = a.box_off2[i + 1] - b2o;
+    int l1o = 0, nl1 = 0, b1o = 0, nb1 = 0;
+    if (d != 2) {
+      l1o = a.lab_off1[i]; nl1 = a.lab_off1[i + 1] - l1o;
+      if (i < ns1) { b1o = a.box_off1[i]; nb1 = a.box_off1[i + 1] - b1o; }
+    }
+    const int take1 = d == 2 ? 0 : nl1, take2 = d == 1 ? 0 : nl2;
+    for (int j = lane; j < take1 + take2; j += 64) {
+      a.lab_out[lo[i] + j] = j < take1 ? a.lab1[l1o + j] : a.lab2[l2o + j - take1];
+      if (a.ratio_out) a.ratio_out[lo[i] + j] = d == 0 ? (j < take1 ? lam : lam1) : (d == 1 && a.ratio1 ? a.ratio1[l1o + j] : 1.f);
+    }
+    const int tb1 = d == 2 ? 0 : nb1, tb2 = d == 1 ? 0 : nb2;
+    for (int j = lane; j < 2 * (tb1 + tb2); j += 64)
+      a.box_out[2 * bo[i] + j] = j < 2 * tb1 ? a.box1[2 * b1o + j] : a.box2[2 * b2o + j - 2 * tb1];
+  }
+}
+
 // ---- SP-SEDT query patches (reference utilities/BoxTransforms.py:315-360, Query.transform_label): crop rows [s, e) of a
 // transformed clip, min-max normalise to [0, 1], quantise to 8 bits (torchvision ToPILImage: x 255, truncated), resize to 128
 // rows with PIL's bilinear resampling, back to float (/ 255) and de-normalise.  Only the vertical pass of Pillow's
@@ -256,4 +347,23 @@ extern "C" int sedt_mixup(const float* x1, const float* x2, const void* jobs, in
   hipLaunchKernelGGL(mixup_kernel, dim3(gx, n_out), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x1, x2,
                      reinterpret_cast<const MixJob*>(jobs), c4, out);
   return check_launch("mixup");
+}
+
+extern "C" int sedt_mixup_targets(const int64_t* lab1, const int32_t* lab_off1, const float* box1, const int32_t* box_off1,
+                                  const float* ratio1, const int32_t* split1, int B1, int ns1, const int64_t* lab2,
+                                  const int32_t* lab_off2, const float* box2, const int32_t* box_off2, int B2, const float* lam,
+                                  int mix_num, int max_events, int64_t* lab_out, int32_t* lab_off_out, float* box_out,
+                                  int32_t* box_off_out, float* ratio_out, int cap, void* jobs, void* stream) {
+  using namespace sedt;
+  SEDT_REQUIRE(lab1 && lab_off1 && box1 && box_off1 && lab2 && lab_off2 && box2 && box_off2 && lam && lab_out && lab_off_out &&
+                   box_out && box_off_out && jobs,
+               "mixup_targets: null pointer");
+  SEDT_REQUIRE(B1 >= 0 && B2 >= 1 && B2 <= 4096 && ns1 >= 0 && ns1 <= B1 && mix_num >= 0 && mix_num <= B2 && mix_num <= B1 &&
+                   max_events >= 0 && cap >= 1,
+               "mixup_targets: B1=%d ns1=%d B2=%d mix_num=%d", B1, ns1, B2, mix_num);
+  MixTargets a{lab1, lab_off1, box1, box_off1, ratio1, split1, lab2, lab_off2, box2, box_off2, lam, lab_out, lab_off_out, box_out,
+               box_off_out, ratio_out, reinterpret_cast<MixJob*>(jobs), B1, ns1, B2, mix_num, max_events, cap};
+  hipLaunchKernelGGL(mixup_targets_kernel, dim3(1), dim3(1024), (3 * (size_t)B2 + 2) * sizeof(int),
+                     reinterpret_cast<hipStream_t>(stream), a);
+  return check_launch("mixup_targets");
 }

@@ -2,6 +2,7 @@
 import math
 
 import os
+import numpy as np
 import torch
 
 from . import ops
@@ -35,6 +36,30 @@ def allreduce_mean(flat, async_op=False):
     return _Done() if async_op else flat
 
 
+class _Upload(object):
+    """small host -> device table refreshed before every replay of a graph: a ring of pinned staging buffers (a slot is reused
+    only after the copy that last read it has finished), asynchronous copies on the current stream"""
+
+    def __init__(self, nbytes, dev, slots=4):
+        self.dev_buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self._pin = [torch.zeros(nbytes, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self._ev = [None] * slots
+        self._k = 0
+
+    def send(self, raw):
+        """raw: CPU uint8 tensor (<= nbytes)"""
+        k = self._k
+        self._k = (k + 1) % len(self._pin)
+        if self._ev[k] is not None:
+            self._ev[k].synchronize()
+        n = raw.numel()
+        self._pin[k][:n].copy_(raw)
+        self.dev_buf[:n].copy_(self._pin[k][:n], non_blocking=True)
+        self._ev[k] = torch.cuda.Event()
+        self._ev[k].record()
+        return self.dev_buf
+
+
 _step_streams = {}
 
 
@@ -54,9 +79,15 @@ _CAPTURE = dict(capture_error_mode='thread_local')
 
 
 def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None, mask_strong=None, max_norm=0.1,
-               normalize=False, check_finite=True, patches=None, allreduce=False, fine_tune=False, fl=False):
-    """forward -> SetCriterion -> weighted sum over weight_dict -> backward -> clip_grad_norm_(max_norm) -> step ->
-    zero_grad.  Raises on a non-finite loss (the reference calls sys.exit(1), engine.py:70-73).
+               normalize=False, check_finite=True, patches=None, allreduce=False, fine_tune=False, fl=False, mix_up_ratio=0,
+               do_step=True):
+    """[mixup_data ->] forward -> SetCriterion -> weighted sum over weight_dict -> backward -> clip_grad_norm_(max_norm) ->
+    step -> zero_grad.  Raises on a non-finite loss (the reference calls sys.exit(1), engine.py:70-73).
+
+    mix_up_ratio > 0 (engine.py:50-53): the batch goes through utilities.mixup.mixup_data first (np.random draws as the
+    reference's) and the criterion uses the strong | weak split it returns.  do_step=False withholds clip + optimizer step +
+    zero_grad: gradients keep accumulating, as in the reference's loop while (i + 1) % accumrating_gradient_steps != 0
+    (engine.py:76).
 
     When called on the default stream the step runs on a dedicated side stream (ordered after / before the caller's
     stream): a backward pass executed on the DEFAULT stream leaves the parameters' gradient accumulators tied to it, and
@@ -70,9 +101,12 @@ def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             out = train_step(model, criterion, optimizer, batch_input, targets, mask_weak, mask_strong, max_norm, normalize,
-                             check_finite, patches, allreduce, fine_tune, fl)
+                             check_finite, patches, allreduce, fine_tune, fl, mix_up_ratio, do_step)
         cur.wait_stream(side)
         return out
+    if mix_up_ratio:
+        from .utilities.mixup import mixup_data
+        batch_input, targets, mask_strong, mask_weak = mixup_data(batch_input, targets, mask_strong, mask_weak, mix_up_ratio, alpha=1)
     outputs = model(batch_input, patches) if patches is not None else model(batch_input)
     loss_dict, _ = criterion(outputs, targets, mask_weak, mask_strong, fine_tune, normalize, fl)
     wd = criterion.weight_dict
@@ -86,6 +120,8 @@ def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None
         if not math.isfinite(v):
             raise FloatingPointError(f'Loss is {v}, stopping training: {loss_dict}')
     losses.backward()
+    if not do_step:
+        return losses.detach(), {k: v.detach() for k, v in loss_dict.items()}
     dp = allreduce and torch.distributed.is_available() and torch.distributed.is_initialized() \
         and torch.distributed.get_world_size() > 1
     if isinstance(optimizer, FusedAdamW) and dp:
@@ -199,14 +235,17 @@ class GraphedTrainStep(_GraphedBase):
     def __init__(self, model, criterion, optimizer, example_input, example_targets, mask_weak=None, mask_strong=None,
                  max_norm=0.1, normalize=False, warmup=3, device_matching=True, max_targets=32, async_wgrad=False,
                  overlap_allreduce=True, coschedule=False, data_parallel=None, example_patches=None, fine_tune=False, fl=False,
-                 ft_rand=None):
+                 ft_rand=None, mix_up_ratio=0.0, mix_alpha=1, max_events=20):
         import gc
         from . import runtime
         from .sedt import TargetTables
         if not isinstance(optimizer, FusedAdamW):
             raise RuntimeError('GraphedTrainStep needs FusedAdamW (device-side step count, one pointer table)')
-        if (fine_tune or fl) and not device_matching:
-            raise NotImplementedError('fine_tune / fl are built for the device-matching graph')
+        if (fine_tune or fl or mix_up_ratio) and not device_matching:
+            raise NotImplementedError('fine_tune / fl / mix-up are built for the device-matching graph')
+        if mix_up_ratio and example_patches is not None:
+            raise NotImplementedError('mix-up is not part of the SP-SEDT recipe (train_spsedt.py has no --mix_up_ratio)')
+        self.mix, self.mix_alpha, self.max_events = float(mix_up_ratio), mix_alpha, max_events
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.mw, self.ms, self.max_norm, self.normalize = mask_weak, mask_strong, max_norm, normalize
         self.fine_tune, self.fl, self.ft_rand = fine_tune, fl, ft_rand
@@ -238,6 +277,14 @@ class GraphedTrainStep(_GraphedBase):
         self._init_common(criterion, optimizer, dev)
         self.static_x = example_input.clone()
         self.static_patches = None if example_patches is None else example_patches.clone()
+        if self.mix:
+            # mix-up (engine.py:50-53) inside the graph: the raw batch is a second static buffer, the feature mixing its first
+            # kernel (job records refreshed per replay), the merged targets + the strong | weak split arrive as table data
+            from .utilities.mixup import job_table
+            self.static_raw = example_input.clone().float().contiguous()
+            self.static_x = torch.empty_like(self.static_raw)
+            self._jobs = _Upload(16 * self.static_raw.shape[0], dev)
+            self._jobs.send(job_table([(i, 0, 1, 0.0) for i in range(self.static_raw.shape[0])]))     # identity until the first call
         snap = _snapshot(net, optimizer)
         side = train_stream(dev)
         self._capture = dict(stream=side, **_CAPTURE)
@@ -304,10 +351,12 @@ class GraphedTrainStep(_GraphedBase):
         B = len(example_targets)
         ns = len(example_targets[self.ms])
         n_lab = self.mw.stop if self.mw is not None else self.ms.stop
-        return TargetTables(B, ns, n_lab, self.dev, max_targets=max_targets,
-                            with_ratio=any('ratio' in t for t in example_targets)).load(example_targets)
+        return TargetTables(B, ns, n_lab, self.dev, max_targets=max_targets, dynamic_split=bool(self.mix),
+                            with_ratio=bool(self.mix) or any('ratio' in t for t in example_targets)).load(example_targets)
 
     def _forward(self):
+        if self.mix:
+            ops.mixup(self.static_raw, self.static_raw, self._jobs.dev_buf, out=self.static_x)
         if self.static_patches is not None:
             mask = torch.zeros(self.static_x.shape[0], self.static_x.shape[2], self.static_x.shape[3], dtype=torch.bool, device=self.dev)
             return self.model((self.static_x, mask), self.static_patches)
@@ -363,13 +412,25 @@ class GraphedTrainStep(_GraphedBase):
             self.flat_g = self.optimizer.gather_grads()      # all gradients -> one flat buffer (one launch)
 
     def __call__(self, batch_input, targets, check_finite=False, patches=None):
-        self.static_x.copy_(batch_input, non_blocking=True)
+        """one step on (batch_input, targets).  With mix-up the batch arrives UNMIXED in the layout the stepper was built with
+        (strong clips, then weak ones); the np.random draws, the label bookkeeping and the new split happen here on the host
+        (utilities.mixup.plan_mixup_data), the feature mixing inside the graph.  Keep the targets on the host for that."""
+        split = {}
+        if self.mix:
+            from .utilities.mixup import draw_mixup_data, plan_mixup_data, job_table
+            lam, index = draw_mixup_data(len(targets), self.mix_alpha)
+            jobs, targets, n_strong, n_weak = plan_mixup_data(targets, self.ms, self.mw, lam, index, self.mix, self.max_events)
+            self.static_raw.copy_(batch_input, non_blocking=True)
+            self._jobs.send(job_table(jobs))
+            split = dict(ns=n_strong, n_lab=n_strong + n_weak)
+        else:
+            self.static_x.copy_(batch_input, non_blocking=True)
         if self.static_patches is not None:
             self.static_patches.copy_(patches, non_blocking=True)
         self.runtime.bump_seed(self.dev)
         self._before_replay()
         if self.device_matching:
-            self.tables.load(targets)
+            self.tables.load(targets, **split)
             self.g_fwd.replay()
         else:
             self.g_fwd.replay()
@@ -516,9 +577,12 @@ def semi_train_step(model, ema, criterion, optimizer, batch_input_teacher, batch
                     counter=None, check_finite=True, do_step=True, do_ema=True, mix_up_ratio=0):
     """one iteration of the reference's semi_train (engine.py:117-181): supervised loss on the labelled part -> teacher
     (EMA weights swapped in, no grad) on the unlabelled part -> pseudo labels -> student on the augmented unlabelled part ->
-    ONE backward over both graphs -> clip / AdamW -> EMA update.  Returns (sup dict, unsup dict, total, pseudo targets)."""
-    if mix_up_ratio:
-        raise NotImplementedError('mixup inside the semi step: apply utilities.mixup.mixup_data / mixup_label_unlabel around it')
+    ONE backward over both graphs -> clip / AdamW -> EMA update.  Returns (sup dict, unsup dict, total, pseudo targets).
+
+    mix_up_ratio > 0 (engine.py:128-133, 150-153; train_ss_sedt.py --mix_up_ratio): the labelled part goes through mixup_data
+    before its forward, and the student's unlabelled view + the pseudo labels through mixup_label_unlabel - mixed with the
+    ALREADY MIXED labelled batch, as the reference passes it on - between the teacher and the student forward.  The pseudo
+    targets returned are then the mixed ones (what the student's criterion saw)."""
     dev = _tensors(batch_input_teacher).device
     if dev.type == 'cuda' and torch.cuda.current_stream(dev) == torch.cuda.default_stream(dev):
         side, cur = train_stream(dev), torch.cuda.current_stream(dev)
@@ -531,7 +595,11 @@ def semi_train_step(model, ema, criterion, optimizer, batch_input_teacher, batch
         return out
     xt, xs = _tensors(batch_input_teacher), _tensors(batch_input_student)
     wd = criterion.weight_dict
-    sup, _ = criterion(model(xt[mask_label]), targets[mask_label], mask_weak, mask_strong, fine_tune, normalize, fl)
+    x_lab, t_lab = xt[mask_label], targets[mask_label]
+    if mix_up_ratio > 0:
+        from .utilities.mixup import mixup_data, mixup_label_unlabel
+        x_lab, t_lab, mask_strong, mask_weak = mixup_data(x_lab, t_lab, mask_strong, mask_weak, mix_up_ratio=mix_up_ratio, alpha=1)
+    sup, _ = criterion(model(x_lab), t_lab, mask_weak, mask_strong, fine_tune, normalize, fl)
     sup_total = criterion.last_total
     unl = [dict(t) for t in targets[mask_unlabel]]
     ema.apply_shadow()
@@ -541,6 +609,8 @@ def semi_train_step(model, ema, criterion, optimizer, batch_input_teacher, batch
         pseudo = get_pseudo_labels(tea, None, sizes, unl, counter, classwise_threshold=classwise_threshold)
     ema.restore()
     x_u = xs[mask_unlabel]
+    if mix_up_ratio > 0:
+        x_u, pseudo = mixup_label_unlabel(x_lab, x_u, t_lab, pseudo, alpha=1)
     unsup, _ = criterion(model(x_u), pseudo, None, slice(x_u.shape[0]), fine_tune, normalize, fl)
     total = sup_total + criterion.last_total
     criterion.last_total = None
@@ -588,7 +658,8 @@ class GraphedSemiStep(_GraphedBase):
 
     def __init__(self, model, ema, criterion, optimizer, x_teacher, x_student, targets, mask_strong, mask_weak, mask_label,
                  mask_unlabel, classwise_threshold, orig_size=10.0, fine_tune=False, normalize=False, fl=False, max_norm=0.1,
-                 warmup=2, max_targets=32, accumulating_ema_steps=1, fuse_student_forwards=True):
+                 warmup=2, max_targets=32, accumulating_ema_steps=1, fuse_student_forwards=True, mix_up_ratio=0.0, mix_alpha=1,
+                 max_events=20):
         import gc
         from . import runtime
         from .sedt import TargetTables
@@ -604,6 +675,7 @@ class GraphedSemiStep(_GraphedBase):
         # concatenation instead of two (clips are independent end to end - FrozenBatchNorm, per-clip attention - so every clip's
         # outputs are what its own forward gives; the GEMMs see twice the rows, the step half the launches)
         self.fuse = fuse_student_forwards
+        self.mix, self.mix_alpha, self.max_events = float(mix_up_ratio), mix_alpha, max_events
         xt, xs = _tensors(x_teacher), _tensors(x_student)
         dev = xt.device
         self.dev = dev
@@ -631,9 +703,26 @@ class GraphedSemiStep(_GraphedBase):
         n_lab = mask_weak.stop if mask_weak is not None else mask_strong.stop
         Q = model.num_queries
         self.counter = torch.zeros(criterion.num_classes, dtype=torch.int32, device=dev)
-        self.tab_l = TargetTables(n_l, ns, n_lab, dev, max_targets=max_targets,
-                                  with_ratio=any('ratio' in t for t in lab_t)).load(lab_t)
+        self.tab_l = TargetTables(n_l, ns, n_lab, dev, max_targets=max_targets, dynamic_split=bool(self.mix),
+                                  with_ratio=bool(self.mix) or any('ratio' in t for t in lab_t)).load(lab_t)
         self.tab_u = TargetTables(n_u, n_u, n_u, dev, max_targets=max(Q, 1))
+        if self.mix:
+            # mix-up inside the step (engine.py:128-133, 150-153): raw labelled / unlabelled-student clips are static inputs, the two
+            # feature mixings are kernels of the graph writing the student's input x_cat; the labelled targets arrive mixed from
+            # the host (plan_mixup_data), the unlabelled ones are merged ON the device with the pseudo labels the graph itself
+            # produces (ops.mixup_targets) - nothing leaves the device between teacher and student forward
+            from .utilities.mixup import job_table
+            self.mix_num_u = int(n_l * 0.5)                   # mixup_label_unlabel's default mix_up_ratio (engine.py:150 passes none)
+            if self.mix_num_u > n_u:
+                raise ValueError(f'mixup_label_unlabel mixes {self.mix_num_u} unlabelled clips, the batch has {n_u}')
+            self.x_lab_raw, self.x_stu_raw = self.x_lab.clone(), self.x_stu.clone()
+            self.tab_p = self.tab_u                           # pseudo labels as the teacher gives them
+            self.tab_u = TargetTables(n_u, n_u, n_u, dev, max_targets=max(max_targets, max_events, Q), with_ratio=True)
+            self._jobs_l = _Upload(16 * n_l, dev)
+            self._jobs_l.send(job_table([(i, 0, 1, 0.0) for i in range(n_l)]))
+            self._lam_u = _Upload(8, dev)
+            self._lam_u.send(torch.from_numpy(np.asarray([1.0, 0.0], np.float32).view(np.uint8).copy()))
+            self.jobs_u = torch.zeros(16 * n_u, dtype=torch.uint8, device=dev)
         snap = _snapshot(model, optimizer, ema)
         side = train_stream(dev)
         self._capture = dict(stream=side, **_CAPTURE)
@@ -671,6 +760,8 @@ class GraphedSemiStep(_GraphedBase):
             self.ema.update()
             return
         crit, model = self.criterion, self.model
+        if self.mix:
+            ops.mixup(self.x_lab_raw, self.x_lab_raw, self._jobs_l.dev_buf, out=self.x_lab)
         if not self.fuse:
             out_l = model(self.x_lab)
             self.sup = crit.compute(out_l, crit.prepare_device(out_l, self.tab_l, **self.flags), self.fl)
@@ -681,7 +772,13 @@ class GraphedSemiStep(_GraphedBase):
                 tea = model(self.x_tea)
         finally:
             self.ema.restore()
-        pseudo_label_tables(tea, self.threshold, self.orig_size, self.tab_u, self.counter)
+        if self.mix:
+            pseudo_label_tables(tea, self.threshold, self.orig_size, self.tab_p, self.counter)
+            ops.mixup_targets(self.tab_l, self.tab_p, self._lam_u.dev_buf.view(torch.float32), self.mix_num_u, self.tab_u, self.jobs_u,
+                              self.max_events)
+            ops.mixup(self.x_lab, self.x_stu_raw, self.jobs_u, out=self.x_stu)
+        else:
+            pseudo_label_tables(tea, self.threshold, self.orig_size, self.tab_u, self.counter)
         if self.fuse:
             out = model(self.x_cat)
             n = self.x_lab.shape[0]
@@ -707,10 +804,22 @@ class GraphedSemiStep(_GraphedBase):
 
     def __call__(self, x_teacher, x_student, targets, check_finite=False):
         xt, xs = _tensors(x_teacher), _tensors(x_student)
-        self.x_lab.copy_(xt[self.ml], non_blocking=True)
         self.x_tea.copy_(xt[self.mu], non_blocking=True)
-        self.x_stu.copy_(xs[self.mu], non_blocking=True)
-        self.tab_l.load(targets[self.ml])
+        if self.mix:
+            from .utilities.mixup import draw_mixup_data, draw_mixup_label_unlabel, plan_mixup_data, job_table, lam_pair
+            lab_t = targets[self.ml]
+            lam, index = draw_mixup_data(len(lab_t), self.mix_alpha)            # np.random in the reference's order (mixup.py:22-29,
+            lam_u = draw_mixup_label_unlabel(self.mix_alpha)                    # then :141; nothing else draws in between)
+            jobs, lab_t, n_strong, n_weak = plan_mixup_data(lab_t, self.ms, self.mw, lam, index, self.mix, self.max_events)
+            self.x_lab_raw.copy_(xt[self.ml], non_blocking=True)
+            self.x_stu_raw.copy_(xs[self.mu], non_blocking=True)
+            self._jobs_l.send(job_table(jobs))
+            self._lam_u.send(torch.from_numpy(lam_pair(lam_u).view(np.uint8).copy()))
+            self.tab_l.load(lab_t, ns=n_strong, n_lab=n_strong + n_weak)
+        else:
+            self.x_lab.copy_(xt[self.ml], non_blocking=True)
+            self.x_stu.copy_(xs[self.mu], non_blocking=True)
+            self.tab_l.load(targets[self.ml])
         self.runtime.bump_seed(self.dev)
         self._before_replay()
         self.graph.replay()

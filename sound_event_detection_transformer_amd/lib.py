@@ -52,7 +52,7 @@ class SedtCriterion(C.Structure):
                [(n, C.c_int32) for n in ('L', 'B', 'ns', 'Q', 'C', 'n_lab', 'Bat')] + \
                [('layer_of', C.c_int32 * CRIT_MAXL), ('w_ce', C.c_float * CRIT_MAXL), ('w_bbox', C.c_float * CRIT_MAXL),
                 ('w_giou', C.c_float * CRIT_MAXL), ('w_weak', C.c_float), ('fl', C.c_int32), ('alpha_fl', C.c_float),
-                ('gamma_fl', C.c_float), ('nonfinite', C.c_void_p)]
+                ('gamma_fl', C.c_float), ('nonfinite', C.c_void_p), ('split', C.c_void_p)]
 
 
 class SedtMatch(C.Structure):
@@ -62,7 +62,7 @@ class SedtMatch(C.Structure):
                [('layer_of', C.c_int32 * CRIT_MAXL), ('w_class', C.c_float), ('w_bbox', C.c_float), ('w_giou', C.c_float),
                 ('fl', C.c_int32), ('fine_tune', C.c_int32), ('normalize', C.c_int32), ('alpha_fl', C.c_float),
                 ('gamma_fl', C.c_float), ('epsilon', C.c_float), ('alpha', C.c_float), ('ft_rand', C.c_void_p),
-                ('ft_seed', C.c_uint32), ('seed_ptr', C.c_void_p)]
+                ('ft_seed', C.c_uint32), ('seed_ptr', C.c_void_p), ('split', C.c_void_p)]
 
 
 MAX_REDUCE_JOBS = 40
@@ -132,6 +132,7 @@ SIGNATURES = {
     'sedt_sum_f32': (_i, [_vp, _i, _vp, _vp]),
     'sedt_box_transform': (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     'sedt_mixup': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    'sedt_mixup_targets': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     'sedt_query_patches': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     'sedt_postprocess': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     'sedt_pseudo_labels': (_i, [_vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -726,6 +726,9 @@ def set_criterion(logits, boxes, at, dense, empty_weight, layer_of, w_ce, w_bbox
     if nonfinite is not None:
         assert nonfinite.dtype == torch.int32 and nonfinite.is_cuda
         a.nonfinite = nonfinite.data_ptr()
+    if dense.get('split') is not None:              # {ns, n_lab} of this batch as device words (mix-up moves the boundary)
+        assert dense['split'].dtype == torch.int32 and dense['split'].is_cuda and dense['split'].numel() >= 2
+        a.split = dense['split'].data_ptr()
     L.check(L.load().sedt_set_criterion(a, L.stream_ptr()), 'set_criterion')
     return out, (a, dl, db, db2, dat)
 
@@ -780,6 +783,9 @@ def match_targets(logits, boxes, tables, dense, layer_of, w_class, w_bbox, w_gio
     a.ft_seed = ft_seed & 0xffffffff
     if seed_ptr is not None:
         a.seed_ptr = seed_ptr.data_ptr()
+    if dense.get('split') is not None:
+        assert dense['split'].dtype == torch.int32 and dense['split'].is_cuda and dense['split'].numel() >= 2
+        a.split = dense['split'].data_ptr()
     L.check(L.load().sedt_match_targets(a, L.stream_ptr()), 'match_targets')
 
 
@@ -854,3 +860,34 @@ def pseudo_labels(logits, boxes, at, thr, min_len, tables, counter=None, del_ove
     L.check(L.load().sedt_pseudo_labels(_p(logits), _p(boxes), _p(at), _p(thr), float(min_len), B, Q, C1 - 1, int(bool(del_overlap)),
                                         _p(tables['lab_cat']), _p(tables['box_cat']), _p(tables['lab_off']), _p(tables['box_off']),
                                         _p(counter), cap, L.stream_ptr()), 'pseudo_labels')
+
+
+def mixup(x1, x2, jobs, out=None):
+    """feature half of utilities/mixup.py: out[i] = lam * x1[src1] + (1 - lam) * x2[src2] / x1[src1] / x2[src2] per job record
+    (jobs: uint8 device tensor of n 16-byte records {int32 src1, src2, mode; f32 lam}); x1 / x2 / out f32 [*, clip...]"""
+    _dev_check(x1, x2, jobs)
+    assert x1.dtype == torch.float32 and x2.dtype == torch.float32 and x1.is_contiguous() and x2.is_contiguous()
+    assert jobs.dtype == torch.uint8 and jobs.numel() % 16 == 0
+    n = jobs.numel() // 16
+    if out is None:
+        out = torch.empty((n,) + tuple(x1.shape[1:]), device=x1.device, dtype=torch.float32)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.shape[0] == n and out[0].numel() == x1[0].numel() == x2[0].numel()
+    L.check(L.load().sedt_mixup(_p(x1), _p(x2), _p(jobs), n, x1[0].numel(), _p(out), L.stream_ptr()), 'mixup')
+    return out
+
+
+def mixup_targets(tab1, tab2, lam, mix_num, tab_out, jobs, max_events=20):
+    """label half of mixup_label_unlabel (utilities/mixup.py:129-196) on the device: tab1 = the labelled targets, tab2 = the pseudo
+    targets (sedt.TargetTables), lam = f32 device [2] {lam, 1 - lam}; writes the merged targets into tab_out (every clip strong)
+    and the B2 feature-mixing records into jobs (uint8 [16 * B2])."""
+    d1, d2, do = tab1.as_dict(), tab2.as_dict(), tab_out.as_dict()
+    B2 = tab2.B
+    assert tab_out.B == B2 and tab_out.ns == B2 and jobs.dtype == torch.uint8 and jobs.numel() >= 16 * B2 and jobs.is_cuda
+    assert lam.dtype == torch.float32 and lam.numel() >= 2 and lam.is_cuda and 0 <= mix_num <= min(tab1.B, B2)
+    cap = min(do['lab_cat'].numel(), do['box_cat'].numel() // 2)
+    L.check(L.load().sedt_mixup_targets(_p(d1['lab_cat']), _p(d1['lab_off']), _p(d1['box_cat']), _p(d1['box_off']), _p(d1['ratio_cat']),
+                                        _p(tab1.split), tab1.B, tab1.ns, _p(d2['lab_cat']), _p(d2['lab_off']), _p(d2['box_cat']),
+                                        _p(d2['box_off']), B2, _p(lam), mix_num, max_events, _p(do['lab_cat']), _p(do['lab_off']),
+                                        _p(do['box_cat']), _p(do['box_off']), _p(do['ratio_cat']), cap, _p(jobs), L.stream_ptr()),
+            'mixup_targets')
+    return tab_out

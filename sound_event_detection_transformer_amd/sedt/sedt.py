@@ -161,27 +161,46 @@ class TargetTables(object):
     fixed capacity (max_targets per clip), so a captured HIP graph can keep reading them while ``load`` refreshes their
     contents for every batch with asynchronous copies only (offsets travel through a small ring of pinned buffers)."""
 
-    def __init__(self, batch, ns, n_lab, device, max_targets=32, with_ratio=False, slots=4):
+    def __init__(self, batch, ns, n_lab, device, max_targets=32, with_ratio=False, slots=4, dynamic_split=False):
+        """ns / n_lab: number of strongly labelled / labelled clips.  dynamic_split=True: they are only the FIRST batch's values -
+        every ``load`` may bring another split (mix-up moves clips across the strong | weak boundary, utilities/mixup.py:13-127);
+        the tables then have room for ``batch`` strong clips and the current split travels to the kernels as two device words."""
         if not 1 <= max_targets <= 63:
             raise ValueError('max_targets must be in 1..63 (one wave lane per target)')
-        self.B, self.ns, self.n_lab, self.max_targets, self.dev = batch, ns, max(n_lab, ns), max_targets, device
+        self.dynamic = bool(dynamic_split)
+        self.B, self.max_targets, self.dev = batch, max_targets, device
+        self.ns, self.n_lab = (batch, batch) if self.dynamic else (ns, max(n_lab, ns))          # capacities = strides
+        self.cur_ns, self.cur_n_lab = ns, max(n_lab, ns)
+        ns = self.ns
         self.lab_cat = torch.zeros(batch * max_targets, dtype=torch.int64, device=device)
         self.box_cat = torch.zeros(max(ns, 1) * max_targets, 2, dtype=torch.float32, device=device)
         self.ratio_cat = torch.ones(batch * max_targets, dtype=torch.float32, device=device) if with_ratio else None
-        self.off = torch.zeros(batch + ns + 2, dtype=torch.int32, device=device)
-        self._pin = [torch.zeros(batch + ns + 2, dtype=torch.int32).pin_memory() for _ in range(slots)] if device.type == 'cuda' else None
+        self.off = torch.zeros(batch + ns + 2 + 2, dtype=torch.int32, device=device)            # lab_off | box_off | split
+        self.split = self.off[batch + ns + 2:] if self.dynamic else None
+        self._pin = [torch.zeros(batch + ns + 4, dtype=torch.int32).pin_memory() for _ in range(slots)] if device.type == 'cuda' else None
         self._ev = [None] * slots
         self._slot = 0
 
     def as_dict(self):
         return {'lab_cat': self.lab_cat, 'box_cat': self.box_cat, 'ratio_cat': self.ratio_cat,
-                'lab_off': self.off[:self.B + 1], 'box_off': self.off[self.B + 1:]}
+                'lab_off': self.off[:self.B + 1], 'box_off': self.off[self.B + 1:self.B + self.ns + 2]}
 
     @torch.no_grad()
-    def load(self, targets):
-        B, ns = self.B, self.ns
+    def load(self, targets, ns=None, n_lab=None):
+        """ns / n_lab: this batch's split (dynamic_split tables only; default: the previous one)"""
+        B = self.B
         if len(targets) != B:
             raise ValueError(f'expected {B} clips, got {len(targets)}')
+        if ns is not None or n_lab is not None:
+            if not self.dynamic:
+                if (ns, n_lab) != (self.cur_ns, self.cur_n_lab):
+                    raise ValueError('these tables were built for a fixed strong/weak split: TargetTables(dynamic_split=True)')
+            else:
+                ns = self.cur_ns if ns is None else ns
+                self.cur_ns, self.cur_n_lab = ns, max(ns if n_lab is None else n_lab, ns)
+                if not 0 <= self.cur_ns <= self.cur_n_lab <= B:
+                    raise ValueError(f'split {self.cur_ns} | {self.cur_n_lab} outside 0..{B}')
+        ns = self.cur_ns
         nlab = [int(t['labels'].shape[0]) for t in targets]
         nbox = [int(targets[b]['boxes'].reshape(-1, 2).shape[0]) for b in range(ns)]
         if max(nlab + nbox + [0]) > self.max_targets:
@@ -196,6 +215,8 @@ class TargetTables(object):
         off.append(0)
         for n in nbox:
             off.append(off[-1] + n)
+        off += [off[-1]] * (self.ns - ns)                     # (dynamic split: clips beyond the strong part own no boxes)
+        off += [self.cur_ns, self.cur_n_lab]
         if self._pin is not None:
             if self._ev[k] is not None:
                 self._ev[k].synchronize()                     # the copy that last used this pinned slot has long finished
@@ -211,9 +232,9 @@ class TargetTables(object):
         if nb:
             self.box_cat[:nb].copy_(torch.cat([targets[b]['boxes'].reshape(-1, 2).float() for b in range(ns)]), non_blocking=True)
         if self.ratio_cat is not None and nl:
-            self.ratio_cat[:nl].copy_(torch.cat([t['ratio'].detach().float().reshape(-1).to(self.dev) if 'ratio' in t else
-                                                 torch.ones(n, device=self.dev) for t, n in zip(targets, nlab)]),
-                                      non_blocking=True)
+            src = targets[0]['labels'].device                 # host targets: ONE host->device copy for the whole table
+            self.ratio_cat[:nl].copy_(torch.cat([t['ratio'].detach().float().reshape(-1).to(src) if 'ratio' in t else
+                                                 torch.ones(n, device=src) for t, n in zip(targets, nlab)]), non_blocking=True)
         elif any('ratio' in t for t in targets):
             raise ValueError('targets carry pseudo-label ratios: build TargetTables(with_ratio=True)')
         return self
@@ -438,6 +459,7 @@ class SetCriterion(nn.Module):
         if pack is None:
             pack = torch.zeros(self.dense_numel(meta), device=logits_all.device, dtype=torch.float32)
         dense = self.dense_views(pack, meta)
+        dense['split'] = getattr(tables, 'split', None)      # {ns, n_lab} as device words: the split is data, not graph structure
         m = self.matcher
         seed_ptr = runtime.seed_ptr(logits_all.device) if (fine_tune and ft_rand is None) else None
         ops.match_targets(logits_all.detach().float().contiguous(), boxes_all.detach().float().contiguous(), tables.as_dict(),
