@@ -53,6 +53,12 @@ def parse():
     ap.add_argument('--no-graph', action='store_true', help='c2/c3: issue every kernel from Python instead of replaying HIP graphs')
     ap.add_argument('--model-only', action='store_true', help='c2: time fwd+bwd of the model with a fixed differentiable loss')
     ap.add_argument('--no-overlap', action='store_true', help='data parallel: one all-reduce after the backward (no cut)')
+    ap.add_argument('--dp-cuts', default='coarse', choices=['none', 'coarse', 'fine'],
+                    help='data parallel: where the backward is cut so that the all-reduce of one segment overlaps the backward of the '
+                         'next (engine.dp_segment_plan); none = one all-reduce after the backward')
+    ap.add_argument('--bf16-buckets', action='store_true', help='data parallel: bf16 flat gradient buffer (half the all-reduce bytes)')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='default c2 line only: skip the bounded c3 / c4 / c5 measurements attached as "other_configs"')
     ap.add_argument('--mix-up-ratio', type=float, default=None,
                     help='mix-up inside the step (engine.py:50-53, 128-133, 150-153); default: 0.6 for c5 (its recipe), off for c2/c3')
     return ap.parse_args()
@@ -154,6 +160,30 @@ def cpu_baseline(budget_s=25.0):
                       f"1+{nfb} fwd+bwd-only at B=64"}
 
 
+def agree_out_of_band(ok, rank, world, tag, timeout_s=180.0):
+    """all ranks learn whether EVERY rank built its captured data-parallel stepper - through the process group's TCP store, not
+    through a collective: a rank whose constructor threw is no longer in step with ranks still inside the constructor's
+    collectives, and one more all-reduce would pair up with the wrong call.  Returns True (all built), False (none built: every
+    rank may take the same fallback), and exits the process with status 3 on a mixed outcome or when a rank never reports
+    (the launcher then tears the job down instead of letting it hang)."""
+    import datetime
+    import torch.distributed as dist
+    store = dist.distributed_c10d._get_default_store()
+    store.set(f'{tag}/{rank}', '1' if ok else '0')
+    try:
+        store.wait([f'{tag}/{r}' for r in range(world)], datetime.timedelta(seconds=timeout_s))
+    except Exception as e:                          # noqa: BLE001
+        print(f'bench.py: rank {rank}: not every rank reported on "{tag}" within {timeout_s:.0f} s ({e!r})', file=sys.stderr)
+        os._exit(3)
+    votes = [store.get(f'{tag}/{r}') == b'1' for r in range(world)]
+    if all(votes):
+        return True
+    if not any(votes):
+        return False
+    print(f'bench.py: rank {rank}: ranks disagree on "{tag}" ({votes}): aborting', file=sys.stderr)
+    os._exit(3)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def build_workload(args, dev, rank, world):
     """returns (step callable, clips per step per rank, flop per step per rank, description, graphed flag, extras)"""
@@ -195,18 +225,19 @@ def build_workload(args, dev, rank, world):
             g, err = None, None
             try:
                 g = GraphedTrainStep(net, criterion, opt, x, targets, wm, slice(ns), max_norm=0.1, device_matching=not args.host_matching,
-                                     overlap_allreduce=not args.no_overlap, mix_up_ratio=mix)
+                                     overlap_allreduce=not args.no_overlap, mix_up_ratio=mix, dp_cuts=args.dp_cuts,
+                                     grad_dtype=torch.bfloat16 if args.bf16_buckets else None)
             except Exception as e:                      # noqa: BLE001
                 if world == 1:
                     raise
                 err = repr(e)[:300]
+                print(f'bench.py: rank {rank}: graphed data-parallel step failed: {err}', file=sys.stderr)
             if world > 1:
-                # every rank must take the same path: if the captured data-parallel schedule could not be built on ANY rank (its
-                # first execution on real multi-GPU hardware is the driver's scaling run), all ranks fall back to the eager step
-                # under torch DDP rather than lose the measurement
-                flag = torch.tensor([0 if g is None else 1], device=dev, dtype=torch.int32)
-                torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
-                if int(flag.item()) == 0:
+                # every rank must take the same path, and must learn the others' outcome WITHOUT another collective (see
+                # agree_out_of_band): all built -> captured schedule; none built (a deterministic failure of the capture - its first
+                # execution on real multi-GPU hardware is the driver's scaling run) -> all ranks fall back to the eager step under
+                # torch DDP rather than lose the measurement; mixed -> exit 3
+                if not agree_out_of_band(g is not None, rank, world, 'graphed_dp_step'):
                     g = None
                     graphed = False
                     extras['graph_fallback'] = err or 'another rank failed to build the graphed data-parallel step'
@@ -230,6 +261,11 @@ def build_workload(args, dev, rank, world):
             def step():
                 train_step(net, criterion, opt, x, targets, wm, slice(ns), max_norm=0.1, mix_up_ratio=mix)
         extras.update(model=model, criterion=criterion, opt=opt, x=x, targets=targets, wm=wm, ns=ns, net=net)
+        if graphed:
+            def local_step():                     # the same step without the data-parallel schedule (exposed_comm)
+                loc = GraphedTrainStep(net, criterion, opt, x, targets, wm, slice(ns), max_norm=0.1, data_parallel=False, mix_up_ratio=mix)
+                return lambda: loc(x, targets)
+            extras['local_step'] = local_step
         what = (f"{'URBAN-SED' if cfg == 'c2' else 'DCASE2019'} SEDT enc_layers={E} dec_at num_queries={Q} B={B}/GPU"
                 f"{'' if cfg == 'c2' else f' ({ns} strong + {B - ns} weak)'}, 10 s @ 64-mel (B,1,{T},64), full train step: fwd + "
                 f"Hungarian matching ({'host' if (args.host_matching or not graphed) else 'device'}) + SetCriterion + bwd + clip 0.1 + "
@@ -271,11 +307,20 @@ def build_workload(args, dev, rank, world):
             targets.append({'labels': torch.zeros(P, dtype=torch.int64), 'boxes': torch.stack([c, l], -1)})
         targets = to_dev(targets)
         g = GraphedTrainStep(model, criterion, opt, x, targets, slice(B), slice(B), max_norm=0.1, example_patches=patches,
-                             overlap_allreduce=False)
+                             overlap_allreduce=not args.no_overlap, dp_cuts=args.dp_cuts,
+                             grad_dtype=torch.bfloat16 if args.bf16_buckets else None)
+        if world > 1 and not agree_out_of_band(True, rank, world, 'graphed_dp_step'):
+            os._exit(3)
         extras.update(stepper=g, model=model)
 
         def step():
             g(x, targets, patches=patches)
+
+        def local_step():
+            loc = GraphedTrainStep(model, criterion, opt, x, targets, slice(B), slice(B), max_norm=0.1, example_patches=patches,
+                                   data_parallel=False)
+            return lambda: loc(x, targets, patches=patches)
+        extras['local_step'] = local_step
         what = (f"SP-SEDT self-sup pre-training (feature_recon, num_patches=10) enc_layers=6 num_queries=20 B={B}/GPU + {B * P} patches "
                 f"(1,128,64), backbone frozen, full step: clip + patch backbone fwd, transformer fwd/bwd, device matching, "
                 f"CE/L1/GIoU/feature losses, clip 0.1 + AdamW, dropout 0.1")
@@ -307,12 +352,21 @@ def build_workload(args, dev, rank, world):
     thr = torch.full((10,), 0.1, device=dev)          # (random-init teacher: a low threshold keeps pseudo events alive)
     import numpy as np
     np.random.seed(seed)
-    g = GraphedSemiStep(model, ema, criterion, opt, x_t, x_s, targets, slice(n_s), slice(n_s, n_s + n_w), slice(n_s + n_w),
-                        slice(n_s + n_w, B), thr, mix_up_ratio=mix)
+    masks = (slice(n_s), slice(n_s, n_s + n_w), slice(n_s + n_w), slice(n_s + n_w, B))
+    g = GraphedSemiStep(model, ema, criterion, opt, x_t, x_s, targets, *masks, thr, mix_up_ratio=mix,
+                        overlap_allreduce=not args.no_overlap, dp_cuts=args.dp_cuts,
+                        grad_dtype=torch.bfloat16 if args.bf16_buckets else None)
+    if world > 1 and not agree_out_of_band(True, rank, world, 'graphed_dp_step'):
+        os._exit(3)
     extras.update(stepper=g, model=model)
 
     def step():
         g(x_t, x_s, targets)
+
+    def local_step():
+        loc = GraphedSemiStep(model, ema, criterion, opt, x_t, x_s, targets, *masks, thr, mix_up_ratio=mix, data_parallel=False)
+        return lambda: loc(x_t, x_s, targets)
+    extras['local_step'] = local_step
     what = (f"semi-supervised mean-teacher step (train_ss_sedt.py) enc_layers=6 num_queries=20 per GPU: {n_s} synthetic + {n_w} weak "
             f"labelled clips fwd/bwd, {n_u} unlabelled clips through the EMA teacher (no grad) -> device pseudo labels -> student "
             f"fwd/bwd on the augmented view, one backward, clip 0.1 + AdamW + EMA update, dropout 0.1, " +
@@ -457,6 +511,43 @@ def kernel_report(dtype, dev):
     return out
 
 
+def other_configs(args, dev, keep_alive, replays=10):
+    """BASELINE.json's configs[2..4] (C3 DCASE weak+strong step, C4 SP-SEDT pre-training step, C5 mean-teacher step with its
+    mix-up) on this GPU, each captured and timed for a bounded number of replays AFTER the headline's timed region, so that they
+    appear in the driver's record too.  Per-rank figures on one GPU; never allowed to cost the headline (errors are reported in
+    place)."""
+    import copy
+    import gc
+    import torch
+    res = {}
+    for name in ('c3', 'c4', 'c5'):
+        try:
+            a = copy.copy(args)
+            a.config, a.mix_up_ratio = name, None
+            step, clips, flop, what, _, ex = build_workload(a, dev, 0, 1)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(replays):
+                step()
+            e1.record()
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / replays
+            ms = e0.elapsed_time(e1) / replays
+            res[name] = {"ms_per_step": round(wall * 1e3, 3), "ms_per_step_hip_events": round(ms, 3), "clips_per_step": clips,
+                         "clips_s": round(clips / wall, 1), "frac": round(flop / wall / MFMA_PEAK[args.dtype], 4), "replays": replays,
+                         "workload": what}
+            del step, ex
+        except Exception as e:                   # noqa: BLE001
+            res[name] = {"error": repr(e)[:200]}
+        gc.collect()
+        torch.cuda.empty_cache()
+    return res
+
+
 def pmc_traffic(config):
     """HBM-side bytes per step from the committed PMC profile of this config (profiles/r02_pmc_<config>.json), or None"""
     path = os.path.join(ROOT, 'profiles', f'r02_pmc_{config}.json')
@@ -522,20 +613,22 @@ def main():
 
     # ---- exposed communication: the same step without the data-parallel schedule (local gradients only), same process
     exposed = None
-    if world > 1 and graphed and args.config in ('c2', 'c3') and 'stepper' in ex:
-        from sound_event_detection_transformer_amd.engine import GraphedTrainStep
+    if world > 1 and graphed and 'local_step' in ex:
         try:                                   # a diagnostic after the timed region: never allowed to cost the result line
-            loc = GraphedTrainStep(ex['net'], ex['criterion'], ex['opt'], ex['x'], ex['targets'], ex['wm'], slice(ex['ns']),
-                                   max_norm=0.1, data_parallel=False)
+            loc = ex['local_step']()
             for _ in range(3):
-                loc(ex['x'], ex['targets'])
+                loc()
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
-                loc(ex['x'], ex['targets'])
+                loc()
             torch.cuda.synchronize()
             local_ms = (time.perf_counter() - t1) / args.steps * 1e3
-            exposed = {"local_step_ms": round(local_ms, 3), "exposed_comm_ms": round(elapsed / args.steps * 1e3 - local_ms, 3)}
+            st = ex.get('stepper')
+            exposed = {"local_step_ms": round(local_ms, 3), "exposed_comm_ms": round(elapsed / args.steps * 1e3 - local_ms, 3),
+                       "allreduce_segments_mb": [round(v.numel() * v.element_size() / 1e6, 2) for v in getattr(st, 'flat_parts', [])],
+                       "dp_cuts": args.dp_cuts, "bucket_dtype": "bf16" if args.bf16_buckets else "f32"}
+            del loc
         except Exception as e:                 # noqa: BLE001
             exposed = {"error": repr(e)[:200]}
         barrier()
@@ -617,6 +710,9 @@ def main():
                 kernels = kernel_report(args.dtype, dev)
             except Exception as e:                                   # the report must never cost the headline number
                 kernels = [{"error": repr(e)}]
+        others = None
+        if args.config == 'c2' and world == 1 and graphed and not args.no_other_configs and args.dtype == 'bf16' and not args.batch:
+            others = other_configs(args, dev, (ex, step))
         cpu = None if (args.no_cpu_baseline or world > 1) else cpu_baseline()
         value = world * clips * args.steps / elapsed
         kind = "inference (validation step)" if args.config == 'eval' else "training"
@@ -628,6 +724,8 @@ def main():
                "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "hip_graph": graphed,
                "rccl_world": rccl_world, "ms_per_step_per_rank": [round(v / args.steps * 1e3, 3) for v in per_rank],
                "exposed_comm": exposed}
+        if others is not None:
+            out["other_configs"] = others
         if ex.get('graph_fallback'):
             out["graph_fallback"] = ex['graph_fallback']
         print(json.dumps(out))

@@ -274,7 +274,7 @@ typedef struct SedtChunk {
   int32_t n;
   float lr;
   float wd;
-  int32_t pad_;
+  int32_t gflags; /* bit 0: g addresses bf16 elements (sedt_multi_sumsq / sedt_multi_adamw reading a bf16 flat gradient buffer) */
 } SedtChunk;
 /* table-driven forms of sedt_bn_fold / sedt_pack_conv: `jobs` is a DEVICE array; one launch serves every FrozenBN layer /
  * every weight tensor of the model.  Pack: one job per tensor (taps <= 9), e0 = index of the tensor's first workgroup
@@ -300,15 +300,24 @@ typedef struct SedtPackJob {
 int sedt_multi_bn_fold(const SedtBnJob* jobs, int njobs, void* stream);
 int sedt_multi_pack(const SedtPackJob* jobs, int njobs, int nblocks, int dtype, void* stream);
 
-/* chunk.p[i] = chunk.g[i] for every chunk: packs all gradient tensors into one flat f32 buffer (one launch) ahead of
- * the single RCCL all-reduce of the data-parallel step */
-int sedt_multi_gather(const SedtChunk* table, int nchunks, void* stream);
+/* chunk.p[i] = chunk.g[i] for every chunk: packs all gradient tensors into one flat buffer (one launch) ahead of the RCCL
+ * all-reduce of the data-parallel step.  mode bit 0: chunk.p[i] += chunk.g[i] instead (gradient accumulation over micro-batches,
+ * engine.py:76, 174); bit 1: the flat buffer is bf16 (chunk.p addresses 2-byte elements; half the all-reduce bytes). */
+int sedt_multi_gather(const SedtChunk* table, int nchunks, int mode, void* stream);
 /* mean-teacher update of every tensor in one launch (utilities/utils.py:62-67, EMA.update):
- * chunk.m[i] = (1 - decay) * chunk.p[i] + decay * chunk.m[i]   (p = student parameter, m = shadow) */
-int sedt_multi_ema(const SedtChunk* table, int nchunks, float decay, void* stream);
-int sedt_multi_sumsq(const SedtChunk* table, int nchunks, float* partial, float* sumsq, void* stream);
+ * chunk.m[i] = (1 - decay) * chunk.p[i] + decay * chunk.m[i]   (p = student parameter, m = shadow)
+ * Non-finite guard (the reference aborts BEFORE the backward when the loss is NaN / inf: engine.py:70-73, 167-169; a captured
+ * step cannot stop itself, its host only polls a flag now and then): `guard` is an optional device int32 word, the same one
+ * SedtCriterion.nonfinite / sedt_feature_loss raise.  sedt_multi_sumsq also raises it when the squared gradient norm is not
+ * finite and - step_ptr given - advances the device-side Adam step count unless the guard is up; sedt_multi_adamw and
+ * sedt_multi_ema return without touching parameters, moments or the shadow weights while it is up.  So a bad batch leaves the
+ * whole training state (student, optimizer, teacher) at its last good value until the host sees the flag and raises. */
+int sedt_multi_ema(const SedtChunk* table, int nchunks, float decay, const int32_t* guard /* or null */, void* stream);
+int sedt_multi_sumsq(const SedtChunk* table, int nchunks, float* partial, float* sumsq, int32_t* step_ptr /* or null: += 1 */,
+                     int32_t* guard /* or null */, void* stream);
 int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float* sumsq, float max_norm, float beta1, float beta2,
-                     float eps, const int32_t* step_ptr /* device: 1-based step count */, void* stream);
+                     float eps, const int32_t* step_ptr /* device: 1-based step count */, const int32_t* guard /* or null */,
+                     void* stream);
 
 /* ------------------------------------------------------------------ device half of SetCriterion (sedt/sedt.py:161-283)
  * After the host matching the targets are dense: for dense layer d (0 = final decoder layer, d>=1 = aux layer d-1),
@@ -376,7 +385,7 @@ int sedt_set_criterion_bwd(const SedtCriterion* args, const float* g, float* glo
 int sedt_feature_loss(const float* pred, const float* gt, const float* wbox, const float* tidx, const float* num_boxes,
                       const int32_t* layer_of /* host [L] */, const float* w /* device [L] or null */, int L, int B, int ns,
                       int Q, int P, int F, float* rowloss, float* out /* [L+1]: out[L] = sum_d w[d] out[d] */, float* dpred,
-                      void* stream);
+                      int32_t* nonfinite /* or null: set to 1 when out[L] is NaN / inf (see SedtCriterion.nonfinite) */, void* stream);
 int sedt_scale_layers(float* x, const float* g, const float* gtot, const float* w, const int32_t* idx /* host [L] or null */,
                       int L, int64_t per_layer, void* stream);
 /* out[0] = sum_i x[i] (one workgroup, fixed order): num_boxes = sum of the final layer's box weights (sedt.py:322-324) */

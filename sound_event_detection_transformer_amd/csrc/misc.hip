@@ -532,7 +532,12 @@ __global__ void sumsq_partial_kernel(const float* __restrict__ g, long n, float*
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void sumsq_final_kernel(const float* part, int nparts, float* out, int accumulate) {
+// step_ptr / guard (multi-tensor optimizer only, may be null): a non-finite squared norm raises the guard word; the device-side
+// Adam step count advances here unless the guard is up - the update kernels that follow skip themselves on a raised guard, so a
+// NaN / inf loss or gradient never reaches parameters, moments, step count or the EMA teacher (the reference aborts before the
+// backward on such a loss, engine.py:70-73 / 167-169; a captured step cannot, its host only polls the word now and then)
+__global__ void sumsq_final_kernel(const float* part, int nparts, float* out, int accumulate, int32_t* step_ptr = nullptr,
+                                   int32_t* guard = nullptr) {
   __shared__ float red[4];
   float s = 0.f;
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
@@ -541,7 +546,10 @@ __global__ void sumsq_final_kernel(const float* part, int nparts, float* out, in
   __syncthreads();
   if (threadIdx.x == 0) {
     float tot = red[0] + red[1] + red[2] + red[3];
-    out[0] = accumulate ? out[0] + tot : tot;
+    tot = accumulate ? out[0] + tot : tot;
+    out[0] = tot;
+    if (guard && !(tot <= 3.0e38f)) *guard = 1;
+    if (step_ptr && !(guard && *guard)) step_ptr[0] += 1;
   }
 }
 static int sumsq_parts(long n) {
@@ -573,19 +581,24 @@ __global__ void adamw_clip_kernel(float* __restrict__ p, const float* __restrict
 __global__ void multi_sumsq_kernel(const SedtChunk* __restrict__ table, float* __restrict__ partial) {
   __shared__ float red[4];
   const SedtChunk c = table[blockIdx.x];
-  const float* g = reinterpret_cast<const float*>(c.g);
   float s = 0.f;
-  int i0 = 0;
-  if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {          // 16-byte loads over the aligned body
-    const int n4 = c.n >> 2;
-    const float4* g4 = reinterpret_cast<const float4*>(g);
-    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
-      const float4 a = g4[i];
-      s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+  if (c.gflags & 1) {                                        // gradients in the bf16 flat buffer of the data-parallel step
+    const bf16_t* gb = reinterpret_cast<const bf16_t*>(c.g);
+    for (int i = threadIdx.x; i < c.n; i += blockDim.x) { const float a = (float)gb[i]; s += a * a; }
+  } else {
+    const float* g = reinterpret_cast<const float*>(c.g);
+    int i0 = 0;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {          // 16-byte loads over the aligned body
+      const int n4 = c.n >> 2;
+      const float4* g4 = reinterpret_cast<const float4*>(g);
+      for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+        const float4 a = g4[i];
+        s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+      }
+      i0 = n4 << 2;
     }
-    i0 = n4 << 2;
+    for (int i = i0 + threadIdx.x; i < c.n; i += blockDim.x) s += g[i] * g[i];
   }
-  for (int i = i0 + threadIdx.x; i < c.n; i += blockDim.x) s += g[i] * g[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -593,7 +606,8 @@ __global__ void multi_sumsq_kernel(const SedtChunk* __restrict__ table, float* _
 }
 
 __global__ void multi_adamw_kernel(const SedtChunk* __restrict__ table, const float* sumsq, float max_norm, float b1,
-                                   float b2, float eps, const int32_t* __restrict__ step_ptr) {
+                                   float b2, float eps, const int32_t* __restrict__ step_ptr, const int32_t* __restrict__ guard) {
+  if (guard && *guard) return;                // non-finite loss / gradient norm upstream: leave every tensor as it is
   const SedtChunk c = table[blockIdx.x];
   const float stepf = (float)step_ptr[0];
   const float bc1 = 1.f - powf(b1, stepf);
@@ -615,6 +629,15 @@ __global__ void multi_adamw_kernel(const SedtChunk* __restrict__ table, const fl
     vi = vi * b2 + gr * gr * (1.f - b2);
     pi -= slr * (mi / (sqrtf(vi) / bc2_sqrt + eps));
   };
+  if (c.gflags & 1) {                                        // bf16 flat gradients (data-parallel step with bf16 buckets)
+    const bf16_t* gb = reinterpret_cast<const bf16_t*>(c.g);
+    for (int i = threadIdx.x; i < c.n; i += blockDim.x) {
+      float pi = p[i], mi = m[i], vi = v[i];
+      upd(pi, (float)gb[i], mi, vi);
+      p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+    return;
+  }
   int i0 = 0;
   if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
         reinterpret_cast<uintptr_t>(v)) & 15) == 0) {          // 16-byte accesses over the aligned body
@@ -642,7 +665,8 @@ __global__ void multi_adamw_kernel(const SedtChunk* __restrict__ table, const fl
 }
 
 // mean-teacher weights (reference utilities/utils.py:62-67): shadow = (1 - decay) * p + decay * shadow, chunk.m = shadow
-__global__ void multi_ema_kernel(const SedtChunk* __restrict__ table, float decay) {
+__global__ void multi_ema_kernel(const SedtChunk* __restrict__ table, float decay, const int32_t* __restrict__ guard) {
+  if (guard && *guard) return;
   const SedtChunk c = table[blockIdx.x];
   const float* p = reinterpret_cast<const float*>(c.p);
   float* sh = reinterpret_cast<float*>(c.m);
@@ -788,11 +812,32 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const SedtPackJob* __re
   }
 }
 
+// chunk.p[i] (=|+=) chunk.g[i]: ACC adds into the flat buffer (gradient accumulation over micro-batches, reference
+// engine.py:76, 174), BF stores the flat buffer as bf16 (half the all-reduce bytes of the data-parallel step; the source gradients
+// and the optimizer's arithmetic stay f32)
+template <bool ACC, bool BF>
 __global__ void multi_gather_kernel(const SedtChunk* __restrict__ table) {
   const SedtChunk c = table[blockIdx.x];
-  float* dst = reinterpret_cast<float*>(c.p);
   const float* src = reinterpret_cast<const float*>(c.g);
-  for (int i = threadIdx.x; i < c.n; i += blockDim.x) dst[i] = src[i];
+  if (BF) {
+    bf16_t* dst = reinterpret_cast<bf16_t*>(c.p);
+    for (int i = threadIdx.x; i < c.n; i += blockDim.x) dst[i] = (bf16_t)(ACC ? (float)dst[i] + src[i] : src[i]);
+    return;
+  }
+  float* dst = reinterpret_cast<float*>(c.p);
+  int i0 = 0;
+  if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0) {
+    const int n4 = c.n >> 2;
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+      float4 v = s4[i];
+      if (ACC) { const float4 o = d4[i]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      d4[i] = v;
+    }
+    i0 = n4 << 2;
+  }
+  for (int i = i0 + threadIdx.x; i < c.n; i += blockDim.x) dst[i] = ACC ? dst[i] + src[i] : src[i];
 }
 
 }  // namespace sedt
@@ -1041,31 +1086,38 @@ extern "C" int sedt_adamw_clip(float* p, const float* g, float* m, float* v, int
   return check_launch("adamw_clip");
 }
 
-extern "C" int sedt_multi_sumsq(const SedtChunk* table, int nchunks, float* partial, float* sumsq, void* stream) {
+extern "C" int sedt_multi_sumsq(const SedtChunk* table, int nchunks, float* partial, float* sumsq, int32_t* step_ptr,
+                                int32_t* guard, void* stream) {
   SEDT_REQUIRE(table && partial && sumsq && nchunks > 0, "multi_sumsq: bad arguments");
   hipLaunchKernelGGL(multi_sumsq_kernel, dim3(nchunks), dim3(256), 0, S(stream), table, partial);
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, S(stream), partial, nchunks, sumsq, 0);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, S(stream), partial, nchunks, sumsq, 0, step_ptr, guard);
   return check_launch("multi_sumsq");
 }
 
 extern "C" int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float* sumsq, float max_norm, float beta1,
-                                float beta2, float eps, const int32_t* step_ptr, void* stream) {
+                                float beta2, float eps, const int32_t* step_ptr, const int32_t* guard, void* stream) {
   SEDT_REQUIRE(table && nchunks > 0 && step_ptr, "multi_adamw: bad arguments");
   SEDT_REQUIRE(max_norm <= 0.f || sumsq, "multi_adamw: clipping needs sumsq");
   hipLaunchKernelGGL(multi_adamw_kernel, dim3(nchunks), dim3(256), 0, S(stream), table, sumsq, max_norm, beta1, beta2, eps,
-                     step_ptr);
+                     step_ptr, guard);
   return check_launch("multi_adamw");
 }
 
-extern "C" int sedt_multi_ema(const SedtChunk* table, int nchunks, float decay, void* stream) {
+extern "C" int sedt_multi_ema(const SedtChunk* table, int nchunks, float decay, const int32_t* guard, void* stream) {
   SEDT_REQUIRE(table && nchunks > 0 && decay >= 0.f && decay <= 1.f, "multi_ema: bad arguments");
-  hipLaunchKernelGGL(multi_ema_kernel, dim3(nchunks), dim3(256), 0, S(stream), table, decay);
+  hipLaunchKernelGGL(multi_ema_kernel, dim3(nchunks), dim3(256), 0, S(stream), table, decay, guard);
   return check_launch("multi_ema");
 }
 
-extern "C" int sedt_multi_gather(const SedtChunk* table, int nchunks, void* stream) {
+extern "C" int sedt_multi_gather(const SedtChunk* table, int nchunks, int mode, void* stream) {
   SEDT_REQUIRE(table && nchunks > 0, "multi_gather: bad arguments");
-  hipLaunchKernelGGL(multi_gather_kernel, dim3(nchunks), dim3(256), 0, S(stream), table);
+  SEDT_REQUIRE(mode >= 0 && mode <= 3, "multi_gather: mode %d (bit 0: accumulate, bit 1: bf16 destination)", mode);
+  switch (mode) {
+    case 0: hipLaunchKernelGGL((multi_gather_kernel<false, false>), dim3(nchunks), dim3(256), 0, S(stream), table); break;
+    case 1: hipLaunchKernelGGL((multi_gather_kernel<true, false>), dim3(nchunks), dim3(256), 0, S(stream), table); break;
+    case 2: hipLaunchKernelGGL((multi_gather_kernel<false, true>), dim3(nchunks), dim3(256), 0, S(stream), table); break;
+    default: hipLaunchKernelGGL((multi_gather_kernel<true, true>), dim3(nchunks), dim3(256), 0, S(stream), table); break;
+  }
   return check_launch("multi_gather");
 }
 

@@ -27,7 +27,7 @@ def allreduce_mean(flat, async_op=False):
     if flat.numel() == 0:
         return _Done() if async_op else flat
     if flat.is_cuda:
-        h = flat.cpu()
+        h = flat.float().cpu()                                # (a bf16 flat buffer is reduced in f32 on the host)
         dist.all_reduce(h, op=dist.ReduceOp.SUM)
         flat.copy_(h.div_(world))
     else:
@@ -168,6 +168,38 @@ def _restore(model, optimizer, snap, ema=None):
             ema.shadow[n].copy_(v)
 
 
+def dp_segment_plan(net, cuts='coarse'):
+    """where the data-parallel steppers cut the backward: [(parameters, cut getter or None, cut name)] in the order autograd
+    produces the gradients.  cuts: 'coarse' = transformer + heads | layer4 | layer3 | layer2 + stem (cut tensors: the outputs of
+    layer4 / layer3 / layer2); 'fine' = additionally decoder + heads | encoder + input_proj (cut: the encoder output).  A model
+    whose backbone is frozen (SP-SEDT, train_spsedt.py:50) has no backbone backward: its one cut is decoder + heads | encoder.
+    Returns [] when the model cannot be cut (no SEDT backbone / transformer).  ``optimizer.set_segments([s[0] for s in plan])``
+    gives any optimizer the same flat layout (same summation order of the gradient norm)."""
+    if cuts == 'none' or not hasattr(net, 'transformer') or not hasattr(net, 'backbone'):
+        return []
+    body = getattr(net.backbone[0], 'body', None)
+    if body is None or not hasattr(body, 'stage_out'):
+        return []
+    train = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+    back = [(n, p) for n, p in train if n.startswith('backbone.')]
+    enc = [p for n, p in train if n.startswith('transformer.encoder.') or n.startswith('input_proj.')]
+    dec = [p for n, p in train if not n.startswith('backbone.') and not n.startswith('transformer.encoder.')
+           and not n.startswith('input_proj.')]
+    tr = net.transformer
+    if back:
+        segs = [(dec, lambda: tr.cut_memory, 'memory'), (enc, lambda: body.stage_out[3], 'stage_out3')] if cuts == 'fine' else \
+               [(dec + enc, lambda: body.stage_out[3], 'stage_out3')]
+        segs += [([p for n, p in back if '.layer4.' in n], lambda: body.stage_out[2], 'stage_out2'),
+                 ([p for n, p in back if '.layer3.' in n], lambda: body.stage_out[1], 'stage_out1'),
+                 ([p for n, p in back if '.layer4.' not in n and '.layer3.' not in n], None, 'tail')]
+    else:
+        segs = [(dec, lambda: tr.cut_memory, 'memory'), (enc, None, 'tail')]
+    segs = [sg for sg in segs if sg[0]]
+    if segs:
+        segs[-1] = (segs[-1][0], None, 'tail')
+    return segs
+
+
 class _GraphedBase(object):
     """what every graphed stepper shares: the optimizer's private chunk tables, the learning-rate refresh before each
     replay, and the device-side non-finite-loss word (reference engine.py:70-73 / 167-169 abort on such a loss)."""
@@ -178,9 +210,53 @@ class _GraphedBase(object):
         self._calls = 0
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
         criterion.nonfinite = self.nonfinite
+        # the same word guards the update: with it raised (non-finite loss, or non-finite gradient norm) the captured clip + AdamW
+        # (and the EMA update) leave parameters, moments, step count and teacher untouched, replay after replay, until the host
+        # polls the word and raises - the training state stays at its last good value (the reference stops before the backward)
+        optimizer.guard = self.nonfinite
+        if getattr(self, 'ema', None) is not None:
+            self.ema.guard = self.nonfinite
 
     def _before_replay(self):
         self.optimizer.refresh_hyperparams(self._tabname)      # StepLR / param_group['lr'] edits reach the captured upload
+
+    # ---- the backward as SEGMENTS (data parallel: all-reduce segment k while the backward of segments k+1.. runs)
+    def _plan_segments(self, net, optimizer, cuts):
+        """decide where the backward is cut (dp_segment_plan) and tell the optimizer to lay its flat buffers out segment by
+        segment.  Sets self.segs = [(parameters, cut getter or None), ...] or None (one segment: no cut)."""
+        self.segs = None
+        if cuts == 'none' or optimizer._static is not None:
+            return
+        segs = dp_segment_plan(net, cuts)
+        if len(segs) < 2:
+            return
+        tr = net.transformer
+        body = net.backbone[0].body
+        body.keep_stage_out = any('stage_out' in sg[2] for sg in segs)
+        tr.keep_cut = any(sg[2] == 'memory' for sg in segs)
+        optimizer.set_segments([sg[0] for sg in segs])
+        self.segs = [(sg[0], sg[1]) for sg in segs]
+
+    def _segment_backward(self, k, root=None, accumulate=False):
+        """(inside the capture of graph k) gradients of segment k's parameters -> segment k of the flat buffer.  k = 0 starts
+        from the loss ``root``; later segments continue from the gradient of the previous cut tensor."""
+        params, cut = self.segs[k]
+        cut_t = None if cut is None else cut()
+        if cut is not None and cut_t is None:
+            raise RuntimeError('the model did not keep the cut tensor of a data-parallel segment')
+        want = ([cut_t] if cut_t is not None else []) + list(params)
+        if k == 0:
+            grads = torch.autograd.grad(root, want)
+        else:
+            grads = torch.autograd.grad(self._cut_t, want, grad_outputs=self._cut_g)
+        if cut_t is not None:
+            self._cut_t, self._cut_g = cut_t, grads[0]
+            grads = grads[1:]
+        else:
+            self._cut_t = self._cut_g = None
+        for p, g in zip(params, grads):
+            p.grad = g
+        return self.optimizer.gather_grads(k, accumulate=accumulate)
 
     def _after_replay(self, check_finite):
         self._calls += 1
@@ -235,7 +311,7 @@ class GraphedTrainStep(_GraphedBase):
     def __init__(self, model, criterion, optimizer, example_input, example_targets, mask_weak=None, mask_strong=None,
                  max_norm=0.1, normalize=False, warmup=3, device_matching=True, max_targets=32, async_wgrad=False,
                  overlap_allreduce=True, coschedule=False, data_parallel=None, example_patches=None, fine_tune=False, fl=False,
-                 ft_rand=None, mix_up_ratio=0.0, mix_alpha=1, max_events=20):
+                 ft_rand=None, mix_up_ratio=0.0, mix_alpha=1, max_events=20, accum_steps=1, dp_cuts='coarse', grad_dtype=None):
         import gc
         from . import runtime
         from .sedt import TargetTables
@@ -254,8 +330,13 @@ class GraphedTrainStep(_GraphedBase):
         self.coschedule = (coschedule or os.environ.get('SEDT_COSCHEDULE', '0') == '1') and not async_wgrad
         self.world = torch.distributed.get_world_size() if (torch.distributed.is_available()
                                                             and torch.distributed.is_initialized()) else 1
-        # data-parallel overlap: parameters whose gradients come last (stem conv0 + layer2) go to the tail of the flat layout
-        self.cut_body = None
+        self.accum_steps, self._micro = int(accum_steps), 0
+        if self.accum_steps < 1:
+            raise ValueError('accum_steps >= 1')
+        if self.accum_steps > 1 and not device_matching:
+            raise NotImplementedError('gradient accumulation is built for the device-matching graph')
+        if self.accum_steps > 1 and grad_dtype == torch.bfloat16:
+            raise ValueError('accumulating micro-batch gradients in a bf16 flat buffer loses them: use the f32 buffer')
         # data_parallel=True forces the data-parallel schedule (flat gradients, all-reduce, optimizer graph) even in a
         # one-process group: lets a single GPU exercise the RCCL calls of the multi-GPU path
         self.dp = (self.world > 1) if data_parallel is None else bool(data_parallel)
@@ -265,13 +346,11 @@ class GraphedTrainStep(_GraphedBase):
         if self.world > 1:
             broadcast_parameters(net)                         # replicas start identical (DDP does the same at wrap time)
             runtime.seed_for_rank(torch.distributed.get_rank())   # ... but drop different elements (seeds are baked at capture)
-        if self.dp and overlap_allreduce and device_matching:
-            body = getattr(getattr(net, 'backbone', [None])[0], 'body', None) if hasattr(net, 'backbone') else None
-            if body is not None and hasattr(body, 'stage_out') and optimizer._static is None:
-                tail = [p for n, p in body.named_parameters() if p.requires_grad and (n.startswith('conv0.') or n.startswith('layer2.'))]
-                if tail:
-                    optimizer.set_tail_params(tail)
-                    self.cut_body = body
+        # flat mode: gradients go through ONE flat buffer and the optimizer is its own graph (data parallel: the all-reduce sits
+        # in between; accumulation: micro-batches add into the buffer and only every accum_steps-th call runs the optimizer)
+        self.flat_mode = self.dp or self.accum_steps > 1
+        self.grad_dtype = grad_dtype
+        self._plan_segments(net, optimizer, dp_cuts if (self.dp and overlap_allreduce and device_matching) else 'none')
         dev = example_input.device
         self.dev = dev
         self._init_common(criterion, optimizer, dev)
@@ -301,15 +380,16 @@ class GraphedTrainStep(_GraphedBase):
         _restore(net, optimizer, snap)
         self.nonfinite.zero_()
         criterion.last_total = None      # drop the warm-up autograd graphs (their AccumulateGrad nodes belong to `side`)
-        if self.cut_body is not None:
-            self.cut_body.keep_stage_out = True              # the capture below needs the layer2 output as the cut tensor
         optimizer.zero_grad(set_to_none=True)
-        if self.dp:
-            optimizer.enable_flat_grads()                    # pinned staging + flat buffer: not allocatable during capture
+        if self.flat_mode:
+            optimizer.enable_flat_grads(grad_dtype)          # pinned staging + flat buffer: not allocatable during capture
+            optimizer._flat_g.zero_()
         gc.collect()
         self.device_matching = device_matching
         self.g_fwd = torch.cuda.CUDAGraph()
-        self.g_bwd = self.g_opt = self.g_low = None
+        self.g_bwd = self.g_opt = None
+        self.g_seg, self.flat_parts = [], []
+        acc = self.accum_steps > 1
         with optimizer.table_set(self._tabname):
             if device_matching:
                 self.tables = self._make_tables(example_targets, max_targets)
@@ -317,14 +397,19 @@ class GraphedTrainStep(_GraphedBase):
                     self.static_out = self._forward()
                     self.static_dense = criterion.prepare_device(self.static_out, self.tables, normalize=normalize,
                                                                  fine_tune=fine_tune, fl=fl, ft_rand=ft_rand)
-                    if self.cut_body is None:
+                    if self.segs is None:
                         self._backward_and_step()
                     else:
-                        self._backward_above_cut()
-                if self.cut_body is not None:
-                    self.g_low = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.g_low, pool=self.g_fwd.pool(), **self._capture):
-                        self._backward_below_cut()
+                        self.static_losses = self.criterion.compute(self.static_out, self.static_dense, self.fl)
+                        self.static_total = self.criterion.last_total
+                        with self.runtime.async_wgrad(self.async_wgrad), ops.coschedule(self.coschedule):
+                            self.flat_parts.append(self._segment_backward(0, self.static_total, acc))
+                for k in range(1, len(self.segs or [])):          # one graph per further segment of the backward
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=self.g_fwd.pool(), **self._capture):
+                        with self.runtime.async_wgrad(self.async_wgrad), ops.coschedule(self.coschedule):
+                            self.flat_parts.append(self._segment_backward(k, None, acc))
+                    self.g_seg.append(g)
             else:
                 with torch.cuda.graph(self.g_fwd, **self._capture):
                     self.static_out = self._forward()
@@ -335,12 +420,14 @@ class GraphedTrainStep(_GraphedBase):
                 self.g_bwd = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.g_bwd, pool=self.g_fwd.pool(), **self._capture):
                     self._backward_and_step()
-            if self.dp:
-                # data parallel: ONE RCCL all-reduce of the flat gradient buffer between the graphs, then the fused
-                # clip + AdamW reads the averaged gradients from the flat buffer
+            if self.flat_mode:
+                # the RCCL all-reduce(s) of the flat gradient buffer sit between the graphs; then the fused clip + AdamW reads
+                # the averaged (accumulated) gradients from the flat buffer
                 self.g_opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.g_opt, pool=self.g_fwd.pool(), **self._capture):
                     optimizer.step(max_norm=max_norm, from_flat=True)
+                    if acc:
+                        optimizer._flat_g.zero_()            # the next micro-batch adds into an empty buffer
         torch.cuda.synchronize()
 
     # ------------------------------------------------------------------ pieces
@@ -372,33 +459,15 @@ class GraphedTrainStep(_GraphedBase):
         total = self.criterion.last_total
         self.criterion.last_total = None
         total.backward()
-        if self.dp:
+        if self.flat_mode:
+            self.optimizer.enable_flat_grads(self.grad_dtype)
             flat = self.optimizer.gather_grads()
-            allreduce_mean(flat)
+            if self.dp:
+                allreduce_mean(flat)
             self.optimizer.step(max_norm=self.max_norm, from_flat=True)
         else:
             self.optimizer.step(max_norm=self.max_norm)
         self.optimizer.zero_grad(set_to_none=True)
-
-    def _backward_above_cut(self):
-        """loss + backward down to the output of layer2; gradients of all parameters above -> head of the flat buffer"""
-        self.static_losses = self.criterion.compute(self.static_out, self.static_dense, self.fl)
-        self.static_total = self.criterion.last_total
-        head, self._tail = self.optimizer.head_tail_params()
-        self._cut = self.cut_body.stage_out[1]
-        with self.runtime.async_wgrad(self.async_wgrad), ops.coschedule(self.coschedule):
-            grads = torch.autograd.grad(self.static_total, [self._cut] + head)
-        self._g_cut = grads[0]
-        for p, g in zip(head, grads[1:]):
-            p.grad = g
-        self.flat_head = self.optimizer.gather_grads('head')
-
-    def _backward_below_cut(self):
-        with self.runtime.async_wgrad(self.async_wgrad), ops.coschedule(self.coschedule):
-            grads = torch.autograd.grad(self._cut, self._tail, grad_outputs=self._g_cut)
-        for p, g in zip(self._tail, grads):
-            p.grad = g
-        self.flat_tail = self.optimizer.gather_grads('tail')
 
     def _backward_and_step(self):
         self.static_losses = self.criterion.compute(self.static_out, self.static_dense, self.fl)
@@ -406,10 +475,10 @@ class GraphedTrainStep(_GraphedBase):
         # weight gradients ride in the spare workgroup slots of the dgrad chain's launches; drained on exit
         with self.runtime.async_wgrad(self.async_wgrad), ops.coschedule(self.coschedule):
             self.static_total.backward()
-        if not self.dp:
+        if not self.flat_mode:
             self.optimizer.step(max_norm=self.max_norm)
-        else:
-            self.flat_g = self.optimizer.gather_grads()      # all gradients -> one flat buffer (one launch)
+        else:                                                # all gradients -> one flat buffer (one launch)
+            self.flat_parts = [self.optimizer.gather_grads(accumulate=self.accum_steps > 1)]
 
     def __call__(self, batch_input, targets, check_finite=False, patches=None):
         """one step on (batch_input, targets).  With mix-up the batch arrives UNMIXED in the layout the stepper was built with
@@ -439,16 +508,20 @@ class GraphedTrainStep(_GraphedBase):
                 raise RuntimeError(f'batch composition changed: captured {self.meta}, got {dense["_meta"]}')
             self.static_pack.copy_(dense['_pack'], non_blocking=True)
             self.g_bwd.replay()
-        if self.g_low is not None:
-            w1 = allreduce_mean(self.flat_head, async_op=True)     # RCCL reduces the head while the tail's backward runs
-            self.g_low.replay()
-            w2 = allreduce_mean(self.flat_tail, async_op=True)
-            w1.wait()
-            w2.wait()
-            self.g_opt.replay()
-        elif self.g_opt is not None:
-            allreduce_mean(self.flat_g)
-            self.g_opt.replay()
+        if self.g_opt is not None:
+            self._micro += 1
+            last = self._micro % self.accum_steps == 0        # (engine.py:76: step on every accum_steps-th batch)
+            works = []
+            if self.dp and last:                              # RCCL reduces segment k while the graphs of k+1.. run
+                works.append(allreduce_mean(self.flat_parts[0], async_op=True))
+            for k, g in enumerate(self.g_seg):
+                g.replay()
+                if self.dp and last:
+                    works.append(allreduce_mean(self.flat_parts[k + 1], async_op=True))
+            for w in works:
+                w.wait()
+            if last:
+                self.g_opt.replay()
         self._after_replay(check_finite)
         return self.static_total, self.static_losses
 
@@ -659,14 +732,17 @@ class GraphedSemiStep(_GraphedBase):
     def __init__(self, model, ema, criterion, optimizer, x_teacher, x_student, targets, mask_strong, mask_weak, mask_label,
                  mask_unlabel, classwise_threshold, orig_size=10.0, fine_tune=False, normalize=False, fl=False, max_norm=0.1,
                  warmup=2, max_targets=32, accumulating_ema_steps=1, fuse_student_forwards=True, mix_up_ratio=0.0, mix_alpha=1,
-                 max_events=20):
+                 max_events=20, accum_steps=1, overlap_allreduce=True, dp_cuts='coarse', grad_dtype=None, data_parallel=None):
         import gc
         from . import runtime
         from .sedt import TargetTables
         if not isinstance(optimizer, FusedAdamW):
             raise RuntimeError('GraphedSemiStep needs FusedAdamW')
-        if accumulating_ema_steps != 1:
-            raise NotImplementedError('the EMA update is part of the graph: every step (accumlating_ema_steps = 1)')
+        self.accum_steps, self.ema_steps, self._micro = int(accum_steps), int(accumulating_ema_steps), 0
+        if self.accum_steps < 1 or self.ema_steps < 1:
+            raise ValueError('accum_steps / accumulating_ema_steps >= 1')
+        if self.accum_steps > 1 and grad_dtype == torch.bfloat16:
+            raise ValueError('accumulating micro-batch gradients in a bf16 flat buffer loses them: use the f32 buffer')
         self.model, self.ema, self.criterion, self.optimizer, self.runtime = model, ema, criterion, optimizer, runtime
         self.ms, self.mw, self.ml, self.mu = mask_strong, mask_weak, mask_label, mask_unlabel
         self.flags = dict(normalize=normalize, fine_tune=fine_tune, fl=fl)
@@ -682,8 +758,14 @@ class GraphedSemiStep(_GraphedBase):
         self._init_common(criterion, optimizer, dev)
         dist = torch.distributed
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        self.dp = self.world > 1
-        if self.dp:
+        self.dp = (self.world > 1) if data_parallel is None else bool(data_parallel)
+        if self.dp and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError('data_parallel=True needs an initialised torch.distributed process group')
+        # flat mode (see GraphedTrainStep): gradients through the flat buffer, optimizer (and EMA update) as graphs of their own
+        self.flat_mode = self.dp or self.accum_steps > 1 or self.ema_steps > 1
+        self.grad_dtype = grad_dtype
+        self._plan_segments(model, optimizer, dp_cuts if (self.dp and overlap_allreduce and fuse_student_forwards) else 'none')
+        if self.world > 1:
             broadcast_parameters(model)
             with torch.no_grad():
                 for n, p in model.named_parameters():         # the teacher starts identical on every rank too
@@ -741,23 +823,34 @@ class GraphedSemiStep(_GraphedBase):
         self.sup = self.unsup = self.total = None
         optimizer.zero_grad(set_to_none=True)
         gc.collect()
-        if self.dp:
-            optimizer.enable_flat_grads()
+        if self.flat_mode:
+            optimizer.enable_flat_grads(grad_dtype)
+            optimizer._flat_g.zero_()
         self.graph = torch.cuda.CUDAGraph()
-        self.g_opt = None
+        self.g_opt = self.g_ema = None
+        self.g_seg, self.flat_parts = [], []
         with optimizer.table_set(self._tabname):
             with torch.cuda.graph(self.graph, **self._capture):
-                self._body(part='fwd_bwd' if self.dp else 'all')
-            if self.dp:                                       # data parallel: RCCL all-reduce of the flat gradients in between
+                self._body(part='fwd_bwd' if self.flat_mode else 'all')
+            for k in range(1, len(self.segs or [])):          # data parallel: one graph per further segment of the backward
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.graph.pool(), **self._capture):
+                    self.flat_parts.append(self._segment_backward(k, None, self.accum_steps > 1))
+                self.g_seg.append(g)
+            if self.flat_mode:                                # (RCCL all-reduces of the flat gradient segments in between)
                 self.g_opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.g_opt, pool=self.graph.pool(), **self._capture):
                     self._body(part='update')
+                self.g_ema = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_ema, pool=self.graph.pool(), **self._capture):
+                    self.ema.update()
         torch.cuda.synchronize()
 
     def _body(self, part='all'):
         if part == 'update':
             self.optimizer.step(max_norm=self.max_norm, from_flat=True)
-            self.ema.update()
+            if self.accum_steps > 1:
+                self.optimizer._flat_g.zero_()
             return
         crit, model = self.criterion, self.model
         if self.mix:
@@ -790,12 +883,18 @@ class GraphedSemiStep(_GraphedBase):
         self.unsup = crit.compute(out_s, crit.prepare_device(out_s, self.tab_u, **self.flags), self.fl)
         self.total = total_l + crit.last_total
         crit.last_total = None
+        if part == 'fwd_bwd' and self.segs is not None:
+            self.flat_parts = [self._segment_backward(0, self.total, self.accum_steps > 1)]
+            return
         self.total.backward()
         if part == 'fwd_bwd':
-            self.flat_g = self.optimizer.gather_grads()
+            self.flat_parts = [self.optimizer.gather_grads(accumulate=self.accum_steps > 1)]
             return
-        if self.dp:                                           # (eager warm-up of the data-parallel schedule)
-            allreduce_mean(self.optimizer.gather_grads())
+        if self.flat_mode:                                    # (eager warm-up of the flat-buffer schedule)
+            self.optimizer.enable_flat_grads(self.grad_dtype)
+            flat = self.optimizer.gather_grads()
+            if self.dp:
+                allreduce_mean(flat)
             self.optimizer.step(max_norm=self.max_norm, from_flat=True)
         else:
             self.optimizer.step(max_norm=self.max_norm)
@@ -824,7 +923,20 @@ class GraphedSemiStep(_GraphedBase):
         self._before_replay()
         self.graph.replay()
         if self.g_opt is not None:
-            allreduce_mean(self.flat_g)
-            self.g_opt.replay()
+            self._micro += 1
+            last = self._micro % self.accum_steps == 0        # engine.py:174 / :180: optimizer and EMA on their own periods
+            works = []
+            if self.dp and last:
+                works.append(allreduce_mean(self.flat_parts[0], async_op=True))
+            for k, g in enumerate(self.g_seg):
+                g.replay()
+                if self.dp and last:
+                    works.append(allreduce_mean(self.flat_parts[k + 1], async_op=True))
+            for w in works:
+                w.wait()
+            if last:
+                self.g_opt.replay()
+            if self._micro % self.ema_steps == 0:
+                self.g_ema.replay()
         self._after_replay(check_finite)
         return self.total, self.sup, self.unsup

@@ -120,14 +120,14 @@ SIGNATURES = {
     'sedt_sumsq_scratch': (_sz, [_i64]),
     'sedt_multi_bn_fold': (_i, [_vp, _i, _vp]),
     'sedt_multi_pack': (_i, [_vp, _i, _i, _i, _vp]),
-    'sedt_multi_gather': (_i, [_vp, _i, _vp]),
-    'sedt_multi_ema': (_i, [_vp, _i, _f, _vp]),
-    'sedt_multi_sumsq': (_i, [_vp, _i, _vp, _vp, _vp]),
-    'sedt_multi_adamw': (_i, [_vp, _i, _vp, _f, _f, _f, _f, _vp, _vp]),
+    'sedt_multi_gather': (_i, [_vp, _i, _i, _vp]),
+    'sedt_multi_ema': (_i, [_vp, _i, _f, _vp, _vp]),
+    'sedt_multi_sumsq': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    'sedt_multi_adamw': (_i, [_vp, _i, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
     'sedt_set_criterion': (_i, [C.POINTER(SedtCriterion), _vp]),
     'sedt_set_criterion_bwd': (_i, [C.POINTER(SedtCriterion), _vp, _vp, _vp, _vp, _vp]),
     'sedt_match_targets': (_i, [C.POINTER(SedtMatch), _vp]),
-    'sedt_feature_loss': (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'sedt_feature_loss': (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'sedt_scale_layers': (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i64, _vp]),
     'sedt_sum_f32': (_i, [_vp, _i, _vp, _vp]),
     'sedt_box_transform': (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),

@@ -799,7 +799,7 @@ def sum_f32(x, out=None):
     return out
 
 
-def feature_loss(pred, gt, dense, layer_of, num_boxes, w=None):
+def feature_loss(pred, gt, dense, layer_of, num_boxes, w=None, nonfinite=None):
     """SP-SEDT feature-reconstruction loss (sedt.py:263-283) of every decoder layer in one launch.  pred [L,B,Q,F] f32,
     gt [B*P,F] f32, w [L] f32 layer weights.  Returns (out[L+1]: loss per dense layer + their weighted sum,
     dpred [L,B,Q,F] = d loss[d] / d pred, unweighted)."""
@@ -814,7 +814,7 @@ def feature_loss(pred, gt, dense, layer_of, num_boxes, w=None):
     out = torch.empty(Lh + 1, device=pred.device, dtype=torch.float32)
     lay = (C.c_int32 * Lh)(*layer_of)
     L.check(L.load().sedt_feature_loss(_p(pred), _p(gt), _p(dense['wbox']), _p(dense['tidx']), _p(num_boxes), lay, _p(w), Lh, B, ns, Q, P, F,
-                                       _p(rowloss), _p(out), _p(dpred), L.stream_ptr()), 'feature_loss')
+                                       _p(rowloss), _p(out), _p(dpred), _p(nonfinite), L.stream_ptr()), 'feature_loss')
     return out, dpred
 
 

@@ -15,17 +15,30 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._step = 0
         self._static = None
-        self._tail_ids = set()
+        self._seg_of = {}                  # id(param) -> segment index of the flat layout (default: one segment)
+        self._nseg = 1
+        self._flat_dtype = torch.float32
         self._tabset = 'eager'
         self._sets = {}
+        # optional device int32 word (engine's graphed steppers: the criterion's non-finite flag): while it is non-zero the
+        # update kernels leave parameters, moments and the step count alone (include/sedt_hip.h "Non-finite guard")
+        self.guard = None
+
+    def set_segments(self, segments):
+        """lay the flat state / gradient buffers out as consecutive SEGMENTS: segments[k] = the parameters whose gradients the
+        backward produces k-th (parameters not listed go to segment 0).  The data-parallel step (engine.GraphedTrainStep) cuts the
+        backward at the segment boundaries and all-reduces segment k while the backward of segments k+1.. still runs.  Call before
+        the first step."""
+        if self._static is not None:
+            raise RuntimeError('set_segments must be called before the optimizer state is built (first step)')
+        self._seg_of = {id(p): k for k, seg in enumerate(segments) for p in seg}
+        self._nseg = max(len(segments), 1)
 
     def set_tail_params(self, params):
-        """put these parameters LAST in the flat state / gradient layout (call before the first step).  The data-parallel
-        step reduces the head part of the flat gradient buffer while the backward of the tail parameters' layers still
-        runs (engine.GraphedTrainStep): the tail is the part of the model whose gradients are produced last."""
-        if self._static is not None:
-            raise RuntimeError('set_tail_params must be called before the optimizer state is built (first step)')
-        self._tail_ids = {id(p) for p in params}
+        """two segments: everything else | these parameters (the ones whose gradients come last)"""
+        params = list(params)
+        ids = {id(p) for p in params}
+        self.set_segments([[p for g in self.param_groups for p in g['params'] if id(p) not in ids], params])
 
     def _build(self):
         ps, gi = [], []
@@ -36,25 +49,29 @@ class FusedAdamW(torch.optim.Optimizer):
                         raise RuntimeError('FusedAdamW needs contiguous f32 GPU parameters')
                     ps.append(p)
                     gi.append(gidx)
-        order = sorted(range(len(ps)), key=lambda i: id(ps[i]) in self._tail_ids)      # stable: tail parameters last
+        order = sorted(range(len(ps)), key=lambda i: self._seg_of.get(id(ps[i]), 0))   # stable: segment by segment
         ps, gi = [ps[i] for i in order], [gi[i] for i in order]
-        total = sum((p.numel() + 3) // 4 * 4 for p in ps)     # every tensor's state starts 16-byte aligned (float4 kernels)
         dev = ps[0].device
-        self._m = torch.zeros(total, device=dev)
-        self._v = torch.zeros(total, device=dev)
         owner, off_in_p, n, state_off = [], [], [], []
         so = 0
-        self._tail_chunk0, self._tail_elem0 = None, None
+        self._seg_chunk0, self._seg_elem0 = [0] * (self._nseg + 1), [0] * (self._nseg + 1)      # segment k = [k], [k+1])
+        seg_seen = -1
         for i, p in enumerate(ps):
             k = p.numel()
-            if id(p) in self._tail_ids and self._tail_chunk0 is None:
-                self._tail_chunk0, self._tail_elem0 = len(owner), so
+            sg = self._seg_of.get(id(p), 0)
+            while seg_seen < sg:
+                seg_seen += 1
+                self._seg_chunk0[seg_seen], self._seg_elem0[seg_seen] = len(owner), so
             for c0 in range(0, k, _CHUNK):
                 owner.append(i); off_in_p.append(c0); n.append(min(_CHUNK, k - c0)); state_off.append(so + c0)
-            so += (k + 3) // 4 * 4
-        if self._tail_chunk0 is None:
-            self._tail_chunk0, self._tail_elem0 = len(owner), so
+            so += (k + 7) // 8 * 8                             # 32-byte aligned f32 state (16-byte aligned as a bf16 flat buffer)
+        for sg in range(seg_seen + 1, self._nseg + 1):
+            self._seg_chunk0[sg], self._seg_elem0[sg] = len(owner), so
+        total = so
+        self._m = torch.zeros(total, device=dev)
+        self._v = torch.zeros(total, device=dev)
         self._ps, self._gi = ps, np.asarray(gi)
+        self._pad = [(p.numel() + 7) // 8 * 8 for p in ps]
         self._owner = np.asarray(owner)
         self._off = np.asarray(off_in_p, np.uint64) * 4
         self._tab = np.zeros(len(owner), _DT)
@@ -66,6 +83,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._sumsq = torch.zeros(1, device=dev)
         self._step_t = torch.zeros(1, dtype=torch.int32, device=dev)   # device-side step count (graph-replay safe)
         self._state_off_b = so_b
+        self._state_off_e = np.asarray(state_off, np.uint64)
         self._flat_g = None
         self._dev = dev
         self._static = True
@@ -113,41 +131,65 @@ class FusedAdamW(torch.optim.Optimizer):
         return _Ctx()
 
     # ---- data-parallel support: all gradients in ONE flat buffer -> one RCCL all-reduce -> update from the flat buffer
-    def enable_flat_grads(self):
+    def enable_flat_grads(self, dtype=None):
+        """the flat gradient buffer (allocated on first use).  dtype torch.bfloat16: bf16 buckets - half the all-reduce bytes;
+        gradients are rounded once when packed, the clip norm and AdamW read them back as f32 values"""
         if self._static is None:
             self._build()
         if self._flat_g is None:
-            self._flat_g = torch.zeros_like(self._m)
+            self._flat_dtype = dtype or torch.float32
+            if self._flat_dtype not in (torch.float32, torch.bfloat16):
+                raise ValueError('flat gradients are f32 or bf16')
+            self._flat_g = torch.zeros(self._m.numel(), device=self._dev, dtype=self._flat_dtype)
             self._gtab = self._tab.copy()
             self._use_set(self._tabset)
+        elif dtype is not None and dtype != self._flat_dtype:
+            raise RuntimeError(f'the flat gradient buffer already exists as {self._flat_dtype}')
         return self._flat_g
 
-    def head_tail_params(self):
-        """(parameters before the tail, tail parameters) in flat-layout order"""
+    @property
+    def n_segments(self):
+        return self._nseg
+
+    def segment_params(self, k):
         if self._static is None:
             self._build()
-        head = [p for p in self._ps if id(p) not in self._tail_ids]
-        return head, [p for p in self._ps if id(p) in self._tail_ids]
+        return [p for p in self._ps if self._seg_of.get(id(p), 0) == k]
+
+    def head_tail_params(self):
+        """(parameters of segment 0, parameters of the last segment) in flat-layout order (two-segment layouts)"""
+        return self.segment_params(0), (self.segment_params(self._nseg - 1) if self._nseg > 1 else [])
+
+    def flat_segment(self, k):
+        """view of segment k of the flat gradient buffer"""
+        return self.enable_flat_grads()[self._seg_elem0[k]:self._seg_elem0[k + 1]]
 
     @torch.no_grad()
-    def gather_grads(self, part=None):
-        """copy p.grad of every parameter (part=None), of the head ('head') or of the tail parameters ('tail') into the
-        flat gradient buffer (one launch); returns the matching view of the flat buffer"""
+    def gather_grads(self, part=None, accumulate=False):
+        """copy (accumulate=True: add) p.grad of every parameter (part=None) or of the parameters of one segment (part = its
+        index; 'head' = 0, 'tail' = the last one) into the flat gradient buffer (one launch); returns the matching view"""
         flat = self.enable_flat_grads()
-        c0, e0, n = self._tail_chunk0, self._tail_elem0, len(self._gtab)
-        lo, hi, view = {None: (0, n, flat), 'head': (0, c0, flat[:e0]), 'tail': (c0, n, flat[e0:])}[part]
-        sel = [p for p in self._ps if part is None or (id(p) in self._tail_ids) == (part == 'tail')]
+        if part == 'head':
+            part = 0
+        elif part == 'tail':
+            part = self._nseg - 1
+        if part is None:
+            lo, hi, view = 0, len(self._gtab), flat
+        else:
+            lo, hi, view = self._seg_chunk0[part], self._seg_chunk0[part + 1], self.flat_segment(part)
+        sel = self._ps if part is None else self.segment_params(part)
         if any(p.grad is None for p in sel):
             raise RuntimeError('gather_grads: a parameter of the requested part has no gradient')
         gbase = np.fromiter((p.grad.data_ptr() if p.grad is not None else 0 for p in self._ps), np.uint64, len(self._ps))
         t = self._gtab
-        t['p'] = np.uint64(flat.data_ptr()) + self._state_off_b
+        t['p'] = np.uint64(flat.data_ptr()) + self._state_off_e * np.uint64(flat.element_size())
         t['g'][lo:hi] = (gbase[self._owner] + self._off)[lo:hi]
         if hi > lo:
             isz = _DT.itemsize
             self._host_gtab.numpy()[lo * isz:hi * isz] = t[lo:hi].view(np.uint8)
             self._dev_gtab[lo * isz:hi * isz].copy_(self._host_gtab[lo * isz:hi * isz], non_blocking=True)
-            L.check(L.load().sedt_multi_gather(L.p(self._dev_gtab[lo * isz:]), hi - lo, L.stream_ptr()), 'multi_gather')
+            mode = (1 if accumulate else 0) | (2 if self._flat_dtype == torch.bfloat16 else 0)
+            L.check(L.load().sedt_multi_gather(L.p(self._dev_gtab[lo * isz:]), hi - lo, mode, L.stream_ptr()), 'multi_gather')
         return view
 
     @torch.no_grad()
@@ -169,21 +211,28 @@ class FusedAdamW(torch.optim.Optimizer):
         wds = np.asarray([g['weight_decay'] for g in self.param_groups], np.float32)
         t = self._tab
         t['p'] = pbase[self._owner] + self._off
-        t['g'] = (np.uint64(self._flat_g.data_ptr()) + self._state_off_b) if from_flat else (gbase[self._owner] + self._off)
+        if from_flat:
+            t['g'] = np.uint64(self._flat_g.data_ptr()) + self._state_off_e * np.uint64(self._flat_g.element_size())
+            t['pad'] = 1 if self._flat_dtype == torch.bfloat16 else 0           # SedtChunk.gflags bit 0: bf16 gradients
+        else:
+            t['g'] = gbase[self._owner] + self._off
+            t['pad'] = 0
         t['lr'] = lrs[self._gi][self._owner]
         t['wd'] = wds[self._gi][self._owner]
         self._host_tab.numpy()[:] = t.view(np.uint8)
         self._sets[self._tabset]['hyper'] = (lrs.tobytes(), wds.tobytes())
         self._dev_tab.copy_(self._host_tab, non_blocking=True)
         self._step += 1
-        self._step_t.add_(1)
         lib = L.load()
         g0 = self.param_groups[0]
         n = len(t)
-        if max_norm > 0:
-            L.check(lib.sedt_multi_sumsq(L.p(self._dev_tab), n, L.p(self._partial), L.p(self._sumsq), L.stream_ptr()), 'multi_sumsq')
+        if max_norm > 0:       # the norm's final reduction also advances the device-side step count (unless the guard is up)
+            L.check(lib.sedt_multi_sumsq(L.p(self._dev_tab), n, L.p(self._partial), L.p(self._sumsq), L.p(self._step_t),
+                                         L.p(self.guard), L.stream_ptr()), 'multi_sumsq')
+        else:
+            self._step_t.add_(1)
         L.check(lib.sedt_multi_adamw(L.p(self._dev_tab), n, L.p(self._sumsq), float(max_norm), g0['betas'][0], g0['betas'][1],
-                                     g0['eps'], L.p(self._step_t), L.stream_ptr()), 'multi_adamw')
+                                     g0['eps'], L.p(self._step_t), L.p(self.guard), L.stream_ptr()), 'multi_adamw')
 
     def refresh_hyperparams(self, name=None):
         """re-read lr / weight_decay of the param groups into the pinned chunk table of set ``name`` (a captured graph
@@ -227,7 +276,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     k = p.numel()
                     state[index[id(p)]] = {'step': torch.tensor(step), 'exp_avg': self._m[off:off + k].view_as(p).clone(),
                                            'exp_avg_sq': self._v[off:off + k].view_as(p).clone()}
-                    off += (k + 3) // 4 * 4
+                    off += (k + 7) // 8 * 8
         return {'state': state, 'param_groups': groups}
 
     def load_state_dict(self, sd):
@@ -261,7 +310,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     self._m[off:off + k].copy_(e['exp_avg'].reshape(-1))
                     self._v[off:off + k].copy_(e['exp_avg_sq'].reshape(-1))
                     steps.add(int(float(e['step'])))
-                off += (k + 3) // 4 * 4
+                off += (k + 7) // 8 * 8
         if len(steps) > 1:
             raise ValueError(f'FusedAdamW keeps ONE step count for all parameters; the checkpoint has {sorted(steps)}')
         n = steps.pop() if steps else 0

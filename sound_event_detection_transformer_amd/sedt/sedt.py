@@ -270,10 +270,10 @@ class _FeatureLossFn(torch.autograd.Function):
     out[L] = their weighted sum.  The forward launch also leaves the unweighted gradient; backward scales it per layer."""
 
     @staticmethod
-    def forward(ctx, pred_all, gt, dense, layer_of, num_boxes, wvec):
+    def forward(ctx, pred_all, gt, dense, layer_of, num_boxes, wvec, nonfinite=None):
         from .. import ops
         out, ctx.dpred = ops.feature_loss(pred_all.detach().float().contiguous(), gt.detach().float().contiguous(), dense,
-                                          layer_of, num_boxes, wvec)
+                                          layer_of, num_boxes, wvec, nonfinite)
         ctx.wvec, ctx.dt = wvec, pred_all.dtype
         inv = [0] * len(layer_of)
         for d, ml in enumerate(layer_of):
@@ -288,7 +288,7 @@ class _FeatureLossFn(torch.autograd.Function):
         L = g.numel() - 1
         d = ops.scale_layers(ctx.dpred, g[:L], g[L:], ctx.wvec, ctx.inv)
         ctx.dpred = None
-        return d.to(ctx.dt), None, None, None, None, None
+        return d.to(ctx.dt), None, None, None, None, None, None
 
 
 class SetCriterion(nn.Module):
@@ -536,7 +536,7 @@ class SetCriterion(nn.Module):
             if nb is None:
                 from .. import ops
                 nb = ops.sum_f32(dense['wbox'][0])
-            fv = _FeatureLossFn.apply(feats, outputs['gt_feature'], dense, layer_of, nb, wv)
+            fv = _FeatureLossFn.apply(feats, outputs['gt_feature'], dense, layer_of, nb, wv, self.nonfinite)
             for d in range(L):
                 out['loss_feature' if d == 0 else f'loss_feature_{d - 1}'] = fv[d]
             total = total + fv[L]

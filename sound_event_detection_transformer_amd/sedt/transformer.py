@@ -187,6 +187,9 @@ class Transformer(nn.Module):
         if tgt is None:
             tgt = torch.zeros((B * Q, C), device=src.device, dtype=runtime.torch_dtype())
         memory = self.encoder.forward_tokens(x, pos, kpm, B, S)
+        # the encoder output as a token matrix, kept on request: engine's data-parallel steppers cut the backward here (gradients of
+        # decoder + heads are all-reduced while the encoder's backward runs)
+        self.cut_memory = memory if getattr(self, 'keep_cut', False) else None
         tmask = decoder_mask.float().contiguous() if (self.self_sup and decoder_mask is not None) else None
         hs = self.decoder.forward_tokens(tgt, memory, pos, qpos, kpm, B, S, Q, tmask)
         if self.self_sup:

@@ -120,7 +120,7 @@ class EMA(object):
             dev = ps[0][1].device
             self._tab = (key, torch.from_numpy(t.view(np.uint8).copy()).to(dev), len(rows))
         _, tab, n = self._tab
-        L.check(L.load().sedt_multi_ema(L.p(tab), n, float(self.decay), L.stream_ptr()), 'multi_ema')
+        L.check(L.load().sedt_multi_ema(L.p(tab), n, float(self.decay), L.p(getattr(self, 'guard', None)), L.stream_ptr()), 'multi_ema')
 
     def apply_shadow(self):
         for name, param in self._params():

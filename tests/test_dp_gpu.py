@@ -1,6 +1,7 @@
-"""GPU: the graphed data-parallel step with world_size 2 (two processes sharing the one test GPU, gloo transport, the
-flat gradient buffer staged through the host by engine.allreduce_mean).  Checked: replicas stay bit-identical; the cut /
-overlapped schedule equals the single all-reduce schedule; and ONE data-parallel step equals a single-process optimizer
+"""GPU: the graphed data-parallel steps with world_size 2 (two processes sharing the one test GPU, gloo transport, the
+flat gradient buffer staged through the host by engine.allreduce_mean).  Checked for the supervised, the SP-SEDT and the
+mean-teacher step: replicas stay bit-identical; the segmented / overlapped schedule equals the single all-reduce schedule;
+bf16 buckets stay close to f32 buckets; and ONE data-parallel step equals a single-process optimizer
 step fed the explicit MEAN of the two ranks' gradients (each computed eagerly on that rank's batch).  Equality with a
 single-process step on the concatenated batch is NOT expected: num_boxes is normalised per rank (sedt.py:322-324)."""
 import os
@@ -25,55 +26,119 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out, overlap=True, nsteps=2):
+def _build(kind, dev, B, rank=0):
+    """(model, criterion, optimizer, extra constructor kwargs, batch function) of one of the three data-parallel workloads"""
+    from sound_event_detection_transformer_amd.sedt import build_model, default_args
+    from sound_event_detection_transformer_amd.engine import build_optimizer
+    from sound_event_detection_transformer_amd.utilities.synthetic import seeded_state_dict, synthetic_batch
+    args = dict(sedt=dict(dropout=0.0), spsedt=dict(enc_layers=3, num_queries=20, dec_at=False, self_sup=True, lr_backbone=0.0, dropout=0.0),
+                semi=dict(dropout=0.0))[kind]
+    model, crit, _ = build_model(default_args(**args))
+    model.load_state_dict(seeded_state_dict(model.state_dict(), 3))
+    model.to(dev).train()
+    if kind == 'spsedt':
+        model.mask_ratio = -1.0                               # every query keeps its patch: no random mask between the runs
+    crit.to(dev)
+    opt = build_optimizer(model)
+
+    def batch(seed):
+        if kind == 'spsedt':
+            g = torch.Generator().manual_seed(seed)
+            x = torch.randn(B, 1, 496, 64, generator=g).to(dev)
+            patches = torch.randn(B, 10, 1, 128, 64, generator=g).to(dev)
+            t = []
+            for _ in range(B):
+                l = torch.rand(10, generator=g) * 0.3 + 0.05
+                c = l / 2 + torch.rand(10, generator=g) * (1 - l)
+                t.append({'labels': torch.zeros(10, dtype=torch.int64, device=dev), 'boxes': torch.stack([c, l], -1).to(dev)})
+            return x, t, patches
+        x, t = synthetic_batch(B, 500, seed, dev)
+        return x, t, None
+    return model, crit, opt, batch
+
+
+def _make_stepper(kind, model, crit, opt, batch, B, **kw):
+    from sound_event_detection_transformer_amd.engine import GraphedTrainStep, GraphedSemiStep
+    from sound_event_detection_transformer_amd.utilities.utils import EMA
+    x, t, patches = batch(100)
+    if kind == 'semi':                                        # labelled clips 0..B/2, unlabelled B/2..B (one view)
+        ema = EMA(model, 0.9)
+        ema.register()
+        h = B // 2
+        for tt in t[h:]:
+            tt['labels'], tt['boxes'] = tt['labels'][:0], tt['boxes'][:0]
+        thr = torch.full((10,), 0.03, device=x.device)           # (random-init teacher: a low threshold keeps pseudo events alive)
+        st = GraphedSemiStep(model, ema, crit, opt, x, x, t, slice(h), None, slice(h), slice(h, B), thr, warmup=1, **kw)
+        return st, (lambda b: st(b[0], b[0], [dict(q, labels=q['labels'][:0], boxes=q['boxes'][:0]) if i >= h else q
+                                              for i, q in enumerate(b[1])]))
+    if kind == 'spsedt':
+        st = GraphedTrainStep(model, crit, opt, x, t, slice(B), slice(B), warmup=1, example_patches=patches, **kw)
+        return st, (lambda b: st(b[0], b[1], patches=b[2]))
+    st = GraphedTrainStep(model, crit, opt, x, t, None, slice(B), warmup=1, **kw)
+    return st, (lambda b: st(b[0], b[1]))
+
+
+def _worker(rank, world, port, out, overlap=True, nsteps=2, kind='sedt', cuts='coarse', bf16=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from sound_event_detection_transformer_amd import runtime
-    from sound_event_detection_transformer_amd.sedt import build_model, default_args
-    from sound_event_detection_transformer_amd.engine import build_optimizer, GraphedTrainStep
-    from oracle import sedt_oracle as O
-    from sound_event_detection_transformer_amd.utilities.synthetic import synthetic_batch
+    from sound_event_detection_transformer_amd.engine import dp_segment_plan
     dev = torch.device('cuda', 0)
     runtime.set_compute_dtype('bf16')
-    model, crit, _ = build_model(default_args(dropout=0.0))
-    model.load_state_dict(O.seeded_state_dict(model.state_dict(), 3))
-    model.to(dev).train()
-    crit.to(dev)
-    opt = build_optimizer(model)
+    B = 4 if kind == 'semi' else 2
+    model, crit, opt, batch = _build(kind, dev, B)
+    plan = dp_segment_plan(model, cuts)
     if not overlap:          # same flat parameter order as the overlapped schedule: identical summation order of the grad norm
-        body = model.backbone[0].body
-        opt.set_tail_params([p for n, p in body.named_parameters()
-                             if p.requires_grad and (n.startswith('conv0.') or n.startswith('layer2.'))])
-    B = 2
-    x, t = synthetic_batch(B, 500, 100 + rank, dev)
-    stepper = GraphedTrainStep(model, crit, opt, x, t, None, slice(B), warmup=1, overlap_allreduce=overlap)
-    assert (stepper.g_low is not None) == overlap
+        opt.set_segments([sg[0] for sg in plan])
+    stepper, run = _make_stepper(kind, model, crit, opt, batch, B, overlap_allreduce=overlap, dp_cuts=cuts,
+                                 grad_dtype=torch.bfloat16 if bf16 else None)
+    assert len(stepper.g_seg) == (len(plan) - 1 if overlap else 0), (len(stepper.g_seg), len(plan))
+    v0 = torch.cat([p.detach().flatten().float().cpu() for p in model.parameters() if p.requires_grad])
     for i in range(nsteps):
-        x, t = synthetic_batch(B, 500, 200 + 10 * i + rank, dev)
-        stepper(x, t)
+        run(batch(200 + 10 * i + rank))
     torch.cuda.synchronize()
     vec = torch.cat([p.detach().flatten().float().cpu() for p in model.parameters() if p.requires_grad])
     both = [torch.zeros_like(vec) for _ in range(world)]
     dist.all_gather(both, vec)
     if rank == 0:
-        torch.save({'same': bool(torch.equal(both[0], both[1])), 'finite': bool(torch.isfinite(vec).all()),
-                    'norm': float(vec.norm()), 'vec': vec}, out)
+        ok = bool(torch.isfinite(vec).all()) and int(stepper.nonfinite.item()) == 0 and bool((vec != v0).any())
+        torch.save({'same': bool(torch.equal(both[0], both[1])), 'finite': ok,
+                    'norm': float(vec.norm()), 'vec': vec, 'nseg': len(plan)}, out)
     dist.destroy_process_group()
 
 
-def test_graphed_dp_world2_replicas_stay_identical(tmp_path):
+@pytest.mark.parametrize('kind,cuts,nseg', [('sedt', 'coarse', 4), ('sedt', 'fine', 5), ('spsedt', 'coarse', 2), ('semi', 'coarse', 4)])
+def test_graphed_dp_world2_replicas_stay_identical(tmp_path, kind, cuts, nseg):
+    """world 2: the backward cut in nseg segments, each segment's all-reduce issued as soon as its graph is queued - for the
+    supervised step (C2/C3), the SP-SEDT pre-training step (C4: the reference's DDP configuration, train_spsedt.py:157-158; frozen
+    backbone, cut at the encoder output) and the mean-teacher step (C5).  Replicas stay bit-identical and the result equals the
+    single all-reduce schedule on the same flat layout"""
     out = str(tmp_path / 'r.pt')
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, True, 2, kind, cuts), nprocs=2, join=True)
     r = torch.load(out)
-    assert r['same'] and r['finite'], {k: v for k, v in r.items() if k != 'vec'}
-    # the same two steps without the backward cut / split all-reduce (same flat layout order): same parameters
+    assert r['same'] and r['finite'] and r['nseg'] == nseg, {k: v for k, v in r.items() if k != 'vec'}
+    # the same two steps without the backward cuts / split all-reduce (same flat layout order): same parameters
     out2 = str(tmp_path / 'r2.pt')
-    mp.spawn(_worker, args=(2, _free_port(), out2, False), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out2, False, 2, kind, cuts), nprocs=2, join=True)
     r2 = torch.load(out2)
     assert r2['same'] and r2['finite']
     d = (r['vec'] - r2['vec']).abs().max().item()
     assert d <= 1e-6 * max(1.0, r2['vec'].abs().max().item()), d
+
+
+def test_bf16_gradient_buckets_stay_close_to_f32_buckets(tmp_path):
+    """grad_dtype=bf16 (half the all-reduce bytes): replicas identical; ONE step lands within a few per cent of an AdamW step of
+    the f32-bucket result (gradients rounded to 8 mantissa bits once, before the average)"""
+    a, b = str(tmp_path / 'bf.pt'), str(tmp_path / 'f32.pt')
+    mp.spawn(_worker, args=(2, _free_port(), a, True, 1, 'sedt', 'coarse', True), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), b, True, 1, 'sedt', 'coarse', False), nprocs=2, join=True)
+    ra, rb = torch.load(a), torch.load(b)
+    assert ra['same'] and ra['finite'] and rb['same']
+    v0 = _initial_vec()
+    moved = (rb['vec'] - v0).abs().max().item()
+    d = (ra['vec'] - rb['vec']).abs().max().item()
+    assert moved > 0 and 0 < d <= 0.1 * moved, (d, moved)
 
 
 def _mean_grad_worker(rank, out):
@@ -92,8 +157,8 @@ def _mean_grad_worker(rank, out):
     model.to(dev).train()
     crit.to(dev)
     opt = build_optimizer(model)
-    body = model.backbone[0].body
-    opt.set_tail_params([p for n, p in body.named_parameters() if p.requires_grad and (n.startswith('conv0.') or n.startswith('layer2.'))])
+    from sound_event_detection_transformer_amd.engine import dp_segment_plan
+    opt.set_segments([sg[0] for sg in dp_segment_plan(model, 'coarse')])
     B = 2
     grads = []
     side = torch.cuda.Stream()
@@ -134,50 +199,43 @@ def _initial_vec():
     return torch.cat([p.detach().flatten().float() for p in model.parameters() if p.requires_grad])
 
 
-def _nccl_worker(rank, port, out, dp):
+def _nccl_worker(rank, port, out, dp, kind='sedt'):
     """one process, one GPU; dp=True: RCCL process group of size 1 with the multi-GPU schedule forced"""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
     from sound_event_detection_transformer_amd import runtime
-    from sound_event_detection_transformer_amd.sedt import build_model, default_args
-    from sound_event_detection_transformer_amd.engine import build_optimizer, GraphedTrainStep
-    from sound_event_detection_transformer_amd.utilities.synthetic import seeded_state_dict, synthetic_batch
+    from sound_event_detection_transformer_amd.engine import dp_segment_plan
     dev = torch.device('cuda', 0)
     torch.cuda.set_device(dev)
     if dp:
         dist.init_process_group('nccl', rank=0, world_size=1)
     runtime.set_compute_dtype('bf16')
-    model, crit, _ = build_model(default_args(dropout=0.0))
-    model.load_state_dict(seeded_state_dict(model.state_dict(), 3))
-    model.to(dev).train()
-    crit.to(dev)
-    opt = build_optimizer(model)
+    B = 4 if kind == 'semi' else 2
+    model, crit, opt, batch = _build(kind, dev, B)
+    plan = dp_segment_plan(model, 'coarse')
     if not dp:
         # same flat parameter order as the data-parallel schedule picks, so that the global-norm summation order - and with
         # it every bit of the clipped AdamW update - is the same in both runs (bf16 training amplifies 1-ulp differences)
-        body = model.backbone[0].body
-        opt.set_tail_params([p for n, p in body.named_parameters()
-                             if p.requires_grad and (n.startswith('conv0.') or n.startswith('layer2.'))])
-    B = 2
-    x, t = synthetic_batch(B, 500, 100, dev)
-    stepper = GraphedTrainStep(model, crit, opt, x, t, None, slice(B), warmup=1, data_parallel=True if dp else None)
-    assert (stepper.g_low is not None) == dp
+        opt.set_segments([sg[0] for sg in plan])
+    stepper, run = _make_stepper(kind, model, crit, opt, batch, B, data_parallel=True if dp else None)
+    assert len(stepper.g_seg) == (len(plan) - 1 if dp else 0)
+    v0 = torch.cat([p.detach().flatten().float().cpu() for p in model.parameters() if p.requires_grad])
     for i in range(2):
-        x, t = synthetic_batch(B, 500, 200 + 10 * i, dev)
-        stepper(x, t)
+        run(batch(200 + 10 * i))
     torch.cuda.synchronize()
     vec = torch.cat([p.detach().flatten().float().cpu() for p in model.parameters() if p.requires_grad])
-    torch.save({'vec': vec, 'finite': bool(torch.isfinite(vec).all())}, out)
+    torch.save({'vec': vec, 'finite': bool(torch.isfinite(vec).all()) and int(stepper.nonfinite.item()) == 0 and bool((vec != v0).any())}, out)
     if dp:
         dist.destroy_process_group()
 
 
-def test_rccl_schedule_on_one_gpu_matches_single_process_step(tmp_path):
-    """the multi-GPU schedule (cut backward, two asynchronous RCCL AVG all-reduces of the flat buffer, optimizer graph) on a
+@pytest.mark.parametrize('kind', ['sedt', 'spsedt', 'semi'])
+def test_rccl_schedule_on_one_gpu_matches_single_process_step(tmp_path, kind):
+    """the multi-GPU schedule (segmented backward, one asynchronous RCCL AVG all-reduce per flat segment, optimizer graph) on a
     process group of size 1 - exercises the real RCCL calls between the graphs - equals the plain one-graph step"""
     a, b = str(tmp_path / 'dp.pt'), str(tmp_path / 'single.pt')
-    mp.spawn(_nccl_worker, args=(_free_port(), a, True), nprocs=1, join=True)
-    mp.spawn(_nccl_worker, args=(_free_port(), b, False), nprocs=1, join=True)
+    mp.spawn(_nccl_worker, args=(_free_port(), a, True, kind), nprocs=1, join=True)
+    mp.spawn(_nccl_worker, args=(_free_port(), b, False, kind), nprocs=1, join=True)
     ra, rb = torch.load(a), torch.load(b)
     assert ra['finite'] and rb['finite']
     d = (ra['vec'] - rb['vec']).abs().max().item()

@@ -458,6 +458,100 @@ def test_graph_sees_lr_changes_and_survives_eager_steps(pkg):
     assert d23 < 0.5 * d12                                            # the smaller learning rate took effect in the replay
 
 
+def test_nonfinite_batch_leaves_training_state_untouched(pkg):
+    """a NaN / inf loss inside a captured step must not reach the weights.  The criterion raises its device word, the
+    captured clip + AdamW + EMA kernels skip themselves while it is up: parameters, moments, the Adam step count and the EMA
+    teacher stay at their last good values however many replays pass before the host polls the word - and the poll raises"""
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import GraphedSemiStep
+    runtime.set_compute_dtype('bf16')
+    masks = dict(mask_strong=slice(2), mask_weak=slice(2, 4), mask_label=slice(4), mask_unlabel=slice(4, 8))
+    thr = torch.full((10,), 0.115).cuda()
+    xt, xs, tg = _rand_semi_batch(950, 2, 2, 4)
+    model, crit, ema, opt = _semi_model(sedt, dropout=0.1)
+    stepper = GraphedSemiStep(model, ema, crit, opt, xt, xs, tg, classwise_threshold=thr, **masks)
+    stepper.check_every = 0                                   # no periodic poll: the host stays blind, as for 49 of 50 replays
+    stepper(xt, xs, tg)
+    torch.cuda.synchronize()
+    good = ({k: v.clone() for k, v in model.state_dict().items()}, {k: v.clone() for k, v in ema.shadow.items()},
+            opt._m.clone(), opt._v.clone(), int(opt._step_t.item()))
+    assert good[4] == 1 and int(stepper.nonfinite.item()) == 0
+    bad = xt.clone()
+    bad[1, 0, 7, 3] = float('nan')                            # one labelled clip with a NaN feature
+    for _ in range(3):
+        stepper(bad, xs, tg)
+    stepper(xt, xs, tg)                                       # (the word is sticky: even a good batch does not update any more)
+    torch.cuda.synchronize()
+    assert int(stepper.nonfinite.item()) == 1
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, good[0][k]), k
+    for k, v in ema.shadow.items():
+        assert torch.equal(v, good[1][k]), k
+    assert torch.equal(opt._m, good[2]) and torch.equal(opt._v, good[3]) and int(opt._step_t.item()) == 1
+    with pytest.raises(FloatingPointError):
+        stepper(xt, xs, tg, check_finite=True)
+    runtime.set_compute_dtype('f32')
+
+
+def test_gradient_accumulation_graph_matches_eager(pkg):
+    """accumrating_gradient_steps = 2 / accumlating_ema_steps = 2 (reference engine.py:76, 174, 180): the captured steps add the
+    micro-batch gradients into the flat buffer and run the optimizer (and the EMA update) only on every second call - the same
+    parameters as eager steps that withhold optimizer.step() on the odd batches, and different from stepping on every batch"""
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import (train_step, build_optimizer, GraphedTrainStep, semi_train_step,
+                                                               GraphedSemiStep)
+    runtime.set_compute_dtype('f32')
+    B = 2
+    batches = [(torch.randn(B, 1, 500, 64, generator=torch.Generator().manual_seed(40 + i)).cuda(),
+                _cuda_targets(synthetic_targets(B, 50 + i, 10))) for i in range(4)]
+    res = {}
+    for mode in ('graph', 'eager', 'every'):
+        model, crit, _ = sedt.build_model(sedt.default_args(dropout=0.0))
+        model.load_state_dict(O.seeded_state_dict(model.state_dict(), 5))
+        model.cuda().train()
+        crit.cuda()
+        opt = build_optimizer(model)
+        if mode == 'graph':
+            stepper = GraphedTrainStep(model, crit, opt, batches[0][0], batches[0][1], None, slice(B), warmup=1, accum_steps=2)
+        for i, (x, t) in enumerate(batches):
+            if mode == 'graph':
+                stepper(x, t)
+            else:
+                train_step(model, crit, opt, x, t, None, slice(B), do_step=(mode == 'every' or i % 2 == 1))
+        res[mode] = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+        if mode == 'graph':
+            assert int(opt._step_t.item()) == 2
+    k = 'transformer.encoder.layers.0.linear1.weight'
+    for name in res['eager']:
+        assert rel(res['graph'][name], res['eager'][name]) < 2e-4, name
+    assert rel(res['every'][k], res['eager'][k]) > 1e-5
+    # mean-teacher step: optimizer every 2nd batch, EMA every 2nd batch
+    masks = dict(mask_strong=slice(2), mask_weak=slice(2, 4), mask_label=slice(4), mask_unlabel=slice(4, 8))
+    thr = torch.full((10,), 0.115).cuda()
+    sb = [_rand_semi_batch(970 + i, 2, 2, 4) for i in range(4)]
+    out = {}
+    for mode in ('graph', 'eager'):
+        model, crit, ema, opt = _semi_model(sedt)
+        with torch.no_grad():
+            for n in ema.shadow:
+                ema.shadow[n].mul_(1.01)
+        if mode == 'graph':
+            stepper = GraphedSemiStep(model, ema, crit, opt, sb[0][0], sb[0][1], sb[0][2], classwise_threshold=thr, accum_steps=2,
+                                      accumulating_ema_steps=2, warmup=1, **masks)
+        for i, (xt, xs, tg) in enumerate(sb):
+            if mode == 'graph':
+                stepper(xt, xs, tg)
+            else:
+                semi_train_step(model, ema, crit, opt, xt, xs, tg, classwise_threshold=thr, do_step=(i % 2 == 1), do_ema=(i % 2 == 1),
+                                **masks)
+        out[mode] = ({k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()},
+                     {k: v.detach().float().cpu().clone() for k, v in ema.shadow.items()})
+    for name in out['eager'][0]:
+        assert rel(out['graph'][0][name], out['eager'][0][name]) < 1e-3, name
+    for name in out['eager'][1]:
+        assert rel(out['graph'][1][name], out['eager'][1][name]) < 1e-3, name
+
+
 def test_predict_step_eager_and_graphed(pkg):
     """the per-batch body of engine.get_sedt_predictions (engine.py:244-285): losses as the criterion gives them for the same
     outputs, audio tags, PostProcess per fusion strategy equal to the oracle's PostProcess on the model's own outputs; the graphed
