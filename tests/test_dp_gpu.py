@@ -136,9 +136,11 @@ def test_bf16_gradient_buckets_stay_close_to_f32_buckets(tmp_path):
     ra, rb = torch.load(a), torch.load(b)
     assert ra['same'] and ra['finite'] and rb['same']
     v0 = _initial_vec()
-    moved = (rb['vec'] - v0).abs().max().item()
-    d = (ra['vec'] - rb['vec']).abs().max().item()
-    assert moved > 0 and 0 < d <= 0.1 * moved, (d, moved)
+    # (L2, not max: the first Adam step moves every element by ~ lr * sign(g), so an element whose tiny gradient changes sign
+    # under the rounding differs by a whole step; what must hold is that such elements are rare)
+    moved = (rb['vec'] - v0).norm().item()
+    d = (ra['vec'] - rb['vec']).norm().item()
+    assert moved > 0 and 0 < d <= 0.05 * moved, (d, moved)
 
 
 def _mean_grad_worker(rank, out):
