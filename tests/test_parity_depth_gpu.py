@@ -164,7 +164,7 @@ def _smooth_loss(o):
     return t
 
 
-def test_bf16_mode_error_is_measured_and_bounded(pkg, golden_dir, capsys):
+def test_bf16_mode_error_vs_fixtures_and_gradient_norms_vs_this_librarys_f32_mode(pkg, golden_dir, capsys):
     """bf16 throughput mode against the f32 reference, measured and printed:
     * eval outputs against fixture G2 (the reference's own numbers);
     * the training loss against fixture G3 with the Hungarian ASSIGNMENT taken from the f32-mode forward of the same model (pinned
