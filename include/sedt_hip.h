@@ -143,13 +143,15 @@ int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, void* stream);
  * sedt/sedt.py:36-38, 90-95, 398-409): direct kernels on the f32 MASTER weight w[N][K] (no packing).
  * fwd: y[m][n] = act(x[m] . w[n] + bias[n]); y is f32 (out_f32) or the compute dtype.
  * bwd: g[M][N] f32 is the gradient of y; with act != NONE the derivative is folded in from ysaved (= y, f32, same ld as g).
- *      gx (compute dtype, optional; masked by mask > 0 when given) = g' w; dw[N][K], db[N] (optional) = g'^T x, column sums. */
+ *      gx (compute dtype, optional; masked by mask > 0 when given) = g' w - or gx += g' w when accumulate_gx != 0 (a head that
+ *      shares its input with other heads adds to the running input gradient; rows ldo apart, so a strided row subset works);
+ *      dw[N][K], db[N] (optional) = g'^T x, column sums. */
 int sedt_skinny_linear_fwd(const void* x, int64_t ldx, const float* w, const float* bias, void* y, int64_t ldy, int M, int N,
                            int K, int act, int out_f32, int dtype, void* stream);
 size_t sedt_skinny_linear_bwd_scratch(int K); /* bytes of `scratch` (row-slice partial sums) when dw is requested */
 int sedt_skinny_linear_bwd(const float* g, const float* ysaved, int64_t ldg, const float* w, const void* x, int64_t ldx,
                            const void* mask, int64_t ldm, void* gx, int64_t ldo, float* dw, float* db, float* scratch, int M, int N,
-                           int K, int act, int dtype, void* stream);
+                           int K, int act, int accumulate_gx, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ elementwise / reductions */
 /* out[c] = sum_r in[r*ld + c]   (in: compute dtype or f32 if in_f32), out f32 */
@@ -161,6 +163,9 @@ int sedt_dropout_grad(const void* in, int64_t ldi, void* out, int64_t ldo, int r
                       uint32_t seed, const uint32_t* seed_ptr, int dtype, void* stream);
 /* out[r][c] = a[r][c] + b[(b_mod ? r % b_mod : r)][c] */
 int sedt_add(const void* a, const void* b, void* out, int rows, int cols, int b_mod, int dtype, void* stream);
+/* out = srcs[0] + ... + srcs[n-1] (n <= 8 equally shaped tensors of the compute dtype, numel a multiple of 8; srcs is a HOST array of
+ * device pointers): the gradient of a tensor with several consumers in one launch */
+int sedt_add_n(const void* const* srcs, int n, void* out, int64_t numel, int dtype, void* stream);
 /* dtype conversion f32 <-> compute dtype, elementwise over n */
 int sedt_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, void* stream);
 /* out = y > 0 ? g : 0 (ReLU backward), compute dtype, elementwise over n */
@@ -314,7 +319,7 @@ int sedt_multi_gather(const SedtChunk* table, int nchunks, int mode, void* strea
  * whole training state (student, optimizer, teacher) at its last good value until the host sees the flag and raises. */
 int sedt_multi_ema(const SedtChunk* table, int nchunks, float decay, const int32_t* guard /* or null */, void* stream);
 int sedt_multi_sumsq(const SedtChunk* table, int nchunks, float* partial, float* sumsq, int32_t* step_ptr /* or null: += 1 */,
-                     int32_t* guard /* or null */, void* stream);
+                     int32_t* guard /* or null */, uint32_t* seed_word /* or null: the device dropout-seed word, += 1 */, void* stream);
 int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float* sumsq, float max_norm, float beta1, float beta2,
                      float eps, const int32_t* step_ptr /* device: 1-based step count */, const int32_t* guard /* or null */,
                      void* stream);
@@ -369,10 +374,16 @@ typedef struct SedtCriterion {
    * (utilities/mixup.py:13-127 returns a new strong | weak split for every batch); ns / n_lab then are the capacities = the
    * strides of the dense tables.  Lets a captured step take batches of any split. */
   const int32_t* split;
+  /* layout of logits / boxes (and of the gradients sedt_set_criterion_bwd returns): [L][B][Qs] rows, of which the Q queries
+   * q0 .. q0 + Q - 1 take part in the losses (dec_at models run their heads over the audio-tag query 0 too: Qs = Q + 1, q0 = 1;
+   * otherwise Qs = Q, q0 = 0).  The per-term gradient buffers dlogits / dboxes / dboxes2 stay compact ([L][B][Q]). */
+  int32_t Qs, q0;
+  float* total; /* optional: receives out[4L+3] as a separate scalar (its own autograd output: no select/backward-of-select) */
 } SedtCriterion;
 int sedt_set_criterion(const SedtCriterion* args, void* stream);
-int sedt_set_criterion_bwd(const SedtCriterion* args, const float* g, float* glogits, float* gboxes, float* gat,
-                           void* stream);
+/* g: gradient that reached out[4L+5] (or null), gtotal: gradient that reached the separate total scalar (or null) */
+int sedt_set_criterion_bwd(const SedtCriterion* args, const float* g, const float* gtotal, float* glogits, float* gboxes,
+                           float* gat, void* stream);
 
 /* ------------------------------------------------------------------ SP-SEDT feature-reconstruction loss (sedt/sedt.py:263-283)
  * For dense layer d, strong clip b, query q matched to patch tidx (wbox > 0):
@@ -436,6 +447,7 @@ typedef struct SedtMatch {
   const uint32_t* seed_ptr; /* or null */
   const int32_t* split;     /* or null: device {ns, n_lab} of this batch, see SedtCriterion.split (box_off then has ns + 1
                                entries for the capacity ns; clips >= split[0] get "no target" rows) */
+  int32_t Qs, q0;           /* logits / boxes rows are [L][B][Qs]; queries q0 .. q0 + Q - 1 are matched (see SedtCriterion) */
 } SedtMatch;
 int sedt_match_targets(const SedtMatch* args, void* stream);
 

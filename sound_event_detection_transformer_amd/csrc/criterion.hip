@@ -61,8 +61,9 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
     float l_ce = 0.f, l_bb = 0.f, l_gi = 0.f, n_hit = 0.f, n_cnt = 0.f;
     for (int rr = t; rr < B * Q; rr += 1024) {  // one row = (clip b, query q)
       const int b = rr / Q, q = rr - b * Q;
-      const long mrow = ((long)ml * B + b) * Q + q;
-      const float* x = a.logits + mrow * C1;
+      const long mrow = ((long)ml * B + b) * Q + q;                       // row of the (compact) per-term gradient buffers
+      const long xrow = ((long)ml * B + b) * a.Qs + a.q0 + q;             // row of the model's head outputs (Qs queries per clip)
+      const float* x = a.logits + xrow * C1;
       float* gx = a.dlogits + mrow * C1;
       float* gbx = a.dboxes + mrow * 2;
       float* gbx2 = a.dboxes2 + mrow * 2;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
         if (amax == tc) n_hit += 1.f;
       }
       // boxes (centre, length) -> interval [s, e]
-      const float* bx = a.boxes + mrow * 2;
+      const float* bx = a.boxes + xrow * 2;
       float gc = 0.f, gl = 0.f, gc2 = 0.f, gl2 = 0.f;
       if (wb > 0.f) {
         const float s1 = bx[0] - 0.5f * bx[1], e1 = bx[0] + 0.5f * bx[1];
@@ -204,29 +205,40 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
   if (t == 0) {
     a.out[SLOT_WEAK] = weak;
     a.out[4 * L + 3] = total;                   // weighted total
+    if (a.total) a.total[0] = total;
     if (a.nonfinite && !(fabsf(total) <= 3.0e38f)) *a.nonfinite = 1;      // NaN or inf (engine.py:70-73)
   }
 }
 
-// grads of the model outputs from the gradient g[4L+5] that reached the loss vector
+// grads of the model outputs from the gradient g[4L+5] that reached the loss vector and / or the gradient gtotal[1] that reached the
+// separately returned total (either may be null).  glogits / gboxes have the layout of the head outputs ([L][B][Qs] rows): the
+// rows of queries outside [q0, q0 + Q) - the audio-tag query of dec_at models - get zeros.
 __global__ __launch_bounds__(256) void set_criterion_bwd_kernel(const SedtCriterion a, const float* __restrict__ g,
-                                                                float* __restrict__ glogits, float* __restrict__ gboxes,
-                                                                float* __restrict__ gat) {
-  const int L = a.L, B = a.B, Q = a.Q, C1 = a.C + 1;
-  const float gtot = g[4 * L + 3];
-  const int nrows = L * B * Q;
+                                                                const float* __restrict__ gtotal, float* __restrict__ glogits,
+                                                                float* __restrict__ gboxes, float* __restrict__ gat) {
+  const int L = a.L, B = a.B, Q = a.Q, Qs = a.Qs, C1 = a.C + 1;
+  const float gtot = (g ? g[4 * L + 3] : 0.f) + (gtotal ? gtotal[0] : 0.f);
+  const int nrows = L * B * Qs;
   for (int r = blockIdx.x * 256 + threadIdx.x; r < nrows; r += gridDim.x * 256) {
-    const int d = r / (Q * B);
+    const int d = r / (Qs * B);
+    const int rem = r - d * Qs * B, b = rem / Qs, qs = rem - b * Qs, q = qs - a.q0;
     const int ml = a.layer_of[d];
-    const long row = (long)ml * B * Q + (r - d * Q * B);
-    const float kce = g[4 * d] + gtot * a.w_ce[d], kl1 = g[4 * d + 1] + gtot * a.w_bbox[d],
-                kgi = g[4 * d + 2] + gtot * a.w_giou[d];
-    for (int c = 0; c < C1; ++c) glogits[row * C1 + c] = kce * a.dlogits[row * C1 + c];
-    gboxes[row * 2] = kl1 * a.dboxes[row * 2] + kgi * a.dboxes2[row * 2];
-    gboxes[row * 2 + 1] = kl1 * a.dboxes[row * 2 + 1] + kgi * a.dboxes2[row * 2 + 1];
+    const long xrow = ((long)ml * B + b) * Qs + qs;
+    if (q < 0 || q >= Q) {
+      for (int c = 0; c < C1; ++c) glogits[xrow * C1 + c] = 0.f;
+      gboxes[xrow * 2] = 0.f;
+      gboxes[xrow * 2 + 1] = 0.f;
+      continue;
+    }
+    const long row = ((long)ml * B + b) * Q + q;
+    const float kce = (g ? g[4 * d] : 0.f) + gtot * a.w_ce[d], kl1 = (g ? g[4 * d + 1] : 0.f) + gtot * a.w_bbox[d],
+                kgi = (g ? g[4 * d + 2] : 0.f) + gtot * a.w_giou[d];
+    for (int c = 0; c < C1; ++c) glogits[xrow * C1 + c] = kce * a.dlogits[row * C1 + c];
+    gboxes[xrow * 2] = kl1 * a.dboxes[row * 2] + kgi * a.dboxes2[row * 2];
+    gboxes[xrow * 2 + 1] = kl1 * a.dboxes[row * 2 + 1] + kgi * a.dboxes2[row * 2 + 1];
   }
   if (gat) {
-    const float kw = g[4 * L + 2] + gtot * a.w_weak;
+    const float kw = (g ? g[4 * L + 2] : 0.f) + gtot * a.w_weak;
     for (int r = blockIdx.x * 256 + threadIdx.x; r < a.Bat * a.C; r += gridDim.x * 256) gat[r] = kw * a.dat[r];
   }
 }
@@ -332,7 +344,7 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
   float* loc = cst + Q * a.max_targets;    // [Q][n] localisation-only cost (fine_tune)
   const bool main_ft = a.fine_tune && d == 0;
   if (lane < Q) {
-    const float* x = a.logits + (((long)ml * B + b) * Q + lane) * C1;
+    const float* x = a.logits + (((long)ml * B + b) * a.Qs + a.q0 + lane) * C1;
     if (a.fl) {                            // matcher.py:73-78: focal cost on sigmoid probabilities
       for (int c = 0; c < C1; ++c) {
         const float p = 1.f / (1.f + expf(-x[c]));
@@ -351,7 +363,7 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
   __syncthreads();
   for (int i = lane; i < Q * n; i += 64) {
     const int q = i / n, t = i % n;
-    const float* bx = a.boxes + (((long)ml * B + b) * Q + q) * 2;
+    const float* bx = a.boxes + (((long)ml * B + b) * a.Qs + a.q0 + q) * 2;
     const float c1 = bx[0], l1 = bx[1], c2 = a.box_cat[2 * (bo + t)], l2 = a.box_cat[2 * (bo + t) + 1];
     const float s1 = c1 - l1 / 2, e1 = c1 + l1 / 2, s2 = c2 - l2 / 2, e2 = c2 + l2 / 2;
     const float cost_bbox = fabsf(s1 - s2) + fabsf(e1 - e2);
@@ -453,20 +465,21 @@ extern "C" int sedt_set_criterion(const SedtCriterion* args, void* stream) {
                "set_criterion: null pointer");
   SEDT_REQUIRE((a.at == nullptr) == (a.dat == nullptr), "set_criterion: at and dat go together");
   SEDT_REQUIRE(a.L * a.B <= SEDT_CRIT_MAXCARD, "set_criterion: L*B = %d exceeds %d", a.L * a.B, SEDT_CRIT_MAXCARD);
+  SEDT_REQUIRE(a.q0 >= 0 && a.Qs >= a.q0 + a.Q, "set_criterion: query window q0=%d Q=%d outside Qs=%d", a.q0, a.Q, a.Qs);
   hipLaunchKernelGGL(set_criterion_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), a);
   return check_launch("set_criterion");
 }
 
-extern "C" int sedt_set_criterion_bwd(const SedtCriterion* args, const float* g, float* glogits, float* gboxes, float* gat,
-                                      void* stream) {
+extern "C" int sedt_set_criterion_bwd(const SedtCriterion* args, const float* g, const float* gtotal, float* glogits, float* gboxes,
+                                      float* gat, void* stream) {
   using namespace sedt;
-  SEDT_REQUIRE(args != nullptr && g && glogits && gboxes, "set_criterion_bwd: null pointer");
+  SEDT_REQUIRE(args != nullptr && (g || gtotal) && glogits && gboxes, "set_criterion_bwd: null pointer");
   const SedtCriterion& a = *args;
   SEDT_REQUIRE(a.L >= 1 && a.L <= SEDT_CRIT_MAXL, "set_criterion_bwd: L=%d", a.L);
   SEDT_REQUIRE(a.dlogits && a.dboxes && a.dboxes2 && ((gat == nullptr) || a.dat), "set_criterion_bwd: null gradient buffers");
-  const int rows = a.L * a.B * a.Q;
+  const int rows = a.L * a.B * a.Qs;
   hipLaunchKernelGGL(set_criterion_bwd_kernel, dim3((rows + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, g,
-                     glogits, gboxes, gat);
+                     gtotal, glogits, gboxes, gat);
   return check_launch("set_criterion_bwd");
 }
 
@@ -477,6 +490,7 @@ extern "C" int sedt_match_targets(const SedtMatch* args, void* stream) {
   SEDT_REQUIRE(a.L >= 1 && a.L <= SEDT_CRIT_MAXL && a.Q >= 1 && a.Q <= 63 && a.C >= 1 && a.C <= 63 && a.ns >= 0 && a.ns <= a.B,
                "match_targets: L=%d Q=%d (<=63) C=%d ns=%d B=%d", a.L, a.Q, a.C, a.ns, a.B);
   SEDT_REQUIRE(a.max_targets >= 1 && a.max_targets <= 63, "match_targets: max_targets=%d (1..63 per clip)", a.max_targets);
+  SEDT_REQUIRE(a.q0 >= 0 && a.Qs >= a.q0 + a.Q, "match_targets: query window q0=%d Q=%d outside Qs=%d", a.q0, a.Q, a.Qs);
   SEDT_REQUIRE(a.logits && a.boxes && a.lab_cat && a.lab_off && a.box_cat && a.box_off && a.tc && a.coef && a.wbox && a.tbox &&
                    a.tidx && a.tgt_len,
                "match_targets: null pointer");

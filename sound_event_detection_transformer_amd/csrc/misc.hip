@@ -250,6 +250,27 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* 
   out[e] = (T)((float)a[e] + (float)b[(long)rb * cols + c]);
 }
 
+// out = sum of up to 8 equally shaped tensors (fixed order): the gradient of a tensor with several consumers in ONE launch (the
+// decoder's query position embedding feeds two attention blocks in each of its layers; autograd would add them pair by pair)
+struct AddN { const void* p[8]; int n; };
+template <typename T>
+__global__ void add_n_kernel(const AddN a, T* __restrict__ out, long n8) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n8) return;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int j = 0; j < a.n; ++j) {
+    const VecT<T, 8> v = reinterpret_cast<const VecT<T, 8>*>(a.p[j])[e];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += (float)v.v[i];
+  }
+  VecT<T, 8> o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o.v[i] = (T)acc[i];
+  reinterpret_cast<VecT<T, 8>*>(out)[e] = o;
+}
+
 template <typename TI, typename TO>
 __global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long n) {
   long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -537,7 +558,7 @@ __global__ void sumsq_partial_kernel(const float* __restrict__ g, long n, float*
 // NaN / inf loss or gradient never reaches parameters, moments, step count or the EMA teacher (the reference aborts before the
 // backward on such a loss, engine.py:70-73 / 167-169; a captured step cannot, its host only polls the word now and then)
 __global__ void sumsq_final_kernel(const float* part, int nparts, float* out, int accumulate, int32_t* step_ptr = nullptr,
-                                   int32_t* guard = nullptr) {
+                                   int32_t* guard = nullptr, uint32_t* seed_word = nullptr) {
   __shared__ float red[4];
   float s = 0.f;
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += part[i];
@@ -550,6 +571,7 @@ __global__ void sumsq_final_kernel(const float* part, int nparts, float* out, in
     out[0] = tot;
     if (guard && !(tot <= 3.0e38f)) *guard = 1;
     if (step_ptr && !(guard && *guard)) step_ptr[0] += 1;
+    if (seed_word) seed_word[0] += 1;          // the device-side dropout seed word: the NEXT step draws other masks
   }
 }
 static int sumsq_parts(long n) {
@@ -913,6 +935,19 @@ extern "C" int sedt_add(const void* a, const void* b, void* out, int rows, int c
   return check_launch("add");
 }
 
+extern "C" int sedt_add_n(const void* const* srcs, int n, void* out, int64_t numel, int dtype, void* stream) {
+  SEDT_REQUIRE(srcs && out && n >= 1 && n <= 8 && numel % 8 == 0, "add_n: 1..8 sources, element count a multiple of 8 (got %d, %ld)", n,
+               (long)numel);
+  AddN a;
+  for (int i = 0; i < 8; ++i) a.p[i] = i < n ? srcs[i] : nullptr;
+  a.n = n;
+  for (int i = 0; i < n; ++i) SEDT_REQUIRE(a.p[i] != nullptr, "add_n: null source %d", i);
+  const long n8 = numel / 8;
+  BY_DTYPE(dtype, hipLaunchKernelGGL(add_n_kernel<float>, dim3(nblk(n8)), dim3(256), 0, S(stream), a, (float*)out, n8),
+           hipLaunchKernelGGL(add_n_kernel<bf16_t>, dim3(nblk(n8)), dim3(256), 0, S(stream), a, (bf16_t*)out, n8));
+  return check_launch("add_n");
+}
+
 extern "C" int sedt_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, void* stream) {
   dim3 g(nblk(n)), b(256);
   if (in_dtype == SEDT_F32 && out_dtype == SEDT_BF16)
@@ -1087,10 +1122,10 @@ extern "C" int sedt_adamw_clip(float* p, const float* g, float* m, float* v, int
 }
 
 extern "C" int sedt_multi_sumsq(const SedtChunk* table, int nchunks, float* partial, float* sumsq, int32_t* step_ptr,
-                                int32_t* guard, void* stream) {
+                                int32_t* guard, uint32_t* seed_word, void* stream) {
   SEDT_REQUIRE(table && partial && sumsq && nchunks > 0, "multi_sumsq: bad arguments");
   hipLaunchKernelGGL(multi_sumsq_kernel, dim3(nchunks), dim3(256), 0, S(stream), table, partial);
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, S(stream), partial, nchunks, sumsq, 0, step_ptr, guard);
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, S(stream), partial, nchunks, sumsq, 0, step_ptr, guard, seed_word);
   return check_launch("multi_sumsq");
 }
 

@@ -61,7 +61,7 @@ __device__ __forceinline__ float skinny_gprime(const float* g, const float* ysav
 template <typename T>
 __global__ __launch_bounds__(256) void skinny_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ ysaved, long ldg,
                                                            const float* __restrict__ w, const T* __restrict__ mask, long ldm,
-                                                           T* __restrict__ gx, long ldo, int M, int N, int K, int act) {
+                                                           T* __restrict__ gx, long ldo, int M, int N, int K, int act, int accumulate) {
   extern __shared__ float sm[];
   float* ws = sm;                       // [N][K]
   const int t = threadIdx.x;
@@ -78,6 +78,11 @@ __global__ __launch_bounds__(256) void skinny_dgrad_kernel(const float* __restri
     const float gv = skinny_gprime(g, ysaved, (long)m * ldg + n, act);
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] = fmaf(gv, ws[n * K + k0 + e], acc[e]);
+  }
+  if (accumulate) {                     // gx += ...: this head shares its input with others (the running input gradient)
+    const VecT<T, 8> old = *reinterpret_cast<const VecT<T, 8>*>(gx + (long)m * ldo + k0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += (float)old.v[e];
   }
   VecT<T, 8> out;
   if (mask) {
@@ -182,7 +187,7 @@ extern "C" size_t sedt_skinny_linear_bwd_scratch(int K) { return (size_t)SK_SPLI
 
 extern "C" int sedt_skinny_linear_bwd(const float* g, const float* ysaved, int64_t ldg, const float* w, const void* x, int64_t ldx,
                                       const void* mask, int64_t ldm, void* gx, int64_t ldo, float* dw, float* db, float* scratch,
-                                      int M, int N, int K, int act, int dtype, void* stream) {
+                                      int M, int N, int K, int act, int accumulate_gx, int dtype, void* stream) {
   SEDT_REQUIRE(g && w && x && M > 0 && N >= 1 && N <= SK_MAXN && K >= 64 && K % 64 == 0 && K <= 1024,
                "skinny_linear_bwd: bad arguments (N <= 16, K a multiple of 64, <= 1024)");
   SEDT_REQUIRE(act == SEDT_ACT_NONE || ysaved, "skinny_linear_bwd: the activation derivative needs the saved output");
@@ -192,10 +197,10 @@ extern "C" int sedt_skinny_linear_bwd(const float* g, const float* ysaved, int64
     dim3 grid((unsigned)((nu + 255) / 256)), block(256);
     if (dtype == SEDT_F32)
       hipLaunchKernelGGL(skinny_dgrad_kernel<float>, grid, block, lds, SS(stream), g, ysaved, (long)ldg, w, (const float*)mask, (long)ldm,
-                         (float*)gx, (long)ldo, M, N, K, act);
+                         (float*)gx, (long)ldo, M, N, K, act, accumulate_gx);
     else if (dtype == SEDT_BF16)
       hipLaunchKernelGGL(skinny_dgrad_kernel<bf16_t>, grid, block, lds, SS(stream), g, ysaved, (long)ldg, w, (const bf16_t*)mask, (long)ldm,
-                         (bf16_t*)gx, (long)ldo, M, N, K, act);
+                         (bf16_t*)gx, (long)ldo, M, N, K, act, accumulate_gx);
     else { set_error("skinny_linear_bwd: unsupported dtype %d", dtype); return 1; }
   }
   if (dw) {

@@ -209,6 +209,7 @@ class _GraphedBase(object):
         self._tabname = f'graph{id(self)}'
         self._calls = 0
         self.nonfinite = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._one = torch.ones((), dtype=torch.float32, device=dev)     # the backward's root gradient (autograd would fill one per step)
         criterion.nonfinite = self.nonfinite
         # the same word guards the update: with it raised (non-finite loss, or non-finite gradient norm) the captured clip + AdamW
         # (and the EMA update) leave parameters, moments, step count and teacher untouched, replay after replay, until the host
@@ -216,6 +217,11 @@ class _GraphedBase(object):
         optimizer.guard = self.nonfinite
         if getattr(self, 'ema', None) is not None:
             self.ema.guard = self.nonfinite
+        # the dropout-seed word is advanced by the captured optimizer step itself (the final reduction of the gradient norm), one
+        # launch less per replay - unless the optimizer does not run on every call (gradient accumulation) or does not clip
+        from . import runtime as _rt
+        self._host_bump = not (getattr(self, 'max_norm', 0) > 0 and getattr(self, 'accum_steps', 1) == 1)
+        optimizer.seed_word = None if self._host_bump else _rt.seed_ptr(dev)
 
     def _before_replay(self):
         self.optimizer.refresh_hyperparams(self._tabname)      # StepLR / param_group['lr'] edits reach the captured upload
@@ -237,6 +243,9 @@ class _GraphedBase(object):
         optimizer.set_segments([sg[0] for sg in segs])
         self.segs = [(sg[0], sg[1]) for sg in segs]
 
+    def _root_grad(self, root):
+        return self._one if (root.dim() == 0 and root.dtype == torch.float32) else torch.ones_like(root)
+
     def _segment_backward(self, k, root=None, accumulate=False):
         """(inside the capture of graph k) gradients of segment k's parameters -> segment k of the flat buffer.  k = 0 starts
         from the loss ``root``; later segments continue from the gradient of the previous cut tensor."""
@@ -246,7 +255,7 @@ class _GraphedBase(object):
             raise RuntimeError('the model did not keep the cut tensor of a data-parallel segment')
         want = ([cut_t] if cut_t is not None else []) + list(params)
         if k == 0:
-            grads = torch.autograd.grad(root, want)
+            grads = torch.autograd.grad(root, want, grad_outputs=self._root_grad(root))
         else:
             grads = torch.autograd.grad(self._cut_t, want, grad_outputs=self._cut_g)
         if cut_t is not None:
@@ -429,6 +438,7 @@ class GraphedTrainStep(_GraphedBase):
                     if acc:
                         optimizer._flat_g.zero_()            # the next micro-batch adds into an empty buffer
         torch.cuda.synchronize()
+        optimizer.flush_uploads()
 
     # ------------------------------------------------------------------ pieces
     def _make_tables(self, example_targets, max_targets):
@@ -445,7 +455,8 @@ class GraphedTrainStep(_GraphedBase):
         if self.mix:
             ops.mixup(self.static_raw, self.static_raw, self._jobs.dev_buf, out=self.static_x)
         if self.static_patches is not None:
-            mask = torch.zeros(self.static_x.shape[0], self.static_x.shape[2], self.static_x.shape[3], dtype=torch.bool, device=self.dev)
+            from .utilities.utils import _no_padding_mask
+            mask = _no_padding_mask(self.static_x.shape[0], self.static_x.shape[2], self.static_x.shape[3], self.dev)
             return self.model((self.static_x, mask), self.static_patches)
         return self.model(self.static_x)
 
@@ -458,7 +469,7 @@ class GraphedTrainStep(_GraphedBase):
         self.criterion.compute(out, dense, self.fl)
         total = self.criterion.last_total
         self.criterion.last_total = None
-        total.backward()
+        torch.autograd.backward(total, grad_tensors=self._root_grad(total))
         if self.flat_mode:
             self.optimizer.enable_flat_grads(self.grad_dtype)
             flat = self.optimizer.gather_grads()
@@ -474,7 +485,7 @@ class GraphedTrainStep(_GraphedBase):
         self.static_total = self.criterion.last_total
         # weight gradients ride in the spare workgroup slots of the dgrad chain's launches; drained on exit
         with self.runtime.async_wgrad(self.async_wgrad), ops.coschedule(self.coschedule):
-            self.static_total.backward()
+            torch.autograd.backward(self.static_total, grad_tensors=self._root_grad(self.static_total))
         if not self.flat_mode:
             self.optimizer.step(max_norm=self.max_norm)
         else:                                                # all gradients -> one flat buffer (one launch)
@@ -496,7 +507,8 @@ class GraphedTrainStep(_GraphedBase):
             self.static_x.copy_(batch_input, non_blocking=True)
         if self.static_patches is not None:
             self.static_patches.copy_(patches, non_blocking=True)
-        self.runtime.bump_seed(self.dev)
+        if self._host_bump:
+            self.runtime.bump_seed(self.dev)
         self._before_replay()
         if self.device_matching:
             self.tables.load(targets, **split)
@@ -710,6 +722,7 @@ def _slice_outputs(out, sl):
         o['aux_outputs'] = [{k: v[sl] for k, v in a.items()} for a in out['aux_outputs']]
     if '_stacked' in out:
         o['_stacked'] = tuple(t[:, sl] for t in out['_stacked'])
+        o['_q0'] = out.get('_q0', 0)
     return o
 
 
@@ -845,6 +858,7 @@ class GraphedSemiStep(_GraphedBase):
                 with torch.cuda.graph(self.g_ema, pool=self.graph.pool(), **self._capture):
                     self.ema.update()
         torch.cuda.synchronize()
+        optimizer.flush_uploads()
 
     def _body(self, part='all'):
         if part == 'update':
@@ -886,7 +900,7 @@ class GraphedSemiStep(_GraphedBase):
         if part == 'fwd_bwd' and self.segs is not None:
             self.flat_parts = [self._segment_backward(0, self.total, self.accum_steps > 1)]
             return
-        self.total.backward()
+        torch.autograd.backward(self.total, grad_tensors=self._root_grad(self.total))
         if part == 'fwd_bwd':
             self.flat_parts = [self.optimizer.gather_grads(accumulate=self.accum_steps > 1)]
             return
@@ -919,7 +933,8 @@ class GraphedSemiStep(_GraphedBase):
             self.x_lab.copy_(xt[self.ml], non_blocking=True)
             self.x_stu.copy_(xs[self.mu], non_blocking=True)
             self.tab_l.load(targets[self.ml])
-        self.runtime.bump_seed(self.dev)
+        if self._host_bump:
+            self.runtime.bump_seed(self.dev)
         self._before_replay()
         self.graph.replay()
         if self.g_opt is not None:

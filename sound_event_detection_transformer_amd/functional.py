@@ -106,6 +106,97 @@ class LinearFn(Function):
         return gx, gw, gb, None, None, None, None
 
 
+class HeadsFn(Function):
+    """the prediction heads on the stacked decoder output hs [L,B,Qp,d] (reference sedt.py:88-95): class_embed on every row,
+    bbox_embed (3-layer MLP + sigmoid) on every row, and - dec_at - weak_class_embed + sigmoid on query 0 of the last layer,
+    as ONE autograd node.  hs has three consumers; as separate nodes their input gradients are summed by autograd (two
+    elementwise launches) and the slices hs[-1, :, 0] / outputs[:, :, 1:] cost copy / fill launches in both directions.  Here the
+    audio-tag head reads its rows strided, the outputs keep all Qp rows (the criterion kernels take the query window as (q0, Q)),
+    and the backward builds ONE dhs: class head writes it, the box MLP's last dgrad adds through the GEMM epilogue's residual
+    operand, the audio-tag head accumulates into its rows.
+    Returns (class logits [L,B,Qp,C+1] f32, boxes [L,B,Qp,2] f32, at [B,C] f32 or None)."""
+
+    @staticmethod
+    def forward(ctx, hs, wc, bc, w1, b1, w2, b2, w3, b3, wa, ba, dt):
+        Lh, B, Qp, d = hs.shape
+        x = _as(hs, dt).view(Lh * B * Qp, d)
+        tr = any(ctx.needs_input_grad)
+        cls = ops.skinny_linear_fwd(dt, x, wc, bc, ACT_NONE, True)
+        w1f, w1b = _prep_linear(dt, w1, tr)
+        w2f, w2b = _prep_linear(dt, w2, tr)
+        h1 = ops.linear(dt, x, w1f, bias=b1, act=ACT_RELU)
+        h2 = ops.linear(dt, h1, w2f, bias=b2, act=ACT_RELU)
+        box = ops.skinny_linear_fwd(dt, h2, w3, b3, ACT_SIGMOID, True)
+        at = None
+        if wa is not None:
+            xa = x.view(Lh, B, Qp, d)[Lh - 1, :, 0, :]                       # [B, d] rows Qp*d apart: no copy
+            at = ops.skinny_linear_fwd(dt, xa, wa, ba, ACT_SIGMOID, True)
+        ctx.dt, ctx.dims, ctx.wb = dt, (Lh, B, Qp, d), (w1b, w2b)
+        ctx.has_at = wa is not None
+        ctx.save_for_backward(x, h1, h2, box, at, wc, w3, wa)
+        cls, box = cls.view(Lh, B, Qp, -1), box.view(Lh, B, Qp, 2)
+        return (cls, box, at) if at is not None else (cls, box)
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box, g_at=None):
+        x, h1, h2, box, at, wc, w3, wa = ctx.saved_tensors
+        dt = ctx.dt
+        Lh, B, Qp, d = ctx.dims
+        w1b, w2b = ctx.wb
+        M = Lh * B * Qp
+        f32 = lambda t: t.contiguous() if t.dtype == torch.float32 else t.contiguous().float()
+        # class head: writes the running input gradient
+        dhs, d_wc, d_bc = ops.skinny_linear_bwd(dt, f32(g_cls).view(M, -1), None, wc, x, ACT_NONE)
+        # box MLP: sigmoid' and the ReLU masks ride in the kernels; the last dgrad adds the running gradient (epilogue residual)
+        g_h2, d_w3, d_b3 = ops.skinny_linear_bwd(dt, f32(g_box).view(M, 2), box.view(M, 2), w3, h2, ACT_SIGMOID, mask=h2)
+        rb = ops.ReduceBatch()
+        d_b2 = torch.empty((g_h2.shape[1],), device=x.device, dtype=torch.float32)
+        d_w2 = ops.linear_wgrad(dt, g_h2, h1, bias_out=d_b2, batch=rb)
+        g_h1 = ops.linear(dt, g_h2, w2b, mask=h1, ldm=h1.stride(0))
+        d_b1 = torch.empty((g_h1.shape[1],), device=x.device, dtype=torch.float32)
+        d_w1 = ops.linear_wgrad(dt, g_h1, x, bias_out=d_b1, batch=rb)
+        dhs = ops.linear(dt, g_h1, w1b, res=dhs, ldr=dhs.stride(0))
+        d_wa = d_ba = None
+        if ctx.has_at:
+            xa = x.view(Lh, B, Qp, d)[Lh - 1, :, 0, :]
+            if g_at is None:
+                d_wa, d_ba = torch.zeros_like(wa), torch.zeros(wa.shape[0], device=wa.device)
+            else:
+                ga = f32(g_at).view(B, -1)
+                _, d_wa, d_ba = ops.skinny_linear_bwd(dt, ga, at.view(B, -1), wa, xa, ACT_SIGMOID,
+                                                      gx_acc=dhs.view(Lh, B, Qp, d)[Lh - 1, :, 0, :])
+        rb.flush()
+        return (dhs.view(Lh, B, Qp, d), d_wc, d_bc, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_wa, d_ba, None)
+
+
+class GradAccumulator(object):
+    """side channel for a tensor that several autograd nodes of one chain consume (the decoder layers all read the encoder
+    memory and the query position embedding): instead of each node returning its share - which autograd then adds pair by pair,
+    one elementwise launch per pair - the nodes hand their shares over here as they run (backward order is the reverse of the
+    forward order, so it is deterministic); every node but the LAST to run returns None for that input, and the last one returns
+    the total: folded through GEMM epilogues (``pending`` = a running sum the next producing GEMM takes as its residual operand)
+    or summed in one launch (``parts``)."""
+
+    def __init__(self, n_nodes):
+        self.n, self.seen, self.pending, self.parts = n_nodes, 0, None, []
+
+    def last(self):
+        """call once per node, in its backward; True for the node that must return the total"""
+        self.seen += 1
+        done = self.seen == self.n
+        if done:
+            self.seen = 0
+        return done
+
+    def take_parts(self):
+        p, self.parts = self.parts, []
+        return p
+
+    def take_pending(self):
+        p, self.pending = self.pending, None
+        return p
+
+
 class LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, dt):
@@ -211,7 +302,8 @@ def _drop_args(s, device):
     return (p, s['seeds'][1], runtime.seed_ptr(device) if p > 0 else None)
 
 
-def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, batch=None, g_dropped=None, kv_fused=False):
+def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, batch=None, g_dropped=None, kv_fused=False,
+             res_kv=None):
     """g_out = grad wrt the block output (the residual branch is the caller's business); g_dropped = the same gradient
     already through the output dropout (ops.layernorm_bwd(drop=...)).
     returns g_q_in, g_k_in, g_v_in, d_in_proj_weight, d_in_proj_bias, d_out_w, d_out_b"""
@@ -260,11 +352,13 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, b
             dgrads.append(('k', dk, wb[:, E:2 * E]))
     ops.linear_wgrad(dt, dv, s['v_in'], out=d_win[2 * E:], bias_out=d_bin[2 * E:], batch=batch)
     if kv_fused and not s['same_qk']:
-        dgrads.append(('v', dkv, wb[:, E:]))              # grad wrt the shared key/value source, returned in the value slot
+        # grad wrt the shared key/value source, returned in the value slot; res_kv: the running sum of the other consumers'
+        # shares of that source's gradient, added in the GEMM epilogue
+        dgrads.append(('v', dkv, wb[:, E:], {} if res_kv is None else dict(res=res_kv, ldr=res_kv.stride(0))))
     elif need_v:
         dgrads.append(('v', dv, wb[:, 2 * E:]))
     if dgrads:
-        got = dict(zip([n for n, _, _ in dgrads], ops.linear_group(dt, [(g, w, {}) for _, g, w in dgrads])))
+        got = dict(zip([d[0] for d in dgrads], ops.linear_group(dt, [(d[1], d[2], dict(d[3]) if len(d) > 3 else {}) for d in dgrads])))
         g_q, g_k, g_v = got.get('q'), got.get('k'), got.get('v')
     return g_q, g_k, g_v, d_win, d_bin, d_wo, d_bo
 
@@ -423,8 +517,11 @@ class DecoderLayerFn(Function):
             g_t2n, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], gt3, w1, w2, batch=rb)
             gt2, d_g3, d_be3, gt2d = ops.layernorm_bwd(dt, g_t2n, sv['t2'], g3, sv['m3'], sv['r3'], dres=gt3, batch=rb,
                                                        drop=_drop_args(sv['ca'], gt3.device))
-            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], gt2, cw_in, cw_o, batch=rb, g_dropped=gt2d,
-                                                                   kv_fused=cfg.get('kv_fused', False))
+            kvf = cfg.get('kv_fused', False)
+            acc_m = cfg.get('acc_mem') if kvf else None
+            acc_q = cfg.get('acc_qpos')
+            g_q, g_k, g_v, d_cwin, d_cbin, d_cwo, d_cbo = _mha_bwd(dt, sv['ca'], gt2, cw_in, cw_o, batch=rb, g_dropped=gt2d, kv_fused=kvf,
+                                                                   res_kv=None if acc_m is None else acc_m.take_pending())
             # LN2 outputs: t1n (unused on its own) and t1n + qpos (cross-attn query)
             gt1, d_g2, d_be2, gt1d = ops.layernorm_bwd(dt, g_q, sv['t1'], g2, sv['m2'], sv['r2'], dres=gt2, batch=rb,
                                                        drop=_drop_args(sv['sa'], gt3.device))
@@ -432,7 +529,13 @@ class DecoderLayerFn(Function):
             g_mem_pos, g_mem = g_k, g_v
             g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], gt1, sw_in, sw_o, batch=rb, g_dropped=gt1d)
             gtgt, d_g1, d_be1 = ops.layernorm_bwd(dt, g_vs, sv['tgt'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gt1, batch=rb)
-            g_qpos = ops.add(dt, g_qpos, g_qk)
+            if acc_m is not None and not acc_m.last():       # memory's gradient: handed on as the next layer's GEMM residual
+                acc_m.pending, g_mem = g_mem, None
+            if acc_q is not None:                            # qpos' gradient: two shares per layer, ONE sum at the end
+                acc_q.parts += [g_q, g_qk]
+                g_qpos = ops.add_n(dt, acc_q.take_parts()) if acc_q.last() else None
+            else:
+                g_qpos = ops.add(dt, g_qpos, g_qk)
         else:
             dev = gt3.device
             g_f, d_g3, d_be3, g_fd = ops.layernorm_bwd(dt, gt3, sv['f'], g3, sv['m3'], sv['r3'], batch=rb,

@@ -52,7 +52,8 @@ class SedtCriterion(C.Structure):
                [(n, C.c_int32) for n in ('L', 'B', 'ns', 'Q', 'C', 'n_lab', 'Bat')] + \
                [('layer_of', C.c_int32 * CRIT_MAXL), ('w_ce', C.c_float * CRIT_MAXL), ('w_bbox', C.c_float * CRIT_MAXL),
                 ('w_giou', C.c_float * CRIT_MAXL), ('w_weak', C.c_float), ('fl', C.c_int32), ('alpha_fl', C.c_float),
-                ('gamma_fl', C.c_float), ('nonfinite', C.c_void_p), ('split', C.c_void_p)]
+                ('gamma_fl', C.c_float), ('nonfinite', C.c_void_p), ('split', C.c_void_p), ('Qs', C.c_int32), ('q0', C.c_int32),
+                ('total', C.c_void_p)]
 
 
 class SedtMatch(C.Structure):
@@ -62,7 +63,7 @@ class SedtMatch(C.Structure):
                [('layer_of', C.c_int32 * CRIT_MAXL), ('w_class', C.c_float), ('w_bbox', C.c_float), ('w_giou', C.c_float),
                 ('fl', C.c_int32), ('fine_tune', C.c_int32), ('normalize', C.c_int32), ('alpha_fl', C.c_float),
                 ('gamma_fl', C.c_float), ('epsilon', C.c_float), ('alpha', C.c_float), ('ft_rand', C.c_void_p),
-                ('ft_seed', C.c_uint32), ('seed_ptr', C.c_void_p), ('split', C.c_void_p)]
+                ('ft_seed', C.c_uint32), ('seed_ptr', C.c_void_p), ('split', C.c_void_p), ('Qs', C.c_int32), ('q0', C.c_int32)]
 
 
 MAX_REDUCE_JOBS = 40
@@ -82,11 +83,12 @@ SIGNATURES = {
     'sedt_multi_wgrad_reduce': (_i, [C.POINTER(SedtReduceJob), _i, _vp]),
     'sedt_skinny_linear_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     'sedt_skinny_linear_bwd_scratch': (_sz, [_i]),
-    'sedt_skinny_linear_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'sedt_skinny_linear_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'sedt_colsum': (_i, [_vp, _i64, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'sedt_colsum_scratch': (_sz, [_i, _i]),
     'sedt_dropout_grad': (_i, [_vp, _i64, _vp, _i64, _i, _i, _f, _u32, _vp, _i, _vp]),
     'sedt_add': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'sedt_add_n': (_i, [C.POINTER(C.c_void_p), _i, _vp, _i64, _i, _vp]),
     'sedt_cast': (_i, [_vp, _i, _vp, _i, _i64, _vp]),
     'sedt_relu_mask': (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     'sedt_sigmoid_grad': (_i, [_vp, _vp, _vp, _i64, _vp]),
@@ -122,10 +124,10 @@ SIGNATURES = {
     'sedt_multi_pack': (_i, [_vp, _i, _i, _i, _vp]),
     'sedt_multi_gather': (_i, [_vp, _i, _i, _vp]),
     'sedt_multi_ema': (_i, [_vp, _i, _f, _vp, _vp]),
-    'sedt_multi_sumsq': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    'sedt_multi_sumsq': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'sedt_multi_adamw': (_i, [_vp, _i, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
     'sedt_set_criterion': (_i, [C.POINTER(SedtCriterion), _vp]),
-    'sedt_set_criterion_bwd': (_i, [C.POINTER(SedtCriterion), _vp, _vp, _vp, _vp, _vp]),
+    'sedt_set_criterion_bwd': (_i, [C.POINTER(SedtCriterion), _vp, _vp, _vp, _vp, _vp, _vp]),
     'sedt_match_targets': (_i, [C.POINTER(SedtMatch), _vp]),
     'sedt_feature_loss': (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'sedt_scale_layers': (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i64, _vp]),

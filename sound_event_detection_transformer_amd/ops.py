@@ -199,19 +199,25 @@ def skinny_linear_fwd(dtype, x, w, bias=None, act=ACT_NONE, out_f32=False):
     return y
 
 
-def skinny_linear_bwd(dtype, g, ysaved, w, x, act=ACT_NONE, mask=None, need_gx=True, need_gw=True, need_gb=True):
-    """(gx, dW, db) of skinny_linear_fwd; g f32 [M,N]; ysaved = the f32 output when act != NONE"""
+def skinny_linear_bwd(dtype, g, ysaved, w, x, act=ACT_NONE, mask=None, need_gx=True, need_gw=True, need_gb=True, gx_acc=None):
+    """(gx, dW, db) of skinny_linear_fwd; g f32 [M,N]; ysaved = the f32 output when act != NONE.  x may be a strided row view
+    (stride(1) == 1).  gx_acc: a [M,K] (row-strided) view the input gradient is ADDED to instead of a fresh gx."""
     M, K = x.shape
     N = w.shape[0]
     assert g.dtype == torch.float32 and g.is_contiguous() and (ysaved is None or (ysaved.dtype == torch.float32 and ysaved.is_contiguous()))
-    gx = torch.empty((M, K), device=x.device, dtype=TORCH_DTYPE[dtype]) if need_gx else None
+    assert x.stride(1) == 1
+    if gx_acc is not None:
+        assert gx_acc.shape == (M, K) and gx_acc.stride(1) == 1 and gx_acc.dtype == TORCH_DTYPE[dtype] and mask is None
+        gx = gx_acc
+    else:
+        gx = torch.empty((M, K), device=x.device, dtype=TORCH_DTYPE[dtype]) if need_gx else None
     dw = torch.empty((N, K), device=x.device, dtype=torch.float32) if need_gw else None
     db = torch.empty((N,), device=x.device, dtype=torch.float32) if (need_gb and need_gw) else None
     lib = L.load()
     scratch = torch.empty((lib.sedt_skinny_linear_bwd_scratch(K) // 4,), device=x.device, dtype=torch.float32) if need_gw else None
     L.check(lib.sedt_skinny_linear_bwd(_p(g), _p(ysaved), g.stride(0), _p(w), _p(x), x.stride(0), _p(mask),
-                                       mask.stride(0) if mask is not None else 0, _p(gx), K, _p(dw), _p(db), _p(scratch), M, N, K, act,
-                                       dtype, L.stream_ptr()), 'skinny_linear_bwd')
+                                       mask.stride(0) if mask is not None else 0, _p(gx), gx.stride(0) if gx is not None else K, _p(dw), _p(db),
+                                       _p(scratch), M, N, K, act, int(gx_acc is not None), dtype, L.stream_ptr()), 'skinny_linear_bwd')
     if need_gb and not need_gw:
         db = g.sum(0) if act == ACT_NONE else (g * ysaved * (1 - ysaved)).sum(0) if act == ACT_SIGMOID else (g * (ysaved > 0)).sum(0)
     return gx, dw, db
@@ -438,6 +444,18 @@ def add(dtype, a, b, b_mod=0, out=None):
     if out is None:
         out = torch.empty_like(a)
     L.check(L.load().sedt_add(_p(a), _p(b), _p(out), rows, cols, b_mod, dtype, L.stream_ptr()), 'add')
+    return out
+
+
+def add_n(dtype, tensors, out=None):
+    """sum of up to 8 equally shaped contiguous tensors of the compute dtype in one launch"""
+    _dev_check(*tensors)
+    n = len(tensors)
+    assert 1 <= n <= 8 and all(t.shape == tensors[0].shape and t.dtype == TORCH_DTYPE[dtype] and t.is_contiguous() for t in tensors)
+    if out is None:
+        out = torch.empty_like(tensors[0])
+    arr = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    L.check(L.load().sedt_add_n(arr, n, _p(out), tensors[0].numel(), dtype, L.stream_ptr()), 'add_n')
     return out
 
 
@@ -692,27 +710,30 @@ def adamw_clip(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, weight_deca
 
 
 def set_criterion(logits, boxes, at, dense, empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak, fl=False, alpha_fl=0.5,
-                  gamma_fl=1.0, nonfinite=None):
-    """device half of SetCriterion in one launch (csrc/criterion.hip).  logits [L,B,Q,C+1], boxes [L,B,Q,2], at [Bat,C] or
-    None - all f32 contiguous; dense = SetCriterion.dense_views(...).  fl: the focal-loss variant (sedt.py:176, 211-218).
-    nonfinite: optional int32 device word set to 1 when the weighted total is NaN/inf.  Returns (out[4L+5], state); state
-    feeds set_criterion_bwd."""
+                  gamma_fl=1.0, nonfinite=None, q0=0):
+    """device half of SetCriterion in one launch (csrc/criterion.hip).  logits [L,B,Qs,C+1], boxes [L,B,Qs,2] (the Q queries
+    q0 .. q0+Q-1 of every clip take part, Q from the dense targets), at [Bat,C] or None - all f32 contiguous; dense =
+    SetCriterion.dense_views(...).  fl: the focal-loss variant (sedt.py:176, 211-218).  nonfinite: optional int32 device word set
+    to 1 when the weighted total is NaN/inf.  Returns (out[4L+5], total scalar, state); state feeds set_criterion_bwd."""
     _dev_check(logits, boxes)
-    Lh, B, Q, C1 = logits.shape
+    Lh, B, Qs, C1 = logits.shape
+    Q = dense['tc'].shape[2]
     assert logits.dtype == torch.float32 and boxes.dtype == torch.float32 and logits.is_contiguous() and boxes.is_contiguous()
-    assert boxes.shape == (Lh, B, Q, 2) and Lh <= L.CRIT_MAXL and len(layer_of) == Lh
+    assert boxes.shape == (Lh, B, Qs, 2) and Lh <= L.CRIT_MAXL and len(layer_of) == Lh and 0 <= q0 and q0 + Q <= Qs
     a = L.SedtCriterion()
-    dl, db, db2 = torch.empty_like(logits), torch.empty_like(boxes), torch.empty_like(boxes)
+    dl = torch.empty((Lh, B, Q, C1), device=logits.device, dtype=torch.float32)
+    db, db2 = torch.empty((Lh, B, Q, 2), device=logits.device, dtype=torch.float32), torch.empty((Lh, B, Q, 2), device=logits.device, dtype=torch.float32)
     dat = None
     out = torch.empty(4 * Lh + 5, device=logits.device, dtype=torch.float32)
-    a.logits, a.boxes, a.out = logits.data_ptr(), boxes.data_ptr(), out.data_ptr()
+    total = torch.empty((), device=logits.device, dtype=torch.float32)
+    a.logits, a.boxes, a.out, a.total = logits.data_ptr(), boxes.data_ptr(), out.data_ptr(), total.data_ptr()
     a.dlogits, a.dboxes, a.dboxes2 = dl.data_ptr(), db.data_ptr(), db2.data_ptr()
     for k in ('tc', 'coef', 'wbox', 'tbox', 'tgt_len'):
         setattr(a, k, dense[k].data_ptr())
     if dense.get('num_boxes') is not None:          # None: the kernel sums the final layer's box weights itself
         a.num_boxes = dense['num_boxes'].data_ptr()
     a.empty_weight = empty_weight.data_ptr()
-    a.L, a.B, a.ns, a.Q, a.C, a.n_lab = Lh, B, dense['ns'], Q, C1 - 1, dense['n_lab']
+    a.L, a.B, a.ns, a.Q, a.C, a.n_lab, a.Qs, a.q0 = Lh, B, dense['ns'], Q, C1 - 1, dense['n_lab'], Qs, q0
     assert dense['tgt_len'].numel() == B and dense['L'] == Lh and empty_weight.is_cuda and empty_weight.numel() == C1
     if at is not None:
         assert at.dtype == torch.float32 and at.is_contiguous() and at.dim() == 2 and at.shape[1] == C1 - 1
@@ -730,29 +751,34 @@ def set_criterion(logits, boxes, at, dense, empty_weight, layer_of, w_ce, w_bbox
         assert dense['split'].dtype == torch.int32 and dense['split'].is_cuda and dense['split'].numel() >= 2
         a.split = dense['split'].data_ptr()
     L.check(L.load().sedt_set_criterion(a, L.stream_ptr()), 'set_criterion')
-    return out, (a, dl, db, db2, dat)
+    return out, total, (a, dl, db, db2, dat, (Lh, B, Qs, C1))
 
 
-def set_criterion_bwd(state, g):
-    """gradients of (logits, boxes, at) given the gradient g[4L+5] of the loss vector"""
-    a, dl, db, db2, dat = state
-    g = g.contiguous().float()
-    gl, gb = torch.empty_like(dl), torch.empty_like(db)
+def set_criterion_bwd(state, g, gtotal=None):
+    """gradients of (logits, boxes, at) - in the layout of the head outputs, zero rows for queries outside the window - given the
+    gradient g[4L+5] of the loss vector and / or the gradient of the separately returned total (either may be None)"""
+    a, dl, db, db2, dat, (Lh, B, Qs, C1) = state
+    g = None if g is None else g.contiguous().float()
+    gtotal = None if gtotal is None else gtotal.contiguous().float()
+    gl = torch.empty((Lh, B, Qs, C1), device=dl.device, dtype=torch.float32)
+    gb = torch.empty((Lh, B, Qs, 2), device=dl.device, dtype=torch.float32)
     gat = None if dat is None else torch.empty_like(dat)
-    L.check(L.load().sedt_set_criterion_bwd(a, _p(g), _p(gl), _p(gb), _p(gat), L.stream_ptr()), 'set_criterion_bwd')
+    L.check(L.load().sedt_set_criterion_bwd(a, _p(g), _p(gtotal), _p(gl), _p(gb), _p(gat), L.stream_ptr()), 'set_criterion_bwd')
     return gl, gb, gat
 
 
 def match_targets(logits, boxes, tables, dense, layer_of, w_class, w_bbox, w_giou, max_targets, assign=None, fl=False,
                   fine_tune=False, normalize=False, epsilon=1.0, alpha=1.0, alpha_fl=0.5, gamma_fl=1.0, ft_rand=None, ft_seed=0,
-                  seed_ptr=None):
+                  seed_ptr=None, q0=0):
     """device-side Hungarian matching + dense targets in one launch (csrc/criterion.hip).  tables: dict with lab_cat (int64),
     lab_off (int32 [B+1]), box_cat (f32 [N,2]), box_off (int32 [ns+1]), ratio_cat (f32 or None); dense: the views of
     SetCriterion.dense_views, written in place.  fl / fine_tune / normalize: the matcher variants of matcher.py:73-78,
     99-121, 124-132 (ft_rand [ns,Q] f32 injects the uniforms of the fine-tune branch; else a counter hash of ft_seed)."""
     _dev_check(logits, boxes)
-    Lh, B, Q, C1 = logits.shape
+    Lh, B, Qs, C1 = logits.shape
+    Q = dense['tc'].shape[2]                        # queries q0 .. q0+Q-1 of the Qs head rows per clip are matched
     assert logits.dtype == torch.float32 and boxes.dtype == torch.float32 and logits.is_contiguous() and boxes.is_contiguous()
+    assert 0 <= q0 and q0 + Q <= Qs
     a = L.SedtMatch()
     a.logits, a.boxes = logits.data_ptr(), boxes.data_ptr()
     assert tables['lab_cat'].dtype == torch.int64 and tables['lab_off'].dtype == torch.int32 and tables['box_off'].dtype == torch.int32
@@ -770,7 +796,7 @@ def match_targets(logits, boxes, tables, dense, layer_of, w_class, w_bbox, w_gio
     if assign is not None:
         assert assign.dtype == torch.int32 and assign.numel() == Lh * dense['ns'] * Q
         a.assign = assign.data_ptr()
-    a.L, a.B, a.ns, a.Q, a.C, a.n_lab, a.max_targets = Lh, B, dense['ns'], Q, C1 - 1, dense['n_lab'], max_targets
+    a.L, a.B, a.ns, a.Q, a.C, a.n_lab, a.max_targets, a.Qs, a.q0 = Lh, B, dense['ns'], Q, C1 - 1, dense['n_lab'], max_targets, Qs, q0
     assert dense['L'] == Lh and dense['tgt_len'].numel() == B
     for i in range(Lh):
         a.layer_of[i] = layer_of[i]

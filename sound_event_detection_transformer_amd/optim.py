@@ -23,6 +23,9 @@ class FusedAdamW(torch.optim.Optimizer):
         # optional device int32 word (engine's graphed steppers: the criterion's non-finite flag): while it is non-zero the
         # update kernels leave parameters, moments and the step count alone (include/sedt_hip.h "Non-finite guard")
         self.guard = None
+        # optional device word (runtime.seed_ptr): the dropout-seed word advanced by the step itself (engine's graphed steppers:
+        # saves the host-side increment launch per replay)
+        self.seed_word = None
 
     def set_segments(self, segments):
         """lay the flat state / gradient buffers out as consecutive SEGMENTS: segments[k] = the parameters whose gradients the
@@ -187,7 +190,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if hi > lo:
             isz = _DT.itemsize
             self._host_gtab.numpy()[lo * isz:hi * isz] = t[lo:hi].view(np.uint8)
-            self._dev_gtab[lo * isz:hi * isz].copy_(self._host_gtab[lo * isz:hi * isz], non_blocking=True)
+            self._upload(self._dev_gtab[lo * isz:hi * isz], self._host_gtab[lo * isz:hi * isz])
             mode = (1 if accumulate else 0) | (2 if self._flat_dtype == torch.bfloat16 else 0)
             L.check(L.load().sedt_multi_gather(L.p(self._dev_gtab[lo * isz:]), hi - lo, mode, L.stream_ptr()), 'multi_gather')
         return view
@@ -221,18 +224,36 @@ class FusedAdamW(torch.optim.Optimizer):
         t['wd'] = wds[self._gi][self._owner]
         self._host_tab.numpy()[:] = t.view(np.uint8)
         self._sets[self._tabset]['hyper'] = (lrs.tobytes(), wds.tobytes())
-        self._dev_tab.copy_(self._host_tab, non_blocking=True)
+        self._upload(self._dev_tab, self._host_tab)
         self._step += 1
         lib = L.load()
         g0 = self.param_groups[0]
         n = len(t)
         if max_norm > 0:       # the norm's final reduction also advances the device-side step count (unless the guard is up)
             L.check(lib.sedt_multi_sumsq(L.p(self._dev_tab), n, L.p(self._partial), L.p(self._sumsq), L.p(self._step_t),
-                                         L.p(self.guard), L.stream_ptr()), 'multi_sumsq')
+                                         L.p(self.guard), L.p(self.seed_word), L.stream_ptr()), 'multi_sumsq')
         else:
             self._step_t.add_(1)
         L.check(lib.sedt_multi_adamw(L.p(self._dev_tab), n, L.p(self._sumsq), float(max_norm), g0['betas'][0], g0['betas'][1],
                                      g0['eps'], L.p(self._step_t), L.p(self.guard), L.stream_ptr()), 'multi_adamw')
+
+    def _upload(self, dev, host):
+        """pinned chunk table -> device.  While a HIP graph is being captured the copy is NOT recorded (it would be replayed with
+        every step: one more node in front of the optimizer kernels for a table that only changes when a learning rate does):
+        it is queued and ``flush_uploads`` - which the capturing stepper calls right after the capture - performs it once."""
+        if dev.is_cuda and torch.cuda.is_current_stream_capturing():
+            self.__dict__.setdefault('_deferred', []).append((dev, host))
+        else:
+            dev.copy_(host, non_blocking=True)
+
+    def flush_uploads(self):
+        """perform the table uploads queued during a capture (see _upload); returns how many"""
+        q, self._deferred = self.__dict__.get('_deferred', []), []
+        for dev, host in q:
+            dev.copy_(host, non_blocking=True)
+        if q:
+            torch.cuda.synchronize(self._dev)
+        return len(q)
 
     def refresh_hyperparams(self, name=None):
         """re-read lr / weight_decay of the param groups into the pinned chunk table of set ``name`` (a captured graph
@@ -253,6 +274,7 @@ class FusedAdamW(torch.optim.Optimizer):
         tab['lr'] = lrs[self._gi][self._owner]
         tab['wd'] = wds[self._gi][self._owner]
         st['hyper'] = key
+        st['dev'].copy_(st['host'], non_blocking=True)       # (a captured step no longer uploads its table itself: _upload)
         return True
 
     # ---- checkpointing in torch.optim.AdamW's layout (reference train_sedt.py:272-283, 318-320 saves / restores it)

@@ -9,7 +9,7 @@ from torch import nn
 
 from .. import functional as Fn
 from .. import ops, runtime
-from ..utilities.utils import NestedTensor
+from ..utilities.utils import NestedTensor, derived_from_static_mask
 from .position_encoding import build_position_encoding
 
 
@@ -136,7 +136,8 @@ class BackboneBase(nn.Module):
             x = self.body(tensor_list.tensors)
             m = tensor_list.mask
             assert m is not None
-            mask = ops.mask_resize(m.contiguous().view(torch.uint8), x.shape[-2], x.shape[-1]).view(torch.bool)
+            mask = derived_from_static_mask(m, ('resize', x.shape[-2], x.shape[-1]),
+                                            lambda: ops.mask_resize(m.contiguous().view(torch.uint8), x.shape[-2], x.shape[-1]).view(torch.bool))
             return {'0': NestedTensor(x, mask)}
         return {'0': self.body(tensor_list)}
 

@@ -5,7 +5,7 @@ import torch
 from torch import nn
 
 from .. import ops, runtime
-from ..utilities.utils import NestedTensor
+from ..utilities.utils import NestedTensor, derived_from_static_mask
 
 
 class PositionEmbeddingSine(nn.Module):
@@ -24,7 +24,9 @@ class PositionEmbeddingSine(nn.Module):
         mask = tensor_list.mask
         assert mask is not None
         B, H, W = mask.shape
-        pos = ops.posenc(runtime.compute_dtype(), mask.contiguous().view(torch.uint8), self.num_pos_feats)   # (B, H*W, D)
+        dt = runtime.compute_dtype()
+        pos = derived_from_static_mask(mask, ('posenc', dt, self.num_pos_feats),
+                                       lambda: ops.posenc(dt, mask.contiguous().view(torch.uint8), self.num_pos_feats))   # (B, H*W, D)
         return pos.view(B, H, W, self.num_pos_feats).permute(0, 3, 1, 2)
 
 

@@ -126,21 +126,24 @@ class SEDT(nn.Module):
         assert mask is not None
         out = {}
         hs, memory = self.transformer(self.input_proj(src), mask, self.query_embed.weight, pos[-1], enc_at_embed=None)
+        # all heads as ONE autograd node over the stacked decoder output (functional.HeadsFn): they run over ALL query rows - with
+        # dec_at query 0 is the audio-tag query - and the event outputs are views of rows q0..; the criterion kernels take the
+        # full tensors plus the window (q0, Q), so no slice is ever materialised in either direction
+        q0 = 1 if self.dec_at else 0
+        b = self.bbox_embed.layers
+        wa = (self.weak_class_embed.weight, self.weak_class_embed.bias) if self.dec_at else (None, None)
+        res = Fn.HeadsFn.apply(hs, self.class_embed.weight, self.class_embed.bias, b[0].weight, b[0].bias, b[1].weight, b[1].bias,
+                               b[2].weight, b[2].bias, wa[0], wa[1], runtime.compute_dtype())
+        cls_full, box_full = res[0], res[1]
+        outputs_class, outputs_coord = cls_full[:, :, q0:, :], box_full[:, :, q0:, :]
         if self.dec_at:
-            # the heads run over ALL Q+1 queries and the (tiny, f32) outputs are sliced - slicing hs[:, :, 1:] first costs a
-            # strided copy of the activations forward and a scatter backward; query 0's event outputs are simply unused
-            outputs_class = self.class_embed(hs, out_f32=True)[:, :, 1:, :]
-            outputs_coord = self.bbox_embed(hs, final_act=ACT_SIGMOID, out_f32=True)[:, :, 1:, :]
-            at = self.weak_class_embed(hs[-1, :, 0, :], act=ACT_SIGMOID, out_f32=True).squeeze()
-            out['at'] = at
-        else:
-            outputs_class = self.class_embed(hs, out_f32=True)
-            outputs_coord = self.bbox_embed(hs, final_act=ACT_SIGMOID, out_f32=True)
+            out['at'] = res[2].squeeze()
         out['pred_logits'] = outputs_class[-1]
         out['pred_boxes'] = outputs_coord[-1]
         if self.aux_loss:
             out['aux_outputs'] = self._set_aux_loss(outputs_class, outputs_coord)
-            out['_stacked'] = (outputs_class, outputs_coord)      # all decoder layers, for the fused criterion kernel
+            out['_stacked'] = (cls_full, box_full)          # all decoder layers and all query rows, for the fused criterion kernels
+            out['_q0'] = q0
         return out
 
     def _set_aux_loss(self, outputs_class, outputs_coord):
@@ -159,7 +162,9 @@ class TargetTables(object):
     """The targets of one batch as the flat device tables the matching kernel reads (include/sedt_hip.h, SedtMatch):
     labels / boxes / ratios concatenated over the clips plus int32 offset tables.  Buffers are allocated once with a
     fixed capacity (max_targets per clip), so a captured HIP graph can keep reading them while ``load`` refreshes their
-    contents for every batch with asynchronous copies only (offsets travel through a small ring of pinned buffers)."""
+    contents for every batch.  All tables are views of ONE device buffer: host-resident targets (what a loader yields) are
+    laid out in a pinned staging buffer and travel in ONE asynchronous host->device copy per batch; device-resident targets
+    are copied table by table."""
 
     def __init__(self, batch, ns, n_lab, device, max_targets=32, with_ratio=False, slots=4, dynamic_split=False):
         """ns / n_lab: number of strongly labelled / labelled clips.  dynamic_split=True: they are only the FIRST batch's values -
@@ -172,12 +177,22 @@ class TargetTables(object):
         self.ns, self.n_lab = (batch, batch) if self.dynamic else (ns, max(n_lab, ns))          # capacities = strides
         self.cur_ns, self.cur_n_lab = ns, max(n_lab, ns)
         ns = self.ns
-        self.lab_cat = torch.zeros(batch * max_targets, dtype=torch.int64, device=device)
-        self.box_cat = torch.zeros(max(ns, 1) * max_targets, 2, dtype=torch.float32, device=device)
-        self.ratio_cat = torch.ones(batch * max_targets, dtype=torch.float32, device=device) if with_ratio else None
-        self.off = torch.zeros(batch + ns + 2 + 2, dtype=torch.int32, device=device)            # lab_off | box_off | split
+        n_off = batch + ns + 4                                                                   # lab_off | box_off | split
+        n_lab_e, n_box_e = batch * max_targets, max(ns, 1) * max_targets
+        o_lab = (4 * n_off + 7) // 8 * 8
+        o_box = o_lab + 8 * n_lab_e
+        o_rat = o_box + 8 * n_box_e
+        total = o_rat + (4 * n_lab_e if with_ratio else 0)
+        self._lay = (n_off, o_lab, n_lab_e, o_box, n_box_e, o_rat, total)
+        self._blob = torch.zeros(total, dtype=torch.uint8, device=device)
+        self.off = self._blob[:4 * n_off].view(torch.int32)
+        self.lab_cat = self._blob[o_lab:o_box].view(torch.int64)
+        self.box_cat = self._blob[o_box:o_rat].view(torch.float32).view(n_box_e, 2)
+        self.ratio_cat = self._blob[o_rat:total].view(torch.float32) if with_ratio else None
+        if with_ratio:
+            self.ratio_cat.fill_(1.0)
         self.split = self.off[batch + ns + 2:] if self.dynamic else None
-        self._pin = [torch.zeros(batch + ns + 4, dtype=torch.int32).pin_memory() for _ in range(slots)] if device.type == 'cuda' else None
+        self._pin = [torch.zeros(total, dtype=torch.uint8).pin_memory() for _ in range(slots)] if device.type == 'cuda' else None
         self._ev = [None] * slots
         self._slot = 0
 
@@ -188,6 +203,7 @@ class TargetTables(object):
     @torch.no_grad()
     def load(self, targets, ns=None, n_lab=None):
         """ns / n_lab: this batch's split (dynamic_split tables only; default: the previous one)"""
+        import numpy as np
         B = self.B
         if len(targets) != B:
             raise ValueError(f'expected {B} clips, got {len(targets)}')
@@ -207,8 +223,8 @@ class TargetTables(object):
             raise ValueError(f'a clip has more than max_targets={self.max_targets} events')
         if any(nb > nl for nb, nl in zip(nbox, nlab)):
             raise ValueError('a strong clip has more boxes than labels')
-        k = self._slot
-        self._slot = (k + 1) % len(self._ev)
+        if self.ratio_cat is None and any('ratio' in t for t in targets):
+            raise ValueError('targets carry pseudo-label ratios: build TargetTables(with_ratio=True)')
         off = [0]
         for n in nlab:
             off.append(off[-1] + n)
@@ -217,26 +233,52 @@ class TargetTables(object):
             off.append(off[-1] + n)
         off += [off[-1]] * (self.ns - ns)                     # (dynamic split: clips beyond the strong part own no boxes)
         off += [self.cur_ns, self.cur_n_lab]
-        if self._pin is not None:
-            if self._ev[k] is not None:
-                self._ev[k].synchronize()                     # the copy that last used this pinned slot has long finished
-            self._pin[k].copy_(torch.tensor(off, dtype=torch.int32))
-            self.off.copy_(self._pin[k], non_blocking=True)
-            self._ev[k] = torch.cuda.Event()
-            self._ev[k].record()
-        else:
-            self.off.copy_(torch.tensor(off, dtype=torch.int32))
         nl, nb = sum(nlab), sum(nbox)
+        n_off, o_lab, n_lab_e, o_box, n_box_e, o_rat, total = self._lay
+        host = self._pin is not None and all(not t['labels'].is_cuda and not t['boxes'].is_cuda for t in targets)
+        if self._pin is None or host:
+            # ---- host-resident targets: lay the whole blob out on the host, ONE copy
+            k = self._slot
+            self._slot = (k + 1) % len(self._ev)
+            if self._pin is not None:
+                if self._ev[k] is not None:
+                    self._ev[k].synchronize()                 # the copy that last used this pinned slot has long finished
+                buf = self._pin[k].numpy()
+            else:
+                buf = np.zeros(total, np.uint8)
+            buf[:4 * n_off].view(np.int32)[:len(off)] = off
+            if nl:
+                buf[o_lab:o_lab + 8 * nl].view(np.int64)[:] = torch.cat([t['labels'].reshape(-1) for t in targets]).numpy()
+            if nb:
+                buf[o_box:o_box + 8 * nb].view(np.float32)[:] = torch.cat([targets[b]['boxes'].reshape(-1, 2).float() for b in range(ns)]).numpy().reshape(-1)
+            if self.ratio_cat is not None and nl:
+                buf[o_rat:o_rat + 4 * nl].view(np.float32)[:] = np.concatenate(
+                    [t['ratio'].detach().float().reshape(-1).cpu().numpy() if 'ratio' in t else np.ones(n, np.float32) for t, n in zip(targets, nlab)])
+            if self._pin is not None:
+                self._blob.copy_(self._pin[k], non_blocking=True)
+                self._ev[k] = torch.cuda.Event()
+                self._ev[k].record()
+            else:
+                self._blob.copy_(torch.from_numpy(buf))
+            return self
+        # ---- device-resident targets: table by table
+        k = self._slot
+        self._slot = (k + 1) % len(self._ev)
+        if self._ev[k] is not None:
+            self._ev[k].synchronize()
+        pin_off = self._pin[k][:4 * n_off].view(torch.int32)
+        pin_off[:len(off)].copy_(torch.tensor(off, dtype=torch.int32))
+        self.off.copy_(pin_off, non_blocking=True)
+        self._ev[k] = torch.cuda.Event()
+        self._ev[k].record()
         if nl:
             self.lab_cat[:nl].copy_(torch.cat([t['labels'].reshape(-1) for t in targets]), non_blocking=True)
         if nb:
             self.box_cat[:nb].copy_(torch.cat([targets[b]['boxes'].reshape(-1, 2).float() for b in range(ns)]), non_blocking=True)
         if self.ratio_cat is not None and nl:
-            src = targets[0]['labels'].device                 # host targets: ONE host->device copy for the whole table
+            src = targets[0]['labels'].device
             self.ratio_cat[:nl].copy_(torch.cat([t['ratio'].detach().float().reshape(-1).to(src) if 'ratio' in t else
                                                  torch.ones(n, device=src) for t, n in zip(targets, nlab)]), non_blocking=True)
-        elif any('ratio' in t for t in targets):
-            raise ValueError('targets carry pseudo-label ratios: build TargetTables(with_ratio=True)')
         return self
 
 
@@ -244,25 +286,26 @@ ALPHA_FL, GAMMA_FL = 0.5, 1.0          # reference config.py:71-72 (focal-loss c
 
 
 class _CriterionFn(torch.autograd.Function):
-    """autograd node around ops.set_criterion / set_criterion_bwd: forward computes the loss vector and every per-term
-    gradient; backward combines them with the gradient that reached the vector (weighted total and/or single entries)."""
+    """autograd node around ops.set_criterion / set_criterion_bwd: forward computes the loss vector, the weighted total as a
+    scalar of its own and every per-term gradient; backward combines them with the gradients that reached the vector (single
+    entries, e.g. a caller's own ``sum(loss_dict[k] * weight_dict[k])``) and / or the total."""
 
     @staticmethod
-    def forward(ctx, logits_all, boxes_all, at, dense, empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak, fl, nonfinite):
+    def forward(ctx, logits_all, boxes_all, at, dense, empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak, fl, nonfinite, q0):
         from .. import ops
-        out, ctx.state = ops.set_criterion(logits_all.detach().float().contiguous(), boxes_all.detach().float().contiguous(),
-                                           None if at is None else at.detach().float().contiguous(), dense,
-                                           empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak, fl=fl, alpha_fl=ALPHA_FL,
-                                           gamma_fl=GAMMA_FL, nonfinite=nonfinite)
+        f32c = lambda t: t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().float().contiguous()
+        out, total, ctx.state = ops.set_criterion(f32c(logits_all), f32c(boxes_all), None if at is None else f32c(at), dense,
+                                                  empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak, fl=fl, alpha_fl=ALPHA_FL,
+                                                  gamma_fl=GAMMA_FL, nonfinite=nonfinite, q0=q0)
         ctx.dts = (logits_all.dtype, boxes_all.dtype, None if at is None else at.dtype)
-        return out
+        return out, total
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, gtotal):
         from .. import ops
-        gl, gb, gat = ops.set_criterion_bwd(ctx.state, g)
+        gl, gb, gat = ops.set_criterion_bwd(ctx.state, g, gtotal)
         return (gl.to(ctx.dts[0]), gb.to(ctx.dts[1]), None if gat is None else gat.to(ctx.dts[2]),
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
 
 
 class _FeatureLossFn(torch.autograd.Function):
@@ -454,20 +497,26 @@ class SetCriterion(nn.Module):
         if '_stacked' not in outputs:
             raise RuntimeError('prepare_device needs the stacked head outputs (model built with aux_loss=True)')
         logits_all, boxes_all = outputs['_stacked']
-        L, B, Q, C1 = logits_all.shape
+        q0 = outputs.get('_q0', 0)
+        L, B, Qs, C1 = logits_all.shape
+        Q = Qs - q0
         meta = (L, tables.ns, Q, tables.n_lab if 'at' in outputs else tables.ns, C1 - 1, B)
-        if pack is None:
-            pack = torch.zeros(self.dense_numel(meta), device=logits_all.device, dtype=torch.float32)
+        if pack is None:                                  # (every entry is written by the matching kernel)
+            pack = torch.empty(self.dense_numel(meta), device=logits_all.device, dtype=torch.float32)
         dense = self.dense_views(pack, meta)
         dense['split'] = getattr(tables, 'split', None)      # {ns, n_lab} as device words: the split is data, not graph structure
         m = self.matcher
         seed_ptr = runtime.seed_ptr(logits_all.device) if (fine_tune and ft_rand is None) else None
-        ops.match_targets(logits_all.detach().float().contiguous(), boxes_all.detach().float().contiguous(), tables.as_dict(),
+        f32c = lambda t: t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().float().contiguous()
+        ops.match_targets(f32c(logits_all), f32c(boxes_all), tables.as_dict(),
                           dense, [L - 1] + list(range(L - 1)), float(m.cost_class), float(m.cost_bbox), float(m.cost_giou),
                           tables.max_targets, assign=assign, fl=fl, fine_tune=fine_tune, normalize=normalize,
                           epsilon=float(m.epsilon), alpha=float(m.alpha), alpha_fl=ALPHA_FL, gamma_fl=GAMMA_FL, ft_rand=ft_rand,
-                          ft_seed=runtime.next_seed() if (fine_tune and ft_rand is None) else 0, seed_ptr=seed_ptr)
-        dense['num_boxes'] = ops.sum_f32(dense['wbox'][0], out=dense['num_boxes'])   # sum of the final layer's coefficients
+                          ft_seed=runtime.next_seed() if (fine_tune and ft_rand is None) else 0, seed_ptr=seed_ptr, q0=q0)
+        if 'feature' in self.losses:                      # sum of the final layer's coefficients (the criterion kernel sums it itself)
+            dense['num_boxes'] = ops.sum_f32(dense['wbox'][0], out=dense['num_boxes'])
+        else:
+            dense['num_boxes'] = None
         return dense
 
     @staticmethod
@@ -490,8 +539,10 @@ class SetCriterion(nn.Module):
     def _compute_fused(self, outputs, dense, fl=False):
         """all losses + their gradients in ONE launch (csrc/criterion.hip) - plus one for the SP-SEDT feature loss; the dict
         returned has the same keys / values as the reference's."""
+        q0 = 0
         if '_stacked' in outputs:
             logits_all, boxes_all = outputs['_stacked']
+            q0 = outputs.get('_q0', 0)
         else:                                          # a hand-made output dict: stack [final, aux_0, ...] -> model order
             layers = list(outputs.get('aux_outputs', [])) + [outputs]
             logits_all = torch.stack([o['pred_logits'] for o in layers])
@@ -504,12 +555,12 @@ class SetCriterion(nn.Module):
         zero = [0.0] * L
         dev = logits_all.device
         ew = self._dev_const('ew', lambda: self.empty_weight.detach().float().cpu(), dev)
-        vec = _CriterionFn.apply(
+        vec, total = _CriterionFn.apply(
             logits_all, boxes_all, at, dense, ew, layer_of,
             self._weights('loss_ce', L) if 'labels' in self.losses else zero,
             self._weights('loss_bbox', L) if 'boxes' in self.losses else zero,
             self._weights('loss_giou', L) if 'boxes' in self.losses else zero,
-            float(self.weight_dict.get('loss_weak', 0.0)) if at is not None else 0.0, fl, self.nonfinite)
+            float(self.weight_dict.get('loss_weak', 0.0)) if at is not None else 0.0, fl, self.nonfinite, q0)
         out = {}
         names = []
         if 'labels' in self.losses:
@@ -525,7 +576,6 @@ class SetCriterion(nn.Module):
                 out[k if d == 0 else f'{k}_{d - 1}'] = v.detach() if slot == 3 else v
         if at is not None:
             out['loss_weak'] = vec[4 * L + 2]
-        total = vec[4 * L + 3]
         if 'feature' in self.losses:
             if '_stacked_feature' in outputs:
                 feats = outputs['_stacked_feature']

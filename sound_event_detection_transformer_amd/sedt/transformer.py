@@ -86,11 +86,13 @@ class TransformerDecoderLayer(nn.Module):
                 self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                 self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.norm3.weight, self.norm3.bias)
 
-    def forward_tokens(self, tgt, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask=None, kv_fused=False, out=None):
+    def forward_tokens(self, tgt, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask=None, kv_fused=False, out=None, acc=None):
         """kv_fused: mem_pos is mem + a constant (the decoder's own sine position add): the key and value input gradients
-        of the cross-attention are returned as ONE tensor on `mem` (one K = 2E GEMM) and nothing on `mem_pos`"""
+        of the cross-attention are returned as ONE tensor on `mem` (one K = 2E GEMM) and nothing on `mem_pos`.
+        acc: (GradAccumulator for mem, GradAccumulator for qpos) shared by the layers of one decoder pass, or None"""
         cfg = dict(kv_fused=kv_fused, dt=runtime.compute_dtype(), B=B, S=S, Q=Q, H=self.nhead, dropout=self.p, training=self.training,
-                   pre_norm=self.normalize_before, out=out)
+                   pre_norm=self.normalize_before, out=out, acc_mem=None if acc is None else acc[0],
+                   acc_qpos=None if acc is None else acc[1])
         return Fn.DecoderLayerFn.apply(tgt, mem, mem_pos, qpos, kpm, tgt_mask, cfg, *self.params())
 
 
@@ -133,9 +135,13 @@ class TransformerDecoder(nn.Module):
         # shared LayerNorm of every layer's output (transformer.py:134-147) is ONE call over all rows without a torch.cat
         stack = (torch.empty((n * R, d), device=tgt.device, dtype=runtime.torch_dtype())
                  if (self.return_intermediate and n > 1 and all(l.normalize_before for l in self.layers)) else None)
+        # the layers all read mem and qpos: their gradient shares are folded as the backward goes (functional.GradAccumulator)
+        # instead of being added pair by pair by autograd (pre-norm layers; every layer of the pass must take part)
+        acc = ((Fn.GradAccumulator(n), Fn.GradAccumulator(n)) if (torch.is_grad_enabled() and all(l.normalize_before for l in self.layers)
+                                                                  and not pos.requires_grad) else None)
         for li, layer in enumerate(self.layers):
             out = layer.forward_tokens(out, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask, kv_fused=not pos.requires_grad,
-                                       out=None if stack is None else stack[li * R:(li + 1) * R])
+                                       out=None if stack is None else stack[li * R:(li + 1) * R], acc=acc)
             outs.append(out)
         if self.return_intermediate:
             stacked = Fn.StackViewFn.apply(stack, *outs) if stack is not None else (torch.cat(outs) if n > 1 else outs[0])
@@ -163,6 +169,19 @@ class Transformer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
+    def _zero_tokens(self, rows, cols, device):
+        """the decoder's all-zero input (transformer.py:67): one buffer per shape, kept and never written (a fill launch per
+        forward otherwise); created fresh while a HIP graph is being captured (see utilities.utils.derived_from_static_mask)"""
+        key = (rows, cols, runtime.torch_dtype(), str(device))
+        z = self.__dict__.setdefault('_zeros', {}).get(key)
+        if z is None:
+            z = torch.zeros((rows, cols), device=device, dtype=runtime.torch_dtype())
+            if not (z.is_cuda and torch.cuda.is_current_stream_capturing()):
+                if len(self._zeros) > 8:
+                    self._zeros.clear()
+                self._zeros[key] = z
+        return z
+
     def forward(self, src, mask, query_embed, pos_embed, enc_at_embed=None, decoder_mask=None):
         """reference transformer.py:48-86.  src/pos_embed (B,C,H,W); mask (B,H,W) bool; query_embed (Q,C), or
         (Q,B,C) when self_sup.  Returns hs (L,B,Q,C) and memory (B,S,C) [self_sup: (B,C,H,W)]."""
@@ -182,10 +201,10 @@ class Transformer(nn.Module):
             qpos = query_embed.permute(1, 0, 2).reshape(B * Q, C)
         else:
             Q = query_embed.shape[0]
-            tgt = torch.zeros((B * Q, C), device=src.device, dtype=runtime.torch_dtype())
+            tgt = self._zero_tokens(B * Q, C, src.device)
             qpos = Fn.BroadcastRowsFn.apply(query_embed, tgt, B, dt)        # (Q,C) -> [B*Q, C] in the compute dtype, one launch
         if tgt is None:
-            tgt = torch.zeros((B * Q, C), device=src.device, dtype=runtime.torch_dtype())
+            tgt = self._zero_tokens(B * Q, C, src.device)
         memory = self.encoder.forward_tokens(x, pos, kpm, B, S)
         # the encoder output as a token matrix, kept on request: engine's data-parallel steppers cut the backward here (gradients of
         # decoder + heads are all-reduced while the encoder's backward runs)

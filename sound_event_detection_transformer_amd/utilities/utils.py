@@ -32,6 +32,30 @@ class NestedTensor(object):
 
 
 _MASKS = {}
+_DERIVED = {}          # (id of a static mask, what) -> tensor derived from it (resized mask, position encoding)
+
+
+def is_static_mask(mask):
+    """True for the cached all-False masks of already batched inputs (and tensors derived from them): constant by construction"""
+    return any(m is mask for m in _MASKS.values()) or any(v is mask for v in _DERIVED.values())
+
+
+def derived_from_static_mask(mask, what, make):
+    """make() computed once per static mask and kept (the resized padding mask and the position encoding of a batch without
+    padding do not depend on the data: two launches per forward otherwise).  Nothing is cached while a HIP graph is being
+    captured - a tensor created inside a capture holds its values only after a replay."""
+    if not is_static_mask(mask):
+        return make()
+    key = (id(mask), what)
+    hit = _DERIVED.get(key)
+    if hit is not None:
+        return hit
+    out = make()
+    if not (mask.is_cuda and torch.cuda.is_current_stream_capturing()):
+        if len(_DERIVED) > 64:
+            _DERIVED.clear()
+        _DERIVED[key] = out
+    return out
 
 
 def _no_padding_mask(b, h, w, device):
@@ -40,6 +64,7 @@ def _no_padding_mask(b, h, w, device):
     if key not in _MASKS:
         if len(_MASKS) > 16:
             _MASKS.clear()
+            _DERIVED.clear()
         _MASKS[key] = torch.zeros((b, h, w), dtype=torch.bool, device=device)
     return _MASKS[key]
 

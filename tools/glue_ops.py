@@ -44,9 +44,12 @@ agg = collections.Counter()
 tim = collections.Counter()
 for ev in prof.events():
     if ev.kernels and not any(c.kernels for c in ev.cpu_children):
-        st = [s for s in ev.stack if 'sound_event' in s or 'engine' in s]
-        key = (ev.name + ' | ' + ev.kernels[0].name[:40], str(ev.input_shapes)[:80], st[0][-70:] if st else ('<autograd>' if not ev.stack else ev.stack[0][-60:]))
+        st = [s.split('sound_event_detection_transformer_amd/')[-1] for s in ev.stack if 'sound_event' in s or 'engine' in s]
+        only = len(sys.argv) > 2 and sys.argv[2] == 'aten'
+        if only and 'sedt' in ev.kernels[0].name:
+            continue
+        key = (ev.name + ' | ' + ev.kernels[0].name[:40], str(ev.input_shapes)[:60], ' <- '.join(x[-48:] for x in st[:3]) if st else ('<autograd>' if not ev.stack else ev.stack[0][-60:]))
         agg[key] += 1
         tim[key] += sum(k.duration for k in ev.kernels)
-for k, n in sorted(agg.items(), key=lambda kv: -tim[kv[0]])[:60]:
-    print(f'{n:4d} {tim[k]:8.1f}us  {k[0]:70s} {k[1]:80s} {k[2]}')
+for k, n in sorted(agg.items(), key=lambda kv: -tim[kv[0]])[:90]:
+    print(f'{n:4d} {tim[k]:8.1f}us  {k[0]:62s} {k[1]:60s} {k[2]}')
