@@ -145,7 +145,8 @@ int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, void* stream);
  * bwd: g[M][N] f32 is the gradient of y; with act != NONE the derivative is folded in from ysaved (= y, f32, same ld as g).
  *      gx (compute dtype, optional; masked by mask > 0 when given) = g' w - or gx += g' w when accumulate_gx != 0 (a head that
  *      shares its input with other heads adds to the running input gradient; rows ldo apart, so a strided row subset works);
- *      dw[N][K], db[N] (optional) = g'^T x, column sums. */
+ *      dw[N][K], db[N] (optional) = g'^T x, column sums.  With scratch given and dw NULL only the partial sums are left in
+ *      scratch as [16 slabs][17][K] (rows 0..15 dW, row 16 = the bias sums in its first 16 entries): the caller adds the slabs. */
 int sedt_skinny_linear_fwd(const void* x, int64_t ldx, const float* w, const float* bias, void* y, int64_t ldy, int M, int N,
                            int K, int act, int out_f32, int dtype, void* stream);
 size_t sedt_skinny_linear_bwd_scratch(int K); /* bytes of `scratch` (row-slice partial sums) when dw is requested */
@@ -184,10 +185,11 @@ int sedt_layernorm_bwd(const void* dy, const void* dy2, const void* x, const flo
 size_t sedt_layernorm_bwd_scratch(int rows, int D);
 /* same, with a second output dx_drop = dropout-backward of dx under (drop_p, seed): the gradient entering the sub-layer
  * whose dropped output fed this LayerNorm (post-norm layers, reference transformer.py:186-189) - saves the separate
- * sedt_dropout_grad launch.  dx_drop may be NULL. */
+ * sedt_dropout_grad launch.  dx_drop may be NULL.  dres2 (may be NULL): a second gradient added to dx - the share of another
+ * consumer of x (a decoder layer's output also feeds the shared final LayerNorm, transformer.py:134-147). */
 int sedt_layernorm_bwd_drop(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean,
-                            const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* scratch,
-                            size_t scratch_bytes, int rows, int D, void* dx_drop, float drop_p, uint32_t seed,
+                            const float* rstd, const void* dres, const void* dres2, void* dx, float* dgamma, float* dbeta,
+                            float* scratch, size_t scratch_bytes, int rows, int D, void* dx_drop, float drop_p, uint32_t seed,
                             const uint32_t* seed_ptr, int dtype, void* stream);
 /* second stage of sedt_layernorm_bwd on its own (call sedt_layernorm_bwd with dgamma = dbeta = NULL first): reduces the
  * per-workgroup partial sums in `scratch` to dgamma / dbeta.  Lets a caller move the parameter-gradient half off the

@@ -59,7 +59,7 @@ template <typename T, int VPT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ dy2,
                                                      const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     const T* __restrict__ dres, T* __restrict__ dx,
+                                                     const T* __restrict__ dres, const T* __restrict__ dres2, T* __restrict__ dx,
                                                      float* __restrict__ partial, int rows, T* __restrict__ dx_drop,
                                                      uint32_t thresh, float inv_keep, uint32_t seed,
                                                      const uint32_t* __restrict__ seed_ptr) {
@@ -75,9 +75,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     const float mu = mean[row], rs = rstd[row];
     const V vdy = *reinterpret_cast<const V*>(dy + base);
     const V vx = *reinterpret_cast<const V*>(x + base);
-    V vdy2, vres;
+    V vdy2, vres, vres2;
     if (dy2) vdy2 = *reinterpret_cast<const V*>(dy2 + base);
     if (dres) vres = *reinterpret_cast<const V*>(dres + base);
+    if (dres2) vres2 = *reinterpret_cast<const V*>(dres2 + base);
     float xh[VPT], dyt[VPT];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -99,6 +100,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     for (int i = 0; i < VPT; ++i) {
       float o = rs * (dyt[i] * g[i] - c1 - xh[i] * c2);
       if (dres) o += (float)vres.v[i];
+      if (dres2) o += (float)vres2.v[i];
       out.v[i] = (T)o;
     }
     *reinterpret_cast<V*>(dx + base) = out;
@@ -426,19 +428,19 @@ extern "C" int sedt_layernorm_fwd(const void* x, const float* gamma, const float
 extern "C" size_t sedt_layernorm_bwd_scratch(int rows, int D) { return (size_t)ln_bwd_blocks(rows) * 2 * D * sizeof(float); }
 
 extern "C" int sedt_layernorm_bwd_drop(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean,
-                                       const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                       const float* rstd, const void* dres, const void* dres2, void* dx, float* dgamma, float* dbeta,
                                        float* scratch, size_t scratch_bytes, int rows, int D, void* dx_drop, float drop_p,
                                        uint32_t seed, const uint32_t* seed_ptr, int dtype, void* stream);
 
 extern "C" int sedt_layernorm_bwd(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean,
                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, float* scratch,
                                   size_t scratch_bytes, int rows, int D, int dtype, void* stream) {
-  return sedt_layernorm_bwd_drop(dy, dy2, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, scratch, scratch_bytes, rows, D, nullptr,
-                                 0.f, 0u, nullptr, dtype, stream);
+  return sedt_layernorm_bwd_drop(dy, dy2, x, gamma, mean, rstd, dres, nullptr, dx, dgamma, dbeta, scratch, scratch_bytes, rows, D,
+                                 nullptr, 0.f, 0u, nullptr, dtype, stream);
 }
 
 extern "C" int sedt_layernorm_bwd_drop(const void* dy, const void* dy2, const void* x, const float* gamma, const float* mean,
-                                       const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                       const float* rstd, const void* dres, const void* dres2, void* dx, float* dgamma, float* dbeta,
                                        float* scratch, size_t scratch_bytes, int rows, int D, void* dx_drop, float drop_p,
                                        uint32_t seed, const uint32_t* seed_ptr, int dtype, void* stream) {
   SEDT_REQUIRE(dy && x && gamma && mean && rstd && dx, "layernorm_bwd: null pointer");
@@ -448,7 +450,7 @@ extern "C" int sedt_layernorm_bwd_drop(const void* dy, const void* dy2, const vo
   SEDT_REQUIRE(scratch && scratch_bytes >= sedt_layernorm_bwd_scratch(rows, D), "layernorm_bwd: scratch too small");
   int nb = ln_bwd_blocks(rows);
   dim3 grid(nb), block(256);
-#define A_(T) grid, block, 0, S(stream), (const T*)dy, (const T*)dy2, (const T*)x, gamma, mean, rstd, (const T*)dres, (T*)dx, scratch, rows, (T*)dx_drop, th, ik, seed, seed_ptr
+#define A_(T) grid, block, 0, S(stream), (const T*)dy, (const T*)dy2, (const T*)x, gamma, mean, rstd, (const T*)dres, (const T*)dres2, (T*)dx, scratch, rows, (T*)dx_drop, th, ik, seed, seed_ptr
   if (dtype == SEDT_F32 && D == 256) hipLaunchKernelGGL((ln_bwd_kernel<float, 4>), A_(float));
   else if (dtype == SEDT_F32 && D == 512) hipLaunchKernelGGL((ln_bwd_kernel<float, 8>), A_(float));
   else if (dtype == SEDT_BF16 && D == 256) hipLaunchKernelGGL((ln_bwd_kernel<bf16_t, 4>), A_(bf16_t));

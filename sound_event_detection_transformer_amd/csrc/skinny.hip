@@ -203,7 +203,8 @@ extern "C" int sedt_skinny_linear_bwd(const float* g, const float* ysaved, int64
                          (bf16_t*)gx, (long)ldo, M, N, K, act, accumulate_gx);
     else { set_error("skinny_linear_bwd: unsupported dtype %d", dtype); return 1; }
   }
-  if (dw) {
+  if (dw || scratch) {                  // scratch without dw: the partial sums only (the caller reduces the SK_SPLIT slabs itself,
+                                        // e.g. as one more column-sum job of a layer's sedt_multi_wgrad_reduce launch)
     SEDT_REQUIRE(scratch != nullptr, "skinny_linear_bwd: dw needs the scratch buffer (sedt_skinny_linear_bwd_scratch bytes)");
     const int rows_per = (M + SK_SPLIT - 1) / SK_SPLIT;
     const size_t lds2 = std::max((size_t)rows_per * 16, (size_t)4 * 17 * 64) * sizeof(float);
@@ -216,8 +217,10 @@ extern "C" int sedt_skinny_linear_bwd(const float* g, const float* ysaved, int64
       hipLaunchKernelGGL(skinny_wgrad_partial_kernel<bf16_t>, grid, block, lds2, SS(stream), g, ysaved, (long)ldg, (const bf16_t*)x,
                          (long)ldx, scratch, M, N, K, act);
     else { set_error("skinny_linear_bwd: unsupported dtype %d", dtype); return 1; }
-    const int nout = N * K + (db ? N : 0);
-    hipLaunchKernelGGL(skinny_wgrad_final_kernel, dim3((nout + 255) / 256), dim3(256), 0, SS(stream), scratch, dw, db, N, K);
+    if (dw) {
+      const int nout = N * K + (db ? N : 0);
+      hipLaunchKernelGGL(skinny_wgrad_final_kernel, dim3((nout + 255) / 256), dim3(256), 0, SS(stream), scratch, dw, db, N, K);
+    }
   }
   return check_launch("skinny_linear_bwd");
 }

@@ -145,11 +145,11 @@ class HeadsFn(Function):
         w1b, w2b = ctx.wb
         M = Lh * B * Qp
         f32 = lambda t: t.contiguous() if t.dtype == torch.float32 else t.contiguous().float()
-        # class head: writes the running input gradient
-        dhs, d_wc, d_bc = ops.skinny_linear_bwd(dt, f32(g_cls).view(M, -1), None, wc, x, ACT_NONE)
-        # box MLP: sigmoid' and the ReLU masks ride in the kernels; the last dgrad adds the running gradient (epilogue residual)
-        g_h2, d_w3, d_b3 = ops.skinny_linear_bwd(dt, f32(g_box).view(M, 2), box.view(M, 2), w3, h2, ACT_SIGMOID, mask=h2)
         rb = ops.ReduceBatch()
+        # class head: writes the running input gradient
+        dhs, d_wc, d_bc = ops.skinny_linear_bwd(dt, f32(g_cls).view(M, -1), None, wc, x, ACT_NONE, batch=rb)
+        # box MLP: sigmoid' and the ReLU masks ride in the kernels; the last dgrad adds the running gradient (epilogue residual)
+        g_h2, d_w3, d_b3 = ops.skinny_linear_bwd(dt, f32(g_box).view(M, 2), box.view(M, 2), w3, h2, ACT_SIGMOID, mask=h2, batch=rb)
         d_b2 = torch.empty((g_h2.shape[1],), device=x.device, dtype=torch.float32)
         d_w2 = ops.linear_wgrad(dt, g_h2, h1, bias_out=d_b2, batch=rb)
         g_h1 = ops.linear(dt, g_h2, w2b, mask=h1, ldm=h1.stride(0))
@@ -164,7 +164,7 @@ class HeadsFn(Function):
             else:
                 ga = f32(g_at).view(B, -1)
                 _, d_wa, d_ba = ops.skinny_linear_bwd(dt, ga, at.view(B, -1), wa, xa, ACT_SIGMOID,
-                                                      gx_acc=dhs.view(Lh, B, Qp, d)[Lh - 1, :, 0, :])
+                                                      gx_acc=dhs.view(Lh, B, Qp, d)[Lh - 1, :, 0, :], batch=rb)
         rb.flush()
         return (dhs.view(Lh, B, Qp, d), d_wc, d_bc, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_wa, d_ba, None)
 
@@ -219,18 +219,25 @@ class StackViewFn(Function):
     Backward: the row ranges of the incoming gradient (views)."""
 
     @staticmethod
-    def forward(ctx, buf, *outs):
+    def forward(ctx, buf, share, *outs):
+        """share (dict or None): when given, the gradient slices of all layers but the last are handed to the NEXT layer's
+        backward through share['stack_g'] (it adds them inside its first-LayerNorm backward kernel) instead of being returned -
+        a layer's output feeds the next layer AND this stack, and autograd would add the two gradients in a launch of its own"""
         R = outs[0].shape[0]
         for i, o in enumerate(outs):
             if o.data_ptr() != buf.data_ptr() + i * R * buf.shape[1] * buf.element_size() or o.shape != outs[0].shape:
                 raise RuntimeError('StackViewFn: the layer outputs are not the row ranges of the stacking buffer')
-        ctx.R, ctx.n = R, len(outs)
+        ctx.R, ctx.n, ctx.share = R, len(outs), share
         return buf.view(buf.shape)
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        return (None,) + tuple(g[i * ctx.R:(i + 1) * ctx.R] for i in range(ctx.n))
+        parts = [g[i * ctx.R:(i + 1) * ctx.R] for i in range(ctx.n)]
+        if ctx.share is not None:
+            ctx.share['stack_g'] = parts
+            return (None, None) + (None,) * (ctx.n - 1) + (parts[-1],)
+        return (None, None) + tuple(parts)
 
 
 class BroadcastRowsFn(Function):
@@ -268,6 +275,7 @@ class AddFn(Function):
 
     @staticmethod
     def forward(ctx, a, b, b_mod, dt):
+        ctx.set_materialize_grads(False)       # (no consumer returned a gradient: pass None on, not a zero-filled tensor)
         return ops.add(dt, _as(a, dt), _as(b, dt), b_mod)
 
     @staticmethod
@@ -528,7 +536,11 @@ class DecoderLayerFn(Function):
             g_qpos = g_q
             g_mem_pos, g_mem = g_k, g_v
             g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], gt1, sw_in, sw_o, batch=rb, g_dropped=gt1d)
-            gtgt, d_g1, d_be1 = ops.layernorm_bwd(dt, g_vs, sv['tgt'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gt1, batch=rb)
+            # this layer's input is the previous layer's output, which also feeds the shared final LayerNorm: that share of its
+            # gradient (StackViewFn) is added here, in the kernel that produces the gradient
+            sg = cfg.get('share', {}).get('stack_g') if cfg.get('share') is not None else None
+            extra = sg[cfg['layer_idx'] - 1] if (sg is not None and cfg.get('layer_idx', 0) > 0) else None
+            gtgt, d_g1, d_be1 = ops.layernorm_bwd(dt, g_vs, sv['tgt'], g1, sv['m1'], sv['r1'], dy2=g_qk, dres=gt1, batch=rb, dres2=extra)
             if acc_m is not None and not acc_m.last():       # memory's gradient: handed on as the next layer's GEMM residual
                 acc_m.pending, g_mem = g_mem, None
             if acc_q is not None:                            # qpos' gradient: two shares per layer, ONE sum at the end

@@ -95,7 +95,7 @@ SIGNATURES = {
     'sedt_layernorm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     'sedt_layernorm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     'sedt_layernorm_bwd_scratch': (_sz, [_i, _i]),
-    'sedt_layernorm_bwd_drop': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp, _f, _u32, _vp, _i, _vp]),
+    'sedt_layernorm_bwd_drop': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _vp, _f, _u32, _vp, _i, _vp]),
     'sedt_layernorm_bwd_final': (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     'sedt_attention_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u32,
                                 _vp, _i, _vp]),

@@ -199,9 +199,10 @@ def skinny_linear_fwd(dtype, x, w, bias=None, act=ACT_NONE, out_f32=False):
     return y
 
 
-def skinny_linear_bwd(dtype, g, ysaved, w, x, act=ACT_NONE, mask=None, need_gx=True, need_gw=True, need_gb=True, gx_acc=None):
+def skinny_linear_bwd(dtype, g, ysaved, w, x, act=ACT_NONE, mask=None, need_gx=True, need_gw=True, need_gb=True, gx_acc=None, batch=None):
     """(gx, dW, db) of skinny_linear_fwd; g f32 [M,N]; ysaved = the f32 output when act != NONE.  x may be a strided row view
-    (stride(1) == 1).  gx_acc: a [M,K] (row-strided) view the input gradient is ADDED to instead of a fresh gx."""
+    (stride(1) == 1).  gx_acc: a [M,K] (row-strided) view the input gradient is ADDED to instead of a fresh gx.
+    batch (a ReduceBatch): the final sum of the 16 partial slabs rides in batch.flush() (dW / db are valid only then)"""
     M, K = x.shape
     N = w.shape[0]
     assert g.dtype == torch.float32 and g.is_contiguous() and (ysaved is None or (ysaved.dtype == torch.float32 and ysaved.is_contiguous()))
@@ -215,9 +216,16 @@ def skinny_linear_bwd(dtype, g, ysaved, w, x, act=ACT_NONE, mask=None, need_gx=T
     db = torch.empty((N,), device=x.device, dtype=torch.float32) if (need_gb and need_gw) else None
     lib = L.load()
     scratch = torch.empty((lib.sedt_skinny_linear_bwd_scratch(K) // 4,), device=x.device, dtype=torch.float32) if need_gw else None
+    deferred = need_gw and batch is not None
     L.check(lib.sedt_skinny_linear_bwd(_p(g), _p(ysaved), g.stride(0), _p(w), _p(x), x.stride(0), _p(mask),
-                                       mask.stride(0) if mask is not None else 0, _p(gx), gx.stride(0) if gx is not None else K, _p(dw), _p(db),
+                                       mask.stride(0) if mask is not None else 0, _p(gx), gx.stride(0) if gx is not None else K,
+                                       None if deferred else _p(dw), None if deferred else _p(db),
                                        _p(scratch), M, N, K, act, int(gx_acc is not None), dtype, L.stream_ptr()), 'skinny_linear_bwd')
+    if deferred:                                  # sum of the 16 slabs [17][K] as a column-sum job of the batch's reduce launch
+        tot = torch.empty((17 * K,), device=x.device, dtype=torch.float32)
+        batch.add_colsum(scratch, 16, 17 * K, tot)
+        dw = tot[:N * K].view(N, K)
+        db = tot[16 * K:16 * K + N] if need_gb else None
     if need_gb and not need_gw:
         db = g.sum(0) if act == ACT_NONE else (g * ysaved * (1 - ysaved)).sum(0) if act == ACT_SIGMOID else (g * (ysaved > 0)).sum(0)
     return gx, dw, db
@@ -497,7 +505,7 @@ def layernorm_fwd(dtype, x, gamma, beta, add_t=None, out=None):
     return y, y2, mean, rstd
 
 
-def layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2=None, dres=None, want_param_grads=True, batch=None, drop=None):
+def layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2=None, dres=None, want_param_grads=True, batch=None, drop=None, dres2=None):
     """batch (a ReduceBatch): the gamma/beta reduction - which only feeds the optimizer - is deferred to batch.flush() and
     rides in the layer's split-K reduction launch.
     drop = (p, seed, seed_ptr): also returns dx passed through that dropout mask (the gradient entering the sub-layer whose
@@ -513,11 +521,11 @@ def layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2=None, dres=None, want_par
     if drop is not None and drop[0] > 0:
         p_, seed_, sp_ = drop
         if os.environ.get('SEDT_LN_DROP_FUSE', '1') == '0':        # A/B switch: separate dropout_grad launch
-            dx, dg, db = layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2, dres, want_param_grads, batch)
+            dx, dg, db = layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2, dres, want_param_grads, batch, dres2=dres2)
             return dx, dg, db, dropout_grad(dtype, dx, p_, seed_, sp_)
         dxd = torch.empty_like(x)
     deferred = want_param_grads and batch is not None
-    L.check(lib.sedt_layernorm_bwd_drop(_p(dy), _p(dy2), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
+    L.check(lib.sedt_layernorm_bwd_drop(_p(dy), _p(dy2), _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dres2), _p(dx),
                                         None if deferred else _p(dg), None if deferred else _p(db), _p(scratch), nb, rows, D,
                                         _p(dxd), p_, seed_ & 0xffffffff, _p(sp_), dtype, L.stream_ptr()), 'layernorm_bwd')
     if deferred:

@@ -293,6 +293,7 @@ class _CriterionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits_all, boxes_all, at, dense, empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak, fl, nonfinite, q0):
         from .. import ops
+        ctx.set_materialize_grads(False)           # usually only the total carries a gradient: no zero-filled g for the vector
         f32c = lambda t: t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().float().contiguous()
         out, total, ctx.state = ops.set_criterion(f32c(logits_all), f32c(boxes_all), None if at is None else f32c(at), dense,
                                                   empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak, fl=fl, alpha_fl=ALPHA_FL,
@@ -303,6 +304,8 @@ class _CriterionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, gtotal):
         from .. import ops
+        if g is None and gtotal is None:
+            return (None,) * 13
         gl, gb, gat = ops.set_criterion_bwd(ctx.state, g, gtotal)
         return (gl.to(ctx.dts[0]), gb.to(ctx.dts[1]), None if gat is None else gat.to(ctx.dts[2]),
                 None, None, None, None, None, None, None, None, None, None)

@@ -86,13 +86,14 @@ class TransformerDecoderLayer(nn.Module):
                 self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
                 self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.norm3.weight, self.norm3.bias)
 
-    def forward_tokens(self, tgt, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask=None, kv_fused=False, out=None, acc=None):
+    def forward_tokens(self, tgt, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask=None, kv_fused=False, out=None, acc=None, share=None,
+                       layer_idx=0):
         """kv_fused: mem_pos is mem + a constant (the decoder's own sine position add): the key and value input gradients
         of the cross-attention are returned as ONE tensor on `mem` (one K = 2E GEMM) and nothing on `mem_pos`.
         acc: (GradAccumulator for mem, GradAccumulator for qpos) shared by the layers of one decoder pass, or None"""
         cfg = dict(kv_fused=kv_fused, dt=runtime.compute_dtype(), B=B, S=S, Q=Q, H=self.nhead, dropout=self.p, training=self.training,
                    pre_norm=self.normalize_before, out=out, acc_mem=None if acc is None else acc[0],
-                   acc_qpos=None if acc is None else acc[1])
+                   acc_qpos=None if acc is None else acc[1], share=share, layer_idx=layer_idx)
         return Fn.DecoderLayerFn.apply(tgt, mem, mem_pos, qpos, kpm, tgt_mask, cfg, *self.params())
 
 
@@ -139,12 +140,13 @@ class TransformerDecoder(nn.Module):
         # instead of being added pair by pair by autograd (pre-norm layers; every layer of the pass must take part)
         acc = ((Fn.GradAccumulator(n), Fn.GradAccumulator(n)) if (torch.is_grad_enabled() and all(l.normalize_before for l in self.layers)
                                                                   and not pos.requires_grad) else None)
+        share = {} if (stack is not None and acc is not None) else None      # (see functional.StackViewFn)
         for li, layer in enumerate(self.layers):
             out = layer.forward_tokens(out, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask, kv_fused=not pos.requires_grad,
-                                       out=None if stack is None else stack[li * R:(li + 1) * R], acc=acc)
+                                       out=None if stack is None else stack[li * R:(li + 1) * R], acc=acc, share=share, layer_idx=li)
             outs.append(out)
         if self.return_intermediate:
-            stacked = Fn.StackViewFn.apply(stack, *outs) if stack is not None else (torch.cat(outs) if n > 1 else outs[0])
+            stacked = Fn.StackViewFn.apply(stack, share, *outs) if stack is not None else (torch.cat(outs) if n > 1 else outs[0])
             return Fn.LayerNormFn.apply(stacked, self.norm.weight, self.norm.bias, dt).view(n, B, Q, d)
         return Fn.LayerNormFn.apply(out, self.norm.weight, self.norm.bias, dt).view(1, B, Q, d)
 
