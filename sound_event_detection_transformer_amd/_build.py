@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsedt_hip.so')
 OBJ = os.path.join(HERE, '..', 'build', 'obj')
-SOURCES = ['igemm.hip', 'igemm2.hip', 'igemm3.hip', 'wgrad2.hip', 'wgrad3.hip', 'wgrad4.hip', 'misc.hip', 'stem.hip', 'conv3x3_c64.hip',
+SOURCES = ['igemm.hip', 'igemm3.hip', 'wgrad3.hip', 'wgrad4.hip', 'misc.hip', 'stem.hip', 'conv3x3_c64.hip',
            'norm_attn.hip', 'attn_mfma.hip', 'criterion.hip', 'postproc.hip', 'input.hip', 'skinny.hip', 'host.cpp']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-failed']
 

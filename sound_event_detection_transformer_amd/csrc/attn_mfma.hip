@@ -650,7 +650,11 @@ int enc_attn_fused_launch(const void* x, const void* pos, const float* gamma, co
   const uint32_t th = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
   const float ik = 1.f / (1.f - drop_p);
   const bool train = xn != nullptr;
-  static const int dbg = getenv("SEDT_ENC_DBG") ? atoi(getenv("SEDT_ENC_DBG")) : 0;      // developer timing switch (1: no projections, 2: no attention)
+#ifdef SEDT_DEV                      // ablation switch (1: no projections, 2: no attention - WRONG results): developer builds only
+  static const int dbg = getenv("SEDT_ENC_DBG") ? atoi(getenv("SEDT_ENC_DBG")) : 0;
+#else
+  const int dbg = 0;
+#endif
   dim3 grid(B * 4), block(512);
   if (train) {
     static bool done = false;

@@ -457,12 +457,12 @@ static int launch_typed(const SedtIgemm& p, hipStream_t st) {
 
 }  // namespace sedt
 
-namespace sedt { int igemm2_try(const SedtIgemm& p, hipStream_t st); }
+namespace sedt { int igemm_lds_try(const SedtIgemm& p, hipStream_t st); }   // igemm3.hip: the LDS-DMA GEMM family's dispatcher
 
-static bool use_v2() {
+static bool use_lds_family() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("SEDT_IGEMM_V2");
+    const char* e = getenv("SEDT_IGEMM_LDS");       // developer A/B switch: 0 = the general kernel of this file for everything
     v = (e && e[0] == '0') ? 0 : 1;
   }
   return v == 1;
@@ -479,8 +479,8 @@ extern "C" int sedt_igemm(const SedtIgemm* args, int dtype, void* stream) {
     return launch_typed<float>(*args, st);
   }
   if (dtype == SEDT_BF16) {
-    if (use_v2()) {                       // LDS-DMA pipeline (igemm2.hip) when the problem fits its envelope
-      int r = igemm2_try(*args, st);
+    if (use_lds_family()) {               // LDS-DMA kernels (igemm3 / wgrad3 / wgrad4) when the problem fits their envelope
+      int r = igemm_lds_try(*args, st);
       if (r >= 0) return r;
     }
     SEDT_REQUIRE(args->colsum_out == nullptr, "igemm: colsum_out needs the bf16 LDS-DMA wgrad kernel (M,N,lda,ldb %% 8 == 0)");

@@ -581,7 +581,7 @@ static int launch3(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipSt
   return check_launch("igemm3");
 }
 
-int igemm2_try(const SedtIgemm& p, hipStream_t st);   // igemm2.hip: envelope checks + tile choice, then igemm3_try
+int igemm_lds_try(const SedtIgemm& p, hipStream_t st);   // below: envelope checks + tile choice, then igemm3_try
 bool igemm3_planning() { return plan3.on; }
 
 // 0 = launched as one grouped kernel, -1 = some problem does not resolve to the 64x64 2-stage kernel (nothing launched)
@@ -599,7 +599,7 @@ int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
     const SedtIgemm& p = jobs[i];
     if (p.trans) return -1;
     plan3 = {true, false, 0, 0, 0, 0u, 0u};
-    const int r = igemm2_try(p, st);
+    const int r = igemm_lds_try(p, st);
     const Igemm3Plan got = plan3;
     plan3.on = false;
     if (r != 0 || !got.ok || got.bm != 64 || got.bn != 64 || (got.s != 2 && got.s != 3)) return -1;
@@ -715,6 +715,69 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
   SEDT_L3(128, 128)
 #undef SEDT_L3
   return -1;
+}
+
+int wgrad_lds_try(const SedtIgemm& p, hipStream_t st);   // wgrad3.hip
+
+// Envelope checks + tile rule of the LDS-DMA GEMM family, then the lean-issue kernel (igemm3_try).
+// Returns -1 when the problem is outside the envelope (the caller - sedt_igemm - then uses the general kernel of igemm.hip).
+int igemm_lds_try(const SedtIgemm& p, hipStream_t st) {
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (p.trans) {
+    return wgrad_lds_try(p, st);
+  }
+  if (p.out_f32 || p.splitk > 1 || p.act == SEDT_ACT_SIGMOID) return -1;
+  if ((p.K & 7) || (p.N & 7) || (p.lda & 7) || (p.ldb & 7) || (p.ldc & 7)) return -1;
+  if (!al16(p.A) || !al16(p.B) || !al16(p.C)) return -1;
+  if (p.res && (!al16(p.res) || (p.ldr & 7))) return -1;
+  if (p.mask && (!al16(p.mask) || (p.ldm & 7))) return -1;
+  if (p.conv && (p.Ci % BK2)) return -1;
+  // bytes addressable through the A descriptor: every gathered pixel row + one K tile past its start
+  long a_rows = p.conv ? (long)((p.M + (long)p.Ho * p.Wo - 1) / ((long)p.Ho * p.Wo)) * p.Hi * p.Wi : (long)p.M;
+  long a_bytes = ((a_rows - 1) * p.lda + (p.conv ? p.Ci : p.K)) * 2;
+  long b_bytes = ((long)(p.N - 1) * p.ldb + p.K) * 2;
+  if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31) || a_bytes <= 0 || b_bytes <= 0) return -1;
+  int bm = p.tile_m, bn = p.tile_n;
+  // measured (tools/tune_igemm.py on MI355X): occupancy beats prefetch depth at every SEDT shape - the 64x64 tile with a
+  // 2-stage ring (32 KB LDS, 5 workgroups per CU) wins or ties; SEDT_IGEMM_STAGES / tile_m override for experiments
+  if (bm == 0 || bn == 0) {
+    bm = 64; bn = 64;
+    // measured with the lean-issue kernel (tools/tune_igemm.py): the wider N tile (one A fragment feeds two MFMAs) wins
+    // once K is deep and enough tiles remain to fill the chip; everything else prefers the 64x64 tile's occupancy
+    // (with the 8-wave form of that tile - igemm3.hip - the tile-count condition of the 4-wave kernel no longer applies)
+    // (a grouped launch - igemm3_planning() - runs on the 64x64 program: worth it for the launch-bound decoder-sized problems)
+    static int mink = -1;
+    if (mink < 0) {
+      const char* e = getenv("SEDT_IGEMM_BN128_MINK");
+      mink = e ? atoi(e) : 512;
+    }
+    static int bn128t = -1;
+    if (bn128t < 0) {
+      const char* e = getenv("SEDT_IGEMM_BN128_MINTILES");
+      bn128t = e ? atoi(e) : 250;
+    }
+    // below 250 tiles of 64x128 the 64x64 tile covers more of the chip: the B = 32 configurations have M = 3968 rows, i.e. 124
+    // tiles of 64x128 at N = 256 (measured, tools/dev/sweep_c3.sh: C3 4.97 -> 4.88 ms, C5 8.71 -> 8.61 ms, C2 - exactly 256 tiles -
+    // unchanged; a threshold of 300 costs C2 0.2 %)
+    const long t128 = (long)((p.M + 63) / 64) * (p.N / 128);
+    if ((p.N % 128) == 0 && p.K >= mink && !(igemm3_planning() && p.M <= 1024) && (t128 >= bn128t || p.M <= 1024)) bn = 128;
+    // the ping-pong 8-wave kernel makes the 128x128 tile (one workgroup per CU) pay where the K loop is long enough to
+    // amortise its exposed prologue / epilogue and the tiles still cover the chip: layer4 conv1 fwd / conv2 / conv3 dgrad
+    static int bm128k = -1, bm128t = -1;
+    if (bm128k < 0) {
+      const char* e = getenv("SEDT_IGEMM_BM128_MINK");
+      bm128k = e ? atoi(e) : 2048;
+      e = getenv("SEDT_IGEMM_BM128_MINTILES");
+      bm128t = e ? atoi(e) : 256;
+    }
+    if (bn == 128 && p.K >= bm128k && (long)((p.M + 127) / 128) * (p.N / 128) >= bm128t && !igemm3_planning()) bm = 128;
+  }
+  {   // the lean-issue kernel takes the common cases
+    int r3 = igemm3_try(p, (unsigned)a_bytes, (unsigned)b_bytes, bm, bn, st);
+    if (r3 >= 0) return r3;
+    if (igemm3_planning()) return -1;      // dry run (sedt_igemm_group): never launch from here
+  }
+  return -1;                             // outside the lean-issue envelope: the general kernel (igemm.hip) takes it
 }
 
 }  // namespace sedt

@@ -1,4 +1,4 @@
-// igemm2_common.h - definitions shared by the LDS-DMA kernels (igemm2.hip, wgrad2.hip)
+// lds_gemm_common.h - definitions shared by the LDS-DMA kernels (igemm3.hip, wgrad3.hip, wgrad4.hip)
 #pragma once
 #include "common.h"
 

@@ -378,9 +378,11 @@ extern "C" int sedt_stem_pool_fwd(const float* x, const void* wcat, const float*
   static int gmax = -1, dbg = 0;
   if (gmax < 0) {
     const char* e = getenv("SEDT_STEM_GRID");
-    gmax = e ? atoi(e) : 512;        // measured: 512 persistent workgroups 37.6 us, 768 40.2, 1024 44.0 (C2 shape)
-    e = getenv("SEDT_STEM_DBG");
+    gmax = std::max(e ? atoi(e) : 512, 1);        // measured: 512 persistent workgroups 37.6 us, 768 40.2, 1024 44.0 (C2 shape)
+#ifdef SEDT_DEV                      // ablation switch of tools/dev/time_stem.py (skips the MFMAs / the prefetch: WRONG results);
+    e = getenv("SEDT_STEM_DBG");     // compiled only into developer builds (hipcc -DSEDT_DEV), never into the product library
     dbg = e ? atoi(e) : 0;
+#endif
   }
   const int grid = (int)std::min<long>(nt, gmax);
   hipLaunchKernelGGL(stem_pool_fwd_kernel, dim3(grid), dim3(320), 0, reinterpret_cast<hipStream_t>(stream), x,

@@ -50,7 +50,7 @@ static bool wgrad3_conv_ok(const SedtIgemm& p) {
   return !(p.conv && ((64 % p.Wo) != 0 || p.Ho * p.Wo < 64 || p.Ho < 64 / p.Wo));
 }
 
-int wgrad2_envelope(const SedtIgemm& p, long* a_bytes, long* b_bytes);   // wgrad2.hip
+int wgrad_lds_envelope(const SedtIgemm& p, long* a_bytes, long* b_bytes);   // below
 bool wgrad4_ok(const SedtIgemm& p);                                        // wgrad4.hip: 128x128 ping-pong kernel
 int launch_wgrad4(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st);
 int launch_wgrad4_group(WgradGroup& g, hipStream_t st);
@@ -68,7 +68,7 @@ int wgrad3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
     const int n = std::min(WG_MAXG, njobs - base);
     for (int i = 0; i < n; ++i) {
       const SedtIgemm& p = jobs[base + i];
-      if (!p.trans || wgrad2_envelope(p, &ab[i], &bb[i]) != 0 || !wgrad3_conv_ok(p)) return -1;
+      if (!p.trans || wgrad_lds_envelope(p, &ab[i], &bb[i]) != 0 || !wgrad3_conv_ok(p)) return -1;
     }
   }
   static bool attr_set = false;
@@ -90,7 +90,7 @@ int wgrad3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
     for (int j = 0; j < n; ++j) {
       const SedtIgemm& p = jobs[base + j];
       long a, b;
-      wgrad2_envelope(p, &a, &b);
+      wgrad_lds_envelope(p, &a, &b);
       if (wgrad4_ok(p)) {
         const int i = gw.n++;
         gw.p[i] = p;
@@ -126,7 +126,7 @@ int wgrad3_group_build(const SedtIgemm* jobs, int njobs, WgradGroup* g) {
   for (int i = 0; i < njobs; ++i) {
     const SedtIgemm& p = jobs[i];
     long ab, bb;
-    if (!p.trans || wgrad2_envelope(p, &ab, &bb) != 0 || !wgrad3_conv_ok(p)) return -1;
+    if (!p.trans || wgrad_lds_envelope(p, &ab, &bb) != 0 || !wgrad3_conv_ok(p)) return -1;
     g->p[i] = p;
     g->a_bytes[i] = (unsigned)ab;
     g->b_bytes[i] = (unsigned)bb;
@@ -158,6 +158,35 @@ int wgrad3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream
   }
   if (wide == 0) bn = 64;
   return bn == 128 ? launch_wgrad3<128>(p, a_bytes, b_bytes, st) : launch_wgrad3<64>(p, a_bytes, b_bytes, st);
+}
+
+// 0 when the problem fits the LDS-DMA weight-gradient kernels (wgrad3 / wgrad4); fills the buffer-descriptor sizes
+int wgrad_lds_envelope(const SedtIgemm& p, long* a_bytes_out, long* b_bytes_out) {
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (p.scale || p.bias || p.res || p.mask || p.act != SEDT_ACT_NONE || p.drop_p > 0.f || p.alpha != 1.f) return -1;
+  if (p.splitk <= 1 && !p.out_f32) return -1;
+  if (p.splitk > 1 && !p.slab) return -1;
+  if ((p.M & 7) || (p.N & 7) || (p.lda & 7) || (p.ldb & 7)) return -1;
+  if (!al16(p.A) || !al16(p.B)) return -1;
+  if (p.conv && ((p.Ci & 7) || p.transposed)) return -1;
+  long a_bytes = ((long)(p.K - 1) * p.lda + p.M) * 2;
+  long b_rows = p.conv ? (long)((p.K + (long)p.Ho * p.Wo - 1) / ((long)p.Ho * p.Wo)) * p.Hi * p.Wi : (long)p.K;
+  long b_bytes = ((b_rows - 1) * p.ldb + (p.conv ? p.Ci : p.N)) * 2;
+  if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31) || a_bytes <= 0 || b_bytes <= 0) return -1;
+  *a_bytes_out = a_bytes;
+  *b_bytes_out = b_bytes;
+  return 0;
+}
+
+// returns -1 when the problem is outside the envelope (the caller then uses the general v1 kernel)
+int wgrad_lds_try(const SedtIgemm& p, hipStream_t st) {
+  long a_bytes, b_bytes;
+  if (wgrad_lds_envelope(p, &a_bytes, &b_bytes) != 0) return -1;
+  {   // the lean-issue kernel takes the common cases
+    int r3 = wgrad3_try(p, (unsigned)a_bytes, (unsigned)b_bytes, st);
+    if (r3 >= 0) return r3;
+  }
+  return -1;
 }
 
 }  // namespace sedt

@@ -2,7 +2,7 @@
 // as a device function, so that it can run as its own kernel (wgrad3.hip), as one problem of a grouped launch, or in the
 // spare workgroups of a forward / dgrad GEMM launch (igemm3.hip: co-scheduling).
 #pragma once
-#include "igemm2_common.h"
+#include "lds_gemm_common.h"
 
 namespace sedt {
 

@@ -667,22 +667,6 @@ def test_fused_encoder_attention_head_matches_unfused_chain(ops, B, S, padded, p
     assert none is None and torch.equal(nctx, fctx) and torch.equal(nlse, flse)
 
 
-def test_previous_generation_kernels_still_pass_the_same_parity_tests():
-    """igemm2 / wgrad2 / wgrad3 are the envelope fallbacks of the current GEMM generation (igemm3 / wgrad4): with the newer kernels
-    switched off (the library reads the switches once per process, hence the child process) the same conv / linear parity
-    tests must pass through them"""
-    import subprocess
-    import sys
-    env = dict(os.environ, SEDT_IGEMM_V3='0', SEDT_WGRAD_V4='0', SEDT_WGRAD_V3='0')
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_ops_gpu.py'), '-q', '-x', '-m', 'gpu', '-k',
-                        'test_linear_epilogues or test_conv_fwd_dgrad_wgrad or test_linear_wgrad_and_colsum or test_wgrad_large_tiles '
-                        'or test_linear_tiles_and_strided_views'],
-                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-    assert ' passed' in r.stdout
-
-
 @pytest.mark.parametrize('B,H', [(2, 125), (3, 124), (1, 16), (2, 7), (5, 33), (70, 125), (300, 32)])   # the last two: 3 tiles per persistent workgroup
 def test_direct_conv3x3_c64_forward_and_dgrad(ops, B, H):
     """csrc/conv3x3_c64.hip (layer1 conv2 geometry: 64 -> 64 channels, 16-wide map) against F.conv2d and against the implicit-GEMM
