@@ -382,7 +382,8 @@ typedef struct SedtCriterion {
   int32_t Qs, q0;
   float* total; /* optional: receives out[4L+3] as a separate scalar (its own autograd output: no select/backward-of-select) */
 } SedtCriterion;
-int sedt_set_criterion(const SedtCriterion* args, void* stream);
+size_t sedt_set_criterion_scratch(int L, int B, int Q); /* bytes of `scratch`: per-row loss terms, summed per layer in a fixed order */
+int sedt_set_criterion(const SedtCriterion* args, float* scratch, void* stream);
 /* g: gradient that reached out[4L+5] (or null), gtotal: gradient that reached the separate total scalar (or null) */
 int sedt_set_criterion_bwd(const SedtCriterion* args, const float* g, const float* gtotal, float* glogits, float* gboxes,
                            float* gat, void* stream);

@@ -32,10 +32,16 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red /* [17] */) 
   return red[16];
 }
 
-__global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion a) {
+__global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion a, float* __restrict__ rowvals) {
+  // Phases (ONE workgroup; the whole problem is a few thousand rows, so what counts is the number of dependent steps, not the
+  // width): (1) every (dense layer, clip, query) row - all layers at once - computes its loss terms and per-term gradients and
+  // leaves {ce, l1, giou, hit, matched} in rowvals[row][5]; (2) one wave per (layer, quantity) adds its column of rowvals in a
+  // fixed order; (3) the audio-tag BCE and the totals.  (The first version looped over the layers with five block-wide
+  // reductions each: 38 us at L = 3, three times what the arithmetic needs.)
   __shared__ float red[17];
   __shared__ int card[SEDT_CRIT_MAXCARD];      // predicted-event count of every (dense layer, clip): integer LDS atomics
-  const int t = threadIdx.x;
+  __shared__ float sums[SEDT_CRIT_MAXL][6];    // per dense layer: ce, l1, giou, hits, matched, cardinality error
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int L = a.L, B = a.B, ns = a.ns, Q = a.Q, C1 = a.C + 1, C = a.C;
   // strong / labelled clip counts as DATA (mix-up moves clips across the strong | weak boundary per batch): a.ns / a.n_lab
   // stay the strides and capacities of the dense tables
@@ -54,125 +60,135 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
   for (int i = t; i < L * B; i += 1024) card[i] = 0;
   __syncthreads();
 
-  float total = 0.f;
-  // ---------------- per dense layer d (uniform loop: every accumulator is a plain register, every sum a block reduction)
-  for (int d = 0; d < L; ++d) {
+  // ---------------- phase 1: all rows of all dense layers
+  const int BQ = B * Q;
+  for (int r = t; r < L * BQ; r += 1024) {
+    const int d = r / BQ, rr = r - d * BQ;
     const int ml = a.layer_of[d];               // which slice of the model's stacked outputs
+    const int b = rr / Q, q = rr - b * Q;
+    const long mrow = ((long)ml * B + b) * Q + q;                       // row of the (compact) per-term gradient buffers
+    const long xrow = ((long)ml * B + b) * a.Qs + a.q0 + q;             // row of the model's head outputs (Qs queries per clip)
+    const float* x = a.logits + xrow * C1;
+    float* gx = a.dlogits + mrow * C1;
+    float* gbx = a.dboxes + mrow * 2;
+    float* gbx2 = a.dboxes2 + mrow * 2;
+    float* rv = rowvals + (long)r * 5;
+    float m = -INFINITY;
+    int amax = 0;
+    for (int c = 0; c < C1; ++c)
+      if (x[c] > m) { m = x[c]; amax = c; }
+    if (amax != C) atomicAdd(&card[d * B + b], 1);
+    if (b >= ns_eff) {                        // not strongly labelled: no CE / box loss, zero grads
+      for (int c = 0; c < C1; ++c) gx[c] = 0.f;
+      gbx[0] = 0.f; gbx[1] = 0.f;
+      gbx2[0] = 0.f; gbx2[1] = 0.f;
+      rv[0] = 0.f; rv[1] = 0.f; rv[2] = 0.f; rv[3] = 0.f; rv[4] = 0.f;
+      continue;
+    }
+    const long di = ((long)d * ns + b) * Q + q;
+    const int tc = (int)a.tc[di];
+    const float coef = a.coef[di], wb = a.wbox[di];
     float l_ce = 0.f, l_bb = 0.f, l_gi = 0.f, n_hit = 0.f, n_cnt = 0.f;
-    for (int rr = t; rr < B * Q; rr += 1024) {  // one row = (clip b, query q)
-      const int b = rr / Q, q = rr - b * Q;
-      const long mrow = ((long)ml * B + b) * Q + q;                       // row of the (compact) per-term gradient buffers
-      const long xrow = ((long)ml * B + b) * a.Qs + a.q0 + q;             // row of the model's head outputs (Qs queries per clip)
-      const float* x = a.logits + xrow * C1;
-      float* gx = a.dlogits + mrow * C1;
-      float* gbx = a.dboxes + mrow * 2;
-      float* gbx2 = a.dboxes2 + mrow * 2;
-      float m = -INFINITY;
-      int amax = 0;
-      for (int c = 0; c < C1; ++c)
-        if (x[c] > m) { m = x[c]; amax = c; }
-      if (amax != C) atomicAdd(&card[d * B + b], 1);
-      if (b >= ns_eff) {                        // not strongly labelled: no CE / box loss, zero grads
-        for (int c = 0; c < C1; ++c) gx[c] = 0.f;
-        gbx[0] = 0.f; gbx[1] = 0.f;
-        gbx2[0] = 0.f; gbx2[1] = 0.f;
-        continue;
-      }
-      const long di = ((long)d * ns + b) * Q + q;
-      const int tc = (int)a.tc[di];
-      const float coef = a.coef[di], wb = a.wbox[di];
-      if (a.fl) {
-        // sigmoid focal loss over the C+1 logits, one-hot target at tc (sedt.py:211-218, 412-422)
-        float row = 0.f;
-        const float ks = coef * inv_nb;
-        for (int c = 0; c < C1; ++c) {
-          const float xv = x[c], p = 1.f / (1.f + __expf(-xv));
-          const float sp_pos = fmaxf(xv, 0.f) + log1pf(__expf(-fabsf(xv)));     // softplus(x)  = -log(1 - p)
-          const float sp_neg = sp_pos - xv;                                     // softplus(-x) = -log p
-          float ce, mod, dce, dmod, at;
-          if (c == tc) {
-            const float w = a.empty_weight[c];
-            ce = w * sp_neg; dce = -w * (1.f - p); mod = 1.f - p; dmod = -p * (1.f - p); at = a.alpha_fl;
-          } else {
-            ce = sp_pos; dce = p; mod = p; dmod = p * (1.f - p); at = 1.f - a.alpha_fl;
-          }
-          if (a.alpha_fl < 0.f) at = 1.f;
-          const float mg = a.gamma_fl == 1.f ? mod : powf(mod, a.gamma_fl);
-          const float dmg = a.gamma_fl == 1.f ? 1.f : a.gamma_fl * powf(mod, a.gamma_fl - 1.f);
-          row += at * ce * mg;
-          gx[c] = ks * at * (dce * mg + ce * dmg * dmod);
+    if (a.fl) {
+      // sigmoid focal loss over the C+1 logits, one-hot target at tc (sedt.py:211-218, 412-422)
+      float row = 0.f;
+      const float ks = coef * inv_nb;
+      for (int c = 0; c < C1; ++c) {
+        const float xv = x[c], p = 1.f / (1.f + __expf(-xv));
+        const float sp_pos = fmaxf(xv, 0.f) + log1pf(__expf(-fabsf(xv)));     // softplus(x)  = -log(1 - p)
+        const float sp_neg = sp_pos - xv;                                     // softplus(-x) = -log p
+        float ce, mod, dce, dmod, at;
+        if (c == tc) {
+          const float w = a.empty_weight[c];
+          ce = w * sp_neg; dce = -w * (1.f - p); mod = 1.f - p; dmod = -p * (1.f - p); at = a.alpha_fl;
+        } else {
+          ce = sp_pos; dce = p; mod = p; dmod = p * (1.f - p); at = 1.f - a.alpha_fl;
         }
-        l_ce += row * ks;
-      } else {
-        float se = 0.f;
-        for (int c = 0; c < C1; ++c) se += __expf(x[c] - m);
-        const float lse = m + __logf(se);
-        const float w = a.empty_weight[tc];
-        l_ce += w * (lse - x[tc]) * coef * inv_nb;
-        const float gscale = coef * w * inv_nb;
-        for (int c = 0; c < C1; ++c) gx[c] = gscale * (__expf(x[c] - lse) - (c == tc ? 1.f : 0.f));
+        if (a.alpha_fl < 0.f) at = 1.f;
+        const float mg = a.gamma_fl == 1.f ? mod : powf(mod, a.gamma_fl);
+        const float dmg = a.gamma_fl == 1.f ? 1.f : a.gamma_fl * powf(mod, a.gamma_fl - 1.f);
+        row += at * ce * mg;
+        gx[c] = ks * at * (dce * mg + ce * dmg * dmod);
       }
-      if (d == 0 && wb > 0.f) {
-        n_cnt += 1.f;
-        if (amax == tc) n_hit += 1.f;
-      }
-      // boxes (centre, length) -> interval [s, e]
-      const float* bx = a.boxes + xrow * 2;
-      float gc = 0.f, gl = 0.f, gc2 = 0.f, gl2 = 0.f;
-      if (wb > 0.f) {
-        const float s1 = bx[0] - 0.5f * bx[1], e1 = bx[0] + 0.5f * bx[1];
-        const float tcn = a.tbox[2 * di], tln = a.tbox[2 * di + 1];
-        const float s2 = tcn - 0.5f * tln, e2 = tcn + 0.5f * tln;
-        // L1 on the fake boxes [s,0,e,1]: |s1-s2| + |e1-e2|
-        l_bb += (fabsf(s1 - s2) + fabsf(e1 - e2)) * wb * inv_nb;
-        const float gs = wb * inv_nb * sgn(s1 - s2), ge = wb * inv_nb * sgn(e1 - e2);
-        gc = gs + ge;
-        gl = 0.5f * (ge - gs);
-        // GIoU
-        const float lo = fmaxf(s1, s2), hi = fminf(e1, e2);
-        const float inter = fmaxf(hi - lo, 0.f);
-        const float di_e = (hi - lo > 0.f && e1 < e2) ? 1.f : 0.f;     // d inter / d e1
-        const float di_s = (hi - lo > 0.f && s1 > s2) ? -1.f : 0.f;    // d inter / d s1
-        const float uni = (e1 - s1) + (e2 - s2) - inter;
-        const float du_e = 1.f - di_e, du_s = -1.f - di_s;
-        const float hull = fmaxf(fmaxf(e1, e2) - fminf(s1, s2), 0.f);
-        const float dh_e = e1 > e2 ? 1.f : 0.f, dh_s = s1 < s2 ? -1.f : 0.f;
-        const float giou = inter / uni - (hull - uni) / hull;
-        l_gi += (1.f - giou) * wb * inv_nb;
-        // d giou = d(inter/uni) + d(uni/hull)
-        const float dg_e = (di_e * uni - inter * du_e) / (uni * uni) + (du_e * hull - uni * dh_e) / (hull * hull);
-        const float dg_s = (di_s * uni - inter * du_s) / (uni * uni) + (du_s * hull - uni * dh_s) / (hull * hull);
-        const float k = -wb * inv_nb;
-        gc2 = k * (dg_s + dg_e);
-        gl2 = 0.5f * k * (dg_e - dg_s);
-      }
-      gbx[0] = gc;
-      gbx[1] = gl;
-      gbx2[0] = gc2;
-      gbx2[1] = gl2;
+      l_ce = row * ks;
+    } else {
+      float se = 0.f;
+      for (int c = 0; c < C1; ++c) se += __expf(x[c] - m);
+      const float lse = m + __logf(se);
+      const float w = a.empty_weight[tc];
+      l_ce = w * (lse - x[tc]) * coef * inv_nb;
+      const float gscale = coef * w * inv_nb;
+      for (int c = 0; c < C1; ++c) gx[c] = gscale * (__expf(x[c] - lse) - (c == tc ? 1.f : 0.f));
     }
-    l_ce = block_sum_1024(l_ce, red);
-    l_bb = block_sum_1024(l_bb, red);
-    l_gi = block_sum_1024(l_gi, red);           // (the barriers inside also publish this layer's card[] counters)
-    float cerr = 0.f;                           // |#predicted events - #targets| averaged over ALL clips
-    for (int b = t; b < B; b += 1024) cerr += fabsf((float)card[d * B + b] - a.tgt_len[b]) / (float)B;
-    cerr = block_sum_1024(cerr, red);
-    if (d == 0) {
-      n_hit = block_sum_1024(n_hit, red);
-      n_cnt = block_sum_1024(n_cnt, red);
-      if (t == 0) {
-        a.out[SLOT_HIT] = n_hit;
-        a.out[SLOT_CNT] = n_cnt;
-        a.out[4 * L + 4] = 100.f - 100.f * n_hit / fmaxf(n_cnt, 1.f);     // class_error
-      }
+    if (d == 0 && wb > 0.f) {
+      n_cnt = 1.f;
+      if (amax == tc) n_hit = 1.f;
     }
-    if (t == 0) {
-      a.out[4 * d] = l_ce;
-      a.out[4 * d + 1] = l_bb;
-      a.out[4 * d + 2] = l_gi;
-      a.out[4 * d + 3] = cerr;
+    // boxes (centre, length) -> interval [s, e]
+    const float* bx = a.boxes + xrow * 2;
+    float gc = 0.f, gl = 0.f, gc2 = 0.f, gl2 = 0.f;
+    if (wb > 0.f) {
+      const float s1 = bx[0] - 0.5f * bx[1], e1 = bx[0] + 0.5f * bx[1];
+      const float tcn = a.tbox[2 * di], tln = a.tbox[2 * di + 1];
+      const float s2 = tcn - 0.5f * tln, e2 = tcn + 0.5f * tln;
+      // L1 on the fake boxes [s,0,e,1]: |s1-s2| + |e1-e2|
+      l_bb = (fabsf(s1 - s2) + fabsf(e1 - e2)) * wb * inv_nb;
+      const float gs = wb * inv_nb * sgn(s1 - s2), ge = wb * inv_nb * sgn(e1 - e2);
+      gc = gs + ge;
+      gl = 0.5f * (ge - gs);
+      // GIoU
+      const float lo = fmaxf(s1, s2), hi = fminf(e1, e2);
+      const float inter = fmaxf(hi - lo, 0.f);
+      const float di_e = (hi - lo > 0.f && e1 < e2) ? 1.f : 0.f;     // d inter / d e1
+      const float di_s = (hi - lo > 0.f && s1 > s2) ? -1.f : 0.f;    // d inter / d s1
+      const float uni = (e1 - s1) + (e2 - s2) - inter;
+      const float du_e = 1.f - di_e, du_s = -1.f - di_s;
+      const float hull = fmaxf(fmaxf(e1, e2) - fminf(s1, s2), 0.f);
+      const float dh_e = e1 > e2 ? 1.f : 0.f, dh_s = s1 < s2 ? -1.f : 0.f;
+      const float giou = inter / uni - (hull - uni) / hull;
+      l_gi = (1.f - giou) * wb * inv_nb;
+      // d giou = d(inter/uni) + d(uni/hull)
+      const float dg_e = (di_e * uni - inter * du_e) / (uni * uni) + (du_e * hull - uni * dh_e) / (hull * hull);
+      const float dg_s = (di_s * uni - inter * du_s) / (uni * uni) + (du_s * hull - uni * dh_s) / (hull * hull);
+      const float k = -wb * inv_nb;
+      gc2 = k * (dg_s + dg_e);
+      gl2 = 0.5f * k * (dg_e - dg_s);
     }
-    total += a.w_ce[d] * l_ce + a.w_bbox[d] * l_bb + a.w_giou[d] * l_gi;
+    gbx[0] = gc;
+    gbx[1] = gl;
+    gbx2[0] = gc2;
+    gbx2[1] = gl2;
+    rv[0] = l_ce; rv[1] = l_bb; rv[2] = l_gi; rv[3] = n_hit; rv[4] = n_cnt;
+  }
+  __syncthreads();                              // (block scope: the rowvals written above are visible to every wave)
+
+  // ---------------- phase 2: one wave per (dense layer, quantity) column; fixed summation order
+  for (int job = wave; job < L * 6; job += 16) {
+    const int d = job / 6, k = job - d * 6;
+    float v = 0.f;
+    if (k < 5) {
+      const float* col = rowvals + (long)d * BQ * 5 + k;
+      for (int i = lane; i < BQ; i += 64) v += col[(long)i * 5];
+    } else {                                    // |#predicted events - #targets| averaged over ALL clips
+      for (int bb = lane; bb < B; bb += 64) v += fabsf((float)card[d * B + bb] - a.tgt_len[bb]) / (float)B;
+    }
+    v = wave_sum(v);
+    if (lane == 0) sums[d][k] = v;
+  }
+  __syncthreads();
+  float total = 0.f;
+  for (int d = 0; d < L; ++d) total += a.w_ce[d] * sums[d][0] + a.w_bbox[d] * sums[d][1] + a.w_giou[d] * sums[d][2];
+  if (t < L) {
+    a.out[4 * t] = sums[t][0];
+    a.out[4 * t + 1] = sums[t][1];
+    a.out[4 * t + 2] = sums[t][2];
+    a.out[4 * t + 3] = sums[t][5];
+  }
+  if (t == 0) {
+    const float n_hit = sums[0][3], n_cnt = sums[0][4];
+    a.out[SLOT_HIT] = n_hit;
+    a.out[SLOT_CNT] = n_cnt;
+    a.out[4 * L + 4] = 100.f - 100.f * n_hit / fmaxf(n_cnt, 1.f);     // class_error
   }
 
   // ---------------- audio-tag BCE (mean over n_lab x C), torch semantics: log clamped at -100, grad denominator >= 1e-12
@@ -250,64 +266,75 @@ __global__ __launch_bounds__(256) void set_criterion_bwd_kernel(const SedtCriter
 // each step is a single wave-wide min/argmin (ties -> lowest column, as the serial scan of csrc/host.cpp), potentials in
 // double precision like scipy.  The assignment is turned into the dense targets the loss kernel reads, so a training
 // step needs no device->host copy at all and the whole step can live in one HIP graph.
-__device__ __forceinline__ double shfl_d(double v, int src) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl(lo, src, 64);
-  hi = __shfl(hi, src, 64);
-  return __hiloint2double(hi, lo);
-}
-
 // rows (n) <= cols (m) <= 63; cost(i, j) for 0-based row i, column j.  Returns in lane j (1..m) the 1-based row assigned
-// to column j (0 = none).  Every lane of the wave must call this.
+// to column j (0 = none).  Every lane of the (single-wave) workgroup must call this.
+// Lane j owns column j (its potential v, its best reduced cost minv, its predecessor `way`); the row potentials u[], the column ->
+// row map p[] and the candidates of the column scan live in LDS (wk: 64 doubles u, 64 doubles scan values, 64 ints p), where any
+// lane reads any entry with one broadcast load: the column scan is m such loads instead of a 6-level butterfly of three
+// cross-lane permutes per level in double precision (the first version: 35 us for the 192 problems of a C2 step).
+struct LsaWork { double u[64]; double sv[64]; int p[64]; };
 template <typename F>
-__device__ int wave_lsa(int n, int m, F cost) {
+__device__ int wave_lsa(int n, int m, F cost, LsaWork* wk) {
   const int lane = threadIdx.x & 63;
   const double INF = 1e300;
-  double u = 0.0, v = 0.0;        // lane r: potential of row r (1-based); lane j: potential of column j
-  int p = 0, way = 0;             // lane j: row matched to column j; predecessor column on the alternating path
+  double v = 0.0;                 // lane j: potential of column j
+  int way = 0;                    // lane j: predecessor column on the alternating path
+  wk->u[lane] = 0.0;
+  wk->p[lane] = 0;
+  __syncthreads();
   for (int i = 1; i <= n; ++i) {
-    if (lane == 0) p = i;
+    if (lane == 0) wk->p[0] = i;
+    __syncthreads();
     int j0 = 0, guard = 0;
     double minv = INF;
-    bool used = false, in_rows = false;
+    bool used = false;
     do {
       if (lane == j0) used = true;
-      const int i0 = __shfl(p, j0, 64);
-      if (lane == i0) in_rows = true;
-      const double u0 = shfl_d(u, i0);
+      const int i0 = wk->p[j0];
+      const double u0 = wk->u[i0];
       const bool cand = lane >= 1 && lane <= m && !used;
       if (cand) {
         const double cur = (double)cost(i0 - 1, lane - 1) - u0 - v;
         if (cur < minv) { minv = cur; way = j0; }
       }
-      // delta = min over candidate columns, j1 = lowest column attaining it
-      double best = cand ? minv : INF;
-      int bj = cand ? lane : 64;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const double ob = shfl_d(best, lane ^ o);
-        const int oj = __shfl(bj, lane ^ o, 64);
-        if (ob < best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+      wk->sv[lane] = cand ? minv : INF;
+      __syncthreads();
+      // delta = min over candidate columns, j1 = lowest column attaining it (the serial scan of csrc/host.cpp)
+      double delta = INF;
+      int j1 = 64;
+      for (int j = 1; j <= m; ++j) {
+        const double c = wk->sv[j];
+        if (c < delta) { delta = c; j1 = j; }
       }
-      const double delta = best;
-      if (in_rows) u += delta;
-      if (used) v -= delta; else minv -= delta;
-      j0 = bj;
-    } while (j0 < 64 && __shfl(p, j0, 64) != 0 && ++guard <= m + 1);
+      // rows on the alternating tree (the rows matched to the used columns) and the used columns move by delta
+      const int r = used ? wk->p[lane] : 0;     // a used column's row gets u += delta (distinct rows: no write conflict)
+      __syncthreads();                          // (all lanes have read sv / p / u of this step)
+      if (used) {
+        v -= delta;
+        wk->u[r] += delta;
+      } else {
+        minv -= delta;
+      }
+      __syncthreads();
+      j0 = j1;
+    } while (j0 < 64 && wk->p[j0] != 0 && ++guard <= m + 1);
     if (j0 >= 64) j0 = 0;         // (unreachable with finite costs)
     guard = 0;
     do {                          // augment along the path
       const int j1 = __shfl(way, j0, 64);
-      const int pj1 = __shfl(p, j1, 64);
-      if (lane == j0) p = pj1;
+      const int pj1 = wk->p[j1];
+      __syncthreads();
+      if (lane == j0) wk->p[j0] = pj1;
+      __syncthreads();
       j0 = j1;
     } while (j0 && ++guard <= m + 1);
   }
-  return p;
+  return wk->p[lane];
 }
 
 __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
   extern __shared__ float lds[];
+  __shared__ LsaWork wk;
   const int lane = threadIdx.x;
   const int L = a.L, B = a.B, ns = a.ns, Q = a.Q, C = a.C, C1 = a.C + 1;
   const int ns_eff = a.split ? min(a.split[0], ns) : ns;          // (see set_criterion_kernel: the split as data)
@@ -386,7 +413,7 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
   int asg = -1;
   if (n > 0) {
     if (n <= Q) {          // every target gets a query: rows = targets, columns = queries
-      const int p = wave_lsa(n, Q, [&](int t, int q) { return cst[q * n + t]; });
+      const int p = wave_lsa(n, Q, [&](int t, int q) { return cst[q * n + t]; }, &wk);
       if (lane >= 1 && lane <= Q && p > 0) {
         // lane j holds column j = query j-1; move the result to the lane of the query
         asg = p - 1;
@@ -394,7 +421,7 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
       asg = __shfl(asg, lane + 1 < 64 ? lane + 1 : 63, 64);
       if (lane >= Q) asg = -1;
     } else {               // more targets than queries: rows = queries, columns = targets
-      const int p = wave_lsa(Q, n, [&](int q, int t) { return cst[q * n + t]; });
+      const int p = wave_lsa(Q, n, [&](int q, int t) { return cst[q * n + t]; }, &wk);
       // lane j (1..n) holds the query (1-based) matched to target j-1: scatter through LDS
       int* tmp = reinterpret_cast<int*>(lds);
       __syncthreads();
@@ -455,18 +482,21 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
 
 }  // namespace sedt
 
-extern "C" int sedt_set_criterion(const SedtCriterion* args, void* stream) {
+extern "C" size_t sedt_set_criterion_scratch(int L, int B, int Q) { return (size_t)L * B * Q * 5 * sizeof(float); }
+
+extern "C" int sedt_set_criterion(const SedtCriterion* args, float* scratch, void* stream) {
   using namespace sedt;
   SEDT_REQUIRE(args != nullptr, "set_criterion: null args");
   const SedtCriterion& a = *args;
   SEDT_REQUIRE(a.L >= 1 && a.L <= SEDT_CRIT_MAXL && a.C >= 1 && a.C <= 63, "set_criterion: L=%d (1..%d), C=%d", a.L, SEDT_CRIT_MAXL, a.C);
+  SEDT_REQUIRE(scratch != nullptr, "set_criterion: scratch (sedt_set_criterion_scratch bytes) is required");
   SEDT_REQUIRE(a.logits && a.boxes && a.dlogits && a.dboxes && a.dboxes2 && a.tc && a.coef && a.wbox && a.tbox && a.tgt_len &&
                    a.empty_weight && a.out,
                "set_criterion: null pointer");
   SEDT_REQUIRE((a.at == nullptr) == (a.dat == nullptr), "set_criterion: at and dat go together");
   SEDT_REQUIRE(a.L * a.B <= SEDT_CRIT_MAXCARD, "set_criterion: L*B = %d exceeds %d", a.L * a.B, SEDT_CRIT_MAXCARD);
   SEDT_REQUIRE(a.q0 >= 0 && a.Qs >= a.q0 + a.Q, "set_criterion: query window q0=%d Q=%d outside Qs=%d", a.q0, a.Q, a.Qs);
-  hipLaunchKernelGGL(set_criterion_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(set_criterion_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), a, scratch);
   return check_launch("set_criterion");
 }
 

@@ -610,13 +610,24 @@ __global__ void multi_sumsq_kernel(const SedtChunk* __restrict__ table, float* _
   } else {
     const float* g = reinterpret_cast<const float*>(c.g);
     int i0 = 0;
-    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {          // 16-byte loads over the aligned body
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {          // 16-byte loads over the aligned body, four in flight per lane
       const int n4 = c.n >> 2;
       const float4* g4 = reinterpret_cast<const float4*>(g);
-      for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+      const int bd = blockDim.x;
+      int i = threadIdx.x;
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (; i + 3 * bd < n4; i += 4 * bd) {
+        const float4 a = g4[i], b = g4[i + bd], cc = g4[i + 2 * bd], d = g4[i + 3 * bd];
+        s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+        s1 += b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+        s2 += cc.x * cc.x + cc.y * cc.y + cc.z * cc.z + cc.w * cc.w;
+        s3 += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+      }
+      for (; i < n4; i += bd) {
         const float4 a = g4[i];
         s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
       }
+      s = (s + s1) + (s2 + s3);
       i0 = n4 << 2;
     }
     for (int i = i0 + threadIdx.x; i < c.n; i += blockDim.x) s += g[i] * g[i];

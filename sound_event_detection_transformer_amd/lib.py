@@ -126,7 +126,8 @@ SIGNATURES = {
     'sedt_multi_ema': (_i, [_vp, _i, _f, _vp, _vp]),
     'sedt_multi_sumsq': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'sedt_multi_adamw': (_i, [_vp, _i, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
-    'sedt_set_criterion': (_i, [C.POINTER(SedtCriterion), _vp]),
+    'sedt_set_criterion_scratch': (_sz, [_i, _i, _i]),
+    'sedt_set_criterion': (_i, [C.POINTER(SedtCriterion), _vp, _vp]),
     'sedt_set_criterion_bwd': (_i, [C.POINTER(SedtCriterion), _vp, _vp, _vp, _vp, _vp, _vp]),
     'sedt_match_targets': (_i, [C.POINTER(SedtMatch), _vp]),
     'sedt_feature_loss': (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -758,7 +758,8 @@ def set_criterion(logits, boxes, at, dense, empty_weight, layer_of, w_ce, w_bbox
     if dense.get('split') is not None:              # {ns, n_lab} of this batch as device words (mix-up moves the boundary)
         assert dense['split'].dtype == torch.int32 and dense['split'].is_cuda and dense['split'].numel() >= 2
         a.split = dense['split'].data_ptr()
-    L.check(L.load().sedt_set_criterion(a, L.stream_ptr()), 'set_criterion')
+    scratch = torch.empty(Lh * B * Q * 5, device=logits.device, dtype=torch.float32)
+    L.check(L.load().sedt_set_criterion(a, _p(scratch), L.stream_ptr()), 'set_criterion')
     return out, total, (a, dl, db, db2, dat, (Lh, B, Qs, C1))
 
 
