@@ -73,10 +73,26 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
     float* gbx = a.dboxes + mrow * 2;
     float* gbx2 = a.dboxes2 + mrow * 2;
     float* rv = rowvals + (long)r * 5;
+    // the row's logits: all loads issued before the first use (a `for c < C1` loop with the load inside serialises C1 global
+    // latencies per pass - two thirds of this kernel's time in its first form); C + 1 <= 16 in every configuration, wider rows
+    // take the loop
+    constexpr int XR = 16;
+    float xr[XR];
+    const bool small = C1 <= XR;
+    if (small) {
+#pragma unroll
+      for (int c = 0; c < XR; ++c) xr[c] = c < C1 ? x[c] : -INFINITY;
+    }
     float m = -INFINITY;
     int amax = 0;
-    for (int c = 0; c < C1; ++c)
-      if (x[c] > m) { m = x[c]; amax = c; }
+    if (small) {
+#pragma unroll
+      for (int c = 0; c < XR; ++c)
+        if (xr[c] > m) { m = xr[c]; amax = c; }
+    } else {
+      for (int c = 0; c < C1; ++c)
+        if (x[c] > m) { m = x[c]; amax = c; }
+    }
     if (amax != C) atomicAdd(&card[d * B + b], 1);
     if (b >= ns_eff) {                        // not strongly labelled: no CE / box loss, zero grads
       for (int c = 0; c < C1; ++c) gx[c] = 0.f;
@@ -111,6 +127,20 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
         gx[c] = ks * at * (dce * mg + ce * dmg * dmod);
       }
       l_ce = row * ks;
+    } else if (small) {
+      float se = 0.f, xt = 0.f;
+#pragma unroll
+      for (int c = 0; c < XR; ++c) {
+        se += __expf(xr[c] - m);               // (-inf pads add 0)
+        xt = c == tc ? xr[c] : xt;
+      }
+      const float lse = m + __logf(se);
+      const float w = a.empty_weight[tc];
+      l_ce = w * (lse - xt) * coef * inv_nb;
+      const float gscale = coef * w * inv_nb;
+#pragma unroll
+      for (int c = 0; c < XR; ++c)
+        if (c < C1) gx[c] = gscale * (__expf(xr[c] - lse) - (c == tc ? 1.f : 0.f));
     } else {
       float se = 0.f;
       for (int c = 0; c < C1; ++c) se += __expf(x[c] - m);
@@ -266,75 +296,76 @@ __global__ __launch_bounds__(256) void set_criterion_bwd_kernel(const SedtCriter
 // each step is a single wave-wide min/argmin (ties -> lowest column, as the serial scan of csrc/host.cpp), potentials in
 // double precision like scipy.  The assignment is turned into the dense targets the loss kernel reads, so a training
 // step needs no device->host copy at all and the whole step can live in one HIP graph.
+// ---- wave-uniform helpers of the assignment solver: everything below runs in ONE wave with one lane per column, and every
+// index it broadcasts (the column j0 being expanded, its row i0) is the same in all lanes - so a value of "lane j0" is a
+// v_readlane (a few cycles) rather than a cross-lane permute through the LDS crossbar, and the minimum over the lanes is a DPP
+// prefix-minimum inside each row of 16 lanes plus four readlanes (the first versions - a 6-level butterfly of three permutes per
+// level in double precision, then a serial scan over LDS - spent 35 us on the 192 small problems of a C2 step).
+__device__ __forceinline__ int rl_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ double rl_d(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_min_step(double v) {     // min(v, v of the lane CTRL names); a lane without source keeps v
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return fmin(v, __hiloint2double(hi2, lo2));
+}
+__device__ __forceinline__ double wave_min_d(double v) {       // the minimum over all 64 lanes, in every lane
+  v = dpp_min_step<0x111>(v);      // row_shr:1
+  v = dpp_min_step<0x112>(v);      // row_shr:2
+  v = dpp_min_step<0x114>(v);      // row_shr:4
+  v = dpp_min_step<0x118>(v);      // row_shr:8  -> lane 15 of every row holds the row's minimum
+  return fmin(fmin(rl_d(v, 15), rl_d(v, 31)), fmin(rl_d(v, 47), rl_d(v, 63)));
+}
+
 // rows (n) <= cols (m) <= 63; cost(i, j) for 0-based row i, column j.  Returns in lane j (1..m) the 1-based row assigned
-// to column j (0 = none).  Every lane of the (single-wave) workgroup must call this.
-// Lane j owns column j (its potential v, its best reduced cost minv, its predecessor `way`); the row potentials u[], the column ->
-// row map p[] and the candidates of the column scan live in LDS (wk: 64 doubles u, 64 doubles scan values, 64 ints p), where any
-// lane reads any entry with one broadcast load: the column scan is m such loads instead of a 6-level butterfly of three
-// cross-lane permutes per level in double precision (the first version: 35 us for the 192 problems of a C2 step).
-struct LsaWork { double u[64]; double sv[64]; int p[64]; };
+// to column j (0 = none).  Every lane of the wave must call this.
 template <typename F>
-__device__ int wave_lsa(int n, int m, F cost, LsaWork* wk) {
+__device__ int wave_lsa(int n, int m, F cost) {
   const int lane = threadIdx.x & 63;
   const double INF = 1e300;
-  double v = 0.0;                 // lane j: potential of column j
-  int way = 0;                    // lane j: predecessor column on the alternating path
-  wk->u[lane] = 0.0;
-  wk->p[lane] = 0;
-  __syncthreads();
+  double u = 0.0, v = 0.0;        // lane r: potential of row r (1-based); lane j: potential of column j
+  int p = 0, way = 0;             // lane j: row matched to column j; predecessor column on the alternating path
   for (int i = 1; i <= n; ++i) {
-    if (lane == 0) wk->p[0] = i;
-    __syncthreads();
+    if (lane == 0) p = i;
     int j0 = 0, guard = 0;
     double minv = INF;
-    bool used = false;
+    bool used = false, in_rows = false;
     do {
       if (lane == j0) used = true;
-      const int i0 = wk->p[j0];
-      const double u0 = wk->u[i0];
+      const int i0 = rl_i(p, j0);
+      if (lane == i0) in_rows = true;
+      const double u0 = rl_d(u, i0);
       const bool cand = lane >= 1 && lane <= m && !used;
       if (cand) {
         const double cur = (double)cost(i0 - 1, lane - 1) - u0 - v;
         if (cur < minv) { minv = cur; way = j0; }
       }
-      wk->sv[lane] = cand ? minv : INF;
-      __syncthreads();
-      // delta = min over candidate columns, j1 = lowest column attaining it (the serial scan of csrc/host.cpp)
-      double delta = INF;
-      int j1 = 64;
-      for (int j = 1; j <= m; ++j) {
-        const double c = wk->sv[j];
-        if (c < delta) { delta = c; j1 = j; }
-      }
-      // rows on the alternating tree (the rows matched to the used columns) and the used columns move by delta
-      const int r = used ? wk->p[lane] : 0;     // a used column's row gets u += delta (distinct rows: no write conflict)
-      __syncthreads();                          // (all lanes have read sv / p / u of this step)
-      if (used) {
-        v -= delta;
-        wk->u[r] += delta;
-      } else {
-        minv -= delta;
-      }
-      __syncthreads();
+      // delta = min over candidate columns, j1 = lowest column attaining it (ties -> lowest column, as the serial scan of host.cpp)
+      const double mine = cand ? minv : INF;
+      const double delta = wave_min_d(mine);
+      const unsigned long long at_min = __ballot(cand && mine == delta);
+      const int j1 = at_min ? (int)__builtin_ctzll(at_min) : 64;
+      if (in_rows) u += delta;
+      if (used) v -= delta; else minv -= delta;
       j0 = j1;
-    } while (j0 < 64 && wk->p[j0] != 0 && ++guard <= m + 1);
+    } while (j0 < 64 && rl_i(p, j0) != 0 && ++guard <= m + 1);
     if (j0 >= 64) j0 = 0;         // (unreachable with finite costs)
     guard = 0;
     do {                          // augment along the path
-      const int j1 = __shfl(way, j0, 64);
-      const int pj1 = wk->p[j1];
-      __syncthreads();
-      if (lane == j0) wk->p[j0] = pj1;
-      __syncthreads();
+      const int j1 = rl_i(way, j0);
+      const int pj1 = rl_i(p, j1);
+      if (lane == j0) p = pj1;
       j0 = j1;
     } while (j0 && ++guard <= m + 1);
   }
-  return wk->p[lane];
+  return p;
 }
 
 __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
   extern __shared__ float lds[];
-  __shared__ LsaWork wk;
   const int lane = threadIdx.x;
   const int L = a.L, B = a.B, ns = a.ns, Q = a.Q, C = a.C, C1 = a.C + 1;
   const int ns_eff = a.split ? min(a.split[0], ns) : ns;          // (see set_criterion_kernel: the split as data)
@@ -379,7 +410,20 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
         const float pos = a.alpha_fl * powf(1.f - p, a.gamma_fl) * (-logf(p + 1e-8f));
         prob[lane * C1 + c] = pos - neg;
       }
-    } else {                               // -softmax probability
+    } else if (C1 <= 16) {                 // -softmax probability; the row's logits loaded up front (see set_criterion_kernel)
+      float xr[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) xr[c] = c < C1 ? x[c] : -INFINITY;
+      float m = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) m = fmaxf(m, xr[c]);
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) se += expf(xr[c] - m);
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c < C1) prob[lane * C1 + c] = -(expf(xr[c] - m) / se);
+    } else {
       float m = -INFINITY;
       for (int c = 0; c < C1; ++c) m = fmaxf(m, x[c]);
       float se = 0.f;
@@ -413,7 +457,7 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
   int asg = -1;
   if (n > 0) {
     if (n <= Q) {          // every target gets a query: rows = targets, columns = queries
-      const int p = wave_lsa(n, Q, [&](int t, int q) { return cst[q * n + t]; }, &wk);
+      const int p = wave_lsa(n, Q, [&](int t, int q) { return cst[q * n + t]; });
       if (lane >= 1 && lane <= Q && p > 0) {
         // lane j holds column j = query j-1; move the result to the lane of the query
         asg = p - 1;
@@ -421,7 +465,7 @@ __global__ __launch_bounds__(64) void match_targets_kernel(const SedtMatch a) {
       asg = __shfl(asg, lane + 1 < 64 ? lane + 1 : 63, 64);
       if (lane >= Q) asg = -1;
     } else {               // more targets than queries: rows = queries, columns = targets
-      const int p = wave_lsa(Q, n, [&](int q, int t) { return cst[q * n + t]; }, &wk);
+      const int p = wave_lsa(Q, n, [&](int q, int t) { return cst[q * n + t]; });
       // lane j (1..n) holds the query (1-based) matched to target j-1: scatter through LDS
       int* tmp = reinterpret_cast<int*>(lds);
       __syncthreads();
