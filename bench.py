@@ -553,13 +553,14 @@ def other_configs(args, dev, keep_alive, replays=10):
 
 
 def pmc_traffic(config):
-    """HBM-side bytes per step from the committed PMC profile of this config (profiles/r02_pmc_<config>.json), or None"""
-    path = os.path.join(ROOT, 'profiles', f'r02_pmc_{config}.json')
-    try:
-        with open(path) as f:
-            return json.load(f)
-    except Exception:
-        return None
+    """HBM-side bytes per step from the committed PMC profile of this config (profiles/rNN_pmc_<config>.json, newest round), or None"""
+    for rnd in ('r03', 'r02'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', f'{rnd}_pmc_{config}.json')) as f:
+                return json.load(f)
+        except Exception:
+            continue
+    return None
 
 
 def main():
