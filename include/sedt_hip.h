@@ -70,6 +70,10 @@ int sedt_version(void);
  * epilogue, in order: v = acc*scale[n] + bias[n]; if(!act_post_res) v = act(v);
  *   dropout(v); v += res[(res_mod ? m % res_mod : m)*ldr + n]; if(act_post_res) v = act(v);
  *   v = mask[m*ldm+n] > 0 ? v : 0; v *= alpha; store as f32 (out_f32) or the compute dtype.
+ * 1-bit ReLU masks (round 3): a backward pass needs only the SIGN of a saved post-ReLU activation.  mask_bits != 0: `mask` is a
+ *   uint8 bit image - bit (n & 7) of mask[m*ldm + (n >> 3)], ldm in BYTES - instead of the activation itself (1/16 of the bytes of a
+ *   bf16 tensor); bits_out != null: the same image of the value stored to C (bit = v > 0) is written to bits_out[m*ldbits + (n >> 3)]
+ *   (N must be a multiple of 8).  trans == 0 only.
  */
 typedef struct SedtIgemm {
   int32_t M, N, K;
@@ -100,6 +104,10 @@ typedef struct SedtIgemm {
   float* colsum_out;      /* trans == 1, bf16 LDS-DMA kernel only: if non-null, per-split column sums of A over the
                              reduction axis (= the bias gradient sum_pix dY[pix][m]) are written to colsum_out[z][M];
                              sedt_wgrad_reduce adds them up.  sedt_igemm fails if the fast kernel cannot take the problem. */
+  uint8_t* bits_out;      /* or null: sign bits of the stored output (see "1-bit ReLU masks") */
+  int64_t ldbits;         /* bytes per row of bits_out */
+  int32_t mask_bits;      /* != 0: `mask` is a bit image, ldm in bytes */
+  int32_t pad_;
 } SedtIgemm;
 
 int sedt_igemm(const SedtIgemm* args, int dtype, void* stream);

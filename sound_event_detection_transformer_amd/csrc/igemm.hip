@@ -354,7 +354,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int
   const uint32_t thresh = drop_threshold(p.drop_p);
   const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
   const T* resT = reinterpret_cast<const T*>(p.res);
-  const T* maskT = reinterpret_cast<const T*>(p.mask);
+  const T* maskT = p.mask_bits ? nullptr : reinterpret_cast<const T*>(p.mask);
+  const uint8_t* maskB = p.mask_bits ? reinterpret_cast<const uint8_t*>(p.mask) : nullptr;
   // one 32x32 accumulator tile; called with compile-time (i, j) so acc stays in registers
   auto epilogue_tile = [&](const f32x16& a, const int i, const int j) {
     const int col = n0 + wn + j * 32 + (lane & 31);
@@ -367,6 +368,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (p.bits_out && !slab) {
+        // (uniform branch) every lane takes part in the ballot below: lanes outside the matrix contribute a 0 bit
+        const bool ok = row < p.M && colok;
+        float v = 0.f;
+        if (ok) {
+          v = a[r] * sc + bi;
+          if (!p.act_post_res) {
+            if (p.act == SEDT_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (p.act == SEDT_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+          }
+          if (p.drop_p > 0.f) v = drop_keep(seed, (uint64_t)row * (uint64_t)p.N + col, thresh) ? v * inv_keep : 0.f;
+          if (resT) {
+            long rr = p.res_mod > 0 ? (row % p.res_mod) : row;
+            v += (float)resT[rr * p.ldr + col];
+          }
+          if (p.act_post_res) {
+            if (p.act == SEDT_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (p.act == SEDT_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+          }
+          if (maskT) v = ((float)maskT[(long)row * p.ldm + col] > 0.f) ? v : 0.f;
+          if (maskB) v = ((maskB[(long)row * p.ldm + (col >> 3)] >> (col & 7)) & 1) ? v : 0.f;
+          v *= p.alpha;
+          if (p.out_f32) reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = v;
+          else { const T tv = (T)v; reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = tv; v = (float)tv; }
+        }
+        const unsigned long long pos = __ballot(ok && v > 0.f);       // lanes 0..31: this row's 32 columns, 32..63: row + 4
+        if (ok && (lane & 7) == 0) p.bits_out[(long)row * p.ldbits + (col >> 3)] = (uint8_t)(pos >> (lane & ~7));
+        continue;
+      }
       if (!(row < p.M && colok)) continue;
       float v = a[r];
       if (slab) {
@@ -388,6 +418,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int
         else if (p.act == SEDT_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
       }
       if (maskT) v = ((float)maskT[(long)row * p.ldm + col] > 0.f) ? v : 0.f;
+      if (maskB) v = ((maskB[(long)row * p.ldm + (col >> 3)] >> (col & 7)) & 1) ? v : 0.f;
       v *= p.alpha;
       if (p.out_f32) reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = v;
       else reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = (T)v;

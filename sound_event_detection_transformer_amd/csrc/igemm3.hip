@@ -67,8 +67,11 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   constexpr int NCH = BM * CPR / NT;                   // chunks per thread
   static_assert(BM * CPR % NT == 0, "epilogue chunks must divide evenly");
   const bf16_t* resT = reinterpret_cast<const bf16_t*>(p.res);
-  const bf16_t* maskT = reinterpret_cast<const bf16_t*>(p.mask);
+  const bool mbits = p.mask_bits != 0;                 // the mask is a 1-bit image: one BYTE per 8-column chunk
+  const bf16_t* maskT = mbits ? nullptr : reinterpret_cast<const bf16_t*>(p.mask);
+  const uint8_t* maskB = mbits ? reinterpret_cast<const uint8_t*>(p.mask) : nullptr;
   bf16x8 res_pf[NCH], mask_pf[NCH];
+  uint32_t mbit_pf[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int u = t + c * NT;
@@ -80,6 +83,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
         res_pf[c] = *reinterpret_cast<const bf16x8*>(resT + (long)rrow * p.ldr + col);
       }
       if (maskT) mask_pf[c] = *reinterpret_cast<const bf16x8*>(maskT + (long)row * p.ldm + col);
+      if (maskB) mbit_pf[c] = maskB[(long)row * p.ldm + (col >> 3)];
     }
   }
 
@@ -443,6 +447,11 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ((float)mv[e] > 0.f) ? v[e] : 0.f;
     }
+    if (maskB) {
+      const uint32_t mb = mbit_pf[c];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ((mb >> e) & 1u) ? v[e] : 0.f;
+    }
     if (p.alpha != 1.f) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
@@ -451,6 +460,12 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
     *reinterpret_cast<bf16x8*>(outT + (long)row * p.ldc + col) = o;
+    if (p.bits_out) {                               // sign bits of what was stored: the backward's ReLU mask at 1/16 of the bytes
+      uint32_t ob = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ob |= ((float)o[e] > 0.f ? 1u : 0u) << e;
+      p.bits_out[(long)row * p.ldbits + (col >> 3)] = (uint8_t)ob;
+    }
   }
 }
 
@@ -730,7 +745,7 @@ int igemm_lds_try(const SedtIgemm& p, hipStream_t st) {
   if ((p.K & 7) || (p.N & 7) || (p.lda & 7) || (p.ldb & 7) || (p.ldc & 7)) return -1;
   if (!al16(p.A) || !al16(p.B) || !al16(p.C)) return -1;
   if (p.res && (!al16(p.res) || (p.ldr & 7))) return -1;
-  if (p.mask && (!al16(p.mask) || (p.ldm & 7))) return -1;
+  if (p.mask && !p.mask_bits && (!al16(p.mask) || (p.ldm & 7))) return -1;
   if (p.conv && (p.Ci % BK2)) return -1;
   // bytes addressable through the A descriptor: every gathered pixel row + one K tile past its start
   long a_rows = p.conv ? (long)((p.M + (long)p.Ho * p.Wo - 1) / ((long)p.Ho * p.Wo)) * p.Hi * p.Wi : (long)p.M;

@@ -60,11 +60,13 @@ class LinearFn(Function):
     """y = act(x @ W^T + b); act in {none, relu, sigmoid}; optional f32 output (heads)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, out_f32, dt, relu_input=False):
+    def forward(ctx, x, weight, bias, act, out_f32, dt, relu_input=False, x_bits=None):
         """relu_input: x is a post-ReLU tensor whose producer expects a gradient already masked by x > 0 (fused into the
-        dgrad epilogue here instead of a separate pass in the producer's backward)"""
+        dgrad epilogue here instead of a separate pass in the producer's backward); x_bits: that mask as the producer's 1-bit
+        image (uint8 [rows, cols / 8]) - read instead of x itself in the backward"""
         x = _as(x, dt)
         ctx.relu_input = relu_input
+        ctx.x_bits = x_bits if relu_input else None
         ctx.dt, ctx.act, ctx.out_f32 = dt, act, out_f32
         ctx.has_bias = bias is not None
         # heads with a handful of outputs (class 11, box 2, audio tag 10): direct kernels on the master weight
@@ -87,7 +89,7 @@ class LinearFn(Function):
             gx, gw, gb = ops.skinny_linear_bwd(dt, gy.float() if gy.dtype != torch.float32 else gy, y, weight, x, ctx.act,
                                                mask=x if ctx.relu_input else None, need_gx=ctx.needs_input_grad[0],
                                                need_gw=ctx.needs_input_grad[1], need_gb=ctx.has_bias and ctx.needs_input_grad[2])
-            return gx, gw, gb, None, None, None, None
+            return gx, gw, gb, None, None, None, None, None
         if ctx.act == ACT_SIGMOID:
             gy = ops.sigmoid_grad(gy.float() if gy.dtype != torch.float32 else gy, y.float() if y.dtype != torch.float32 else y)
         elif ctx.act == ACT_RELU:
@@ -95,7 +97,10 @@ class LinearFn(Function):
         g = _as(gy, dt)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = ops.linear(dt, g, ctx.wb, mask=x, ldm=x.stride(0)) if ctx.relu_input else ops.linear(dt, g, ctx.wb)
+            if ctx.relu_input and ctx.x_bits is not None:
+                gx = ops.linear(dt, g, ctx.wb, mask=ctx.x_bits, ldm=ctx.x_bits.stride(0), mask_bits=True)
+            else:
+                gx = ops.linear(dt, g, ctx.wb, mask=x, ldm=x.stride(0)) if ctx.relu_input else ops.linear(dt, g, ctx.wb)
         gb = torch.empty((g.shape[1],), device=g.device, dtype=torch.float32) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         if ctx.needs_input_grad[1]:
             gw = ops.linear_wgrad(dt, g, x, bias_out=gb)
@@ -103,7 +108,7 @@ class LinearFn(Function):
             gw = None
             if gb is not None:
                 ops.colsum(dt, g, out=gb)
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 class HeadsFn(Function):
@@ -645,6 +650,12 @@ class StageFn(Function):
         x = _as(x, dt)
         saved = []
         i = 0
+        # 1-bit ReLU masks: the backward needs only the SIGN of a block's (post-ReLU) output x - for the mask of the gradient that
+        # flows into it - and reading the bf16 tensor for that is 16x the bytes (65 MB per layer1 block at B = 64).  Every block's
+        # last convolution also writes the sign bits of its output; the next block's backward (or the next stage's, or
+        # input_proj's: meta['holder']) reads those.
+        tr = any(ctx.needs_input_grad) and ops.RELU_BITS
+        xbits = meta.get('x_bits')
         for blk in blocks:
             n = 20 if blk.ds else 15
             t = T[i:i + n]
@@ -666,10 +677,14 @@ class StageFn(Function):
                 rec.update(gd=gd, sd=sd, wdb=wdb)
             else:
                 idn = x
-            y = ops.conv_fwd(dt, b, B, g3, w3f, scale=s3, bias=b3, res=idn, ldr=idn.stride(0), act=ACT_RELU, act_post_res=1)
-            rec['y'] = y
+            ybits = torch.empty((B * g3.Ho * g3.Wo, g3.Co // 8), device=x.device, dtype=torch.uint8) if (tr and g3.Co % 8 == 0) else None
+            y = ops.conv_fwd(dt, b, B, g3, w3f, scale=s3, bias=b3, res=idn, ldr=idn.stride(0), act=ACT_RELU, act_post_res=1,
+                             **({} if ybits is None else dict(bits_out=ybits)))
+            rec['y'], rec['xbits'] = y, xbits
             saved.append(rec)
-            x, H, W = y, g2.Ho, g2.Wo
+            x, H, W, xbits = y, g2.Ho, g2.Wo, ybits
+        if meta.get('holder') is not None:
+            meta['holder']['bits'] = xbits
         ctx.saved, ctx.meta, ctx.T = saved, meta, T
         ctx.out_hw = (H, W)
         return x
@@ -711,7 +726,10 @@ class StageFn(Function):
             if want_gx:
                 side = ops.conv_dgrad(dt, gp, B, r['gd'], r['wdb']) if blk.ds else gp
                 mask_x = (not first) or meta['mask_input']
-                ep = dict(mask=r['x'], ldm=r['x'].stride(0)) if mask_x else {}
+                if mask_x and r.get('xbits') is not None:
+                    ep = dict(mask=r['xbits'], ldm=r['xbits'].stride(0), mask_bits=True)
+                else:
+                    ep = dict(mask=r['x'], ldm=r['x'].stride(0)) if mask_x else {}
                 gp = ops.conv_dgrad(dt, ga, B, r['g1'], w1b, res=side, ldr=side.stride(0), **ep)
             else:
                 gp = None

@@ -34,6 +34,7 @@ class SedtIgemm(C.Structure):
         ('splitk', C.c_int32), ('slab', C.c_void_p),
         ('tile_m', C.c_int32), ('tile_n', C.c_int32),
         ('colsum_out', C.c_void_p),
+        ('bits_out', C.c_void_p), ('ldbits', C.c_int64), ('mask_bits', C.c_int32), ('pad_', C.c_int32),
     ]
 
 

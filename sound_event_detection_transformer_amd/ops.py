@@ -35,6 +35,7 @@ class ConvGeom(object):
         return self.KH == 1 and self.KW == 1 and self.sh == 1 and self.sw == 1 and self.ph == 0 and self.pw == 0
 
 
+RELU_BITS = os.environ.get('SEDT_RELU_BITS', '1') != '0'      # developer A/B switch: 0 = the backward masks with the bf16 activations
 PROFILE = None   # bench.py sets this to a list: every GEMM launch then also records (argument block, dtype, shape, operands)
 
 
@@ -46,7 +47,7 @@ def _dev_check(*ts):
 
 def igemm_args(M, N, K, A, lda, B, ldb, Cout, ldc, *, trans=0, conv=None, transposed=0, out_f32=0, scale=None,
                bias=None, res=None, ldr=0, res_mod=0, mask=None, ldm=0, act=ACT_NONE, act_post_res=0, alpha=1.0, drop_p=0.0,
-               seed=0, seed_ptr=None, splitk=1, slab=None, tile=(0, 0), colsum_out=None):
+               seed=0, seed_ptr=None, splitk=1, slab=None, tile=(0, 0), colsum_out=None, mask_bits=False, bits_out=None):
     """the SedtIgemm argument block of one implicit GEMM; ``conv`` = (Hi, Wi, Ci, Ho, Wo, KH, KW, sh, sw, ph, pw, dh, dw)"""
     _dev_check(A, B, Cout)
     a = L.SedtIgemm()
@@ -74,6 +75,12 @@ def igemm_args(M, N, K, A, lda, B, ldb, Cout, ldc, *, trans=0, conv=None, transp
     a.slab = slab.data_ptr() if slab is not None else None
     a.tile_m, a.tile_n = tile
     a.colsum_out = colsum_out.data_ptr() if colsum_out is not None else None
+    if mask_bits:                                   # 1-bit ReLU mask: uint8 [M, N/8] image, ldm in bytes
+        assert mask is not None and mask.dtype == torch.uint8
+        a.mask_bits = 1
+    if bits_out is not None:                        # sign bits of the stored output, uint8 [M, N/8]
+        assert bits_out.dtype == torch.uint8 and bits_out.shape == (M, N // 8) and N % 8 == 0 and bits_out.stride(1) == 1 and not trans
+        a.bits_out, a.ldbits = bits_out.data_ptr(), bits_out.stride(0)
     return a
 
 

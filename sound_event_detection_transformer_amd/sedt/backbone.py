@@ -103,19 +103,23 @@ class ResNet50Body(nn.Module):
         tok = Fn.StemFn.apply(x, self.conv0.weight, self.conv0.bias, self.conv1.weight, *self.bn1.tensors(), dt)
         H, W = (T - 1) // 2 + 1, (Fq - 1) // 2 + 1            # conv1 7x7 s2 p3
         H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1              # maxpool 3x3 s2 p1
+        bits = None                                           # sign bits of the running stage output (functional.StageFn)
         for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
             blocks = [b.cfg for b in layer]
             # consumers of a stage output (the next stage, or SEDT.input_proj) return gradients already masked by the
             # stage's final ReLU, so the stage backward need not mask again (premasked=False -> standalone use)
+            holder = {}
             meta = dict(dt=dt, B=B, H=H, W=W, blocks=blocks, mask_input=li > 0,
-                        grad_premasked=True if li < 3 else (premasked or self.premasked_consumer))
+                        grad_premasked=True if li < 3 else (premasked or self.premasked_consumer), x_bits=bits, holder=holder)
             ts = [t for b in layer for t in b.tensors()]
             tok = Fn.StageFn.apply(tok, meta, *ts)
+            bits = holder.get('bits')
             if self.keep_stage_out:
                 self.stage_out[li] = tok
             for c in blocks:
                 H, W = (H - 1) // c.stride + 1, (W - 1) // c.stride + 1
         C = tok.shape[1]
+        self.out_bits = bits                                  # (for a consumer that masks its input gradient itself: SEDT.input_proj)
         return tok.view(B, H, W, C).permute(0, 3, 1, 2)
 
 

@@ -25,12 +25,16 @@ class HipConv1x1(nn.Conv2d):
     """1x1 nn.Conv2d (input_proj, sedt.py:36) as a GEMM over NHWC tokens; returns (B,Cout,H,W) with channels-last strides"""
 
     relu_input = False      # SEDT sets it: the input is the backbone's post-ReLU feature map (see ResNet50Body.forward)
+    input_bits = None       # ... and this: a callable returning the 1-bit image of [input > 0] the backbone left (or None)
 
     def forward(self, x):
         B, C, H, W = x.shape
         tok = x.permute(0, 2, 3, 1).reshape(B * H * W, C)
+        bits = self.input_bits() if (self.relu_input and self.input_bits is not None) else None
+        if bits is not None and tuple(bits.shape) != (B * H * W, C // 8):
+            bits = None
         y = Fn.LinearFn.apply(tok, self.weight.view(self.out_channels, self.in_channels), self.bias, ACT_NONE, False,
-                              runtime.compute_dtype(), self.relu_input)
+                              runtime.compute_dtype(), self.relu_input, bits)
         return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
 
 
@@ -69,6 +73,7 @@ class SEDT(nn.Module):
             # contract between the two modules: input_proj's dgrad epilogue applies the ReLU mask of layer4's output,
             # so layer4's backward skips its own masking pass
             self.input_proj.relu_input = True
+            self.input_proj.input_bits = lambda: getattr(body, 'out_bits', None)
             body.premasked_consumer = True
         self.aux_loss = aux_loss
         self.dec_at = dec_at

@@ -4,6 +4,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -69,3 +70,26 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     if torch.cuda.device_count() < 2:
         r = subprocess.run([sys.executable, bench, '--gpus', '2', '--steps', '1'], env=env, capture_output=True, text=True)
         assert r.returncode == 2 and 'GPU(s) visible' in r.stderr and not r.stdout.strip()
+
+
+def _agree_worker(rank, world, port, votes, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bench
+    res = bench.agree_out_of_band(votes[rank], rank, world, 'unit', timeout_s=20.0)
+    torch.save({'res': res}, f'{out}.{rank}')
+    dist.destroy_process_group()
+
+
+def test_bench_ranks_agree_out_of_band_on_the_graphed_step(tmp_path):
+    """bench.agree_out_of_band: every rank learns through the process group's store - not through a collective - whether
+    ALL ranks built the captured data-parallel stepper: all yes -> True, all no -> False (everyone takes the same fallback), mixed ->
+    the processes exit with status 3 instead of continuing out of step"""
+    for votes, want in (((True, True), True), ((False, False), False)):
+        out = str(tmp_path / f'a{int(votes[0])}')
+        mp.spawn(_agree_worker, args=(2, _free_port(), votes, out), nprocs=2, join=True)
+        assert all(torch.load(f'{out}.{r}')['res'] is want for r in range(2))
+    with pytest.raises(Exception) as e:
+        mp.spawn(_agree_worker, args=(2, _free_port(), (True, False), str(tmp_path / 'mixed')), nprocs=2, join=True)
+    assert 'exit code 3' in str(e.value) or 'exitcode 3' in str(e.value).replace(' ', '') or '3' in str(e.value)

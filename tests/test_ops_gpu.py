@@ -703,3 +703,25 @@ def test_direct_conv3x3_c64_forward_and_dgrad(ops, B, H):
     assert (y.float() - yi.float()).abs().max().item() <= 2e-2 * yi.float().abs().max().item()
     assert (dx.float() - dxi.float()).abs().max().item() <= 2e-2 * dxi.float().abs().max().item()
     assert torch.equal(ops.conv_fwd(dt, xd, B, g, wf, scale=sc.cuda(), bias=bi.cuda(), act=ops.ACT_RELU), y)     # reproducible
+
+
+@pytest.mark.parametrize('dt,M,N,K', [(BF16, 640, 256, 128), (BF16, 200, 72, 40), (F32, 130, 64, 96), (BF16, 8192, 1024, 256)])
+def test_one_bit_relu_masks_in_the_gemm_epilogue(ops, dt, M, N, K):
+    """SedtIgemm.bits_out / mask_bits (round 3): a GEMM that stores relu(x w^T + res) also leaves the 1-bit image of [out > 0];
+    a later GEMM masked by that image equals the GEMM masked by the bf16 / f32 tensor itself - on the LDS-DMA kernels (aligned bf16
+    shapes) and on the general kernel (f32 mode, unaligned shapes)"""
+    td = torch.bfloat16 if dt == BF16 else torch.float32
+    x, w = dev(randn(M, K), dt), dev(randn(N, K) / math.sqrt(K), dt)
+    res = dev(randn(M, N), dt)
+    bits = torch.zeros((M, N // 8), dtype=torch.uint8, device='cuda')
+    y = ops.linear(dt, x, w, res=res, ldr=res.stride(0), act=ops.ACT_RELU, act_post_res=1, bits_out=bits)
+    y2 = ops.linear(dt, x, w, res=res, ldr=res.stride(0), act=ops.ACT_RELU, act_post_res=1)
+    assert torch.equal(y, y2)
+    want = (y.float() > 0).view(M, N // 8, 8).to(torch.int32)
+    packed = (want * (2 ** torch.arange(8, device='cuda', dtype=torch.int32))).sum(-1).to(torch.uint8)
+    assert torch.equal(bits, packed)
+    assert 0.2 < want.float().mean().item() < 0.8
+    g, w2 = dev(randn(M, K), dt), dev(randn(N, K) / math.sqrt(K), dt)
+    a = ops.linear(dt, g, w2, mask=y, ldm=y.stride(0))
+    b = ops.linear(dt, g, w2, mask=bits, ldm=bits.stride(0), mask_bits=True)
+    assert a.dtype == td and torch.equal(a, b)
