@@ -344,3 +344,47 @@ def test_graphed_train_step_with_mixup_matches_eager(pkg):
     np.testing.assert_allclose(res['graph'][0], res['eager'][0], rtol=2e-3)
     for k in res['eager'][1]:
         assert rel(res['graph'][1][k], res['eager'][1][k]) < 2e-3, k
+
+
+def test_c5_full_size_semi_step_with_mixup_properties(pkg):
+    """BASELINE config C5 as its recipe runs it (train_ss_sedt.py --mix_up_ratio 0.6): 16 synthetic + 16 weak + 32 unlabelled clips,
+    E=6, Q=20, bf16, dropout on, both mix-ups inside the captured step.  Two independently captured steppers fed the same batches
+    under the same np.random seed end bit-identical; losses finite; the strong | weak split moves between replays; mixed unlabelled
+    clips carry ratios; parameters and the EMA teacher move"""
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import GraphedSemiStep
+    runtime.set_compute_dtype('bf16')
+    masks = dict(mask_strong=slice(16), mask_weak=slice(16, 32), mask_label=slice(32), mask_unlabel=slice(32, 64))
+    thr = torch.full((10,), 0.1).cuda()
+    batches = [_rand_semi_batch(1900 + i, 16, 16, 32) for i in range(3)]
+    finals, curves, splits = [], [], []
+    for run in range(2):
+        runtime.manual_seed(777)
+        np.random.seed(11)
+        model, crit, ema, opt = _mix_semi_model(sedt, 2023, dropout=0.1, decay=0.9996, perturb=False)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        stepper = GraphedSemiStep(model, ema, crit, opt, batches[0][0], batches[0][1], batches[0][2], classwise_threshold=thr,
+                                  mix_up_ratio=0.6, **masks)
+        losses = []
+        for it in range(5):
+            xt, xs, tg = batches[it % 3]
+            total, sup, unsup = stepper(xt, xs, tg, check_finite=True)
+            losses.append(float(total))
+            if run == 0:
+                splits.append((stepper.tab_l.cur_ns, stepper.tab_l.cur_n_lab))
+        torch.cuda.synchronize()
+        if run == 0:
+            modes = stepper.jobs_u.cpu().numpy().view(np.int32).reshape(-1, 4)[:, 2]
+            assert set(modes[16:].tolist()) == {2} and len(modes) == 32            # clips beyond mix_num keep their pseudo target
+            ratios = stepper.tab_u.ratio_cat[:int(stepper.tab_u.off[32])].cpu()
+            assert (modes[:16] == 0).any() and ((ratios - 1.0).abs() > 1e-6).any()      # some clips really were mixed
+            assert any(not torch.equal(v, sd0[k]) for k, v in model.state_dict().items() if v.dtype.is_floating_point)
+        curves.append(losses)
+        finals.append(({k: v.detach().clone() for k, v in model.state_dict().items()}, {k: v.clone() for k, v in ema.shadow.items()}))
+    runtime.set_compute_dtype('f32')
+    assert np.isfinite(curves).all() and curves[0] == curves[1]
+    assert len(set(splits)) > 1 and all(s[1] == 32 for s in splits), splits
+    for k in finals[0][0]:
+        assert torch.equal(finals[0][0][k], finals[1][0][k]), k
+    for k in finals[0][1]:
+        assert torch.equal(finals[0][1][k], finals[1][1][k]), k
