@@ -606,7 +606,17 @@ __global__ void multi_sumsq_kernel(const SedtChunk* __restrict__ table, float* _
   float s = 0.f;
   if (c.gflags & 1) {                                        // gradients in the bf16 flat buffer of the data-parallel step
     const bf16_t* gb = reinterpret_cast<const bf16_t*>(c.g);
-    for (int i = threadIdx.x; i < c.n; i += blockDim.x) { const float a = (float)gb[i]; s += a * a; }
+    int i0 = 0;
+    if ((reinterpret_cast<uintptr_t>(gb) & 15) == 0) {
+      const int n8 = c.n >> 3;
+      for (int i = threadIdx.x; i < n8; i += blockDim.x) {
+        const VecT<bf16_t, 8> a = reinterpret_cast<const VecT<bf16_t, 8>*>(gb)[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float x = (float)a.v[e]; s += x * x; }
+      }
+      i0 = n8 << 3;
+    }
+    for (int i = i0 + threadIdx.x; i < c.n; i += blockDim.x) { const float a = (float)gb[i]; s += a * a; }
   } else {
     const float* g = reinterpret_cast<const float*>(c.g);
     int i0 = 0;
@@ -664,7 +674,25 @@ __global__ void multi_adamw_kernel(const SedtChunk* __restrict__ table, const fl
   };
   if (c.gflags & 1) {                                        // bf16 flat gradients (data-parallel step with bf16 buckets)
     const bf16_t* gb = reinterpret_cast<const bf16_t*>(c.g);
-    for (int i = threadIdx.x; i < c.n; i += blockDim.x) {
+    int i0 = 0;
+    if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(gb) & 7) == 0) {
+      const int n4 = c.n >> 2;
+      float4* p4 = reinterpret_cast<float4*>(p);
+      float4* m4 = reinterpret_cast<float4*>(m);
+      float4* v4 = reinterpret_cast<float4*>(v);
+      for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+        float4 pp = p4[i], mm = m4[i], vv = v4[i];
+        const VecT<bf16_t, 4> gg = reinterpret_cast<const VecT<bf16_t, 4>*>(gb)[i];
+        upd(pp.x, (float)gg.v[0], mm.x, vv.x);
+        upd(pp.y, (float)gg.v[1], mm.y, vv.y);
+        upd(pp.z, (float)gg.v[2], mm.z, vv.z);
+        upd(pp.w, (float)gg.v[3], mm.w, vv.w);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+      }
+      i0 = n4 << 2;
+    }
+    for (int i = i0 + threadIdx.x; i < c.n; i += blockDim.x) {
       float pi = p[i], mi = m[i], vi = v[i];
       upd(pi, (float)gb[i], mi, vi);
       p[i] = pi; m[i] = mi; v[i] = vi;
@@ -850,27 +878,51 @@ __global__ __launch_bounds__(256) void multi_pack_kernel(const SedtPackJob* __re
 // and the optimizer's arithmetic stay f32)
 template <bool ACC, bool BF>
 __global__ void multi_gather_kernel(const SedtChunk* __restrict__ table) {
+  // grid (chunks, GATHER_SPLIT): a chunk (<= 65536 elements) is shared by GATHER_SPLIT workgroups - one workgroup per chunk walked
+  // 64 dependent 16-byte loads per lane, and the small segments of the data-parallel schedule (19 chunks for the 4.8 MB tail)
+  // took as long as the large ones
   const SedtChunk c = table[blockIdx.x];
   const float* src = reinterpret_cast<const float*>(c.g);
+  const int per = (((c.n + gridDim.y - 1) / gridDim.y) + 7) & ~7;          // elements per workgroup, a multiple of 8
+  const int e0 = blockIdx.y * per, e1 = min(c.n, e0 + per);
+  if (e0 >= e1) return;
   if (BF) {
     bf16_t* dst = reinterpret_cast<bf16_t*>(c.p);
-    for (int i = threadIdx.x; i < c.n; i += blockDim.x) dst[i] = (bf16_t)(ACC ? (float)dst[i] + src[i] : src[i]);
+    int i0 = e0;
+    if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0) {      // 8 elements per lane and access
+      const int n8 = (e1 - e0) >> 3;
+      for (int i = threadIdx.x; i < n8; i += blockDim.x) {
+        const float4 a = reinterpret_cast<const float4*>(src + e0)[2 * i], b2 = reinterpret_cast<const float4*>(src + e0)[2 * i + 1];
+        float v[8] = {a.x, a.y, a.z, a.w, b2.x, b2.y, b2.z, b2.w};
+        VecT<bf16_t, 8> o;
+        if (ACC) {
+          const VecT<bf16_t, 8> old = reinterpret_cast<const VecT<bf16_t, 8>*>(dst + e0)[i];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)old.v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.v[e] = (bf16_t)v[e];
+        reinterpret_cast<VecT<bf16_t, 8>*>(dst + e0)[i] = o;
+      }
+      i0 = e0 + (n8 << 3);
+    }
+    for (int i = i0 + threadIdx.x; i < e1; i += blockDim.x) dst[i] = (bf16_t)(ACC ? (float)dst[i] + src[i] : src[i]);
     return;
   }
   float* dst = reinterpret_cast<float*>(c.p);
-  int i0 = 0;
+  int i0 = e0;
   if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0) {
-    const int n4 = c.n >> 2;
-    float4* d4 = reinterpret_cast<float4*>(dst);
-    const float4* s4 = reinterpret_cast<const float4*>(src);
+    const int n4 = (e1 - e0) >> 2;
+    float4* d4 = reinterpret_cast<float4*>(dst + e0);
+    const float4* s4 = reinterpret_cast<const float4*>(src + e0);
     for (int i = threadIdx.x; i < n4; i += blockDim.x) {
       float4 v = s4[i];
       if (ACC) { const float4 o = d4[i]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
       d4[i] = v;
     }
-    i0 = n4 << 2;
+    i0 = e0 + (n4 << 2);
   }
-  for (int i = i0 + threadIdx.x; i < c.n; i += blockDim.x) dst[i] = ACC ? dst[i] + src[i] : src[i];
+  for (int i = i0 + threadIdx.x; i < e1; i += blockDim.x) dst[i] = ACC ? dst[i] + src[i] : src[i];
 }
 
 }  // namespace sedt
@@ -1159,10 +1211,10 @@ extern "C" int sedt_multi_gather(const SedtChunk* table, int nchunks, int mode, 
   SEDT_REQUIRE(table && nchunks > 0, "multi_gather: bad arguments");
   SEDT_REQUIRE(mode >= 0 && mode <= 3, "multi_gather: mode %d (bit 0: accumulate, bit 1: bf16 destination)", mode);
   switch (mode) {
-    case 0: hipLaunchKernelGGL((multi_gather_kernel<false, false>), dim3(nchunks), dim3(256), 0, S(stream), table); break;
-    case 1: hipLaunchKernelGGL((multi_gather_kernel<true, false>), dim3(nchunks), dim3(256), 0, S(stream), table); break;
-    case 2: hipLaunchKernelGGL((multi_gather_kernel<false, true>), dim3(nchunks), dim3(256), 0, S(stream), table); break;
-    default: hipLaunchKernelGGL((multi_gather_kernel<true, true>), dim3(nchunks), dim3(256), 0, S(stream), table); break;
+    case 0: hipLaunchKernelGGL((multi_gather_kernel<false, false>), dim3(nchunks, 8), dim3(256), 0, S(stream), table); break;
+    case 1: hipLaunchKernelGGL((multi_gather_kernel<true, false>), dim3(nchunks, 8), dim3(256), 0, S(stream), table); break;
+    case 2: hipLaunchKernelGGL((multi_gather_kernel<false, true>), dim3(nchunks, 8), dim3(256), 0, S(stream), table); break;
+    default: hipLaunchKernelGGL((multi_gather_kernel<true, true>), dim3(nchunks, 8), dim3(256), 0, S(stream), table); break;
   }
   return check_launch("multi_gather");
 }
