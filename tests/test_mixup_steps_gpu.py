@@ -388,3 +388,61 @@ def test_c5_full_size_semi_step_with_mixup_properties(pkg):
         assert torch.equal(finals[0][0][k], finals[1][0][k]), k
     for k in finals[0][1]:
         assert torch.equal(finals[0][1][k], finals[1][1][k]), k
+
+
+def test_cached_constants_follow_shape_and_dtype_changes(pkg):
+    """round 3 keeps three per-shape constants instead of recomputing them every forward (the decoder's zero input, the resized
+    all-False padding mask, its position encoding): a forward must give the same result whatever ran before it - other batch
+    sizes, the other compute dtype, an explicit NestedTensor with real padding in between"""
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.utilities.utils import NestedTensor
+    model, _, _ = sedt.build_model(sedt.default_args(dropout=0.0))
+    model.load_state_dict(O.seeded_state_dict(model.state_dict(), 17))
+    model.cuda().eval()
+    xs = {b: torch.randn(b, 1, 500, 64, generator=torch.Generator().manual_seed(b)).cuda() for b in (2, 3)}
+
+    def run(b, dt):
+        runtime.set_compute_dtype(dt)
+        with torch.no_grad():
+            o = model(xs[b])
+        return {k: o[k].float().clone() for k in ('pred_logits', 'pred_boxes', 'at')}
+    first = {(b, dt): run(b, dt) for dt in ('f32', 'bf16') for b in (2, 3)}
+    # a padded batch in between: its mask is NOT one of the cached all-False masks and must not poison the caches
+    m = torch.zeros(2, 500, 64, dtype=torch.bool).cuda()
+    m[1, 300:] = True
+    runtime.set_compute_dtype('f32')
+    with torch.no_grad():
+        padded = model(NestedTensor(xs[2], m))
+    assert (padded['pred_logits'][1] - first[(2, 'f32')]['pred_logits'][1]).abs().max() > 1e-4       # padding changed clip 1
+    assert rel(padded['pred_logits'][0], first[(2, 'f32')]['pred_logits'][0]) < 1e-5                   # ... and only clip 1
+    for dt in ('bf16', 'f32'):
+        for b in (3, 2):
+            again = run(b, dt)
+            for k, v in again.items():
+                assert torch.equal(v, first[(b, dt)][k]), (b, dt, k)
+    runtime.set_compute_dtype('f32')
+
+
+def test_target_tables_host_and_device_targets_agree():
+    """TargetTables.load: host-resident targets travel as ONE pinned blob, device-resident ones table by table - same tables"""
+    from sound_event_detection_transformer_amd.sedt import TargetTables
+    dev = torch.device('cuda')
+    B = 7
+    tg = synthetic_targets(B, 5, 10)
+    for t in tg[4:]:
+        t['boxes'] = torch.zeros(0, 2)
+    tg[1]['ratio'] = torch.rand(len(tg[1]['labels']))
+    a = TargetTables(B, 4, 6, dev, with_ratio=True, dynamic_split=True).load(tg, ns=4, n_lab=6)
+    b = TargetTables(B, 4, 6, dev, with_ratio=True, dynamic_split=True).load(_cuda_targets(tg), ns=4, n_lab=6)
+    torch.cuda.synchronize()
+    nl = int(a.off[B])
+    nb = int(a.off[B + 1 + 4])
+    assert torch.equal(a.off, b.off) and torch.equal(a.split.cpu(), torch.tensor([4, 6], dtype=torch.int32))
+    assert torch.equal(a.lab_cat[:nl], b.lab_cat[:nl]) and torch.equal(a.box_cat[:nb], b.box_cat[:nb])
+    assert torch.equal(a.ratio_cat[:nl], b.ratio_cat[:nl])
+    # a second load with fewer events leaves no stale offsets behind
+    tg2 = synthetic_targets(B, 6, 10)
+    a.load(tg2, ns=7, n_lab=7)
+    b.load(_cuda_targets(tg2), ns=7, n_lab=7)
+    torch.cuda.synchronize()
+    assert torch.equal(a.off, b.off) and torch.equal(a.lab_cat[:int(a.off[B])], b.lab_cat[:int(b.off[B])])
