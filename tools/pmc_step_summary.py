@@ -3,7 +3,7 @@
   time (kernel trace), HBM-side bytes (FETCH_SIZE x 2 as the guide prescribes for wide coalesced reads on gfx950, WRITE_SIZE),
   matrix-core busy share (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): rocprofv3 sums GRBM_GUI_ACTIVE over the 8
   XCDs; calibrated on the layer4 3x3 conv: 1.18 M MFMAs x 32 cycles over 1024 SIMDs), VALU instructions per MFMA.
-usage: pmc_step_summary.py <gpurun_out/prof_<tag>> <profiles/rNN_step_c2.csv> <profiles/rNN_pmc_c2.json>
+usage: pmc_step_summary.py <gpurun_out/prof_<tag>> <profiles/rNN_step_c2.csv> <profiles/rNN_pmc_c2.json> [config, default c2]
 Steps are split at the stem forward launch (stem_pool_fwd, or stem_im2col in builds before the one-launch stem: one per forward of the supervised step)."""
 import collections
 import csv
@@ -13,6 +13,7 @@ import re
 import sys
 
 root, out_csv, out_json = sys.argv[1], sys.argv[2], sys.argv[3]
+cfg = sys.argv[4] if len(sys.argv) > 4 else 'c2'
 
 
 def short(n):
@@ -46,7 +47,7 @@ def counters(d):
     return res
 
 
-tr = glob.glob(root + '/trace_c2/**/*_kernel_trace.csv', recursive=True)[0]
+tr = glob.glob(root + f'/trace_{cfg}/**/*_kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(tr)))
 seg = last_step(rows, lambda r: int(r['Start_Timestamp']))
 span = (int(seg[-1]['End_Timestamp']) - int(seg[0]['Start_Timestamp'])) / 1e6
