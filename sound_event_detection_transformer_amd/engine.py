@@ -305,12 +305,15 @@ class GraphedTrainStep(_GraphedBase):
     seed word (runtime.bump_seed); the Adam step count lives on the device too.  The optimizer's learning rates are re-read
     before every replay.  Eager ``optimizer.step()`` calls between replays are safe (the graph owns its pointer tables).
 
-    Data parallel (world > 1): parameters are broadcast from rank 0 at construction; gradients are packed into ONE flat f32
-    buffer and averaged with RCCL between the backward graph and an optimizer graph.  With a SEDT backbone the backward is
-    cut after layer3 (overlap_allreduce=True): the first graph ends with the gradients of everything above the cut
-    (transformer, heads, layer4, layer3 = 90 % of the bytes) packed into the head of the flat buffer, their all-reduce is
-    launched asynchronously, and a second graph runs the backward of layer2 / layer1 / stem meanwhile; the small tail is
-    reduced after it.
+    Data parallel (world > 1): parameters are broadcast from rank 0 at construction; gradients are packed into ONE flat buffer
+    (f32, or bf16 with ``grad_dtype=torch.bfloat16``) and averaged with RCCL between the backward graph(s) and an optimizer graph.
+    With ``overlap_allreduce`` the backward is cut in segments (``dp_cuts``: 'coarse' = transformer + heads | layer4 | layer3 |
+    layer2 + stem; 'fine' also splits decoder + heads | encoder; a frozen backbone leaves decoder + heads | encoder): every
+    segment's graph ends by packing its gradients into its part of the flat buffer, whose all-reduce is launched asynchronously
+    while the next segment's graph runs (engine.dp_segment_plan).
+
+    ``mix_up_ratio`` > 0: mix-up inside the step (reference engine.py:50-53) - see ``__call__``.  ``accum_steps`` = k: gradients of
+    k consecutive calls are added in the flat buffer and clip + AdamW run on every k-th call (engine.py:76).
 
     Two alternatives for the weight gradients are implemented and measured slower than the default (a layer's wgrads as ONE
     grouped launch on the main stream): async_wgrad=True issues them as a parallel branch of the graph (ROCm 7.2 pays

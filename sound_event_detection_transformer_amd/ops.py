@@ -302,7 +302,7 @@ def conv_dgrad(dtype, dy, B, g, wb, out=None, **ep):
 
 
 def _fused_bias_ok(dtype, dy, x, g):
-    """envelope of the bf16 LDS-DMA wgrad kernel (csrc/wgrad2.hip): only there the bias gradient rides along"""
+    """envelope of the bf16 LDS-DMA wgrad kernel (csrc/wgrad3.hip / wgrad4.hip, envelope in wgrad_lds_envelope): only there the bias gradient rides along"""
     return (dtype == BF16 and L.load() is not None and g.Co % 8 == 0 and (g.taps * g.Ci) % 8 == 0 and dy.stride(0) % 8 == 0
             and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and g.Ci % 8 == 0)
 
