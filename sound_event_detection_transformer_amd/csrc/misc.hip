@@ -648,6 +648,7 @@ __global__ void multi_sumsq_kernel(const SedtChunk* __restrict__ table, float* _
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+template <bool NT>
 __global__ void multi_adamw_kernel(const SedtChunk* __restrict__ table, const float* sumsq, float max_norm, float b1,
                                    float b2, float eps, const int32_t* __restrict__ step_ptr, const int32_t* __restrict__ guard) {
   if (guard && *guard) return;                // non-finite loss / gradient norm upstream: leave every tensor as it is
@@ -707,14 +708,26 @@ __global__ void multi_adamw_kernel(const SedtChunk* __restrict__ table, const fl
     const float4* g4 = reinterpret_cast<const float4*>(g);
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
+    // the gradient is dead after this pass and the two moments are next touched one step later: non-temporal accesses keep the
+    // 390 MB of them from evicting the freshly written weights (which the next forward's packing kernel reads) from the MALL
+    typedef float __attribute__((ext_vector_type(4))) f4v;
+    const f4v* g4n = reinterpret_cast<const f4v*>(g);
+    f4v* m4n = reinterpret_cast<f4v*>(m);
+    f4v* v4n = reinterpret_cast<f4v*>(v);
     for (int i = threadIdx.x; i < n4; i += blockDim.x) {
-      float4 pp = p4[i], mm = m4[i], vv = v4[i];
-      const float4 gg = g4[i];
-      upd(pp.x, gg.x, mm.x, vv.x);
-      upd(pp.y, gg.y, mm.y, vv.y);
-      upd(pp.z, gg.z, mm.z, vv.z);
-      upd(pp.w, gg.w, mm.w, vv.w);
-      p4[i] = pp; m4[i] = mm; v4[i] = vv;
+      float4 pp = p4[i];
+      f4v mm = NT ? __builtin_nontemporal_load(m4n + i) : m4n[i];
+      f4v vv = NT ? __builtin_nontemporal_load(v4n + i) : v4n[i];
+      const f4v gg = NT ? __builtin_nontemporal_load(g4n + i) : g4n[i];
+      float m0 = mm.x, m1 = mm.y, m2 = mm.z, m3 = mm.w, v0 = vv.x, v1 = vv.y, v2 = vv.z, v3 = vv.w;
+      upd(pp.x, gg.x, m0, v0);
+      upd(pp.y, gg.y, m1, v1);
+      upd(pp.z, gg.z, m2, v2);
+      upd(pp.w, gg.w, m3, v3);
+      p4[i] = pp;
+      const f4v mo = {m0, m1, m2, m3}, vo = {v0, v1, v2, v3};
+      if (NT) { __builtin_nontemporal_store(mo, m4n + i); __builtin_nontemporal_store(vo, v4n + i); }
+      else { m4n[i] = mo; v4n[i] = vo; }
     }
     i0 = n4 << 2;
   }
@@ -1196,8 +1209,15 @@ extern "C" int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float
                                 float beta2, float eps, const int32_t* step_ptr, const int32_t* guard, void* stream) {
   SEDT_REQUIRE(table && nchunks > 0 && step_ptr, "multi_adamw: bad arguments");
   SEDT_REQUIRE(max_norm <= 0.f || sumsq, "multi_adamw: clipping needs sumsq");
-  hipLaunchKernelGGL(multi_adamw_kernel, dim3(nchunks), dim3(256), 0, S(stream), table, sumsq, max_norm, beta1, beta2, eps,
-                     step_ptr, guard);
+  static int nt = -1;
+  if (nt < 0) {
+    const char* e = getenv("SEDT_ADAMW_NT");          // developer A/B switch (default on)
+    nt = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (nt) hipLaunchKernelGGL(multi_adamw_kernel<true>, dim3(nchunks), dim3(256), 0, S(stream), table, sumsq, max_norm, beta1, beta2, eps,
+                             step_ptr, guard);
+  else hipLaunchKernelGGL(multi_adamw_kernel<false>, dim3(nchunks), dim3(256), 0, S(stream), table, sumsq, max_norm, beta1, beta2, eps,
+                          step_ptr, guard);
   return check_launch("multi_adamw");
 }
 
