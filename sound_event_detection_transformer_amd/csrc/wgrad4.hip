@@ -24,22 +24,25 @@ namespace sedt {
 // conflicts by SQ_LDS_BANK_CONFLICT.)
 __device__ __forceinline__ int w4_swz(int row) { return (row & 3) << 2; }
 
-template <bool CONV>
+template <bool CONV, int S, int NA>
 __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int nmajor,
                                             const int bx, const int by) {
-  constexpr int BM = 128, BN = 128, BKP = 64, NW = 8, S = 3;
+  // NA = 1: 128 x 128 tile; NA = 2: 256 x 128 (two dY images per stage, 85 flop per staged byte instead of 64)
+  constexpr int BM = 128 * NA, BN = 128, BKP = 64, NW = 8;
   constexpr int IMG_ROWB = 256;                       // image row: 128 channels of bf16
-  constexpr int IMG_BYTES = BKP * IMG_ROWB;           // 16 KB per operand per stage
-  constexpr int STAGE_BYTES = 2 * IMG_BYTES;
+  constexpr int IMG_BYTES = BKP * IMG_ROWB;           // 16 KB per image per stage
+  constexpr int STAGE_BYTES = (NA + 1) * IMG_BYTES;   // NA images of dY, then one of X
+  constexpr int B_IMG = NA * IMG_BYTES;
   constexpr int CPR = 16, RPI = 4;                    // 16-byte chunks per image row, rows per DMA instruction
-  constexpr int GA = BKP / RPI / NW, GB = GA;         // 2 + 2 DMA instructions per wave per tile
+  constexpr int GB = BKP / RPI / NW, GA = NA * GB;    // 2 DMA instructions per wave per image and tile
   constexpr int G = GA + GB;
+  constexpr int MI = 2 * NA;                          // 32-row blocks of a wave's sub-tile (64 x 64 or 128 x 64)
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = w3_uniform(t >> 6);
   const int kgrp = wave >> 2;
-  const int wm = ((wave & 3) >> 1) * 64, wn = (wave & 1) * 64;
+  const int wm = ((wave & 3) >> 1) * (32 * MI), wn = (wave & 1) * 64;
 
   const int ntn = p.N / BN, ntm = p.M / BM;
   const int nwg = ntn * ntm;
@@ -72,10 +75,10 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
   const unsigned a_step = (unsigned)(BKP * p.lda * 2);
 #pragma unroll
   for (int i = 0; i < GA; ++i) {
-    const int trow = (i * NW + wave) * RPI + drow;
+    const int trow = ((i % GB) * NW + wave) * RPI + drow;
     const int lchunk = pchunk ^ w4_swz(trow);
     a_trow[i] = trow;
-    a_poff[i] = (unsigned)((((long)kb_begin * BKP + trow) * p.lda + m0 + lchunk * 8) * 2);
+    a_poff[i] = (unsigned)((((long)kb_begin * BKP + trow) * p.lda + m0 + (i / GB) * 128 + lchunk * 8) * 2);
   }
   unsigned b_poff[GB];
   int b_ho[GB], b_hoff[GB], b_trow[GB];
@@ -119,7 +122,8 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
       unsigned voff = (full || a_trow[i] < left) ? a_poff[i] : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(st + ((i * NW + wave) * RPI) * IMG_ROWB), 16, voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(st + (i / GB) * IMG_BYTES + (((i % GB) * NW + wave) * RPI) * IMG_ROWB), 16,
+                                               voff, 0, 0, 0);
       a_poff[i] += a_step;
     }
 #pragma unroll
@@ -128,8 +132,7 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
       bool ok = b_wok[i] && (full || b_trow[i] < left);
       if (CONV) ok = ok && (unsigned)(b_ho[i] * p.sh + b_hoff[i]) < (unsigned)p.Hi;
       if (ok) voff = b_poff[i];
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(st + IMG_BYTES + ((i * NW + wave) * RPI) * IMG_ROWB), 16, voff, 0, 0,
-                                               0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(st + B_IMG + ((i * NW + wave) * RPI) * IMG_ROWB), 16, voff, 0, 0, 0);
       b_poff[i] += b_step;
       if (CONV) {
         b_ho[i] += step_h;
@@ -139,9 +142,9 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
     kbase += BKP;
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -150,41 +153,48 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
   // ---- transposing fragment reads of this wave's two k16 steps: per-thread constant offsets inside a stage
   const int grp = lane >> 4, s16 = lane & 15;
   const int src_pix = (grp >> 1) * 8 + (s16 >> 2);
-  int a_rd[2][2][2], b_rd[2][2][2];            // [k16 step][32-wide sub-tile][half]
+  int a_rd[2][MI][2], b_rd[2][2][2];           // [k16 step][32-wide sub-tile][half]
 #pragma unroll
   for (int kq = 0; kq < 2; ++kq)
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
       const int pixrow = (2 * kgrp + kq) * 16 + src_pix + 4 * h2;
 #pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int a_ch = wm + i * 32 + (grp & 1) * 16 + (s16 & 3) * 4;       // channel inside the 128 * NA rows of the tile
+        const int aphys = ((a_ch & 127) >> 3) ^ w4_swz(pixrow);
+        a_rd[kq][i][h2] = (a_ch >> 7) * IMG_BYTES + pixrow * IMG_ROWB + aphys * 16 + ((a_ch >> 2) & 1) * 8;
+      }
+#pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int a_ch = wm + j * 32 + (grp & 1) * 16 + (s16 & 3) * 4;
         const int b_ch = wn + j * 32 + (grp & 1) * 16 + (s16 & 3) * 4;
-        const int a8 = a_ch >> 3, b8 = b_ch >> 3;
-        const int aphys = a8 ^ w4_swz(pixrow), bphys = b8 ^ w4_swz(pixrow);
-        a_rd[kq][j][h2] = pixrow * IMG_ROWB + aphys * 16 + ((a_ch >> 2) & 1) * 8;
-        b_rd[kq][j][h2] = IMG_BYTES + pixrow * IMG_ROWB + bphys * 16 + ((b_ch >> 2) & 1) * 8;
+        const int bphys = (b_ch >> 3) ^ w4_swz(pixrow);
+        b_rd[kq][j][h2] = B_IMG + pixrow * IMG_ROWB + bphys * 16 + ((b_ch >> 2) & 1) * 8;
       }
     }
   auto tr = [&](const unsigned char* ptr) -> w3_s16x4 { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((w3_lds_s16x4*)ptr); };
-  w3_s16x8 fa[2][2], fb[2][2];
+  w3_s16x8 fa[2][MI], fb[2][2];
   auto load_frags = [&](const int stage) {
     const unsigned char* st = smem + stage * STAGE_BYTES;
 #pragma unroll
-    for (int kq = 0; kq < 2; ++kq)
+    for (int kq = 0; kq < 2; ++kq) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const w3_s16x4 a0 = tr(st + a_rd[kq][i][0]), a1 = tr(st + a_rd[kq][i][1]);
+        fa[kq][i] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const w3_s16x4 a0 = tr(st + a_rd[kq][j][0]), a1 = tr(st + a_rd[kq][j][1]);
-        fa[kq][j] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
         const w3_s16x4 b0 = tr(st + b_rd[kq][j][0]), b1 = tr(st + b_rd[kq][j][1]);
         fb[kq][j] = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
       }
+    }
   };
   auto mfma_all = [&]() {
 #pragma unroll
     for (int kq = 0; kq < 2; ++kq)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[kq][i]), __builtin_bit_cast(bf16x8, fb[kq][j]),
@@ -195,13 +205,14 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
   // from the dY image in the load segment of either group (all 512 threads take part, each in its own group's segment)
   const bool do_colsum = p.colsum_out != nullptr && n0 == 0;
   float bsum = 0.f;
-  const int cs_ch = t & 127, cs_q = t >> 7;
+  constexpr int CS_PARTS = NW * 64 / BM, CS_ROWS = BKP / CS_PARTS;       // pixel ranges per channel: 4 x 16 or 2 x 32 rows
+  const int cs_ch = t % BM, cs_q = t / BM;
   auto colsum_tile = [&](const int stage) {
-    const unsigned char* st = smem + stage * STAGE_BYTES;
-    const int c8 = cs_ch >> 3;
+    const unsigned char* st = smem + stage * STAGE_BYTES + (cs_ch >> 7) * IMG_BYTES;
+    const int c8 = (cs_ch & 127) >> 3;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int pixrow = cs_q * 16 + r;
+    for (int r = 0; r < CS_ROWS; ++r) {
+      const int pixrow = cs_q * CS_ROWS + r;
       const int phys = c8 ^ w4_swz(pixrow);
       bsum += (float)*reinterpret_cast<const bf16_t*>(st + pixrow * IMG_ROWB + phys * 16 + (cs_ch & 7) * 2);
     }
@@ -256,18 +267,23 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
     float* red = reinterpret_cast<float*>(smem);
     red[t] = bsum;
     __syncthreads();
-    if (t < 128)
-      p.colsum_out[(long)(p.splitk > 1 ? by : 0) * p.M + m0 + t] = (red[t] + red[t + 128]) + (red[t + 256] + red[t + 384]);
+    if (t < BM) {
+      float sum = red[t];
+#pragma unroll
+      for (int q = 1; q < CS_PARTS; ++q) sum += red[t + q * BM];
+      p.colsum_out[(long)(p.splitk > 1 ? by : 0) * p.M + m0 + t] = sum;
+    }
     __syncthreads();
   }
 
   // ---- epilogue: the two groups' halves of the K sum meet in LDS, then 16-byte rows go to the slab / gradient
   constexpr int CP = BN + 4;
+  static_assert((size_t)BM * CP * 4 <= (size_t)S * STAGE_BYTES, "the epilogue tile re-uses the ring");
   float* Cs = reinterpret_cast<float*>(smem);
   const int frow = lane & 31, fhalf = lane >> 5;
   if (kgrp == 0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -279,7 +295,7 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
   __syncthreads();
   if (kgrp == 1) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -299,17 +315,25 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
   }
 }
 
+template <int S>
 __device__ __forceinline__ void wgrad4_body(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int nmajor,
                                             const int bx, const int by) {
-  if (p.conv) wgrad4_impl<true>(p, a_bytes, b_bytes, nmajor, bx, by);
-  else wgrad4_impl<false>(p, a_bytes, b_bytes, nmajor, bx, by);
+  if (nmajor & 2) {                      // 256 x 128 tiles (wg4_wide)
+    if (p.conv) wgrad4_impl<true, 3, 2>(p, a_bytes, b_bytes, nmajor, bx, by);
+    else wgrad4_impl<false, 3, 2>(p, a_bytes, b_bytes, nmajor, bx, by);
+    return;
+  }
+  if (p.conv) wgrad4_impl<true, S, 1>(p, a_bytes, b_bytes, nmajor, bx, by);
+  else wgrad4_impl<false, S, 1>(p, a_bytes, b_bytes, nmajor, bx, by);
 }
 
+template <int S>
 __global__ __launch_bounds__(512) void wgrad4_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes,
                                                      const int nmajor) {
-  wgrad4_body(p, a_bytes, b_bytes, nmajor, blockIdx.x, blockIdx.y);
+  wgrad4_body<S>(p, a_bytes, b_bytes, nmajor, blockIdx.x, blockIdx.y);
 }
 
+template <int S>
 __global__ __launch_bounds__(512) void wgrad4_group_kernel(const WgradGroup g) {
   const int b = blockIdx.x;
   int i = 0;
@@ -317,10 +341,33 @@ __global__ __launch_bounds__(512) void wgrad4_group_kernel(const WgradGroup g) {
   const int local = b - g.blk0[i];
   const int nwg = g.nwg[i], sk = g.p[i].splitk > 1 ? g.p[i].splitk : 1;
   if (local >= nwg * sk) return;                       // padding workgroups (problem ranges start on multiples of 8)
-  wgrad4_body(g.p[i], g.a_bytes[i], g.b_bytes[i], g.nmajor[i], local % nwg, local / nwg);
+  wgrad4_body<S>(g.p[i], g.a_bytes[i], g.b_bytes[i], g.nmajor[i], local % nwg, local / nwg);
 }
 
-constexpr size_t WG4_LDS = (size_t)3 * 2 * 64 * 256;      // 96 KB ring >= the 128 x 132 f32 epilogue tile (66 KB)
+// ring of S stages x 32 KB (96 / 128 KB) >= the 128 x 132 f32 epilogue tile (66 KB).  SEDT_WGRAD4_STAGES picks the depth.
+static int wg4_stages() {
+  static int s = -1;
+  if (s < 0) {
+    const char* e = getenv("SEDT_WGRAD4_STAGES");
+    s = (e && atoi(e) == 3) ? 3 : (e && atoi(e) == 4) ? 4 : 3;
+  }
+  return s;
+}
+// rows of a tile for a problem with M output rows (Cout): the 256 x 128 tile where M allows it (SEDT_WGRAD4_BM=128: never).
+// Same-box A/B on the C2 step (tools/dev/ab_wgrad4.sh, ms/step): 128-row tiles 5.85-5.86 at every split target; 256-row tiles
+// with split-K target 32 / 48 / 64 / 80 / 128 / 192 tiles: 5.79 / 5.71 / 5.67 / 5.74 / 5.81 / 5.96
+int wgrad4_tile_m(int M) {
+  static int bm = -1;
+  if (bm < 0) {
+    const char* e = getenv("SEDT_WGRAD4_BM");
+    bm = (e && atoi(e) == 128) ? 128 : 256;
+  }
+  return (bm == 256 && M % 256 == 0) ? 256 : 128;
+}
+static size_t wg4_lds() {
+  const size_t narrow = (size_t)wg4_stages() * 2 * 64 * 256, wide = (size_t)3 * 3 * 64 * 256;
+  return wgrad4_tile_m(256) == 256 ? std::max(narrow, wide) : narrow;
+}
 
 // shape part of the envelope (sedt_igemm_splitk sizes the split for the 128x128 tiling when this holds)
 bool wgrad4_shape_ok(int M, int N) {
@@ -352,7 +399,7 @@ bool wgrad4_ok(const SedtIgemm& p) {
 
 template <typename K>
 static int wg4_attr(K kern, const char* what) {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)WG4_LDS);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wg4_lds());
   if (e != hipSuccess) {
     set_error("%s: hipFuncSetAttribute failed: %s", what, hipGetErrorString(e));
     return 1;
@@ -363,12 +410,15 @@ static int wg4_attr(K kern, const char* what) {
 int launch_wgrad4(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (wg4_attr(wgrad4_kernel, "wgrad4")) return 1;
+    if (wg4_attr(wgrad4_kernel<3>, "wgrad4") || wg4_attr(wgrad4_kernel<4>, "wgrad4")) return 1;
     attr_set = true;
   }
-  const int nwg = (p.N / 128) * (p.M / 128);
-  hipLaunchKernelGGL(wgrad4_kernel, dim3(nwg, p.splitk > 1 ? p.splitk : 1), dim3(512), WG4_LDS, st, p, a_bytes, b_bytes,
-                     p.N > p.M ? 1 : 0);
+  const int bm = wgrad4_tile_m(p.M);
+  const int nwg = (p.N / 128) * (p.M / bm);
+  const int nmajor = (p.N > p.M ? 1 : 0) | (bm == 256 ? 2 : 0);
+  const dim3 grid(nwg, p.splitk > 1 ? p.splitk : 1);
+  if (wg4_stages() == 4) hipLaunchKernelGGL(wgrad4_kernel<4>, grid, dim3(512), wg4_lds(), st, p, a_bytes, b_bytes, nmajor);
+  else hipLaunchKernelGGL(wgrad4_kernel<3>, grid, dim3(512), wg4_lds(), st, p, a_bytes, b_bytes, nmajor);
   return check_launch("wgrad4");
 }
 
@@ -376,19 +426,21 @@ int launch_wgrad4(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStr
 int launch_wgrad4_group(WgradGroup& g, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (wg4_attr(wgrad4_group_kernel, "wgrad4 group")) return 1;
+    if (wg4_attr(wgrad4_group_kernel<3>, "wgrad4 group") || wg4_attr(wgrad4_group_kernel<4>, "wgrad4 group")) return 1;
     attr_set = true;
   }
   int blk = 0;
   for (int i = 0; i < g.n; ++i) {
     const SedtIgemm& p = g.p[i];
-    g.nwg[i] = (p.N / 128) * (p.M / 128);
-    g.nmajor[i] = p.N > p.M ? 1 : 0;
+    const int bm = wgrad4_tile_m(p.M);
+    g.nwg[i] = (p.N / 128) * (p.M / bm);
+    g.nmajor[i] = (p.N > p.M ? 1 : 0) | (bm == 256 ? 2 : 0);
     g.blk0[i] = blk;
     blk += (g.nwg[i] * (p.splitk > 1 ? p.splitk : 1) + 7) / 8 * 8;
   }
   g.blk0[g.n] = blk;
-  hipLaunchKernelGGL(wgrad4_group_kernel, dim3(blk), dim3(512), WG4_LDS, st, g);
+  if (wg4_stages() == 4) hipLaunchKernelGGL(wgrad4_group_kernel<4>, dim3(blk), dim3(512), wg4_lds(), st, g);
+  else hipLaunchKernelGGL(wgrad4_group_kernel<3>, dim3(blk), dim3(512), wg4_lds(), st, g);
   return check_launch("wgrad4_group");
 }
 

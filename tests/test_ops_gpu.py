@@ -570,7 +570,8 @@ def test_layernorm_bwd_with_fused_dropout_grad(ops, dt):
 
 
 @pytest.mark.parametrize('dt', [F32, BF16])
-@pytest.mark.parametrize('cfg', [(32, 4, 128, 512, 3, 1, 2, 2, 5), (16, 4, 512, 640, 1, 1, 0, 1, 7), (17, 4, 640, 512, 1, 1, 0, 1, 3)])
+@pytest.mark.parametrize('cfg', [(32, 4, 128, 512, 3, 1, 2, 2, 5), (16, 4, 512, 640, 1, 1, 0, 1, 7), (17, 4, 640, 512, 1, 1, 0, 1, 3),
+                                 (16, 4, 256, 256, 3, 1, 1, 1, 6), (16, 4, 256, 1024, 1, 1, 0, 1, 5)])
 def test_wgrad_large_tiles(ops, dt, cfg):
     """weight gradients with Cout, taps*Cin >= 512: the 128x128 ping-pong kernel (csrc/wgrad4.hip) in bf16 mode -
     layer4-like dilated 3x3 and 1x1 problems, K a multiple of the 64-pixel tile or not, every split-K slice count the library picks"""
