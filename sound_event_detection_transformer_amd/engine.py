@@ -152,7 +152,9 @@ def build_optimizer(model, lr=1e-4, lr_backbone=1e-4, weight_decay=1e-4, fused=T
 def _snapshot(model, optimizer, ema=None):
     """parameters + optimizer moments (+ EMA shadow) before the warm-up steps of a capture; _restore puts them back, so that
     constructing a graphed stepper leaves the training state untouched"""
-    snap = {'p': [p.detach().clone() for p in model.parameters()], 'o': optimizer.snapshot()}
+    from . import runtime
+    snap = {'p': [p.detach().clone() for p in model.parameters()], 'o': optimizer.snapshot(),
+            'seed': {k: t.clone() for k, t in runtime._seed_tensors.items()}}       # device-side dropout replay counters
     if ema is not None:
         snap['e'] = {n: v.clone() for n, v in ema.shadow.items()}
     return snap
@@ -163,6 +165,12 @@ def _restore(model, optimizer, snap, ema=None):
     for p, v in zip(model.parameters(), snap['p']):
         p.copy_(v)
     optimizer.restore(snap['o'])
+    from . import runtime
+    for k, t in runtime._seed_tensors.items():
+        if k in snap['seed']:
+            t.copy_(snap['seed'][k])
+        else:
+            t.zero_()
     if ema is not None:
         for n, v in snap['e'].items():
             ema.shadow[n].copy_(v)

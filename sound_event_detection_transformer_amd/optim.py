@@ -189,8 +189,7 @@ class FusedAdamW(torch.optim.Optimizer):
         t['g'][lo:hi] = (gbase[self._owner] + self._off)[lo:hi]
         if hi > lo:
             isz = _DT.itemsize
-            self._host_gtab.numpy()[lo * isz:hi * isz] = t[lo:hi].view(np.uint8)
-            self._upload(self._dev_gtab[lo * isz:hi * isz], self._host_gtab[lo * isz:hi * isz])
+            self._upload(self._dev_gtab[lo * isz:hi * isz], self._host_gtab[lo * isz:hi * isz], t[lo:hi].view(np.uint8), ('g', lo, hi))
             mode = (1 if accumulate else 0) | (2 if self._flat_dtype == torch.bfloat16 else 0)
             L.check(L.load().sedt_multi_gather(L.p(self._dev_gtab[lo * isz:]), hi - lo, mode, L.stream_ptr()), 'multi_gather')
         return view
@@ -222,9 +221,8 @@ class FusedAdamW(torch.optim.Optimizer):
             t['pad'] = 0
         t['lr'] = lrs[self._gi][self._owner]
         t['wd'] = wds[self._gi][self._owner]
-        self._host_tab.numpy()[:] = t.view(np.uint8)
         self._sets[self._tabset]['hyper'] = (lrs.tobytes(), wds.tobytes())
-        self._upload(self._dev_tab, self._host_tab)
+        self._upload(self._dev_tab, self._host_tab, t.view(np.uint8), ('s',))
         self._step += 1
         lib = L.load()
         g0 = self.param_groups[0]
@@ -237,19 +235,41 @@ class FusedAdamW(torch.optim.Optimizer):
         L.check(lib.sedt_multi_adamw(L.p(self._dev_tab), n, L.p(self._sumsq), float(max_norm), g0['betas'][0], g0['betas'][1],
                                      g0['eps'], L.p(self._step_t), L.p(self.guard), L.stream_ptr()), 'multi_adamw')
 
-    def _upload(self, dev, host):
-        """pinned chunk table -> device.  While a HIP graph is being captured the copy is NOT recorded (it would be replayed with
-        every step: one more node in front of the optimizer kernels for a table that only changes when a learning rate does):
-        it is queued and ``flush_uploads`` - which the capturing stepper calls right after the capture - performs it once."""
-        if dev.is_cuda and torch.cuda.is_current_stream_capturing():
-            self.__dict__.setdefault('_deferred', []).append((dev, host))
+    def _upload(self, dev, host, content, what):
+        """chunk table ``content`` (bytes) -> pinned ``host`` -> ``dev``.  The copy is asynchronous, so the pinned buffer must
+        not be rewritten while an earlier copy from it is still queued behind the device's work (eager steps issued back to back
+        used to do exactly that: a step whose gradients had moved could run on the NEXT step's pointers).  Hence: nothing is
+        written or copied when the table is what the device already has (the steady state: the caching allocator hands the
+        gradients the same blocks every step); otherwise the event of the last copy from this buffer is waited for first.
+        While a HIP graph is being captured the copy is NOT recorded (it would be replayed with every step: one more node in
+        front of the optimizer kernels for a table that only changes when a learning rate does): it is queued and
+        ``flush_uploads`` - which the capturing stepper calls right after the capture - performs it once."""
+        st = self._sets[self._tabset]
+        marks = st.setdefault('marks', {})                  # per table part: the event of its last copy (None: copy pending in _deferred)
+        hv = host.numpy()
+        capturing = dev.is_cuda and torch.cuda.is_current_stream_capturing()
+        if what in marks and np.array_equal(hv, content):
+            return
+        if not capturing:                                  # (a capture starts after a device synchronize: nothing is pending)
+            for key, ev in marks.items():                  # every earlier copy that read bytes about to be rewritten
+                if ev is not None and key[0] == what[0] and (len(key) == 1 or (key[1] < what[2] and what[1] < key[2])):
+                    ev.synchronize()
+        hv[:] = content
+        if capturing:
+            self.__dict__.setdefault('_deferred', []).append((dev, host, st, what))
+            marks[what] = None
         else:
             dev.copy_(host, non_blocking=True)
+            if dev.is_cuda:
+                marks[what] = torch.cuda.Event()
+                marks[what].record()
+            else:
+                marks[what] = None
 
     def flush_uploads(self):
         """perform the table uploads queued during a capture (see _upload); returns how many"""
         q, self._deferred = self.__dict__.get('_deferred', []), []
-        for dev, host in q:
+        for dev, host, st, what in q:
             dev.copy_(host, non_blocking=True)
         if q:
             torch.cuda.synchronize(self._dev)

@@ -432,6 +432,41 @@ def test_fused_multi_tensor_adamw_matches_torch(ops):
             np.testing.assert_allclose(m.detach().cpu().numpy(), r.detach().numpy(), rtol=2e-5, atol=1e-7)
 
 
+def test_fused_adamw_steps_issued_back_to_back_keep_their_own_gradient_pointers(ops):
+    """two eager steps queued behind a busy device, the second with its gradients at OTHER addresses: each step must run on
+    the chunk table it was issued with (the pinned table used to be rewritten while the first step's upload was still queued,
+    so both steps read the second step's gradients); a third step with unchanged pointers re-uses the device table as is"""
+    from sound_event_detection_transformer_amd.optim import FusedAdamW
+    shapes = [(300, 70), (40000,), (11,)]
+
+    def run(sync):
+        ps = [(randn(*s) * 0 + 1.0).cuda().requires_grad_(True) for s in shapes]
+        opt = FusedAdamW(ps, lr=1e-2, weight_decay=0.0)
+        g1 = [torch.full(s, 0.5, device='cuda') for s in shapes]
+        g2 = [torch.full(s, -3.0, device='cuda') for s in shapes]
+        for p, g in zip(ps, g1):
+            p.grad = g
+        opt.step(max_norm=0.0)                       # (builds the tables; everything below re-uses them)
+        torch.cuda.synchronize()
+        busy = torch.randn(4096, 4096, device='cuda')
+        for _ in range(60):                          # ~10 ms of queued work: the host runs ahead of the device
+            busy = busy @ busy * 1e-3
+        opt.step(max_norm=0.0)
+        if sync:
+            torch.cuda.synchronize()
+        for p, g in zip(ps, g2):
+            p.grad = g
+        opt.step(max_norm=0.0)
+        if sync:
+            torch.cuda.synchronize()
+        opt.step(max_norm=0.0)
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in ps]
+
+    for a, b in zip(run(False), run(True)):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('dt', [F32, BF16])
 @pytest.mark.parametrize('M,N,K', [(8192, 256, 2048), (300, 768, 256), (704, 11, 256), (1000, 64, 64)])
 def test_linear_wgrad_with_fused_bias_grad(ops, dt, M, N, K):
