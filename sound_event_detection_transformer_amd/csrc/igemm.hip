@@ -524,7 +524,7 @@ extern "C" int sedt_igemm(const SedtIgemm* args, int dtype, void* stream) {
 namespace sedt {
 int wgrad3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st);
 bool wgrad4_shape_ok(int M, int N);
-int wgrad4_tile_m(int M);
+int wgrad4_tile_m(int M, int N);
 int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st);
 }
 
@@ -603,8 +603,8 @@ extern "C" int sedt_igemm_splitk(int M, int N, int K, int dtype) {
       const char* e = getenv("SEDT_SPLITK_TARGET_WIDE");
       wide_env = e ? atoi(e) : -1;
     }
-    tiles = (long)(M / sedt::wgrad4_tile_m(M)) * (N / 128);
-    tgt = wide_env > 0 ? wide_env : (sedt::wgrad4_tile_m(M) == 256 ? 64 : 128);
+    tiles = (long)(M / sedt::wgrad4_tile_m(M, N)) * (N / 128);
+    tgt = wide_env > 0 ? wide_env : (sedt::wgrad4_tile_m(M, N) == 256 ? 64 : 128);
   }
   int s = (int)((tgt + tiles - 1) / tiles);
   int maxs = nkb / 4 > 1 ? nkb / 4 : 1;

@@ -356,17 +356,19 @@ static int wg4_stages() {
 // rows of a tile for a problem with M output rows (Cout): the 256 x 128 tile where M allows it (SEDT_WGRAD4_BM=128: never).
 // Same-box A/B on the C2 step (tools/dev/ab_wgrad4.sh, ms/step): 128-row tiles 5.85-5.86 at every split target; 256-row tiles
 // with split-K target 32 / 48 / 64 / 80 / 128 / 192 tiles: 5.79 / 5.71 / 5.67 / 5.74 / 5.81 / 5.96
-int wgrad4_tile_m(int M) {
-  static int bm = -1;
+int wgrad4_tile_m(int M, int N) {
+  static int bm = -1, min_tiles = 1;
   if (bm < 0) {
     const char* e = getenv("SEDT_WGRAD4_BM");
     bm = (e && atoi(e) == 128) ? 128 : 256;
+    e = getenv("SEDT_WGRAD4_WIDE_MIN");               // experiment: the 256-row tile only for problems with at least this many of them
+    min_tiles = e ? atoi(e) : 1;
   }
-  return (bm == 256 && M % 256 == 0) ? 256 : 128;
+  return (bm == 256 && M % 256 == 0 && (long)(M / 256) * (N / 128) >= min_tiles) ? 256 : 128;
 }
 static size_t wg4_lds() {
   const size_t narrow = (size_t)wg4_stages() * 2 * 64 * 256, wide = (size_t)3 * 3 * 64 * 256;
-  return wgrad4_tile_m(256) == 256 ? std::max(narrow, wide) : narrow;
+  return wgrad4_tile_m(256, 1 << 20) == 256 ? std::max(narrow, wide) : narrow;
 }
 
 // shape part of the envelope (sedt_igemm_splitk sizes the split for the 128x128 tiling when this holds)
@@ -413,7 +415,7 @@ int launch_wgrad4(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStr
     if (wg4_attr(wgrad4_kernel<3>, "wgrad4") || wg4_attr(wgrad4_kernel<4>, "wgrad4")) return 1;
     attr_set = true;
   }
-  const int bm = wgrad4_tile_m(p.M);
+  const int bm = wgrad4_tile_m(p.M, p.N);
   const int nwg = (p.N / 128) * (p.M / bm);
   const int nmajor = (p.N > p.M ? 1 : 0) | (bm == 256 ? 2 : 0);
   const dim3 grid(nwg, p.splitk > 1 ? p.splitk : 1);
@@ -432,7 +434,7 @@ int launch_wgrad4_group(WgradGroup& g, hipStream_t st) {
   int blk = 0;
   for (int i = 0; i < g.n; ++i) {
     const SedtIgemm& p = g.p[i];
-    const int bm = wgrad4_tile_m(p.M);
+    const int bm = wgrad4_tile_m(p.M, p.N);
     g.nwg[i] = (p.N / 128) * (p.M / bm);
     g.nmajor[i] = (p.N > p.M ? 1 : 0) | (bm == 256 ? 2 : 0);
     g.blk0[i] = blk;
