@@ -251,6 +251,12 @@ class _GraphedBase(object):
         optimizer.set_segments([sg[0] for sg in segs])
         self.segs = [(sg[0], sg[1]) for sg in segs]
 
+    def _grad_sink(self, accumulate=False):
+        """scope in which the large weight gradients are written straight into their slots of the f32 flat gradient buffer
+        (ops.grad_sink); a no-op scope when micro-batches accumulate there or the buffer is bf16"""
+        views = None if accumulate else self.optimizer.flat_views()
+        return ops.grad_sink(views)
+
     def _root_grad(self, root):
         return self._one if (root.dim() == 0 and root.dtype == torch.float32) else torch.ones_like(root)
 
@@ -262,10 +268,11 @@ class _GraphedBase(object):
         if cut is not None and cut_t is None:
             raise RuntimeError('the model did not keep the cut tensor of a data-parallel segment')
         want = ([cut_t] if cut_t is not None else []) + list(params)
-        if k == 0:
-            grads = torch.autograd.grad(root, want, grad_outputs=self._root_grad(root))
-        else:
-            grads = torch.autograd.grad(self._cut_t, want, grad_outputs=self._cut_g)
+        with self._grad_sink(accumulate):
+            if k == 0:
+                grads = torch.autograd.grad(root, want, grad_outputs=self._root_grad(root))
+            else:
+                grads = torch.autograd.grad(self._cut_t, want, grad_outputs=self._cut_g)
         if cut_t is not None:
             self._cut_t, self._cut_g = cut_t, grads[0]
             grads = grads[1:]

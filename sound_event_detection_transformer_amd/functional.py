@@ -329,7 +329,7 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, b
     else:
         g1 = ops.dropout_grad(dt, g_out, p, s['seeds'][1], sp) if p > 0 else g_out
     d_bo = torch.empty((E,), device=g_out.device, dtype=torch.float32)
-    d_wo = ops.linear_wgrad(dt, g1, s['ctxv'], bias_out=d_bo, batch=batch)
+    d_wo = ops.linear_wgrad(dt, g1, s['ctxv'], bias_out=d_bo, batch=batch, param=w_out)
     g_ctx = ops.linear(dt, g1, s['wb_o'])
     td = g_out.dtype
     if s['same_qk']:
@@ -347,7 +347,9 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, b
         dv = torch.empty((B * Lk, E), device=g_out.device, dtype=td)
     ops.attention_bwd(dt, s['q'], s['k'], s['v'], s['ctxv'], g_ctx, s['lse'], B, H, Lq, Lk, dq, dk, dv, s['kpm'], s['amask'],
                       p, s['seeds'][0], sp)
-    d_win = torch.empty((3 * E, E), device=g_out.device, dtype=torch.float32)
+    d_win = ops._sink(w_in, (3 * E, E))                     # (the data-parallel steppers' flat gradient buffer, ops.grad_sink)
+    if d_win is None:
+        d_win = torch.empty((3 * E, E), device=g_out.device, dtype=torch.float32)
     d_bin = torch.empty((3 * E,), device=g_out.device, dtype=torch.float32)
     wb = s['wb_in']                                         # [E][3E]
     g_q = g_k = g_v = None
@@ -393,11 +395,11 @@ def _ffn_bwd(dt, s, g_out, w1, w2, res_for_gx=None, batch=None, g_dropped=None):
     else:
         g2 = ops.dropout_grad(dt, g_out, p, s['seeds'][1], runtime.seed_ptr(g_out.device)) if p > 0 else g_out
     d_b2 = torch.empty((g2.shape[1],), device=g2.device, dtype=torch.float32)
-    d_w2 = ops.linear_wgrad(dt, g2, s['h'], bias_out=d_b2, batch=batch)
+    d_w2 = ops.linear_wgrad(dt, g2, s['h'], bias_out=d_b2, batch=batch, param=w2)
     # d_hidden = (g2 @ W2) * [h > 0] / (1-p): h = drop(relu(.)) is positive exactly where kept and active
     gh = ops.linear(dt, g2, s['wb2'], mask=s['h'], ldm=s['h'].stride(0), alpha=1.0 / (1.0 - p) if p > 0 else 1.0)
     d_b1 = torch.empty((gh.shape[1],), device=gh.device, dtype=torch.float32)
-    d_w1 = ops.linear_wgrad(dt, gh, s['x_in'], bias_out=d_b1, batch=batch)
+    d_w1 = ops.linear_wgrad(dt, gh, s['x_in'], bias_out=d_b1, batch=batch, param=w1)
     if res_for_gx is not None:
         gx = ops.linear(dt, gh, s['wb1'], res=res_for_gx, ldr=res_for_gx.stride(0))
     else:
@@ -712,17 +714,17 @@ class StageFn(Function):
             want_gx = (not first) or need_x_grad
             # conv3 (1x1): wgrad, dgrad masked by relu(b)
             if t[10].requires_grad:
-                grads[base + 10] = ops.wgrad(dt, gp, r['b'], B, r['g3'], rowscale=s3, batch=rb)
+                grads[base + 10] = ops.wgrad(dt, gp, r['b'], B, r['g3'], rowscale=s3, batch=rb, param=t[10])
             gb = ops.conv_dgrad(dt, gp, B, r['g3'], w3b, mask=r['b'], ldm=r['b'].stride(0))
             # conv2 (3x3): wgrad, dgrad masked by relu(a)
             if t[5].requires_grad:
-                grads[base + 5] = ops.wgrad(dt, gb, r['a'], B, r['g2'], rowscale=s2, batch=rb)
+                grads[base + 5] = ops.wgrad(dt, gb, r['a'], B, r['g2'], rowscale=s2, batch=rb, param=t[5])
             ga = ops.conv_dgrad(dt, gb, B, r['g2'], w2b, mask=r['a'], ldm=r['a'].stride(0))
             # conv1 (1x1) wgrad
             if t[0].requires_grad:
-                grads[base + 0] = ops.wgrad(dt, ga, r['x'], B, r['g1'], rowscale=s1, batch=rb)
+                grads[base + 0] = ops.wgrad(dt, ga, r['x'], B, r['g1'], rowscale=s1, batch=rb, param=t[0])
             if blk.ds and t[15].requires_grad:
-                grads[base + 15] = ops.wgrad(dt, gp, r['x'], B, r['gd'], rowscale=r['sd'], batch=rb)
+                grads[base + 15] = ops.wgrad(dt, gp, r['x'], B, r['gd'], rowscale=r['sd'], batch=rb, param=t[15])
             if want_gx:
                 side = ops.conv_dgrad(dt, gp, B, r['gd'], r['wdb']) if blk.ds else gp
                 mask_x = (not first) or meta['mask_input']

@@ -7,6 +7,7 @@ allocator.  No arithmetic happens in torch here; torch is device memory + stream
 import ctypes as C
 
 import os
+import numpy as np
 import torch
 
 from . import lib as L
@@ -387,14 +388,48 @@ class ReduceBatch(object):
             self._launch()
 
 
-def wgrad(dtype, dy, x, B, g, rowscale=None, out=None, bias_out=None, batch=None):
+GRAD_SINK = None      # {parameter data_ptr: f32 view}: where the weight gradient of that parameter is to be written (grad_sink())
+
+
+class grad_sink(object):
+    """inside the scope, weight-gradient kernels called with ``param=`` write into the view registered for that parameter - the data-
+    parallel steppers register the parameters' slots in the flat gradient buffer (FusedAdamW.flat_views), which spares the
+    130 MB gather pass for the tensors that are produced this way"""
+
+    def __init__(self, views):
+        self.views = dict(views) if views else None      # own copy: a slot is handed out ONCE per scope (see _sink)
+
+    def __enter__(self):
+        global GRAD_SINK
+        self.prev, GRAD_SINK = GRAD_SINK, self.views
+        return self
+
+    def __exit__(self, *a):
+        global GRAD_SINK
+        GRAD_SINK = self.prev
+        return False
+
+
+def _sink(param, shape):
+    if GRAD_SINK is None or param is None:
+        return None
+    # pop: a parameter that receives a second contribution in the same backward (a module applied twice) gets an ordinary
+    # buffer for it - autograd then sums the two into a new tensor and the gather pass copies that one
+    v = GRAD_SINK.pop(param.data_ptr(), None)
+    return v.view(shape) if v is not None and v.numel() == int(np.prod(shape)) else None
+
+
+def wgrad(dtype, dy, x, B, g, rowscale=None, out=None, bias_out=None, batch=None, param=None):
     """dW (Co, Ci, KH, KW) f32 = sum over pixels dy[pix][co] * gather(x)[pix][tap][ci] (* rowscale[co]).
     bias_out (f32 [Co]): also receives sum over pixels of dy (fused into the wgrad kernel when it can, else a colsum).
-    batch: a ReduceBatch - the split-K reduction is deferred until batch.flush() (the result is valid only then)"""
+    batch: a ReduceBatch - the split-K reduction is deferred until batch.flush() (the result is valid only then).
+    param: the parameter this is the gradient of - with a grad_sink() active the result lands in the registered view"""
     from . import runtime
     lib = L.load()
     Mo, No, Kp = g.Co, g.taps * g.Ci, B * g.Ho * g.Wo
     sk = lib.sedt_igemm_splitk(Mo, No, Kp, dtype)
+    if out is None:
+        out = _sink(param, (g.Co, g.Ci, g.KH, g.KW))
     if out is None:
         out = torch.empty((g.Co, g.Ci, g.KH, g.KW), device=dy.device, dtype=torch.float32)
 
@@ -424,12 +459,12 @@ def wgrad(dtype, dy, x, B, g, rowscale=None, out=None, bias_out=None, batch=None
     return out
 
 
-def linear_wgrad(dtype, dy, x, out=None, bias_out=None, batch=None):
+def linear_wgrad(dtype, dy, x, out=None, bias_out=None, batch=None, param=None):
     """dW [N,K] f32 = dy[M,N]^T @ x[M,K]; bias_out f32 [N] optionally receives the column sums of dy"""
     N, K = dy.shape[1], x.shape[1]
     g = ConvGeom(1, 1, K, N)
     return wgrad(dtype, dy, x, dy.shape[0], g, out=out.view(N, K, 1, 1) if out is not None else None,
-                 bias_out=bias_out, batch=batch).view(N, K)
+                 bias_out=bias_out, batch=batch, param=param).view(N, K)
 
 
 def colsum(dtype, x, out=None):

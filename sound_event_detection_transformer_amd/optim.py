@@ -150,6 +150,19 @@ class FusedAdamW(torch.optim.Optimizer):
             raise RuntimeError(f'the flat gradient buffer already exists as {self._flat_dtype}')
         return self._flat_g
 
+    def flat_views(self):
+        """{parameter data_ptr: view of its slot in the f32 flat gradient buffer, shaped like the parameter}: a kernel that
+        writes a weight gradient there (ops.GRAD_SINK) has delivered it - gather_grads skips tensors whose gradient already
+        lives in its slot.  None for a bf16 flat buffer (the gradients need the rounding pass)."""
+        flat = self.enable_flat_grads()
+        if self._flat_dtype != torch.float32:
+            return None
+        views, e0 = {}, 0
+        for p, pad in zip(self._ps, self._pad):
+            views[p.data_ptr()] = flat[e0:e0 + p.numel()].view(p.shape)
+            e0 += pad
+        return views
+
     @property
     def n_segments(self):
         return self._nseg
@@ -189,9 +202,15 @@ class FusedAdamW(torch.optim.Optimizer):
         t['g'][lo:hi] = (gbase[self._owner] + self._off)[lo:hi]
         if hi > lo:
             isz = _DT.itemsize
-            self._upload(self._dev_gtab[lo * isz:hi * isz], self._host_gtab[lo * isz:hi * isz], t[lo:hi].view(np.uint8), ('g', lo, hi))
-            mode = (1 if accumulate else 0) | (2 if self._flat_dtype == torch.bfloat16 else 0)
-            L.check(L.load().sedt_multi_gather(L.p(self._dev_gtab[lo * isz:]), hi - lo, mode, L.stream_ptr()), 'multi_gather')
+            rows = t[lo:hi]
+            if not accumulate:
+                rows = rows[rows['g'] != rows['p']]          # gradients written straight into their slot (flat_views)
+            k = len(rows)
+            if k:
+                self._upload(self._dev_gtab[lo * isz:(lo + k) * isz], self._host_gtab[lo * isz:(lo + k) * isz],
+                             np.ascontiguousarray(rows).view(np.uint8), ('g', lo, lo + k))
+                mode = (1 if accumulate else 0) | (2 if self._flat_dtype == torch.bfloat16 else 0)
+                L.check(L.load().sedt_multi_gather(L.p(self._dev_gtab[lo * isz:]), k, mode, L.stream_ptr()), 'multi_gather')
         return view
 
     @torch.no_grad()
