@@ -30,21 +30,28 @@ __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_read
 // PP (8 waves only): "ping-pong" - the second wave group runs its MFMAs half a stage late, i.e. while the first group reads
 // its fragments and issues the next LDS-DMA, and reads its own fragments while the first group's MFMAs run: with one
 // workgroup per CU (128x128 tiles at M = 8192, N = 512) nothing else overlaps the LDS phase with the MFMA phase.
-template <int BM, int BN, int S, int NW, bool CONV, int PP = 0>
+// KH = 2 (8 waves, ping-pong only): TWO such 8-wave teams in one 1024-thread workgroup, each with its own ring, each over one half
+// of K; the four wave groups' partial sums meet in the epilogue.  For the problems with exactly one 64x128 tile per CU
+// (M = 8192, N = 256: layer3, the FFN's second linear) it doubles the waves per SIMD without shrinking the tile.
+template <int BM, int BN, int S, int NW, bool CONV, int PP = 0, int KH = 1>
 __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int bx) {
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int STAGE_BYTES = (BM + BN) * ROWB;
   constexpr int GA = BM / (8 * NW), GB = BN / (8 * NW);
-  constexpr int NT = NW * 64;
+  constexpr int NT = NW * KH * 64;
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(KH == 1 || (KH == 2 && NW == 8 && PP), "two K halves: the ping-pong 8-wave form only");
   static_assert(GA >= 1 && GB >= 1, "tile too small for the wave count");
   constexpr unsigned OOB = 0x80000000u;          // >= 2^31 > num_records; stays out of range after adding any K offset
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int t = threadIdx.x, lane = t & 63;
-  const int wave = uniform_i32(t >> 6);
+  const int wave_all = uniform_i32(t >> 6);
+  const int khalf = KH == 2 ? wave_all >> 3 : 0;       // which half of K (and which ring) this wave's team works on
+  const int wave = KH == 2 ? (wave_all & 7) : wave_all;
   const int kgrp = wave >> 2;                          // 0, or 0/1 with 8 waves: which half of the k16 steps
   const int wm = ((wave & 3) >> 1) * WM, wn = (wave & 1) * WN;
+  unsigned char* const ring = smem + khalf * (S * STAGE_BYTES);
 
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
   const int nwg = ntn * ntm;
@@ -54,7 +61,8 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
   const int m0 = (vid / ntn) * BM, n0 = (vid % ntn) * BN;
-  const int nkb = p.K / BK2;
+  const int nkb = p.K / BK2 / KH;                       // K tiles of this team
+  const int kb0 = khalf * nkb;                         // its first K tile
 
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, b_bytes, 0x00020000);
@@ -140,13 +148,22 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   }
 
   // ---- wave-uniform K position: channel offset inside the tap, tap index, its pixel shift in bytes
-  int c0 = 0, tap = 0, kh = 0, kw = 0, k0 = 0;
+  int c0 = 0, tap = 0, kh = 0, kw = 0, k0 = kb0 * BK2;
   const int rowbytes = (int)(tsub * 2);
+  if (CONV && KH == 2) {                                // the second team starts in the middle of the (tap, channel) walk
+    tap = k0 / p.Ci;
+    c0 = k0 - tap * p.Ci;
+    kh = tap / p.KW;
+    kw = tap - kh * p.KW;
+  }
   // CONV: per A row, the offset of the CURRENT tap with its validity folded in (out of range when the tap misses the image);
   // it changes only when the tap does, so a K tile costs one add per row
   unsigned a_cur[GA];
+  {
+    const unsigned tapdelta0 = CONV ? (unsigned)(sg * (kh * p.dh * p.Wi + kw * p.dw) * rowbytes) : 0u;
 #pragma unroll
-  for (int i = 0; i < GA; ++i) a_cur[i] = (!CONV || (a_mask[i] & 1u)) ? a_off[i] : OOB;
+    for (int i = 0; i < GA; ++i) a_cur[i] = (!CONV || (a_mask[i] & (1u << tap))) ? a_off[i] + tapdelta0 : OOB;
+  }
   auto advance = [&]() {
     k0 += BK2;
     if (!CONV) return;
@@ -167,7 +184,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
 
   // one LDS-DMA piece of the tile at the current K position: pieces 0..GA-1 are A rows, GA..GA+GB-1 are B rows
   auto issue_piece = [&](const int stage, const int i) {      // literal stage / piece only: folds to immediates
-    unsigned char* st = smem + stage * STAGE_BYTES;
+    unsigned char* st = ring + stage * STAGE_BYTES;
     const unsigned kb2 = (unsigned)(k0 * 2);
     if (i < GA) {
       const unsigned koff = CONV ? (unsigned)(c0 * 2) : kb2;    // (an out-of-range a_cur stays out of range: c0 * 2 < 2^31)
@@ -216,7 +233,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   // The waves of a workgroup run in lockstep between barriers, so nothing else hides that latency.
   bf16x8 fa[NKQ][MI], fb[NKQ][NI];
   auto load_frags = [&](const int stage) {
-    const unsigned char* st = smem + stage * STAGE_BYTES;
+    const unsigned char* st = ring + stage * STAGE_BYTES;
 #pragma unroll
     for (int kq = 0; kq < NKQ; ++kq) {
 #pragma unroll
@@ -343,11 +360,12 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   // 8 waves: the two groups hold the two halves of the K sum.  When the ring has room for two staging tiles each group
   // writes its own and the chunk loop adds them (one phase, one barrier); otherwise the second group adds into the first
   // group's tile in a second phase.
-  constexpr bool TWO_CS = NW == 8 && (size_t)S * (BM + BN) * ROWB >= (size_t)2 * BM * CP * sizeof(float);
+  constexpr bool TWO_CS = NW == 8 && (size_t)KH * S * (BM + BN) * ROWB >= (size_t)2 * KH * BM * CP * sizeof(float);
+  static_assert(KH == 1 || TWO_CS, "two K halves: the rings must hold the four staging tiles");
   float* Cs = reinterpret_cast<float*>(smem);
   float* Cs2 = Cs + BM * CP;
   if (NW == 4 || kgrp == 0 || TWO_CS) {
-    float* dst = (TWO_CS && kgrp == 1) ? Cs2 : Cs;
+    float* dst = Cs + (TWO_CS ? (khalf * 2 + kgrp) * (BM * CP) : 0);
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -408,9 +426,12 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       const float4 x1 = *reinterpret_cast<const float4*>(Cs + trow * CP + cc + 4);
       v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
       if (TWO_CS) {
-        const float4 y0 = *reinterpret_cast<const float4*>(Cs2 + trow * CP + cc);
-        const float4 y1 = *reinterpret_cast<const float4*>(Cs2 + trow * CP + cc + 4);
-        v[0] += y0.x; v[1] += y0.y; v[2] += y0.z; v[3] += y0.w; v[4] += y1.x; v[5] += y1.y; v[6] += y1.z; v[7] += y1.w;
+#pragma unroll
+        for (int gq = 1; gq < 2 * KH; ++gq) {           // the other wave groups' shares of the K sum, in a fixed order
+          const float4 y0 = *reinterpret_cast<const float4*>(Cs2 + (gq - 1) * (BM * CP) + trow * CP + cc);
+          const float4 y1 = *reinterpret_cast<const float4*>(Cs2 + (gq - 1) * (BM * CP) + trow * CP + cc + 4);
+          v[0] += y0.x; v[1] += y0.y; v[2] += y0.z; v[3] += y0.w; v[4] += y1.x; v[5] += y1.y; v[6] += y1.z; v[7] += y1.w;
+        }
       }
     }
     if (affine) {
@@ -469,10 +490,10 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   }
 }
 
-template <int BM, int BN, int S, int NW = 4, int PP = 0>
+template <int BM, int BN, int S, int NW = 4, int PP = 0, int KH = 1>
 __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int bx) {
-  if (p.conv) igemm3_impl<BM, BN, S, NW, true, PP>(p, a_bytes, b_bytes, bx);      // uniform branch: two specialised programs
-  else igemm3_impl<BM, BN, S, NW, false, PP>(p, a_bytes, b_bytes, bx);
+  if (p.conv) igemm3_impl<BM, BN, S, NW, true, PP, KH>(p, a_bytes, b_bytes, bx);      // uniform branch: two specialised programs
+  else igemm3_impl<BM, BN, S, NW, false, PP, KH>(p, a_bytes, b_bytes, bx);
 }
 
 template <int BM, int BN, int S>
@@ -483,6 +504,32 @@ __global__ __launch_bounds__(256) void igemm3_kernel(const SedtIgemm p, const un
 template <int BM, int BN, int S, int PP = 0>
 __global__ __launch_bounds__(512) void igemm3_w8_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes) {
   igemm3_body<BM, BN, S, 8, PP>(p, a_bytes, b_bytes, blockIdx.x);
+}
+
+// 16 waves: two 8-wave ping-pong teams, each over one half of K (KH = 2)
+template <int BM, int BN, int S>
+__global__ __launch_bounds__(1024) void igemm3_w16_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes) {
+  igemm3_body<BM, BN, S, 8, 1, 2>(p, a_bytes, b_bytes, blockIdx.x);
+}
+
+template <int BM, int BN, int S>
+static int launch3_w16(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  constexpr size_t ring = (size_t)2 * S * (BM + BN) * ROWB;
+  constexpr size_t ctile = (size_t)4 * BM * (BN + 4) * sizeof(float);
+  constexpr size_t lds = ring > ctile ? ring : ctile;
+  static bool attr_set = false;
+  auto kern = igemm3_w16_kernel<BM, BN, S>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("igemm3 w16: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+      return 1;
+    }
+    attr_set = true;
+  }
+  const int nwg = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(1024), lds, st, p, a_bytes, b_bytes);
+  return check_launch("igemm3_w16");
 }
 
 template <int BM, int BN, int S, int PP = 0>
@@ -700,6 +747,18 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
     w4k = e ? atoi(e) : 0;
   }
   const bool force4 = p.K < w4k;
+  // exactly one 64x128 tile per CU and a long K: two 8-wave teams per workgroup, half of K each (SEDT_IGEMM3_W16=1)
+  static int w16 = -1, w16_mink = 0;
+  if (w16 < 0) {
+    const char* e = getenv("SEDT_IGEMM3_W16");        // same-box A/B on the C2 step: 5.688 -> 5.657 ms (29 launches, ~ -10 % each)
+    w16 = (e && e[0] == '0') ? 0 : 1;
+    e = getenv("SEDT_IGEMM3_W16_MINK");
+    w16_mink = e ? atoi(e) : 1024;
+  }
+  if (w16 && !plan3.on && co_group == nullptr && bm == 64 && bn == 128 && S >= 3 && p.K >= w16_mink && (p.K / BK2) % 2 == 0) {
+    const long tiles = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
+    if (tiles <= 320) return launch3_w16<64, 128, 3>(p, a_bytes, b_bytes, st);
+  }
   if (!plan3.on && co_group == nullptr && nw_env != 4 && pp_env && !force4) {
 #define SEDT_PP(BM_, BN_)                                                                                   \
   if (bm == BM_ && bn == BN_) {                                                                             \

@@ -226,7 +226,13 @@ def _nccl_worker(rank, port, out, dp, kind='sedt'):
         run(batch(200 + 10 * i))
     torch.cuda.synchronize()
     vec = torch.cat([p.detach().flatten().float().cpu() for p in model.parameters() if p.requires_grad])
-    torch.save({'vec': vec, 'finite': bool(torch.isfinite(vec).all()) and int(stepper.nonfinite.item()) == 0 and bool((vec != v0).any())}, out)
+    sunk = 0
+    if dp:                  # parameters whose static gradient IS its slot of the flat buffer (ops.grad_sink): no packing copy for them
+        flat = opt._flat_g
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+        sunk = sum(1 for p in model.parameters() if p.grad is not None and lo <= p.grad.data_ptr() < hi)
+    torch.save({'vec': vec, 'sunk': sunk,
+                'finite': bool(torch.isfinite(vec).all()) and int(stepper.nonfinite.item()) == 0 and bool((vec != v0).any())}, out)
     if dp:
         dist.destroy_process_group()
 
@@ -240,6 +246,8 @@ def test_rccl_schedule_on_one_gpu_matches_single_process_step(tmp_path, kind):
     mp.spawn(_nccl_worker, args=(_free_port(), b, False, kind), nprocs=1, join=True)
     ra, rb = torch.load(a), torch.load(b)
     assert ra['finite'] and rb['finite']
+    # the convolution / FFN / attention-projection weights of the trainable part deliver their gradients in place
+    assert ra['sunk'] >= {'sedt': 60, 'spsedt': 30, 'semi': 60}[kind], ra['sunk']
     diff = (ra['vec'] - rb['vec']).abs()
     d = diff.max().item()
     where = torch.nonzero(diff > 0).flatten()

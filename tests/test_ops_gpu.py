@@ -741,6 +741,33 @@ def test_direct_conv3x3_c64_forward_and_dgrad(ops, B, H):
     assert torch.equal(ops.conv_fwd(dt, xd, B, g, wf, scale=sc.cuda(), bias=bi.cuda(), act=ops.ACT_RELU), y)     # reproducible
 
 
+@pytest.mark.parametrize('cfg', [(32, 4, 256, 256, 3, 1, 1, 1), (32, 4, 1024, 256, 1, 1, 0, 1), (32, 4, 2048, 256, 1, 1, 0, 1)])
+def test_sixteen_wave_gemm_matches_the_four_wave_tiles(ops, cfg):
+    """M = 8192, N = 256, K >= 1024 (layer3's convolutions, the FFN's second linear: exactly one 64x128 tile per CU) run as a
+    1024-thread workgroup - two 8-wave ping-pong teams, half of K each (csrc/igemm3.hip, KH = 2); tile = (64, 64) keeps the
+    problem on the 4-wave kernel.  Same bf16 inputs, f32 sums in another order: equal to a bf16 rounding; forward with the
+    Bottleneck epilogue, input gradient with a 1-bit mask; repeats are bit-identical"""
+    Hi, Wi, Ci, Co, k, s, pd, dl = cfg
+    B, dt = 64, BF16
+    g = ops.ConvGeom(Hi, Wi, Ci, Co, k, s, pd, dl)
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    x = torch.randn(B * Hi * Wi, Ci, device='cuda', generator=gen).bfloat16()
+    gy = torch.randn(B * g.Ho * g.Wo, Co, device='cuda', generator=gen).bfloat16()
+    res = torch.randn(B * g.Ho * g.Wo, Co, device='cuda', generator=gen).bfloat16()
+    sc, bi = torch.rand(Co, device='cuda', generator=gen) + 0.5, torch.randn(Co, device='cuda', generator=gen)
+    w = torch.randn(Co, Ci, k, k, device='cuda', generator=gen) / math.sqrt(Ci * k * k)
+    wf, wb = ops.pack_conv(dt, w)
+    bits = torch.zeros((x.shape[0], Ci // 8), dtype=torch.uint8, device='cuda')
+    bits.copy_(((x.float() > 0).view(-1, Ci // 8, 8).to(torch.int32) * (2 ** torch.arange(8, device='cuda', dtype=torch.int32))).sum(-1).to(torch.uint8))
+    for fn in (lambda **t: ops.conv_fwd(dt, x, B, g, wf, scale=sc, bias=bi, res=res, ldr=Co, act=ops.ACT_RELU, act_post_res=1, **t),
+               lambda **t: ops.conv_dgrad(dt, gy, B, g, wb, mask=bits, ldm=bits.stride(0), mask_bits=True, **t)):
+        a, b = fn(), fn(tile=(64, 64))
+        assert torch.isfinite(a.float()).all()
+        assert (a.float() - b.float()).abs().max().item() <= 2e-2 * b.float().abs().max().item()
+        assert ((a == 0) != (b == 0)).float().mean().item() < 1e-3
+        assert torch.equal(fn(), a)
+
+
 @pytest.mark.parametrize('dt,M,N,K', [(BF16, 640, 256, 128), (BF16, 200, 72, 40), (F32, 130, 64, 96), (BF16, 8192, 1024, 256)])
 def test_one_bit_relu_masks_in_the_gemm_epilogue(ops, dt, M, N, K):
     """SedtIgemm.bits_out / mask_bits (round 3): a GEMM that stores relu(x w^T + res) also leaves the 1-bit image of [out > 0];
