@@ -72,8 +72,9 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   //      store); issuing the residual/mask loads first overlaps them with the whole K loop.  They are older than every
   //      LDS-DMA, so the counted vmcnt waits of the ring stay valid.
   constexpr int CPR = BN / 8;                          // 16-byte chunks per tile row
-  constexpr int NCH = BM * CPR / NT;                   // chunks per thread
-  static_assert(BM * CPR % NT == 0, "epilogue chunks must divide evenly");
+  constexpr int NCH = (BM * CPR + NT - 1) / NT;        // chunks per thread
+  constexpr bool PARTIAL = BM * CPR % NT != 0;         // more threads than chunks (64x64 tile, 1024 threads): the upper threads idle
+  static_assert(!PARTIAL || NCH == 1, "epilogue chunks must divide evenly, or be fewer than the threads");
   const bf16_t* resT = reinterpret_cast<const bf16_t*>(p.res);
   const bool mbits = p.mask_bits != 0;                 // the mask is a 1-bit image: one BYTE per 8-column chunk
   const bf16_t* maskT = mbits ? nullptr : reinterpret_cast<const bf16_t*>(p.mask);
@@ -84,7 +85,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   for (int c = 0; c < NCH; ++c) {
     const int u = t + c * NT;
     const int row = m0 + u / CPR, col = n0 + (u % CPR) * 8;
-    if (row < p.M && col < p.N) {
+    if (row < p.M && col < p.N && (!PARTIAL || u < BM * CPR)) {
       if (resT) {
         int rrow = row;
         if (p.res_mod > 0) rrow = row % p.res_mod;          // uniform branch: the common case pays no integer division
@@ -419,7 +420,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     const int u = t + c * NT;
     const int trow = u / CPR, cc = (u % CPR) * 8;
     const int row = m0 + trow, col = n0 + cc;
-    if (row >= p.M || !col_ok) continue;
+    if (row >= p.M || !col_ok || (PARTIAL && u >= BM * CPR)) continue;
     float v[8];
     {
       const float4 x0 = *reinterpret_cast<const float4*>(Cs + trow * CP + cc);
@@ -753,11 +754,22 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
     const char* e = getenv("SEDT_IGEMM3_W16");        // same-box A/B on the C2 step: 5.688 -> 5.657 ms (29 launches, ~ -10 % each)
     w16 = (e && e[0] == '0') ? 0 : 1;
     e = getenv("SEDT_IGEMM3_W16_MINK");
-    w16_mink = e ? atoi(e) : 1024;
+    w16_mink = e ? atoi(e) : 512;            // (512 vs 1024: C2 5.61 vs 5.65 ms, C3 4.56 vs 4.58 - within the run-to-run spread)
   }
   if (w16 && !plan3.on && co_group == nullptr && bm == 64 && bn == 128 && S >= 3 && p.K >= w16_mink && (p.K / BK2) % 2 == 0) {
     const long tiles = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
     if (tiles <= 320) return launch3_w16<64, 128, 3>(p, a_bytes, b_bytes, st);
+  }
+  // the B = 32 configurations (M = 3968 rows) run on 64x64 tiles, 248 of them at N = 256 - one 4-wave workgroup per CU: the same
+  // two-team form on that tile (same-box A/B: C3 4.655 -> 4.568 ms, C5 8.34 -> 8.27; one 8-wave team instead: no change)
+  static int small16 = -1;
+  if (small16 < 0) {
+    const char* e = getenv("SEDT_IGEMM3_SMALL16");
+    small16 = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (small16 && !plan3.on && co_group == nullptr && bm == 64 && bn == 64 && S >= 3 && p.K >= w16_mink && (p.K / BK2) % 2 == 0) {
+    const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    if (tiles <= 320) return launch3_w16<64, 64, 3>(p, a_bytes, b_bytes, st);
   }
   if (!plan3.on && co_group == nullptr && nw_env != 4 && pp_env && !force4) {
 #define SEDT_PP(BM_, BN_)                                                                                   \
