@@ -749,16 +749,18 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
   }
   const bool force4 = p.K < w4k;
   // exactly one 64x128 tile per CU and a long K: two 8-wave teams per workgroup, half of K each (SEDT_IGEMM3_W16=1)
-  static int w16 = -1, w16_mink = 0;
+  static int w16 = -1, w16_mink = 0, w16_tiles = 320;
   if (w16 < 0) {
     const char* e = getenv("SEDT_IGEMM3_W16");        // same-box A/B on the C2 step: 5.688 -> 5.657 ms (29 launches, ~ -10 % each)
     w16 = (e && e[0] == '0') ? 0 : 1;
+    e = getenv("SEDT_IGEMM3_W16_TILES");
+    w16_tiles = e ? atoi(e) : 320;
     e = getenv("SEDT_IGEMM3_W16_MINK");
     w16_mink = e ? atoi(e) : 512;            // (512 vs 1024: C2 5.61 vs 5.65 ms, C3 4.56 vs 4.58 - within the run-to-run spread)
   }
   if (w16 && !plan3.on && co_group == nullptr && bm == 64 && bn == 128 && S >= 3 && p.K >= w16_mink && (p.K / BK2) % 2 == 0) {
     const long tiles = (long)((p.M + 63) / 64) * ((p.N + 127) / 128);
-    if (tiles <= 320) return launch3_w16<64, 128, 3>(p, a_bytes, b_bytes, st);
+    if (tiles <= w16_tiles) return launch3_w16<64, 128, 3>(p, a_bytes, b_bytes, st);
   }
   // the B = 32 configurations (M = 3968 rows) run on 64x64 tiles, 248 of them at N = 256 - one 4-wave workgroup per CU: the same
   // two-team form on that tile (same-box A/B: C3 4.655 -> 4.568 ms, C5 8.34 -> 8.27; one 8-wave team instead: no change)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of the wgrad4 variants on the C2 step (SEDT_WGRAD4_STAGES / SEDT_WGRAD4_BM / SEDT_SPLITK_TARGET_WIDE / SEDT_WGRAD4_WIDE_MIN)
+# same-box A/B of the wgrad4 variants on the C2 step (SEDT_WGRAD4_STAGES / SEDT_WGRAD4_BM / SEDT_SPLITK_TARGET_WIDE / SEDT_WGRAD4_WIDE_MIN / SEDT_WGRAD4_BIAS)
 set -o pipefail
 out=gpurun_out/ab_wgrad4.log
 : > $out
@@ -9,9 +9,8 @@ run() {
 }
 for rep in 1 2; do
   run SEDT_X=0
-  run SEDT_WGRAD4_WIDE_MIN=9
-  run SEDT_WGRAD4_WIDE_MIN=17
-  run SEDT_WGRAD4_WIDE_MIN=20
-  run SEDT_SPLITK_TARGET_WIDE=56
-  run SEDT_SPLITK_TARGET_WIDE=72
+  run SEDT_WGRAD4_BIAS=1
+  run SEDT_WGRAD4_BIAS=1 SEDT_SPLITK_TARGET_WIDE=48
+  run SEDT_WGRAD4_BIAS=1 SEDT_SPLITK_TARGET_WIDE=40
+  run SEDT_WGRAD4_BIAS=1 SEDT_SPLITK_TARGET_WIDE=32
 done
