@@ -25,11 +25,37 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const T* __restrict__ x
   float* ws = sm;                       // [N][P]
   float* xs = sm + N * P;               // [16][P]
   const int t = threadIdx.x;
-  for (int i = t; i < N * K; i += 256) ws[(i / K) * P + i % K] = w[i];
   const int r0 = blockIdx.x * 16;
-  for (int i = t; i < 16 * K; i += 256) {
-    const int r = i / K, k = i - r * K;
-    xs[r * P + k] = r0 + r < M ? (float)x[(long)(r0 + r) * ldx + k] : 0.f;
+  // 16-byte global loads when the operands allow it (K % 8 == 0, aligned rows): the tile is 16 x K activations + N x K weights,
+  // and with one element per load a thread issued 27 dependent-latency loads before the first multiply
+  const bool vec = (K & 7) == 0 && (ldx & 7) == 0 && (reinterpret_cast<uintptr_t>(x) & 31) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0;
+  if (vec) {
+    const int k4 = K >> 2;
+    for (int i = t; i < N * k4; i += 256) {
+      const int n = i / k4, q = i - n * k4;
+      *reinterpret_cast<float4*>(ws + n * P + 4 * q) = *reinterpret_cast<const float4*>(w + (long)n * K + 4 * q);
+    }
+    const int k8 = K >> 3;
+    for (int i = t; i < 16 * k8; i += 256) {
+      const int r = i / k8, q = i - r * k8;
+      float v[8];
+      if (r0 + r < M) {
+        const VecT<T, 8> xv = *reinterpret_cast<const VecT<T, 8>*>(x + (long)(r0 + r) * ldx + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)xv.v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      }
+      *reinterpret_cast<float4*>(xs + r * P + 8 * q) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(xs + r * P + 8 * q + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  } else {
+    for (int i = t; i < N * K; i += 256) ws[(i / K) * P + i % K] = w[i];
+    for (int i = t; i < 16 * K; i += 256) {
+      const int r = i / K, k = i - r * K;
+      xs[r * P + k] = r0 + r < M ? (float)x[(long)(r0 + r) * ldx + k] : 0.f;
+    }
   }
   __syncthreads();
   const int r = t >> 4, n = t & 15;
