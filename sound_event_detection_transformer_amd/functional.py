@@ -500,9 +500,26 @@ class DecoderLayerFn(Function):
         tgt, mem, mem_pos, qpos = _as(tgt, dt), _as(mem, dt), _as(mem_pos, dt), _as(qpos, dt)
         sv = {}
         tr = any(ctx.needs_input_grad)
-        if cfg['pre_norm']:
+        if cfg['pre_norm'] and ops.FUSED_DEC_SA and ops.encoder_attn_ok(dt, tgt.shape[1], H, Q, tgt_mask) and tgt.is_contiguous() \
+                and qpos.is_contiguous() and qpos.shape == tgt.shape:
+            # self-attention of the Q queries of a clip: LayerNorm1 + Q|K|V projections + attention core in ONE launch - the kernel
+            # built for the encoder (csrc/attn_mfma.hip: enc_attn_fused_kernel) with S = Q.  At M = B*Q rows the three launches it
+            # replaces are pure launch latency
+            wf, wb_in = _prep_linear(dt, sw_in, tr)
+            wf_o, wb_o = _prep_linear(dt, sw_o, tr)
+            sp = runtime.seed_ptr(tgt.device) if p > 0 else None
+            ctxv, lse, by = ops.encoder_attn_fwd(dt, tgt, qpos, g1, be1, wf, sb_in, B, Q, H, None, p, seeds[0], sp, train=tr)
+            t1 = ops.linear(dt, ctxv, wf_o, bias=sb_o, drop_p=p, seed=seeds[1], seed_ptr=sp, res=tgt, ldr=tgt.stride(0))
+            m1 = r1 = None
+            if tr:
+                tn, tnp, m1, r1, qk, v = by
+                E = tgt.shape[1]
+                sv['sa'] = dict(wb_in=wb_in, wb_o=wb_o, q_in=tnp, k_in=tnp, v_in=tn, same_qk=True, qk=qk, q=qk[:, :E], k=qk[:, E:], v=v,
+                                ctxv=ctxv, lse=lse, dims=(B, H, Q, Q), kpm=None, amask=None, p=p, seeds=seeds[0:2])
+        elif cfg['pre_norm']:
             tn, tnp, m1, r1 = ops.layernorm_fwd(dt, tgt, g1, be1, add_t=qpos)
             t1, sv['sa'] = _mha_fwd(dt, tnp, tnp, tn, True, sw_in, sb_in, sw_o, sb_o, tgt, B, H, Q, Q, None, tgt_mask, p, seeds[0:2], tr)
+        if cfg['pre_norm']:
             t1n, t1np, m2, r2 = ops.layernorm_fwd(dt, t1, g2, be2, add_t=qpos)
             t2, sv['ca'] = _mha_fwd(dt, t1np, mem_pos, mem, False, cw_in, cb_in, cw_o, cb_o, t1, B, H, Q, S, kpm, None, p, seeds[2:4], tr)
             t2n, _, m3, r3 = ops.layernorm_fwd(dt, t2, g3, be3)

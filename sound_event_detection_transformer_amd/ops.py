@@ -607,6 +607,10 @@ STEM_DIRECT = os.environ.get('SEDT_STEM_DIRECT', '1') != '0'     # one-launch st
 # MI355X, level with the three launches it replaces (30.6 vs 32.7 us no-grad, 32.2 in training form) but not ahead: one
 # workgroup per CU runs its phases strictly in sequence.  Opt in with SEDT_FUSED_ENC=1.
 FUSED_ENC = os.environ.get('SEDT_FUSED_ENC', '0') == '1'
+# the same kernel for the decoder's self-attention over the Q queries of a clip (S = Q <= 32): three launches -> one.  Correct (tests)
+# and slower: its fixed skeleton (~18 us, see above) exceeds the three latency-bound launches it replaces - C2 5.49 -> 5.57 ms, C3
+# 4.55 -> 4.59 ms (same-box A/B).  Opt in with SEDT_FUSED_DEC_SA=1.
+FUSED_DEC_SA = os.environ.get('SEDT_FUSED_DEC_SA', '0') == '1'
 
 
 def encoder_attn_ok(dtype, D, H, S, amask):

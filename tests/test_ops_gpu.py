@@ -662,7 +662,8 @@ def test_gemm_repeat_runs_are_bit_identical(ops, cfg):
             assert torch.equal(fn(), first), name
 
 
-@pytest.mark.parametrize('B,S,padded,p', [(3, 128, False, 0.0), (2, 124, True, 0.0), (2, 124, False, 0.1), (64, 128, False, 0.1)])
+@pytest.mark.parametrize('B,S,padded,p', [(3, 128, False, 0.0), (2, 124, True, 0.0), (2, 124, False, 0.1), (64, 128, False, 0.1),
+                                         (64, 11, False, 0.1), (5, 21, False, 0.0)])      # S = 11 / 21: the decoder's self-attention over its queries
 def test_fused_encoder_attention_head_matches_unfused_chain(ops, B, S, padded, p):
     """sedt_encoder_attn_fwd (LayerNorm1 + Q|K|V projections + attention core in one launch) == layernorm_fwd + linear_group +
     attention_fwd on the same inputs and the same dropout seed; by-products included.  bf16: both sides round q/k/v/xn to bf16;
