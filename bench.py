@@ -338,11 +338,15 @@ def build_workload(args, dev, rank, world):
     ema = EMA(model, 0.9996)
     ema.register()
     opt = build_optimizer(model)
-    gen = torch.Generator().manual_seed(seed)
-    x_t = torch.randn(B, 1, 496, 64, generator=gen)
-    x_s = x_t.clone()
-    x_s[n_s + n_w:] += 0.1 * torch.randn(n_u, 1, 496, 64, generator=gen)     # the student's augmented view of the unlabelled clips
-    x_t, x_s = x_t.to(dev), x_s.to(dev)
+    # both views come from raw mel amplitudes through the reference's transform chain ON THE DEVICE, inside every timed step
+    # (train_ss_sedt.py:87-90 --freq_mask --time_mask; utilities/BoxTransforms.py:363-427, 454-490): teacher = ApplyLog + PadOrTrunc
+    # + FreqMask + Normalize, student = the noisy copy through ApplyLog + PadOrTrunc + TimeMask + FreqMask + Normalize, np.random
+    # parameters drawn per clip on the host in the reference's order
+    from sound_event_detection_transformer_amd.utilities.synthetic import synthetic_semi_raw, semi_view_transforms
+    raw_t, raw_s = synthetic_semi_raw(n_s + n_w, n_u, 496, seed)
+    raw_t, raw_s = raw_t.to(dev), raw_s.to(dev)
+    tf_t, tf_s = semi_view_transforms(496, dev)
+    x_t, x_s = tf_t(raw_t), tf_s(raw_s)
     targets = synthetic_targets(B, seed + 1, 10)
     for t in targets[n_s:]:
         t['boxes'] = torch.zeros(0, 2)
@@ -362,16 +366,27 @@ def build_workload(args, dev, rank, world):
         os._exit(3)
     extras.update(stepper=g, model=model)
 
+    def views():
+        tf_t(raw_t, out=x_t)
+        tf_s(raw_s, out=x_s)
+
     def step():
+        views()
         g(x_t, x_s, targets)
 
     def local_step():
         loc = GraphedSemiStep(model, ema, criterion, opt, x_t, x_s, targets, *masks, thr, mix_up_ratio=mix, data_parallel=False)
-        return lambda: loc(x_t, x_s, targets)
+
+        def run():
+            views()
+            loc(x_t, x_s, targets)
+        return run
     extras['local_step'] = local_step
     what = (f"semi-supervised mean-teacher step (train_ss_sedt.py) enc_layers=6 num_queries=20 per GPU: {n_s} synthetic + {n_w} weak "
             f"labelled clips fwd/bwd, {n_u} unlabelled clips through the EMA teacher (no grad) -> device pseudo labels -> student "
-            f"fwd/bwd on the augmented view, one backward, clip 0.1 + AdamW + EMA update, dropout 0.1, " +
+            f"fwd/bwd on the augmented view (both views produced per step from raw mel amplitudes by sedt_box_transform: ApplyLog, "
+            f"PadOrTrunc, FreqMask(mean), Normalize; the student's also TimeMask), one backward, clip 0.1 + AdamW + EMA update, "
+            f"dropout 0.1, " +
             (f"mixup {mix} inside the step (mixup_data on the labelled clips, mixup_label_unlabel of the student view with the "
              f"pseudo labels: np.random draws + label plan on the host per step, feature mixing + label merge in the graph)"
              if mix else "mixup off"))

@@ -29,6 +29,19 @@ def _newer(target, deps):
 
 
 def build(force=False, verbose=False, jobs=None):
+    """concurrent importers (torchrun ranks, mp.spawn test workers) serialise on build/.lock: one of them compiles, the others find
+    everything up to date; objects and the library are written to a temporary name and renamed"""
+    import fcntl
+    os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, '..', '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose, jobs)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose, jobs):
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     objs = [os.path.join(OBJ, s + '.o') for s in SOURCES]
@@ -41,20 +54,23 @@ def build(force=False, verbose=False, jobs=None):
     os.makedirs(OBJ, exist_ok=True)
 
     def compile_one(so):
-        cmd = [hipcc, *FLAGS, '-c', so[0], '-o', so[1]]
+        tmp = f'{so[1]}.{os.getpid()}.tmp'
+        cmd = [hipcc, *FLAGS, '-c', so[0], '-o', tmp]
         if verbose:
             print(' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed on {so[0]}:\n' + r.stdout + r.stderr)
+        os.replace(tmp, so[1])
 
     with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(compile_one, todo))
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', LIB + '.tmp']
+    tmp = f'{LIB}.{os.getpid()}.tmp'
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', tmp]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n' + r.stdout + r.stderr)
-    os.replace(LIB + '.tmp', LIB)
+    os.replace(tmp, LIB)
     return LIB
 
 

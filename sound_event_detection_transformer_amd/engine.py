@@ -231,6 +231,17 @@ class _GraphedBase(object):
         self._host_bump = not (getattr(self, 'max_norm', 0) > 0 and getattr(self, 'accum_steps', 1) == 1)
         optimizer.seed_word = None if self._host_bump else _rt.seed_ptr(dev)
 
+    def _release_shared(self):
+        """the guard / seed words are baked into THIS stepper's captured launches (pointers); the shared optimizer / EMA objects must
+        not keep them, or eager optimizer.step() / ema.update() calls - the eager fallback of a stepper whose construction failed,
+        or eager steps between replays - would be silently skipped by a flag nothing polls"""
+        opt = getattr(self, 'optimizer', None)
+        if opt is not None:
+            opt.guard = opt.seed_word = None
+        ema = getattr(self, 'ema', None)
+        if ema is not None and hasattr(ema, 'guard'):
+            ema.guard = None
+
     def _before_replay(self):
         self.optimizer.refresh_hyperparams(self._tabname)      # StepLR / param_group['lr'] edits reach the captured upload
 
@@ -335,7 +346,13 @@ class GraphedTrainStep(_GraphedBase):
     50-100 us per cross-queue dependency: 7.6 vs 7.3 ms/step), coschedule=True lets them ride in the spare workgroup
     slots of later dgrad launches (ops.WgradPool; 7.3 vs 7.2 ms/step)."""
 
-    def __init__(self, model, criterion, optimizer, example_input, example_targets, mask_weak=None, mask_strong=None,
+    def __init__(self, *args, **kw):
+        try:
+            self._construct(*args, **kw)
+        finally:
+            self._release_shared()
+
+    def _construct(self, model, criterion, optimizer, example_input, example_targets, mask_weak=None, mask_strong=None,
                  max_norm=0.1, normalize=False, warmup=3, device_matching=True, max_targets=32, async_wgrad=False,
                  overlap_allreduce=True, coschedule=False, data_parallel=None, example_patches=None, fine_tune=False, fl=False,
                  ft_rand=None, mix_up_ratio=0.0, mix_alpha=1, max_events=20, accum_steps=1, dp_cuts='coarse', grad_dtype=None):
@@ -516,8 +533,17 @@ class GraphedTrainStep(_GraphedBase):
         split = {}
         if self.mix:
             from .utilities.mixup import draw_mixup_data, plan_mixup_data, job_table
+            import numpy as np
+            rng = np.random.get_state()
             lam, index = draw_mixup_data(len(targets), self.mix_alpha)
-            jobs, targets, n_strong, n_weak = plan_mixup_data(targets, self.ms, self.mw, lam, index, self.mix, self.max_events)
+            jobs, mixed, n_strong, n_weak = plan_mixup_data(targets, self.ms, self.mw, lam, index, self.mix, self.max_events)
+            if len(mixed) != len(targets):
+                # mixup_data dropped clips (utilities/mixup.py:104-122 without a weak mask: a merged pair with no events at all
+                # and the unlabelled remainder leave the batch) - the captured shapes do not hold for this batch: it takes the
+                # eager step, with the np.random stream rewound so that mixup_data makes the same draws
+                np.random.set_state(rng)
+                return self._eager_batch(batch_input, targets, patches)
+            targets = mixed
             self.static_raw.copy_(batch_input, non_blocking=True)
             self._jobs.send(job_table(jobs))
             split = dict(ns=n_strong, n_lab=n_strong + n_weak)
@@ -554,6 +580,22 @@ class GraphedTrainStep(_GraphedBase):
                 self.g_opt.replay()
         self._after_replay(check_finite)
         return self.static_total, self.static_losses
+
+
+    def _eager_batch(self, batch_input, targets, patches=None):
+        """one batch the captured graph cannot take, through engine.train_step on the training stream (same optimizer state: the
+        device-side step count and moments are shared)"""
+        if self.flat_mode:
+            raise NotImplementedError('a batch that mix-up shrinks cannot bypass the captured data-parallel / accumulation schedule: '
+                                      'pass mask_weak (mixup_data then keeps the batch size) or use the eager train_step')
+        side, cur = train_stream(self.dev), torch.cuda.current_stream(self.dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            out = train_step(self.model, self.criterion, self.optimizer, batch_input, targets, self.mw, self.ms, self.max_norm,
+                             self.normalize, check_finite=True, patches=patches, fine_tune=self.fine_tune, fl=self.fl,
+                             mix_up_ratio=self.mix)
+        cur.wait_stream(side)
+        return out
 
 
 def broadcast_parameters(model, src=0):
@@ -760,7 +802,13 @@ class GraphedSemiStep(_GraphedBase):
     place (``stepper.threshold.copy_(...)``) when the driver adjusts them per epoch (train_ss_sedt.py:207).
     ``counter`` (int32 [C]) accumulates the pseudo events per class like the reference's pseudo_labels_counter."""
 
-    def __init__(self, model, ema, criterion, optimizer, x_teacher, x_student, targets, mask_strong, mask_weak, mask_label,
+    def __init__(self, *args, **kw):
+        try:
+            self._construct(*args, **kw)
+        finally:
+            self._release_shared()
+
+    def _construct(self, model, ema, criterion, optimizer, x_teacher, x_student, targets, mask_strong, mask_weak, mask_label,
                  mask_unlabel, classwise_threshold, orig_size=10.0, fine_tune=False, normalize=False, fl=False, max_norm=0.1,
                  warmup=2, max_targets=32, accumulating_ema_steps=1, fuse_student_forwards=True, mix_up_ratio=0.0, mix_alpha=1,
                  max_events=20, accum_steps=1, overlap_allreduce=True, dp_cuts='coarse', grad_dtype=None, data_parallel=None):

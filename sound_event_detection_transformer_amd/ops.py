@@ -498,10 +498,16 @@ def add(dtype, a, b, b_mod=0, out=None):
 
 
 def add_n(dtype, tensors, out=None):
-    """sum of up to 8 equally shaped contiguous tensors of the compute dtype in one launch"""
+    """sum of equally shaped contiguous tensors of the compute dtype: one launch for up to 8 (sedt_add_n has 8 pointer slots), more are
+    folded in groups of 8 with the running sum as the first source of the next group (--dec_layers >= 5 hands over 2 shares per
+    layer of the query-position gradient, functional.DecoderLayerFn)"""
     _dev_check(*tensors)
+    tensors = list(tensors)
     n = len(tensors)
-    assert 1 <= n <= 8 and all(t.shape == tensors[0].shape and t.dtype == TORCH_DTYPE[dtype] and t.is_contiguous() for t in tensors)
+    assert n >= 1 and all(t.shape == tensors[0].shape and t.dtype == TORCH_DTYPE[dtype] and t.is_contiguous() for t in tensors)
+    while n > 8:
+        tensors = [add_n(dtype, tensors[:8])] + tensors[8:]
+        n = len(tensors)
     if out is None:
         out = torch.empty_like(tensors[0])
     arr = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])

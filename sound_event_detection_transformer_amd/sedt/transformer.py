@@ -176,6 +176,9 @@ class Transformer(nn.Module):
         forward otherwise); created fresh while a HIP graph is being captured (see utilities.utils.derived_from_static_mask)"""
         key = (rows, cols, runtime.torch_dtype(), str(device))
         z = self.__dict__.setdefault('_zeros', {}).get(key)
+        if z is not None:
+            from ..utilities.utils import pin_if_capturing
+            return pin_if_capturing(z)           # (a graph keeps the raw pointer: survive the eviction below)
         if z is None:
             z = torch.zeros((rows, cols), device=device, dtype=runtime.torch_dtype())
             if not (z.is_cuda and torch.cuda.is_current_stream_capturing()):

@@ -60,3 +60,31 @@ def synthetic_batch(B, T, seed, device=None, num_classes=10):
         x = x.to(device)
         targets = [{k: v.to(device) for k, v in t.items()} for t in targets]
     return x, targets
+
+
+SEMI_SCALER = (0.0, 10.0)          # per-band (mean, std) in dB of the synthetic amplitudes below: normalised features ~ N(0, 1)
+
+
+def synthetic_semi_raw(n_label, n_unl, T, seed, snr_db=30.0):
+    """raw mel AMPLITUDES (B, T, 64) for the mean-teacher step, as the reference's semi loader sees them before its transform
+    chain (train_ss_sedt.py:87-96): amplitudes 10^(N(0,1)/2), i.e. 10 dB of spread around 0 dB; the STUDENT copy of the
+    unlabelled clips carries AugmentGaussianNoise's additive noise (BoxTransforms.py:136-159: per band std = sqrt(mean_t(x^2 *
+    10^(-snr/10)))).  The two views then go through utilities.transforms.DeviceBoxTransform per step (teacher: FreqMask; student:
+    TimeMask + FreqMask - the reference's TimeMask skips view 0, BoxTransforms.py:24-26)."""
+    g = torch.Generator().manual_seed(seed)
+    B = n_label + n_unl
+    raw_t = torch.pow(10.0, 0.5 * torch.randn(B, T, 64, generator=g))
+    raw_s = raw_t.clone()
+    u = raw_t[n_label:]
+    std = torch.sqrt((u * u * 10.0 ** (-snr_db / 10.0)).mean(dim=1, keepdim=True))
+    raw_s[n_label:] = u + std * torch.randn(u.shape, generator=g)
+    return raw_t, raw_s
+
+
+def semi_view_transforms(T, device):
+    """(teacher transform, student transform) of the mean-teacher recipe with --freq_mask --time_mask (train_ss_sedt.py:87-90)"""
+    import numpy as np
+    from .transforms import DeviceBoxTransform
+    mean, std = np.full(64, SEMI_SCALER[0]), np.full(64, SEMI_SCALER[1])
+    return (DeviceBoxTransform(T, mean, std, time_mask=False, freq_mask=True, device=device),
+            DeviceBoxTransform(T, mean, std, time_mask=True, freq_mask=True, device=device))

@@ -33,6 +33,16 @@ class NestedTensor(object):
 
 _MASKS = {}
 _DERIVED = {}          # (id of a static mask, what) -> tensor derived from it (resized mask, position encoding)
+_PINNED = []           # cached tensors a HIP-graph capture has seen: a graph keeps raw pointers, so these are never released
+
+
+def pin_if_capturing(t):
+    """a cached tensor handed to a capture in progress must outlive every replay of that graph: the caches below are evicted by
+    .clear(), after which the allocator could reuse the memory under a live graph.  Small tensors (masks, position
+    encodings, zero tokens); kept for the life of the process."""
+    if t is not None and t.is_cuda and torch.cuda.is_current_stream_capturing() and not any(t is q for q in _PINNED):
+        _PINNED.append(t)
+    return t
 
 
 def is_static_mask(mask):
@@ -49,7 +59,7 @@ def derived_from_static_mask(mask, what, make):
     key = (id(mask), what)
     hit = _DERIVED.get(key)
     if hit is not None:
-        return hit
+        return pin_if_capturing(hit)
     out = make()
     if not (mask.is_cuda and torch.cuda.is_current_stream_capturing()):
         if len(_DERIVED) > 64:
@@ -66,7 +76,7 @@ def _no_padding_mask(b, h, w, device):
             _MASKS.clear()
             _DERIVED.clear()
         _MASKS[key] = torch.zeros((b, h, w), dtype=torch.bool, device=device)
-    return _MASKS[key]
+    return pin_if_capturing(_MASKS[key])
 
 
 def nested_tensor_from_tensor_list(tensor_list: List[Tensor]) -> NestedTensor:

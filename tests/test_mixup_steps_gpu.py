@@ -346,34 +346,102 @@ def test_graphed_train_step_with_mixup_matches_eager(pkg):
         assert rel(res['graph'][1][k], res['eager'][1][k]) < 2e-3, k
 
 
-def test_c5_full_size_semi_step_with_mixup_properties(pkg):
-    """BASELINE config C5 as its recipe runs it (train_ss_sedt.py --mix_up_ratio 0.6): 16 synthetic + 16 weak + 32 unlabelled clips,
-    E=6, Q=20, bf16, dropout on, both mix-ups inside the captured step.  Two independently captured steppers fed the same batches
-    under the same np.random seed end bit-identical; losses finite; the strong | weak split moves between replays; mixed unlabelled
-    clips carry ratios; parameters and the EMA teacher move"""
+def test_graphed_train_step_takes_the_eager_step_when_mixup_shrinks_the_batch(pkg):
+    """mixup_data without a weak mask (train_sedt.py --mix_up_ratio on URBAN-SED) drops a merged pair of clips that both have no
+    events (utilities/mixup.py:104-122): the batch shrinks and the captured shapes do not hold.  The stepper then runs that batch
+    through engine.train_step with the np.random stream rewound - same result as the eager loop; batches that keep their size
+    are replayed.  Also: a stepper leaves no guard / seed word behind on the shared optimizer."""
     runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import train_step, GraphedTrainStep
+    runtime.set_compute_dtype('bf16')
+    B = 8
+    batches = []
+    for i in range(4):
+        x = torch.randn(B, 1, 496, 64, generator=torch.Generator().manual_seed(900 + i)).cuda()
+        tg = GI.sparse_targets(B, 910 + i)
+        if i % 2 == 1:                                    # six clips without events: some mixed pair is empty | empty
+            for t in tg[:6]:
+                t['labels'], t['boxes'] = torch.zeros(0, dtype=torch.int64), torch.zeros(0, 2)
+        batches.append((x, tg))
+    res, fallbacks = {}, []
+    for mode in ('eager', 'graph'):
+        model, crit, opt = _sup_model(sedt, 2025)
+        if mode == 'graph':
+            stepper = GraphedTrainStep(model, crit, opt, batches[0][0], batches[0][1], None, slice(B), mix_up_ratio=0.6, warmup=2)
+            assert opt.guard is None and opt.seed_word is None
+            inner = stepper._eager_batch
+            stepper._eager_batch = lambda *a, **k: (fallbacks.append(1), inner(*a, **k))[1]
+        np.random.seed(7)
+        losses = []
+        for x, tg in batches:
+            if mode == 'eager':
+                l, _ = train_step(model, crit, opt, x, _cuda_targets(tg), None, slice(B), mix_up_ratio=0.6)
+            else:
+                l, _ = stepper(x, tg)
+            losses.append(float(l))
+        res[mode] = (losses, {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()})
+    runtime.set_compute_dtype('f32')
+    assert 1 <= len(fallbacks) <= 2, fallbacks
+    np.testing.assert_allclose(res['graph'][0], res['eager'][0], rtol=2e-3)
+    for k in res['eager'][1]:
+        assert rel(res['graph'][1][k], res['eager'][1][k]) < 2e-3, k
+
+
+def test_c5_full_size_semi_step_with_mixup_properties(pkg):
+    """BASELINE config C5 as its recipe runs it (train_ss_sedt.py --mix_up_ratio 0.6 --freq_mask --time_mask): 16 synthetic + 16 weak
+    + 32 unlabelled clips, E=6, Q=20, bf16, dropout on.  Per step BOTH views are produced on the device from raw mel amplitudes by
+    the reference's transform chain (sedt_box_transform; utilities/BoxTransforms.py:363-427, 454-490: teacher = log + pad + FreqMask
+    + normalise, student = the noisy copy + TimeMask too - TimeMask skips view 0, BoxTransforms.py:24-26), then both mix-ups run
+    inside the captured step.  Two independently captured steppers fed the same raw batches under the same np.random seed end
+    bit-identical; losses finite; the strong | weak split moves between replays; mixed unlabelled clips carry ratios; parameters and
+    the EMA teacher move; the student view of a clip equals the CPU oracle's chain on the same drawn parameters."""
+    runtime, sedt = pkg
+    from oracle import transforms_oracle as TO
     from sound_event_detection_transformer_amd.engine import GraphedSemiStep
+    from sound_event_detection_transformer_amd.utilities.synthetic import synthetic_semi_raw, semi_view_transforms, SEMI_SCALER
     runtime.set_compute_dtype('bf16')
     masks = dict(mask_strong=slice(16), mask_weak=slice(16, 32), mask_label=slice(32), mask_unlabel=slice(32, 64))
     thr = torch.full((10,), 0.1).cuda()
-    batches = [_rand_semi_batch(1900 + i, 16, 16, 32) for i in range(3)]
+    raws = []
+    for i in range(3):
+        rt, rs = synthetic_semi_raw(32, 32, 496, 1900 + i)
+        raws.append((rt.cuda(), rs.cuda(), _rand_semi_batch(1900 + i, 16, 16, 32)[2]))
+    tf_t, tf_s = semi_view_transforms(496, 'cuda')
     finals, curves, splits = [], [], []
     for run in range(2):
         runtime.manual_seed(777)
         np.random.seed(11)
         model, crit, ema, opt = _mix_semi_model(sedt, 2023, dropout=0.1, decay=0.9996, perturb=False)
         sd0 = {k: v.clone() for k, v in model.state_dict().items()}
-        stepper = GraphedSemiStep(model, ema, crit, opt, batches[0][0], batches[0][1], batches[0][2], classwise_threshold=thr,
-                                  mix_up_ratio=0.6, **masks)
-        losses = []
+        xt, xs = tf_t(raws[0][0]), tf_s(raws[0][1])
+        stepper = GraphedSemiStep(model, ema, crit, opt, xt, xs, raws[0][2], classwise_threshold=thr, mix_up_ratio=0.6, **masks)
+        losses, masked_rows, masked_bands = [], 0, 0
         for it in range(5):
-            xt, xs, tg = batches[it % 3]
+            rt, rs, tg = raws[it % 3]
+            p_t = np.stack([tf_t.draw(496) for _ in range(64)])
+            p_s = np.stack([tf_s.draw(496) for _ in range(64)])
+            tf_t(rt, params=p_t, out=xt)
+            tf_s(rs, params=p_s, out=xs)
+            if run == 0:
+                masked_rows += int((p_s['tm_t'] > 0).sum())
+                masked_bands += int(p_s['fm_on'].sum()) + int(p_t['fm_on'].sum())
+                assert int(p_t['tm_t'].sum()) == 0                       # the teacher view is never time-masked
+                if it == 0:                                              # composition check of one masked student clip vs the oracle
+                    b = int(np.argmax((p_s['tm_t'] > 0) & (p_s['fm_on'] > 0))) if ((p_s['tm_t'] > 0) & (p_s['fm_on'] > 0)).any() \
+                        else int(np.argmax(p_s['fm_on'] > 0))
+                    q = p_s[b]
+                    ref = TO.box_transform(rs[b].cpu().numpy().astype(np.float32), 496, np.full(64, SEMI_SCALER[0]),
+                                           np.full(64, SEMI_SCALER[1]),
+                                           (q['tm_t'] > 0, q['tm_t'] / 496 + 1e-9, q['tm_t0'] / 496 + 1e-9),
+                                           (bool(q['fm_on']), q['fm_f'] / 64 + 1e-9, q['fm_f0'] / 64 + 1e-9), None)
+                    assert rel(xs[b, 0], np.asarray(ref).reshape(496, 64)) < 5e-5
             total, sup, unsup = stepper(xt, xs, tg, check_finite=True)
             losses.append(float(total))
             if run == 0:
                 splits.append((stepper.tab_l.cur_ns, stepper.tab_l.cur_n_lab))
         torch.cuda.synchronize()
         if run == 0:
+            assert masked_rows > 0 and masked_bands > 0, (masked_rows, masked_bands)
             modes = stepper.jobs_u.cpu().numpy().view(np.int32).reshape(-1, 4)[:, 2]
             assert set(modes[16:].tolist()) == {2} and len(modes) == 32            # clips beyond mix_num keep their pseudo target
             ratios = stepper.tab_u.ratio_cat[:int(stepper.tab_u.off[32])].cpu()
