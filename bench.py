@@ -59,6 +59,18 @@ def parse():
     ap.add_argument('--bf16-buckets', action='store_true', help='data parallel: bf16 flat gradient buffer (half the all-reduce bytes)')
     ap.add_argument('--no-other-configs', action='store_true',
                     help='default c2 line only: skip the bounded c3 / c4 / c5 measurements attached as "other_configs"')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="process-group backend; 'gloo' (flat gradient segments staged through the host) exists for the multi-GPU readiness "
+                         "test on a one-GPU box (tests/test_dp_gpu.py): it exercises this file's rank path, not RCCL")
+    ap.add_argument('--share-gpu', action='store_true', help='readiness test: every rank uses cuda:0')
+    ap.add_argument('--force-graph-fallback', action='store_true',
+                    help='readiness test: pretend the captured data-parallel stepper cannot be built (every rank then has to agree on the '
+                         'eager fallback out of band)')
+    ap.add_argument('--no-families', action='store_true',
+                    help='skip roofline.families (the in-process kernel trace of three extra steps; use under rocprofv3, which owns the tracer)')
+    ap.add_argument('--loader', action='store_true',
+                    help='c2: feed every step from HOST-resident raw mel batches (pinned double buffer -> H2D on a copy stream -> '
+                         'sedt_box_transform -> graphed step) instead of replaying a device-resident batch')
     ap.add_argument('--mix-up-ratio', type=float, default=None,
                     help='mix-up inside the step (engine.py:50-53, 128-133, 150-153); default: 0.6 for c5 (its recipe), off for c2/c3')
     return ap.parse_args()
@@ -226,6 +238,8 @@ def build_workload(args, dev, rank, world):
         if graphed:
             g, err = None, None
             try:
+                if args.force_graph_fallback:
+                    raise RuntimeError('--force-graph-fallback (readiness test)')
                 g = GraphedTrainStep(net, criterion, opt, x, targets, wm, slice(ns), max_norm=0.1, device_matching=not args.host_matching,
                                      overlap_allreduce=not args.no_overlap, mix_up_ratio=mix, dp_cuts=args.dp_cuts,
                                      grad_dtype=torch.bfloat16 if args.bf16_buckets else None)
@@ -243,11 +257,46 @@ def build_workload(args, dev, rank, world):
                     g = None
                     graphed = False
                     extras['graph_fallback'] = err or 'another rank failed to build the graphed data-parallel step'
-                    from sound_event_detection_transformer_amd.engine import train_stream
-                    with torch.cuda.stream(train_stream(dev)):
-                        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False,
-                                                                        gradient_as_bucket_view=True)
-        if graphed:
+                    from sound_event_detection_transformer_amd.engine import train_stream, broadcast_parameters
+                    if torch.distributed.get_backend() == 'nccl':
+                        with torch.cuda.stream(train_stream(dev)):
+                            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], broadcast_buffers=False,
+                                                                            gradient_as_bucket_view=True)
+                    else:      # gloo moves no GPU tensors in this image: the eager step averages its flat gradient buffer itself
+                        broadcast_parameters(model)
+                        extras['eager_allreduce'] = True
+        if graphed and args.loader:
+            # input side in the loop: the batch is HOST-resident raw mel amplitudes per clip, as the reference's
+            # DataLoader hands them over (data_utils/DataLoad.py:160-180 before its transform chain); per step: pinned staging + ONE
+            # H2D copy on the prefetcher's copy stream (data_utils/DataLoad.py:304-336), the BoxTransforms chain of train_sedt.py:194-207
+            # (ApplyLog, PadOrTrunc, TimeMask, FreqMask, FreqShift, Normalize) as sedt_box_transform on that stream, np.random draws in
+            # the reference's order on the host, then the graphed step on what the prefetcher hands over
+            import numpy as np
+            from sound_event_detection_transformer_amd.utilities.prefetch import DevicePrefetcher
+            from sound_event_detection_transformer_amd.utilities.transforms import DeviceBoxTransform
+            from sound_event_detection_transformer_amd.utilities.synthetic import SEMI_SCALER
+            rng = np.random.RandomState(seed)
+            pool = [([np.power(10.0, 0.5 * rng.randn(T, 64)).astype(np.float32) for _ in range(B)],
+                     synthetic_batch(B, T, seed + 10 * i, torch.device('cpu'))[1]) for i in range(4)]
+            for _, tg in pool:
+                for t in tg[ns:]:
+                    t['boxes'] = torch.zeros(0, 2)
+
+            def endless():
+                i = 0
+                while True:
+                    yield pool[i % len(pool)]
+                    i += 1
+            tf = DeviceBoxTransform(T, np.full(64, SEMI_SCALER[0]), np.full(64, SEMI_SCALER[1]), time_mask=True, freq_mask=True,
+                                    freq_shift=True, device=dev)
+            pf = DevicePrefetcher(endless(), dev, transform=tf, targets_to_device=False)
+            extras['stepper'] = g
+            extras['loader'] = "host raw mel clips -> pinned staging -> H2D (copy stream) -> sedt_box_transform(time/freq mask, shift) -> step"
+
+            def step():
+                xb, tb = pf.next()
+                g(xb, tb)
+        elif graphed:
             extras['stepper'] = g
 
             def step():
@@ -261,7 +310,8 @@ def build_workload(args, dev, rank, world):
                 opt.zero_grad(set_to_none=True)
         else:
             def step():
-                train_step(net, criterion, opt, x, targets, wm, slice(ns), max_norm=0.1, mix_up_ratio=mix)
+                train_step(net, criterion, opt, x, targets, wm, slice(ns), max_norm=0.1, mix_up_ratio=mix,
+                           allreduce=bool(extras.get('eager_allreduce')))
         extras.update(model=model, criterion=criterion, opt=opt, x=x, targets=targets, wm=wm, ns=ns, net=net)
         if graphed:
             def local_step():                     # the same step without the data-parallel schedule (exposed_comm)
@@ -271,7 +321,8 @@ def build_workload(args, dev, rank, world):
         what = (f"{'URBAN-SED' if cfg == 'c2' else 'DCASE2019'} SEDT enc_layers={E} dec_at num_queries={Q} B={B}/GPU"
                 f"{'' if cfg == 'c2' else f' ({ns} strong + {B - ns} weak)'}, 10 s @ 64-mel (B,1,{T},64), full train step: fwd + "
                 f"Hungarian matching ({'host' if (args.host_matching or not graphed) else 'device'}) + SetCriterion + bwd + clip 0.1 + "
-                f"AdamW, dropout 0.1" + (f", mixup {mix} inside the step" if mix else "") + (" [model-only timing]" if args.model_only else ""))
+                f"AdamW, dropout 0.1" + (f", mixup {mix} inside the step" if mix else "") + (" [model-only timing]" if args.model_only else "")
+                + (" [INPUT SIDE IN THE LOOP: " + extras['loader'] + "]" if extras.get('loader') else ""))
         return step, B, FLOP_PER_CLIP[cfg] * B, what, graphed, extras
     if cfg == 'eval':
         from sound_event_detection_transformer_amd.engine import GraphedPredictStep
@@ -391,6 +442,167 @@ def build_workload(args, dev, rank, world):
              f"pseudo labels: np.random draws + label plan on the host per step, feature mixing + label merge in the graph)"
              if mix else "mixup off"))
     return step, B, FLOP_C5_STEP_64 * B / 64.0, what, True, extras
+
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _short_kernel_name(name):
+    """'void sedt::igemm3_kernel<64, 64, 2>(SedtIgemm, unsigned, unsigned)' -> 'igemm3_kernel<64, 64, 2>'"""
+    n = name.strip()
+    if n.startswith('_ZN4sedt'):                 # a mangled name the demangler could not take (DF16b = __bf16): the length-prefixed identifier
+        import re
+        m = re.match(r'_ZN4sedt(\d+)', n)
+        if m:
+            k = int(m.group(1))
+            ident = n[len(m.group(0)):len(m.group(0)) + k]
+            return ident + ('<bf16>' if 'DF16b' in n else '<float>' if 'IfL' in n or 'IfE' in n else '')
+    if n.startswith('void '):
+        n = n[5:]
+    depth, cut = 0, len(n)
+    for i, ch in enumerate(n):
+        if ch == '<':
+            depth += 1
+        elif ch == '>':
+            depth -= 1
+        elif ch == '(' and depth == 0:
+            cut = i
+            break
+    n = n[:cut].strip()
+    return n.replace('sedt::', '').replace('(anonymous namespace)::', '')
+
+
+def _demangle(names):
+    mangled = [n for n in names if n.startswith('_Z')]
+    if not mangled:
+        return {}
+    for tool in ('/opt/rocm/lib/llvm/bin/llvm-cxxfilt', 'llvm-cxxfilt', 'c++filt'):
+        try:
+            r = subprocess.run([tool], input='\n'.join(mangled), capture_output=True, text=True, timeout=30)
+            out = r.stdout.split('\n')
+            if r.returncode == 0 and len(out) >= len(mangled):
+                return dict(zip(mangled, out))
+        except Exception:                            # noqa: BLE001
+            continue
+    return {}
+
+
+def kernel_times(step, reps=3):
+    """{short kernel name: [us per step, launches per step]} of `reps` further steps, from the activity records the torch profiler
+    collects in THIS process (every kernel dispatch of the replayed graphs, whoever launched it)"""
+    import torch
+    from torch.profiler import profile, ProfilerActivity
+    from torch.autograd import DeviceType
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+    raw = {}
+    for e in prof.events():
+        if e.device_type != DeviceType.CUDA:
+            continue
+        dur = e.time_range.elapsed_us() if hasattr(e, 'time_range') else float(getattr(e, 'device_time', 0.0))
+        r = raw.setdefault(e.name, [0.0, 0])
+        r[0] += dur
+        r[1] += 1
+    dem = _demangle(list(raw))
+    out = {}
+    for name, (us, n) in raw.items():
+        k = _short_kernel_name(dem.get(name, name))
+        r = out.setdefault(k, [0.0, 0.0])
+        r[0] += us / reps
+        r[1] += n / reps
+    return out
+
+
+def gemm_algorithmic(rec_entry, es):
+    """(flop, bytes) one recorded GEMM launch HAS to do / move: 2 M N K, and every operand once - gathered input pixels (not the im2col
+    matrix), weights, output (+ residual / ReLU-mask operands the epilogue reads); a weight gradient reads dY and X once and leaves
+    4 B per weight (its split-K slabs are overhead, not algorithm)"""
+    a, _, (M, N, K, trans, conv), _, _ = rec_entry
+    flop = 2.0 * M * N * K
+    if trans:                      # dW[M = Cout][N = taps*Cin] over K pixels: A = dY [K][M], B = X (input pixels x Cin)
+        rows_b = K if not conv else (K // max(a.Ho * a.Wo, 1)) * a.Hi * a.Wi
+        nbytes = (K * M + rows_b * (a.Ci if conv else N)) * es + 4.0 * M * N
+    else:
+        rows_a = M if not conv else ((M + a.Ho * a.Wo - 1) // (a.Ho * a.Wo)) * a.Hi * a.Wi
+        nbytes = (rows_a * (a.Ci if conv else K) + N * K) * es + M * N * (4 if a.out_f32 else es)
+        if a.res:
+            nbytes += M * N * es
+        if a.mask:
+            nbytes += M * N / 8.0 if a.mask_bits else M * N * es
+        if a.bits_out:
+            nbytes += M * N / 8.0
+    return flop, nbytes
+
+
+def family_report(step, rec, dtype, n_params, step_ms):
+    """roofline.families: every kernel instance of the measured step with its time (in-process kernel trace of three further steps),
+    and - for the GEMM families, whose shapes one recorded eager step gives - algorithmic flops and bytes, the roofline that bounds it
+    (mfma when flops / peak > bytes / HBM peak) and the fraction of that roofline it reaches"""
+    import ctypes
+    from sound_event_detection_transformer_amd import lib as L_
+    times = kernel_times(step)
+    es = 2 if dtype == 'bf16' else 4
+    peak = MFMA_PEAK[dtype]
+    lib = L_.load()
+    buf = ctypes.create_string_buffer(128)
+    work, unmatched = {}, 0
+
+    def match(label):
+        if label in times:
+            return label
+        c = [k for k in times if k.startswith(label)]
+        return c[0] if len(c) == 1 else None
+    alg_gemm_bytes = 0.0
+    for ent in rec or []:
+        a, dt_, _, _, hint = ent
+        flop, nb = gemm_algorithmic(ent, es)
+        alg_gemm_bytes += nb
+        label = None
+        if hint == 'conv3x3_c64_kernel':
+            label = match('conv3x3_c64_kernel')
+        elif hint == 'igemm_group':
+            label = match('igemm3_group_kernel<2>') or match('igemm3_group_kernel<3>') or match('igemm3_group_kernel')
+        if label is None:
+            if lib.sedt_igemm_describe(ctypes.byref(a), dt_, 1 if hint == 'wgrad_group' else 0, buf, 128) == 0:
+                label = match(buf.value.decode())
+        if label is None:
+            unmatched += 1
+            continue
+        w = work.setdefault(label, [0.0, 0.0])
+        w[0] += flop
+        w[1] += nb
+    # the streaming kernels whose byte counts follow from the parameter count alone
+    for k in times:
+        if k.startswith('multi_adamw_kernel'):
+            work[k] = [0.0, 28.0 * n_params]
+        elif k.startswith('multi_sumsq_kernel'):
+            work[k] = [0.0, 4.0 * n_params]
+    fams = []
+    for k, (us, n) in sorted(times.items(), key=lambda kv: -kv[1][0]):
+        row = {"kernel": k, "launches": round(n, 1), "us": round(us, 1), "share": round(us / (step_ms * 1e3), 4)}
+        if k in work:
+            flop, nb = work[k]
+            t = us * 1e-6
+            t_m, t_h = flop / peak, nb / HBM_PEAK
+            row.update(flop=flop, bytes=nb)
+            if t_m >= t_h:
+                row.update(bound="mfma", achieved=round(flop / t / 1e12, 1), unit="TFLOP/s", peak=peak / 1e12, frac=round(t_m / t, 4))
+            else:
+                row.update(bound="hbm", achieved=round(nb / t / 1e9, 1), unit="GB/s", peak=HBM_PEAK / 1e9, frac=round(t_h / t, 4))
+        fams.append(row)
+    small = [r for r in fams if r["share"] < 0.004 and "flop" not in r]
+    keep = [r for r in fams if not (r["share"] < 0.004 and "flop" not in r)]
+    if small:
+        keep.append({"kernel": f"{len(small)} further kernels below 0.4 % of the step each", "launches": round(sum(r["launches"] for r in small), 1),
+                     "us": round(sum(r["us"] for r in small), 1), "share": round(sum(r["share"] for r in small), 4)})
+    total_us = sum(v[0] for v in times.values())
+    # algorithmic bytes of one step AS IT IS LAUNCHED (no cross-launch fusion assumed): every GEMM operand once (above), the optimizer's
+    # 28 B per trainable parameter + 4 B for the norm, the two packed bf16 weight layouts (4 B read + 2 x 2 B written per parameter)
+    alg = alg_gemm_bytes + (28.0 + 4.0 + 8.0) * n_params
+    return {"families": keep, "kernel_time_us": round(total_us, 1), "unmatched_gemm_records": unmatched,
+            "algorithmic_bytes": round(alg), "algorithmic_bytes_gemm_operands": round(alg_gemm_bytes)}
 
 
 def kernel_report(dtype, dev):
@@ -540,10 +752,12 @@ def other_configs(args, dev, keep_alive, replays=10):
     import torch
     from sound_event_detection_transformer_amd import runtime
     res = {}
-    for name in ('c3', 'c4', 'c5', 'c2_f32'):
+    for name in ('c3', 'c4', 'c5', 'c2_f32', 'c2_loader'):
         try:
             a = copy.copy(args)
-            a.config, a.mix_up_ratio = name, None
+            a.config, a.mix_up_ratio, a.loader = name, None, False
+            if name == 'c2_loader':                  # the headline config fed from host-resident raw clips (H2D + transforms in the loop)
+                a.config, a.loader = 'c2', True
             if name == 'c2_f32':                     # the f32 parity mode (the mode that meets north_star's 1e-3) on the headline config
                 a.config, a.dtype = 'c2', 'f32'
                 runtime.set_compute_dtype('f32')
@@ -574,7 +788,7 @@ def other_configs(args, dev, keep_alive, replays=10):
 
 def pmc_traffic(config):
     """HBM-side bytes per step from the committed PMC profile of this config (profiles/rNN_pmc_<config>.json, newest round), or None"""
-    for rnd in ('r03', 'r02'):
+    for rnd in ('r04', 'r03', 'r02'):
         try:
             with open(os.path.join(ROOT, 'profiles', f'{rnd}_pmc_{config}.json')) as f:
                 return json.load(f)
@@ -598,8 +812,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl')
+        dist.init_process_group(args.backend)
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
@@ -629,7 +845,7 @@ def main():
     rccl_world = 1
     if world > 1:
         dist = torch.distributed
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         per_rank = [float(v) for v in allt]
@@ -661,11 +877,13 @@ def main():
     # ---- GEMM family alone (c2/c3, rank 0): ONE extra eager step records the argument block of every GEMM launch, which are
     #      then replayed back to back on the launch stream between two HIP events
     gemm = None
+    gemm_rec = None
     if args.config in ('c2', 'c3') and not args.model_only:
         if rank != 0 and world > 1 and not graphed:
             ops.PROFILE = []                      # eager DDP: the extra step contains collectives, every rank must take part
             from sound_event_detection_transformer_amd.engine import train_step
-            train_step(ex['net'], ex['criterion'], ex['opt'], ex['x'], ex['targets'], ex['wm'], slice(ex['ns']), max_norm=0.1)
+            train_step(ex['net'], ex['criterion'], ex['opt'], ex['x'], ex['targets'], ex['wm'], slice(ex['ns']), max_norm=0.1,
+                         allreduce=bool(ex.get('eager_allreduce')))
             torch.cuda.synchronize()
             ops.PROFILE = None
         if rank == 0:
@@ -674,7 +892,8 @@ def main():
               from sound_event_detection_transformer_amd import lib as L_
               from sound_event_detection_transformer_amd.engine import train_step
               ops.PROFILE = []
-              train_step(ex['net'], ex['criterion'], ex['opt'], ex['x'], ex['targets'], ex['wm'], slice(ex['ns']), max_norm=0.1)
+              train_step(ex['net'], ex['criterion'], ex['opt'], ex['x'], ex['targets'], ex['wm'], slice(ex['ns']), max_norm=0.1,
+                         allreduce=bool(ex.get('eager_allreduce')))
               torch.cuda.synchronize()
               rec = ops.PROFILE
               ops.PROFILE = None
@@ -682,7 +901,7 @@ def main():
               lib = L_.load()
 
               def replay():
-                  for a, dt_, _, _ in rec:
+                  for a, dt_, *_ in rec:
                       L_.check(lib.sedt_igemm(ctypes.byref(a), dt_, L_.stream_ptr()), 'sedt_igemm')
               replay()
               torch.cuda.synchronize()
@@ -696,7 +915,7 @@ def main():
               tot_ms = g0.elapsed_time(g1) / reps
               if args.dump_igemm:
                   per = []
-                  for a, dt_, sh, _ in rec:
+                  for a, dt_, sh, *_ in rec:
                       s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                       s0.record()
                       for _ in range(5):
@@ -712,23 +931,44 @@ def main():
                       "frac": round(flop_step / (tot_ms * 1e-3) / MFMA_PEAK[args.dtype], 4),
                       "note": "every conv/linear fwd, dgrad and wgrad launch of one step issued back to back (eager, ungrouped); "
                               "the same family inside the step graph is ~15 % faster (profiles/)"}
-              del rec
+              gemm_rec = rec
           except Exception as e:               # noqa: BLE001
             ops.PROFILE = None
             gemm = {"error": repr(e)[:200]}
+
+    # ---- per-kernel-family roofline of the measured step (rank 0): in-process kernel trace of three further steps, joined with the
+    #      shapes of the recorded GEMM launches
+    fam = None
+    if rank == 0 and world == 1 and graphed and not args.no_families and not args.model_only:
+        try:
+            n_params = sum(p.numel() for p in ex['model'].parameters() if p.requires_grad)
+            fam = family_report(step, gemm_rec, args.dtype, n_params, dev_ms)
+        except Exception as e:                 # noqa: BLE001  (a diagnostic: never allowed to cost the result line)
+            fam = {"error": repr(e)[:300]}
+    gemm_rec = None
 
     if rank == 0:
         peak = MFMA_PEAK[args.dtype]
         ach = flop_step / (dev_ms * 1e-3)
         traffic = pmc_traffic(args.config)
+        dom = None
+        if fam and fam.get('families'):
+            dom = next((r for r in fam['families'] if 'frac' in r), None)
         roof = {"bound": "mfma",
                 "kernel": "whole training-step graph (>= 99 % of its algorithmic flops are the MFMA implicit-GEMM family "
-                          "sedt::igemm3* / wgrad3/4*; see gemm_family and kernels)",
+                          "sedt::igemm3* / wgrad3/4*)" + (f"; dominant kernel by time: {dom['kernel']} - see dominant / families" if dom else
+                                                          "; see gemm_family and kernels"),
                 "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None if traffic is None else traffic.get('hbm_bytes_per_step'),
                 "traffic_source": None if traffic is None else traffic.get('source'),
                 "algorithmic_flop_per_launch": flop_step, "launch": "one step = one replay of the step's HIP graph(s)",
                 "avg_launch_ms_hip_events": round(dev_ms, 4), "gemm_family": gemm}
+        if fam is not None:
+            if dom is not None:       # the dominant kernel instance against ITS roofline: algorithmic flops (bytes) of its launches in one
+                roof["dominant"] = dict(dom, avg_launch_us=round(dom['us'] / max(dom['launches'], 1), 2))      # step / their summed duration
+            roof.update({k: v for k, v in fam.items()})
+            if roof.get("traffic") and fam.get("algorithmic_bytes"):
+                roof["traffic_over_algorithmic"] = round(roof["traffic"] / fam["algorithmic_bytes"], 2)
         kernels = None
         if not args.no_kernels and args.config == 'c2':
             try:

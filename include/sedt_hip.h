@@ -124,6 +124,10 @@ int sedt_wgrad_group(const SedtIgemm* jobs, int njobs, int dtype, void* stream);
 int sedt_igemm_co(const SedtIgemm* main, const SedtIgemm* wjobs, int nw, int dtype, void* stream, int* taken);
 /* recommended split-K factor and slab bytes for a trans==1 problem */
 int sedt_igemm_splitk(int M, int N, int K, int dtype);
+/* measurement aid: the name of the kernel instance the problem runs on - as rocprofv3 prints it, e.g. "igemm3_w16_kernel<64, 128, 3>" -
+ * through sedt_igemm (grouped = 0) or through sedt_wgrad_group (grouped = 1, trans problems).  Nothing is launched.  bench.py joins
+ * these names with the per-kernel times of the measured step to price every kernel family against its roofline. */
+int sedt_igemm_describe(const SedtIgemm* args, int dtype, int grouped, char* out, int cap);
 
 /* out[r][c...] = rowscale[r] * sum_z slab[z][r][tap][c], written in (R, Ci, taps) order
  * (the torch (Cout, Cin, KH, KW) parameter layout) as f32.  taps == 1: plain [R][Ci]. */

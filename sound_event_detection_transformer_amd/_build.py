@@ -14,6 +14,12 @@ OBJ = os.path.join(HERE, '..', 'build', 'obj')
 SOURCES = ['igemm.hip', 'igemm3.hip', 'wgrad3.hip', 'wgrad4.hip', 'misc.hip', 'stem.hip', 'conv3x3_c64.hip',
            'norm_attn.hip', 'attn_mfma.hip', 'criterion.hip', 'postproc.hip', 'input.hip', 'skinny.hip', 'host.cpp']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-failed']
+if os.environ.get('SEDT_DEV_BUILD') == '1':
+    # developer build: the tuning switches read the environment (csrc/common.h: dev_getenv) and the ablation hooks are compiled in.
+    # Written beside the product library, never loaded unless SEDT_DEV=1 SEDT_LIB_AB=<path> asks for it (lib.py)
+    FLAGS = FLAGS + ['-DSEDT_DEV']
+    LIB = os.path.join(HERE, '..', 'build', 'dev', 'libsedt_hip_dev.so')
+    OBJ = os.path.join(HERE, '..', 'build', 'dev', 'obj')
 
 
 def _headers():
@@ -65,6 +71,7 @@ def _build_locked(force, verbose, jobs):
 
     with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
         list(ex.map(compile_one, todo))
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     tmp = f'{LIB}.{os.getpid()}.tmp'
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', tmp]
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -651,7 +651,7 @@ int enc_attn_fused_launch(const void* x, const void* pos, const float* gamma, co
   const float ik = 1.f / (1.f - drop_p);
   const bool train = xn != nullptr;
 #ifdef SEDT_DEV                      // ablation switch (1: no projections, 2: no attention - WRONG results): developer builds only
-  static const int dbg = getenv("SEDT_ENC_DBG") ? atoi(getenv("SEDT_ENC_DBG")) : 0;
+  static const int dbg = sedt::dev_getenv("SEDT_ENC_DBG") ? atoi(sedt::dev_getenv("SEDT_ENC_DBG")) : 0;
 #else
   const int dbg = 0;
 #endif

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/sedt_hip.h"
 
 namespace sedt {
@@ -10,6 +11,36 @@ namespace sedt {
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ---- tuning switches.  Every host-side dispatch rule of the library (tile per shape, ring depth, split-K target, grid caps, which
+// kernel generation takes a problem) has its MEASURED default written at its site; the environment can override a default only in a
+// developer build (hipcc -DSEDT_DEV: `SEDT_DEV_BUILD=1 python -m sound_event_detection_transformer_amd._build` writes
+// build/dev/libsedt_hip_dev.so for the sweeps under tools/).  The product library never reads the environment: dev_getenv() is a
+// constant nullptr there, so its behaviour cannot depend on variables leaked into a training job.
+inline const char* dev_getenv(const char* name) {
+#ifdef SEDT_DEV
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
+// ---- describe mode (sedt_igemm_describe): while `describe.on`, every GEMM launcher writes the name of the kernel instance it WOULD
+// launch for the problem (as a profiler prints it) and returns 0 without launching - bench.py uses it to attach algorithmic flops and
+// bytes to the per-kernel times of the measured step (roofline.families).
+struct Describe {
+  bool on;
+  char name[96];
+};
+extern thread_local Describe describe;
+#define SEDT_DESCRIBE(...)                                                   \
+  do {                                                                       \
+    if (sedt::describe.on) {                                                 \
+      snprintf(sedt::describe.name, sizeof(sedt::describe.name), __VA_ARGS__); \
+      return 0;                                                              \
+    }                                                                        \
+  } while (0)
 
 // ---- error plumbing (thread-local message, integer status across the C ABI)
 void set_error(const char* fmt, ...);

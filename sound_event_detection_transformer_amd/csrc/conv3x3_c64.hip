@@ -163,7 +163,7 @@ extern "C" int sedt_conv3x3_c64(const void* x, const void* w, int flip, const fl
   }
   static int gmax = -1;
   if (gmax < 0) {
-    const char* e = getenv("SEDT_C3_GRID");
+    const char* e = sedt::dev_getenv("SEDT_C3_GRID");
     gmax = std::max(e ? atoi(e) : 256, 1);          // (a tuning override; never a zero-size grid)
   }
   const int grid = (int)std::min<long>(nt, gmax);

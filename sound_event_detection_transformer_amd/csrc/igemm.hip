@@ -433,6 +433,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int
 // ---------------------------------------------------------------------------- host side
 template <typename T, int BM, int BN, bool TRANS>
 static int launch_cfg(const SedtIgemm& p, int vecA, int vecB, hipStream_t st) {
+  SEDT_DESCRIBE("igemm_kernel<%s, %d, %d, %s>", sizeof(T) == 4 ? "float" : "__bf16", BM, BN, TRANS ? "true" : "false");
   constexpr size_t lds = (size_t)(BM + BN) * Cfg<T>::PITCH * sizeof(T) * 2;
   static bool attr_set = false;  // idempotent; a benign race sets it twice
   auto kern = igemm_kernel<T, BM, BN, TRANS>;
@@ -493,7 +494,7 @@ namespace sedt { int igemm_lds_try(const SedtIgemm& p, hipStream_t st); }   // i
 static bool use_lds_family() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("SEDT_IGEMM_LDS");       // developer A/B switch: 0 = the general kernel of this file for everything
+    const char* e = sedt::dev_getenv("SEDT_IGEMM_LDS");       // developer A/B switch: 0 = the general kernel of this file for everything
     v = (e && e[0] == '0') ? 0 : 1;
   }
   return v == 1;
@@ -519,6 +520,33 @@ extern "C" int sedt_igemm(const SedtIgemm* args, int dtype, void* stream) {
   }
   set_error("igemm: unsupported dtype %d", dtype);
   return 1;
+}
+
+namespace sedt {
+thread_local Describe describe = {false, {0}};
+bool wgrad4_ok(const SedtIgemm& p);
+int wgrad_lds_envelope(const SedtIgemm& p, long* a_bytes, long* b_bytes);
+}
+
+// name of the kernel instance sedt_igemm (grouped == 0), sedt_igemm_group (1: forward / dgrad) or sedt_wgrad_group (1: trans) runs
+// the problem on, as rocprofv3 / the torch profiler print it; nothing is launched.  A measurement aid (bench.py roofline.families).
+extern "C" int sedt_igemm_describe(const SedtIgemm* args, int dtype, int grouped, char* out, int cap) {
+  using namespace sedt;
+  SEDT_REQUIRE(args && out && cap > 0, "igemm_describe: bad arguments");
+  out[0] = 0;
+  if (grouped && dtype == SEDT_BF16 && args->trans) {       // sedt_wgrad_group: the 256/128x128 group or the 64x64 group
+    long a, b;
+    if (wgrad_lds_envelope(*args, &a, &b) == 0) {
+      snprintf(out, cap, "%s", wgrad4_ok(*args) ? "wgrad4_group_kernel" : "wgrad3_group_kernel");
+      return 0;
+    }
+  }
+  describe.on = true;
+  describe.name[0] = 0;
+  const int r = sedt_igemm(args, dtype, nullptr);
+  describe.on = false;
+  if (r == 0) snprintf(out, cap, "%s", describe.name);
+  return r;
 }
 
 namespace sedt {
@@ -566,7 +594,7 @@ extern "C" int sedt_igemm_co(const SedtIgemm* main, const SedtIgemm* wjobs, int 
   if (nw == 0) return sedt_igemm(main, dtype, stream);
   static int on = -1;
   if (on < 0) {
-    const char* e = getenv("SEDT_COSCHEDULE");
+    const char* e = sedt::dev_getenv("SEDT_COSCHEDULE");
     on = (e && e[0] == '0') ? 0 : 1;
   }
   WgradGroup g;
@@ -585,7 +613,7 @@ extern "C" int sedt_igemm_splitk(int M, int N, int K, int dtype) {
   // balances occupancy against slab traffic (measured on the full step: SEDT_SPLITK_TARGET sweep)
   static int target_env = -2;
   if (target_env == -2) {
-    const char* e = getenv("SEDT_SPLITK_TARGET");
+    const char* e = sedt::dev_getenv("SEDT_SPLITK_TARGET");
     target_env = e ? atoi(e) : -1;
   }
   // bf16: wgrads of a layer are issued as one grouped launch, so the union of their tiles fills the chip and each problem
@@ -600,7 +628,7 @@ extern "C" int sedt_igemm_splitk(int M, int N, int K, int dtype) {
   if (dtype == SEDT_BF16 && sedt::wgrad4_shape_ok(M, N)) {
     static int wide_env = -2;
     if (wide_env == -2) {
-      const char* e = getenv("SEDT_SPLITK_TARGET_WIDE");
+      const char* e = sedt::dev_getenv("SEDT_SPLITK_TARGET_WIDE");
       wide_env = e ? atoi(e) : -1;
     }
     tiles = (long)(M / sedt::wgrad4_tile_m(M, N)) * (N / 128);
@@ -621,7 +649,7 @@ extern "C" int sedt_igemm_splitk(int M, int N, int K, int dtype) {
   // 9 taps), slabs 2 * s * M*N*4 B (written, then read by the reduction).
   static int kslice = -1;
   if (kslice < 0) {
-    const char* e = getenv("SEDT_WGRAD_KSLICE");
+    const char* e = sedt::dev_getenv("SEDT_WGRAD_KSLICE");
     kslice = (e && e[0] == '1') ? 1 : 0;      // opt-in: measured -33 % fetched bytes for the wgrad launches, same run time
   }
   if (kslice && dtype == SEDT_BF16) {

@@ -515,6 +515,7 @@ __global__ __launch_bounds__(1024) void igemm3_w16_kernel(const SedtIgemm p, con
 
 template <int BM, int BN, int S>
 static int launch3_w16(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  SEDT_DESCRIBE("igemm3_w16_kernel<%d, %d, %d>", BM, BN, S);
   constexpr size_t ring = (size_t)2 * S * (BM + BN) * ROWB;
   constexpr size_t ctile = (size_t)4 * BM * (BN + 4) * sizeof(float);
   constexpr size_t lds = ring > ctile ? ring : ctile;
@@ -535,6 +536,7 @@ static int launch3_w16(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, h
 
 template <int BM, int BN, int S, int PP = 0>
 static int launch3_w8(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  SEDT_DESCRIBE("igemm3_w8_kernel<%d, %d, %d, %d>", BM, BN, S, PP);
   constexpr size_t ring = (size_t)S * (BM + BN) * ROWB;
   constexpr size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);
   constexpr size_t lds = ring > ctile ? ring : ctile;
@@ -618,6 +620,7 @@ static int launch3_co(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hi
 
 template <int BM, int BN, int S>
 static int launch3(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  if (!plan3.on) SEDT_DESCRIBE("igemm3_kernel<%d, %d, %d>", BM, BN, S);
   if (plan3.on) {
     plan3.ok = true;
     plan3.bm = BM; plan3.bn = BN; plan3.s = S;
@@ -651,7 +654,7 @@ bool igemm3_planning() { return plan3.on; }
 int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
   static int on = -1;
   if (on < 0) {
-    const char* e = getenv("SEDT_IGEMM_GROUP");
+    const char* e = sedt::dev_getenv("SEDT_IGEMM_GROUP");
     on = (e && e[0] == '0') ? 0 : 1;
   }
   if (!on || njobs < 2 || njobs > IG_MAXG) return -1;
@@ -709,7 +712,7 @@ int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
 int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, int bn, hipStream_t st) {
   static int on = -1;
   if (on < 0) {
-    const char* e = getenv("SEDT_IGEMM_V3");
+    const char* e = sedt::dev_getenv("SEDT_IGEMM_V3");
     on = (e && e[0] == '0') ? 0 : 1;
   }
   if (!on) return -1;
@@ -718,7 +721,7 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
   if ((reinterpret_cast<uintptr_t>(p.scale) & 15) || (reinterpret_cast<uintptr_t>(p.bias) & 15)) return -1;
   static int stages = -1;
   if (stages < 0) {
-    const char* e = getenv("SEDT_IGEMM3_STAGES");
+    const char* e = sedt::dev_getenv("SEDT_IGEMM3_STAGES");
     stages = e ? atoi(e) : 0;
   }
   int S = stages;
@@ -732,30 +735,30 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
   }
   static int nw_env = -1;
   if (nw_env < 0) {
-    const char* e = getenv("SEDT_IGEMM3_NW");
+    const char* e = sedt::dev_getenv("SEDT_IGEMM3_NW");
     nw_env = e ? atoi(e) : 0;
   }
   // measured (tools/tune_igemm.py, SEDT_IGEMM3_NW): the 64x128 tile runs 2-14 % faster with 8 waves (two groups splitting the
   // k16 steps) at every shape that selects it; 128x128 / 128x64 with 8 waves are experiment-only (SEDT_IGEMM3_NW=8)
   static int pp_env = -1;
   if (pp_env < 0) {
-    const char* e = getenv("SEDT_IGEMM3_PP");
+    const char* e = sedt::dev_getenv("SEDT_IGEMM3_PP");
     pp_env = e ? atoi(e) : 1;
   }
   static int w4k = -1;          // experiment: below this K the 64x128 tile runs on the 4-wave kernel (32 MFMAs per wave and tile)
   if (w4k < 0) {
-    const char* e = getenv("SEDT_IGEMM3_W4_BELOW_K");
+    const char* e = sedt::dev_getenv("SEDT_IGEMM3_W4_BELOW_K");
     w4k = e ? atoi(e) : 0;
   }
   const bool force4 = p.K < w4k;
   // exactly one 64x128 tile per CU and a long K: two 8-wave teams per workgroup, half of K each (SEDT_IGEMM3_W16=1)
   static int w16 = -1, w16_mink = 0, w16_tiles = 320;
   if (w16 < 0) {
-    const char* e = getenv("SEDT_IGEMM3_W16");        // same-box A/B on the C2 step: 5.688 -> 5.657 ms (29 launches, ~ -10 % each)
+    const char* e = sedt::dev_getenv("SEDT_IGEMM3_W16");        // same-box A/B on the C2 step: 5.688 -> 5.657 ms (29 launches, ~ -10 % each)
     w16 = (e && e[0] == '0') ? 0 : 1;
-    e = getenv("SEDT_IGEMM3_W16_TILES");
+    e = sedt::dev_getenv("SEDT_IGEMM3_W16_TILES");
     w16_tiles = e ? atoi(e) : 320;
-    e = getenv("SEDT_IGEMM3_W16_MINK");
+    e = sedt::dev_getenv("SEDT_IGEMM3_W16_MINK");
     w16_mink = e ? atoi(e) : 512;            // (512 vs 1024: C2 5.61 vs 5.65 ms, C3 4.56 vs 4.58 - within the run-to-run spread)
   }
   if (w16 && !plan3.on && co_group == nullptr && bm == 64 && bn == 128 && S >= 3 && p.K >= w16_mink && (p.K / BK2) % 2 == 0) {
@@ -766,7 +769,7 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
   // two-team form on that tile (same-box A/B: C3 4.655 -> 4.568 ms, C5 8.34 -> 8.27; one 8-wave team instead: no change)
   static int small16 = -1;
   if (small16 < 0) {
-    const char* e = getenv("SEDT_IGEMM3_SMALL16");
+    const char* e = sedt::dev_getenv("SEDT_IGEMM3_SMALL16");
     small16 = (e && e[0] == '0') ? 0 : 1;
   }
   if (small16 && !plan3.on && co_group == nullptr && bm == 64 && bn == 64 && S >= 3 && p.K >= w16_mink && (p.K / BK2) % 2 == 0) {
@@ -836,12 +839,12 @@ int igemm_lds_try(const SedtIgemm& p, hipStream_t st) {
     // (a grouped launch - igemm3_planning() - runs on the 64x64 program: worth it for the launch-bound decoder-sized problems)
     static int mink = -1;
     if (mink < 0) {
-      const char* e = getenv("SEDT_IGEMM_BN128_MINK");
+      const char* e = sedt::dev_getenv("SEDT_IGEMM_BN128_MINK");
       mink = e ? atoi(e) : 512;
     }
     static int bn128t = -1;
     if (bn128t < 0) {
-      const char* e = getenv("SEDT_IGEMM_BN128_MINTILES");
+      const char* e = sedt::dev_getenv("SEDT_IGEMM_BN128_MINTILES");
       bn128t = e ? atoi(e) : 250;
     }
     // below 250 tiles of 64x128 the 64x64 tile covers more of the chip: the B = 32 configurations have M = 3968 rows, i.e. 124
@@ -853,9 +856,9 @@ int igemm_lds_try(const SedtIgemm& p, hipStream_t st) {
     // amortise its exposed prologue / epilogue and the tiles still cover the chip: layer4 conv1 fwd / conv2 / conv3 dgrad
     static int bm128k = -1, bm128t = -1;
     if (bm128k < 0) {
-      const char* e = getenv("SEDT_IGEMM_BM128_MINK");
+      const char* e = sedt::dev_getenv("SEDT_IGEMM_BM128_MINK");
       bm128k = e ? atoi(e) : 2048;
-      e = getenv("SEDT_IGEMM_BM128_MINTILES");
+      e = sedt::dev_getenv("SEDT_IGEMM_BM128_MINTILES");
       bm128t = e ? atoi(e) : 256;
     }
     if (bn == 128 && p.K >= bm128k && (long)((p.M + 127) / 128) * (p.N / 128) >= bm128t && !igemm3_planning()) bm = 128;

@@ -1211,7 +1211,7 @@ extern "C" int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float
   SEDT_REQUIRE(max_norm <= 0.f || sumsq, "multi_adamw: clipping needs sumsq");
   static int nt = -1;
   if (nt < 0) {
-    const char* e = getenv("SEDT_ADAMW_NT");          // developer A/B switch (default on)
+    const char* e = sedt::dev_getenv("SEDT_ADAMW_NT");          // developer A/B switch (default on)
     nt = (e && e[0] == '0') ? 0 : 1;
   }
   if (nt) hipLaunchKernelGGL(multi_adamw_kernel<true>, dim3(nchunks), dim3(256), 0, S(stream), table, sumsq, max_norm, beta1, beta2, eps,

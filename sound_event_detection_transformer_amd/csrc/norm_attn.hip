@@ -401,7 +401,7 @@ int attn_bwd_mfma_try(const void* q, int64_t ldq, const void* k, int64_t ldk, co
 static bool use_attn_mfma() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("SEDT_ATTN_MFMA");
+    const char* e = sedt::dev_getenv("SEDT_ATTN_MFMA");
     v = (e && e[0] == '0') ? 0 : 1;
   }
   return v == 1;

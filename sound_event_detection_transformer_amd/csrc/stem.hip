@@ -377,10 +377,10 @@ extern "C" int sedt_stem_pool_fwd(const float* x, const void* wcat, const float*
   SEDT_REQUIRE(nt < (1L << 30) && (long)B * H * 64 < (1L << 40), "stem_pool_fwd: too many tiles");
   static int gmax = -1, dbg = 0;
   if (gmax < 0) {
-    const char* e = getenv("SEDT_STEM_GRID");
+    const char* e = sedt::dev_getenv("SEDT_STEM_GRID");
     gmax = std::max(e ? atoi(e) : 512, 1);        // measured: 512 persistent workgroups 37.6 us, 768 40.2, 1024 44.0 (C2 shape)
 #ifdef SEDT_DEV                      // ablation switch of tools/dev/time_stem.py (skips the MFMAs / the prefetch: WRONG results);
-    e = getenv("SEDT_STEM_DBG");     // compiled only into developer builds (hipcc -DSEDT_DEV), never into the product library
+    e = sedt::dev_getenv("SEDT_STEM_DBG");     // compiled only into developer builds (hipcc -DSEDT_DEV), never into the product library
     dbg = e ? atoi(e) : 0;
 #endif
   }

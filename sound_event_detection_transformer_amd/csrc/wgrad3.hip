@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void wgrad3_group_kernel(const WgradGroup g) {
 
 template <int BN>
 static int launch_wgrad3(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  SEDT_DESCRIBE("wgrad3_kernel<%d>", BN);
   constexpr size_t lds = (size_t)2 * (64 * ROWB + 64 * BN * 2);
   static bool attr_set = false;
   auto kern = wgrad3_kernel<BN>;
@@ -38,7 +39,7 @@ static int launch_wgrad3(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes,
   const int nwg = ((p.N + BN - 1) / BN) * ((p.M + 63) / 64);
   static int force = -2;
   if (force == -2) {
-    const char* e = getenv("SEDT_WGRAD_NMAJOR");
+    const char* e = sedt::dev_getenv("SEDT_WGRAD_NMAJOR");
     force = e ? atoi(e) : -1;
   }
   const int nmajor = force >= 0 ? force : (p.N > p.M ? 1 : 0);
@@ -59,7 +60,7 @@ int launch_wgrad4_group(WgradGroup& g, hipStream_t st);
 int wgrad3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
   static int on = -1;
   if (on < 0) {
-    const char* e = getenv("SEDT_WGRAD_GROUP");
+    const char* e = sedt::dev_getenv("SEDT_WGRAD_GROUP");
     on = (e && e[0] == '0') ? 0 : 1;
   }
   if (!on || njobs < 1) return -1;
@@ -143,9 +144,9 @@ int wgrad3_group_build(const SedtIgemm* jobs, int njobs, WgradGroup* g) {
 int wgrad3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
   static int on = -1, wide = -1;
   if (on < 0) {
-    const char* e = getenv("SEDT_WGRAD_V3");
+    const char* e = sedt::dev_getenv("SEDT_WGRAD_V3");
     on = (e && e[0] == '0') ? 0 : 1;
-    const char* w = getenv("SEDT_WGRAD_WIDE");
+    const char* w = sedt::dev_getenv("SEDT_WGRAD_WIDE");
     wide = w ? atoi(w) : -1;
   }
   if (!on) return -1;

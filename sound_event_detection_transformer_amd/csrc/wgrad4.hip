@@ -348,7 +348,7 @@ __global__ __launch_bounds__(512) void wgrad4_group_kernel(const WgradGroup g) {
 static int wg4_stages() {
   static int s = -1;
   if (s < 0) {
-    const char* e = getenv("SEDT_WGRAD4_STAGES");
+    const char* e = sedt::dev_getenv("SEDT_WGRAD4_STAGES");
     s = (e && atoi(e) == 3) ? 3 : (e && atoi(e) == 4) ? 4 : 3;
   }
   return s;
@@ -359,9 +359,9 @@ static int wg4_stages() {
 int wgrad4_tile_m(int M, int N) {
   static int bm = -1, min_tiles = 1;
   if (bm < 0) {
-    const char* e = getenv("SEDT_WGRAD4_BM");
+    const char* e = sedt::dev_getenv("SEDT_WGRAD4_BM");
     bm = (e && atoi(e) == 128) ? 128 : 256;
-    e = getenv("SEDT_WGRAD4_WIDE_MIN");               // experiment: the 256-row tile only for problems with at least this many of them
+    e = sedt::dev_getenv("SEDT_WGRAD4_WIDE_MIN");               // experiment: the 256-row tile only for problems with at least this many of them
     min_tiles = e ? atoi(e) : 1;
   }
   return (bm == 256 && M % 256 == 0 && (long)(M / 256) * (N / 128) >= min_tiles) ? 256 : 128;
@@ -375,7 +375,7 @@ static size_t wg4_lds() {
 bool wgrad4_shape_ok(int M, int N) {
   static int mn = -1;
   if (mn < 0) {
-    const char* e = getenv("SEDT_WGRAD4_MIN");
+    const char* e = sedt::dev_getenv("SEDT_WGRAD4_MIN");
     mn = e ? atoi(e) : 256;     // full-step sweep: 512 -> 6.32, 256 -> 6.27, 128 -> 6.30 ms
   }
   return M >= mn && N >= mn && (M % 128) == 0 && (N % 128) == 0;
@@ -384,14 +384,14 @@ bool wgrad4_shape_ok(int M, int N) {
 bool wgrad4_ok(const SedtIgemm& p) {
   static int on = -1;
   if (on < 0) {
-    const char* e = getenv("SEDT_WGRAD_V4");
+    const char* e = sedt::dev_getenv("SEDT_WGRAD_V4");
     on = (e && e[0] == '0') ? 0 : 1;
   }
   // problems with a fused bias gradient are the transformer linears: measured on the full step they are better off in the
   // 64x64 grouped launch with the rest of their layer (6.05 vs 6.10-6.13 ms); SEDT_WGRAD4_BIAS=1 sends them here (tests do)
   static int with_bias = -1;
   if (with_bias < 0) {
-    const char* e = getenv("SEDT_WGRAD4_BIAS");
+    const char* e = sedt::dev_getenv("SEDT_WGRAD4_BIAS");
     with_bias = (e && e[0] == '1') ? 1 : 0;
   }
   return on && p.trans && wgrad4_shape_ok(p.M, p.N) && (p.colsum_out == nullptr || with_bias) && p.out_f32 &&
@@ -410,6 +410,7 @@ static int wg4_attr(K kern, const char* what) {
 }
 
 int launch_wgrad4(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  SEDT_DESCRIBE("wgrad4_kernel<%d>", wg4_stages());
   static bool attr_set = false;
   if (!attr_set) {
     if (wg4_attr(wgrad4_kernel<3>, "wgrad4") || wg4_attr(wgrad4_kernel<4>, "wgrad4")) return 1;

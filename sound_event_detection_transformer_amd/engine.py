@@ -329,7 +329,9 @@ class GraphedTrainStep(_GraphedBase):
     Shapes are static: every batch must have the batch size, clip length and strong/weak split it was captured with (and,
     for the host split, the same per-clip target counts).  Dropout masks change on each replay through the device-side
     seed word (runtime.bump_seed); the Adam step count lives on the device too.  The optimizer's learning rates are re-read
-    before every replay.  Eager ``optimizer.step()`` calls between replays are safe (the graph owns its pointer tables).
+    before every replay.  Eager ``optimizer.step()`` calls between replays are safe (the graph owns its pointer tables) - but call
+    ``optimizer.zero_grad(set_to_none=True)`` before an eager BACKWARD: the captured backward leaves its static gradient tensors
+    attached to the parameters, and autograd would add to them.
 
     Data parallel (world > 1): parameters are broadcast from rank 0 at construction; gradients are packed into ONE flat buffer
     (f32, or bf16 with ``grad_dtype=torch.bfloat16``) and averaged with RCCL between the backward graph(s) and an optimizer graph.
@@ -371,7 +373,7 @@ class GraphedTrainStep(_GraphedBase):
         self.fine_tune, self.fl, self.ft_rand = fine_tune, fl, ft_rand
         self.runtime = runtime
         self.async_wgrad = async_wgrad
-        self.coschedule = (coschedule or os.environ.get('SEDT_COSCHEDULE', '0') == '1') and not async_wgrad
+        self.coschedule = (coschedule or ops._dev_env('SEDT_COSCHEDULE', '0') == '1') and not async_wgrad
         self.world = torch.distributed.get_world_size() if (torch.distributed.is_available()
                                                             and torch.distributed.is_initialized()) else 1
         self.accum_steps, self._micro = int(accum_steps), 0
@@ -588,6 +590,8 @@ class GraphedTrainStep(_GraphedBase):
         if self.flat_mode:
             raise NotImplementedError('a batch that mix-up shrinks cannot bypass the captured data-parallel / accumulation schedule: '
                                       'pass mask_weak (mixup_data then keeps the batch size) or use the eager train_step')
+        # the captured backward leaves its (static) gradient tensors attached to the parameters: an eager backward would ADD to them
+        self.optimizer.zero_grad(set_to_none=True)
         side, cur = train_stream(self.dev), torch.cuda.current_stream(self.dev)
         side.wait_stream(cur)
         with torch.cuda.stream(side):

@@ -8,7 +8,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libsedt_hip.so')
-if os.environ.get('SEDT_LIB_AB'):          # developer A/B runs: another build of the same library (tools/README.md)
+if os.environ.get('SEDT_LIB_AB') and os.environ.get('SEDT_DEV') == '1':   # developer A/B runs: another build of the same library (tools/README.md)
     LIB_PATH = os.environ['SEDT_LIB_AB']
 
 F32, BF16 = 0, 1
@@ -79,6 +79,7 @@ SIGNATURES = {
     'sedt_wgrad_group': (_i, [C.POINTER(SedtIgemm), _i, _i, _vp]),
     'sedt_igemm_co': (_i, [C.POINTER(SedtIgemm), C.POINTER(SedtIgemm), _i, _i, _vp, C.POINTER(C.c_int)]),
     'sedt_igemm_splitk': (_i, [_i, _i, _i, _i]),
+    'sedt_igemm_describe': (_i, [C.POINTER(SedtIgemm), _i, _i, C.c_char_p, _i]),
     'sedt_wgrad_reduce': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sedt_wgrad_reduce_bias': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'sedt_multi_wgrad_reduce': (_i, [C.POINTER(SedtReduceJob), _i, _vp]),

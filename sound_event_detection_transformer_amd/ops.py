@@ -36,8 +36,15 @@ class ConvGeom(object):
         return self.KH == 1 and self.KW == 1 and self.sh == 1 and self.sw == 1 and self.ph == 0 and self.pw == 0
 
 
-RELU_BITS = os.environ.get('SEDT_RELU_BITS', '1') != '0'      # developer A/B switch: 0 = the backward masks with the bf16 activations
-PROFILE = None   # bench.py sets this to a list: every GEMM launch then also records (argument block, dtype, shape, operands)
+def _dev_env(name, default):
+    """a developer A/B switch: the environment is consulted only when SEDT_DEV=1 is set as well (tools/README.md); a training job's
+    behaviour never depends on a leaked variable"""
+    return os.environ.get(name, default) if os.environ.get('SEDT_DEV') == '1' else default
+
+
+RELU_BITS = _dev_env('SEDT_RELU_BITS', '1') != '0'      # developer A/B switch: 0 = the backward masks with the bf16 activations
+PROFILE = None   # bench.py sets this to a list: every GEMM launch then also records (argument block, dtype, shape, operands, hint)
+PROFILE_HINT = None   # how the un-profiled step launches the problem being recorded: 'conv3x3_c64_kernel' (direct kernel), 'igemm_group'
 
 
 def _dev_check(*ts):
@@ -170,7 +177,7 @@ def igemm(dtype, M, N, K, A, lda, B, ldb, Cout, ldc, **kw):
             POOL.give_back(riders)
         return
     if PROFILE is not None:     # the operand tensors are kept alive so that the launch can be replayed for timing
-        PROFILE.append((a, dtype, (M, N, K, trans, 0 if conv is None else 1), (A, B, Cout, kw)))
+        PROFILE.append((a, dtype, (M, N, K, trans, 0 if conv is None else 1), (A, B, Cout, kw), PROFILE_HINT))
     L.check(L.load().sedt_igemm(C.byref(a), dtype, L.stream_ptr()), 'sedt_igemm')
 
 
@@ -254,17 +261,20 @@ def linear_group(dtype, items):
         outs.append(out)
         args.append(((M, N, K, x, x.stride(0), w, w.stride(0), out, out.stride(0)), dict(out_f32=int(out_f32), **kw)))
     if len(args) == 1 or PROFILE is not None or (_co['on'] and POOL.gemms):
+        global PROFILE_HINT
+        PROFILE_HINT = 'igemm_group' if len(args) > 1 else None
         for a, kw in args:
             igemm(dtype, *a, **kw)
+        PROFILE_HINT = None
         return outs
     arr = (L.SedtIgemm * len(args))(*[igemm_args(*a, **kw) for a, kw in args])
     L.check(L.load().sedt_igemm_group(arr, len(args), dtype, L.stream_ptr()), 'igemm_group')
     return outs
 
 
-def _conv3_c64_ok(dtype, t, g, ep, out):
+def _conv3_c64_ok(dtype, t, g, ep, out, profiling_ok=False):
     """envelope of the direct 3x3 kernel (csrc/conv3x3_c64.hip): the layer1 conv2 geometry, plain epilogues"""
-    return (CONV3_DIRECT and PROFILE is None and dtype == BF16 and g.Ci == 64 and g.Co == 64 and g.KH == 3 and g.KW == 3
+    return (CONV3_DIRECT and (PROFILE is None or profiling_ok) and dtype == BF16 and g.Ci == 64 and g.Co == 64 and g.KH == 3 and g.KW == 3
             and g.sh == 1 and g.sw == 1 and g.ph == 1 and g.pw == 1 and g.dh == 1 and g.dw == 1 and g.Wi == 16
             and t.stride(0) == 64 and out.stride(0) == 64 and set(ep) <= {'scale', 'bias', 'act', 'mask', 'ldm', 'tile'}
             and ep.get('act', 0) in (0, ACT_RELU) and tuple(ep.get('tile', (0, 0))) == (0, 0)
@@ -285,7 +295,11 @@ def conv_fwd(dtype, x, B, g, wf, out=None, **ep):
     if _conv3_c64_ok(dtype, x, g, ep, out):
         return _conv3_c64(x, B, g, wf, 0, out, ep)
     conv = None if g.plain else _geom_tuple(g)
+    global PROFILE_HINT
+    if PROFILE is not None and _conv3_c64_ok(dtype, x, g, ep, out, True):
+        PROFILE_HINT = 'conv3x3_c64_kernel'
     igemm(dtype, M, g.Co, g.taps * g.Ci, x, x.stride(0), wf, g.taps * g.Ci, out, out.stride(0), conv=conv, **ep)
+    PROFILE_HINT = None
     return out
 
 
@@ -297,8 +311,12 @@ def conv_dgrad(dtype, dy, B, g, wb, out=None, **ep):
     if _conv3_c64_ok(dtype, dy, g, ep, out) and 'scale' not in ep and 'bias' not in ep:
         return _conv3_c64(dy, B, g, wb, 1, out, ep)       # the input gradient of a stride-1 3x3 conv is the same conv, taps flipped
     conv = None if g.plain else _geom_tuple(g, transposed=True)
+    global PROFILE_HINT
+    if PROFILE is not None and _conv3_c64_ok(dtype, dy, g, ep, out, True) and 'scale' not in ep and 'bias' not in ep:
+        PROFILE_HINT = 'conv3x3_c64_kernel'
     igemm(dtype, M, g.Ci, g.taps * g.Co, dy, dy.stride(0), wb, g.taps * g.Co, out, out.stride(0), conv=conv,
           transposed=0 if g.plain else 1, **ep)
+    PROFILE_HINT = None
     return out
 
 
@@ -329,7 +347,7 @@ class ReduceBatch(object):
         if PROFILE is not None:                       # bench.py replays every GEMM on its own for the per-launch timing
             for a, shape in self.group:
                 L.check(lib.sedt_igemm(C.byref(a), self.group_dtype, L.stream_ptr()), 'sedt_igemm')
-                PROFILE.append((a, self.group_dtype, shape, (list(self.keep), list(self.operands))))
+                PROFILE.append((a, self.group_dtype, shape, (list(self.keep), list(self.operands)), 'wgrad_group'))
         else:
             arr = (L.SedtIgemm * len(self.group))(*[a for a, _ in self.group])
             L.check(lib.sedt_wgrad_group(arr, len(self.group), self.group_dtype, L.stream_ptr()), 'wgrad_group')
@@ -568,7 +586,7 @@ def layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2=None, dres=None, want_par
     dxd, p_, seed_, sp_ = None, 0.0, 0, None
     if drop is not None and drop[0] > 0:
         p_, seed_, sp_ = drop
-        if os.environ.get('SEDT_LN_DROP_FUSE', '1') == '0':        # A/B switch: separate dropout_grad launch
+        if _dev_env('SEDT_LN_DROP_FUSE', '1') == '0':        # A/B switch: separate dropout_grad launch
             dx, dg, db = layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dy2, dres, want_param_grads, batch, dres2=dres2)
             return dx, dg, db, dropout_grad(dtype, dx, p_, seed_, sp_)
         dxd = torch.empty_like(x)
@@ -606,17 +624,17 @@ def attention_bwd(dtype, q, k, v, o, do, lse, B, H, Lq, Lk, dq, dk, dv, kpm=None
     return dq, dk, dv
 
 
-NO_RIDE = os.environ.get('SEDT_CO_NORIDE', '0') == '1'      # experiment: park all wgrads until the end of the backward, no riders
-CONV3_DIRECT = os.environ.get('SEDT_CONV3_DIRECT', '1') != '0'   # direct 3x3 kernel for the layer1 conv2 geometry (conv3x3_c64.hip)
-STEM_DIRECT = os.environ.get('SEDT_STEM_DIRECT', '1') != '0'     # one-launch stem forward / backward (stem.hip)
+NO_RIDE = _dev_env('SEDT_CO_NORIDE', '0') == '1'      # experiment: park all wgrads until the end of the backward, no riders
+CONV3_DIRECT = _dev_env('SEDT_CONV3_DIRECT', '1') != '0'   # direct 3x3 kernel for the layer1 conv2 geometry (conv3x3_c64.hip)
+STEM_DIRECT = _dev_env('SEDT_STEM_DIRECT', '1') != '0'     # one-launch stem forward / backward (stem.hip)
 # The fused encoder head (LN1 + QKV + attention in one launch) is correct (tests/test_ops_gpu.py) and, as measured on the
 # MI355X, level with the three launches it replaces (30.6 vs 32.7 us no-grad, 32.2 in training form) but not ahead: one
 # workgroup per CU runs its phases strictly in sequence.  Opt in with SEDT_FUSED_ENC=1.
-FUSED_ENC = os.environ.get('SEDT_FUSED_ENC', '0') == '1'
+FUSED_ENC = _dev_env('SEDT_FUSED_ENC', '0') == '1'
 # the same kernel for the decoder's self-attention over the Q queries of a clip (S = Q <= 32): three launches -> one.  Correct (tests)
 # and slower: its fixed skeleton (~18 us, see above) exceeds the three latency-bound launches it replaces - C2 5.49 -> 5.57 ms, C3
 # 4.55 -> 4.59 ms (same-box A/B).  Opt in with SEDT_FUSED_DEC_SA=1.
-FUSED_DEC_SA = os.environ.get('SEDT_FUSED_DEC_SA', '0') == '1'
+FUSED_DEC_SA = _dev_env('SEDT_FUSED_DEC_SA', '0') == '1'
 
 
 def encoder_attn_ok(dtype, D, H, S, amask):

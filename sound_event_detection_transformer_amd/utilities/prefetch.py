@@ -9,9 +9,12 @@ from .utils import NestedTensor
 
 
 class DevicePrefetcher(object):
-    def __init__(self, loader, device='cuda', transform=None, return_indexes=False, slots=2):
+    def __init__(self, loader, device='cuda', transform=None, return_indexes=False, slots=2, targets_to_device=True):
         """loader yields (input, targets) [or ((input, targets), index)]: input = NestedTensor / tensor of features, or - with
-        ``transform`` - a list of raw (T, F) mel-amplitude arrays that the transform turns into the (B,1,frames,F) batch"""
+        ``transform`` - a list of raw (T, F) mel-amplitude arrays that the transform turns into the (B,1,frames,F) batch.
+        targets_to_device=False leaves the targets on the host: the graphed steppers lay them out in ONE pinned blob and send one
+        copy per step (sedt.TargetTables), which is cheaper than a copy per tensor here"""
+        self.targets_to_device = targets_to_device
         self.loader = iter(loader)
         self.dev = torch.device(device)
         self.stream = torch.cuda.Stream(device=self.dev)
@@ -66,14 +69,13 @@ class DevicePrefetcher(object):
         with torch.cuda.stream(self.stream):
             if self.transform is not None and not torch.is_tensor(inp) and not isinstance(inp, NestedTensor):
                 nraw = max(int(c.shape[0]) for c in inp)
-                k, stage = self._pinned((len(inp), nraw, self.transform.F))
-                stage.zero_()
+                k, stage = self._pinned((len(inp), nraw, self.transform.F))      # (rows beyond a clip's own length are never read)
                 self.next_input = self.transform(inp, staging=stage)
                 self._done[k] = torch.cuda.Event()
                 self._done[k].record(self.stream)
             else:
                 self.next_input = self._to_device(inp)
-            self.next_target = self._to_device(tgt)
+            self.next_target = self._to_device(tgt) if self.targets_to_device else tgt
 
     def next(self):
         torch.cuda.current_stream(self.dev).wait_stream(self.stream)

@@ -32,6 +32,26 @@ class DeviceBoxTransform(object):
             self.mean = torch.as_tensor(np.asarray(scaler_mean, np.float64)).to(self.dev)
             self.std = torch.as_tensor(np.asarray(scaler_std, np.float64)).to(self.dev)
 
+    def _upload(self, raw):
+        """the per-clip parameter records through a ring of PINNED staging buffers: a copy from pageable memory blocks the host until
+        everything queued before it has run - the host would lose its run-ahead over the GPU on every batch (measured on the C5
+        step: 8.25 -> 8.65 ms)"""
+        n = raw.size
+        ring = self.__dict__.setdefault('_ring', {'pin': [], 'ev': [], 'dev': [], 'k': 0})
+        if not ring['pin'] or ring['pin'][0].numel() < n:
+            ring['pin'] = [torch.zeros(max(n, 4096), dtype=torch.uint8).pin_memory() for _ in range(4)]
+            ring['dev'] = [torch.zeros(max(n, 4096), dtype=torch.uint8, device=self.dev) for _ in range(4)]
+            ring['ev'] = [None] * 4
+        k = ring['k']
+        ring['k'] = (k + 1) % 4
+        if ring['ev'][k] is not None:
+            ring['ev'][k].synchronize()
+        ring['pin'][k].numpy()[:n] = raw
+        ring['dev'][k][:n].copy_(ring['pin'][k][:n], non_blocking=True)
+        ring['ev'][k] = torch.cuda.Event()
+        ring['ev'][k].record()
+        return ring['dev'][k]
+
     def draw(self, nframes_raw):
         """one record of augmentation parameters for a clip, consuming np.random like the reference's transform objects"""
         r = np.zeros((), _AUG)
@@ -61,6 +81,39 @@ class DeviceBoxTransform(object):
                 r['fs_shift'] = s
         return r
 
+    def draw_batch(self, nraws):
+        """the records of a batch: the same np.random calls in the same order as draw() clip by clip, without a structured-array
+        scalar per clip (64 clips: 1.4 ms -> 0.2 ms of host time per batch)"""
+        rows = []
+        u, nrm = np.random.uniform, np.random.normal
+        nf, nm = self.frames, self.F
+        for n in nraws:
+            tm_t = tm_t0 = fm_f = fm_f0 = fm_on = fs = 0
+            if self.time_mask:
+                lo, hi, p = self.tm
+                apply = u(0, 1) < p
+                t = u(lo, hi)
+                t0 = u(0, 1 - t)
+                if apply:
+                    tm_t, tm_t0 = int(t * nf), int(t0 * nf)
+            if self.freq_mask:
+                lo, hi, p = self.fm
+                apply = u(0, 1) < p
+                f = u(lo, hi)
+                f0 = u(0, 1 - f)
+                if apply:
+                    fm_on, fm_f, fm_f0 = 1, int(f * nm), int(f0 * nm)
+            if self.freq_shift:
+                p, max_band, mean, std = self.fs
+                apply = u(0, 1) < p
+                s_ = int(nrm(mean, std))
+                while abs(s_) > max_band:
+                    s_ = int(nrm(mean, std))
+                if apply:
+                    fs = s_
+            rows.append((n, tm_t, tm_t0, fm_f, fm_f0, fm_on, fs, 0))
+        return np.asarray(rows, np.int32).view(_AUG).reshape(-1)
+
     def __call__(self, clips, params=None, out=None, staging=None):
         """clips: list of (T_raw, n_mels) float arrays / tensors (mel amplitudes), or a (B, T_raw, n_mels) tensor already on
         the device.  params: optional structured array of _AUG records (else drawn).  Returns (B, 1, frames, n_mels) f32."""
@@ -73,13 +126,14 @@ class DeviceBoxTransform(object):
             nraw = [int(c.shape[0]) for c in clips]
             stride = max(nraw)
             host = staging if staging is not None else torch.zeros((B, stride, self.F), dtype=torch.float32).pin_memory()
-            for i, c in enumerate(clips):
-                host[i, :nraw[i]].copy_(torch.as_tensor(np.asarray(c, dtype=np.float32)))
+            hv = host.numpy()
+            for i, c in enumerate(clips):                       # plain memcpys into the pinned buffer (rows >= nraw[i] are never read)
+                hv[i, :nraw[i]] = c.numpy() if torch.is_tensor(c) else c
             amp = host.to(self.dev, non_blocking=True)
         if params is None:
-            params = np.stack([self.draw(n) for n in nraw])
+            params = self.draw_batch(nraw)
         params = np.ascontiguousarray(params)
-        aug = torch.from_numpy(params.view(np.uint8).reshape(-1).copy()).to(self.dev, non_blocking=True)
+        aug = self._upload(params.view(np.uint8).reshape(-1))
         if out is None:
             out = torch.empty((B, 1, self.frames, self.F), device=self.dev, dtype=torch.float32)
         L.check(L.load().sedt_box_transform(L.p(amp), stride, L.p(aug), L.p(self.mean), L.p(self.std), B, self.frames, self.F,

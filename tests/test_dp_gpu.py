@@ -306,3 +306,40 @@ def test_eager_step_under_torch_ddp_matches_plain_eager_step(tmp_path):
     ua, ub = ra['vec'] - v0, rb['vec'] - v0
     assert ub.norm().item() > 0
     assert (ua - ub).norm().item() <= 0.1 * ub.norm().item(), ((ua - ub).norm().item(), ub.norm().item())
+
+
+def _run_bench_world2(extra):
+    """bench.py's own rank path, launched exactly as the driver launches it (python -m torch.distributed.run, one process per rank),
+    two ranks sharing the one test GPU over gloo"""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--batch', '4', '--backend', 'gloo', '--share-gpu', '--no-cpu-baseline', '--no-kernels', '--no-other-configs'] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{') and '"metric"' in l]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE line, the other ranks none
+    return json.loads(lines[0]), r.stderr
+
+
+def test_bench_rank_path_world2_gloo_graphed_schedule():
+    """multi-GPU readiness without multi-GPU hardware: build -> agree_out_of_band -> timed loop -> exposed_comm
+    -> line, through the captured data-parallel schedule.  The line must say what it is: 2 ranks, NOT RCCL (rccl_world 0)."""
+    out, _ = _run_bench_world2([])
+    assert out['n_gpus'] == 2 and out['rccl_world'] == 0 and out['hip_graph'] is True and 'graph_fallback' not in out
+    assert out['config']['global_batch'] == 8 and out['config']['parallelism'] == 'dp2' and out['scaling'] == 'weak'
+    assert len(out['ms_per_step_per_rank']) == 2 and out['value'] > 0
+    ec = out['exposed_comm']
+    assert ec and 'error' not in ec and ec['local_step_ms'] > 0 and len(ec['allreduce_segments_mb']) >= 2, ec
+    assert abs(out['value'] - 8 * 3 / (out['ms_per_step'] * 3e-3)) < 1e-2 * out['value']       # value = all ranks' clips / max-rank time
+
+
+def test_bench_rank_path_world2_gloo_forced_graph_fallback():
+    """the branch the first real multi-GPU execution may take: no rank can build the captured stepper, the ranks agree on that through
+    the TCP store (no collective) and ALL take the eager data-parallel step; the line reports it"""
+    out, err = _run_bench_world2(['--force-graph-fallback'])
+    assert out['n_gpus'] == 2 and out['rccl_world'] == 0 and out['hip_graph'] is False
+    assert 'force-graph-fallback' in out['graph_fallback'] and 'graphed data-parallel step failed' in err
+    assert out['exposed_comm'] is None and out['value'] > 0 and len(out['ms_per_step_per_rank']) == 2

@@ -445,6 +445,7 @@ def test_graph_sees_lr_changes_and_survives_eager_steps(pkg):
             if mode == 'graph' and i != 1:
                 stepper(x, t)
             else:
+                opt.zero_grad(set_to_none=True)                         # (the replay's static gradients are still attached)
                 train_step(model, crit, opt, x, t, None, slice(B))      # step 1 of the graph run is an EAGER step
             seq.append({k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()})
         res[mode] = seq

@@ -39,3 +39,19 @@ def test_transform_parameter_draws_follow_the_reference_order(golden_dir=None):
         assert (r['tm_t'], r['tm_t0']) == ((int(p[1] * 496), int(p[2] * 496)) if p[0] else (0, 0))
         assert (r['fm_on'], r['fm_f'], r['fm_f0']) == ((1, int(p[4] * 64), int(p[5] * 64)) if p[3] else (0, 0, 0))
         assert r['fs_shift'] == (int(p[7]) if p[6] else 0)
+
+
+def test_box_transform_batch_draws_equal_the_per_clip_draws():
+    """DeviceBoxTransform.draw_batch (the loader's fast path) consumes np.random exactly like draw() clip by clip - the order the
+    reference's TimeMask / FreqMask / FreqShift objects draw in (utilities/BoxTransforms.py:380-383, 410-413, 437-443)"""
+    import numpy as np
+    from sound_event_detection_transformer_amd.utilities.transforms import DeviceBoxTransform
+    for flags in ((True, True, True), (False, True, False), (True, False, True)):
+        tf = DeviceBoxTransform(496, None, None, *flags, device='cpu')
+        np.random.seed(3)
+        a = np.stack([tf.draw(n) for n in (496, 431, 520, 496) * 8])
+        sa = np.random.get_state()[1][:4].copy()
+        np.random.seed(3)
+        b = tf.draw_batch([496, 431, 520, 496] * 8)
+        assert a.dtype == b.dtype and (a.view(np.int32) == b.view(np.int32)).all()
+        assert (np.random.get_state()[1][:4] == sa).all()
