@@ -696,6 +696,43 @@ def kernel_report(dtype, dev):
         return ops.linear(dt, h, w2, bias=b2, drop_p=0.1, seed=6, res=x, ldr=x.stride(0))
     t = timeit(ffn)
     mf("encoder FFN fwd (linear1 + ReLU + dropout, linear2 + dropout + residual)", 2.0 * 2 * M * E * FF, t)
+    # the whole pre-norm encoder layer: the per-op chain (seven launches) against the x-stationary slab kernels (two launches)
+    gam2, bet2 = rnd(E, dtype_=torch.float32), rnd(E, dtype_=torch.float32)
+
+    def layer_chain():
+        x1 = block()
+        x1n, _, _, _ = ops.layernorm_fwd(dt, x1, gam2, bet2)
+        h = ops.linear(dt, x1n, w1, bias=b1, act=L.ACT_RELU, drop_p=0.1, seed=5)
+        return ops.linear(dt, h, w2, bias=b2, drop_p=0.1, seed=6, res=x1, ldr=x1.stride(0))
+    layer_flop = 352.3e6 * B                                     # FFN 268.4 + QKV / out 67.1 + attention 16.8 MFLOP per clip
+    t = timeit(layer_chain)
+    mf("encoder layer fwd, per-op chain (LN1, QK|V, attention, out-proj, LN2, linear1, linear2: 7 launches)", layer_flop, t)
+    if ops.encoder_slab_ok(dt, E, H, S, FF, None):
+        from sound_event_detection_transformer_amd import packing
+        masters = [torch.nn.Parameter(w.float()) for w in (w_in, w_o, w1, w2)]
+        plan = packing.PackPlan(dt, dev, [], masters, (), masters)
+        plan.run()
+        torch.cuda.synchronize()
+        fr = [plan.frag_table[m.data_ptr()][0] for m in masters]
+
+        def slab_layer(train):
+            qk_, v_, _ = ops.encoder_qkv_fwd(x, pos, gam, bet, fr[0], b_in, B, S, train=train)
+            return ops.encoder_attn_ffn_fwd(x, qk_, v_, None, fr[1], b_o, gam2, bet2, fr[2], b1, fr[3], b2, B, S, FF, 0.1, (7, 3, 5, 6), None,
+                                            train=train)
+        t = timeit(lambda: slab_layer(True))
+        mf("encoder layer fwd, slab kernels (sedt_encoder_qkv_fwd + sedt_encoder_attn_ffn_fwd: 2 launches), training form", layer_flop, t,
+           "a workgroup owns 32 tokens, activations stay in LDS, only weights stream L2 -> registers (csrc/slab.h); by-products for the backward written")
+        t = timeit(lambda: slab_layer(False))
+        mf("encoder layer fwd, slab kernels, no-grad form (teacher / eval)", layer_flop, t)
+        t = timeit(lambda: ops.encoder_qkv_fwd(x, pos, gam, bet, fr[0], b_in, B, S, train=True))
+        mf("  sedt_encoder_qkv_fwd alone (LN1 + pos, Q|K|V projections; 393 KB of weights per 32-token slab)", 2.0 * M * E * 3 * E, t)
+        qk0, v0, _ = ops.encoder_qkv_fwd(x, pos, gam, bet, fr[0], b_in, B, S, train=False)
+        t = timeit(lambda: ops.encoder_attn_ffn_fwd(x, qk0, v0, None, fr[1], b_o, gam2, bet2, fr[2], b1, fr[3], b2, B, S, FF, 0.1, (7, 3, 5, 6),
+                                                    None, train=True))
+        mf("  sedt_encoder_attn_ffn_fwd alone (attention, out-proj, LN2, FFN pair; 2.23 MB of weights per slab)",
+           layer_flop - 2.0 * M * E * 3 * E, t)
+        t = timeit(lambda: plan.run())
+        hb("weight packing of one encoder layer incl. the fragment-major forms (multi_pack + pack_frag)", 1.31e6 * (4 + 4 * 2), t)
     xin = rnd(B * 32 * 4, 512)
     wc = rnd(512, 9 * 512, scale=0.02)
     sc, bi = rnd(512, dtype_=torch.float32), rnd(512, dtype_=torch.float32)

@@ -319,6 +319,57 @@ typedef struct SedtPackJob {
 int sedt_multi_bn_fold(const SedtBnJob* jobs, int njobs, void* stream);
 int sedt_multi_pack(const SedtPackJob* jobs, int njobs, int nblocks, int dtype, void* stream);
 
+/* ------------------------------------------------------------------ x-stationary ("slab") transformer kernels (csrc/slab.h)
+ * A workgroup owns a slab of 32 token rows for a whole chain of sub-layers: activations stay in LDS as the B operand of
+ * v_mfma_f32_32x32x16_bf16, and only the WEIGHTS move - from L2 straight into registers as A operands - in a fragment-major
+ * packing: W [N][K] (nn.Linear layout; N % 32 == 0, K % 32 == 0) as 1 KB blocks, block (n / 32, k / 16) at byte
+ * ((n / 32) * (K / 16) + k / 16) * 1024, inside it lane l = 32 * ((k % 16) / 8) + n % 32 owns 8 consecutive k (16 bytes).
+ * sedt_pack_frag packs any number of f32 master weights into that form (wf) and / or the same form of W^T (wb: the operand of the
+ * input-gradient chain) in one launch; nblocks = sum over the jobs of (N / 32) * (K / 32), blk0 = first block of a job. */
+typedef struct SedtFragJob {
+  const float* w; /* f32 master [N][K] */
+  void* wf;       /* fragment-major W, bf16, or null */
+  void* wb;       /* fragment-major W^T, bf16, or null */
+  int32_t N, K;
+  int32_t blk0, pad_;
+} SedtFragJob;
+int sedt_pack_frag(const SedtFragJob* jobs, int njobs, int nblocks, void* stream);
+/* The pre-norm encoder layer (sedt/transformer.py:192-204; nn.MultiheadAttention arithmetic as in sedt_attention_fwd) in TWO launches:
+ *   sedt_encoder_qkv_fwd:      xn = LayerNorm1(x); q | k = (xn + pos) Wqk^T + b; v = xn Wv^T + b
+ *   sedt_encoder_attn_ffn_fwd: ctx = dropout(softmax(q k^T / sqrt(32) + key padding)) v over the clip's S keys;
+ *                              x1 = x + dropout(ctx Wo^T + bo); x1n = LayerNorm2(x1);
+ *                              x2 = x1 + dropout(dropout(relu(x1n W1^T + b1)) W2^T + b2)
+ * x, pos, x2 [B*S][256] bf16 contiguous; qk [B*S][512], v [B*S][256] bf16; weights fragment-major (sedt_pack_frag), biases and
+ * LayerNorm parameters f32; kpm [B][S] (1 = padding) or null.  Training by-products - what sedt_layernorm_bwd, sedt_attention_bwd and
+ * the weight-gradient GEMMs read; all or none (null: a no-grad forward): xn, xnp [B*S][256], mean, rstd [B*S]; ctx, x1, x1n
+ * [B*S][256], lse [B][8][S], mean2, rstd2 [B*S], h [B*S][FF] (the dropped ReLU output).  Dropout decisions are the counter hashes of
+ * the unfused chain: attention ((b*8 + h)*S + q)*S + k under seed_attn, out-proj row*256 + col under seed_o, hidden row*FF + col
+ * under seed_h, FFN output row*256 + col under seed_f (each + *seed_ptr).  Envelope (sedt_encoder_slab_ok): bf16, d_model 256,
+ * 8 heads, S <= 128, FF a multiple of 512. */
+int sedt_encoder_slab_ok(int D, int H, int S, int FF, int dtype);
+/* The input-gradient chain of the same layer, two launches around sedt_attention_bwd (weights as fragment-major W^T, the `wb` of
+ * sedt_pack_frag):
+ *   sedt_encoder_ffn_bwd:  g2 = dropout'(gx2); gh = (g2 W2) [h > 0] / (1 - p); g_x1n = gh W1; gx1 = LayerNorm2'(g_x1n) + gx2;
+ *                          g1 = dropout'(gx1); gctx = g1 Wo          (g2 may be null when drop_p == 0: it equals gx2; g1 likewise)
+ *   sedt_encoder_qkv_bwd:  gx = LayerNorm1'(dq|dk Wqk + dv Wv) + gx1
+ * g2, gh, g1 are the left operands of the weight-gradient GEMMs of linear2, linear1, out_proj; ln_part [slabs][512] = per-slab
+ * sums of (dy * xhat | dy) whose column sums are the LayerNorm gamma / beta gradients (slabs = B * ceil(S / 32)). */
+int sedt_encoder_ffn_bwd(const void* gx2, const void* h, const void* x1, const float* mean2, const float* rstd2,
+                         const float* gamma2, const void* w2t_frag, const void* w1t_frag, const void* wot_frag, void* g2, void* gh,
+                         void* gx1, void* g1, void* gctx, float* ln_part, int B, int S, int FF, float drop_p, uint32_t seed_f,
+                         uint32_t seed_o, const uint32_t* seed_ptr, void* stream);
+int sedt_encoder_qkv_bwd(const void* dqk, const void* dv, const void* x, const float* mean1, const float* rstd1,
+                         const float* gamma1, const void* gx1, const void* wint_frag, void* gx, float* ln_part, int B, int S,
+                         void* stream);
+int sedt_encoder_qkv_fwd(const void* x, const void* pos, const float* gamma, const float* beta, const void* w_in_frag,
+                         const float* b_in, void* qk, void* v, void* xn, void* xnp, float* mean, float* rstd, int B, int S,
+                         void* stream);
+int sedt_encoder_attn_ffn_fwd(const void* x, const void* qk, const void* v, const uint8_t* kpm, const void* w_o_frag,
+                              const float* b_o, const float* gamma2, const float* beta2, const void* w1_frag, const float* b1,
+                              const void* w2_frag, const float* b2, void* x2, void* ctx, float* lse, void* x1, float* mean2,
+                              float* rstd2, void* x1n, void* h, int B, int S, int FF, float drop_p, uint32_t seed_attn,
+                              uint32_t seed_o, uint32_t seed_h, uint32_t seed_f, const uint32_t* seed_ptr, void* stream);
+
 /* chunk.p[i] = chunk.g[i] for every chunk: packs all gradient tensors into one flat buffer (one launch) ahead of the RCCL
  * all-reduce of the data-parallel step.  mode bit 0: chunk.p[i] += chunk.g[i] instead (gradient accumulation over micro-batches,
  * engine.py:76, 174); bit 1: the flat buffer is bf16 (chunk.p addresses 2-byte elements; half the all-reduce bytes). */

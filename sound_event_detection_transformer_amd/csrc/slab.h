@@ -1,0 +1,141 @@
+// slab.h - the "x-stationary" GEMM building block of the transformer-side kernels (enc_slab.hip, dec_slab.hip).
+//
+// At B = 64 every GEMM of the transformer has M = 8192 (encoder) or M = 704 (decoder) rows: one or two 64x128 tiles per CU in the
+// LDS-DMA GEMM family, whose tiles move BOTH operands through LDS at ~30 B/clk/CU, launch by launch.  Here a workgroup owns a SLAB of
+// 32 token rows for a whole chain of layers: the activations stay in LDS (bf16 [32][K] tiles) as the B operand of
+// v_mfma_f32_32x32x16_bf16 (lane <-> token), and only the WEIGHTS move - straight from L2 into registers as A operands
+// (lane <-> output feature), in a fragment-major packing (sedt_pack_frag) in which one wave instruction reads one fully contiguous
+// 1 KB block.  Measured (tools/probes/wstream.hip, 256 workgroups streaming the same matrix): 36-44 B/clk/CU = 88-106 GB/s per CU,
+// 23-27 TB/s over the chip, against ~30 B/clk/CU for the LDS-DMA ring - and nothing but W moves.
+//
+// Fragment-major packing of W [N][K] (N outputs, K inputs; N % 32 == 0, K % 16 == 0): block (ft = n / 32, ks = k / 16) of 1 KB at
+// byte ((ft * (K / 16) + ks) * 1024); inside, lane l = 32 * ((k % 16) / 8) + n % 32 owns the 8 consecutive k of its half = 16 bytes.
+// That is exactly the A operand of the 32x32x16 MFMA (row = lane % 32, k-slots 8 * (lane / 32) ..+7).
+#pragma once
+#include "common.h"
+
+namespace sedt {
+namespace slab {
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr int SR = 32;             // token rows of a slab
+constexpr int XP = 256 + 8;        // element pitch of a [32][256] bf16 LDS tile: 528 B rows (16-byte fragment reads conflict-free)
+
+// C-layout row (= output feature inside its tile of 32) of accumulator register r in lane half hf
+__device__ __forceinline__ int crow(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
+
+// A weight CHUNK = 8 fragments (8 KB per wave): T output-feature tiles x U = 8 / T k-steps of 16.
+//   W : the fragment-major weight, pointing at the block of (first tile, first k-step); tstride = 16-byte units between the same
+//       k-step of consecutive tiles (= 64 * K / 16)
+template <int T>
+__device__ __forceinline__ void load_chunk(u32x4 (&dst)[8], const u32x4* __restrict__ W, long tstride, int ks0, int lane) {
+  constexpr int U = 8 / T;
+  const u32x4* wl = W + lane;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int u = 0; u < U; ++u) dst[t * U + u] = wl[t * tstride + (long)(ks0 + u) * 64];
+}
+
+// "everything issued above stays above": keeps a block of loads ahead of the work that hides their latency
+__device__ __forceinline__ void issue_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+struct NoNext {
+  __device__ __forceinline__ void operator()(u32x4 (&)[8]) const {}
+};
+
+// T output-feature tiles x the slab's 32 tokens over NKS k-steps of 16; xs = the activation tile in LDS (element pitch xp, the k-steps
+// start at its column 0).  On entry `cur` holds chunk 0 (load_chunk<T>(cur, W, tstride, 0, lane), issued by the caller as early as
+// it likes - weights do not depend on activations); chunk c + 1 is in flight while chunk c is multiplied, and while the LAST chunk
+// is multiplied `next(cur)` has the first chunk of the FOLLOWING GEMM in flight (the number of chunks is even, so it lands in
+// `cur` again): a wave's weight stream never drains across the barriers and epilogues between the GEMMs of a chain - each
+// restart exposed a full L2 round trip (measured on the FFN pair: 48 -> 2x us).
+template <int T, int NKS, class Next>
+__device__ __forceinline__ void wave_gemm(f32x16 (&acc)[T], const bf16_t* xs, int xp, const u32x4* __restrict__ W, long tstride,
+                                          int lane, u32x4 (&cur)[8], u32x4 (&alt)[8], Next next) {
+  constexpr int U = 8 / T, NCH = NKS / U;
+  static_assert(NKS % U == 0 && NCH % 2 == 0, "an even number of chunks");
+  const bf16_t* xrow = xs + (lane & 31) * xp + 8 * (lane >> 5);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    u32x4(&src)[8] = (c & 1) ? alt : cur;
+    u32x4(&dst)[8] = (c & 1) ? cur : alt;
+    if (c + 1 < NCH) load_chunk<T>(dst, W, tstride, (c + 1) * U, lane);
+    else next(dst);
+    // the machine scheduler otherwise sinks every load to just above its MFMA (fewer live registers): global_load -> s_waitcnt
+    // vmcnt(0) -> v_mfma, one exposed L2 round trip per fragment (seen in the ISA of the first version: the FFN pair at 18 B/clk)
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 xb[U];                                              // the chunk's activation fragments: all LDS reads ahead of the MFMAs
+#pragma unroll
+    for (int u = 0; u < U; ++u) xb[u] = *reinterpret_cast<const bf16x8*>(xrow + (c * U + u) * 16);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, src[t * U + u]), xb[u], acc[t], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// the 4 x 4 per-feature values (bias, ...) a lane needs for the epilogue of output tile `tile`: feature tile * 32 + 8 * g4 + 4 * hf + e.
+// Issued BEFORE the GEMM whose epilogue uses them: loads return in order, so a load issued in the epilogue would wait behind the
+// weight chunks already prefetched for the next GEMM - the stream would drain once per epilogue.
+__device__ __forceinline__ void load_feat4(float4 (&dst)[4], const float* __restrict__ p, int tile, int hf) {
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) dst[g4] = *reinterpret_cast<const float4*>(p + tile * 32 + 8 * g4 + 4 * hf);
+}
+
+template <int T>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[T]) {
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+}
+
+// LayerNorm of the slab rows [4 * wave, 4 * wave + 4) over 256 features: a lane owns 4 consecutive features of a row.
+// src(row) -> pointer to the row's 256 bf16 values (global or LDS); rows >= nvalid give zeros.  f(row, lane, y[4], mean, rstd).
+template <class Src, class Out>
+__device__ __forceinline__ void slab_layernorm(int wave, int lane, int nvalid, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, Src src, Out out) {
+  const float4 g4 = *reinterpret_cast<const float4*>(gamma + lane * 4), b4 = *reinterpret_cast<const float4*>(beta + lane * 4);
+  const float g[4] = {g4.x, g4.y, g4.z, g4.w}, bt[4] = {b4.x, b4.y, b4.z, b4.w};
+  VecT<bf16_t, 4> xin[4];                                     // all four rows on their way before the first reduction
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 4 + i;
+    xin[i] = row < nvalid ? *reinterpret_cast<const VecT<bf16_t, 4>*>(src(row) + lane * 4) : VecT<bf16_t, 4>{};
+  }
+  issue_fence();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wave * 4 + i;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)xin[i].v[e];
+    const float mu = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = v[e] - mu; q += d * d; }
+    const float rs = rsqrtf(wave_sum(q) * (1.f / 256.f) + 1e-5f);
+    float y[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = row < nvalid ? (v[e] - mu) * rs * g[e] + bt[e] : 0.f;
+    out(row, y, mu, rs);
+  }
+}
+
+// cooperative copy of an LDS tile [rows][cols] (bf16, element pitch lp) to global rows of stride ld (16 bytes per thread and step)
+__device__ __forceinline__ void tile_to_global(const bf16_t* tile, int lp, bf16_t* __restrict__ dst, long ld, int rows, int cols, int tid,
+                                               int nthr) {
+  const int cpr = cols >> 3;
+  for (int u = tid; u < rows * cpr; u += nthr) {
+    const int r = u / cpr, c = (u - r * cpr) * 8;
+    *reinterpret_cast<uint4*>(dst + (long)r * ld + c) = *reinterpret_cast<const uint4*>(tile + r * lp + c);
+  }
+}
+
+}  // namespace slab
+}  // namespace sedt

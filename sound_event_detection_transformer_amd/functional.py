@@ -424,6 +424,32 @@ class EncoderLayerFn(Function):
         pos = _as(pos, dt)
         sv = {}
         tr = any(ctx.needs_input_grad)
+        fr = None
+        if cfg['pre_norm'] and ops.encoder_slab_ok(dt, x.shape[1], H, S, w1.shape[0], amask):
+            fr = [packing.lookup_frag(w) for w in (w_in, w_o, w1, w2)]
+            fr = fr if all(f is not None for f in fr) else None
+        if fr is not None:
+            # the whole layer in TWO launches on the x-stationary slab kernels (csrc/enc_slab.hip); by-products for the per-op backward
+            # kernels are written only when a backward will follow
+            x, pos = x.contiguous(), pos.contiguous()
+            sp = runtime.seed_ptr(x.device) if p > 0 else None
+            _, wb_in = _prep_linear(dt, w_in, tr)
+            _, wb_o = _prep_linear(dt, w_o, tr)
+            _, wb1 = _prep_linear(dt, w1, tr)
+            _, wb2 = _prep_linear(dt, w2, tr)
+            qk, v, by1 = ops.encoder_qkv_fwd(x, pos, g1, be1, fr[0][0], b_in, B, S, train=tr)
+            x2, by2 = ops.encoder_attn_ffn_fwd(x, qk, v, kpm, fr[1][0], b_o, g2, be2, fr[2][0], b1, fr[3][0], b2, B, S, w1.shape[0],
+                                               p, seeds, sp, train=tr)
+            if tr:
+                xn, xnp, m1, r1 = by1
+                ctxv, lse, x1, m2, r2, x1n, h = by2
+                E = x.shape[1]
+                sv['mha'] = dict(wb_in=wb_in, wb_o=wb_o, q_in=xnp, k_in=xnp, v_in=xn, same_qk=True, qk=qk, q=qk[:, :E], k=qk[:, E:], v=v,
+                                 ctxv=ctxv, lse=lse, dims=(B, H, S, S), kpm=kpm, amask=None, p=p, seeds=seeds[0:2])
+                sv['ffn'] = dict(x_in=x1n, h=h, p=p, seeds=seeds[2:4], wb1=wb1, wb2=wb2)
+                sv.update(x=x, x1=x1, m1=m1, r1=r1, m2=m2, r2=r2, slab=(fr[0][1], fr[1][1], fr[2][1], fr[3][1]))
+            ctx.sv, ctx.cfg, ctx.P = sv, cfg, P
+            return x2
         if cfg['pre_norm'] and ops.FUSED_ENC and ops.encoder_attn_ok(dt, x.shape[1], H, S, amask) and x.is_contiguous() and pos.is_contiguous():
             # LayerNorm1 + Q|K|V projections + attention core in ONE launch (csrc/attn_mfma.hip); the by-products the unfused
             # backward kernels read are written only when a backward will follow
@@ -463,6 +489,42 @@ class EncoderLayerFn(Function):
         (w_in, b_in, w_o, b_o, w1, b1, w2, b2, g1, be1, g2, be2) = P
         gx2 = _as(gx2, dt)
         rb = ops.ReduceBatch()
+        if sv.get('slab') is not None and ops.SLAB_ENC_BWD:
+            # the input-gradient chain on the slab kernels: [FFN + LayerNorm2 + out-proj] | attention core | [in-proj + LayerNorm1];
+            # the weight gradients stay the layer's one grouped GEMM launch + one reduce launch
+            B, S, H = cfg['B'], cfg['S'], cfg['H']
+            wint, wot, w1t, w2t = sv['slab']
+            ff, mh = sv['ffn'], sv['mha']
+            p = ff['p']
+            dev = gx2.device
+            sp = runtime.seed_ptr(dev) if p > 0 else None
+            E = gx2.shape[1]
+            g2d, gh, gx1, g1d, gctx, part2 = ops.encoder_ffn_bwd(gx2.contiguous(), ff['h'], sv['x1'], sv['m2'], sv['r2'], g2, w2t, w1t, wot,
+                                                                 B, S, p, (ff['seeds'][1], mh['seeds'][1]), sp)
+            d_b2 = torch.empty((E,), device=dev, dtype=torch.float32)
+            d_w2 = ops.linear_wgrad(dt, g2d, ff['h'], bias_out=d_b2, batch=rb, param=w2)
+            d_b1 = torch.empty((gh.shape[1],), device=dev, dtype=torch.float32)
+            d_w1 = ops.linear_wgrad(dt, gh, ff['x_in'], bias_out=d_b1, batch=rb, param=w1)
+            d_bo = torch.empty((E,), device=dev, dtype=torch.float32)
+            d_wo = ops.linear_wgrad(dt, g1d, mh['ctxv'], bias_out=d_bo, batch=rb, param=w_o)
+            dgb2 = torch.empty((2 * E,), device=dev, dtype=torch.float32)
+            rb.add_colsum(part2, part2.shape[0], 2 * E, dgb2)
+            dqk = torch.empty((B * S, 2 * E), device=dev, dtype=gx2.dtype)
+            dv = torch.empty((B * S, E), device=dev, dtype=gx2.dtype)
+            ops.attention_bwd(dt, mh['q'], mh['k'], mh['v'], mh['ctxv'], gctx, mh['lse'], B, H, S, S, dqk[:, :E], dqk[:, E:], dv, mh['kpm'],
+                              None, p, mh['seeds'][0], sp)
+            d_win = ops._sink(w_in, (3 * E, E))
+            if d_win is None:
+                d_win = torch.empty((3 * E, E), device=dev, dtype=torch.float32)
+            d_bin = torch.empty((3 * E,), device=dev, dtype=torch.float32)
+            ops.linear_wgrad(dt, dqk, mh['q_in'], out=d_win[:2 * E], bias_out=d_bin[:2 * E], batch=rb)
+            ops.linear_wgrad(dt, dv, mh['v_in'], out=d_win[2 * E:], bias_out=d_bin[2 * E:], batch=rb)
+            gx, part1 = ops.encoder_qkv_bwd(dqk, dv, sv['x'], sv['m1'], sv['r1'], g1, gx1, wint, B, S)
+            dgb1 = torch.empty((2 * E,), device=dev, dtype=torch.float32)
+            rb.add_colsum(part1, part1.shape[0], 2 * E, dgb1)
+            rb.flush()
+            ctx.sv = None
+            return (gx, None, None, None, None, d_win, d_bin, d_wo, d_bo, d_w1, d_b1, d_w2, d_b2, dgb1[:E], dgb1[E:], dgb2[:E], dgb2[E:])
         if cfg['pre_norm']:
             g_x1n, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], gx2, w1, w2, batch=rb)
             gx1, d_g2, d_be2, gx1d = ops.layernorm_bwd(dt, g_x1n, sv['x1'], g2, sv['m2'], sv['r2'], dres=gx2, batch=rb,

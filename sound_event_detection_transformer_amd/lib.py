@@ -105,6 +105,12 @@ SIGNATURES = {
                                 _i64, _vp, _i64, _i, _i, _i, _i, _f, _u32, _vp, _i, _vp]),
     'sedt_encoder_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u32,
                                _vp, _i, _vp]),
+    'sedt_pack_frag': (_i, [_vp, _i, _i, _vp]),
+    'sedt_encoder_slab_ok': (_i, [_i, _i, _i, _i, _i]),
+    'sedt_encoder_qkv_fwd': (_i, [_vp] * 12 + [_i, _i, _vp]),
+    'sedt_encoder_attn_ffn_fwd': (_i, [_vp] * 20 + [_i, _i, _i, _f, _u32, _u32, _u32, _u32, _vp, _vp]),
+    'sedt_encoder_ffn_bwd': (_i, [_vp] * 15 + [_i, _i, _i, _f, _u32, _u32, _vp, _vp]),
+    'sedt_encoder_qkv_bwd': (_i, [_vp] * 10 + [_i, _i, _vp]),
     'sedt_posenc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'sedt_mask_resize': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'sedt_bn_fold': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -665,6 +665,87 @@ def encoder_attn_fwd(dtype, x, pos, gamma, beta, w_in, b_in, B, S, H, kpm=None, 
     return ctx, lse, saved
 
 
+# The pre-norm encoder layer on the x-stationary slab kernels (csrc/enc_slab.hip: two launches per layer instead of seven; a workgroup
+# owns 32 tokens, only weights stream).  Default in the bf16 mode; SLAB_ENC = False (tests, A/B) keeps the per-op chain.
+SLAB_ENC = _dev_env('SEDT_SLAB_ENC', '1') != '0'
+SLAB_ENC_BWD = _dev_env('SEDT_SLAB_ENC_BWD', '1') != '0'      # the input-gradient chain of those layers on the slab kernels as well
+
+
+def encoder_slab_ok(dtype, D, H, S, FF, amask):
+    return bool(SLAB_ENC and dtype == BF16 and amask is None and L.load().sedt_encoder_slab_ok(D, H, S, FF, dtype))
+
+
+def encoder_qkv_fwd(x, pos, gamma, beta, w_in_frag, b_in, B, S, train=True):
+    """xn = LayerNorm1(x); q | k = (xn + pos) Wqk^T + b; v = xn Wv^T + b.  x, pos [B*S, 256] bf16 contiguous; w_in_frag = the
+    fragment-major in_proj_weight (packing.lookup_frag).  Returns (qk [B*S, 512], v [B*S, 256], (xn, xnp, mean, rstd) or None)"""
+    _dev_check(x, pos, w_in_frag)
+    M, D = x.shape
+    assert x.is_contiguous() and pos.is_contiguous() and pos.shape == x.shape and M == B * S and D == 256 and x.dtype == torch.bfloat16
+    qk = torch.empty((M, 2 * D), device=x.device, dtype=x.dtype)
+    v = torch.empty((M, D), device=x.device, dtype=x.dtype)
+    by = None
+    if train:
+        by = (torch.empty_like(x), torch.empty_like(x), torch.empty((M,), device=x.device, dtype=torch.float32),
+              torch.empty((M,), device=x.device, dtype=torch.float32))
+    s = by if by is not None else (None,) * 4
+    L.check(L.load().sedt_encoder_qkv_fwd(_p(x), _p(pos), _p(gamma), _p(beta), _p(w_in_frag), _p(b_in), _p(qk), _p(v), _p(s[0]), _p(s[1]),
+                                          _p(s[2]), _p(s[3]), B, S, L.stream_ptr()), 'encoder_qkv_fwd')
+    return qk, v, by
+
+
+def encoder_attn_ffn_fwd(x, qk, v, kpm, w_o_frag, b_o, gamma2, beta2, w1_frag, b1, w2_frag, b2, B, S, FF, drop_p=0.0, seeds=(0, 0, 0, 0),
+                         seed_ptr=None, train=True):
+    """attention over the clip's keys + out-proj + residual + LayerNorm2 + the FFN pair + residual for every 32-token slab in ONE
+    launch.  Returns (x2, (ctx, lse, x1, mean2, rstd2, x1n, h) or None); seeds = (attention, out-proj, hidden, FFN output)"""
+    _dev_check(x, qk, v)
+    M, D = x.shape
+    assert x.is_contiguous() and qk.is_contiguous() and v.is_contiguous() and M == B * S
+    x2 = torch.empty_like(x)
+    by = None
+    if train:
+        f32 = dict(device=x.device, dtype=torch.float32)
+        by = (torch.empty_like(x), torch.empty((B, 8, S), **f32), torch.empty_like(x), torch.empty((M,), **f32), torch.empty((M,), **f32),
+              torch.empty_like(x), torch.empty((M, FF), device=x.device, dtype=x.dtype))
+    s = by if by is not None else (None,) * 7
+    L.check(L.load().sedt_encoder_attn_ffn_fwd(_p(x), _p(qk), _p(v), _p(kpm), _p(w_o_frag), _p(b_o), _p(gamma2), _p(beta2), _p(w1_frag),
+                                               _p(b1), _p(w2_frag), _p(b2), _p(x2), _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]), _p(s[4]),
+                                               _p(s[5]), _p(s[6]), B, S, FF, drop_p, seeds[0] & 0xffffffff, seeds[1] & 0xffffffff,
+                                               seeds[2] & 0xffffffff, seeds[3] & 0xffffffff, _p(seed_ptr), L.stream_ptr()),
+            'encoder_attn_ffn_fwd')
+    return x2, by
+
+
+def encoder_ffn_bwd(gx2, h, x1, mean2, rstd2, gamma2, w2t_frag, w1t_frag, wot_frag, B, S, drop_p=0.0, seeds=(0, 0), seed_ptr=None):
+    """FFN backward + LayerNorm2 backward + out-proj input gradient per 32-token slab in ONE launch (csrc/enc_slab.hip).
+    seeds = (FFN-output dropout, out-proj dropout).  Returns (g2, gh, gx1, g1, gctx, ln_part [slabs, 512])"""
+    _dev_check(gx2, h, x1)
+    M, D = gx2.shape
+    FF = h.shape[1]
+    assert gx2.is_contiguous() and h.is_contiguous() and x1.is_contiguous() and M == B * S
+    nsl = B * ((S + 31) // 32)
+    g2 = torch.empty_like(gx2) if drop_p > 0 else None
+    g1 = torch.empty_like(gx2) if drop_p > 0 else None
+    gh = torch.empty_like(h)
+    gx1, gctx = torch.empty_like(gx2), torch.empty_like(gx2)
+    part = torch.empty((nsl, 2 * D), device=gx2.device, dtype=torch.float32)
+    L.check(L.load().sedt_encoder_ffn_bwd(_p(gx2), _p(h), _p(x1), _p(mean2), _p(rstd2), _p(gamma2), _p(w2t_frag), _p(w1t_frag),
+                                          _p(wot_frag), _p(g2), _p(gh), _p(gx1), _p(g1), _p(gctx), _p(part), B, S, FF, drop_p,
+                                          seeds[0] & 0xffffffff, seeds[1] & 0xffffffff, _p(seed_ptr), L.stream_ptr()), 'encoder_ffn_bwd')
+    return (g2 if g2 is not None else gx2), gh, gx1, (g1 if g1 is not None else gx1), gctx, part
+
+
+def encoder_qkv_bwd(dqk, dv, x, mean1, rstd1, gamma1, gx1, wint_frag, B, S):
+    """gx = LayerNorm1'(dq|dk Wqk + dv Wv) + gx1 per slab in one launch.  Returns (gx, ln_part [slabs, 512])"""
+    _dev_check(dqk, dv, x, gx1)
+    M, D = x.shape
+    assert dqk.is_contiguous() and dv.is_contiguous() and x.is_contiguous() and gx1.is_contiguous() and M == B * S
+    gx = torch.empty_like(x)
+    part = torch.empty((B * ((S + 31) // 32), 2 * D), device=x.device, dtype=torch.float32)
+    L.check(L.load().sedt_encoder_qkv_bwd(_p(dqk), _p(dv), _p(x), _p(mean1), _p(rstd1), _p(gamma1), _p(gx1), _p(wint_frag), _p(gx),
+                                          _p(part), B, S, L.stream_ptr()), 'encoder_qkv_bwd')
+    return gx, part
+
+
 def posenc(dtype, mask_u8, D):
     B, H, W = mask_u8.shape
     pos = torch.empty((B, H * W, D), device=mask_u8.device, dtype=TORCH_DTYPE[dtype])

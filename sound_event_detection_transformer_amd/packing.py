@@ -15,9 +15,20 @@ _BN = np.dtype([('w', np.uint64), ('b', np.uint64), ('rm', np.uint64), ('rv', np
                 ('bias', np.uint64), ('n', np.int32), ('pad', np.int32)])
 _PK = np.dtype([('w', np.uint64), ('bnscale', np.uint64), ('wf', np.uint64), ('wb', np.uint64), ('e0', np.int64),
                 ('ne', np.int32), ('Cout', np.int32), ('Cin', np.int32), ('taps', np.int32)])
+_FJ = np.dtype([('w', np.uint64), ('wf', np.uint64), ('wb', np.uint64), ('N', np.int32), ('K', np.int32), ('blk0', np.int32),
+                ('pad', np.int32)])
 _CHUNK = 32768
 
 _active = []          # stack of plans whose prepared tensors are valid right now (inside a model forward)
+
+
+def lookup_frag(weight):
+    """(fragment-major W, fragment-major W^T) prepared for this 2-D parameter by the active plan (csrc/slab.h), or None"""
+    for plan in reversed(_active):
+        hit = plan.frag_table.get(weight.data_ptr())
+        if hit is not None:
+            return hit
+    return None
 
 
 def lookup(weight):
@@ -30,10 +41,13 @@ def lookup(weight):
 
 
 class PackPlan(object):
-    def __init__(self, dt, device, convs, linears, bn_only=()):
+    def __init__(self, dt, device, convs, linears, bn_only=(), frags=()):
         """convs: list of (weight Parameter, (bn_w, bn_b, bn_rm, bn_rv) or None); linears: list of weight Parameters (2-D).
-        A linear in f32 mode uses the parameter itself as the forward operand."""
+        A linear in f32 mode uses the parameter itself as the forward operand.
+        frags (bf16 mode): 2-D weight Parameters [N][K] (N, K multiples of 32) that are ALSO packed fragment-major, W and W^T, for
+        the x-stationary slab kernels (one more launch: sedt_pack_frag)"""
         self.dt, self.device = dt, device
+        self._init_frags(frags if dt == BF16 else (), device)
         td = TORCH_DTYPE[dt]
         es = 4 if dt == F32 else 2
         bns = [(w, bn) for w, bn in list(convs) + list(bn_only) if bn is not None]
@@ -109,6 +123,29 @@ class PackPlan(object):
         self._host_pk = torch.empty(max(self._pk.nbytes, 8), dtype=torch.uint8).pin_memory()
         self._last = None
 
+    def _init_frags(self, frags, device):
+        self.frag_table, self._fr_params, self._fr_entries = {}, [], []
+        frags = [w for w in frags if w.dim() == 2 and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0]
+        self._fj = np.zeros(len(frags), _FJ)
+        self._fr_blocks = 0
+        if not frags:
+            return
+        total = sum(2 * w.numel() for w in frags)
+        self.fbuf = torch.empty(total, device=device, dtype=torch.bfloat16)
+        base, off = self.fbuf.data_ptr(), 0
+        for r, w in enumerate(frags):
+            N, K = w.shape
+            n = w.numel()
+            wf, wb = self.fbuf[off:off + n], self.fbuf[off + n:off + 2 * n]
+            row = self._fj[r]
+            row['wf'], row['wb'], row['N'], row['K'], row['blk0'] = base + 2 * off, base + 2 * (off + n), N, K, self._fr_blocks
+            self._fr_blocks += (N // 32) * (K // 32)
+            off += 2 * n
+            self._fr_params.append(w)
+            self._fr_entries.append((w, wf, wb))
+        self._dev_fj = torch.empty(self._fj.nbytes, dtype=torch.uint8, device=device)
+        self._host_fj = torch.empty(self._fj.nbytes, dtype=torch.uint8).pin_memory()
+
     def pointer_key(self):
         """the live parameter / buffer pointers this plan would read now (changes under EMA.apply_shadow, load_state_dict)"""
         wp = np.fromiter((w.data_ptr() for w in self._params), np.uint64, len(self._params))
@@ -128,10 +165,18 @@ class PackPlan(object):
                 self._dev_bn.copy_(self._host_bn, non_blocking=True)
             self._last = key
             self.table = {w.data_ptr(): (wf if wf is not None else w, wb, sc, bi) for w, wf, wb, sc, bi in self._entries}
+            if len(self._fj):
+                # (the fragment-packed weights are a subset of the linears: a pointer change there changed `key` as well)
+                self._fj['w'] = np.fromiter((w.data_ptr() for w in self._fr_params), np.uint64, len(self._fr_params))
+                self._host_fj.numpy()[:] = self._fj.view(np.uint8)
+                self._dev_fj.copy_(self._host_fj, non_blocking=True)
+                self.frag_table = {w.data_ptr(): (wf, wb) for w, wf, wb in self._fr_entries}
         lib = L.load()
         if len(self._bn):
             L.check(lib.sedt_multi_bn_fold(L.p(self._dev_bn), len(self._bn), L.stream_ptr()), 'multi_bn_fold')
         L.check(lib.sedt_multi_pack(L.p(self._dev_pk), len(self._pk), self._nblocks, self.dt, L.stream_ptr()), 'multi_pack')
+        if len(self._fj):
+            L.check(lib.sedt_pack_frag(L.p(self._dev_fj), len(self._fj), self._fr_blocks, L.stream_ptr()), 'pack_frag')
 
     def __enter__(self):
         self.run()

@@ -102,8 +102,10 @@ class SEDT(nn.Module):
                         if b.downsample is not None:
                             convs.append((b.downsample[0].weight, b.downsample[1].tensors()))
                 lin = [self.input_proj.weight]          # (Co, Ci, 1, 1): the Parameter itself, so pointer swaps are seen
+                frags = []                              # weights the slab kernels stream fragment-major (csrc/slab.h)
                 for l in self.transformer.encoder.layers:
                     lin += [l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.linear1.weight, l.linear2.weight]
+                    frags += [l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.linear1.weight, l.linear2.weight]
                 for l in self.transformer.decoder.layers:
                     lin += [l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.multihead_attn.in_proj_weight,
                             l.multihead_attn.out_proj.weight, l.linear1.weight, l.linear2.weight]
@@ -113,7 +115,7 @@ class SEDT(nn.Module):
                         lin.append(getattr(self, name).weight)
                 if hasattr(self, 'feature_align'):
                     lin += [m.weight for m in self.feature_align.layers]
-                return packing.PackPlan(dt, dev, convs, lin, bn_only)
+                return packing.PackPlan(dt, dev, convs, lin, bn_only, frags)
             plans[key] = packing.PlanSet(factory)
         return plans[key]
 
