@@ -354,6 +354,38 @@ int sedt_encoder_slab_ok(int D, int H, int S, int FF, int dtype);
  *   sedt_encoder_qkv_bwd:  gx = LayerNorm1'(dq|dk Wqk + dv Wv) + gx1
  * g2, gh, g1 are the left operands of the weight-gradient GEMMs of linear2, linear1, out_proj; ln_part [slabs][512] = per-slab
  * sums of (dy * xhat | dy) whose column sums are the LayerNorm gamma / beta gradients (slabs = B * ceil(S / 32)). */
+/* One pre-norm decoder layer (sedt/transformer.py:263-284) in ONE launch, a workgroup per clip (csrc/dec_slab.hip): the Q <= 32 query
+ * rows of a clip stay in LDS from LayerNorm1 to the FFN output, the layer's weights stream fragment-major (sedt_pack_frag), the 8
+ * waves are the 8 heads of both attention cores.  Outside stays the K | V projection of the encoder memory: kc / vc [B*S][ldk / ldv]
+ * (bf16, row strides in elements) are its outputs.  s_win = in_proj_weight [768][256] of self_attn, c_wq = the first 256 rows of
+ * multihead_attn.in_proj_weight (its query projection; c_bq = the first 256 entries of its bias), all weights as fragment-major W.
+ * tgt, qpos, out, t1 [B*Q][256] bf16 contiguous (t1 is always written: the cross out-projection re-reads it); amask = additive
+ * self-attention mask [Q][Q] f32 (SP-SEDT) or null; kpm [B][S] or null.  Training by-products (all or none; null = no-grad forward),
+ * exactly what the per-op backward kernels read: tn, tnp, m1, r1, qk_s [B*Q][512], v_s, ctx_s, lse_s [B][8][Q]; t1np, m2, r2, q_c,
+ * ctx_c, lse_c; t2, m3, r3, t2n, h [B*Q][FF].  seed[6] = self attention, self out-proj, cross attention, cross out-proj, hidden,
+ * FFN output (each + *seed_ptr); element indices as in the per-op kernels.  Envelope (sedt_decoder_slab_ok): bf16, d_model 256,
+ * 8 heads, Q <= 32, S <= 128, FF a multiple of 512. */
+typedef struct SedtDecLayer {
+  const void* tgt; const void* qpos;
+  const void* kc; int64_t ldk; const void* vc; int64_t ldv;
+  const uint8_t* kpm; const float* amask;
+  const void* s_win; const float* s_bin; const void* s_wo; const float* s_bo;
+  const void* c_wq; const float* c_bq; const void* c_wo; const float* c_bo;
+  const void* w1; const float* b1; const void* w2; const float* b2;
+  const float* g1; const float* be1; const float* g2; const float* be2; const float* g3; const float* be3;
+  void* out; void* t1;
+  void* tn; void* tnp; float* m1; float* r1; void* qk_s; void* v_s; void* ctx_s; float* lse_s;
+  void* t1np; float* m2; float* r2; void* q_c; void* ctx_c; float* lse_c;
+  void* t2; float* m3; float* r3; void* t2n; void* h;
+  int32_t B, Q, S, FF;
+  float drop_p;
+  uint32_t seed[6];
+  int32_t pad_;
+  const uint32_t* seed_ptr;
+} SedtDecLayer;
+int sedt_decoder_slab_ok(int D, int H, int Q, int S, int FF, int dtype);
+int sedt_decoder_layer_fwd(const SedtDecLayer* args, void* stream);
+
 int sedt_encoder_ffn_bwd(const void* gx2, const void* h, const void* x1, const float* mean2, const float* rstd2,
                          const float* gamma2, const void* w2t_frag, const void* w1t_frag, const void* wot_frag, void* g2, void* gh,
                          void* gx1, void* g1, void* gctx, float* ln_part, int B, int S, int FF, float drop_p, uint32_t seed_f,

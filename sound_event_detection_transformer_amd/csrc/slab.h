@@ -87,6 +87,31 @@ __device__ __forceinline__ void load_feat4(float4 (&dst)[4], const float* __rest
   for (int g4 = 0; g4 < 4; ++g4) dst[g4] = *reinterpret_cast<const float4*>(p + tile * 32 + 8 * g4 + 4 * hf);
 }
 
+// a SMALL GEMM: one output tile over 16 k-steps = two chunks, BOTH preloaded (cur = chunk 0, alt = chunk 1: load_chunk<1>(cur, W, 0, 0,
+// lane); load_chunk<1>(alt, W, 0, 8, lane)).  As soon as a chunk is multiplied its registers take a chunk of the FOLLOWING GEMM
+// (next0(cur) / next1(alt)): between two GEMMs of a chain of 256 x 256 projections (the decoder layer: LayerNorms, attention
+// cores, barriers in between) the whole next weight tile is in flight, so the GEMM itself costs its 16 MFMAs and no memory round trip.
+template <class Next0, class Next1>
+__device__ __forceinline__ void wave_gemm_small(f32x16 (&acc)[1], const bf16_t* xs, int xp, int lane, u32x4 (&cur)[8], u32x4 (&alt)[8],
+                                                Next0 next0, Next1 next1) {
+  const bf16_t* xrow = xs + (lane & 31) * xp + 8 * (lane >> 5);
+  bf16x8 xb[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) xb[u] = *reinterpret_cast<const bf16x8*>(xrow + u * 16);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[u]), xb[u], acc[0], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  next0(cur);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) xb[u] = *reinterpret_cast<const bf16x8*>(xrow + (8 + u) * 16);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, alt[u]), xb[u], acc[0], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  next1(alt);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int T>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[T]) {
 #pragma unroll

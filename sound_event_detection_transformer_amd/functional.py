@@ -425,7 +425,7 @@ class EncoderLayerFn(Function):
         sv = {}
         tr = any(ctx.needs_input_grad)
         fr = None
-        if cfg['pre_norm'] and ops.encoder_slab_ok(dt, x.shape[1], H, S, w1.shape[0], amask):
+        if cfg['pre_norm'] and ops.encoder_slab_ok(dt, x.shape[1], H, S, w1.shape[0], amask, B):
             fr = [packing.lookup_frag(w) for w in (w_in, w_o, w1, w2)]
             fr = fr if all(f is not None for f in fr) else None
         if fr is not None:
@@ -562,6 +562,35 @@ class DecoderLayerFn(Function):
         tgt, mem, mem_pos, qpos = _as(tgt, dt), _as(mem, dt), _as(mem_pos, dt), _as(qpos, dt)
         sv = {}
         tr = any(ctx.needs_input_grad)
+        fr = None
+        if cfg['pre_norm'] and ops.decoder_slab_ok(dt, tgt.shape[1], H, Q, S, w1.shape[0]) and qpos.shape == tgt.shape:
+            fr = [packing.lookup_frag(w) for w in (sw_in, sw_o, cw_in, cw_o, w1, w2)]
+            fr = fr if all(f is not None for f in fr) else None
+        if fr is not None:
+            # the whole layer in ONE launch, a workgroup per clip (csrc/dec_slab.hip); the K | V projection of the memory stays a GEMM
+            E = tgt.shape[1]
+            sp = runtime.seed_ptr(tgt.device) if p > 0 else None
+            cwf, cwb_in = _prep_linear(dt, cw_in, tr)
+            _, swb_in = _prep_linear(dt, sw_in, tr)
+            _, swb_o = _prep_linear(dt, sw_o, tr)
+            _, cwb_o = _prep_linear(dt, cw_o, tr)
+            _, wb1 = _prep_linear(dt, w1, tr)
+            _, wb2 = _prep_linear(dt, w2, tr)
+            k_c, v_c = ops.linear_group(dt, [(mem_pos, cwf[E:2 * E], dict(bias=cb_in[E:2 * E])), (mem, cwf[2 * E:], dict(bias=cb_in[2 * E:]))])
+            tmask = tgt_mask.contiguous() if tgt_mask is not None else None
+            t3, by = ops.decoder_layer_fwd(tgt.contiguous(), qpos.contiguous(), k_c, v_c, kpm, tmask, [f[0] for f in fr],
+                                           (sb_in, sb_o, cb_in, cb_o, b1, b2, g1, be1, g2, be2, g3, be3), B, Q, S, w1.shape[0], p, seeds, sp,
+                                           train=tr, out=cfg.get('out'))
+            if tr:
+                sv['sa'] = dict(wb_in=swb_in, wb_o=swb_o, q_in=by['tnp'], k_in=by['tnp'], v_in=by['tn'], same_qk=True, qk=by['qk_s'],
+                                q=by['qk_s'][:, :E], k=by['qk_s'][:, E:], v=by['v_s'], ctxv=by['ctx_s'], lse=by['lse_s'], dims=(B, H, Q, Q),
+                                kpm=None, amask=tmask, p=p, seeds=seeds[0:2])
+                sv['ca'] = dict(wb_in=cwb_in, wb_o=cwb_o, q_in=by['t1np'], k_in=mem_pos, v_in=mem, same_qk=False, qk=None, q=by['q_c'], k=k_c,
+                                v=v_c, ctxv=by['ctx_c'], lse=by['lse_c'], dims=(B, H, Q, S), kpm=kpm, amask=None, p=p, seeds=seeds[2:4])
+                sv['ffn'] = dict(x_in=by['t2n'], h=by['h'], p=p, seeds=seeds[4:6], wb1=wb1, wb2=wb2)
+                sv.update(tgt=tgt, t1=by['t1'], t2=by['t2'], m1=by['m1'], r1=by['r1'], m2=by['m2'], r2=by['r2'], m3=by['m3'], r3=by['r3'])
+            ctx.sv, ctx.cfg, ctx.P = sv, cfg, P
+            return t3
         if cfg['pre_norm'] and ops.FUSED_DEC_SA and ops.encoder_attn_ok(dt, tgt.shape[1], H, Q, tgt_mask) and tgt.is_contiguous() \
                 and qpos.is_contiguous() and qpos.shape == tgt.shape:
             # self-attention of the Q queries of a clip: LayerNorm1 + Q|K|V projections + attention core in ONE launch - the kernel

@@ -67,6 +67,17 @@ class SedtMatch(C.Structure):
                 ('ft_seed', C.c_uint32), ('seed_ptr', C.c_void_p), ('split', C.c_void_p), ('Qs', C.c_int32), ('q0', C.c_int32)]
 
 
+class SedtDecLayer(C.Structure):
+    _fields_ = [('tgt', C.c_void_p), ('qpos', C.c_void_p), ('kc', C.c_void_p), ('ldk', C.c_int64), ('vc', C.c_void_p), ('ldv', C.c_int64),
+                ('kpm', C.c_void_p), ('amask', C.c_void_p)] + \
+               [(n, C.c_void_p) for n in ('s_win', 's_bin', 's_wo', 's_bo', 'c_wq', 'c_bq', 'c_wo', 'c_bo', 'w1', 'b1', 'w2', 'b2',
+                                           'g1', 'be1', 'g2', 'be2', 'g3', 'be3', 'out', 't1',
+                                           'tn', 'tnp', 'm1', 'r1', 'qk_s', 'v_s', 'ctx_s', 'lse_s', 't1np', 'm2', 'r2', 'q_c', 'ctx_c', 'lse_c',
+                                           't2', 'm3', 'r3', 't2n', 'h')] + \
+               [('B', C.c_int32), ('Q', C.c_int32), ('S', C.c_int32), ('FF', C.c_int32), ('drop_p', C.c_float), ('seed', C.c_uint32 * 6),
+                ('pad_', C.c_int32), ('seed_ptr', C.c_void_p)]
+
+
 MAX_REDUCE_JOBS = 40
 _vp, _i, _i64, _f, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32, C.c_size_t
 
@@ -109,6 +120,8 @@ SIGNATURES = {
     'sedt_encoder_slab_ok': (_i, [_i, _i, _i, _i, _i]),
     'sedt_encoder_qkv_fwd': (_i, [_vp] * 12 + [_i, _i, _vp]),
     'sedt_encoder_attn_ffn_fwd': (_i, [_vp] * 20 + [_i, _i, _i, _f, _u32, _u32, _u32, _u32, _vp, _vp]),
+    'sedt_decoder_slab_ok': (_i, [_i, _i, _i, _i, _i, _i]),
+    'sedt_decoder_layer_fwd': (_i, [C.POINTER(SedtDecLayer), _vp]),
     'sedt_encoder_ffn_bwd': (_i, [_vp] * 15 + [_i, _i, _i, _f, _u32, _u32, _vp, _vp]),
     'sedt_encoder_qkv_bwd': (_i, [_vp] * 10 + [_i, _i, _vp]),
     'sedt_posenc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

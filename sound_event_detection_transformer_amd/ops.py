@@ -671,8 +671,12 @@ SLAB_ENC = _dev_env('SEDT_SLAB_ENC', '1') != '0'
 SLAB_ENC_BWD = _dev_env('SEDT_SLAB_ENC_BWD', '1') != '0'      # the input-gradient chain of those layers on the slab kernels as well
 
 
-def encoder_slab_ok(dtype, D, H, S, FF, amask):
-    return bool(SLAB_ENC and dtype == BF16 and amask is None and L.load().sedt_encoder_slab_ok(D, H, S, FF, dtype))
+SLAB_MIN_WGS = 192      # slabs (= workgroups) below which the per-op chain fills the chip better (B = 32: 128 slabs; same-box A/B on C3)
+
+
+def encoder_slab_ok(dtype, D, H, S, FF, amask, B=None):
+    return bool(SLAB_ENC and dtype == BF16 and amask is None and (B is None or B * ((S + 31) // 32) >= SLAB_MIN_WGS)
+                and L.load().sedt_encoder_slab_ok(D, H, S, FF, dtype))
 
 
 def encoder_qkv_fwd(x, pos, gamma, beta, w_in_frag, b_in, B, S, train=True):
@@ -713,6 +717,60 @@ def encoder_attn_ffn_fwd(x, qk, v, kpm, w_o_frag, b_o, gamma2, beta2, w1_frag, b
                                                seeds[2] & 0xffffffff, seeds[3] & 0xffffffff, _p(seed_ptr), L.stream_ptr()),
             'encoder_attn_ffn_fwd')
     return x2, by
+
+
+# One pre-norm decoder layer in ONE launch, a workgroup per clip (csrc/dec_slab.hip).  Default in the bf16 mode.
+# Measured level with the per-op chain, not ahead (B = 64, Q = 11: 59 us + 12 us for the K | V projection against 73 us; same-box A/B of
+# the C2 / C3 steps: +0.2 / +0.8 %): per clip the chain of phases is a chain of memory round trips whichever way it is launched, and
+# B = 16 takes as long as B = 64.  Correct and tested (tests/test_slab_gpu.py); opt-in: ops.SLAB_DEC = True.
+SLAB_DEC = _dev_env('SEDT_SLAB_DEC', '0') == '1'
+
+
+def decoder_slab_ok(dtype, D, H, Q, S, FF):
+    return bool(SLAB_DEC and dtype == BF16 and L.load().sedt_decoder_slab_ok(D, H, Q, S, FF, dtype))
+
+
+def decoder_layer_fwd(tgt, qpos, kc, vc, kpm, amask, frags, vecs, B, Q, S, FF, drop_p=0.0, seeds=(0,) * 6, seed_ptr=None, train=True, out=None):
+    """frags = fragment-major (self in_proj, self out_proj, cross in_proj, cross out_proj, linear1, linear2); vecs = (self in_proj bias,
+    self out bias, cross in_proj bias, cross out bias, b1, b2, g1, be1, g2, be2, g3, be3) f32.  kc / vc: the projected memory keys /
+    values [B*S, >= 256] (row-strided views).  Returns (out [B*Q, 256], by-products dict or None)"""
+    _dev_check(tgt, qpos, kc, vc)
+    M, D = tgt.shape
+    assert tgt.is_contiguous() and qpos.is_contiguous() and qpos.shape == tgt.shape and M == B * Q and tgt.dtype == torch.bfloat16
+    assert kc.stride(1) == 1 and vc.stride(1) == 1 and kc.shape[0] == B * S and vc.shape[0] == B * S
+    dev = tgt.device
+    bf = lambda *sh: torch.empty(sh, device=dev, dtype=torch.bfloat16)
+    f32 = lambda *sh: torch.empty(sh, device=dev, dtype=torch.float32)
+    if out is None:
+        out = bf(M, D)
+    assert out.is_contiguous() and out.shape == (M, D)
+    a = L.SedtDecLayer()
+    keep = [tgt, qpos, kc, vc, kpm, amask, out]
+    a.tgt, a.qpos, a.kc, a.ldk, a.vc, a.ldv = tgt.data_ptr(), qpos.data_ptr(), kc.data_ptr(), kc.stride(0), vc.data_ptr(), vc.stride(0)
+    a.kpm = kpm.data_ptr() if kpm is not None else None
+    if amask is not None:
+        assert amask.dtype == torch.float32 and amask.is_contiguous() and amask.shape == (Q, Q)
+        a.amask = amask.data_ptr()
+    a.s_win, a.s_wo, a.c_wq, a.c_wo, a.w1, a.w2 = (f.data_ptr() for f in frags)
+    (a.s_bin, a.s_bo, a.c_bq, a.c_bo, a.b1, a.b2, a.g1, a.be1, a.g2, a.be2, a.g3, a.be3) = (v.data_ptr() for v in vecs)
+    a.out = out.data_ptr()
+    by = None
+    t1 = bf(M, D)
+    a.t1 = t1.data_ptr()
+    if train:
+        by = dict(tn=bf(M, D), tnp=bf(M, D), m1=f32(M), r1=f32(M), qk_s=bf(M, 2 * D), v_s=bf(M, D), ctx_s=bf(M, D), lse_s=f32(B, 8, Q),
+                  t1np=bf(M, D), m2=f32(M), r2=f32(M), q_c=bf(M, D), ctx_c=bf(M, D), lse_c=f32(B, 8, Q), t2=bf(M, D), m3=f32(M), r3=f32(M),
+                  t2n=bf(M, D), h=bf(M, FF))
+        for k_, v_ in by.items():
+            setattr(a, k_, v_.data_ptr())
+        by['t1'] = t1
+    a.B, a.Q, a.S, a.FF, a.drop_p = B, Q, S, FF, drop_p
+    for i in range(6):
+        a.seed[i] = seeds[i] & 0xffffffff
+    a.seed_ptr = seed_ptr.data_ptr() if seed_ptr is not None else None
+    L.check(L.load().sedt_decoder_layer_fwd(C.byref(a), L.stream_ptr()), 'decoder_layer_fwd')
+    del keep
+    return out, by
 
 
 def encoder_ffn_bwd(gx2, h, x1, mean2, rstd2, gamma2, w2t_frag, w1t_frag, wot_frag, B, S, drop_p=0.0, seeds=(0, 0), seed_ptr=None):

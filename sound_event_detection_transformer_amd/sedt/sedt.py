@@ -109,6 +109,8 @@ class SEDT(nn.Module):
                 for l in self.transformer.decoder.layers:
                     lin += [l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.multihead_attn.in_proj_weight,
                             l.multihead_attn.out_proj.weight, l.linear1.weight, l.linear2.weight]
+                    frags += [l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.multihead_attn.in_proj_weight,
+                              l.multihead_attn.out_proj.weight, l.linear1.weight, l.linear2.weight]
                 lin += [self.class_embed.weight] + [m.weight for m in self.bbox_embed.layers]
                 for name in ('weak_class_embed', 'patch2query'):
                     if hasattr(self, name):

@@ -37,6 +37,15 @@ def test_pack_frag_layout():
             assert torch.equal(t, want_t)
 
 
+@pytest.fixture(autouse=True)
+def _small_batches_take_the_slab_path():
+    from sound_event_detection_transformer_amd import ops
+    keep = ops.SLAB_MIN_WGS
+    ops.SLAB_MIN_WGS = 1            # (the fill rule B * ceil(S / 32) >= 192 would send these small test batches down the per-op chain)
+    yield
+    ops.SLAB_MIN_WGS = keep
+
+
 def _layer_and_plan(seed):
     from sound_event_detection_transformer_amd import packing
     from sound_event_detection_transformer_amd.lib import BF16
@@ -157,4 +166,70 @@ def test_encoder_slab_backward_matches_per_op_backward():
             assert rel(res[True][1][n_], res[False][1][n_]) < 2e-2, n_
     finally:
         ops.SLAB_ENC_BWD = True
+        runtime.set_compute_dtype('f32')
+
+
+def _dec_layer_and_plan(seed):
+    from sound_event_detection_transformer_amd import packing
+    from sound_event_detection_transformer_amd.lib import BF16
+    from sound_event_detection_transformer_amd.sedt.transformer import TransformerDecoderLayer
+    torch.manual_seed(seed)
+    layer = TransformerDecoderLayer(256, 8, 2048, 0.1, 'relu', True).cuda().train()
+    with torch.no_grad():
+        for n_, p in layer.named_parameters():
+            if 'norm' in n_:
+                p.add_(0.1 * torch.randn_like(p))
+            elif p.dim() == 1:
+                p.normal_(0, 0.05)
+    a, c = layer.self_attn, layer.multihead_attn
+    lin = [a.in_proj_weight, a.out_proj.weight, c.in_proj_weight, c.out_proj.weight, layer.linear1.weight, layer.linear2.weight]
+    return layer, packing.PackPlan(BF16, torch.device('cuda'), [], lin, (), lin)
+
+
+@pytest.mark.parametrize('B,Q,S,pad,masked', [(4, 11, 128, 0, False), (3, 21, 124, 17, False), (2, 20, 124, 0, True), (5, 32, 40, 5, False)])
+@pytest.mark.parametrize('train', [True, False])
+def test_decoder_slab_layer_matches_per_op_chain(B, Q, S, pad, masked, train):
+    """one pre-norm decoder layer in ONE launch (csrc/dec_slab.hip) against the eleven launches it replaces: same dropout masks, same
+    rounding points; output, input gradients (tgt, memory, memory + pos, query positions) and all 18 parameter gradients"""
+    from sound_event_detection_transformer_amd import ops, runtime
+    runtime.set_compute_dtype('bf16')
+    try:
+        layer, plan = _dec_layer_and_plan(21)
+        if not train:
+            layer.eval()
+        g = torch.Generator().manual_seed(8)
+        rnd = lambda *sh, s=1.0: (s * torch.randn(*sh, generator=g)).cuda().bfloat16()
+        tgt0, qpos0, mem0, mp0 = rnd(B * Q, 256), rnd(B * Q, 256), rnd(B * S, 256), rnd(B * S, 256)
+        kpm = torch.zeros(B, S, dtype=torch.uint8)
+        if pad:
+            kpm[B - 1, S - pad:] = 1
+        kpm = kpm.cuda()
+        tmask = None
+        if masked:                                    # SP-SEDT's block-diagonal mask (spsedt.py:29-32): queries see their own patch group only
+            tmask = torch.full((Q, Q), float('-inf'))
+            for i in range(0, Q, 10):
+                tmask[i:i + 10, i:i + 10] = 0
+            tmask = tmask.cuda()
+        gy = rnd(B * Q, 256)
+        res = {}
+        for mode in ('slab', 'chain'):
+            ops.SLAB_DEC = mode == 'slab'
+            runtime.manual_seed(77)
+            ins = [t.clone().requires_grad_(train) for t in (tgt0, mem0, mp0, qpos0)]
+            for p in layer.parameters():
+                p.grad = None
+            with plan:
+                assert ops.decoder_slab_ok(1, 256, 8, Q, S, 2048) == (mode == 'slab')
+                y = layer.forward_tokens(ins[0], ins[1], ins[2], ins[3], kpm, B, S, Q, tmask)
+                if train:
+                    y.backward(gy)
+            res[mode] = (y.detach().clone(), [t.grad.clone() for t in ins] if train else [],
+                         {n_: p.grad.clone() for n_, p in layer.named_parameters()} if train else {})
+        assert rel(res['slab'][0], res['chain'][0]) < 2e-2
+        for a_, b_ in zip(res['slab'][1], res['chain'][1]):
+            assert rel(a_, b_) < 2e-2
+        for n_ in res['chain'][2]:
+            assert rel(res['slab'][2][n_], res['chain'][2][n_]) < 2e-2, n_
+    finally:
+        ops.SLAB_DEC = False
         runtime.set_compute_dtype('f32')
