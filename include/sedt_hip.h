@@ -42,6 +42,12 @@ extern "C" {
 
 #define SEDT_F32 0
 #define SEDT_BF16 1
+/* GEMM entry points only (sedt_igemm, sedt_igemm_group, sedt_wgrad_group, sedt_igemm_splitk): f32 tensors exactly as SEDT_F32, but
+ * every product computed from bf16 hi / lo splits of both operands - hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16, f32
+ * accumulation - instead of v_mfma_f32_32x32x2_f32: ~2^-16 relative error per product, about five times the matrix rate of the
+ * exact-f32 mode.  The "bf16x3" compute mode (runtime.set_compute_dtype('bf16x3')): f32 activations and gradients everywhere,
+ * this code for the contractions; meets the 1e-3 parity tolerance (tests/test_x3_gpu.py). */
+#define SEDT_BF16X3 2
 
 #define SEDT_ACT_NONE 0
 #define SEDT_ACT_RELU 1

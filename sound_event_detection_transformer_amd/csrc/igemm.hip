@@ -17,6 +17,11 @@
 //         v_mfma_f32_32x32x16_bf16, 8 k per lane fragment read as one ds_read_b128.
 //   f32 : BK=32, pitch 33 (odd: 32 rows x fixed k conflict-free for ds_read_b32),
 //         v_mfma_f32_32x32x2_f32 (exact f32 FMA chain - the parity mode).
+//   x3  : (T = float, X3) the "bf16x3" mode: f32 tensors in memory, every f32 operand element split ONCE - when its tile is
+//         staged - into hi = bf16(x) and lo = bf16(x - hi), kept as two bf16 LDS images ([row][32 k], pitch 40), and each
+//         k16 block of a product computed as hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_bf16 with f32 accumulation: the
+//         dropped lo.lo term and the rounding of lo bound the per-product error near 2^-16 relative (f32: 2^-24, plain bf16:
+//         2^-8), at 3 bf16 MFMAs per 16 k instead of 8 f32 MFMAs - north_star's 1e-3 tolerance at MFMA rate.
 // trans=1 sources have the reduction index as the slow axis; bf16 transposes 4(k)x8(r) blocks
 // in registers before the LDS write so the fragment reads stay ds_read_b128.
 #include <stdlib.h>
@@ -67,13 +72,28 @@ __device__ __forceinline__ uint4 load_chunk(const T* base, long off, int valid_e
   return r;
 }
 
-template <typename T, int BM, int BN, bool TRANS>
+constexpr int X3P = 40;      // bf16 element pitch of the hi / lo images of the x3 mode (80-byte rows: 16-byte fragment reads of 16 rows conflict-free)
+
+// hi / lo split of 4 consecutive f32 values -> 4 + 4 bf16
+__device__ __forceinline__ void split4(const float* s, VecT<bf16_t, 4>& hi, VecT<bf16_t, 4>& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hi.v[e] = (bf16_t)s[e];
+    lo.v[e] = (bf16_t)(s[e] - (float)hi.v[e]);
+  }
+}
+
+template <typename T, int BM, int BN, bool TRANS, bool X3 = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int vecA, const int vecB) {
+  static_assert(!X3 || sizeof(T) == 4, "the x3 mode splits f32 operands");
   constexpr int BK = Cfg<T>::BK, PITCH = Cfg<T>::PITCH, EPC = Cfg<T>::EPC, KSTEP = Cfg<T>::KSTEP;
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* sA = reinterpret_cast<T*>(smem_raw);  // [2][BM*PITCH]
   T* sB = sA + 2 * BM * PITCH;             // [2][BN*PITCH]
+  // x3: per buffer and operand a hi image and a lo image [rows][X3P] bf16
+  bf16_t* xA = reinterpret_cast<bf16_t*>(smem_raw);          // [2][2][BM * X3P]
+  bf16_t* xB = xA + 2 * 2 * BM * X3P;                        // [2][2][BN * X3P]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
@@ -221,6 +241,53 @@ __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int
   auto store_tiles = [&](int buf) {
     T* dA = sA + buf * BM * PITCH;
     T* dB = sB + buf * BN * PITCH;
+    if constexpr (X3) {
+      bf16_t* hA = xA + buf * 2 * BM * X3P;
+      bf16_t* lA = hA + BM * X3P;
+      bf16_t* hB = xB + buf * 2 * BN * X3P;
+      bf16_t* lB = hB + BN * X3P;
+      if constexpr (!TRANS) {
+#pragma unroll
+        for (int ps = 0; ps < APASS; ++ps) {
+          VecT<bf16_t, 4> hi, lo;
+          split4(reinterpret_cast<const float*>(&ra[ps]), hi, lo);
+          *reinterpret_cast<VecT<bf16_t, 4>*>(hA + (lrow + ps * RPP) * X3P + chunk * EPC) = hi;
+          *reinterpret_cast<VecT<bf16_t, 4>*>(lA + (lrow + ps * RPP) * X3P + chunk * EPC) = lo;
+        }
+#pragma unroll
+        for (int ps = 0; ps < BPASS; ++ps) {
+          VecT<bf16_t, 4> hi, lo;
+          split4(reinterpret_cast<const float*>(&rb[ps]), hi, lo);
+          *reinterpret_cast<VecT<bf16_t, 4>*>(hB + (lrow + ps * RPP) * X3P + chunk * EPC) = hi;
+          *reinterpret_cast<VecT<bf16_t, 4>*>(lB + (lrow + ps * RPP) * X3P + chunk * EPC) = lo;
+        }
+      } else {
+        // registers hold 1 k-row x 4 r: element (r, k) of the [r][k] images
+#pragma unroll
+        for (int ps = 0; ps < TAP; ++ps) {
+          const int u = t + ps * 256;
+          if (u < AU) {
+            const int ku = u / (BM / EPC), iu = u % (BM / EPC);
+            VecT<bf16_t, 4> hi, lo;
+            split4(reinterpret_cast<const float*>(&ra[ps]), hi, lo);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hA[(iu * 4 + e) * X3P + ku] = hi.v[e]; lA[(iu * 4 + e) * X3P + ku] = lo.v[e]; }
+          }
+        }
+#pragma unroll
+        for (int ps = 0; ps < TBP; ++ps) {
+          const int u = t + ps * 256;
+          if (u < BU) {
+            const int ku = u / (BN / EPC), ju = u % (BN / EPC);
+            VecT<bf16_t, 4> hi, lo;
+            split4(reinterpret_cast<const float*>(&rb[ps]), hi, lo);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { hB[(ju * 4 + e) * X3P + ku] = hi.v[e]; lB[(ju * 4 + e) * X3P + ku] = lo.v[e]; }
+          }
+        }
+      }
+      return;
+    }
     if constexpr (!TRANS) {
       if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -298,6 +365,36 @@ __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int
   };
 
   auto compute = [&](int buf) {
+    if constexpr (X3) {
+      const bf16_t* hA = xA + buf * 2 * BM * X3P + (wm + (lane & 31)) * X3P + 8 * (lane >> 5);
+      const bf16_t* lA = hA + BM * X3P;
+      const bf16_t* hB = xB + buf * 2 * BN * X3P + (wn + (lane & 31)) * X3P + 8 * (lane >> 5);
+      const bf16_t* lB = hB + BN * X3P;
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 16) {
+        bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          ah[i] = *reinterpret_cast<const bf16x8*>(hA + i * 32 * X3P + kk);
+          al[i] = *reinterpret_cast<const bf16x8*>(lA + i * 32 * X3P + kk);
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          bh[j] = *reinterpret_cast<const bf16x8*>(hB + j * 32 * X3P + kk);
+          bl[j] = *reinterpret_cast<const bf16x8*>(lB + j * 32 * X3P + kk);
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            // small terms first: their sum is formed before it meets the large one
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+      return;
+    }
     const T* cA = sA + buf * BM * PITCH + (wm + (lane & 31)) * PITCH;
     const T* cB = sB + buf * BN * PITCH + (wn + (lane & 31)) * PITCH;
     if constexpr (sizeof(T) == 2) {
@@ -431,12 +528,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int
 }
 
 // ---------------------------------------------------------------------------- host side
-template <typename T, int BM, int BN, bool TRANS>
+template <typename T, int BM, int BN, bool TRANS, bool X3 = false>
 static int launch_cfg(const SedtIgemm& p, int vecA, int vecB, hipStream_t st) {
-  SEDT_DESCRIBE("igemm_kernel<%s, %d, %d, %s>", sizeof(T) == 4 ? "float" : "__bf16", BM, BN, TRANS ? "true" : "false");
-  constexpr size_t lds = (size_t)(BM + BN) * Cfg<T>::PITCH * sizeof(T) * 2;
+  SEDT_DESCRIBE("igemm_kernel<%s, %d, %d, %s%s>", sizeof(T) == 4 ? "float" : "__bf16", BM, BN, TRANS ? "true" : "false", X3 ? ", true" : "");
+  constexpr size_t lds = X3 ? (size_t)(BM + BN) * X3P * sizeof(bf16_t) * 2 * 2 : (size_t)(BM + BN) * Cfg<T>::PITCH * sizeof(T) * 2;
   static bool attr_set = false;  // idempotent; a benign race sets it twice
-  auto kern = igemm_kernel<T, BM, BN, TRANS>;
+  auto kern = igemm_kernel<T, BM, BN, TRANS, X3>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -451,7 +548,7 @@ static int launch_cfg(const SedtIgemm& p, int vecA, int vecB, hipStream_t st) {
   return check_launch("igemm");
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 static int launch_typed(const SedtIgemm& p, hipStream_t st) {
   constexpr int EPC = Cfg<T>::EPC;
   const size_t es = sizeof(T);
@@ -472,12 +569,21 @@ static int launch_typed(const SedtIgemm& p, hipStream_t st) {
     // measured on MI355X (tools/tune_igemm.py, profiles/): this register-staged pipeline is latency-bound, so the
     // 64x64 tile (4 workgroups / CU resident) beats the larger tiles at every shape of the SEDT step
     bm = 64; bn = 64;
+    if (X3) {
+      // the split-bf16 products cost a third of the exact-f32 MFMA time: per K tile a 64x64 workgroup has 6 MFMAs per wave between
+      // two barriers.  Larger tiles (24 per wave for 128x128) wherever enough of them remain to cover the chip
+      static const int big = sedt::dev_getenv("SEDT_X3_BIG_MINTILES") ? atoi(sedt::dev_getenv("SEDT_X3_BIG_MINTILES")) : 192;
+      static const int mid = sedt::dev_getenv("SEDT_X3_MID_MINTILES") ? atoi(sedt::dev_getenv("SEDT_X3_MID_MINTILES")) : 192;
+      const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128), t12864 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
+      if (p.N >= 128 && t128 >= big) { bm = 128; bn = 128; }
+      else if (t12864 >= mid) { bm = 128; bn = 64; }
+    }
   }
   if (p.splitk > 1) SEDT_REQUIRE(p.slab != nullptr, "igemm: splitk > 1 needs a slab");
 #define SEDT_DISPATCH(BM_, BN_)                                                         \
   if (bm == BM_ && bn == BN_) {                                                         \
-    return p.trans ? launch_cfg<T, BM_, BN_, true>(p, vecA, vecB, st)                   \
-                   : launch_cfg<T, BM_, BN_, false>(p, vecA, vecB, st);                 \
+    return p.trans ? launch_cfg<T, BM_, BN_, true, X3>(p, vecA, vecB, st)               \
+                   : launch_cfg<T, BM_, BN_, false, X3>(p, vecA, vecB, st);             \
   }
   SEDT_DISPATCH(128, 128)
   SEDT_DISPATCH(128, 64)
@@ -509,6 +615,10 @@ extern "C" int sedt_igemm(const SedtIgemm* args, int dtype, void* stream) {
   if (dtype == SEDT_F32) {
     SEDT_REQUIRE(args->colsum_out == nullptr, "igemm: colsum_out is a bf16-only feature");
     return launch_typed<float>(*args, st);
+  }
+  if (dtype == SEDT_BF16X3) {           // f32 tensors, split-bf16 products (see the header of this file)
+    SEDT_REQUIRE(args->colsum_out == nullptr, "igemm: colsum_out is a bf16-only feature");
+    return launch_typed<float, true>(*args, st);
   }
   if (dtype == SEDT_BF16) {
     if (use_lds_family()) {               // LDS-DMA kernels (igemm3 / wgrad3 / wgrad4) when the problem fits their envelope

@@ -12,6 +12,13 @@ if os.environ.get('SEDT_LIB_AB') and os.environ.get('SEDT_DEV') == '1':   # deve
     LIB_PATH = os.environ['SEDT_LIB_AB']
 
 F32, BF16 = 0, 1
+BF16X3 = 2            # GEMM entry points only: f32 tensors, split-bf16 products (include/sedt_hip.h)
+GEMM_X3 = False       # runtime.set_compute_dtype('bf16x3'): the f32 mode's contractions go through the BF16X3 code
+
+
+def gemm_dtype(dtype):
+    """the dtype code a GEMM entry point gets for tensors of compute dtype `dtype`"""
+    return BF16X3 if (dtype == F32 and GEMM_X3) else dtype
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
 

@@ -134,7 +134,7 @@ class WgradPool(object):
         while self.gemms:
             chunk, self.gemms = self.gemms[:10], self.gemms[10:]
             arr = (L.SedtIgemm * len(chunk))(*[a for a, _ in chunk])
-            L.check(lib.sedt_wgrad_group(arr, len(chunk), self.dtype, L.stream_ptr()), 'wgrad_group')
+            L.check(lib.sedt_wgrad_group(arr, len(chunk), L.gemm_dtype(self.dtype), L.stream_ptr()), 'wgrad_group')
         while self.reduces:
             chunk, self.reduces = self.reduces[:L.MAX_REDUCE_JOBS], self.reduces[L.MAX_REDUCE_JOBS:]
             arr = (L.SedtReduceJob * len(chunk))(*chunk)
@@ -172,13 +172,13 @@ def igemm(dtype, M, N, K, A, lda, B, ldb, Cout, ldc, **kw):
         riders = POOL.take(((M + 63) // 64) * ((N + 63) // 64))
         arr = (L.SedtIgemm * len(riders))(*[r[0] for r in riders])
         taken = C.c_int(0)
-        L.check(L.load().sedt_igemm_co(C.byref(a), arr, len(riders), dtype, L.stream_ptr(), C.byref(taken)), 'sedt_igemm_co')
+        L.check(L.load().sedt_igemm_co(C.byref(a), arr, len(riders), L.gemm_dtype(dtype), L.stream_ptr(), C.byref(taken)), 'sedt_igemm_co')
         if not taken.value:
             POOL.give_back(riders)
         return
     if PROFILE is not None:     # the operand tensors are kept alive so that the launch can be replayed for timing
-        PROFILE.append((a, dtype, (M, N, K, trans, 0 if conv is None else 1), (A, B, Cout, kw), PROFILE_HINT))
-    L.check(L.load().sedt_igemm(C.byref(a), dtype, L.stream_ptr()), 'sedt_igemm')
+        PROFILE.append((a, L.gemm_dtype(dtype), (M, N, K, trans, 0 if conv is None else 1), (A, B, Cout, kw), PROFILE_HINT))
+    L.check(L.load().sedt_igemm(C.byref(a), L.gemm_dtype(dtype), L.stream_ptr()), 'sedt_igemm')
 
 
 def _geom_tuple(g, transposed=False):
@@ -268,7 +268,7 @@ def linear_group(dtype, items):
         PROFILE_HINT = None
         return outs
     arr = (L.SedtIgemm * len(args))(*[igemm_args(*a, **kw) for a, kw in args])
-    L.check(L.load().sedt_igemm_group(arr, len(args), dtype, L.stream_ptr()), 'igemm_group')
+    L.check(L.load().sedt_igemm_group(arr, len(args), L.gemm_dtype(dtype), L.stream_ptr()), 'igemm_group')
     return outs
 
 
@@ -346,11 +346,11 @@ class ReduceBatch(object):
         lib = L.load()
         if PROFILE is not None:                       # bench.py replays every GEMM on its own for the per-launch timing
             for a, shape in self.group:
-                L.check(lib.sedt_igemm(C.byref(a), self.group_dtype, L.stream_ptr()), 'sedt_igemm')
-                PROFILE.append((a, self.group_dtype, shape, (list(self.keep), list(self.operands)), 'wgrad_group'))
+                L.check(lib.sedt_igemm(C.byref(a), L.gemm_dtype(self.group_dtype), L.stream_ptr()), 'sedt_igemm')
+                PROFILE.append((a, L.gemm_dtype(self.group_dtype), shape, (list(self.keep), list(self.operands)), 'wgrad_group'))
         else:
             arr = (L.SedtIgemm * len(self.group))(*[a for a, _ in self.group])
-            L.check(lib.sedt_wgrad_group(arr, len(self.group), self.group_dtype, L.stream_ptr()), 'wgrad_group')
+            L.check(lib.sedt_wgrad_group(arr, len(self.group), L.gemm_dtype(self.group_dtype), L.stream_ptr()), 'wgrad_group')
         self.group = []
 
     def defer(self, body, operands):

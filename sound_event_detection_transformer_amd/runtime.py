@@ -8,8 +8,20 @@ _seed_tensors = {}
 
 
 def set_compute_dtype(name):
-    """'f32' = parity mode (exact-f32 MFMA), 'bf16' = throughput mode (bf16 MFMA, f32 accumulate)."""
+    """'f32' = parity mode (exact-f32 MFMA), 'bf16' = throughput mode (bf16 MFMA, f32 accumulate), 'bf16x3' = parity-grade fast mode:
+    f32 tensors everywhere as in 'f32', every contraction from bf16 hi / lo splits of its operands (three bf16 MFMAs per product
+    block, f32 accumulate: ~2^-16 per product) - meets the 1e-3 tolerance at several times the exact-f32 rate."""
+    from . import lib
+    lib.GEMM_X3 = name in ('bf16x3', 'x3')
+    if lib.GEMM_X3:
+        name = 'f32'
     _state['dtype'] = {'f32': F32, 'fp32': F32, 'float32': F32, 'bf16': BF16, 'bfloat16': BF16, F32: F32, BF16: BF16}[name]
+
+
+def compute_mode():
+    """'f32' | 'bf16x3' | 'bf16'"""
+    from . import lib
+    return 'bf16' if _state['dtype'] == BF16 else ('bf16x3' if lib.GEMM_X3 else 'f32')
 
 
 def compute_dtype():
