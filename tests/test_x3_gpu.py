@@ -62,6 +62,7 @@ GRADIENT_ELEMENT_CHECKS = [
     'tests/test_mixup_steps_gpu.py::test_g15_mean_teacher_step_with_mixup_f32',
     'tests/test_mixup_steps_gpu.py::test_g15_supervised_step_with_mixup_f32',
     'tests/test_gradient_parity_gpu.py::test_every_gradient_tensor_matches_the_oracle_f32',
+    'tests/test_gradient_parity_gpu.py::test_every_gradient_tensor_matches_the_oracle_spsedt_f32',
 ]
 
 
