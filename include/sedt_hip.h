@@ -392,6 +392,23 @@ typedef struct SedtDecLayer {
 int sedt_decoder_slab_ok(int D, int H, int Q, int S, int FF, int dtype);
 int sedt_decoder_layer_fwd(const SedtDecLayer* args, void* stream);
 
+/* The prediction heads on the stacked decoder output hs [L*B*Qp][256] bf16 (sedt/sedt.py:88-95, 398-409) in ONE launch each way
+ * (csrc/heads_slab.hip; a workgroup per 32 rows): class logits cls [rows][C1] = hs wc^T + bc, boxes [rows][2] = sigmoid(W3 relu(W2
+ * relu(W1 hs + b1) + b2) + b3), audio tags at [B][CA] = sigmoid(wa hs + ba) on query 0 of the last layer (CA = 0: no such head).
+ * wc, w3, wa: the f32 master weights; W1, W2 fragment-major (sedt_pack_frag).  h1 / h2 [rows][256] bf16: the hidden activations, kept
+ * for the backward (both or none).  sedt_heads_bwd: from the gradients of the three outputs (g_at may be null) the input gradient dhs,
+ * the hidden-layer gradients g_h1 / g_h2 (left operands of the W1 / W2 weight-gradient GEMMs) and part [slabs][NG * 257], NG = C1 +
+ * CA + 2: per 32-row slab the [NG][256] weight-gradient sums of the head outputs (class rows, then audio-tag rows, then the 2 box
+ * rows) followed by their NG bias sums; the sums over the slabs are the gradients of wc | wa | w3 and bc | ba | b3.  Envelope: bf16, d = 256, C1, CA <= 16. */
+int sedt_heads_slab_ok(int D, int C1, int CA, int dtype);
+int sedt_heads_fwd(const void* x, const float* wc, const float* bc, const void* w1_frag, const float* b1, const void* w2_frag,
+                   const float* b2, const float* w3, const float* b3, const float* wa, const float* ba, float* cls, float* box, float* at,
+                   void* h1, void* h2, int L, int B, int Qp, int C1, int CA, void* stream);
+size_t sedt_heads_bwd_part_floats(int L, int B, int Qp, int C1, int CA);
+int sedt_heads_bwd(const void* x, const void* h1, const void* h2, const float* box, const float* at, const float* g_cls,
+                   const float* g_box, const float* g_at, const float* wc, const float* w3, const float* wa, const void* w2t_frag,
+                   const void* w1t_frag, void* dhs, void* g_h1, void* g_h2, float* part, int L, int B, int Qp, int C1, int CA, void* stream);
+
 int sedt_encoder_ffn_bwd(const void* gx2, const void* h, const void* x1, const float* mean2, const float* rstd2,
                          const float* gamma2, const void* w2t_frag, const void* w1t_frag, const void* wot_frag, void* g2, void* gh,
                          void* gx1, void* g1, void* gctx, float* ln_part, int B, int S, int FF, float drop_p, uint32_t seed_f,

@@ -126,6 +126,18 @@ class HeadsFn(Function):
         Lh, B, Qp, d = hs.shape
         x = _as(hs, dt).view(Lh * B * Qp, d)
         tr = any(ctx.needs_input_grad)
+        ctx.slab = None
+        if ops.heads_slab_ok(dt, d, wc.shape[0], 0 if wa is None else wa.shape[0]) and wc.is_contiguous() and w3.is_contiguous():
+            fr = [packing.lookup_frag(w) for w in (w1, w2)]
+            if all(f is not None for f in fr):
+                # all heads in ONE launch (csrc/heads_slab.hip)
+                cls, box, at, hh = ops.heads_fwd(x, wc, bc, fr[0][0], b1, fr[1][0], b2, w3, b3, wa, ba, Lh, B, Qp, train=tr)
+                ctx.dt, ctx.dims, ctx.has_at = dt, (Lh, B, Qp, d), wa is not None
+                if tr:
+                    ctx.slab = (fr[0][1], fr[1][1])
+                    ctx.save_for_backward(x, hh[0], hh[1], box, at, wc, w3, wa)
+                cls, box = cls.view(Lh, B, Qp, -1), box.view(Lh, B, Qp, 2)
+                return (cls, box, at) if at is not None else (cls, box)
         cls = ops.skinny_linear_fwd(dt, x, wc, bc, ACT_NONE, True)
         w1f, w1b = _prep_linear(dt, w1, tr)
         w2f, w2b = _prep_linear(dt, w2, tr)
@@ -147,8 +159,30 @@ class HeadsFn(Function):
         x, h1, h2, box, at, wc, w3, wa = ctx.saved_tensors
         dt = ctx.dt
         Lh, B, Qp, d = ctx.dims
-        w1b, w2b = ctx.wb
         M = Lh * B * Qp
+        if ctx.slab is not None:
+            f32c = lambda t: None if t is None else (t.contiguous() if t.dtype == torch.float32 else t.contiguous().float())
+            C1, CA = wc.shape[0], 0 if wa is None else wa.shape[0]
+            w1t, w2t = ctx.slab
+            dhs, g_h1, g_h2, part = ops.heads_bwd(x, h1, h2, box.view(M, 2), at, f32c(g_cls).view(M, -1), f32c(g_box).view(M, 2),
+                                                  f32c(g_at) if ctx.has_at else None, wc, w3, wa, w2t, w1t, Lh, B, Qp)
+            rb = ops.ReduceBatch()
+            d_b2 = torch.empty((d,), device=x.device, dtype=torch.float32)
+            d_w2 = ops.linear_wgrad(dt, g_h2, h1, bias_out=d_b2, batch=rb)
+            d_b1 = torch.empty((d,), device=x.device, dtype=torch.float32)
+            d_w1 = ops.linear_wgrad(dt, g_h1, x, bias_out=d_b1, batch=rb)
+            NG = C1 + CA + 2
+            tot = torch.empty((NG * 257,), device=x.device, dtype=torch.float32)
+            rb.add_colsum(part, part.shape[0], NG * 257, tot)
+            rb.flush()
+            tw, tb = tot[:NG * 256].view(NG, 256), tot[NG * 256:]
+            d_wc, d_bc = tw[:C1], tb[:C1]
+            d_w3, d_b3 = tw[C1 + CA:], tb[C1 + CA:]
+            d_wa = d_ba = None
+            if ctx.has_at:
+                d_wa, d_ba = tw[C1:C1 + CA], tb[C1:C1 + CA]
+            return (dhs.view(Lh, B, Qp, d), d_wc, d_bc, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_wa, d_ba, None)
+        w1b, w2b = ctx.wb
         f32 = lambda t: t.contiguous() if t.dtype == torch.float32 else t.contiguous().float()
         rb = ops.ReduceBatch()
         # class head: writes the running input gradient

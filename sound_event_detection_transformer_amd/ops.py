@@ -719,6 +719,44 @@ def encoder_attn_ffn_fwd(x, qk, v, kpm, w_o_frag, b_o, gamma2, beta2, w1_frag, b
     return x2, by
 
 
+# The prediction heads in ONE launch each way (csrc/heads_slab.hip).  Default in the bf16 mode.
+SLAB_HEADS = _dev_env('SEDT_SLAB_HEADS', '1') != '0'
+
+
+def heads_slab_ok(dtype, D, C1, CA):
+    return bool(SLAB_HEADS and dtype == BF16 and L.load().sedt_heads_slab_ok(D, C1, CA, dtype))
+
+
+def heads_fwd(x, wc, bc, w1f, b1, w2f, b2, w3, b3, wa, ba, Lh, B, Qp, train=True):
+    """x [Lh*B*Qp, 256] bf16 contiguous; wc / w3 / wa f32 masters; w1f / w2f fragment-major.  Returns (cls [rows, C1], box [rows, 2], at
+    [B, CA] or None, (h1, h2) or None)"""
+    _dev_check(x, wc, w3)
+    rows, D = x.shape
+    assert x.is_contiguous() and rows == Lh * B * Qp and wc.is_contiguous() and w3.is_contiguous() and (wa is None or wa.is_contiguous())
+    C1, CA = wc.shape[0], 0 if wa is None else wa.shape[0]
+    f32 = dict(device=x.device, dtype=torch.float32)
+    cls, box = torch.empty((rows, C1), **f32), torch.empty((rows, 2), **f32)
+    at = torch.empty((B, CA), **f32) if CA else None
+    hh = (torch.empty_like(x), torch.empty_like(x)) if train else None
+    L.check(L.load().sedt_heads_fwd(_p(x), _p(wc), _p(bc), _p(w1f), _p(b1), _p(w2f), _p(b2), _p(w3), _p(b3), _p(wa), _p(ba), _p(cls), _p(box),
+                                    _p(at), _p(hh[0]) if hh else None, _p(hh[1]) if hh else None, Lh, B, Qp, C1, CA, L.stream_ptr()), 'heads_fwd')
+    return cls, box, at, hh
+
+
+def heads_bwd(x, h1, h2, box, at, g_cls, g_box, g_at, wc, w3, wa, w2t, w1t, Lh, B, Qp):
+    """returns (dhs, g_h1, g_h2, part [slabs, (C1 + CA + 2) * 257])"""
+    rows, D = x.shape
+    C1, CA = wc.shape[0], 0 if wa is None else wa.shape[0]
+    dhs, g_h1, g_h2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    nsl = (rows + 31) // 32
+    part = torch.empty((nsl, (C1 + CA + 2) * 257), device=x.device, dtype=torch.float32)
+    for g in (g_cls, g_box, g_at):
+        assert g is None or (g.dtype == torch.float32 and g.is_contiguous())
+    L.check(L.load().sedt_heads_bwd(_p(x), _p(h1), _p(h2), _p(box), _p(at), _p(g_cls), _p(g_box), _p(g_at), _p(wc), _p(w3), _p(wa), _p(w2t),
+                                    _p(w1t), _p(dhs), _p(g_h1), _p(g_h2), _p(part), Lh, B, Qp, C1, CA, L.stream_ptr()), 'heads_bwd')
+    return dhs, g_h1, g_h2, part
+
+
 # One pre-norm decoder layer in ONE launch, a workgroup per clip (csrc/dec_slab.hip).  Default in the bf16 mode.
 # Measured level with the per-op chain, not ahead (B = 64, Q = 11: 59 us + 12 us for the K | V projection against 73 us; same-box A/B of
 # the C2 / C3 steps: +0.2 / +0.8 %): per clip the chain of phases is a chain of memory round trips whichever way it is launched, and

@@ -112,6 +112,7 @@ class SEDT(nn.Module):
                     frags += [l.self_attn.in_proj_weight, l.self_attn.out_proj.weight, l.multihead_attn.in_proj_weight,
                               l.multihead_attn.out_proj.weight, l.linear1.weight, l.linear2.weight]
                 lin += [self.class_embed.weight] + [m.weight for m in self.bbox_embed.layers]
+                frags += [m.weight for m in self.bbox_embed.layers[:2]]
                 for name in ('weak_class_embed', 'patch2query'):
                     if hasattr(self, name):
                         lin.append(getattr(self, name).weight)

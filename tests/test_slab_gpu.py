@@ -233,3 +233,45 @@ def test_decoder_slab_layer_matches_per_op_chain(B, Q, S, pad, masked, train):
     finally:
         ops.SLAB_DEC = False
         runtime.set_compute_dtype('f32')
+
+
+@pytest.mark.parametrize('L_,B,Qp,dec_at', [(3, 4, 11, True), (3, 2, 21, True), (3, 5, 20, False), (1, 3, 11, True)])
+@pytest.mark.parametrize('train', [True, False])
+def test_heads_slab_kernels_match_per_op_heads(L_, B, Qp, dec_at, train):
+    """functional.HeadsFn on csrc/heads_slab.hip (one launch each way) against its per-op form (3 skinny kernels + 2 GEMMs forward, 10
+    launches backward): outputs, the input gradient and all head parameter gradients"""
+    from sound_event_detection_transformer_amd import ops, runtime, packing, functional as Fn
+    from sound_event_detection_transformer_amd.lib import BF16
+    runtime.set_compute_dtype('bf16')
+    try:
+        g = torch.Generator().manual_seed(31)
+        P = lambda *sh, s=0.06: torch.nn.Parameter((s * torch.randn(*sh, generator=g)).cuda())
+        wc, bc = P(11, 256), P(11)
+        w1, b1, w2, b2, w3, b3 = P(256, 256), P(256), P(256, 256), P(256), P(2, 256), P(2)
+        wa, ba = (P(10, 256), P(10)) if dec_at else (None, None)
+        params = [p for p in (wc, bc, w1, b1, w2, b2, w3, b3, wa, ba) if p is not None]
+        plan = packing.PackPlan(BF16, torch.device('cuda'), [], [w1, w2], (), [w1, w2])
+        hs0 = torch.randn(L_, B, Qp, 256, generator=g).cuda().bfloat16()
+        gc, gb = torch.randn(L_, B, Qp, 11, generator=g).cuda(), torch.randn(L_, B, Qp, 2, generator=g).cuda()
+        ga = torch.randn(B, 10, generator=g).cuda()
+        res = {}
+        for mode in (True, False):
+            ops.SLAB_HEADS = mode
+            hs = hs0.clone().requires_grad_(train)
+            for p in params:
+                p.grad = None
+            with plan:
+                out = Fn.HeadsFn.apply(hs, wc, bc, w1, b1, w2, b2, w3, b3, wa, ba, BF16)
+                if train:
+                    loss = (out[0] * gc).sum() + (out[1] * gb).sum() + ((out[2] * ga).sum() if dec_at else 0)
+                    loss.backward()
+            res[mode] = ([o.detach().clone() for o in out], hs.grad.clone() if train else None, [p.grad.clone() for p in params] if train else [])
+        for a_, b_ in zip(res[True][0], res[False][0]):
+            assert rel(a_, b_) < 5e-3
+        if train:
+            assert rel(res[True][1], res[False][1]) < 2e-2
+            for a_, b_ in zip(res[True][2], res[False][2]):
+                assert a_.is_contiguous() and rel(a_, b_) < 2e-2
+    finally:
+        ops.SLAB_HEADS = True
+        runtime.set_compute_dtype('f32')
