@@ -413,6 +413,28 @@ int sedt_encoder_ffn_bwd(const void* gx2, const void* h, const void* x1, const f
                          const float* gamma2, const void* w2t_frag, const void* w1t_frag, const void* wot_frag, void* g2, void* gh,
                          void* gx1, void* g1, void* gctx, float* ln_part, int B, int S, int FF, float drop_p, uint32_t seed_f,
                          uint32_t seed_o, const uint32_t* seed_ptr, void* stream);
+/* The FFN pair tiled in two dimensions (csrc/ffn_split.hip): a workgroup = 128 rows x a quarter of the hidden features; the four
+ * workgroups of a row block leave f32 partial sums in `part` (sedt_ffn_split_part_floats(M) floats) and the last to arrive - ticket
+ * counters cnt[sedt_ffn_split_blocks(M)], uint32, ZERO before the first launch, re-armed by the kernel - adds them in a fixed order.
+ *   sedt_ffn_split_fwd: x2 = x1 + drop(drop(relu(x1n W1^T + b1)) W2^T + b2); h [M][FF] written when non-null (training)
+ *   sedt_ffn_split_bwd: g2 = dropout'(gx2) (written when drop_p > 0); gh = (g2 W2) [h > 0] / (1 - p); g_x1n = gh W1
+ * with sedt_encoder_attn_fwd2 (the encoder kernel stopped after LayerNorm2; x1, x1n always written) in front of the forward and
+ * sedt_encoder_ln2_bwd (gx1 = LayerNorm2'(g_x1n) + gx2; g1 = dropout'(gx1); gctx = g1 Wo) behind the backward.  Weights fragment-
+ * major (W for the forward, W^T for the backward).  Envelope (sedt_ffn_split_ok): bf16, d = 256, FF a multiple of 1024. */
+int sedt_ffn_split_ok(int D, int FF, int dtype);
+size_t sedt_ffn_split_part_floats(int M);
+int sedt_ffn_split_blocks(int M);
+int sedt_ffn_split_fwd(const void* x1n, const void* x1, const void* w1_frag, const float* b1, const void* w2_frag, const float* b2, void* h,
+                       void* x2, float* part, uint32_t* cnt, int M, int FF, float drop_p, uint32_t seed_h, uint32_t seed_f,
+                       const uint32_t* seed_ptr, void* stream);
+int sedt_ffn_split_bwd(const void* gx2, const void* h, const void* w2t_frag, const void* w1t_frag, void* g2, void* gh, void* g_x1n,
+                       float* part, uint32_t* cnt, int M, int FF, float drop_p, uint32_t seed_f, const uint32_t* seed_ptr, void* stream);
+int sedt_encoder_attn_fwd2(const void* x, const void* qk, const void* v, const uint8_t* kpm, const void* w_o_frag, const float* b_o,
+                           const float* gamma2, const float* beta2, void* x1, void* x1n, void* ctx, float* lse, float* mean2, float* rstd2,
+                           int B, int S, float drop_p, uint32_t seed_attn, uint32_t seed_o, const uint32_t* seed_ptr, void* stream);
+int sedt_encoder_ln2_bwd(const void* gx1n, const void* gx2, const void* x1, const float* mean2, const float* rstd2, const float* gamma2,
+                         const void* wot_frag, void* gx1, void* g1, void* gctx, float* ln_part, int B, int S, float drop_p, uint32_t seed_o,
+                         const uint32_t* seed_ptr, void* stream);
 int sedt_encoder_qkv_bwd(const void* dqk, const void* dv, const void* x, const float* mean1, const float* rstd1,
                          const float* gamma1, const void* gx1, const void* wint_frag, void* gx, float* ln_part, int B, int S,
                          void* stream);

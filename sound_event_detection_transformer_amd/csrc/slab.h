@@ -112,6 +112,64 @@ __device__ __forceinline__ void wave_gemm_small(f32x16 (&acc)[1], const bf16_t* 
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// ONE output-feature tile x FOUR row slabs (a 128-row block in LDS, rows s * 32 + (lane & 31) of slab s) over NKS k-steps: every
+// weight fragment feeds four MFMAs, so a 128-row workgroup moves a quarter of the weight bytes per row of the 32-row scheme.  Chunks
+// of 8 k-steps alternate between `cur` and `alt` as in wave_gemm; `next(cur)` issues the first chunk of the following GEMM.
+template <int NKS, class Next>
+__device__ __forceinline__ void wave_gemm_r4(f32x16 (&acc)[4], const bf16_t* xs, int xp, const u32x4* __restrict__ W, int lane,
+                                             u32x4 (&cur)[8], u32x4 (&alt)[8], Next next) {
+  constexpr int NCH = NKS / 8;
+  static_assert(NKS % 8 == 0 && NCH % 2 == 0, "an even number of chunks");
+  const bf16_t* xrow = xs + (lane & 31) * xp + 8 * (lane >> 5);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    u32x4(&src)[8] = (c & 1) ? alt : cur;
+    u32x4(&dst)[8] = (c & 1) ? cur : alt;
+    if (c + 1 < NCH) load_chunk<1>(dst, W, 0, (c + 1) * 8, lane);
+    else next(dst);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      bf16x8 xb[4];
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) xb[sl] = *reinterpret_cast<const bf16x8*>(xrow + sl * 32 * xp + (c * 8 + u) * 16);
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl)
+        acc[sl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, src[u]), xb[sl], acc[sl], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// 16 bytes stored WRITE-THROUGH (sc1): the line leaves this XCD's L2 at once, so publishing it needs no release fence (a
+// release = buffer_wbl2 writes back EVERYTHING dirty in the XCD's L2 - with 32 workgroups per XCD each leaving 128-256 KB of fresh
+// partial sums and activations that made the first version of the split FFN take 58 us instead of 14)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+__device__ __forceinline__ void store_sc1(float* p, f32x4_t v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
+// In-launch reduction over the workgroups that share an output block (the split-K seam of cdna_hip_programming.md section 5 /
+// Guideline 16, counter form with write-through payload stores): call after the workgroup's partial result has been stored with
+// store_sc1.  Returns true in the workgroup that arrived LAST (all `nparts` partials are then visible to it: one agent-scope
+// acquire drops its CU's stale L1 lines); that workgroup also re-arms the counter.  `flag` = one LDS word.  The counter must be
+// zero before the first launch that uses it.
+__device__ __forceinline__ bool arrive_last(unsigned* cnt, unsigned nparts, unsigned* flag, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave drains its (write-through) stores
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = ticket == nparts - 1;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
+    }
+    *flag = last ? 1u : 0u;
+  }
+  __syncthreads();
+  return *flag != 0u;
+}
+
 template <int T>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[T]) {
 #pragma unroll

@@ -472,8 +472,15 @@ class EncoderLayerFn(Function):
             _, wb1 = _prep_linear(dt, w1, tr)
             _, wb2 = _prep_linear(dt, w2, tr)
             qk, v, by1 = ops.encoder_qkv_fwd(x, pos, g1, be1, fr[0][0], b_in, B, S, train=tr)
-            x2, by2 = ops.encoder_attn_ffn_fwd(x, qk, v, kpm, fr[1][0], b_o, g2, be2, fr[2][0], b1, fr[3][0], b2, B, S, w1.shape[0],
-                                               p, seeds, sp, train=tr)
+            split = ops.ffn_split_ok(dt, x.shape[1], w1.shape[0])
+            if split:
+                # attention | out-proj | LayerNorm2 per 32-token slab, then the FFN pair tiled 128 rows x a quarter of the hidden features
+                x1_, x1n_, bya = ops.encoder_attn_fwd2(x, qk, v, kpm, fr[1][0], b_o, g2, be2, B, S, p, seeds[0:2], sp, train=tr)
+                x2, h_ = ops.ffn_split_fwd(x1n_, x1_, fr[2][0], b1, fr[3][0], b2, w1.shape[0], p, seeds[2:4], sp, train=tr)
+                by2 = (bya[0], bya[1], x1_, bya[2], bya[3], x1n_, h_) if tr else None
+            else:
+                x2, by2 = ops.encoder_attn_ffn_fwd(x, qk, v, kpm, fr[1][0], b_o, g2, be2, fr[2][0], b1, fr[3][0], b2, B, S, w1.shape[0],
+                                                   p, seeds, sp, train=tr)
             if tr:
                 xn, xnp, m1, r1 = by1
                 ctxv, lse, x1, m2, r2, x1n, h = by2
@@ -533,8 +540,13 @@ class EncoderLayerFn(Function):
             dev = gx2.device
             sp = runtime.seed_ptr(dev) if p > 0 else None
             E = gx2.shape[1]
-            g2d, gh, gx1, g1d, gctx, part2 = ops.encoder_ffn_bwd(gx2.contiguous(), ff['h'], sv['x1'], sv['m2'], sv['r2'], g2, w2t, w1t, wot,
-                                                                 B, S, p, (ff['seeds'][1], mh['seeds'][1]), sp)
+            if ops.ffn_split_ok(dt, E, ff['h'].shape[1]):
+                g2d, gh, gx1n = ops.ffn_split_bwd(gx2.contiguous(), ff['h'], w2t, w1t, p, ff['seeds'][1], sp)
+                gx1, g1d, gctx, part2 = ops.encoder_ln2_bwd(gx1n, gx2.contiguous(), sv['x1'], sv['m2'], sv['r2'], g2, wot, B, S, p,
+                                                            mh['seeds'][1], sp)
+            else:
+                g2d, gh, gx1, g1d, gctx, part2 = ops.encoder_ffn_bwd(gx2.contiguous(), ff['h'], sv['x1'], sv['m2'], sv['r2'], g2, w2t, w1t, wot,
+                                                                     B, S, p, (ff['seeds'][1], mh['seeds'][1]), sp)
             d_b2 = torch.empty((E,), device=dev, dtype=torch.float32)
             d_w2 = ops.linear_wgrad(dt, g2d, ff['h'], bias_out=d_b2, batch=rb, param=w2)
             d_b1 = torch.empty((gh.shape[1],), device=dev, dtype=torch.float32)

@@ -133,6 +133,13 @@ SIGNATURES = {
     'sedt_heads_bwd': (_i, [_vp] * 17 + [_i] * 5 + [_vp]),
     'sedt_decoder_slab_ok': (_i, [_i, _i, _i, _i, _i, _i]),
     'sedt_decoder_layer_fwd': (_i, [C.POINTER(SedtDecLayer), _vp]),
+    'sedt_ffn_split_ok': (_i, [_i, _i, _i]),
+    'sedt_ffn_split_part_floats': (_sz, [_i]),
+    'sedt_ffn_split_blocks': (_i, [_i]),
+    'sedt_ffn_split_fwd': (_i, [_vp] * 10 + [_i, _i, _f, _u32, _u32, _vp, _vp]),
+    'sedt_ffn_split_bwd': (_i, [_vp] * 9 + [_i, _i, _f, _u32, _vp, _vp]),
+    'sedt_encoder_attn_fwd2': (_i, [_vp] * 14 + [_i, _i, _f, _u32, _u32, _vp, _vp]),
+    'sedt_encoder_ln2_bwd': (_i, [_vp] * 11 + [_i, _i, _f, _u32, _vp, _vp]),
     'sedt_encoder_ffn_bwd': (_i, [_vp] * 15 + [_i, _i, _i, _f, _u32, _u32, _vp, _vp]),
     'sedt_encoder_qkv_bwd': (_i, [_vp] * 10 + [_i, _i, _vp]),
     'sedt_posenc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

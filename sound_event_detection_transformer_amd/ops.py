@@ -811,6 +811,87 @@ def decoder_layer_fwd(tgt, qpos, kc, vc, kpm, amask, frags, vecs, B, Q, S, FF, d
     return out, by
 
 
+# The FFN pair tiled in two dimensions (csrc/ffn_split.hip: 128 rows x a quarter of the hidden features per workgroup, in-launch reduction
+# over the quarters) behind the encoder's attention kernel.  Correct, bit-reproducible (tests/test_slab_gpu.py) and SLOWER than the FFN
+# inside the slab kernel: 58 us against ~35 us at M = 8192 (phase ablation, tools/dev/time_ffn_split.py: GEMMs 14 us, the dropout hashes
+# of the 16.8 M hidden elements 12 us - the same in either tiling -, the 16-byte write-through stores of the f32 partial sums and their
+# reduction 26 us; C2 step 5.37 -> 5.45 ms).  Opt-in: ops.SLAB_FFN_SPLIT = True.
+SLAB_FFN_SPLIT = _dev_env('SEDT_SLAB_FFN_SPLIT', '0') == '1'
+_FFN_CNT = {}
+
+
+def _ffn_counters(device, nblocks):
+    """the arrival counters of the split-FFN kernels: zero once, re-armed by every launch (launches are ordered on the training stream)"""
+    key = str(device)
+    c = _FFN_CNT.get(key)
+    if c is None or c.numel() < nblocks:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('the split-FFN counters must exist before a capture (run one eager step first)')
+        c = _FFN_CNT[key] = torch.zeros(max(nblocks, 1024), device=device, dtype=torch.int32)
+    return c
+
+
+def ffn_split_ok(dtype, D, FF):
+    return bool(SLAB_FFN_SPLIT and dtype == BF16 and L.load().sedt_ffn_split_ok(D, FF, dtype))
+
+
+def encoder_attn_fwd2(x, qk, v, kpm, w_o_frag, b_o, gamma2, beta2, B, S, drop_p=0.0, seeds=(0, 0), seed_ptr=None, train=True):
+    """attention + out-proj + residual + LayerNorm2 per 32-token slab (the encoder kernel stopped before the FFN).  Returns (x1, x1n,
+    (ctx, lse, mean2, rstd2) or None)"""
+    _dev_check(x, qk, v)
+    M, D = x.shape
+    x1, x1n = torch.empty_like(x), torch.empty_like(x)
+    by = None
+    if train:
+        f32 = dict(device=x.device, dtype=torch.float32)
+        by = (torch.empty_like(x), torch.empty((B, 8, S), **f32), torch.empty((M,), **f32), torch.empty((M,), **f32))
+    s = by if by is not None else (None,) * 4
+    L.check(L.load().sedt_encoder_attn_fwd2(_p(x), _p(qk), _p(v), _p(kpm), _p(w_o_frag), _p(b_o), _p(gamma2), _p(beta2), _p(x1), _p(x1n),
+                                            _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]), B, S, drop_p, seeds[0] & 0xffffffff,
+                                            seeds[1] & 0xffffffff, _p(seed_ptr), L.stream_ptr()), 'encoder_attn_fwd2')
+    return x1, x1n, by
+
+
+def ffn_split_fwd(x1n, x1, w1_frag, b1, w2_frag, b2, FF, drop_p=0.0, seeds=(0, 0), seed_ptr=None, train=True, out=None):
+    """x2 = x1 + drop(drop(relu(x1n W1^T + b1)) W2^T + b2); seeds = (hidden, output).  Returns (x2, h or None)"""
+    _dev_check(x1n, x1)
+    M, D = x1n.shape
+    lib = L.load()
+    x2 = out if out is not None else torch.empty_like(x1)
+    h = torch.empty((M, FF), device=x1.device, dtype=x1.dtype) if train else None
+    part = torch.empty((lib.sedt_ffn_split_part_floats(M),), device=x1.device, dtype=torch.float32)
+    cnt = _ffn_counters(x1.device, lib.sedt_ffn_split_blocks(M))
+    L.check(lib.sedt_ffn_split_fwd(_p(x1n), _p(x1), _p(w1_frag), _p(b1), _p(w2_frag), _p(b2), _p(h), _p(x2), _p(part), _p(cnt), M, FF, drop_p,
+                                   seeds[0] & 0xffffffff, seeds[1] & 0xffffffff, _p(seed_ptr), L.stream_ptr()), 'ffn_split_fwd')
+    return x2, h
+
+
+def ffn_split_bwd(gx2, h, w2t_frag, w1t_frag, drop_p=0.0, seed_f=0, seed_ptr=None):
+    """returns (g2, gh, g_x1n): g2 = dropout'(gx2) (gx2 itself when drop_p == 0), gh = (g2 W2) [h > 0] / (1 - p), g_x1n = gh W1"""
+    _dev_check(gx2, h)
+    M, D = gx2.shape
+    FF = h.shape[1]
+    lib = L.load()
+    g2 = torch.empty_like(gx2) if drop_p > 0 else None
+    gh, gx1n = torch.empty_like(h), torch.empty_like(gx2)
+    part = torch.empty((lib.sedt_ffn_split_part_floats(M),), device=gx2.device, dtype=torch.float32)
+    cnt = _ffn_counters(gx2.device, lib.sedt_ffn_split_blocks(M))
+    L.check(lib.sedt_ffn_split_bwd(_p(gx2), _p(h), _p(w2t_frag), _p(w1t_frag), _p(g2), _p(gh), _p(gx1n), _p(part), _p(cnt), M, FF, drop_p,
+                                   seed_f & 0xffffffff, _p(seed_ptr), L.stream_ptr()), 'ffn_split_bwd')
+    return (g2 if g2 is not None else gx2), gh, gx1n
+
+
+def encoder_ln2_bwd(gx1n, gx2, x1, mean2, rstd2, gamma2, wot_frag, B, S, drop_p=0.0, seed_o=0, seed_ptr=None):
+    """gx1 = LayerNorm2'(g_x1n) + gx2; g1 = dropout'(gx1); gctx = g1 Wo.  Returns (gx1, g1, gctx, ln_part)"""
+    M, D = gx2.shape
+    gx1, gctx = torch.empty_like(gx2), torch.empty_like(gx2)
+    g1 = torch.empty_like(gx2) if drop_p > 0 else None
+    part = torch.empty((B * ((S + 31) // 32), 2 * D), device=gx2.device, dtype=torch.float32)
+    L.check(L.load().sedt_encoder_ln2_bwd(_p(gx1n), _p(gx2), _p(x1), _p(mean2), _p(rstd2), _p(gamma2), _p(wot_frag), _p(gx1), _p(g1), _p(gctx),
+                                          _p(part), B, S, drop_p, seed_o & 0xffffffff, _p(seed_ptr), L.stream_ptr()), 'encoder_ln2_bwd')
+    return gx1, (g1 if g1 is not None else gx1), gctx, part
+
+
 def encoder_ffn_bwd(gx2, h, x1, mean2, rstd2, gamma2, w2t_frag, w1t_frag, wot_frag, B, S, drop_p=0.0, seeds=(0, 0), seed_ptr=None):
     """FFN backward + LayerNorm2 backward + out-proj input gradient per 32-token slab in ONE launch (csrc/enc_slab.hip).
     seeds = (FFN-output dropout, out-proj dropout).  Returns (g2, gh, gx1, g1, gctx, ln_part [slabs, 512])"""

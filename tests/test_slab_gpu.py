@@ -275,3 +275,39 @@ def test_heads_slab_kernels_match_per_op_heads(L_, B, Qp, dec_at, train):
     finally:
         ops.SLAB_HEADS = True
         runtime.set_compute_dtype('f32')
+
+
+def test_split_ffn_in_launch_reduction_is_bit_reproducible():
+    """the 2-D tiled FFN (csrc/ffn_split.hip) reduces the four hidden quarters of a row block INSIDE the launch: the last workgroup to
+    arrive adds the partials in a fixed order, whichever it is.  Repeated runs of the layer (forward + backward, M = 64 * 128 rows:
+    256 workgroups racing for their tickets; and a ragged M) must be bit-identical, and equal to the single-slab FFN within bf16"""
+    from sound_event_detection_transformer_amd import ops, runtime
+    runtime.set_compute_dtype('bf16')
+    try:
+        layer, plan = _layer_and_plan(17)
+        for B, S in ((64, 128), (3, 124)):
+            g = torch.Generator().manual_seed(9)
+            x0 = torch.randn(B * S, 256, generator=g).cuda().bfloat16()
+            pos = (0.5 * torch.randn(B * S, 256, generator=g)).cuda().bfloat16()
+            gy = torch.randn(B * S, 256, generator=g).cuda().bfloat16()
+            runs = []
+            for rep, split in enumerate((True, True, True, False)):
+                ops.SLAB_FFN_SPLIT = split
+                runtime.manual_seed(55)
+                x = x0.clone().requires_grad_(True)
+                for p in layer.parameters():
+                    p.grad = None
+                with plan:
+                    y = layer.forward_tokens(x, pos, None, B, S)
+                    y.backward(gy)
+                torch.cuda.synchronize()
+                runs.append((y.detach().clone(), x.grad.clone(), layer.linear1.weight.grad.clone(), layer.linear2.weight.grad.clone()))
+            for a_, b_ in zip(runs[0], runs[1]):
+                assert torch.equal(a_, b_)
+            for a_, b_ in zip(runs[0], runs[2]):
+                assert torch.equal(a_, b_)
+            for a_, b_ in zip(runs[0], runs[3]):
+                assert rel(a_, b_) < 2e-2
+    finally:
+        ops.SLAB_FFN_SPLIT = False
+        runtime.set_compute_dtype('f32')

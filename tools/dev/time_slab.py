@@ -65,7 +65,18 @@ for p_ in (0.1, 0.0):
 x2, by2 = ops.encoder_attn_ffn_fwd(x, qk, v, None, fr[1][0], b_o, gam2, bet2, fr[2][0], b1, fr[3][0], b2, B, S, FF, 0.1, (7, 3, 5, 6), None,
                                    train=True)
 ctx, lse, x1, m2, r2, x1n, h = by2
+x1b, x1nb, _ = ops.encoder_attn_fwd2(x, qk, v, None, fr[1][0], b_o, gam2, bet2, B, S, 0.1, (7, 3), None, train=True)
+t = timeit(lambda: ops.encoder_attn_fwd2(x, qk, v, None, fr[1][0], b_o, gam2, bet2, B, S, 0.1, (7, 3), None, train=True))
+print('enc_attn_fwd2 (attention + out-proj + LN2) %7.2f us' % t)
+for tr in (True, False):
+    t = timeit(lambda: ops.ffn_split_fwd(x1nb, x1b, fr[2][0], b1, fr[3][0], b2, FF, 0.1, (5, 6), None, train=tr))
+    print('ffn_split_fwd train=%d  %7.2f us' % (tr, t))
 gx2 = rnd(M, E)
+t = timeit(lambda: ops.ffn_split_bwd(gx2, h, fr[3][1], fr[2][1], 0.1, 6, None))
+print('ffn_split_bwd          %7.2f us' % t)
+_, _, gx1n_ = ops.ffn_split_bwd(gx2, h, fr[3][1], fr[2][1], 0.1, 6, None)
+t = timeit(lambda: ops.encoder_ln2_bwd(gx1n_, gx2, x1, m2, r2, gam2, fr[1][1], B, S, 0.1, 3, None))
+print('enc_ln2_bwd            %7.2f us' % t)
 if hasattr(ops, 'encoder_ffn_bwd'):
     t = timeit(lambda: ops.encoder_ffn_bwd(gx2, h, x1, m2, r2, gam2, fr[3][1], fr[2][1], fr[1][1], B, S, 0.1, (6, 3), None))
     print('enc_ffn_bwd            %7.2f us' % t)
