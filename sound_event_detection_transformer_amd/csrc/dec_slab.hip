@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512) void dec_layer_kernel(const DecLayerArgs a) {
       if (n < nvalid) {
         const uint64_t idx = (uint64_t)(row0 + n) * DS_D + f;
         uint32_t keep = 0xfu;
-        if (a.thresh) keep = drop_keep4(drop_inner(sd, (uint32_t)(idx >> 33)), (uint32_t)(idx >> 33), sd, idx, a.thresh);
+        if (a.thresh) keep = drop_keep4(slab::inner0(sd), 0u, sd, idx, a.thresh);
 #pragma unroll
         for (int e = 0; e < 4; ++e) o.v[e] = (bf16_t)(((keep >> e & 1u) ? v4[e] * inv_keep : 0.f) + (float)res[g4].v[e]);
         *reinterpret_cast<VecT<bf16_t, 4>*>(a.t1 + (row0 + n) * DS_D + f) = o;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(512) void dec_layer_kernel(const DecLayerArgs a) {
       if (n < nvalid) {
         const uint64_t idx = (uint64_t)(row0 + n) * DS_D + f;
         uint32_t keep = 0xfu;
-        if (a.thresh) keep = drop_keep4(drop_inner(sd, (uint32_t)(idx >> 33)), (uint32_t)(idx >> 33), sd, idx, a.thresh);
+        if (a.thresh) keep = drop_keep4(slab::inner0(sd), 0u, sd, idx, a.thresh);
 #pragma unroll
         for (int e = 0; e < 4; ++e) o.v[e] = (bf16_t)(((keep >> e & 1u) ? v4[e] * inv_keep : 0.f) + (float)res[g4].v[e]);
         if (TRAIN) *reinterpret_cast<VecT<bf16_t, 4>*>(a.t2 + (row0 + n) * DS_D + f) = o;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(512) void dec_layer_kernel(const DecLayerArgs a) {
         tile_epilogue(acc[t], b1r[t], t0 + t, hf, [&](int g4, int f, const float* v4) {
           const uint64_t idx = (uint64_t)(row0 + n) * FF + f;
           uint32_t keep = 0xfu;
-          if (a.thresh) keep = drop_keep4(drop_inner(sd_h, (uint32_t)(idx >> 33)), (uint32_t)(idx >> 33), sd_h, idx, a.thresh);
+          if (a.thresh) keep = drop_keep4(slab::inner0(sd_h), 0u, sd_h, idx, a.thresh);
           VecT<bf16_t, 4> o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o.v[e] = (bf16_t)((n < nvalid && (keep >> e & 1u)) ? fmaxf(v4[e], 0.f) * inv_keep : 0.f);
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(512) void dec_layer_kernel(const DecLayerArgs a) {
     if (n >= nvalid) return;
     const uint64_t idx = (uint64_t)(row0 + n) * DS_D + f;
     uint32_t keep = 0xfu;
-    if (a.thresh) keep = drop_keep4(drop_inner(sd_f, (uint32_t)(idx >> 33)), (uint32_t)(idx >> 33), sd_f, idx, a.thresh);
+    if (a.thresh) keep = drop_keep4(slab::inner0(sd_f), 0u, sd_f, idx, a.thresh);
     const VecT<bf16_t, 4> xr = *reinterpret_cast<const VecT<bf16_t, 4>*>(T2 + n * XP + f);
     VecT<bf16_t, 4> o;
 #pragma unroll

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512) void enc_attn_ffn_kernel(const EncAttnFfnArgs 
       if (n < nvalid) {
         const uint64_t idx = (uint64_t)(row0 + n) * ES_D + f;
         uint32_t keep = 0xfu;
-        if (a.thresh) keep = drop_keep4(drop_inner(sd, (uint32_t)(idx >> 33)), (uint32_t)(idx >> 33), sd, idx, a.thresh);
+        if (a.thresh) keep = drop_keep4(slab::inner0(sd), 0u, sd, idx, a.thresh);
         const VecT<bf16_t, 4> xr = xres[g4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) o.v[e] = (bf16_t)(((keep >> e & 1u) ? v4[e] * inv_keep : 0.f) + (float)xr.v[e]);
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(512) void enc_attn_ffn_kernel(const EncAttnFfnArgs 
           float v4[4] = {acc[t][4 * g4 + 0] + bb.x, acc[t][4 * g4 + 1] + bb.y, acc[t][4 * g4 + 2] + bb.z, acc[t][4 * g4 + 3] + bb.w};
           const uint64_t idx = (uint64_t)(row0 + n) * FF + f;
           uint32_t keep = 0xfu;
-          if (a.thresh) keep = drop_keep4(drop_inner(sd_h, (uint32_t)(idx >> 33)), (uint32_t)(idx >> 33), sd_h, idx, a.thresh);
+          if (a.thresh) keep = drop_keep4(slab::inner0(sd_h), 0u, sd_h, idx, a.thresh);
           VecT<bf16_t, 4> o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o.v[e] = (bf16_t)((n < nvalid && (keep >> e & 1u)) ? fmaxf(v4[e], 0.f) * inv_keep : 0.f);
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(512) void enc_attn_ffn_kernel(const EncAttnFfnArgs 
     float v4[4] = {acc2[0][4 * g4 + 0] + bb.x, acc2[0][4 * g4 + 1] + bb.y, acc2[0][4 * g4 + 2] + bb.z, acc2[0][4 * g4 + 3] + bb.w};
     const uint64_t idx = (uint64_t)(row0 + n) * ES_D + f;
     uint32_t keep = 0xfu;
-    if (a.thresh) keep = drop_keep4(drop_inner(sd_f, (uint32_t)(idx >> 33)), (uint32_t)(idx >> 33), sd_f, idx, a.thresh);
+    if (a.thresh) keep = drop_keep4(slab::inner0(sd_f), 0u, sd_f, idx, a.thresh);
     const VecT<bf16_t, 4> xr = *reinterpret_cast<const VecT<bf16_t, 4>*>(X1 + n * XP + f);
     VecT<bf16_t, 4> o;
 #pragma unroll
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(512) void enc_ffn_bwd_kernel(const EncFfnBwdArgs a)
           for (int e = 0; e < 4; ++e) ov.v[e] = (bf16_t)o[e];
           *reinterpret_cast<VecT<bf16_t, 4>*>(a.gx1 + base) = ov;
           uint32_t keep = 0xfu;
-          if (a.thresh) keep = drop_keep4(drop_inner(sd, (uint32_t)((uint64_t)base >> 33)), (uint32_t)((uint64_t)base >> 33), sd, (uint64_t)base, a.thresh);
+          if (a.thresh) keep = drop_keep4(slab::inner0(sd), 0u, sd, (uint64_t)base, a.thresh);
 #pragma unroll
           for (int e = 0; e < 4; ++e) od.v[e] = (keep >> e & 1u) ? (a.thresh ? (bf16_t)((float)ov.v[e] * inv_keep) : ov.v[e]) : (bf16_t)0.f;
           if (a.g1) *reinterpret_cast<VecT<bf16_t, 4>*>(a.g1 + base) = od;
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(512) void enc_ln2_bwd_kernel(const EncLn2BwdArgs a)
         for (int e = 0; e < 4; ++e) ov.v[e] = (bf16_t)o[e];
         *reinterpret_cast<VecT<bf16_t, 4>*>(a.gx1 + base) = ov;
         uint32_t keep = 0xfu;
-        if (a.thresh) keep = drop_keep4(drop_inner(sd, (uint32_t)((uint64_t)base >> 33)), (uint32_t)((uint64_t)base >> 33), sd, (uint64_t)base, a.thresh);
+        if (a.thresh) keep = drop_keep4(slab::inner0(sd), 0u, sd, (uint64_t)base, a.thresh);
 #pragma unroll
         for (int e = 0; e < 4; ++e) od.v[e] = (keep >> e & 1u) ? (a.thresh ? (bf16_t)((float)ov.v[e] * inv_keep) : ov.v[e]) : (bf16_t)0.f;
         if (a.g1) *reinterpret_cast<VecT<bf16_t, 4>*>(a.g1 + base) = od;

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(512) void ffn_split_fwd_kernel(const FfnSplitArgs a
           const float bv[4] = {bb[g4].x, bb[g4].y, bb[g4].z, bb[g4].w};
           const uint64_t idx = (uint64_t)(row0 + r) * FF + f;
           uint32_t keep = 0xfu;
-          if (a.thresh) keep = drop_keep4(drop_inner(sd_h, (uint32_t)(idx >> 33)), (uint32_t)(idx >> 33), sd_h, idx, a.thresh);
+          if (a.thresh) keep = drop_keep4(slab::inner0(sd_h), 0u, sd_h, idx, a.thresh);
           VecT<bf16_t, 4> o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) o.v[e] = (bf16_t)((r < nvalid && (keep >> e & 1u)) ? fmaxf(acc[sl][4 * g4 + e] + bv[e], 0.f) * inv_keep : 0.f);

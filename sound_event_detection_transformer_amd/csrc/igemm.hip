@@ -569,15 +569,9 @@ static int launch_typed(const SedtIgemm& p, hipStream_t st) {
     // measured on MI355X (tools/tune_igemm.py, profiles/): this register-staged pipeline is latency-bound, so the
     // 64x64 tile (4 workgroups / CU resident) beats the larger tiles at every shape of the SEDT step
     bm = 64; bn = 64;
-    if (X3) {
-      // the split-bf16 products cost a third of the exact-f32 MFMA time: per K tile a 64x64 workgroup has 6 MFMAs per wave between
-      // two barriers.  Larger tiles (24 per wave for 128x128) wherever enough of them remain to cover the chip
-      static const int big = sedt::dev_getenv("SEDT_X3_BIG_MINTILES") ? atoi(sedt::dev_getenv("SEDT_X3_BIG_MINTILES")) : 192;
-      static const int mid = sedt::dev_getenv("SEDT_X3_MID_MINTILES") ? atoi(sedt::dev_getenv("SEDT_X3_MID_MINTILES")) : 192;
-      const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128), t12864 = (long)((p.M + 127) / 128) * ((p.N + 63) / 64);
-      if (p.N >= 128 && t128 >= big) { bm = 128; bn = 128; }
-      else if (t12864 >= mid) { bm = 128; bn = 64; }
-    }
+    // (x3: larger tiles - 24 instead of 6 MFMAs per wave between two barriers - measured SLOWER on this register-staged pipeline:
+    // C2 step 29.5 ms with 64x64 everywhere, 31.2-36.7 ms with 128x128 / 128x64 above 64-512 tiles; the pipeline is bound by its
+    // one-tile-ahead global loads, not by the matrix pipe)
   }
   if (p.splitk > 1) SEDT_REQUIRE(p.slab != nullptr, "igemm: splitk > 1 needs a slab");
 #define SEDT_DISPATCH(BM_, BN_)                                                         \

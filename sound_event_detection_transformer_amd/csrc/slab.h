@@ -38,6 +38,10 @@ __device__ __forceinline__ void load_chunk(u32x4 (&dst)[8], const u32x4* __restr
     for (int u = 0; u < U; ++u) dst[t * U + u] = wl[t * tstride + (long)(ks0 + u) * 64];
 }
 
+// the seed-only half of the dropout hash for element indices below 2^33 (every tensor of this path): hoisted out of the epilogues'
+// inner loops by the compiler once it is a pure function of a kernel-constant seed (drop_keep4 recomputes it for larger indices)
+__device__ __forceinline__ uint32_t inner0(uint32_t seed) { return drop_inner(seed, 0u); }
+
 // "everything issued above stays above": keeps a block of loads ahead of the work that hides their latency
 __device__ __forceinline__ void issue_fence() { __builtin_amdgcn_sched_barrier(0); }
 
