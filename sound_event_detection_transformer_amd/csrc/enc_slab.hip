@@ -767,10 +767,20 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(const SedtFragJob* __res
   const int tb = (int)blockIdx.x - j.blk0;
   const int kt = j.K / 32, n0 = (tb / kt) * 32, k0 = (tb % kt) * 32;
   const int tid = threadIdx.x;
-  for (int u = tid; u < 32 * 8; u += 256) {                       // 32 rows x 8 float4
-    const int r = u >> 3, c = (u & 7) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(j.w + (long)(n0 + r) * j.K + k0 + c);
-    tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
+  if (j.src_bf16) {                                               // the source is a bf16 matrix already (a packed conv operand)
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(j.w);
+    for (int u = tid; u < 32 * 8; u += 256) {
+      const int r = u >> 3, c = (u & 7) * 4;
+      const VecT<bf16_t, 4> v = *reinterpret_cast<const VecT<bf16_t, 4>*>(src + (long)(n0 + r) * j.K + k0 + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) tile[r][c + e] = (float)v.v[e];
+    }
+  } else {
+    for (int u = tid; u < 32 * 8; u += 256) {                     // 32 rows x 8 float4
+      const int r = u >> 3, c = (u & 7) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(j.w + (long)(n0 + r) * j.K + k0 + c);
+      tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
+    }
   }
   __syncthreads();
   const int which = tid >> 7, t = tid & 127, sub = t >> 6, l = t & 63, m = l & 31, hf = l >> 5;

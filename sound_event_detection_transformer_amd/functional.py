@@ -823,6 +823,19 @@ class StageFn(Function):
             g1 = ConvGeom(H, W, cin, pl, 1)
             g2 = ConvGeom(H, W, pl, pl, 3, blk.stride, blk.dil, blk.dil)
             g3 = ConvGeom(g2.Ho, g2.Wo, pl, 4 * pl, 1)
+            if ops.bneck_ok(dt, blk, W) and x.is_contiguous():
+                # the whole block in one launch, its intermediates never in HBM (csrc/bneck.hip)
+                cf = [packing.lookup_conv_frag(t[k]) for k in (0, 5, 10)]
+                if all(c is not None for c in cf):
+                    # a frozen block (layer1, backbone.py:60-62) keeps only the sign bits of its intermediates: the fused backward
+                    # needs nothing else; a trainable one keeps a and b for the per-op backward with its weight gradients
+                    frozen = not (t[0].requires_grad or t[5].requires_grad or t[10].requires_grad)
+                    y, a, b, ybits, abits, bbits = ops.bneck_fwd(x, B, H, [c[0] for c in cf], ((s1, b1), (s2, b2), (s3, b3)),
+                                                                 train=any(ctx.needs_input_grad), want_bits=bool(tr), want_ab=not frozen)
+                    saved.append(dict(blk=blk, x=x, a=a, b=b, g1=g1, g2=g2, g3=g3, s=(s1, s2, s3), wb=(w1b, w2b, w3b), H=H, W=W, y=y,
+                                      xbits=xbits, fused=[c[1] for c in cf] if frozen else None, ab_bits=(abits, bbits)))
+                    x, xbits = y, ybits
+                    continue
             a = ops.conv_fwd(dt, x, B, g1, w1f, scale=s1, bias=b1, act=ACT_RELU)
             b = ops.conv_fwd(dt, a, B, g2, w2f, scale=s2, bias=b2, act=ACT_RELU)
             rec = dict(blk=blk, x=x, a=a, b=b, g1=g1, g2=g2, g3=g3, s=(s1, s2, s3), wb=(w1b, w2b, w3b), H=H, W=W)
@@ -866,6 +879,12 @@ class StageFn(Function):
             w1b, w2b, w3b = r['wb']
             first = bi_ == 0
             want_gx = (not first) or need_x_grad
+            if r.get('fused') is not None and want_gx and not (t[0].requires_grad or t[5].requires_grad or t[10].requires_grad):
+                # frozen block (layer1, backbone.py:60-62): only the input gradient is needed - one launch
+                mask_x = (not first) or meta['mask_input']
+                if not mask_x or r.get('xbits') is not None:
+                    gp = ops.bneck_bwd(gp, B, r['H'], r['fused'], *r['ab_bits'], r['xbits'] if mask_x else None)
+                    continue
             # conv3 (1x1): wgrad, dgrad masked by relu(b)
             if t[10].requires_grad:
                 grads[base + 10] = ops.wgrad(dt, gp, r['b'], B, r['g3'], rowscale=s3, batch=rb, param=t[10])

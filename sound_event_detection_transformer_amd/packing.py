@@ -16,7 +16,7 @@ _BN = np.dtype([('w', np.uint64), ('b', np.uint64), ('rm', np.uint64), ('rv', np
 _PK = np.dtype([('w', np.uint64), ('bnscale', np.uint64), ('wf', np.uint64), ('wb', np.uint64), ('e0', np.int64),
                 ('ne', np.int32), ('Cout', np.int32), ('Cin', np.int32), ('taps', np.int32)])
 _FJ = np.dtype([('w', np.uint64), ('wf', np.uint64), ('wb', np.uint64), ('N', np.int32), ('K', np.int32), ('blk0', np.int32),
-                ('pad', np.int32)])
+                ('src_bf16', np.int32)])
 _CHUNK = 32768
 
 _active = []          # stack of plans whose prepared tensors are valid right now (inside a model forward)
@@ -26,6 +26,16 @@ def lookup_frag(weight):
     """(fragment-major W, fragment-major W^T) prepared for this 2-D parameter by the active plan (csrc/slab.h), or None"""
     for plan in reversed(_active):
         hit = plan.frag_table.get(weight.data_ptr())
+        if hit is not None:
+            return hit
+    return None
+
+
+def lookup_conv_frag(weight):
+    """(fragment-major forward operand, fragment-major dgrad operand) of a convolution weight the active plan lists under
+    ``conv_frags`` (csrc/bneck.hip), or None"""
+    for plan in reversed(_active):
+        hit = plan.conv_frag_table.get(weight.data_ptr())
         if hit is not None:
             return hit
     return None
@@ -41,13 +51,14 @@ def lookup(weight):
 
 
 class PackPlan(object):
-    def __init__(self, dt, device, convs, linears, bn_only=(), frags=()):
+    def __init__(self, dt, device, convs, linears, bn_only=(), frags=(), conv_frags=()):
         """convs: list of (weight Parameter, (bn_w, bn_b, bn_rm, bn_rv) or None); linears: list of weight Parameters (2-D).
         A linear in f32 mode uses the parameter itself as the forward operand.
         frags (bf16 mode): 2-D weight Parameters [N][K] (N, K multiples of 32) that are ALSO packed fragment-major, W and W^T, for
-        the x-stationary slab kernels (one more launch: sedt_pack_frag)"""
+        the x-stationary slab kernels (one more launch: sedt_pack_frag).
+        conv_frags (bf16 mode): convolution weights out of `convs` whose two packed operands are ALSO laid out fragment-major (same
+        launch, reading the packed bf16 operands): the fused Bottleneck kernels (csrc/bneck.hip)"""
         self.dt, self.device = dt, device
-        self._init_frags(frags if dt == BF16 else (), device)
         td = TORCH_DTYPE[dt]
         es = 4 if dt == F32 else 2
         bns = [(w, bn) for w, bn in list(convs) + list(bn_only) if bn is not None]
@@ -122,15 +133,20 @@ class PackPlan(object):
         self._host_bn = torch.empty(max(self._bn.nbytes, 8), dtype=torch.uint8).pin_memory()
         self._host_pk = torch.empty(max(self._pk.nbytes, 8), dtype=torch.uint8).pin_memory()
         self._last = None
+        self._init_frags(frags if dt == BF16 else (), device, conv_frags if dt == BF16 else ())
 
-    def _init_frags(self, frags, device):
+    def _init_frags(self, frags, device, conv_frags):
         self.frag_table, self._fr_params, self._fr_entries = {}, [], []
+        self.conv_frag_table, self._cf_entries = {}, []
         frags = [w for w in frags if w.dim() == 2 and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0]
-        self._fj = np.zeros(len(frags), _FJ)
+        packed = {id(w): (wf, wb) for w, wf, wb, _, _ in self._entries}
+        conv_frags = [w for w in conv_frags if id(w) in packed and packed[id(w)][0] is not None and packed[id(w)][1] is not None
+                      and all(d % 32 == 0 for d in packed[id(w)][0].shape + packed[id(w)][1].shape)]
+        self._fj = np.zeros(len(frags) + 2 * len(conv_frags), _FJ)
         self._fr_blocks = 0
-        if not frags:
+        if not len(self._fj):
             return
-        total = sum(2 * w.numel() for w in frags)
+        total = sum(2 * w.numel() for w in frags) + sum(2 * w.numel() for w in conv_frags)
         self.fbuf = torch.empty(total, device=device, dtype=torch.bfloat16)
         base, off = self.fbuf.data_ptr(), 0
         for r, w in enumerate(frags):
@@ -143,6 +159,20 @@ class PackPlan(object):
             off += 2 * n
             self._fr_params.append(w)
             self._fr_entries.append((w, wf, wb))
+        r = len(frags)
+        for w in conv_frags:
+            outs = []
+            for src in packed[id(w)]:                              # the packed bf16 operands: fixed addresses inside self.wbuf
+                N, K = src.shape
+                n = src.numel()
+                row = self._fj[r]
+                row['wf'], row['N'], row['K'], row['blk0'], row['src_bf16'] = base + 2 * off, N, K, self._fr_blocks, 1
+                outs.append(self.fbuf[off:off + n])
+                self._fr_blocks += (N // 32) * (K // 32)
+                off += n
+                self._fr_params.append(src)
+                r += 1
+            self._cf_entries.append((w, outs[0], outs[1]))
         self._dev_fj = torch.empty(self._fj.nbytes, dtype=torch.uint8, device=device)
         self._host_fj = torch.empty(self._fj.nbytes, dtype=torch.uint8).pin_memory()
 
@@ -171,6 +201,7 @@ class PackPlan(object):
                 self._host_fj.numpy()[:] = self._fj.view(np.uint8)
                 self._dev_fj.copy_(self._host_fj, non_blocking=True)
                 self.frag_table = {w.data_ptr(): (wf, wb) for w, wf, wb in self._fr_entries}
+                self.conv_frag_table = {w.data_ptr(): (ff, bf) for w, ff, bf in self._cf_entries}
         lib = L.load()
         if len(self._bn):
             L.check(lib.sedt_multi_bn_fold(L.p(self._dev_bn), len(self._bn), L.stream_ptr()), 'multi_bn_fold')

@@ -1,0 +1,143 @@
+"""GPU: the fused identity Bottleneck of layer1 (csrc/bneck.hip) against the three per-op launches it replaces, each way.
+
+Both paths round the two 64-channel intermediates (and their gradients) to bf16 and accumulate in f32; the fused kernel sums the
+contraction in a different order, so an intermediate may land on the neighbouring bf16 value.  Tolerance: 2e-2 of the tensor's largest
+entry (observed <= 8e-3); the sign bits must describe the y the kernel wrote exactly.  Strip edge cases: H not a multiple of the 8-row
+strip, H smaller than one strip, a single row."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(got, ref):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    return ((got - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
+
+
+def _stage(seed):
+    """layer1 of the backbone with seeded weights and non-trivial FrozenBN statistics, and the pack plan of its convolutions"""
+    from sound_event_detection_transformer_amd import packing
+    from sound_event_detection_transformer_amd.lib import BF16
+    from sound_event_detection_transformer_amd.sedt.backbone import ResNet50Body
+    torch.manual_seed(seed)
+    body = ResNet50Body(True).cuda()
+    layer = body.layer1
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for b in layer:
+            for bn in (b.bn1, b.bn2, b.bn3) + ((b.downsample[1],) if b.downsample is not None else ()):
+                bn.weight.copy_(1 + 0.2 * torch.randn(bn.weight.shape, generator=g))
+                bn.bias.copy_(0.1 * torch.randn(bn.bias.shape, generator=g))
+                bn.running_mean.copy_(0.1 * torch.randn(bn.bias.shape, generator=g))
+                bn.running_var.copy_(1 + 0.3 * torch.rand(bn.bias.shape, generator=g))
+    for p in layer.parameters():
+        p.requires_grad_(False)                         # reference backbone.py:60-62: layer1 is frozen
+    convs, cfr = [], []
+    for i, b in enumerate(layer):
+        convs += [(b.conv1.weight, b.bn1.tensors()), (b.conv2.weight, b.bn2.tensors()), (b.conv3.weight, b.bn3.tensors())]
+        if b.downsample is not None:
+            convs.append((b.downsample[0].weight, b.downsample[1].tensors()))
+        else:
+            cfr += [b.conv1.weight, b.conv2.weight, b.conv3.weight]
+    plan = packing.PackPlan(BF16, torch.device('cuda'), convs, [], (), (), cfr)
+    return layer, plan
+
+
+def _run(layer, plan, x, B, H, fused, gy=None):
+    from sound_event_detection_transformer_amd import functional as Fn, ops
+    from sound_event_detection_transformer_amd.lib import BF16
+    keep = ops.FUSED_BNECK
+    ops.FUSED_BNECK = fused
+    try:
+        xin = x.clone().requires_grad_(gy is not None)
+        holder = {}
+        meta = dict(dt=BF16, B=B, H=H, W=16, blocks=[b.cfg for b in layer], mask_input=False, grad_premasked=True, x_bits=None, holder=holder)
+        ts = [t for b in layer for t in b.tensors()]
+        with plan:
+            if gy is None:
+                with torch.no_grad():
+                    return Fn.StageFn.apply(xin, meta, *ts), None, None
+            y = Fn.StageFn.apply(xin, meta, *ts)
+            bits = holder.get('bits')
+            g = gy * (y.detach() > 0)                     # the consumer's promise: masked by the stage's final ReLU
+            y.backward(g)
+        return y.detach(), xin.grad, bits
+    finally:
+        ops.FUSED_BNECK = keep
+
+
+@pytest.mark.parametrize('B,H', [(2, 125), (3, 13), (1, 8), (2, 1), (1, 32)])
+def test_fused_bottleneck_matches_the_per_op_chain(B, H):
+    from sound_event_detection_transformer_amd import ops
+    layer, plan = _stage(5)
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B * H * 16, 64, generator=g).cuda().bfloat16().relu()          # (layer1's input is the pooled stem output: >= 0)
+    gy = torch.randn(B * H * 16, 256, generator=g).cuda().bfloat16()
+    assert ops.bneck_ok(ops.BF16, layer[1].cfg, 16) and not ops.bneck_ok(ops.BF16, layer[0].cfg, 16)
+    y1, gx1, bits1 = _run(layer, plan, x, B, H, True, gy)
+    y0, gx0, bits0 = _run(layer, plan, x, B, H, False, gy)
+    assert rel(y1, y0) < 2e-2
+    assert rel(gx1, gx0) < 2e-2
+    # the sign bits are those of the y this path wrote: bit c % 8 of byte c / 8
+    want = (y1.float() > 0).view(-1, 32, 8).to(torch.uint8)
+    packed = (want << torch.arange(8, device='cuda', dtype=torch.uint8)).sum(-1).to(torch.uint8)
+    assert torch.equal(bits1, packed)
+    # no-grad forward (teacher / evaluation): same output, no by-products
+    y2, _, _ = _run(layer, plan, x, B, H, True)
+    assert torch.equal(y2, y1)
+    # a trainable block keeps its intermediates and takes the per-op backward (weight gradients): same forward output
+    for p in layer[2].parameters():
+        p.requires_grad_(True)
+    y3, gx3, _ = _run(layer, plan, x, B, H, True, gy)
+    assert torch.equal(y3, y1) and rel(gx3, gx0) < 2e-2
+    assert layer[2].conv2.weight.grad is not None
+
+
+def test_fused_bottleneck_kernels_against_torch():
+    """the two entry points on their own against an f32 torch restatement of the block (conv / FrozenBN affine / ReLU), operands and the
+    two intermediates rounded to bf16 as the kernels do"""
+    import torch.nn.functional as F
+    from sound_event_detection_transformer_amd import ops, packing
+    layer, plan = _stage(11)
+    blk = layer[2]
+    B, H = 2, 19
+    g = torch.Generator().manual_seed(1)
+    x = (0.5 * torch.randn(B * H * 16, 256, generator=g)).cuda().bfloat16().relu()
+    gy = torch.randn(B * H * 16, 256, generator=g).cuda().bfloat16()
+    with plan:
+        cf = [packing.lookup_conv_frag(w) for w in (blk.conv1.weight, blk.conv2.weight, blk.conv3.weight)]
+        sb = [packing.lookup(w)[2:] for w in (blk.conv1.weight, blk.conv2.weight, blk.conv3.weight)]
+        y, a, b, bits, abits, bbits = ops.bneck_fwd(x, B, H, [c[0] for c in cf], sb, want_ab=True)
+        for t_, tb in ((a, abits), (b, bbits)):             # the sign bits describe the intermediates the kernel wrote
+            w_ = (t_.float() > 0).view(-1, 8, 8).to(torch.uint8)
+            assert torch.equal(tb, (w_ << torch.arange(8, device='cuda', dtype=torch.uint8)).sum(-1).to(torch.uint8))
+        xb = (x.float() > 0).view(-1, 32, 8).to(torch.uint8)
+        xbits = (xb << torch.arange(8, device='cuda', dtype=torch.uint8)).sum(-1).to(torch.uint8)
+        gym = gy * (y > 0)
+        gx = ops.bneck_bwd(gym, B, H, [c[1] for c in cf], abits, bbits, xbits)
+        torch.cuda.synchronize()
+
+    def q(t):
+        return t.bfloat16().float()
+
+    def nchw(t, C):
+        return t.float().view(B, H, 16, C).permute(0, 3, 1, 2)
+
+    def tok(t):
+        return t.permute(0, 2, 3, 1).reshape(B * H * 16, -1)
+
+    (s1, b1), (s2, b2), (s3, b3) = [(s.view(1, -1, 1, 1), bb.view(1, -1, 1, 1)) for s, bb in sb]
+    w1, w2, w3 = q(blk.conv1.weight), q(blk.conv2.weight), q(blk.conv3.weight)
+    X = nchw(x, 256)
+    A = q(F.relu(F.conv2d(X, w1) * s1 + b1))
+    Bt = q(F.relu(F.conv2d(A, w2, padding=1) * s2 + b2))
+    Y = F.relu(F.conv2d(Bt, w3) * s3 + b3 + X)
+    assert rel(a, tok(A)) < 1e-2 and rel(b, tok(Bt)) < 1e-2 and rel(y, tok(Y)) < 1e-2
+    # input gradients with the BN scale folded into bf16 weights, as the dgrad operands are packed
+    GY = nchw(gym, 256)
+    w3s, w2s, w1s = q(w3 * s3.view(-1, 1, 1, 1)), q(w2 * s2.view(-1, 1, 1, 1)), q(w1 * s1.view(-1, 1, 1, 1))
+    GB = q(F.conv_transpose2d(GY, w3s) * (nchw(b, 64) > 0))
+    GA = q(F.conv_transpose2d(GB, w2s, padding=1) * (nchw(a, 64) > 0))
+    GX = (F.conv_transpose2d(GA, w1s) + GY) * (X > 0)
+    assert rel(gx, tok(GX)) < 1e-2
