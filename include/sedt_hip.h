@@ -392,25 +392,27 @@ typedef struct SedtDecLayer {
 int sedt_decoder_slab_ok(int D, int H, int Q, int S, int FF, int dtype);
 int sedt_decoder_layer_fwd(const SedtDecLayer* args, void* stream);
 
-/* An identity Bottleneck of ResNet layer1 (torchvision v1.5 block behind sedt/backbone.py:97-113; 256 -> 64 -> 64 -> 256 on a map 16
- * columns wide, stride 1, no downsample branch) in ONE launch, and its input-gradient chain in one more (csrc/bneck.hip; a workgroup
- * per strip of 8 image rows, the 64-channel intermediates never leave the CU).
+/* An identity Bottleneck of ResNet layer1 / layer2 (torchvision v1.5 block behind sedt/backbone.py:97-113; cin -> planes -> planes -> cin,
+ * stride 1, no downsample branch) in ONE launch, and its input-gradient chain in one more (csrc/bneck.hip; a workgroup per strip of 8
+ * image rows, the planes-channel intermediates never leave the CU).  M = B*H*W pixels, NHWC.
  *   sedt_bneck_fwd: a = relu(s1 (x W1^T) + b1); b = relu(s2 conv3x3(a, W2) + b2); y = relu(s3 (b W3^T) + b3 + x)
- *     x, y [B*H*16][256] bf16 NHWC; w1/w2/w3_frag = sedt_pack_frag (src_bf16) of the forward operands of sedt_multi_pack ([Cout][taps][Cin]);
- *     s*, b* the folded FrozenBN scale / bias.  Training by-products, each group may be null: abits_out, bbits_out [B*H*16][8] = sign
- *     bits of a, b (bit c % 8 of byte c / 8) - all sedt_bneck_bwd needs of them, 1/16 of the bytes; a_out, b_out [B*H*16][64] - what a
- *     per-op backward with weight gradients reads; bits_out [B*H*16][32] = sign bits of y.
+ *     x, y [M][cin] bf16; w1/w2/w3_frag = sedt_pack_frag (src_bf16) of the forward operands of sedt_multi_pack ([Cout][taps][Cin]);
+ *     s*, b* the folded FrozenBN scale / bias.  Training by-products, each group may be null: abits_out, bbits_out [M][planes/8] = sign
+ *     bits of a, b (bit c % 8 of byte c / 8) - all sedt_bneck_bwd needs of them, 1/16 of the bytes; a_out, b_out [M][planes] - what the
+ *     weight-gradient GEMMs of a trainable block read; bits_out [M][cin/8] = sign bits of y.
  *   sedt_bneck_bwd: gb = (gy W3s) [b > 0]; ga = conv3x3^T(gb, W2s) [a > 0]; gx = (ga W1s + gy) [x > 0]
  *     w*t_frag = sedt_pack_frag (src_bf16) of the dgrad operands of sedt_multi_pack ([Cin][taps][Cout], BN scale folded in); gy is the
- *     gradient w.r.t. y already masked by [y > 0]; abits / bbits from the forward; xbits = sign bits of the block input, or null (no mask).  Weight gradients are NOT
- *     produced (layer1 is frozen in the reference, backbone.py:60-62; a trainable block keeps the per-op backward).
- * Envelope (sedt_bneck_ok): bf16, cin 256, planes 64, W 16, stride 1, dilation 1, no downsample. */
+ *     gradient w.r.t. y already masked by [y > 0]; abits / bbits from the forward; xbits = sign bits of the block input, or null (no mask).
+ *     gb_out, ga_out [M][planes] (both or none): the two intermediate gradients, left operands of the weight-gradient GEMMs of a
+ *     trainable block (layer2; layer1 is frozen in the reference, backbone.py:60-62, and needs neither).
+ * Envelope (sedt_bneck_ok): bf16, stride 1, dilation 1, no downsample, and (cin, planes, W) = (256, 64, 16) or (512, 128, 8). */
 int sedt_bneck_ok(int cin, int planes, int W, int stride, int dil, int has_downsample, int dtype);
 int sedt_bneck_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const float* s1, const float* b1,
                    const float* s2, const float* b2, const float* s3, const float* b3, void* a_out, void* b_out, uint8_t* abits_out,
-                   uint8_t* bbits_out, uint8_t* bits_out, int B, int H, void* stream);
+                   uint8_t* bbits_out, uint8_t* bits_out, int cin, int planes, int W, int B, int H, void* stream);
 int sedt_bneck_bwd(const void* gy, void* gx, const void* w3t_frag, const void* w2t_frag, const void* w1t_frag, const uint8_t* abits,
-                   const uint8_t* bbits, const uint8_t* xbits, int B, int H, void* stream);
+                   const uint8_t* bbits, const uint8_t* xbits, void* gb_out, void* ga_out, int cin, int planes, int W, int B, int H,
+                   void* stream);
 
 /* The prediction heads on the stacked decoder output hs [L*B*Qp][256] bf16 (sedt/sedt.py:88-95, 398-409) in ONE launch each way
  * (csrc/heads_slab.hip; a workgroup per 32 rows): class logits cls [rows][C1] = hs wc^T + bc, boxes [rows][2] = sigmoid(W3 relu(W2

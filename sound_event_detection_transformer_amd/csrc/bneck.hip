@@ -19,43 +19,55 @@
 namespace sedt {
 
 using slab::u32x4;
-using slab::XP;
 
-constexpr int BN_W = 16;                  // map width
-constexpr int BN_C = 256, BN_P = 64;      // block channels, bottleneck planes
-constexpr int BN_AP = BN_P + 8;           // element pitch of the 64-channel tiles: 144 B, conflict-free 16-byte fragment reads
-constexpr int BN_AW = BN_W + 2;           // a row of the zero-padded 3x3 input tile
+// Geometry of an identity Bottleneck: C block channels, P = C / 4 planes, W map columns; strips of R = 8 image rows.
+// layer1: C 256, P 64, W 16 (128-pixel strips); layer2: C 512, P 128, W 8 (64-pixel strips) - the same bytes per image row, so every
+// tile of the two has the same size in bytes and the same number of 16-byte pieces.
+template <int C_, int P_, int W_>
+struct BG {
+  static constexpr int C = C_, P = P_, W = W_, R = 8;
+  static constexpr int NP1 = (R + 2) * W, NP = R * W;                // pixels of the halo tile / of the strip
+  static constexpr int NS1 = (NP1 + 31) / 32, NS = NP / 32;          // their 32-pixel slabs (the last halo slab may be partial)
+  static constexpr int XP = C + 8, AP = P + 8, AW = W + 2;           // LDS pitches (elements): 16-byte fragment reads conflict-free
+  static constexpr int T12 = P / 32, T3 = C / 32;                    // output tiles of stages 1, 2 / of stage 3
+  static constexpr int KS1 = C / 16, KT = P / 16, KS3 = P / 16;      // k-steps of stage 1 / per tap of stage 2 / of stage 3
+  static constexpr int G1 = 4 / T12;                                 // slab groups of the four compute waves (tile = wave % T12, group = wave / T12)
+  static constexpr int S1 = 3, S2 = NS / G1;                         // slabs per compute wave in stage 1 / stage 2
+  static constexpr int T3W = T3 / 8;                                 // stage-3 tiles per wave (all eight waves)
+  static constexpr int NU = 9 * KT / 4;                              // stage 2 as a stream of 4-fragment units (a tap = KT / 4 units)
+  static constexpr int CP = C / 8, PP = P / 8;                       // 16-byte pieces (= sign-bit bytes) per pixel of a C- / P-channel row
+  static constexpr int NX = NP1 * CP / 256;                          // pieces of the in tile per moving thread
+  static_assert(T12 * G1 == 4 && G1 * S1 >= NS1 && S2 * G1 == NS && T3W * 8 == T3 && KS1 % 16 == 0 && KT % 4 == 0, "wave assignment");
+  static_assert(NX == 20 && NP1 * PP == 80 * 16 && NP * PP == 64 * 16 && NP * CP == 256 * 16 && W * CP == 512, "tile pieces");
+};
 
 struct BneckArgs {
-  const bf16_t* in;                  // x (forward) / gy (backward) [B*H*16][256]
+  const bf16_t* in;                  // x (forward) / gy (backward) [B*H*W][C]
   bf16_t* out;                       // y / gx
-  const u32x4* wA;                   // [64][256]  conv1 (fwd) / (s3 . conv3)^T (bwd), fragment-major
-  const u32x4* wB;                   // [64][9*64] conv2, k = tap * 64 + channel
-  const u32x4* wC;                   // [256][64]  conv3 (fwd) / (s1 . conv1)^T (bwd)
+  const u32x4* wA;                   // [P][C]    conv1 (fwd) / (s3 . conv3)^T (bwd), fragment-major
+  const u32x4* wB;                   // [P][9*P]  conv2, k = tap * P + channel
+  const u32x4* wC;                   // [C][P]    conv3 (fwd) / (s1 . conv1)^T (bwd)
   const float* sA; const float* bA; const float* sB; const float* bB; const float* sC; const float* bC;   // folded BN (fwd)
-  bf16_t* a_out; bf16_t* b_out;      // fwd by-products [M][64] or null (what a per-op backward with weight gradients reads)
-  uint8_t* abits_out; uint8_t* bbits_out;      // fwd: sign bits of a, b [M][8] or null (ALL the fused backward needs of them)
-  uint8_t* bits_out;                 // fwd: sign bits of y [M][32] or null
+  bf16_t* a_out; bf16_t* b_out;      // [M][P] or null: fwd the two intermediates a, b; bwd their gradients ga (stage 2) and gb (stage 1) - what
+                                     // the weight-gradient GEMMs of a trainable block read (a_out <- stage 1, b_out <- stage 2)
+  uint8_t* abits_out; uint8_t* bbits_out;      // fwd: sign bits of a, b [M][P/8] or null (ALL the fused backward needs of them)
+  uint8_t* bits_out;                 // fwd: sign bits of y [M][C/8] or null
   const uint8_t* abits_in; const uint8_t* bbits_in;      // bwd: sign bits of the saved a, b
-  const uint8_t* bits_in;            // bwd: sign bits of the block input [M][32], or null (no mask)
+  const uint8_t* bits_in;            // bwd: sign bits of the block input [M][C/8], or null (no mask)
   int B, H, spw;                     // spw: consecutive strips per workgroup
   int dbg;                           // developer build: phase ablation (1 stage 1, 2 stage 2, 4 stage 3, 8 stores, 16 tile loads)
 };
 
-constexpr int BN_R = 8;                                           // image rows of a strip
-constexpr int BN_NP1 = (BN_R + 2) * BN_W, BN_NP = BN_R * BN_W;    // pixels of the halo tile / of the strip: 160 / 128
-constexpr int BN_NS1 = BN_NP1 / 32, BN_NS = BN_NP / 32;           // their 32-pixel slabs: 5 / 4
-
-template <bool BWD>
+template <class G, bool BWD>
 struct BneckLds {
   static constexpr size_t XT = 0;
-  static constexpr size_t AT = XT + (size_t)BN_NP1 * XP * 2;
-  static constexpr size_t BT = AT + (size_t)(BN_R + 2) * BN_AW * BN_AP * 2;
-  static constexpr size_t BITS = BT + (size_t)BN_NP * BN_AP * 2;                // [NP][32]
-  static constexpr size_t MH = BITS + (size_t)BN_NP * 32;                       // [NP1][8] sign bits on the halo tile: of a (fwd, out) / b (bwd, in)
-  static constexpr size_t MA = MH + (size_t)BN_NP1 * 8;                         // [NP][8] sign bits on the strip: of b (fwd, out) / a (bwd, in)
-  static constexpr size_t SB = MA + (size_t)BN_NP * 8;
-  static constexpr size_t TOTAL = SB + (BWD ? 0 : 768 * 4);
+  static constexpr size_t AT = XT + (size_t)G::NP1 * G::XP * 2;
+  static constexpr size_t BT = AT + (size_t)(G::R + 2) * G::AW * G::AP * 2;
+  static constexpr size_t BITS = BT + (size_t)G::NP * G::AP * 2;                // [NP][C/8]
+  static constexpr size_t MH = BITS + (size_t)G::NP * G::CP;                    // [NP1][P/8] sign bits on the halo tile: of a (fwd, out) / b (bwd, in)
+  static constexpr size_t MA = MH + (size_t)G::NP1 * G::PP;                     // [NP][P/8] sign bits on the strip: of b (fwd, out) / a (bwd, in)
+  static constexpr size_t SB = MA + (size_t)G::NP * G::PP;
+  static constexpr size_t TOTAL = SB + (BWD ? 0 : (4 * G::P + 2 * G::C) * 4);
 };
 
 // NSW pixel slabs x one output tile over NKS k-steps (chunks of 8 fragments alternating cur / alt as in slab::wave_gemm)
@@ -85,7 +97,7 @@ __device__ __forceinline__ void gemm_slabs(f32x16 (&acc)[NSW], const bf16_t* xs,
   }
 }
 
-// four fragments (one tap of the 3x3, or a 64-deep 1x1) into dst[o .. o + 3]
+// four fragments (a 4-k-step unit of one tile) into dst[o .. o + 3]
 template <int NR>
 __device__ __forceinline__ void load4(u32x4 (&dst)[NR], int o, const u32x4* __restrict__ W, int lane) {
 #pragma unroll
@@ -122,71 +134,63 @@ __device__ __forceinline__ unsigned nibble4(unsigned w0, unsigned w1) {
   return (t | (t >> 15)) & 0xfu;
 }
 
-// sign bits of 8 bf16 values (a 16-byte piece): bit e <-> element e > 0
-__device__ __forceinline__ unsigned sign_byte(u32x4 v) {
-  const unsigned w[4] = {v[0], v[1], v[2], v[3]};
-  unsigned m = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned lo = w[i] & 0xffffu, hi = w[i] >> 16;
-    m |= ((lo != 0u && lo < 0x8000u) ? 1u : 0u) << (2 * i);
-    m |= ((hi != 0u && hi < 0x8000u) ? 1u : 0u) << (2 * i + 1);
-  }
-  return m;
-}
-
 // The workgroup walks `spw` consecutive strips, one workgroup per CU (the tile is 84 KB of LDS).  What the measurements of the earlier
 // versions say (profiles/r04_bneck_ablation.txt): a strip is bound by the L2 -> CU weight stream (~40 B/clk/CU, csrc/slab.h), not by HBM
-// and not by the MFMAs - so a weight fragment has to serve as many pixels as the accumulators allow (8-row strips: 2-3 slabs per
-// fragment; the 4-row version with two tile buffers streamed twice the bytes per pixel and took 8.6 us per 64 pixels) - and HBM latency
-// must never sit inside a stage.  Waves 0..3 COMPUTE stages 1 and 2 (one per SIMD; the weight stream never stops: the next chunk / tap /
-// strip is always in flight) and issue no stores (loads and stores share one in-order counter: a store ahead of a weight fragment would
-// hold the MFMA that waits for the fragment until HBM has acknowledged the store); waves 4..7 MOVE: they hold the NEXT strip's tile in
-// registers for a whole strip (issued right after the current tile went to LDS) and write the first intermediate out; stage 3 and the
-// output stores are everybody's.
+// and not by the MFMAs - so a weight fragment has to serve as many pixels as the accumulators allow (2-3 slabs per fragment; a 4-row
+// version with two tile buffers streamed twice the bytes per pixel and took 8.6 us per 64 pixels) - and HBM latency must never sit
+// inside a stage.  Waves 0..3 COMPUTE stages 1 and 2 (one per SIMD; the weight stream never stops: the next chunk / tap / strip is
+// always in flight) and issue no stores (loads and stores share one in-order counter: a store ahead of a weight fragment would hold the
+// MFMA that waits for the fragment until HBM has acknowledged the store); waves 4..7 MOVE: they hold the NEXT strip's tile in registers
+// for a whole strip (issued right after the current tile went to LDS) and write the first intermediate out; stage 3 and the output
+// stores are everybody's.
 //   A(s) .. B(s): compute stage 1 (reads XT, writes AT)             | move: issue the loads of strip s + 1 (registers)
-//   B(s) .. C(s): compute stage 2 (reads AT, writes BT)             | move: store a of s (AT)
+//   B(s) .. C(s): compute stage 2 (reads AT, writes BT)             | move: store the stage-1 result of s (AT)
 //   C(s) .. D(s): all: stage 3 (reads BT, XT in place, BITS)
-//   D(s) .. E(s): all: store y / b / bits of s (XT, BT, BITS)
-//   E(s) .. A(s+1): move: registers -> XT (+ the sign bits of a, b of strip s + 1; bwd)
-template <bool BWD>
+//   D(s) .. E(s): all: store out / stage-2 result / sign bits of s (XT, BT, BITS, MA)
+//   E(s) .. A(s+1): move: registers -> XT (+ the sign bits of strip s + 1; bwd)
+template <class G, bool BWD>
 __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
-  using LD = BneckLds<BWD>;
-  constexpr int NP1 = BN_NP1, NP = BN_NP, NS1 = BN_NS1, NS = BN_NS, R = BN_R;
-  static_assert(NS1 == 5 && NS == 4, "the wave assignment below is written for 8-row strips");
+  using LD = BneckLds<G, BWD>;
+  constexpr int NP1 = G::NP1, NP = G::NP, NS1 = G::NS1, NS = G::NS, R = G::R, W = G::W, C = G::C, P = G::P;
+  constexpr int XP = G::XP, AP = G::AP, AW = G::AW, CP = G::CP, PP = G::PP, NX = G::NX;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   bf16_t* XT = reinterpret_cast<bf16_t*>(smem + LD::XT);        // [NP1][XP]: in tile, halo row first; becomes the out tile
-  bf16_t* AT = reinterpret_cast<bf16_t*>(smem + LD::AT);        // [(R + 2)][18][AP]: 3x3 input, zero border
+  bf16_t* AT = reinterpret_cast<bf16_t*>(smem + LD::AT);        // [(R + 2)][W + 2][AP]: 3x3 input, zero border
   bf16_t* BT = reinterpret_cast<bf16_t*>(smem + LD::BT);        // [NP][AP]: 3x3 output
-  uint8_t* BITS = smem + LD::BITS;                              // [NP][32]: fwd sign bits of y; bwd sign bits of the block input
-  uint8_t* MH = smem + LD::MH;                                  // [NP1][8]
-  uint8_t* MA = smem + LD::MA;                                  // [NP][8]
-  float* SB = reinterpret_cast<float*>(smem + LD::SB);          // fwd: sA bA sB bB (64 each) sC bC (256 each)
+  uint8_t* BITS = smem + LD::BITS;                              // [NP][C/8]: fwd sign bits of y; bwd sign bits of the block input
+  uint8_t* MH = smem + LD::MH;                                  // [NP1][P/8]
+  uint8_t* MA = smem + LD::MA;                                  // [NP][P/8]
+  float* SB = reinterpret_cast<float*>(smem + LD::SB);          // fwd: sA bA sB bB (P each) sC bC (C each)
   const int tid = threadIdx.x, wave = tid >> 6;
   const int strips = (a.H + R - 1) / R, nst = a.B * strips;
   const int first = blockIdx.x * a.spw, last = min(first + a.spw, nst);
   if (first >= last) return;
   const bool comp = wave < 4;
-  const int tl = wave & 1, grp = (wave >> 1) & 1;               // compute waves: output tile of stages 1 / 2, slab group
-  constexpr int NX = NP1 * 32 / 256;                            // 16-byte pieces of the in tile per moving thread: 20
-  static_assert(NX == 20 && NP1 * 8 == 80 * 16 && NP * 8 == 64 * 16 && NP * 2 == 256, "tile pieces");
+  const int tl = wave % G::T12, grp = (wave / G::T12) % G::G1;  // compute waves: output tile of stages 1 / 2, slab group
 
   // ONE register pool for both roles (a wave computes or moves for its whole life): the compute waves' weight chunks cur = pool[0..7],
   // alt = pool[8..15]; the moving waves' tile in flight xr = pool[0..19] and (bwd) the three sign-bit pieces pool[20..22]
-  u32x4 pool[BWD ? 23 : 20], w3r[4];
+  constexpr int NW3 = G::T3W * G::KS3;                          // stage-3 fragments of a wave: 4 (kept for every strip) or 16 (loaded per strip)
+  constexpr bool W3_KEPT = NW3 <= 4;
+  u32x4 pool[BWD ? 23 : 20], w3r[NW3];
   u32x4(&cur)[8] = *reinterpret_cast<u32x4(*)[8]>(&pool[0]);
   u32x4(&alt)[8] = *reinterpret_cast<u32x4(*)[8]>(&pool[8]);
   u32x4(&xr)[20] = *reinterpret_cast<u32x4(*)[20]>(&pool[0]);
-  const u32x4* w1p = a.wA + (long)tl * 16 * 64;
-  const u32x4* w2p = a.wB + (long)tl * 36 * 64;
-  load4(w3r, 0, a.wC + (long)wave * 4 * 64, tid & 63);           // stage 3: tile = wave - the same four fragments for every strip
+  const u32x4* w1p = a.wA + (long)tl * G::KS1 * 64;
+  const u32x4* w2p = a.wB + (long)tl * (9 * G::KT) * 64;
+  const u32x4* w3p = a.wC + (long)(wave * G::T3W) * G::KS3 * 64;            // stage 3: tiles wave * T3W + [0, T3W), KS3 fragments each, contiguous
+  auto load_w3 = [&](int t, int lane) {                         // tile t of this wave into half t & 1 of w3r
+#pragma unroll
+    for (int u = 0; u < G::KS3; ++u) w3r[(NW3 > G::KS3 ? (t & 1) * G::KS3 : 0) + u] = w3p[(t * G::KS3 + u) * 64 + lane];
+  };
+  if (W3_KEPT) load_w3(0, tid & 63);
   if (comp) slab::load_chunk<1>(cur, w1p, 0, 0, tid & 63);
   slab::issue_fence();
 
   auto geom = [&](int s, int& r0, long& pix0) {
     const int clip = s / strips;
     r0 = (s % strips) * R;
-    pix0 = ((long)clip * a.H + r0) * BN_W;
+    pix0 = ((long)clip * a.H + r0) * W;
   };
   const u32x4 zero4 = {0u, 0u, 0u, 0u}, ones4 = {~0u, ~0u, ~0u, ~0u};
   // the in tile of strip s into the moving threads' registers / from there into LDS
@@ -196,21 +200,21 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
     const int mt = opaque(tid) - 256;
 #pragma unroll
     for (int q = 0; q < NX; ++q) {
-      const int u = mt + q * 256, p = u >> 5, c = (u & 31) * 8, gr = r0 - 1 + (p >> 4);
-      xr[q] = (gr >= 0 && gr < a.H) ? *reinterpret_cast<const u32x4*>(a.in + (pix0 + p - BN_W) * BN_C + c) : zero4;
+      const int u = mt + q * 256, p = u / CP, c = (u % CP) * 8, gr = r0 - 1 + p / W;
+      xr[q] = (gr >= 0 && gr < a.H) ? *reinterpret_cast<const u32x4*>(a.in + (pix0 + p - W) * C + c) : zero4;
     }
-    if (BWD) {                                                   // sign bits: b on the halo tile, a, the block input (16-byte pieces = 2 pixels)
+    if (BWD) {          // sign bits: b on the halo tile, a, the block input (an image row is 8 / 8 / 32 pieces of 16 bytes in both geometries)
       const int grh = r0 - 1 + (mt >> 3);
-      pool[BWD ? 20 : 0] = (mt < 80 && grh >= 0 && grh < a.H) ? reinterpret_cast<const u32x4*>(a.bbits_in + (pix0 - BN_W) * 8)[mt] : zero4;
-      pool[BWD ? 21 : 0] = (mt < 64 && r0 + (mt >> 3) < a.H) ? reinterpret_cast<const u32x4*>(a.abits_in + pix0 * 8)[mt] : zero4;
-      pool[BWD ? 22 : 0] = !a.bits_in ? ones4 : r0 + (mt >> 5) < a.H ? reinterpret_cast<const u32x4*>(a.bits_in + pix0 * 32)[mt] : zero4;
+      pool[BWD ? 20 : 0] = (mt < 80 && grh >= 0 && grh < a.H) ? reinterpret_cast<const u32x4*>(a.bbits_in + (pix0 - W) * PP)[mt] : zero4;
+      pool[BWD ? 21 : 0] = (mt < 64 && r0 + (mt >> 3) < a.H) ? reinterpret_cast<const u32x4*>(a.abits_in + pix0 * PP)[mt] : zero4;
+      pool[BWD ? 22 : 0] = !a.bits_in ? ones4 : r0 + (mt >> 5) < a.H ? reinterpret_cast<const u32x4*>(a.bits_in + pix0 * CP)[mt] : zero4;
     }
   };
   auto put = [&]() {
     const int mt = opaque(tid) - 256;
 #pragma unroll
     for (int q = 0; q < NX; ++q) {
-      const int u = mt + q * 256, p = u >> 5, c = (u & 31) * 8;
+      const int u = mt + q * 256, p = u / CP, c = (u % CP) * 8;
       *reinterpret_cast<u32x4*>(XT + p * XP + c) = xr[q];
     }
     if (BWD) {
@@ -221,11 +225,11 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
   };
 
   // ---- prologue: constants, the zero border of the 3x3 input tile, the first strip's tiles
-  for (int u = tid; u < (R + 2) * BN_AW * BN_AP / 8; u += 512) reinterpret_cast<uint4*>(AT)[u] = make_uint4(0, 0, 0, 0);
+  for (int u = tid; u < (R + 2) * AW * AP / 8; u += 512) reinterpret_cast<uint4*>(AT)[u] = make_uint4(0, 0, 0, 0);
   if (!BWD)
-    for (int u = tid; u < 768; u += 512) {
-      const float* src = u < 64 ? a.sA + u : u < 128 ? a.bA + (u - 64) : u < 192 ? a.sB + (u - 128) : u < 256 ? a.bB + (u - 192)
-                         : u < 512 ? a.sC + (u - 256) : a.bC + (u - 512);
+    for (int u = tid; u < 4 * P + 2 * C; u += 512) {
+      const float* src = u < P ? a.sA + u : u < 2 * P ? a.bA + (u - P) : u < 3 * P ? a.sB + (u - 2 * P) : u < 4 * P ? a.bB + (u - 3 * P)
+                         : u < 4 * P + C ? a.sC + (u - 4 * P) : a.bC + (u - 4 * P - C);
       SB[u] = *src;
     }
   if (!comp) {
@@ -244,15 +248,15 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
     // ---- A(s) .. B(s)
     if (comp) {
      if (!(a.dbg & 1)) {
-      // stage 1: 1x1, 256 -> 64 on the halo tile: tile tl, slabs 3 * grp + {0, 1, 2} (slab 5 does not exist: computed on whatever follows
-      // the tile in LDS and dropped)
+      // stage 1: 1x1, C -> P on the halo tile: tile tl, slabs 3 * grp + {0, 1, 2} (pixels past the tile: computed on whatever follows it
+      // in LDS and dropped)
       f32x16 acc[3];
       slab::zero_acc<3>(acc);
-      gemm_slabs<3, 16>(acc, XT + (3 * grp) * 32 * XP, XP, w1p, lane, cur, alt, [&](u32x4(&d)[8]) {
-        load4(d, 0, w2p, lane);                                  // taps 0, 1 of the 3x3 (land in cur)
+      gemm_slabs<3, G::KS1>(acc, XT + (3 * grp) * 32 * XP, XP, w1p, lane, cur, alt, [&](u32x4(&d)[8]) {
+        load4(d, 0, w2p, lane);                                  // units 0, 1 of the 3x3 (land in cur)
         load4(d, 4, w2p + 4 * 64, lane);
       });
-      load4(alt, 0, w2p + 8 * 64, lane);                         // taps 2, 3
+      load4(alt, 0, w2p + 8 * 64, lane);                         // units 2, 3
       load4(alt, 4, w2p + 12 * 64, lane);
       slab::issue_fence();
       float4 sc[4], bi[4];
@@ -260,18 +264,19 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           sc[g4] = *reinterpret_cast<const float4*>(SB + tl * 32 + 8 * g4 + 4 * hf);
-          bi[g4] = *reinterpret_cast<const float4*>(SB + 64 + tl * 32 + 8 * g4 + 4 * hf);
+          bi[g4] = *reinterpret_cast<const float4*>(SB + P + tl * 32 + 8 * g4 + 4 * hf);
         }
       }
 #pragma unroll
       for (int s3 = 0; s3 < 3; ++s3) {
         const int sl = 3 * grp + s3;
         if (sl < NS1) {
-          const int p = sl * 32 + n, trow = p >> 4, pc = p & 15, gr = r0 - 1 + trow;
+          const int p = sl * 32 + n, trow = p / W, pc = p % W, gr = r0 - 1 + trow;
+          const bool intile = NP1 % 32 == 0 || p < NP1;          // (the last slab of the halo tile may be partial)
           const bool inimg = gr >= 0 && gr < a.H;
-          bf16_t* dst = AT + (trow * BN_AW + pc + 1) * BN_AP + tl * 32 + 4 * hf;
+          bf16_t* dst = AT + (trow * AW + pc + 1) * AP + tl * 32 + 4 * hf;
           unsigned m4 = 0, nb = 0;
-          if (BWD) m4 = *reinterpret_cast<const unsigned*>(MH + p * 8 + tl * 4) >> (4 * hf);       // bytes g4 = 0..3 of this tile
+          if (BWD && intile) m4 = *reinterpret_cast<const unsigned*>(MH + p * PP + tl * 4) >> (4 * hf);       // bytes g4 = 0..3 of this tile
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const f32x2 lo = {acc[s3][4 * g4], acc[s3][4 * g4 + 1]}, hi = {acc[s3][4 * g4 + 2], acc[s3][4 * g4 + 3]};
@@ -285,11 +290,11 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
               if (!inimg) o = make_uint2(0, 0);
               nb |= nibble4(o.x, o.y) << (8 * g4 + 4 * hf);
             }
-            *reinterpret_cast<uint2*>(dst + 8 * g4) = o;
+            if (intile) *reinterpret_cast<uint2*>(dst + 8 * g4) = o;
           }
           if (!BWD && a.abits_out) {                             // the two lane halves hold the two nibbles of every byte
             const unsigned other = (unsigned)__shfl_xor((int)nb, 32);
-            if (hf == 0) *reinterpret_cast<unsigned*>(MH + p * 8 + tl * 4) = nb | other;
+            if (hf == 0 && intile) *reinterpret_cast<unsigned*>(MH + p * PP + tl * 4) = nb | other;
           }
         }
       }
@@ -302,50 +307,52 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
     // ---- B(s) .. C(s)
     if (comp) {
      if (!(a.dbg & 2)) {
-      // stage 2: 3x3, 64 -> 64: tile tl, slabs 2 * grp + {0, 1}
-      f32x16 acc[2];
-      slab::zero_acc<2>(acc);
-      const bf16_t* ctr[2];                                      // lane n <-> pixel: centre of its 3x3 neighbourhood in the padded tile
+      // stage 2: 3x3, P -> P: tile tl, slabs S2 * grp + [0, S2)
+      constexpr int S2 = G::S2, UPT = G::KT / 4;                 // (units per tap)
+      f32x16 acc[S2];
+      slab::zero_acc<S2>(acc);
+      const bf16_t* ctr[S2];                                     // lane n <-> pixel: centre of its 3x3 neighbourhood in the padded tile
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int q = (grp * 2 + s2) * 32 + n;
-        ctr[s2] = AT + (((q >> 4) + 1) * BN_AW + (q & 15) + 1) * BN_AP + 8 * hf;
+      for (int s2 = 0; s2 < S2; ++s2) {
+        const int q = (grp * S2 + s2) * 32 + n;
+        ctr[s2] = AT + ((q / W + 1) * AW + q % W + 1) * AP + 8 * hf;
       }
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        // tap t sits in quarter t % 4 of (cur | alt); three taps are in flight behind it
-        u32x4(&src)[8] = (tap & 2) ? alt : cur;
-        const int so = (tap & 1) * 4;
+      for (int u = 0; u < G::NU; ++u) {
+        // unit u sits in quarter u % 4 of (cur | alt); three units are in flight behind it
+        u32x4(&src)[8] = (u & 2) ? alt : cur;
+        const int so = (u & 1) * 4;
+        const int tap = u / UPT, kk0 = (u % UPT) * 4;
         const int dr = tap / 3 - 1, dc = tap % 3 - 1;
-        const int off = (BWD ? -(dr * BN_AW + dc) : (dr * BN_AW + dc)) * BN_AP;     // the input gradient mirrors the taps
-        bf16x8 xb[4][2];
+        const int off = (BWD ? -(dr * AW + dc) : (dr * AW + dc)) * AP + kk0 * 16;       // the input gradient mirrors the taps
+        bf16x8 xb[4][S2];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) xb[kk][s2] = *reinterpret_cast<const bf16x8*>(ctr[s2] + off + kk * 16);
+          for (int s2 = 0; s2 < S2; ++s2) xb[kk][s2] = *reinterpret_cast<const bf16x8*>(ctr[s2] + off + kk * 16);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2)
+          for (int s2 = 0; s2 < S2; ++s2)
             acc[s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, src[so + kk]), xb[kk][s2], acc[s2], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (tap + 4 < 9) load4(src, so, w2p + (long)(tap + 4) * 4 * 64, lane);
-        if (tap == 8) slab::load_chunk<1>(cur, w1p, 0, 0, lane);  // the next strip's first chunk (cur is free from here)
+        if (u + 4 < G::NU) load4(src, so, w2p + (long)(u + 4) * 4 * 64, lane);
+        if (u == G::NU - 1) slab::load_chunk<1>(cur, w1p, 0, 0, lane);  // the next strip's first chunk (cur is free from here)
         __builtin_amdgcn_sched_barrier(0);
       }
       float4 sc[4], bi[4];
       if (!BWD) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          sc[g4] = *reinterpret_cast<const float4*>(SB + 128 + tl * 32 + 8 * g4 + 4 * hf);
-          bi[g4] = *reinterpret_cast<const float4*>(SB + 192 + tl * 32 + 8 * g4 + 4 * hf);
+          sc[g4] = *reinterpret_cast<const float4*>(SB + 2 * P + tl * 32 + 8 * g4 + 4 * hf);
+          bi[g4] = *reinterpret_cast<const float4*>(SB + 3 * P + tl * 32 + 8 * g4 + 4 * hf);
         }
       }
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int q = (grp * 2 + s2) * 32 + n;
+      for (int s2 = 0; s2 < S2; ++s2) {
+        const int q = (grp * S2 + s2) * 32 + n;
         unsigned m4 = 0, nb = 0;
-        if (BWD) m4 = *reinterpret_cast<const unsigned*>(MA + q * 8 + tl * 4) >> (4 * hf);
+        if (BWD) m4 = *reinterpret_cast<const unsigned*>(MA + q * PP + tl * 4) >> (4 * hf);
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int ch = tl * 32 + 8 * g4 + 4 * hf;
@@ -359,79 +366,87 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
             o.y = pack2(relu2(hi * f32x2{sc[g4].z, sc[g4].w} + f32x2{bi[g4].z, bi[g4].w}));
             nb |= nibble4(o.x, o.y) << (8 * g4 + 4 * hf);
           }
-          *reinterpret_cast<uint2*>(BT + q * BN_AP + ch) = o;
+          *reinterpret_cast<uint2*>(BT + q * AP + ch) = o;
         }
         if (!BWD && a.bbits_out) {
           const unsigned other = (unsigned)__shfl_xor((int)nb, 32);
-          if (hf == 0) *reinterpret_cast<unsigned*>(MA + q * 8 + tl * 4) = nb | other;
+          if (hf == 0) *reinterpret_cast<unsigned*>(MA + q * PP + tl * 4) = nb | other;
         }
       }
      }
-    } else if (!BWD && !(a.dbg & 8)) {
-      if (a.a_out)
-        for (int u = mt; u < NP * 8; u += 256) {
-          const int q = u >> 3, c = (u & 7) * 8;
-          if ((q >> 4) < rows_in)
-            *reinterpret_cast<uint4*>(a.a_out + (pix0 + q) * BN_P + c) =
-                *reinterpret_cast<const uint4*>(AT + (((q >> 4) + 1) * BN_AW + (q & 15) + 1) * BN_AP + c);
+    } else if (!(a.dbg & 8)) {
+      if (a.a_out)                                               // the stage-1 result on the strip's own rows
+        for (int u = mt; u < NP * PP; u += 256) {
+          const int q = u / PP, c = (u % PP) * 8;
+          if (q / W < rows_in)
+            *reinterpret_cast<uint4*>(a.a_out + (pix0 + q) * P + c) = *reinterpret_cast<const uint4*>(AT + ((q / W + 1) * AW + q % W + 1) * AP + c);
         }
-      if (a.abits_out && mt < 64 && (mt >> 3) < rows_in)         // (interior rows of the halo tile: 2 pixels per 16-byte piece)
-        reinterpret_cast<uint4*>(a.abits_out + pix0 * 8)[mt] = reinterpret_cast<const uint4*>(MH + BN_W * 8)[mt];
+      if (!BWD && a.abits_out && mt < 64 && (mt >> 3) < rows_in)         // (the strip's own rows of the halo tile)
+        reinterpret_cast<uint4*>(a.abits_out + pix0 * PP)[mt] = reinterpret_cast<const uint4*>(MH + W * PP)[mt];
     }
+    if (!W3_KEPT) load_w3(0, lane);                              // (two tiles per wave: loaded per strip, the first in flight across the barrier)
     __syncthreads();
 
-    // ---- C(s) .. D(s): stage 3 (all waves, tile = wave): 1x1, 64 -> 256, + the in tile (residual), ReLU / sign-bit mask, in place
+    // ---- C(s) .. D(s): stage 3 (all waves, tiles wave * T3W + t): 1x1, P -> C, + the in tile (residual), ReLU / sign-bit mask, in place
     if (!(a.dbg & 4)) {
-      f32x16 acc[NS];
-      slab::zero_acc<NS>(acc);
-      const bf16_t* xrow = BT + n * BN_AP + 8 * hf;
+      constexpr int T3W = G::T3W;
+      const bf16_t* xrow = BT + n * AP + 8 * hf;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        bf16x8 xb[NS];
+      for (int t = 0; t < T3W; ++t) {
+        const int tile = wave * T3W + t;
+        if (!W3_KEPT && t + 1 < T3W) load_w3(t + 1, lane);        // (the next tile's fragments land while this one is multiplied)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[NS];
+        slab::zero_acc<NS>(acc);
 #pragma unroll
-        for (int s3 = 0; s3 < NS; ++s3) xb[s3] = *reinterpret_cast<const bf16x8*>(xrow + s3 * 32 * BN_AP + kk * 16);
+        for (int kk = 0; kk < G::KS3; ++kk) {
+          bf16x8 xb[NS];
 #pragma unroll
-        for (int s3 = 0; s3 < NS; ++s3)
-          acc[s3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w3r[kk]), xb[s3], acc[s3], 0, 0, 0);
-      }
-      float4 sc[4], bi[4];
-      if (!BWD) {
+          for (int s3 = 0; s3 < NS; ++s3) xb[s3] = *reinterpret_cast<const bf16x8*>(xrow + s3 * 32 * AP + kk * 16);
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          sc[g4] = *reinterpret_cast<const float4*>(SB + 256 + wave * 32 + 8 * g4 + 4 * hf);
-          bi[g4] = *reinterpret_cast<const float4*>(SB + 512 + wave * 32 + 8 * g4 + 4 * hf);
+          for (int s3 = 0; s3 < NS; ++s3)
+            acc[s3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w3r[(NW3 > G::KS3 ? (t & 1) * G::KS3 : 0) + kk]), xb[s3],
+                                                              acc[s3], 0, 0, 0);
         }
-      }
-      unsigned nibs[NS];                                         // fwd: this lane's sign nibbles of slab s3, nibble g4 at bits 8 * g4 (+ 4 * hf)
+        float4 sc[4], bi[4];
+        if (!BWD) {
 #pragma unroll
-      for (int s3 = 0; s3 < NS; ++s3) {
-        const int q = s3 * 32 + n;
-        bf16_t* xp = XT + (q + BN_W) * XP + wave * 32 + 4 * hf;
-        unsigned m4 = 0;
-        if (BWD) m4 = *reinterpret_cast<const unsigned*>(BITS + q * 32 + wave * 4) >> (4 * hf);
-        nibs[s3] = 0;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const uint2 xw = *reinterpret_cast<const uint2*>(xp + 8 * g4);
-          const f32x2 lo = {acc[s3][4 * g4], acc[s3][4 * g4 + 1]}, hi = {acc[s3][4 * g4 + 2], acc[s3][4 * g4 + 3]};
-          uint2 o;
-          if (BWD) {
-            o.x = pack2(lo + widen2(xw.x)) & keep2(m4, 8 * g4);
-            o.y = pack2(hi + widen2(xw.y)) & keep2(m4, 8 * g4 + 2);
-          } else {
-            o.x = pack2(relu2(lo * f32x2{sc[g4].x, sc[g4].y} + f32x2{bi[g4].x, bi[g4].y} + widen2(xw.x)));
-            o.y = pack2(relu2(hi * f32x2{sc[g4].z, sc[g4].w} + f32x2{bi[g4].z, bi[g4].w} + widen2(xw.y)));
-            nibs[s3] |= nibble4(o.x, o.y) << (8 * g4 + 4 * hf);
+          for (int g4 = 0; g4 < 4; ++g4) {
+            sc[g4] = *reinterpret_cast<const float4*>(SB + 4 * P + tile * 32 + 8 * g4 + 4 * hf);
+            bi[g4] = *reinterpret_cast<const float4*>(SB + 4 * P + C + tile * 32 + 8 * g4 + 4 * hf);
           }
-          *reinterpret_cast<uint2*>(xp + 8 * g4) = o;
         }
-      }
-      if (!BWD && a.bits_out) {
-        // the two lane halves hold the two nibbles of every byte: one exchange per slab, one 4-byte store by the lower half
+        unsigned nibs[NS];                                       // fwd: this lane's sign nibbles of slab s3, nibble g4 at bits 8 * g4 (+ 4 * hf)
 #pragma unroll
         for (int s3 = 0; s3 < NS; ++s3) {
-          const unsigned other = (unsigned)__shfl_xor((int)nibs[s3], 32);
-          if (hf == 0) *reinterpret_cast<unsigned*>(BITS + (s3 * 32 + n) * 32 + wave * 4) = nibs[s3] | other;
+          const int q = s3 * 32 + n;
+          bf16_t* xp = XT + (q + W) * XP + tile * 32 + 4 * hf;
+          unsigned m4 = 0;
+          if (BWD) m4 = *reinterpret_cast<const unsigned*>(BITS + q * CP + tile * 4) >> (4 * hf);
+          nibs[s3] = 0;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const uint2 xw = *reinterpret_cast<const uint2*>(xp + 8 * g4);
+            const f32x2 lo = {acc[s3][4 * g4], acc[s3][4 * g4 + 1]}, hi = {acc[s3][4 * g4 + 2], acc[s3][4 * g4 + 3]};
+            uint2 o;
+            if (BWD) {
+              o.x = pack2(lo + widen2(xw.x)) & keep2(m4, 8 * g4);
+              o.y = pack2(hi + widen2(xw.y)) & keep2(m4, 8 * g4 + 2);
+            } else {
+              o.x = pack2(relu2(lo * f32x2{sc[g4].x, sc[g4].y} + f32x2{bi[g4].x, bi[g4].y} + widen2(xw.x)));
+              o.y = pack2(relu2(hi * f32x2{sc[g4].z, sc[g4].w} + f32x2{bi[g4].z, bi[g4].w} + widen2(xw.y)));
+              nibs[s3] |= nibble4(o.x, o.y) << (8 * g4 + 4 * hf);
+            }
+            *reinterpret_cast<uint2*>(xp + 8 * g4) = o;
+          }
+        }
+        if (!BWD && a.bits_out) {
+          // the two lane halves hold the two nibbles of every byte: one exchange per slab, one 4-byte store by the lower half
+#pragma unroll
+          for (int s3 = 0; s3 < NS; ++s3) {
+            const unsigned other = (unsigned)__shfl_xor((int)nibs[s3], 32);
+            if (hf == 0) *reinterpret_cast<unsigned*>(BITS + (s3 * 32 + n) * CP + tile * 4) = nibs[s3] | other;
+          }
         }
       }
     }
@@ -441,19 +456,19 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
     if (!(a.dbg & 8)) {
       const int t = opaque(tid);
 #pragma unroll 4
-      for (int u = t; u < NP * 32; u += 512) {
-        const int q = u >> 5, c = (u & 31) * 8;
-        if ((q >> 4) < rows_in) *reinterpret_cast<uint4*>(a.out + (pix0 + q) * BN_C + c) = *reinterpret_cast<const uint4*>(XT + (q + BN_W) * XP + c);
+      for (int u = t; u < NP * CP; u += 512) {
+        const int q = u / CP, c = (u % CP) * 8;
+        if (q / W < rows_in) *reinterpret_cast<uint4*>(a.out + (pix0 + q) * C + c) = *reinterpret_cast<const uint4*>(XT + (q + W) * XP + c);
       }
+      if (a.b_out)                                               // the stage-2 result
+        for (int u = t; u < NP * PP; u += 512) {
+          const int q = u / PP, c = (u % PP) * 8;
+          if (q / W < rows_in) *reinterpret_cast<uint4*>(a.b_out + (pix0 + q) * P + c) = *reinterpret_cast<const uint4*>(BT + q * AP + c);
+        }
       if (!BWD) {
-        if (a.b_out)
-          for (int u = t; u < NP * 8; u += 512) {
-            const int q = u >> 3, c = (u & 7) * 8;
-            if ((q >> 4) < rows_in) *reinterpret_cast<uint4*>(a.b_out + (pix0 + q) * BN_P + c) = *reinterpret_cast<const uint4*>(BT + q * BN_AP + c);
-          }
-        if (a.bits_out && t < NP * 2 && (t >> 5) < rows_in) reinterpret_cast<uint4*>(a.bits_out + pix0 * 32)[t] = reinterpret_cast<const uint4*>(BITS)[t];
+        if (a.bits_out && t < 256 && (t >> 5) < rows_in) reinterpret_cast<uint4*>(a.bits_out + pix0 * CP)[t] = reinterpret_cast<const uint4*>(BITS)[t];
         if (a.bbits_out && t >= 256 && t < 320 && ((t - 256) >> 3) < rows_in)
-          reinterpret_cast<uint4*>(a.bbits_out + pix0 * 8)[t - 256] = reinterpret_cast<const uint4*>(MA)[t - 256];
+          reinterpret_cast<uint4*>(a.bbits_out + pix0 * PP)[t - 256] = reinterpret_cast<const uint4*>(MA)[t - 256];
       }
     }
     if (more) {
@@ -465,12 +480,13 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
   }
 }
 
-template <bool BWD>
+template <class G, bool BWD>
 static int bneck_launch(BneckArgs& a, hipStream_t s, const char* what) {
-  using LD = BneckLds<BWD>;
+  using LD = BneckLds<G, BWD>;
+  static_assert(LD::TOTAL <= 160 * 1024, "LDS");
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LD::TOTAL);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_kernel<G, BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LD::TOTAL);
     if (e != hipSuccess) {
       set_error("%s: hipFuncSetAttribute(%zu B LDS) failed: %s", what, (size_t)LD::TOTAL, hipGetErrorString(e));
       return 1;
@@ -478,47 +494,61 @@ static int bneck_launch(BneckArgs& a, hipStream_t s, const char* what) {
     attr = true;
   }
   // one workgroup per CU: 256 workgroups walk ceil(strips / 256) consecutive strips each
-  const int nst = a.B * ((a.H + BN_R - 1) / BN_R);
+  const int nst = a.B * ((a.H + G::R - 1) / G::R);
   static int spw_env = [] { const char* e = dev_getenv("SEDT_BNECK_SPW"); return e ? atoi(e) : 0; }();
   a.spw = spw_env > 0 ? spw_env : (nst + 255) / 256;
   static int dbg_env = [] { const char* e = dev_getenv("SEDT_BNECK_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg_env;
-  hipLaunchKernelGGL((bneck_kernel<BWD>), dim3((nst + a.spw - 1) / a.spw), dim3(512), LD::TOTAL, s, a);
+  hipLaunchKernelGGL((bneck_kernel<G, BWD>), dim3((nst + a.spw - 1) / a.spw), dim3(512), LD::TOTAL, s, a);
   return check_launch(what);
 }
+
+typedef BG<256, 64, 16> BG1;          // layer1
+typedef BG<512, 128, 8> BG2;          // layer2
+
+static int bneck_geom(int cin, int planes, int W) { return (cin == 256 && planes == 64 && W == 16) ? 1 : (cin == 512 && planes == 128 && W == 8) ? 2 : 0; }
 
 }  // namespace sedt
 
 using namespace sedt;
 
 extern "C" int sedt_bneck_ok(int cin, int planes, int W, int stride, int dil, int has_downsample, int dtype) {
-  return dtype == SEDT_BF16 && cin == BN_C && planes == BN_P && W == BN_W && stride == 1 && dil == 1 && !has_downsample;
+  return dtype == SEDT_BF16 && bneck_geom(cin, planes, W) != 0 && stride == 1 && dil == 1 && !has_downsample;
 }
 
 extern "C" int sedt_bneck_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const float* s1,
                               const float* b1, const float* s2, const float* b2, const float* s3, const float* b3, void* a_out, void* b_out,
-                              uint8_t* abits_out, uint8_t* bbits_out, uint8_t* bits_out, int B, int H, void* stream) {
+                              uint8_t* abits_out, uint8_t* bbits_out, uint8_t* bits_out, int cin, int planes, int W, int B, int H, void* stream) {
   SEDT_REQUIRE(x && y && w1_frag && w2_frag && w3_frag && s1 && b1 && s2 && b2 && s3 && b3, "bneck_fwd: null pointer");
   SEDT_REQUIRE(B >= 1 && H >= 1, "bneck_fwd: B = %d, H = %d", B, H);
   SEDT_REQUIRE((a_out == nullptr) == (b_out == nullptr) && (abits_out == nullptr) == (bbits_out == nullptr),
                "bneck_fwd: the two intermediates (their sign bits) come both or not at all");
+  const int g = bneck_geom(cin, planes, W);
+  SEDT_REQUIRE(g != 0, "bneck_fwd: cin %d, planes %d, W %d outside the envelope (256/64/16, 512/128/8)", cin, planes, W);
   BneckArgs a{};
   a.in = (const bf16_t*)x; a.out = (bf16_t*)y;
   a.wA = (const u32x4*)w1_frag; a.wB = (const u32x4*)w2_frag; a.wC = (const u32x4*)w3_frag;
   a.sA = s1; a.bA = b1; a.sB = s2; a.bB = b2; a.sC = s3; a.bC = b3;
   a.a_out = (bf16_t*)a_out; a.b_out = (bf16_t*)b_out; a.abits_out = abits_out; a.bbits_out = bbits_out; a.bits_out = bits_out;
   a.B = B; a.H = H;
-  return bneck_launch<false>(a, reinterpret_cast<hipStream_t>(stream), "bneck_fwd");
+  return g == 1 ? bneck_launch<BG1, false>(a, reinterpret_cast<hipStream_t>(stream), "bneck_fwd")
+                : bneck_launch<BG2, false>(a, reinterpret_cast<hipStream_t>(stream), "bneck_fwd");
 }
 
 extern "C" int sedt_bneck_bwd(const void* gy, void* gx, const void* w3t_frag, const void* w2t_frag, const void* w1t_frag, const uint8_t* abits,
-                              const uint8_t* bbits, const uint8_t* xbits, int B, int H, void* stream) {
+                              const uint8_t* bbits, const uint8_t* xbits, void* gb_out, void* ga_out, int cin, int planes, int W, int B, int H,
+                              void* stream) {
   SEDT_REQUIRE(gy && gx && w3t_frag && w2t_frag && w1t_frag && abits && bbits, "bneck_bwd: null pointer");
   SEDT_REQUIRE(B >= 1 && H >= 1, "bneck_bwd: B = %d, H = %d", B, H);
+  SEDT_REQUIRE((gb_out == nullptr) == (ga_out == nullptr), "bneck_bwd: the two intermediate gradients come both or not at all");
+  const int g = bneck_geom(cin, planes, W);
+  SEDT_REQUIRE(g != 0, "bneck_bwd: cin %d, planes %d, W %d outside the envelope (256/64/16, 512/128/8)", cin, planes, W);
   BneckArgs a{};
   a.in = (const bf16_t*)gy; a.out = (bf16_t*)gx;
   a.wA = (const u32x4*)w3t_frag; a.wB = (const u32x4*)w2t_frag; a.wC = (const u32x4*)w1t_frag;
   a.abits_in = abits; a.bbits_in = bbits; a.bits_in = xbits;
+  a.a_out = (bf16_t*)gb_out; a.b_out = (bf16_t*)ga_out;          // (stage 1 of the chain produces gb, stage 2 ga)
   a.B = B; a.H = H;
-  return bneck_launch<true>(a, reinterpret_cast<hipStream_t>(stream), "bneck_bwd");
+  return g == 1 ? bneck_launch<BG1, true>(a, reinterpret_cast<hipStream_t>(stream), "bneck_bwd")
+                : bneck_launch<BG2, true>(a, reinterpret_cast<hipStream_t>(stream), "bneck_bwd");
 }

@@ -828,12 +828,12 @@ class StageFn(Function):
                 cf = [packing.lookup_conv_frag(t[k]) for k in (0, 5, 10)]
                 if all(c is not None for c in cf):
                     # a frozen block (layer1, backbone.py:60-62) keeps only the sign bits of its intermediates: the fused backward
-                    # needs nothing else; a trainable one keeps a and b for the per-op backward with its weight gradients
+                    # needs nothing else; a trainable one (layer2) keeps a and b as well, for its weight gradients
                     frozen = not (t[0].requires_grad or t[5].requires_grad or t[10].requires_grad)
-                    y, a, b, ybits, abits, bbits = ops.bneck_fwd(x, B, H, [c[0] for c in cf], ((s1, b1), (s2, b2), (s3, b3)),
+                    y, a, b, ybits, abits, bbits = ops.bneck_fwd(x, B, H, W, [c[0] for c in cf], ((s1, b1), (s2, b2), (s3, b3)),
                                                                  train=any(ctx.needs_input_grad), want_bits=bool(tr), want_ab=not frozen)
                     saved.append(dict(blk=blk, x=x, a=a, b=b, g1=g1, g2=g2, g3=g3, s=(s1, s2, s3), wb=(w1b, w2b, w3b), H=H, W=W, y=y,
-                                      xbits=xbits, fused=[c[1] for c in cf] if frozen else None, ab_bits=(abits, bbits)))
+                                      xbits=xbits, fused=[c[1] for c in cf], ab_bits=(abits, bbits)))
                     x, xbits = y, ybits
                     continue
             a = ops.conv_fwd(dt, x, B, g1, w1f, scale=s1, bias=b1, act=ACT_RELU)
@@ -879,11 +879,20 @@ class StageFn(Function):
             w1b, w2b, w3b = r['wb']
             first = bi_ == 0
             want_gx = (not first) or need_x_grad
-            if r.get('fused') is not None and want_gx and not (t[0].requires_grad or t[5].requires_grad or t[10].requires_grad):
-                # frozen block (layer1, backbone.py:60-62): only the input gradient is needed - one launch
+            if r.get('fused') is not None and want_gx:
                 mask_x = (not first) or meta['mask_input']
                 if not mask_x or r.get('xbits') is not None:
-                    gp = ops.bneck_bwd(gp, B, r['H'], r['fused'], *r['ab_bits'], r['xbits'] if mask_x else None)
+                    # the input-gradient chain in one launch; a trainable block (layer2) also takes the two intermediate gradients out
+                    # of it for its three weight-gradient GEMMs (a frozen one - layer1, backbone.py:60-62 - needs neither)
+                    train_w = t[0].requires_grad or t[5].requires_grad or t[10].requires_grad
+                    gx, gb, ga = ops.bneck_bwd(gp, B, r['H'], r['W'], r['fused'], *r['ab_bits'], r['xbits'] if mask_x else None, want_g=train_w)
+                    if t[10].requires_grad:
+                        grads[base + 10] = ops.wgrad(dt, gp, r['b'], B, r['g3'], rowscale=s3, batch=rb, param=t[10])
+                    if t[5].requires_grad:
+                        grads[base + 5] = ops.wgrad(dt, gb, r['a'], B, r['g2'], rowscale=s2, batch=rb, param=t[5])
+                    if t[0].requires_grad:
+                        grads[base + 0] = ops.wgrad(dt, ga, r['x'], B, r['g1'], rowscale=s1, batch=rb, param=t[0])
+                    gp = gx
                     continue
             # conv3 (1x1): wgrad, dgrad masked by relu(b)
             if t[10].requires_grad:

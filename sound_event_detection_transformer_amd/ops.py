@@ -720,44 +720,53 @@ def encoder_attn_ffn_fwd(x, qk, v, kpm, w_o_frag, b_o, gamma2, beta2, w1_frag, b
 
 
 # The prediction heads in ONE launch each way (csrc/heads_slab.hip).  Default in the bf16 mode.
-FUSED_BNECK = _dev_env('SEDT_BNECK', '1') != '0'
+FUSED_BNECK = int(_dev_env('SEDT_BNECK', '2'))      # 0 off, 1 layer1 only, 2 layer1 + layer2
 
 
 def bneck_ok(dtype, blk, W):
-    """the fused-Bottleneck envelope (csrc/bneck.hip): an identity block of layer1 on a 16-column map, bf16"""
-    return bool(FUSED_BNECK and dtype == BF16 and L.load().sedt_bneck_ok(blk.cin, blk.planes, W, blk.stride, blk.dil, int(blk.ds), dtype))
+    """the fused-Bottleneck envelope (csrc/bneck.hip): an identity block of layer1 (256/64 on 16 columns) or layer2 (512/128 on 8), bf16"""
+    return bool(int(FUSED_BNECK) >= (1 if blk.cin == 256 else 2) and dtype == BF16
+                and L.load().sedt_bneck_ok(blk.cin, blk.planes, W, blk.stride, blk.dil, int(blk.ds), dtype))
 
 
-def bneck_fwd(x, B, H, wf, sb, train=True, want_bits=True, want_ab=False):
-    """x [B*H*16, 256] bf16 contiguous; wf = the three fragment-major forward operands; sb = ((s1, b1), (s2, b2), (s3, b3)).
-    Returns (y, a, b, ybits, abits, bbits).  Training: the sign bits of the two intermediates (all bneck_bwd needs of them; [M, 8] bytes)
-    and, on request, the sign bits of y; want_ab: the intermediates themselves as well (a per-op backward with weight gradients)"""
+def bneck_fwd(x, B, H, W, wf, sb, train=True, want_bits=True, want_ab=False):
+    """x [B*H*W, C] bf16 contiguous; wf = the three fragment-major forward operands; sb = ((s1, b1), (s2, b2), (s3, b3)).
+    Returns (y, a, b, ybits, abits, bbits).  Training: the sign bits of the two intermediates (all bneck_bwd needs of them; [M, P/8] bytes)
+    and, on request, the sign bits of y; want_ab: the intermediates themselves as well (the weight-gradient GEMMs of a trainable block)"""
     _dev_check(x)
-    M = x.shape[0]
-    assert x.is_contiguous() and M == B * H * 16 and x.shape[1] == 256
+    M, C = x.shape
+    P = C // 4
+    assert x.is_contiguous() and M == B * H * W
     y = torch.empty_like(x)
     a = b = bits = abits = bbits = None
     if train:
-        abits = torch.empty((M, 8), device=x.device, dtype=torch.uint8)
+        abits = torch.empty((M, P // 8), device=x.device, dtype=torch.uint8)
         bbits = torch.empty_like(abits)
         if want_ab:
-            a = torch.empty((M, 64), device=x.device, dtype=torch.bfloat16)
+            a = torch.empty((M, P), device=x.device, dtype=torch.bfloat16)
             b = torch.empty_like(a)
         if want_bits:
-            bits = torch.empty((M, 32), device=x.device, dtype=torch.uint8)
+            bits = torch.empty((M, C // 8), device=x.device, dtype=torch.uint8)
     (s1, b1), (s2, b2), (s3, b3) = sb
     L.check(L.load().sedt_bneck_fwd(_p(x), _p(y), _p(wf[0]), _p(wf[1]), _p(wf[2]), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3), _p(a), _p(b),
-                                    _p(abits), _p(bbits), _p(bits), B, H, L.stream_ptr()), 'bneck_fwd')
+                                    _p(abits), _p(bbits), _p(bits), C, P, W, B, H, L.stream_ptr()), 'bneck_fwd')
     return y, a, b, bits, abits, bbits
 
 
-def bneck_bwd(gy, B, H, wt, abits, bbits, xbits):
-    """input gradient of the fused Bottleneck: gy [B*H*16, 256] bf16 (already masked by [y > 0]); wt = the three fragment-major dgrad
-    operands (conv1, conv2, conv3 order); abits / bbits from bneck_fwd; xbits = sign bits of the block input or None"""
+def bneck_bwd(gy, B, H, W, wt, abits, bbits, xbits, want_g=False):
+    """input gradient of the fused Bottleneck: gy [B*H*W, C] bf16 (already masked by [y > 0]); wt = the three fragment-major dgrad
+    operands (conv1, conv2, conv3 order); abits / bbits from bneck_fwd; xbits = sign bits of the block input or None.
+    Returns (gx, gb, ga): gb / ga [M, P] = the gradients of the two intermediates (want_g: a trainable block's weight gradients read them)"""
     assert gy.is_contiguous() and abits.is_contiguous() and bbits.is_contiguous() and (xbits is None or xbits.is_contiguous())
+    M, C = gy.shape
     gx = torch.empty_like(gy)
-    L.check(L.load().sedt_bneck_bwd(_p(gy), _p(gx), _p(wt[2]), _p(wt[1]), _p(wt[0]), _p(abits), _p(bbits), _p(xbits), B, H, L.stream_ptr()), 'bneck_bwd')
-    return gx
+    gb = ga = None
+    if want_g:
+        gb = torch.empty((M, C // 4), device=gy.device, dtype=torch.bfloat16)
+        ga = torch.empty_like(gb)
+    L.check(L.load().sedt_bneck_bwd(_p(gy), _p(gx), _p(wt[2]), _p(wt[1]), _p(wt[0]), _p(abits), _p(bbits), _p(xbits), _p(gb), _p(ga), C, C // 4, W,
+                                    B, H, L.stream_ptr()), 'bneck_bwd')
+    return gx, gb, ga
 
 
 SLAB_HEADS = _dev_env('SEDT_SLAB_HEADS', '1') != '0'

@@ -118,8 +118,10 @@ class SEDT(nn.Module):
                         lin.append(getattr(self, name).weight)
                 if hasattr(self, 'feature_align'):
                     lin += [m.weight for m in self.feature_align.layers]
-                # identity Bottlenecks of layer1 run as one fused kernel each way (csrc/bneck.hip): their packed operands fragment-major too
-                cfr = [w for b in list(body.layer1)[1:] if b.downsample is None for w in (b.conv1.weight, b.conv2.weight, b.conv3.weight)]
+                # identity Bottlenecks of layer1 / layer2 run as one fused kernel each way (csrc/bneck.hip): their packed operands
+                # fragment-major too
+                cfr = [w for layer in (body.layer1, body.layer2) for b in layer if b.downsample is None
+                       for w in (b.conv1.weight, b.conv2.weight, b.conv3.weight)]
                 return packing.PackPlan(dt, dev, convs, lin, bn_only, frags, cfr)
             plans[key] = packing.PlanSet(factory)
         return plans[key]
