@@ -414,6 +414,17 @@ int sedt_bneck_bwd(const void* gy, void* gx, const void* w3t_frag, const void* w
                    const uint8_t* bbits, const uint8_t* xbits, void* gb_out, void* ga_out, int cin, int planes, int W, int B, int H,
                    void* stream);
 
+/* The first Bottleneck of layer1 (64 -> 64 -> 64 -> 256, 1x1 projection 64 -> 256 on the skip path, stride 1, map 16 columns wide) in ONE
+ * forward launch (csrc/bneck.hip: bneck0_fwd_kernel): a = relu(s1 (x W1^T) + b1); b = relu(s2 conv3x3(a, W2) + b2);
+ * y = relu(s3 (b W3^T) + b3 + bf16(sd (x Wd^T) + bd)).  x [M][64], y [M][256] bf16 NHWC (M = B*H*16); w*_frag as for sedt_bneck_fwd (wd = the
+ * projection); training by-products a_out / b_out [M][64] (both or none) and bits_out [M][32] = sign bits of y, each may be null.
+ * The block's backward stays per-op (it reads x, a, b and the sign bits).  Envelope (sedt_bneck0_ok): bf16, cin 64, planes 64, W 16,
+ * stride 1, dilation 1, WITH the downsample branch. */
+int sedt_bneck0_ok(int cin, int planes, int W, int stride, int dil, int has_downsample, int dtype);
+int sedt_bneck0_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const void* wd_frag, const float* s1,
+                    const float* b1, const float* s2, const float* b2, const float* s3, const float* b3, const float* sd, const float* bd,
+                    void* a_out, void* b_out, uint8_t* bits_out, int B, int H, void* stream);
+
 /* The prediction heads on the stacked decoder output hs [L*B*Qp][256] bf16 (sedt/sedt.py:88-95, 398-409) in ONE launch each way
  * (csrc/heads_slab.hip; a workgroup per 32 rows): class logits cls [rows][C1] = hs wc^T + bc, boxes [rows][2] = sigmoid(W3 relu(W2
  * relu(W1 hs + b1) + b2) + b3), audio tags at [B][CA] = sigmoid(wa hs + ba) on query 0 of the last layer (CA = 0: no such head).

@@ -503,6 +503,304 @@ static int bneck_launch(BneckArgs& a, hipStream_t s, const char* what) {
   return check_launch(what);
 }
 
+// ---------------------------------------------------------------------------------------------------------------- layer1, block 0
+// The first Bottleneck of layer1 (64 -> 64 -> 64 -> 256 with the 1x1 projection 64 -> 256 on the skip path, stride 1) in ONE forward
+// launch: x (the pooled stem output, 128 B per pixel) in, y out; the per-op chain of four launches moves 2.3 KB per pixel for the 640 B
+// this one does (C4 runs the block over 2,200 clip-equivalents per step).  Same strip walk and wave roles as bneck_kernel; the
+// differences: the in tile has 64 channels (so the out tile is its own LDS buffer), stage 1 has K = 64, and stage 3 is TWO K = 64
+// products per output tile - conv3 over b and the projection over x - with separate FrozenBN affines, the projection rounded to bf16
+// before the sum exactly where the per-op chain stores it.  W1 / W3 / Wd fragments live in registers for the whole launch; only the
+// 3x3 streams.  The backward of this block stays per-op (it reads x, a, b, y: written here when training).
+struct Bneck0Args {
+  const bf16_t* in;                  // x [M][64]
+  bf16_t* out;                       // y [M][256]
+  const u32x4* w1; const u32x4* w2; const u32x4* w3; const u32x4* wd;      // [64][64], [64][576], [256][64], [256][64] fragment-major
+  const float* s1; const float* b1; const float* s2; const float* b2; const float* s3; const float* b3; const float* sd; const float* bd;
+  bf16_t* a_out; bf16_t* b_out;      // [M][64] or null
+  uint8_t* bits_out;                 // sign bits of y [M][32] or null
+  int B, H, spw;
+};
+
+struct B0 {
+  static constexpr int CI = 64, P = 64, C = 256, W = 16, R = 8, NP1 = (R + 2) * W, NP = R * W, NS1 = NP1 / 32, NS = NP / 32;
+  static constexpr int XP = CI + 8, AP = P + 8, AW = W + 2, YP = C + 8;
+  static constexpr size_t XT = 0;
+  static constexpr size_t AT = XT + (size_t)NP1 * XP * 2;
+  static constexpr size_t BT = AT + (size_t)(R + 2) * AW * AP * 2;
+  static constexpr size_t YT = BT + (size_t)NP * AP * 2;
+  static constexpr size_t BITS = YT + (size_t)NP * YP * 2;
+  static constexpr size_t SB = BITS + (size_t)NP * 32;
+  static constexpr size_t TOTAL = SB + (4 * 64 + 4 * 256) * 4;
+};
+
+__global__ __launch_bounds__(512) void bneck0_fwd_kernel(const Bneck0Args a) {
+  constexpr int NP1 = B0::NP1, NP = B0::NP, NS1 = B0::NS1, R = B0::R, W = B0::W, XP = B0::XP, AP = B0::AP, AW = B0::AW, YP = B0::YP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* XT = reinterpret_cast<bf16_t*>(smem + B0::XT);        // [NP1][72]: x on the halo tile
+  bf16_t* AT = reinterpret_cast<bf16_t*>(smem + B0::AT);        // [10][18][72]: 3x3 input, zero border
+  bf16_t* BT = reinterpret_cast<bf16_t*>(smem + B0::BT);        // [NP][72]: 3x3 output
+  bf16_t* YT = reinterpret_cast<bf16_t*>(smem + B0::YT);        // [NP][264]: out tile
+  uint8_t* BITS = smem + B0::BITS;                              // [NP][32]
+  float* SB = reinterpret_cast<float*>(smem + B0::SB);          // s1 b1 s2 b2 (64 each) s3 b3 sd bd (256 each)
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int strips = (a.H + R - 1) / R, nst = a.B * strips;
+  const int first = blockIdx.x * a.spw, last = min(first + a.spw, nst);
+  if (first >= last) return;
+  const bool comp = wave < 4;
+  const int tl = wave & 1, grp = (wave >> 1) & 1;
+
+  // one register pool for both roles: the compute waves' 3x3 units (cur | alt), the moving waves' next in tile (5 pieces)
+  u32x4 pool[16], w1r[4], w3r[4], wdr[4];
+  u32x4(&cur)[8] = *reinterpret_cast<u32x4(*)[8]>(&pool[0]);
+  u32x4(&alt)[8] = *reinterpret_cast<u32x4(*)[8]>(&pool[8]);
+  const u32x4* w2p = a.w2 + (long)tl * 36 * 64;
+  load4(w3r, 0, a.w3 + (long)wave * 4 * 64, tid & 63);
+  load4(wdr, 0, a.wd + (long)wave * 4 * 64, tid & 63);
+  if (comp) {
+    load4(w1r, 0, a.w1 + (long)tl * 4 * 64, tid & 63);
+    load4(cur, 0, w2p, tid & 63);                                // units 0..3 of the 3x3 (reloaded at the end of every stage 2 for the next strip)
+    load4(cur, 4, w2p + 4 * 64, tid & 63);
+    load4(alt, 0, w2p + 8 * 64, tid & 63);
+    load4(alt, 4, w2p + 12 * 64, tid & 63);
+  }
+  slab::issue_fence();
+
+  auto geom = [&](int s, int& r0, long& pix0) {
+    const int clip = s / strips;
+    r0 = (s % strips) * R;
+    pix0 = ((long)clip * a.H + r0) * W;
+  };
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto fetch = [&](int s) {
+    int r0; long pix0;
+    geom(s, r0, pix0);
+    const int mt = opaque(tid) - 256;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int u = mt + q * 256, p = u >> 3, c = (u & 7) * 8, gr = r0 - 1 + (p >> 4);
+      pool[q] = (gr >= 0 && gr < a.H) ? *reinterpret_cast<const u32x4*>(a.in + (pix0 + p - W) * 64 + c) : zero4;
+    }
+  };
+  auto put = [&]() {
+    const int mt = opaque(tid) - 256;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      const int u = mt + q * 256, p = u >> 3, c = (u & 7) * 8;
+      *reinterpret_cast<u32x4*>(XT + p * XP + c) = pool[q];
+    }
+  };
+
+  for (int u = tid; u < (R + 2) * AW * AP / 8; u += 512) reinterpret_cast<uint4*>(AT)[u] = make_uint4(0, 0, 0, 0);
+  for (int u = tid; u < 1280; u += 512) {
+    const float* src = u < 64 ? a.s1 + u : u < 128 ? a.b1 + (u - 64) : u < 192 ? a.s2 + (u - 128) : u < 256 ? a.b2 + (u - 192)
+                       : u < 512 ? a.s3 + (u - 256) : u < 768 ? a.b3 + (u - 512) : u < 1024 ? a.sd + (u - 768) : a.bd + (u - 1024);
+    SB[u] = *src;
+  }
+  if (!comp) {
+    fetch(first);
+    put();
+  }
+  __syncthreads();
+
+  for (int s = first; s < last; ++s) {
+    int r0; long pix0;
+    geom(s, r0, pix0);
+    const int rows_in = min(R, a.H - r0);
+    const bool more = s + 1 < last;
+    const int lane = opaque(tid) & 63, n = lane & 31, hf = lane >> 5, mt = opaque(tid) - 256;
+
+    // ---- A .. B: stage 1 (1x1, 64 -> 64 on the halo tile: tile tl, slabs 3 * grp + {0, 1, 2}) | move: the next in tile into registers
+    if (comp) {
+      f32x16 acc[3];
+      slab::zero_acc<3>(acc);
+      const bf16_t* xrow = XT + ((3 * grp) * 32 + n) * XP + 8 * hf;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 xb[3];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) xb[s3] = *reinterpret_cast<const bf16x8*>(xrow + s3 * 32 * XP + kk * 16);
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) acc[s3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w1r[kk]), xb[s3], acc[s3], 0, 0, 0);
+      }
+      float4 sc[4], bi[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        sc[g4] = *reinterpret_cast<const float4*>(SB + tl * 32 + 8 * g4 + 4 * hf);
+        bi[g4] = *reinterpret_cast<const float4*>(SB + 64 + tl * 32 + 8 * g4 + 4 * hf);
+      }
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const int sl = 3 * grp + s3;
+        if (sl < NS1) {
+          const int p = sl * 32 + n, trow = p >> 4, pc = p & 15, gr = r0 - 1 + trow;
+          const bool inimg = gr >= 0 && gr < a.H;
+          bf16_t* dst = AT + (trow * AW + pc + 1) * AP + tl * 32 + 4 * hf;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x2 lo = {acc[s3][4 * g4], acc[s3][4 * g4 + 1]}, hi = {acc[s3][4 * g4 + 2], acc[s3][4 * g4 + 3]};
+            uint2 o;
+            o.x = pack2(relu2(lo * f32x2{sc[g4].x, sc[g4].y} + f32x2{bi[g4].x, bi[g4].y}));
+            o.y = pack2(relu2(hi * f32x2{sc[g4].z, sc[g4].w} + f32x2{bi[g4].z, bi[g4].w}));
+            if (!inimg) o = make_uint2(0, 0);
+            *reinterpret_cast<uint2*>(dst + 8 * g4) = o;
+          }
+        }
+      }
+    } else if (more) {
+      fetch(s + 1);
+    }
+    __syncthreads();
+
+    // ---- B .. C: stage 2 (3x3: tile tl, slabs 2 * grp + {0, 1}) | move: the first intermediate out
+    if (comp) {
+      f32x16 acc[2];
+      slab::zero_acc<2>(acc);
+      const bf16_t* ctr[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int q = (grp * 2 + s2) * 32 + n;
+        ctr[s2] = AT + (((q >> 4) + 1) * AW + (q & 15) + 1) * AP + 8 * hf;
+      }
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        u32x4(&src)[8] = (u & 2) ? alt : cur;
+        const int so = (u & 1) * 4;
+        const int off = ((u / 3 - 1) * AW + (u % 3 - 1)) * AP;
+        bf16x8 xb[4][2];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) xb[kk][s2] = *reinterpret_cast<const bf16x8*>(ctr[s2] + off + kk * 16);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+            acc[s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, src[so + kk]), xb[kk][s2], acc[s2], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 4 < 9) load4(src, so, w2p + (long)(u + 4) * 4 * 64, lane);        // the ring: unit u + 4 into the quarter just used
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      load4(cur, 0, w2p, lane);                                  // the next strip's units 0..3 (unit u lives in quarter u % 4): in flight
+      load4(cur, 4, w2p + 4 * 64, lane);                         // through stage 3, the stores and stage 1
+      load4(alt, 0, w2p + 8 * 64, lane);
+      load4(alt, 4, w2p + 12 * 64, lane);
+      slab::issue_fence();
+      float4 sc[4], bi[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        sc[g4] = *reinterpret_cast<const float4*>(SB + 128 + tl * 32 + 8 * g4 + 4 * hf);
+        bi[g4] = *reinterpret_cast<const float4*>(SB + 192 + tl * 32 + 8 * g4 + 4 * hf);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int q = (grp * 2 + s2) * 32 + n;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x2 lo = {acc[s2][4 * g4], acc[s2][4 * g4 + 1]}, hi = {acc[s2][4 * g4 + 2], acc[s2][4 * g4 + 3]};
+          uint2 o;
+          o.x = pack2(relu2(lo * f32x2{sc[g4].x, sc[g4].y} + f32x2{bi[g4].x, bi[g4].y}));
+          o.y = pack2(relu2(hi * f32x2{sc[g4].z, sc[g4].w} + f32x2{bi[g4].z, bi[g4].w}));
+          *reinterpret_cast<uint2*>(BT + q * AP + tl * 32 + 8 * g4 + 4 * hf) = o;
+        }
+      }
+    } else if (a.a_out) {
+      for (int u = mt; u < NP * 8; u += 256) {
+        const int q = u >> 3, c = (u & 7) * 8;
+        if ((q >> 4) < rows_in)
+          *reinterpret_cast<uint4*>(a.a_out + (pix0 + q) * 64 + c) = *reinterpret_cast<const uint4*>(AT + (((q >> 4) + 1) * AW + (q & 15) + 1) * AP + c);
+      }
+    }
+    __syncthreads();
+
+    // ---- C .. D: stage 3 (all waves, tile = wave): conv3 over b and the projection over x, two slabs at a time
+    {
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        f32x16 acc3[2], accd[2];
+        slab::zero_acc<2>(acc3);
+        slab::zero_acc<2>(accd);
+        const bf16_t* brow = BT + ((2 * sp) * 32 + n) * AP + 8 * hf;
+        const bf16_t* xrow = XT + ((2 * sp) * 32 + n + W) * XP + 8 * hf;        // (the strip's own rows of the halo tile)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          bf16x8 bb[2], xb[2];
+#pragma unroll
+          for (int s3 = 0; s3 < 2; ++s3) {
+            bb[s3] = *reinterpret_cast<const bf16x8*>(brow + s3 * 32 * AP + kk * 16);
+            xb[s3] = *reinterpret_cast<const bf16x8*>(xrow + s3 * 32 * XP + kk * 16);
+          }
+#pragma unroll
+          for (int s3 = 0; s3 < 2; ++s3) {
+            acc3[s3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w3r[kk]), bb[s3], acc3[s3], 0, 0, 0);
+            accd[s3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wdr[kk]), xb[s3], accd[s3], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int s3 = 0; s3 < 2; ++s3) {
+          const int q = (2 * sp + s3) * 32 + n;
+          unsigned nibs = 0;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const float* sbp = SB + wave * 32 + 8 * g4 + 4 * hf;      // (read per use: sixteen float4 held across the slab loop spilled)
+            const float4 s3v_ = *reinterpret_cast<const float4*>(sbp + 256), b3v_ = *reinterpret_cast<const float4*>(sbp + 512);
+            const float4 sdv_ = *reinterpret_cast<const float4*>(sbp + 768), bdv_ = *reinterpret_cast<const float4*>(sbp + 1024);
+            const f32x2 lo = {acc3[s3][4 * g4], acc3[s3][4 * g4 + 1]}, hi = {acc3[s3][4 * g4 + 2], acc3[s3][4 * g4 + 3]};
+            const f32x2 dlo = {accd[s3][4 * g4], accd[s3][4 * g4 + 1]}, dhi = {accd[s3][4 * g4 + 2], accd[s3][4 * g4 + 3]};
+            // the skip path as the per-op chain stores it: bf16(sd * acc + bd)
+            const unsigned ilo = pack2(dlo * f32x2{sdv_.x, sdv_.y} + f32x2{bdv_.x, bdv_.y});
+            const unsigned ihi = pack2(dhi * f32x2{sdv_.z, sdv_.w} + f32x2{bdv_.z, bdv_.w});
+            uint2 o;
+            o.x = pack2(relu2(lo * f32x2{s3v_.x, s3v_.y} + f32x2{b3v_.x, b3v_.y} + widen2(ilo)));
+            o.y = pack2(relu2(hi * f32x2{s3v_.z, s3v_.w} + f32x2{b3v_.z, b3v_.w} + widen2(ihi)));
+            nibs |= nibble4(o.x, o.y) << (8 * g4 + 4 * hf);
+            *reinterpret_cast<uint2*>(YT + q * YP + wave * 32 + 8 * g4 + 4 * hf) = o;
+          }
+          if (a.bits_out) {
+            const unsigned other = (unsigned)__shfl_xor((int)nibs, 32);
+            if (hf == 0) *reinterpret_cast<unsigned*>(BITS + q * 32 + wave * 4) = nibs | other;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- D .. E: out (all waves); the moving waves then put the next in tile into LDS (XT's last readers were stage 3)
+    {
+      const int t = opaque(tid);
+#pragma unroll 4
+      for (int u = t; u < NP * 32; u += 512) {
+        const int q = u >> 5, c = (u & 31) * 8;
+        if ((q >> 4) < rows_in) *reinterpret_cast<uint4*>(a.out + (pix0 + q) * 256 + c) = *reinterpret_cast<const uint4*>(YT + q * YP + c);
+      }
+      if (a.b_out)
+        for (int u = t; u < NP * 8; u += 512) {
+          const int q = u >> 3, c = (u & 7) * 8;
+          if ((q >> 4) < rows_in) *reinterpret_cast<uint4*>(a.b_out + (pix0 + q) * 64 + c) = *reinterpret_cast<const uint4*>(BT + q * AP + c);
+        }
+      if (a.bits_out && t < 256 && (t >> 5) < rows_in) reinterpret_cast<uint4*>(a.bits_out + pix0 * 32)[t] = reinterpret_cast<const uint4*>(BITS)[t];
+      if (more && !comp) put();
+    }
+    __syncthreads();
+  }
+}
+
+static int bneck0_launch(Bneck0Args& a, hipStream_t s) {
+  static_assert(B0::TOTAL <= 160 * 1024, "LDS");
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck0_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)B0::TOTAL);
+    if (e != hipSuccess) {
+      set_error("bneck0_fwd: hipFuncSetAttribute(%zu B LDS) failed: %s", (size_t)B0::TOTAL, hipGetErrorString(e));
+      return 1;
+    }
+    attr = true;
+  }
+  const int nst = a.B * ((a.H + B0::R - 1) / B0::R);
+  a.spw = (nst + 255) / 256;
+  hipLaunchKernelGGL(bneck0_fwd_kernel, dim3((nst + a.spw - 1) / a.spw), dim3(512), B0::TOTAL, s, a);
+  return check_launch("bneck0_fwd");
+}
+
 typedef BG<256, 64, 16> BG1;          // layer1
 typedef BG<512, 128, 8> BG2;          // layer2
 
@@ -551,4 +849,23 @@ extern "C" int sedt_bneck_bwd(const void* gy, void* gx, const void* w3t_frag, co
   a.B = B; a.H = H;
   return g == 1 ? bneck_launch<BG1, true>(a, reinterpret_cast<hipStream_t>(stream), "bneck_bwd")
                 : bneck_launch<BG2, true>(a, reinterpret_cast<hipStream_t>(stream), "bneck_bwd");
+}
+
+extern "C" int sedt_bneck0_ok(int cin, int planes, int W, int stride, int dil, int has_downsample, int dtype) {
+  return dtype == SEDT_BF16 && cin == 64 && planes == 64 && W == 16 && stride == 1 && dil == 1 && has_downsample;
+}
+
+extern "C" int sedt_bneck0_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const void* wd_frag,
+                               const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3, const float* sd,
+                               const float* bd, void* a_out, void* b_out, uint8_t* bits_out, int B, int H, void* stream) {
+  SEDT_REQUIRE(x && y && w1_frag && w2_frag && w3_frag && wd_frag && s1 && b1 && s2 && b2 && s3 && b3 && sd && bd, "bneck0_fwd: null pointer");
+  SEDT_REQUIRE(B >= 1 && H >= 1, "bneck0_fwd: B = %d, H = %d", B, H);
+  SEDT_REQUIRE((a_out == nullptr) == (b_out == nullptr), "bneck0_fwd: the two intermediates come both or not at all");
+  Bneck0Args a{};
+  a.in = (const bf16_t*)x; a.out = (bf16_t*)y;
+  a.w1 = (const u32x4*)w1_frag; a.w2 = (const u32x4*)w2_frag; a.w3 = (const u32x4*)w3_frag; a.wd = (const u32x4*)wd_frag;
+  a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2; a.s3 = s3; a.b3 = b3; a.sd = sd; a.bd = bd;
+  a.a_out = (bf16_t*)a_out; a.b_out = (bf16_t*)b_out; a.bits_out = bits_out;
+  a.B = B; a.H = H;
+  return bneck0_launch(a, reinterpret_cast<hipStream_t>(stream));
 }

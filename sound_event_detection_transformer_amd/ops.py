@@ -720,7 +720,7 @@ def encoder_attn_ffn_fwd(x, qk, v, kpm, w_o_frag, b_o, gamma2, beta2, w1_frag, b
 
 
 # The prediction heads in ONE launch each way (csrc/heads_slab.hip).  Default in the bf16 mode.
-FUSED_BNECK = int(_dev_env('SEDT_BNECK', '2'))      # 0 off, 1 layer1 only, 2 layer1 + layer2
+FUSED_BNECK = int(_dev_env('SEDT_BNECK', '3'))      # 0 off, 1 layer1's identity blocks, 2 + layer2's, 3 + layer1's block 0 (forward)
 
 
 def bneck_ok(dtype, blk, W):
@@ -767,6 +767,30 @@ def bneck_bwd(gy, B, H, W, wt, abits, bbits, xbits, want_g=False):
     L.check(L.load().sedt_bneck_bwd(_p(gy), _p(gx), _p(wt[2]), _p(wt[1]), _p(wt[0]), _p(abits), _p(bbits), _p(xbits), _p(gb), _p(ga), C, C // 4, W,
                                     B, H, L.stream_ptr()), 'bneck_bwd')
     return gx, gb, ga
+
+
+def bneck0_ok(dtype, blk, W):
+    """the fused forward of layer1's first Bottleneck (csrc/bneck.hip: 64 -> 64 -> 64 -> 256 with the projection skip, 16 columns), bf16"""
+    return bool(int(FUSED_BNECK) >= 3 and dtype == BF16 and L.load().sedt_bneck0_ok(blk.cin, blk.planes, W, blk.stride, blk.dil, int(blk.ds), dtype))
+
+
+def bneck0_fwd(x, B, H, wf, sb, train=True, want_bits=True):
+    """x [B*H*16, 64] bf16 contiguous; wf = the fragment-major forward operands of conv1, conv2, conv3 and the projection; sb = their four
+    (scale, bias) pairs.  Returns (y, a, b, ybits); a, b (what the per-op backward reads) and ybits only when training"""
+    _dev_check(x)
+    M = x.shape[0]
+    assert x.is_contiguous() and M == B * H * 16 and x.shape[1] == 64
+    y = torch.empty((M, 256), device=x.device, dtype=torch.bfloat16)
+    a = b = bits = None
+    if train:
+        a = torch.empty((M, 64), device=x.device, dtype=torch.bfloat16)
+        b = torch.empty_like(a)
+        if want_bits:
+            bits = torch.empty((M, 32), device=x.device, dtype=torch.uint8)
+    (s1, b1), (s2, b2), (s3, b3), (sd, bd) = sb
+    L.check(L.load().sedt_bneck0_fwd(_p(x), _p(y), _p(wf[0]), _p(wf[1]), _p(wf[2]), _p(wf[3]), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3),
+                                     _p(sd), _p(bd), _p(a), _p(b), _p(bits), B, H, L.stream_ptr()), 'bneck0_fwd')
+    return y, a, b, bits
 
 
 SLAB_HEADS = _dev_env('SEDT_SLAB_HEADS', '1') != '0'

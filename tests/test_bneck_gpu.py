@@ -39,6 +39,8 @@ def _stage(seed, which=1):
         convs += [(b.conv1.weight, b.bn1.tensors()), (b.conv2.weight, b.bn2.tensors()), (b.conv3.weight, b.bn3.tensors())]
         if b.downsample is not None:
             convs.append((b.downsample[0].weight, b.downsample[1].tensors()))
+            if which == 1:                                  # layer1's first block has a fused forward of its own
+                cfr += [b.conv1.weight, b.conv2.weight, b.conv3.weight, b.downsample[0].weight]
         else:
             cfr += [b.conv1.weight, b.conv2.weight, b.conv3.weight]
     plan = packing.PackPlan(BF16, torch.device('cuda'), convs, [], (), (), cfr)
@@ -49,7 +51,7 @@ def _run(layer, plan, x, B, H, fused, gy=None, mask_input=False):
     from sound_event_detection_transformer_amd import functional as Fn, ops
     from sound_event_detection_transformer_amd.lib import BF16
     keep = ops.FUSED_BNECK
-    ops.FUSED_BNECK = 2 if fused else 0
+    ops.FUSED_BNECK = 3 if fused else 0
     try:
         xin = x.clone().requires_grad_(gy is not None)
         holder = {}
@@ -173,3 +175,44 @@ def test_fused_bottleneck_kernels_against_torch(which):
     GA = q(F.conv_transpose2d(GB, w2s, padding=1) * (nchw(a, P) > 0))
     GX = (F.conv_transpose2d(GA, w1s) + GY) * (X > 0)
     assert rel(gb, tok(GB)) < 1e-2 and rel(ga, tok(GA)) < 1e-2 and rel(gx, tok(GX)) < 1e-2
+
+
+def test_fused_first_block_forward_against_torch():
+    """layer1's block 0 (projection skip) in one forward launch against the f32 torch restatement; the skip path is rounded to bf16 before
+    the sum, as the per-op chain stores it"""
+    import torch.nn.functional as F
+    from sound_event_detection_transformer_amd import ops, packing
+    layer, plan = _stage(13, 1)
+    blk = layer[0]
+    B, H = 3, 21
+    g = torch.Generator().manual_seed(2)
+    x = (0.7 * torch.randn(B * H * 16, 64, generator=g)).cuda().bfloat16().relu()
+    ws = (blk.conv1.weight, blk.conv2.weight, blk.conv3.weight, blk.downsample[0].weight)
+    assert ops.bneck0_ok(ops.BF16, blk.cfg, 16) and not ops.bneck0_ok(ops.BF16, layer[1].cfg, 16)
+    with plan:
+        cf = [packing.lookup_conv_frag(w) for w in ws]
+        sb = [packing.lookup(w)[2:] for w in ws]
+        y, a, b, bits = ops.bneck0_fwd(x, B, H, [c[0] for c in cf], sb)
+        y2, a2, b2, bits2 = ops.bneck0_fwd(x, B, H, [c[0] for c in cf], sb, train=False)
+        torch.cuda.synchronize()
+    assert torch.equal(y, y2) and a2 is None and bits2 is None
+    want = (y.float() > 0).view(-1, 32, 8).to(torch.uint8)
+    assert torch.equal(bits, (want << torch.arange(8, device='cuda', dtype=torch.uint8)).sum(-1).to(torch.uint8))
+
+    def q(t):
+        return t.bfloat16().float()
+
+    def nchw(t, Cn):
+        return t.float().view(B, H, 16, Cn).permute(0, 3, 1, 2)
+
+    def tok(t):
+        return t.permute(0, 2, 3, 1).reshape(B * H * 16, -1)
+
+    (s1, b1), (s2, b2_), (s3, b3), (sd, bd) = [(s_.view(1, -1, 1, 1), bb.view(1, -1, 1, 1)) for s_, bb in sb]
+    w1, w2, w3, wd = (q(w) for w in ws)
+    X = nchw(x, 64)
+    A = q(F.relu(F.conv2d(X, w1) * s1 + b1))
+    Bt = q(F.relu(F.conv2d(A, w2, padding=1) * s2 + b2_))
+    I = q(F.conv2d(X, wd) * sd + bd)
+    Y = F.relu(F.conv2d(Bt, w3) * s3 + b3 + I)
+    assert rel(a, tok(A)) < 1e-2 and rel(b, tok(Bt)) < 1e-2 and rel(y, tok(Y)) < 1e-2
