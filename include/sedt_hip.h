@@ -404,7 +404,9 @@ int sedt_decoder_layer_fwd(const SedtDecLayer* args, void* stream);
  *     w*t_frag = sedt_pack_frag (src_bf16) of the dgrad operands of sedt_multi_pack ([Cin][taps][Cout], BN scale folded in); gy is the
  *     gradient w.r.t. y already masked by [y > 0]; abits / bbits from the forward; xbits = sign bits of the block input, or null (no mask).
  *     gb_out, ga_out [M][planes] (both or none): the two intermediate gradients, left operands of the weight-gradient GEMMs of a
- *     trainable block (layer2; layer1 is frozen in the reference, backbone.py:60-62, and needs neither).
+ *     trainable block (layer2; layer1 is frozen in the reference, backbone.py:60-62, and needs neither).  gx == null: the chain stops
+ *     at ga (ga_out required, w1t_frag / xbits ignored) - for a block whose first convolution has another shape (layer1's block 0: the
+ *     caller finishes with its own two input-gradient GEMMs).
  * Envelope (sedt_bneck_ok): bf16, stride 1, dilation 1, no downsample, and (cin, planes, W) = (256, 64, 16) or (512, 128, 8). */
 int sedt_bneck_ok(int cin, int planes, int W, int stride, int dil, int has_downsample, int dtype);
 int sedt_bneck_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const float* s1, const float* b1,
@@ -417,13 +419,14 @@ int sedt_bneck_bwd(const void* gy, void* gx, const void* w3t_frag, const void* w
 /* The first Bottleneck of layer1 (64 -> 64 -> 64 -> 256, 1x1 projection 64 -> 256 on the skip path, stride 1, map 16 columns wide) in ONE
  * forward launch (csrc/bneck.hip: bneck0_fwd_kernel): a = relu(s1 (x W1^T) + b1); b = relu(s2 conv3x3(a, W2) + b2);
  * y = relu(s3 (b W3^T) + b3 + bf16(sd (x Wd^T) + bd)).  x [M][64], y [M][256] bf16 NHWC (M = B*H*16); w*_frag as for sedt_bneck_fwd (wd = the
- * projection); training by-products a_out / b_out [M][64] (both or none) and bits_out [M][32] = sign bits of y, each may be null.
- * The block's backward stays per-op (it reads x, a, b and the sign bits).  Envelope (sedt_bneck0_ok): bf16, cin 64, planes 64, W 16,
+ * projection); training by-products a_out / b_out [M][64], abits_out / bbits_out [M][8] (their sign bits; each pair both or none) and
+ * bits_out [M][32] = sign bits of y, each may be null.  The block's backward: sedt_bneck_bwd with gx == null (gy -> gb -> ga in one
+ * launch), then the two input-gradient GEMMs of conv1 and the projection.  Envelope (sedt_bneck0_ok): bf16, cin 64, planes 64, W 16,
  * stride 1, dilation 1, WITH the downsample branch. */
 int sedt_bneck0_ok(int cin, int planes, int W, int stride, int dil, int has_downsample, int dtype);
 int sedt_bneck0_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const void* wd_frag, const float* s1,
                     const float* b1, const float* s2, const float* b2, const float* s3, const float* b3, const float* sd, const float* bd,
-                    void* a_out, void* b_out, uint8_t* bits_out, int B, int H, void* stream);
+                    void* a_out, void* b_out, uint8_t* abits_out, uint8_t* bbits_out, uint8_t* bits_out, int B, int H, void* stream);
 
 /* The prediction heads on the stacked decoder output hs [L*B*Qp][256] bf16 (sedt/sedt.py:88-95, 398-409) in ONE launch each way
  * (csrc/heads_slab.hip; a workgroup per 32 rows): class logits cls [rows][C1] = hs wc^T + bc, boxes [rows][2] = sigmoid(W3 relu(W2

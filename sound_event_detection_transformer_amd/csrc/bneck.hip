@@ -148,7 +148,7 @@ __device__ __forceinline__ unsigned nibble4(unsigned w0, unsigned w1) {
 //   C(s) .. D(s): all: stage 3 (reads BT, XT in place, BITS)
 //   D(s) .. E(s): all: store out / stage-2 result / sign bits of s (XT, BT, BITS, MA)
 //   E(s) .. A(s+1): move: registers -> XT (+ the sign bits of strip s + 1; bwd)
-template <class G, bool BWD>
+template <class G, bool BWD, bool SKIP3 = false>      // SKIP3 (bwd): stop after stage 2 - the caller finishes the chain
 __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
   using LD = BneckLds<G, BWD>;
   constexpr int NP1 = G::NP1, NP = G::NP, NS1 = G::NS1, NS = G::NS, R = G::R, W = G::W, C = G::C, P = G::P;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
 #pragma unroll
     for (int u = 0; u < G::KS3; ++u) w3r[(NW3 > G::KS3 ? (t & 1) * G::KS3 : 0) + u] = w3p[(t * G::KS3 + u) * 64 + lane];
   };
-  if (W3_KEPT) load_w3(0, tid & 63);
+  if (W3_KEPT && !SKIP3) load_w3(0, tid & 63);
   if (comp) slab::load_chunk<1>(cur, w1p, 0, 0, tid & 63);
   slab::issue_fence();
 
@@ -384,11 +384,11 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
       if (!BWD && a.abits_out && mt < 64 && (mt >> 3) < rows_in)         // (the strip's own rows of the halo tile)
         reinterpret_cast<uint4*>(a.abits_out + pix0 * PP)[mt] = reinterpret_cast<const uint4*>(MH + W * PP)[mt];
     }
-    if (!W3_KEPT) load_w3(0, lane);                              // (two tiles per wave: loaded per strip, the first in flight across the barrier)
+    if (!W3_KEPT && !SKIP3) load_w3(0, lane);                  // (two tiles per wave: loaded per strip, the first in flight across the barrier)
     __syncthreads();
 
     // ---- C(s) .. D(s): stage 3 (all waves, tiles wave * T3W + t): 1x1, P -> C, + the in tile (residual), ReLU / sign-bit mask, in place
-    if (!(a.dbg & 4)) {
+    if (!(a.dbg & 4) && !SKIP3) {
       constexpr int T3W = G::T3W;
       const bf16_t* xrow = BT + n * AP + 8 * hf;
 #pragma unroll
@@ -455,10 +455,12 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
     // ---- D(s) .. E(s): out (all waves)
     if (!(a.dbg & 8)) {
       const int t = opaque(tid);
+      if (!SKIP3) {
 #pragma unroll 4
-      for (int u = t; u < NP * CP; u += 512) {
-        const int q = u / CP, c = (u % CP) * 8;
-        if (q / W < rows_in) *reinterpret_cast<uint4*>(a.out + (pix0 + q) * C + c) = *reinterpret_cast<const uint4*>(XT + (q + W) * XP + c);
+        for (int u = t; u < NP * CP; u += 512) {
+          const int q = u / CP, c = (u % CP) * 8;
+          if (q / W < rows_in) *reinterpret_cast<uint4*>(a.out + (pix0 + q) * C + c) = *reinterpret_cast<const uint4*>(XT + (q + W) * XP + c);
+        }
       }
       if (a.b_out)                                               // the stage-2 result
         for (int u = t; u < NP * PP; u += 512) {
@@ -480,13 +482,13 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
   }
 }
 
-template <class G, bool BWD>
+template <class G, bool BWD, bool SKIP3 = false>
 static int bneck_launch(BneckArgs& a, hipStream_t s, const char* what) {
   using LD = BneckLds<G, BWD>;
   static_assert(LD::TOTAL <= 160 * 1024, "LDS");
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_kernel<G, BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LD::TOTAL);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck_kernel<G, BWD, SKIP3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LD::TOTAL);
     if (e != hipSuccess) {
       set_error("%s: hipFuncSetAttribute(%zu B LDS) failed: %s", what, (size_t)LD::TOTAL, hipGetErrorString(e));
       return 1;
@@ -499,7 +501,7 @@ static int bneck_launch(BneckArgs& a, hipStream_t s, const char* what) {
   a.spw = spw_env > 0 ? spw_env : (nst + 255) / 256;
   static int dbg_env = [] { const char* e = dev_getenv("SEDT_BNECK_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg_env;
-  hipLaunchKernelGGL((bneck_kernel<G, BWD>), dim3((nst + a.spw - 1) / a.spw), dim3(512), LD::TOTAL, s, a);
+  hipLaunchKernelGGL((bneck_kernel<G, BWD, SKIP3>), dim3((nst + a.spw - 1) / a.spw), dim3(512), LD::TOTAL, s, a);
   return check_launch(what);
 }
 
@@ -517,6 +519,7 @@ struct Bneck0Args {
   const u32x4* w1; const u32x4* w2; const u32x4* w3; const u32x4* wd;      // [64][64], [64][576], [256][64], [256][64] fragment-major
   const float* s1; const float* b1; const float* s2; const float* b2; const float* s3; const float* b3; const float* sd; const float* bd;
   bf16_t* a_out; bf16_t* b_out;      // [M][64] or null
+  uint8_t* abits_out; uint8_t* bbits_out;      // sign bits of a, b [M][8] or null (what sedt_bneck_bwd reads)
   uint8_t* bits_out;                 // sign bits of y [M][32] or null
   int B, H, spw;
 };
@@ -529,7 +532,9 @@ struct B0 {
   static constexpr size_t BT = AT + (size_t)(R + 2) * AW * AP * 2;
   static constexpr size_t YT = BT + (size_t)NP * AP * 2;
   static constexpr size_t BITS = YT + (size_t)NP * YP * 2;
-  static constexpr size_t SB = BITS + (size_t)NP * 32;
+  static constexpr size_t MH = BITS + (size_t)NP * 32;           // sign bits of a on the halo tile [NP1][8]
+  static constexpr size_t MA = MH + (size_t)NP1 * 8;             // sign bits of b [NP][8]
+  static constexpr size_t SB = MA + (size_t)NP * 8;
   static constexpr size_t TOTAL = SB + (4 * 64 + 4 * 256) * 4;
 };
 
@@ -541,6 +546,8 @@ __global__ __launch_bounds__(512) void bneck0_fwd_kernel(const Bneck0Args a) {
   bf16_t* BT = reinterpret_cast<bf16_t*>(smem + B0::BT);        // [NP][72]: 3x3 output
   bf16_t* YT = reinterpret_cast<bf16_t*>(smem + B0::YT);        // [NP][264]: out tile
   uint8_t* BITS = smem + B0::BITS;                              // [NP][32]
+  uint8_t* MH = smem + B0::MH;
+  uint8_t* MA = smem + B0::MA;
   float* SB = reinterpret_cast<float*>(smem + B0::SB);          // s1 b1 s2 b2 (64 each) s3 b3 sd bd (256 each)
   const int tid = threadIdx.x, wave = tid >> 6;
   const int strips = (a.H + R - 1) / R, nst = a.B * strips;
@@ -635,6 +642,7 @@ __global__ __launch_bounds__(512) void bneck0_fwd_kernel(const Bneck0Args a) {
           const int p = sl * 32 + n, trow = p >> 4, pc = p & 15, gr = r0 - 1 + trow;
           const bool inimg = gr >= 0 && gr < a.H;
           bf16_t* dst = AT + (trow * AW + pc + 1) * AP + tl * 32 + 4 * hf;
+          unsigned nb = 0;
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const f32x2 lo = {acc[s3][4 * g4], acc[s3][4 * g4 + 1]}, hi = {acc[s3][4 * g4 + 2], acc[s3][4 * g4 + 3]};
@@ -642,7 +650,12 @@ __global__ __launch_bounds__(512) void bneck0_fwd_kernel(const Bneck0Args a) {
             o.x = pack2(relu2(lo * f32x2{sc[g4].x, sc[g4].y} + f32x2{bi[g4].x, bi[g4].y}));
             o.y = pack2(relu2(hi * f32x2{sc[g4].z, sc[g4].w} + f32x2{bi[g4].z, bi[g4].w}));
             if (!inimg) o = make_uint2(0, 0);
+            nb |= nibble4(o.x, o.y) << (8 * g4 + 4 * hf);
             *reinterpret_cast<uint2*>(dst + 8 * g4) = o;
+          }
+          if (a.abits_out) {
+            const unsigned other = (unsigned)__shfl_xor((int)nb, 32);
+            if (hf == 0) *reinterpret_cast<unsigned*>(MH + p * 8 + tl * 4) = nb | other;
           }
         }
       }
@@ -694,21 +707,29 @@ __global__ __launch_bounds__(512) void bneck0_fwd_kernel(const Bneck0Args a) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const int q = (grp * 2 + s2) * 32 + n;
+        unsigned nb = 0;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const f32x2 lo = {acc[s2][4 * g4], acc[s2][4 * g4 + 1]}, hi = {acc[s2][4 * g4 + 2], acc[s2][4 * g4 + 3]};
           uint2 o;
           o.x = pack2(relu2(lo * f32x2{sc[g4].x, sc[g4].y} + f32x2{bi[g4].x, bi[g4].y}));
           o.y = pack2(relu2(hi * f32x2{sc[g4].z, sc[g4].w} + f32x2{bi[g4].z, bi[g4].w}));
+          nb |= nibble4(o.x, o.y) << (8 * g4 + 4 * hf);
           *reinterpret_cast<uint2*>(BT + q * AP + tl * 32 + 8 * g4 + 4 * hf) = o;
         }
+        if (a.bbits_out) {
+          const unsigned other = (unsigned)__shfl_xor((int)nb, 32);
+          if (hf == 0) *reinterpret_cast<unsigned*>(MA + q * 8 + tl * 4) = nb | other;
+        }
       }
-    } else if (a.a_out) {
-      for (int u = mt; u < NP * 8; u += 256) {
-        const int q = u >> 3, c = (u & 7) * 8;
-        if ((q >> 4) < rows_in)
-          *reinterpret_cast<uint4*>(a.a_out + (pix0 + q) * 64 + c) = *reinterpret_cast<const uint4*>(AT + (((q >> 4) + 1) * AW + (q & 15) + 1) * AP + c);
-      }
+    } else {
+      if (a.a_out)
+        for (int u = mt; u < NP * 8; u += 256) {
+          const int q = u >> 3, c = (u & 7) * 8;
+          if ((q >> 4) < rows_in)
+            *reinterpret_cast<uint4*>(a.a_out + (pix0 + q) * 64 + c) = *reinterpret_cast<const uint4*>(AT + (((q >> 4) + 1) * AW + (q & 15) + 1) * AP + c);
+        }
+      if (a.abits_out && mt < 64 && (mt >> 3) < rows_in) reinterpret_cast<uint4*>(a.abits_out + pix0 * 8)[mt] = reinterpret_cast<const uint4*>(MH + W * 8)[mt];
     }
     __syncthreads();
 
@@ -778,6 +799,8 @@ __global__ __launch_bounds__(512) void bneck0_fwd_kernel(const Bneck0Args a) {
           if ((q >> 4) < rows_in) *reinterpret_cast<uint4*>(a.b_out + (pix0 + q) * 64 + c) = *reinterpret_cast<const uint4*>(BT + q * AP + c);
         }
       if (a.bits_out && t < 256 && (t >> 5) < rows_in) reinterpret_cast<uint4*>(a.bits_out + pix0 * 32)[t] = reinterpret_cast<const uint4*>(BITS)[t];
+      if (a.bbits_out && t >= 256 && t < 320 && ((t - 256) >> 3) < rows_in)
+        reinterpret_cast<uint4*>(a.bbits_out + pix0 * 8)[t - 256] = reinterpret_cast<const uint4*>(MA)[t - 256];
       if (more && !comp) put();
     }
     __syncthreads();
@@ -836,9 +859,11 @@ extern "C" int sedt_bneck_fwd(const void* x, void* y, const void* w1_frag, const
 extern "C" int sedt_bneck_bwd(const void* gy, void* gx, const void* w3t_frag, const void* w2t_frag, const void* w1t_frag, const uint8_t* abits,
                               const uint8_t* bbits, const uint8_t* xbits, void* gb_out, void* ga_out, int cin, int planes, int W, int B, int H,
                               void* stream) {
-  SEDT_REQUIRE(gy && gx && w3t_frag && w2t_frag && w1t_frag && abits && bbits, "bneck_bwd: null pointer");
+  const bool skip3 = gx == nullptr;                              // the chain stops at ga: the caller's block has another first convolution
+  SEDT_REQUIRE(gy && w3t_frag && w2t_frag && abits && bbits && (skip3 || w1t_frag), "bneck_bwd: null pointer");
   SEDT_REQUIRE(B >= 1 && H >= 1, "bneck_bwd: B = %d, H = %d", B, H);
-  SEDT_REQUIRE((gb_out == nullptr) == (ga_out == nullptr), "bneck_bwd: the two intermediate gradients come both or not at all");
+  SEDT_REQUIRE(skip3 ? ga_out != nullptr : (gb_out == nullptr) == (ga_out == nullptr),
+               "bneck_bwd: the two intermediate gradients come both or not at all (ga alone when gx is null)");
   const int g = bneck_geom(cin, planes, W);
   SEDT_REQUIRE(g != 0, "bneck_bwd: cin %d, planes %d, W %d outside the envelope (256/64/16, 512/128/8)", cin, planes, W);
   BneckArgs a{};
@@ -847,6 +872,11 @@ extern "C" int sedt_bneck_bwd(const void* gy, void* gx, const void* w3t_frag, co
   a.abits_in = abits; a.bbits_in = bbits; a.bits_in = xbits;
   a.a_out = (bf16_t*)gb_out; a.b_out = (bf16_t*)ga_out;          // (stage 1 of the chain produces gb, stage 2 ga)
   a.B = B; a.H = H;
+  if (skip3) {
+    SEDT_REQUIRE(g == 1, "bneck_bwd: the chain-only form exists for the layer1 geometry");
+    a.bits_in = nullptr;
+    return bneck_launch<BG1, true, true>(a, reinterpret_cast<hipStream_t>(stream), "bneck_bwd");
+  }
   return g == 1 ? bneck_launch<BG1, true>(a, reinterpret_cast<hipStream_t>(stream), "bneck_bwd")
                 : bneck_launch<BG2, true>(a, reinterpret_cast<hipStream_t>(stream), "bneck_bwd");
 }
@@ -857,15 +887,17 @@ extern "C" int sedt_bneck0_ok(int cin, int planes, int W, int stride, int dil, i
 
 extern "C" int sedt_bneck0_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const void* wd_frag,
                                const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3, const float* sd,
-                               const float* bd, void* a_out, void* b_out, uint8_t* bits_out, int B, int H, void* stream) {
+                               const float* bd, void* a_out, void* b_out, uint8_t* abits_out, uint8_t* bbits_out, uint8_t* bits_out, int B, int H,
+                               void* stream) {
   SEDT_REQUIRE(x && y && w1_frag && w2_frag && w3_frag && wd_frag && s1 && b1 && s2 && b2 && s3 && b3 && sd && bd, "bneck0_fwd: null pointer");
   SEDT_REQUIRE(B >= 1 && H >= 1, "bneck0_fwd: B = %d, H = %d", B, H);
-  SEDT_REQUIRE((a_out == nullptr) == (b_out == nullptr), "bneck0_fwd: the two intermediates come both or not at all");
+  SEDT_REQUIRE((a_out == nullptr) == (b_out == nullptr) && (abits_out == nullptr) == (bbits_out == nullptr),
+               "bneck0_fwd: the two intermediates (their sign bits) come both or not at all");
   Bneck0Args a{};
   a.in = (const bf16_t*)x; a.out = (bf16_t*)y;
   a.w1 = (const u32x4*)w1_frag; a.w2 = (const u32x4*)w2_frag; a.w3 = (const u32x4*)w3_frag; a.wd = (const u32x4*)wd_frag;
   a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2; a.s3 = s3; a.b3 = b3; a.sd = sd; a.bd = bd;
-  a.a_out = (bf16_t*)a_out; a.b_out = (bf16_t*)b_out; a.bits_out = bits_out;
+  a.a_out = (bf16_t*)a_out; a.b_out = (bf16_t*)b_out; a.abits_out = abits_out; a.bbits_out = bbits_out; a.bits_out = bits_out;
   a.B = B; a.H = H;
   return bneck0_launch(a, reinterpret_cast<hipStream_t>(stream));
 }

@@ -841,10 +841,12 @@ class StageFn(Function):
                 wdf, wdb, sd, bd = _prep_conv(dt, t[15], t[16:20])
                 cf = [packing.lookup_conv_frag(t[k]) for k in (0, 5, 10, 15)]
                 if all(c is not None for c in cf):
-                    y, a, b, ybits = ops.bneck0_fwd(x, B, H, [c[0] for c in cf], ((s1, b1), (s2, b2), (s3, b3), (sd, bd)),
-                                                    train=any(ctx.needs_input_grad), want_bits=bool(tr))
+                    frozen = not any(t[k].requires_grad for k in (0, 5, 10, 15))
+                    y, a, b, ybits, abits, bbits = ops.bneck0_fwd(x, B, H, [c[0] for c in cf], ((s1, b1), (s2, b2), (s3, b3), (sd, bd)),
+                                                                  train=any(ctx.needs_input_grad), want_bits=bool(tr), want_ab=not frozen)
                     saved.append(dict(blk=blk, x=x, a=a, b=b, g1=g1, g2=g2, g3=g3, s=(s1, s2, s3), wb=(w1b, w2b, w3b), H=H, W=W, y=y,
-                                      xbits=xbits, gd=ConvGeom(H, W, cin, 4 * pl, 1, blk.stride), sd=sd, wdb=wdb))
+                                      xbits=xbits, gd=ConvGeom(H, W, cin, 4 * pl, 1, blk.stride), sd=sd, wdb=wdb,
+                                      chain=[c[1] for c in cf] if frozen else None, ab_bits=(abits, bbits)))
                     x, xbits = y, ybits
                     continue
             a = ops.conv_fwd(dt, x, B, g1, w1f, scale=s1, bias=b1, act=ACT_RELU)
@@ -890,6 +892,16 @@ class StageFn(Function):
             w1b, w2b, w3b = r['wb']
             first = bi_ == 0
             want_gx = (not first) or need_x_grad
+            if r.get('chain') is not None and want_gx:
+                # layer1's block 0, frozen: gy -> gb -> ga in one launch (sign bits of b, a from the fused forward), then the input-gradient
+                # GEMMs of the projection and of conv1 (its residual operand); the stem's output needs no mask here (StemFn masks by its own
+                # pooled output)
+                _, _, ga = ops.bneck_bwd(gp, B, r['H'], r['W'], r['chain'], *r['ab_bits'], None, chain_only=True)
+                side = ops.conv_dgrad(dt, gp, B, r['gd'], r['wdb'])
+                mask_x = (not first) or meta['mask_input']
+                ep = (dict(mask=r['x'], ldm=r['x'].stride(0)) if mask_x else {})
+                gp = ops.conv_dgrad(dt, ga, B, r['g1'], w1b, res=side, ldr=side.stride(0), **ep)
+                continue
             if r.get('fused') is not None and want_gx:
                 mask_x = (not first) or meta['mask_input']
                 if not mask_x or r.get('xbits') is not None:

@@ -753,19 +753,20 @@ def bneck_fwd(x, B, H, W, wf, sb, train=True, want_bits=True, want_ab=False):
     return y, a, b, bits, abits, bbits
 
 
-def bneck_bwd(gy, B, H, W, wt, abits, bbits, xbits, want_g=False):
+def bneck_bwd(gy, B, H, W, wt, abits, bbits, xbits, want_g=False, chain_only=False):
     """input gradient of the fused Bottleneck: gy [B*H*W, C] bf16 (already masked by [y > 0]); wt = the three fragment-major dgrad
     operands (conv1, conv2, conv3 order); abits / bbits from bneck_fwd; xbits = sign bits of the block input or None.
-    Returns (gx, gb, ga): gb / ga [M, P] = the gradients of the two intermediates (want_g: a trainable block's weight gradients read them)"""
+    Returns (gx, gb, ga): gb / ga [M, P] = the gradients of the two intermediates (want_g: a trainable block's weight gradients read them).
+    chain_only: stop at ga (gx None; wt[0] and xbits unused) - the caller's block has another first convolution (layer1's block 0)"""
     assert gy.is_contiguous() and abits.is_contiguous() and bbits.is_contiguous() and (xbits is None or xbits.is_contiguous())
     M, C = gy.shape
-    gx = torch.empty_like(gy)
+    gx = None if chain_only else torch.empty_like(gy)
     gb = ga = None
-    if want_g:
-        gb = torch.empty((M, C // 4), device=gy.device, dtype=torch.bfloat16)
-        ga = torch.empty_like(gb)
-    L.check(L.load().sedt_bneck_bwd(_p(gy), _p(gx), _p(wt[2]), _p(wt[1]), _p(wt[0]), _p(abits), _p(bbits), _p(xbits), _p(gb), _p(ga), C, C // 4, W,
-                                    B, H, L.stream_ptr()), 'bneck_bwd')
+    if want_g or chain_only:
+        ga = torch.empty((M, C // 4), device=gy.device, dtype=torch.bfloat16)
+        gb = torch.empty_like(ga) if want_g else None
+    L.check(L.load().sedt_bneck_bwd(_p(gy), _p(gx), _p(wt[2]), _p(wt[1]), None if chain_only else _p(wt[0]), _p(abits), _p(bbits),
+                                    None if chain_only else _p(xbits), _p(gb), _p(ga), C, C // 4, W, B, H, L.stream_ptr()), 'bneck_bwd')
     return gx, gb, ga
 
 
@@ -774,23 +775,26 @@ def bneck0_ok(dtype, blk, W):
     return bool(int(FUSED_BNECK) >= 3 and dtype == BF16 and L.load().sedt_bneck0_ok(blk.cin, blk.planes, W, blk.stride, blk.dil, int(blk.ds), dtype))
 
 
-def bneck0_fwd(x, B, H, wf, sb, train=True, want_bits=True):
+def bneck0_fwd(x, B, H, wf, sb, train=True, want_bits=True, want_ab=False):
     """x [B*H*16, 64] bf16 contiguous; wf = the fragment-major forward operands of conv1, conv2, conv3 and the projection; sb = their four
     (scale, bias) pairs.  Returns (y, a, b, ybits); a, b (what the per-op backward reads) and ybits only when training"""
     _dev_check(x)
     M = x.shape[0]
     assert x.is_contiguous() and M == B * H * 16 and x.shape[1] == 64
     y = torch.empty((M, 256), device=x.device, dtype=torch.bfloat16)
-    a = b = bits = None
+    a = b = bits = abits = bbits = None
     if train:
-        a = torch.empty((M, 64), device=x.device, dtype=torch.bfloat16)
-        b = torch.empty_like(a)
+        abits = torch.empty((M, 8), device=x.device, dtype=torch.uint8)
+        bbits = torch.empty_like(abits)
+        if want_ab:
+            a = torch.empty((M, 64), device=x.device, dtype=torch.bfloat16)
+            b = torch.empty_like(a)
         if want_bits:
             bits = torch.empty((M, 32), device=x.device, dtype=torch.uint8)
     (s1, b1), (s2, b2), (s3, b3), (sd, bd) = sb
     L.check(L.load().sedt_bneck0_fwd(_p(x), _p(y), _p(wf[0]), _p(wf[1]), _p(wf[2]), _p(wf[3]), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3),
-                                     _p(sd), _p(bd), _p(a), _p(b), _p(bits), B, H, L.stream_ptr()), 'bneck0_fwd')
-    return y, a, b, bits
+                                     _p(sd), _p(bd), _p(a), _p(b), _p(abits), _p(bbits), _p(bits), B, H, L.stream_ptr()), 'bneck0_fwd')
+    return y, a, b, bits, abits, bbits
 
 
 SLAB_HEADS = _dev_env('SEDT_SLAB_HEADS', '1') != '0'

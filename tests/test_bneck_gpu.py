@@ -192,8 +192,11 @@ def test_fused_first_block_forward_against_torch():
     with plan:
         cf = [packing.lookup_conv_frag(w) for w in ws]
         sb = [packing.lookup(w)[2:] for w in ws]
-        y, a, b, bits = ops.bneck0_fwd(x, B, H, [c[0] for c in cf], sb)
-        y2, a2, b2, bits2 = ops.bneck0_fwd(x, B, H, [c[0] for c in cf], sb, train=False)
+        y, a, b, bits, abits, bbits = ops.bneck0_fwd(x, B, H, [c[0] for c in cf], sb, want_ab=True)
+        for t_, tb in ((a, abits), (b, bbits)):
+            w_ = (t_.float() > 0).view(-1, 8, 8).to(torch.uint8)
+            assert torch.equal(tb, (w_ << torch.arange(8, device='cuda', dtype=torch.uint8)).sum(-1).to(torch.uint8))
+        y2, a2, b2, bits2, _, _ = ops.bneck0_fwd(x, B, H, [c[0] for c in cf], sb, train=False)
         torch.cuda.synchronize()
     assert torch.equal(y, y2) and a2 is None and bits2 is None
     want = (y.float() > 0).view(-1, 32, 8).to(torch.uint8)
