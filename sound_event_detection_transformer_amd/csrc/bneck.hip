@@ -7,7 +7,8 @@
 // pixels, csrc/slab.h): the x tile with one halo row above and below sits in LDS once - it is the B operand of the first 1x1 AND the
 // residual of the last - the two 64-channel intermediates never leave the CU (LDS tiles; the 3x3 reads its nine shifted views of a
 // zero-padded tile), and only the weights stream from L2 (fragment-major, sedt_pack_frag).  HBM traffic per pixel: 512 B in (+ 2/R
-// halo) + 512 B out (+ 256 B of a, b and 32 B of sign bits when the backward will need them) against 1,792 B.
+// halo, mostly L2 hits) + 512 B out (+ 48 B of sign bits when a backward will follow; + 256 B of a and b only for a trainable block)
+// against 2,080 B.
 //
 // The input-gradient chain has the same shape with the weights transposed (gy -> 1x1 256 -> 64 masked by [b > 0] -> 3x3 with the taps
 // mirrored, masked by [a > 0] -> 1x1 64 -> 256 + gy, masked by the sign bits of the block input), so ONE kernel template serves both;
