@@ -1,5 +1,6 @@
-// bneck.hip - an identity Bottleneck of ResNet layer1 (torchvision v1.5 block behind reference sedt/backbone.py:97-113: 1x1 256 -> 64,
-// 3x3 64 -> 64, 1x1 64 -> 256, FrozenBatchNorm after each, residual + ReLU) in ONE launch, and its input-gradient chain in one more.
+// bneck.hip - an identity Bottleneck of ResNet layer1 / layer2 (torchvision v1.5 block behind reference sedt/backbone.py:97-113: 1x1
+// C -> C/4, 3x3, 1x1 C/4 -> C, FrozenBatchNorm after each, residual + ReLU) in ONE launch, its input-gradient chain in one more, and
+// (end of file) the forward of layer1's first block with its projection skip.  The numbers below are layer1's (C = 256).
 //
 // The per-op path moves every intermediate through HBM: at B = 64 (128,000 pixels of a 125 x 16 map) a block reads x (65 MB) twice,
 // writes and re-reads a and b (16 MB each) and writes y (65 MB) in three launches, ~70 us forward and ~79 us for the input gradients,
@@ -13,7 +14,8 @@
 // The input-gradient chain has the same shape with the weights transposed (gy -> 1x1 256 -> 64 masked by [b > 0] -> 3x3 with the taps
 // mirrored, masked by [a > 0] -> 1x1 64 -> 256 + gy, masked by the sign bits of the block input), so ONE kernel template serves both;
 // the FrozenBN scales are folded into the transposed weights exactly as for the per-op dgrad kernels.  layer1 is frozen in the
-// reference (backbone.py:60-62): no weight gradients are needed there; a trainable block keeps the per-op backward.
+// reference (backbone.py:60-62): no weight gradients are needed there; a trainable block (layer2) takes the two intermediate
+// gradients out of the chain (gb_out / ga_out) for its weight-gradient GEMMs.
 // Rounding points are those of the per-op chain: a, b (their gradients) rounded to bf16, accumulation in f32.
 #include "slab.h"
 
