@@ -428,6 +428,16 @@ int sedt_bneck0_fwd(const void* x, void* y, const void* w1_frag, const void* w2_
                     const float* b1, const float* s2, const float* b2, const float* s3, const float* b3, const float* sd, const float* bd,
                     void* a_out, void* b_out, uint8_t* abits_out, uint8_t* bbits_out, uint8_t* bits_out, int B, int H, void* stream);
 
+/* The first Bottleneck of layer2 (256 -> 128 at the input resolution, 3x3 stride 2, 128 -> 512, stride-2 1x1 projection 256 -> 512 on the
+ * skip path; input map 16 columns wide, output 8) in ONE forward launch (csrc/bneck.hip: bneck2_fwd_kernel).  x [B*H*16][256], y
+ * [B*H2*8][512] with H2 = (H - 1) / 2 + 1; w*_frag / s* / b* as for sedt_bneck0_fwd.  Training by-products, each may be null: a_out
+ * [B*H*16][128] and b_out [B*H2*8][128] (both or none; what the per-op backward of the block reads), bits_out [B*H2*8][64] = sign bits
+ * of y.  Envelope (sedt_bneck2_ok): bf16, cin 256, planes 128, W 16, stride 2, dilation 1, WITH the downsample branch. */
+int sedt_bneck2_ok(int cin, int planes, int W, int stride, int dil, int has_downsample, int dtype);
+int sedt_bneck2_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const void* wd_frag, const float* s1,
+                    const float* b1, const float* s2, const float* b2, const float* s3, const float* b3, const float* sd, const float* bd,
+                    void* a_out, void* b_out, uint8_t* bits_out, int B, int H, void* stream);
+
 /* The prediction heads on the stacked decoder output hs [L*B*Qp][256] bf16 (sedt/sedt.py:88-95, 398-409) in ONE launch each way
  * (csrc/heads_slab.hip; a workgroup per 32 rows): class logits cls [rows][C1] = hs wc^T + bc, boxes [rows][2] = sigmoid(W3 relu(W2
  * relu(W1 hs + b1) + b2) + b3), audio tags at [B][CA] = sigmoid(wa hs + ba) on query 0 of the last layer (CA = 0: no such head).

@@ -827,6 +827,290 @@ static int bneck0_launch(Bneck0Args& a, hipStream_t s) {
   return check_launch("bneck0_fwd");
 }
 
+// ---------------------------------------------------------------------------------------------------------------- layer2, block 0
+// The first Bottleneck of layer2 (256 -> 128 at full resolution, 3x3 STRIDE 2 -> half resolution, 128 -> 512, with the stride-2 1x1
+// projection 256 -> 512 on the skip path) in ONE forward launch.  A workgroup walks strips of 4 OUTPUT rows (8 columns: one slab of 32
+// pixels); the in tile is the 9 input rows x 16 columns under them (144 pixels x 256 channels, 76 KB), the first intermediate a
+// zero-bordered 9 x 18 tile whose stride-2 views are the taps, and the out tile re-uses that tile's memory once the 3x3 is done.
+// Roles, barriers and the register pool as in bneck_kernel; stage 3 streams its weights (conv3 + the projection: 24 fragments per output
+// tile, two tiles per wave) in chunks of 8 through the same cur / alt registers.  The backward of this block stays per-op.
+struct Bneck2Args {
+  const bf16_t* in;                  // x [B*H*16][256]
+  bf16_t* out;                       // y [B*H2*8][512], H2 = (H - 1) / 2 + 1
+  const u32x4* w1; const u32x4* w2; const u32x4* w3; const u32x4* wd;      // [128][256], [128][1152], [512][128], [512][256] fragment-major
+  const float* s1; const float* b1; const float* s2; const float* b2; const float* s3; const float* b3; const float* sd; const float* bd;
+  bf16_t* a_out;                     // [B*H*16][128] or null
+  bf16_t* b_out;                     // [B*H2*8][128] or null
+  uint8_t* bits_out;                 // sign bits of y [B*H2*8][64] or null
+  int B, H, H2, spw;
+};
+
+struct B2 {
+  static constexpr int CI = 256, P = 128, C = 512, WI = 16, WO = 8, RO = 4, RI = 2 * RO + 1;
+  static constexpr int NPI = RI * WI, NPO = RO * WO, NS1 = (NPI + 31) / 32;                   // 144 in pixels (5 slabs, the last half), 32 out
+  static constexpr int XP = CI + 8, AP = P + 8, AW = WI + 2, YP = C + 8;
+  static constexpr size_t XT = 0;
+  static constexpr size_t AT = XT + (size_t)NPI * XP * 2;                                    // [9][18][136]; the out tile [32][520] later
+  static constexpr size_t BT = AT + (size_t)RI * AW * AP * 2;
+  static constexpr size_t BITS = BT + (size_t)NPO * AP * 2;
+  static constexpr size_t SB = BITS + (size_t)NPO * (C / 8);
+  static constexpr size_t TOTAL = SB + (4 * P + 4 * C) * 4;
+  static_assert((size_t)NPO * YP * 2 <= (size_t)RI * AW * AP * 2, "the out tile fits in the 3x3 input tile");
+};
+
+__global__ __launch_bounds__(512) void bneck2_fwd_kernel(const Bneck2Args a) {
+  constexpr int NPI = B2::NPI, NPO = B2::NPO, NS1 = B2::NS1, RO = B2::RO, XP = B2::XP, AP = B2::AP, AW = B2::AW, YP = B2::YP, P = B2::P, C = B2::C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* XT = reinterpret_cast<bf16_t*>(smem + B2::XT);
+  bf16_t* AT = reinterpret_cast<bf16_t*>(smem + B2::AT);
+  bf16_t* YT = AT;                                              // (stage 3 on: the 3x3 input tile is dead)
+  bf16_t* BT = reinterpret_cast<bf16_t*>(smem + B2::BT);
+  uint8_t* BITS = smem + B2::BITS;                              // [32][64]
+  float* SB = reinterpret_cast<float*>(smem + B2::SB);          // s1 b1 s2 b2 (128 each) s3 b3 sd bd (512 each)
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int strips = (a.H2 + RO - 1) / RO, nst = a.B * strips;
+  const int first = blockIdx.x * a.spw, last = min(first + a.spw, nst);
+  if (first >= last) return;
+  const bool comp = wave < 4;
+
+  // registers: cur = pool[0..7], alt = pool[8..15] (everybody: stage 3 streams through them too); pool[16..35] is the moving waves' next
+  // in tile (18 pieces) AND the compute waves' five stage-1 accumulators - a wave is one or the other for life
+  u32x4 pool[36];
+  f32x16(&acc1)[5] = *reinterpret_cast<f32x16(*)[5]>(&pool[16]);
+  u32x4(&cur)[8] = *reinterpret_cast<u32x4(*)[8]>(&pool[0]);
+  u32x4(&alt)[8] = *reinterpret_cast<u32x4(*)[8]>(&pool[8]);
+  const u32x4* w1p = a.w1 + (long)wave * 16 * 64;               // compute waves: stage 1 / 2 tile = wave
+  const u32x4* w2p = a.w2 + (long)wave * 72 * 64;
+  if (comp) slab::load_chunk<1>(cur, w1p, 0, 0, tid & 63);
+  slab::issue_fence();
+
+  auto geom = [&](int s, int& clip, int& r0o) {
+    clip = s / strips;
+    r0o = (s % strips) * RO;
+  };
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto fetch = [&](int s) {
+    int clip, r0o;
+    geom(s, clip, r0o);
+    const int mt = opaque(tid) - 256;
+#pragma unroll
+    for (int q = 0; q < 18; ++q) {
+      const int u = mt + q * 256, p = u >> 5, c = (u & 31) * 8, gr = 2 * r0o - 1 + (p >> 4);
+      pool[16 + q] = (gr >= 0 && gr < a.H) ? *reinterpret_cast<const u32x4*>(a.in + (((long)clip * a.H + gr) * 16 + (p & 15)) * 256 + c) : zero4;
+    }
+  };
+  auto put = [&]() {
+    const int mt = opaque(tid) - 256;
+#pragma unroll
+    for (int q = 0; q < 18; ++q) {
+      const int u = mt + q * 256, p = u >> 5, c = (u & 31) * 8;
+      *reinterpret_cast<u32x4*>(XT + p * XP + c) = pool[16 + q];
+    }
+  };
+
+  for (int u = tid; u < B2::RI * AW * AP / 8; u += 512) reinterpret_cast<uint4*>(AT)[u] = make_uint4(0, 0, 0, 0);
+  for (int u = tid; u < 4 * P + 4 * C; u += 512) {
+    const float* src = u < P ? a.s1 + u : u < 2 * P ? a.b1 + (u - P) : u < 3 * P ? a.s2 + (u - 2 * P) : u < 4 * P ? a.b2 + (u - 3 * P)
+                       : u < 4 * P + C ? a.s3 + (u - 4 * P) : u < 4 * P + 2 * C ? a.b3 + (u - 4 * P - C)
+                       : u < 4 * P + 3 * C ? a.sd + (u - 4 * P - 2 * C) : a.bd + (u - 4 * P - 3 * C);
+    SB[u] = *src;
+  }
+  if (!comp) {
+    fetch(first);
+    put();
+  }
+  __syncthreads();
+
+  for (int s = first; s < last; ++s) {
+    int clip, r0o;
+    geom(s, clip, r0o);
+    const int rows_out = min(RO, a.H2 - r0o);
+    const long opix0 = ((long)clip * a.H2 + r0o) * 8;            // first out pixel
+    const bool more = s + 1 < last;
+    const int lane = opaque(tid) & 63, n = lane & 31, hf = lane >> 5, mt = opaque(tid) - 256;
+
+    // ---- A .. B: stage 1 (1x1, 256 -> 128 on the 144 in pixels: tile = wave, all five slabs) | move: the next in tile into registers
+    if (comp) {
+      f32x16(&acc)[5] = acc1;
+      slab::zero_acc<5>(acc);
+      gemm_slabs<5, 16>(acc, XT, XP, w1p, lane, cur, alt, [&](u32x4(&d)[8]) {
+        load4(d, 0, w2p, lane);                                  // units 0, 1 of the 3x3 (land in cur)
+        load4(d, 4, w2p + 4 * 64, lane);
+      });
+      load4(alt, 0, w2p + 8 * 64, lane);                         // units 2, 3
+      load4(alt, 4, w2p + 12 * 64, lane);
+      slab::issue_fence();
+      float4 sc[4], bi[4];
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        sc[g4] = *reinterpret_cast<const float4*>(SB + wave * 32 + 8 * g4 + 4 * hf);
+        bi[g4] = *reinterpret_cast<const float4*>(SB + P + wave * 32 + 8 * g4 + 4 * hf);
+      }
+#pragma unroll
+      for (int s3 = 0; s3 < 5; ++s3) {
+        const int p = s3 * 32 + n, trow = p >> 4, pc = p & 15, gr = 2 * r0o - 1 + trow;
+        const bool inimg = gr >= 0 && gr < a.H;
+        bf16_t* dst = AT + (trow * AW + pc + 1) * AP + wave * 32 + 4 * hf;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x2 lo = {acc[s3][4 * g4], acc[s3][4 * g4 + 1]}, hi = {acc[s3][4 * g4 + 2], acc[s3][4 * g4 + 3]};
+          uint2 o;
+          o.x = pack2(relu2(lo * f32x2{sc[g4].x, sc[g4].y} + f32x2{bi[g4].x, bi[g4].y}));
+          o.y = pack2(relu2(hi * f32x2{sc[g4].z, sc[g4].w} + f32x2{bi[g4].z, bi[g4].w}));
+          if (!inimg) o = make_uint2(0, 0);
+          if (p < NPI) *reinterpret_cast<uint2*>(dst + 8 * g4) = o;
+        }
+      }
+    } else if (more) {
+      fetch(s + 1);
+    }
+    __syncthreads();
+
+    // ---- B .. C: stage 2 (3x3 stride 2, 128 -> 128: tile = wave, the strip's one slab) | move: the first intermediate out
+    if (comp) {
+      f32x16 acc[1];
+      slab::zero_acc<1>(acc);
+      const bf16_t* ctr = AT + ((2 * (n >> 3) + 1) * AW + 2 * (n & 7) + 1) * AP + 8 * hf;      // out pixel n <-> in (2 ro, 2 co), padded
+#pragma unroll
+      for (int u = 0; u < 18; ++u) {
+        u32x4(&src)[8] = (u & 2) ? alt : cur;
+        const int so = (u & 1) * 4;
+        const int tap = u >> 1, kk0 = (u & 1) * 4;
+        const int off = ((tap / 3 - 1) * AW + (tap % 3 - 1)) * AP + kk0 * 16;
+        bf16x8 xb[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const bf16x8*>(ctr + off + kk * 16);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, src[so + kk]), xb[kk], acc[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 4 < 18) load4(src, so, w2p + (long)(u + 4) * 4 * 64, lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 sc = *reinterpret_cast<const float4*>(SB + 2 * P + wave * 32 + 8 * g4 + 4 * hf);
+        const float4 bi = *reinterpret_cast<const float4*>(SB + 3 * P + wave * 32 + 8 * g4 + 4 * hf);
+        const f32x2 lo = {acc[0][4 * g4], acc[0][4 * g4 + 1]}, hi = {acc[0][4 * g4 + 2], acc[0][4 * g4 + 3]};
+        uint2 o;
+        o.x = pack2(relu2(lo * f32x2{sc.x, sc.y} + f32x2{bi.x, bi.y}));
+        o.y = pack2(relu2(hi * f32x2{sc.z, sc.w} + f32x2{bi.z, bi.w}));
+        *reinterpret_cast<uint2*>(BT + n * AP + wave * 32 + 8 * g4 + 4 * hf) = o;
+      }
+    } else if (a.a_out) {
+      // in rows 2 r0o .. 2 r0o + 7 = tile rows 1 .. 8 (tile row 0 is the previous strip's row 8): every image row exactly once
+      for (int u = mt; u < 128 * 16; u += 256) {
+        const int p = (u >> 4) + 16, c = (u & 15) * 8, gr = 2 * r0o - 1 + (p >> 4);
+        if (gr < a.H && (gr >> 1) < a.H2 && ((p >> 4) - 1) < 2 * rows_out)
+          *reinterpret_cast<uint4*>(a.a_out + (((long)clip * a.H + gr) * 16 + (p & 15)) * P + c) =
+              *reinterpret_cast<const uint4*>(AT + ((p >> 4) * AW + (p & 15) + 1) * AP + c);
+      }
+    }
+    // stage 3's first chunk (conv3 of this wave's first tile) in flight across the barrier
+    slab::load_chunk<1>(cur, a.w3 + (long)(2 * wave) * 8 * 64, 0, 0, lane);
+    __syncthreads();
+
+    // ---- C .. D: stage 3 (all waves, tiles 2 wave + {0, 1}): conv3 over b + the stride-2 projection over x, ReLU; out tile in AT's memory
+    {
+      const bf16_t* brow = BT + n * AP + 8 * hf;
+      const bf16_t* xrow = XT + ((2 * (n >> 3) + 1) * 16 + 2 * (n & 7)) * XP + 8 * hf;      // x at (2 ro, 2 co)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int tile = 2 * wave + t;
+        f32x16 acc3[1], accd[1];
+        slab::zero_acc<1>(acc3);
+        slab::zero_acc<1>(accd);
+        // chunks of this tile: conv3 (8 k-steps) in cur/alt[t & 1 ? alt : cur], projection k-steps 0..7, 8..15 in the other two turns
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const int turn = t * 3 + c;                            // 0..5: even turns sit in cur, odd in alt
+          u32x4(&src)[8] = (turn & 1) ? alt : cur;
+          u32x4(&dst)[8] = (turn & 1) ? cur : alt;
+          // the next turn's chunk: conv3 of the next tile after this tile's projection; the next strip's first stage-1 chunk at the very end
+          if (c < 2) slab::load_chunk<1>(dst, a.wd + (long)tile * 16 * 64, 0, c * 8, lane);
+          else if (t == 0) slab::load_chunk<1>(dst, a.w3 + (long)(tile + 1) * 8 * 64, 0, 0, lane);
+          else if (comp) slab::load_chunk<1>(dst, w1p, 0, 0, lane);      // (turn 5 sits in alt: cur takes the next strip's first chunk)
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (c == 0) {
+              const bf16x8 xb = *reinterpret_cast<const bf16x8*>(brow + u * 16);
+              acc3[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, src[u]), xb, acc3[0], 0, 0, 0);
+            } else {
+              const bf16x8 xb = *reinterpret_cast<const bf16x8*>(xrow + ((c - 1) * 8 + u) * 16);
+              accd[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, src[u]), xb, accd[0], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        unsigned nibs = 0;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const float* sbp = SB + 4 * P + tile * 32 + 8 * g4 + 4 * hf;
+          const float4 s3v = *reinterpret_cast<const float4*>(sbp), b3v = *reinterpret_cast<const float4*>(sbp + C);
+          const float4 sdv = *reinterpret_cast<const float4*>(sbp + 2 * C), bdv = *reinterpret_cast<const float4*>(sbp + 3 * C);
+          const f32x2 lo = {acc3[0][4 * g4], acc3[0][4 * g4 + 1]}, hi = {acc3[0][4 * g4 + 2], acc3[0][4 * g4 + 3]};
+          const f32x2 dlo = {accd[0][4 * g4], accd[0][4 * g4 + 1]}, dhi = {accd[0][4 * g4 + 2], accd[0][4 * g4 + 3]};
+          const unsigned ilo = pack2(dlo * f32x2{sdv.x, sdv.y} + f32x2{bdv.x, bdv.y});      // the skip path as the per-op chain stores it
+          const unsigned ihi = pack2(dhi * f32x2{sdv.z, sdv.w} + f32x2{bdv.z, bdv.w});
+          uint2 o;
+          o.x = pack2(relu2(lo * f32x2{s3v.x, s3v.y} + f32x2{b3v.x, b3v.y} + widen2(ilo)));
+          o.y = pack2(relu2(hi * f32x2{s3v.z, s3v.w} + f32x2{b3v.z, b3v.w} + widen2(ihi)));
+          nibs |= nibble4(o.x, o.y) << (8 * g4 + 4 * hf);
+          *reinterpret_cast<uint2*>(YT + n * YP + tile * 32 + 8 * g4 + 4 * hf) = o;
+        }
+        if (a.bits_out) {
+          const unsigned other = (unsigned)__shfl_xor((int)nibs, 32);
+          if (hf == 0) *reinterpret_cast<unsigned*>(BITS + n * 64 + tile * 4) = nibs | other;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- D .. E: out (all waves)
+    {
+      const int t = opaque(tid);
+      for (int u = t; u < NPO * 64; u += 512) {
+        const int q = u >> 6, c = (u & 63) * 8;
+        if ((q >> 3) < rows_out) *reinterpret_cast<uint4*>(a.out + (opix0 + q) * C + c) = *reinterpret_cast<const uint4*>(YT + q * YP + c);
+      }
+      if (a.b_out) {
+        const int q = t >> 4, c = (t & 15) * 8;                  // 32 pixels x 16 pieces = 512 threads
+        if ((q >> 3) < rows_out) *reinterpret_cast<uint4*>(a.b_out + (opix0 + q) * P + c) = *reinterpret_cast<const uint4*>(BT + q * AP + c);
+      }
+      if (a.bits_out && t < 128 && (t >> 5) < rows_out) reinterpret_cast<uint4*>(a.bits_out + opix0 * 64)[t] = reinterpret_cast<const uint4*>(BITS)[t];
+    }
+    if (more) {
+      __syncthreads();
+      // ---- E .. A: the out tile is gone: the zero border of the 3x3 input tile back (its interior is rewritten by the next stage 1),
+      // the next in tile into LDS
+      for (int u = tid; u < B2::RI * 2 * (AP / 8); u += 512) {
+        const int r = u / (2 * (AP / 8)), w = u % (2 * (AP / 8)), side = w / (AP / 8), c = (w % (AP / 8)) * 8;
+        *reinterpret_cast<uint4*>(AT + (r * AW + side * (AW - 1)) * AP + c) = make_uint4(0, 0, 0, 0);
+      }
+      if (!comp) put();
+      __syncthreads();
+    }
+  }
+}
+
+static int bneck2_launch(Bneck2Args& a, hipStream_t s) {
+  static_assert(B2::TOTAL <= 160 * 1024, "LDS");
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck2_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)B2::TOTAL);
+    if (e != hipSuccess) {
+      set_error("bneck2_fwd: hipFuncSetAttribute(%zu B LDS) failed: %s", (size_t)B2::TOTAL, hipGetErrorString(e));
+      return 1;
+    }
+    attr = true;
+  }
+  const int nst = a.B * ((a.H2 + B2::RO - 1) / B2::RO);
+  a.spw = (nst + 255) / 256;
+  hipLaunchKernelGGL(bneck2_fwd_kernel, dim3((nst + a.spw - 1) / a.spw), dim3(512), B2::TOTAL, s, a);
+  return check_launch("bneck2_fwd");
+}
+
 typedef BG<256, 64, 16> BG1;          // layer1
 typedef BG<512, 128, 8> BG2;          // layer2
 
@@ -903,4 +1187,23 @@ extern "C" int sedt_bneck0_fwd(const void* x, void* y, const void* w1_frag, cons
   a.a_out = (bf16_t*)a_out; a.b_out = (bf16_t*)b_out; a.abits_out = abits_out; a.bbits_out = bbits_out; a.bits_out = bits_out;
   a.B = B; a.H = H;
   return bneck0_launch(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int sedt_bneck2_ok(int cin, int planes, int W, int stride, int dil, int has_downsample, int dtype) {
+  return dtype == SEDT_BF16 && cin == 256 && planes == 128 && W == 16 && stride == 2 && dil == 1 && has_downsample;
+}
+
+extern "C" int sedt_bneck2_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const void* wd_frag,
+                               const float* s1, const float* b1, const float* s2, const float* b2, const float* s3, const float* b3, const float* sd,
+                               const float* bd, void* a_out, void* b_out, uint8_t* bits_out, int B, int H, void* stream) {
+  SEDT_REQUIRE(x && y && w1_frag && w2_frag && w3_frag && wd_frag && s1 && b1 && s2 && b2 && s3 && b3 && sd && bd, "bneck2_fwd: null pointer");
+  SEDT_REQUIRE(B >= 1 && H >= 1, "bneck2_fwd: B = %d, H = %d", B, H);
+  SEDT_REQUIRE((a_out == nullptr) == (b_out == nullptr), "bneck2_fwd: the two intermediates come both or not at all");
+  Bneck2Args a{};
+  a.in = (const bf16_t*)x; a.out = (bf16_t*)y;
+  a.w1 = (const u32x4*)w1_frag; a.w2 = (const u32x4*)w2_frag; a.w3 = (const u32x4*)w3_frag; a.wd = (const u32x4*)wd_frag;
+  a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2; a.s3 = s3; a.b3 = b3; a.sd = sd; a.bd = bd;
+  a.a_out = (bf16_t*)a_out; a.b_out = (bf16_t*)b_out; a.bits_out = bits_out;
+  a.B = B; a.H = H; a.H2 = (H - 1) / 2 + 1;
+  return bneck2_launch(a, reinterpret_cast<hipStream_t>(stream));
 }

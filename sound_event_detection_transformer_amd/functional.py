@@ -836,6 +836,17 @@ class StageFn(Function):
                                       xbits=xbits, fused=[c[1] for c in cf], ab_bits=(abits, bbits)))
                     x, xbits = y, ybits
                     continue
+            if blk.ds and ops.bneck2_ok(dt, blk, W) and x.is_contiguous():
+                # layer2's first block (stride 2), forward in one launch; the per-op backward below finds x, a, b, y as usual
+                wdf, wdb, sd, bd = _prep_conv(dt, t[15], t[16:20])
+                cf = [packing.lookup_conv_frag(t[k]) for k in (0, 5, 10, 15)]
+                if all(c is not None for c in cf):
+                    y, a, b, ybits = ops.bneck2_fwd(x, B, H, [c[0] for c in cf], ((s1, b1), (s2, b2), (s3, b3), (sd, bd)),
+                                                    train=any(ctx.needs_input_grad), want_bits=bool(tr))
+                    saved.append(dict(blk=blk, x=x, a=a, b=b, g1=g1, g2=g2, g3=g3, s=(s1, s2, s3), wb=(w1b, w2b, w3b), H=H, W=W, y=y,
+                                      xbits=xbits, gd=ConvGeom(H, W, cin, 4 * pl, 1, blk.stride), sd=sd, wdb=wdb))
+                    x, H, W, xbits = y, g2.Ho, g2.Wo, ybits
+                    continue
             if blk.ds and ops.bneck0_ok(dt, blk, W) and x.is_contiguous():
                 # layer1's first block, forward in one launch (the backward below is the per-op one: it finds x, a, b, y as usual)
                 wdf, wdb, sd, bd = _prep_conv(dt, t[15], t[16:20])

@@ -129,6 +129,8 @@ SIGNATURES = {
     'sedt_encoder_attn_ffn_fwd': (_i, [_vp] * 20 + [_i, _i, _i, _f, _u32, _u32, _u32, _u32, _vp, _vp]),
     'sedt_bneck_ok': (_i, [_i] * 7),
     'sedt_bneck0_ok': (_i, [_i] * 7),
+    'sedt_bneck2_ok': (_i, [_i] * 7),
+    'sedt_bneck2_fwd': (_i, [_vp] * 17 + [_i, _i, _vp]),
     'sedt_bneck0_fwd': (_i, [_vp] * 19 + [_i, _i, _vp]),
     'sedt_bneck_fwd': (_i, [_vp] * 16 + [_i] * 5 + [_vp]),
     'sedt_bneck_bwd': (_i, [_vp] * 10 + [_i] * 5 + [_vp]),

@@ -720,7 +720,7 @@ def encoder_attn_ffn_fwd(x, qk, v, kpm, w_o_frag, b_o, gamma2, beta2, w1_frag, b
 
 
 # The prediction heads in ONE launch each way (csrc/heads_slab.hip).  Default in the bf16 mode.
-FUSED_BNECK = int(_dev_env('SEDT_BNECK', '3'))      # 0 off, 1 layer1's identity blocks, 2 + layer2's, 3 + layer1's block 0 (forward)
+FUSED_BNECK = int(_dev_env('SEDT_BNECK', '4'))      # 0 off, 1 layer1's identity blocks, 2 + layer2's, 3 + layer1's block 0, 4 + layer2's block 0 (forward)
 
 
 def bneck_ok(dtype, blk, W):
@@ -795,6 +795,31 @@ def bneck0_fwd(x, B, H, wf, sb, train=True, want_bits=True, want_ab=False):
     L.check(L.load().sedt_bneck0_fwd(_p(x), _p(y), _p(wf[0]), _p(wf[1]), _p(wf[2]), _p(wf[3]), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3),
                                      _p(sd), _p(bd), _p(a), _p(b), _p(abits), _p(bbits), _p(bits), B, H, L.stream_ptr()), 'bneck0_fwd')
     return y, a, b, bits, abits, bbits
+
+
+def bneck2_ok(dtype, blk, W):
+    """the fused forward of layer2's first Bottleneck (csrc/bneck.hip: 256 -> 128, 3x3 stride 2, -> 512 with the stride-2 projection), bf16"""
+    return bool(int(FUSED_BNECK) >= 4 and dtype == BF16 and L.load().sedt_bneck2_ok(blk.cin, blk.planes, W, blk.stride, blk.dil, int(blk.ds), dtype))
+
+
+def bneck2_fwd(x, B, H, wf, sb, train=True, want_bits=True):
+    """x [B*H*16, 256] bf16 contiguous; wf = the fragment-major forward operands of conv1, conv2, conv3 and the projection; sb = their four
+    (scale, bias) pairs.  Returns (y [B*H2*8, 512], a [B*H*16, 128], b [B*H2*8, 128], ybits); a, b, ybits only when training"""
+    _dev_check(x)
+    M = x.shape[0]
+    assert x.is_contiguous() and M == B * H * 16 and x.shape[1] == 256
+    M2 = B * ((H - 1) // 2 + 1) * 8
+    y = torch.empty((M2, 512), device=x.device, dtype=torch.bfloat16)
+    a = b = bits = None
+    if train:
+        a = torch.empty((M, 128), device=x.device, dtype=torch.bfloat16)
+        b = torch.empty((M2, 128), device=x.device, dtype=torch.bfloat16)
+        if want_bits:
+            bits = torch.empty((M2, 64), device=x.device, dtype=torch.uint8)
+    (s1, b1), (s2, b2), (s3, b3), (sd, bd) = sb
+    L.check(L.load().sedt_bneck2_fwd(_p(x), _p(y), _p(wf[0]), _p(wf[1]), _p(wf[2]), _p(wf[3]), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3),
+                                     _p(sd), _p(bd), _p(a), _p(b), _p(bits), B, H, L.stream_ptr()), 'bneck2_fwd')
+    return y, a, b, bits
 
 
 SLAB_HEADS = _dev_env('SEDT_SLAB_HEADS', '1') != '0'

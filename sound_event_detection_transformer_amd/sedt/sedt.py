@@ -122,8 +122,8 @@ class SEDT(nn.Module):
                 # fragment-major too
                 cfr = [w for layer in (body.layer1, body.layer2) for b in layer if b.downsample is None
                        for w in (b.conv1.weight, b.conv2.weight, b.conv3.weight)]
-                b0 = body.layer1[0]                     # layer1's first block: fused forward (bneck0_fwd_kernel)
-                cfr += [b0.conv1.weight, b0.conv2.weight, b0.conv3.weight, b0.downsample[0].weight]
+                for b0 in (body.layer1[0], body.layer2[0]):     # the two projection blocks: fused forwards (bneck0 / bneck2_fwd_kernel)
+                    cfr += [b0.conv1.weight, b0.conv2.weight, b0.conv3.weight, b0.downsample[0].weight]
                 return packing.PackPlan(dt, dev, convs, lin, bn_only, frags, cfr)
             plans[key] = packing.PlanSet(factory)
         return plans[key]
