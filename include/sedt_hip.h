@@ -416,6 +416,18 @@ int sedt_bneck_bwd(const void* gy, void* gx, const void* w3t_frag, const void* w
                    const uint8_t* bbits, const uint8_t* xbits, void* gb_out, void* ga_out, int cin, int planes, int W, int B, int H,
                    void* stream);
 
+/* The same pair for an identity Bottleneck of layer3 (1024 -> 256 -> 256 -> 1024 on a map 4 columns wide; csrc/bneck3.hip): one workgroup
+ * per strip of 8 rows x 4 columns = 32 pixels, every workgroup streams all 2.2 MB of the block's weights from L2 while its activations
+ * stay in LDS - a ~25 us floor set by the L2 -> CU stream, which beats the three per-op launches only while the strips cover the chip
+ * about once: sedt_bneck3_ok additionally wants 192 <= B * ceil(H / 8) <= 512.  Arguments as for sedt_bneck_fwd / sedt_bneck_bwd (cin,
+ * planes, W implied); abits / bbits [M][32], bits [M][128]. */
+int sedt_bneck3_ok(int cin, int planes, int W, int stride, int dil, int has_downsample, int B, int H, int dtype);
+int sedt_bneck3_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const float* s1, const float* b1,
+                    const float* s2, const float* b2, const float* s3, const float* b3, void* a_out, void* b_out, uint8_t* abits_out,
+                    uint8_t* bbits_out, uint8_t* bits_out, int B, int H, void* stream);
+int sedt_bneck3_bwd(const void* gy, void* gx, const void* w3t_frag, const void* w2t_frag, const void* w1t_frag, const uint8_t* abits,
+                    const uint8_t* bbits, const uint8_t* xbits, void* gb_out, void* ga_out, int B, int H, void* stream);
+
 /* The first Bottleneck of layer1 (64 -> 64 -> 64 -> 256, 1x1 projection 64 -> 256 on the skip path, stride 1, map 16 columns wide) in ONE
  * forward launch (csrc/bneck.hip: bneck0_fwd_kernel): a = relu(s1 (x W1^T) + b1); b = relu(s2 conv3x3(a, W2) + b2);
  * y = relu(s3 (b W3^T) + b3 + bf16(sd (x Wd^T) + bd)).  x [M][64], y [M][256] bf16 NHWC (M = B*H*16); w*_frag as for sedt_bneck_fwd (wd = the

@@ -1,0 +1,329 @@
+// bneck3.hip - an identity Bottleneck of ResNet layer3 (1x1 1024 -> 256, 3x3 256 -> 256, 1x1 256 -> 1024, FrozenBatchNorm after each,
+// residual + ReLU; torchvision v1.5 block behind reference sedt/backbone.py:97-113) in ONE launch, and its input-gradient chain in one
+// more - the layer1 / layer2 scheme of bneck.hip at the other end of its range.
+//
+// At B = 64 the layer3 map is 32 x 4 per clip: M = 8192 pixels, and the three convolutions of a block are three launches of ~13 / 20 /
+// 16 us (one 64x128 tile per CU each: fixed costs and a fill-bound main loop).  Here a workgroup owns ONE strip of
+// 8 image rows x 4 columns = 32 pixels = one MFMA slab (plus the halo rows: 40 pixels), the 256 strips of the batch cover the chip
+// once, and every workgroup streams ALL 2.2 MB of the block's weights from L2 through registers (fragment-major, sedt_pack_frag) while
+// its activations never leave LDS.  That is 563 MB of L2 -> CU traffic per launch at the ~23-27 TB/s the chip sustains for this access
+// pattern (tools/probes/wstream.hip): a ~25 us floor, against 49 us forward / 52 us backward for the per-op launches.  No wave roles and
+// no strip loop here - one strip per workgroup, all eight waves compute; a wave's weight stream (34 chunks of 8 fragments over the
+// three stages) never drains.  Worth it only while the strips fill the chip about once (sedt_bneck3_ok): at larger batches the per-op
+// GEMMs amortise the weights over more rows than a 32-pixel strip can.
+// The backward is the same kernel with the transposed, BN-scaled weights, mirrored taps and sign-bit masks (BWD); a trainable block
+// (layer3 trains) writes a, b forward and takes the two intermediate gradients gb, ga out of the chain for its weight-gradient GEMMs.
+#include "bneck_common.h"
+
+namespace sedt {
+
+struct Bneck3Args {
+  const bf16_t* in;                  // x (forward) / gy (backward) [B*H*4][1024]
+  bf16_t* out;                       // y / gx
+  const u32x4* wA;                   // [256][1024]  conv1 (fwd) / (s3 . conv3)^T (bwd), fragment-major
+  const u32x4* wB;                   // [256][9*256] conv2, k = tap * 256 + channel
+  const u32x4* wC;                   // [1024][256]  conv3 (fwd) / (s1 . conv1)^T (bwd)
+  const float* sA; const float* bA; const float* sB; const float* bB; const float* sC; const float* bC;   // folded BN (fwd)
+  bf16_t* a_out; bf16_t* b_out;      // [M][256] or null: fwd a, b; bwd gb (stage 1), ga (stage 2)
+  uint8_t* abits_out; uint8_t* bbits_out;      // fwd: sign bits of a, b [M][32] or null
+  uint8_t* bits_out;                 // fwd: sign bits of y [M][128] or null
+  const uint8_t* abits_in; const uint8_t* bbits_in;      // bwd
+  const uint8_t* bits_in;            // bwd: sign bits of the block input [M][128], or null (no mask)
+  int B, H;
+};
+
+struct G3 {
+  static constexpr int C = 1024, P = 256, W = 4, R = 8, NP1 = (R + 2) * W, NP = R * W;      // 40 / 32 pixels
+  static constexpr int XP = C + 8, AP = P + 8, AW = W + 2, CP = C / 8, PP = P / 8;
+  static constexpr size_t XT = 0;
+  static constexpr size_t AT = XT + (size_t)NP1 * XP * 2;
+  static constexpr size_t BT = AT + (size_t)(R + 2) * AW * AP * 2;
+  static constexpr size_t BITS = BT + (size_t)NP * AP * 2;
+  static constexpr size_t MH = BITS + (size_t)NP * CP;
+  static constexpr size_t MA = MH + (size_t)NP1 * PP;
+  static constexpr size_t SB = MA + (size_t)NP * PP;
+  static constexpr size_t TOTAL_F = SB + (4 * P + 2 * C) * 4, TOTAL_B = SB;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(512) void bneck3_kernel(const Bneck3Args a) {
+  constexpr int NP1 = G3::NP1, NP = G3::NP, R = G3::R, W = G3::W, C = G3::C, P = G3::P, XP = G3::XP, AP = G3::AP, AW = G3::AW, CP = G3::CP,
+                PP = G3::PP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* XT = reinterpret_cast<bf16_t*>(smem + G3::XT);        // [40][1032]: in tile, halo row first; becomes the out tile
+  bf16_t* AT = reinterpret_cast<bf16_t*>(smem + G3::AT);        // [10][6][264]: 3x3 input, zero border
+  bf16_t* BT = reinterpret_cast<bf16_t*>(smem + G3::BT);        // [32][264]: 3x3 output
+  uint8_t* BITS = smem + G3::BITS;                              // [32][128]
+  uint8_t* MH = smem + G3::MH;                                  // [40][32]
+  uint8_t* MA = smem + G3::MA;                                  // [32][32]
+  float* SB = reinterpret_cast<float*>(smem + G3::SB);          // fwd: sA bA sB bB (256 each) sC bC (1024 each)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, n = lane & 31, hf = lane >> 5;
+  const int strips = (a.H + R - 1) / R;
+  const int clip = blockIdx.x / strips, r0 = (blockIdx.x % strips) * R;
+  const long pix0 = ((long)clip * a.H + r0) * W;
+  const int rows_in = min(R, a.H - r0);
+
+  u32x4 cur[8], alt[8];
+  const u32x4* w1p = a.wA + (long)wave * 64 * 64;               // stages 1, 2: output tile = wave
+  const u32x4* w2p = a.wB + (long)wave * 144 * 64;
+  const u32x4* w3p = a.wC + (long)(4 * wave) * 16 * 64;         // stage 3: tiles 4 * wave + {0..3}, 16 fragments each, contiguous
+  slab::load_chunk<1>(cur, w1p, 0, 0, lane);
+  slab::issue_fence();
+
+  // ---- tiles to LDS
+  {
+    uint4 xr[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      const int u = tid + q * 512, p = u >> 7, c = (u & 127) * 8, gr = r0 - 1 + (p >> 2);
+      xr[q] = (gr >= 0 && gr < a.H) ? *reinterpret_cast<const uint4*>(a.in + (pix0 + p - W) * C + c) : make_uint4(0, 0, 0, 0);
+    }
+    for (int u = tid; u < (R + 2) * AW * AP / 8; u += 512) reinterpret_cast<uint4*>(AT)[u] = make_uint4(0, 0, 0, 0);
+    if (BWD) {
+      // sign bits: b on the halo tile (80 pieces of 16 bytes: 2 per pixel), a (64 pieces), the block input (256 pieces: 8 per pixel)
+      if (tid < 80) {
+        const int gr = r0 - 1 + (tid >> 3);
+        reinterpret_cast<uint4*>(MH)[tid] = (gr >= 0 && gr < a.H) ? reinterpret_cast<const uint4*>(a.bbits_in + (pix0 - W) * PP)[tid] : make_uint4(0, 0, 0, 0);
+      } else if (tid >= 128 && tid < 192) {
+        const int t = tid - 128;
+        reinterpret_cast<uint4*>(MA)[t] = r0 + (t >> 3) < a.H ? reinterpret_cast<const uint4*>(a.abits_in + pix0 * PP)[t] : make_uint4(0, 0, 0, 0);
+      } else if (tid >= 256) {
+        const int t = tid - 256;
+        reinterpret_cast<uint4*>(BITS)[t] = !a.bits_in ? make_uint4(~0u, ~0u, ~0u, ~0u)
+                                            : r0 + (t >> 5) < a.H ? reinterpret_cast<const uint4*>(a.bits_in + pix0 * CP)[t] : make_uint4(0, 0, 0, 0);
+      }
+    } else {
+      for (int u = tid; u < 4 * P + 2 * C; u += 512) {
+        const float* src = u < P ? a.sA + u : u < 2 * P ? a.bA + (u - P) : u < 3 * P ? a.sB + (u - 2 * P) : u < 4 * P ? a.bB + (u - 3 * P)
+                           : u < 4 * P + C ? a.sC + (u - 4 * P) : a.bC + (u - 4 * P - C);
+        SB[u] = *src;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      const int u = tid + q * 512, p = u >> 7, c = (u & 127) * 8;
+      *reinterpret_cast<uint4*>(XT + p * XP + c) = xr[q];
+    }
+  }
+  __syncthreads();
+
+  // ---- stage 1: 1x1, 1024 -> 256 on the halo tile (tile = wave, slabs 0 and 1: pixels 40..63 do not exist - computed on whatever
+  //      follows the tile in LDS and dropped)
+  {
+    f32x16 acc[2];
+    slab::zero_acc<2>(acc);
+    gemm_slabs<2, 64>(acc, XT, XP, w1p, lane, cur, alt, [&](u32x4(&d)[8]) { slab::load_chunk<1>(d, w2p, 0, 0, lane); });
+    float4 sc[4], bi[4];
+    if (!BWD) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        sc[g4] = *reinterpret_cast<const float4*>(SB + wave * 32 + 8 * g4 + 4 * hf);
+        bi[g4] = *reinterpret_cast<const float4*>(SB + P + wave * 32 + 8 * g4 + 4 * hf);
+      }
+    }
+#pragma unroll
+    for (int s3 = 0; s3 < 2; ++s3) {
+      const int p = s3 * 32 + n, trow = p >> 2, pc = p & 3, gr = r0 - 1 + trow;
+      const bool intile = p < NP1, inimg = gr >= 0 && gr < a.H;
+      bf16_t* dst = AT + (trow * AW + pc + 1) * AP + wave * 32 + 4 * hf;
+      unsigned m4 = 0, nb = 0;
+      if (BWD && intile) m4 = *reinterpret_cast<const unsigned*>(MH + p * PP + wave * 4) >> (4 * hf);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x2 lo = {acc[s3][4 * g4], acc[s3][4 * g4 + 1]}, hi = {acc[s3][4 * g4 + 2], acc[s3][4 * g4 + 3]};
+        uint2 o;
+        if (BWD) {
+          o.x = pack2(lo) & keep2(m4, 8 * g4);
+          o.y = pack2(hi) & keep2(m4, 8 * g4 + 2);
+        } else {
+          o.x = pack2(relu2(lo * f32x2{sc[g4].x, sc[g4].y} + f32x2{bi[g4].x, bi[g4].y}));
+          o.y = pack2(relu2(hi * f32x2{sc[g4].z, sc[g4].w} + f32x2{bi[g4].z, bi[g4].w}));
+          if (!inimg) o = make_uint2(0, 0);
+          nb |= nibble4(o.x, o.y) << (8 * g4 + 4 * hf);
+        }
+        if (intile) *reinterpret_cast<uint2*>(dst + 8 * g4) = o;
+      }
+      if (!BWD && a.abits_out) {
+        const unsigned other = (unsigned)__shfl_xor((int)nb, 32);
+        if (hf == 0 && intile) *reinterpret_cast<unsigned*>(MH + p * PP + wave * 4) = nb | other;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- stage 2: 3x3, 256 -> 256 (tile = wave, the strip's one slab): 18 chunks of 8 k-steps = half a tap each
+  {
+    f32x16 acc[1];
+    slab::zero_acc<1>(acc);
+    const bf16_t* ctr = AT + (((n >> 2) + 1) * AW + (n & 3) + 1) * AP + 8 * hf;
+#pragma unroll
+    for (int j = 0; j < 18; ++j) {
+      u32x4(&src)[8] = (j & 1) ? alt : cur;
+      u32x4(&dst)[8] = (j & 1) ? cur : alt;
+      if (j + 1 < 18) slab::load_chunk<1>(dst, w2p, 0, (j + 1) * 8, lane);
+      else slab::load_chunk<1>(dst, w3p, 0, 0, lane);           // (chunk 17 sits in alt: stage 3's first chunk lands in cur)
+      __builtin_amdgcn_sched_barrier(0);
+      const int tap = j >> 1, dr = tap / 3 - 1, dc = tap % 3 - 1;
+      const int off = (BWD ? -(dr * AW + dc) : (dr * AW + dc)) * AP + (j & 1) * 128;       // the input gradient mirrors the taps
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(ctr + off + u * 16);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, src[u]), xb, acc[0], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    unsigned m4 = 0, nb = 0;
+    if (BWD) m4 = *reinterpret_cast<const unsigned*>(MA + n * PP + wave * 4) >> (4 * hf);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x2 lo = {acc[0][4 * g4], acc[0][4 * g4 + 1]}, hi = {acc[0][4 * g4 + 2], acc[0][4 * g4 + 3]};
+      uint2 o;
+      if (BWD) {
+        o.x = pack2(lo) & keep2(m4, 8 * g4);
+        o.y = pack2(hi) & keep2(m4, 8 * g4 + 2);
+      } else {
+        const float4 sc = *reinterpret_cast<const float4*>(SB + 2 * P + wave * 32 + 8 * g4 + 4 * hf);
+        const float4 bi = *reinterpret_cast<const float4*>(SB + 3 * P + wave * 32 + 8 * g4 + 4 * hf);
+        o.x = pack2(relu2(lo * f32x2{sc.x, sc.y} + f32x2{bi.x, bi.y}));
+        o.y = pack2(relu2(hi * f32x2{sc.z, sc.w} + f32x2{bi.z, bi.w}));
+        nb |= nibble4(o.x, o.y) << (8 * g4 + 4 * hf);
+      }
+      *reinterpret_cast<uint2*>(BT + n * AP + wave * 32 + 8 * g4 + 4 * hf) = o;
+    }
+    if (!BWD && a.bbits_out) {
+      const unsigned other = (unsigned)__shfl_xor((int)nb, 32);
+      if (hf == 0) *reinterpret_cast<unsigned*>(MA + n * PP + wave * 4) = nb | other;
+    }
+  }
+  __syncthreads();
+
+  // ---- stage 3: 1x1, 256 -> 1024 (tiles 4 * wave + {0..3}, two chunks each), + the in tile (residual), ReLU / sign-bit mask, in place
+  {
+    const bf16_t* xrow = BT + n * AP + 8 * hf;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int tile = 4 * wave + t;
+      f32x16 acc[1];
+      slab::zero_acc<1>(acc);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int turn = 2 * t + c;                              // even turns sit in cur, odd in alt
+        u32x4(&src)[8] = (turn & 1) ? alt : cur;
+        u32x4(&dst)[8] = (turn & 1) ? cur : alt;
+        if (turn + 1 < 8) slab::load_chunk<1>(dst, w3p, 0, (turn + 1) * 8, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bf16x8 xb = *reinterpret_cast<const bf16x8*>(xrow + (c * 8 + u) * 16);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, src[u]), xb, acc[0], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bf16_t* xp = XT + (n + W) * XP + tile * 32 + 4 * hf;
+      unsigned m4 = 0, nibs = 0;
+      if (BWD) m4 = *reinterpret_cast<const unsigned*>(BITS + n * CP + tile * 4) >> (4 * hf);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const uint2 xw = *reinterpret_cast<const uint2*>(xp + 8 * g4);
+        const f32x2 lo = {acc[0][4 * g4], acc[0][4 * g4 + 1]}, hi = {acc[0][4 * g4 + 2], acc[0][4 * g4 + 3]};
+        uint2 o;
+        if (BWD) {
+          o.x = pack2(lo + widen2(xw.x)) & keep2(m4, 8 * g4);
+          o.y = pack2(hi + widen2(xw.y)) & keep2(m4, 8 * g4 + 2);
+        } else {
+          const float4 sc = *reinterpret_cast<const float4*>(SB + 4 * P + tile * 32 + 8 * g4 + 4 * hf);
+          const float4 bi = *reinterpret_cast<const float4*>(SB + 4 * P + C + tile * 32 + 8 * g4 + 4 * hf);
+          o.x = pack2(relu2(lo * f32x2{sc.x, sc.y} + f32x2{bi.x, bi.y} + widen2(xw.x)));
+          o.y = pack2(relu2(hi * f32x2{sc.z, sc.w} + f32x2{bi.z, bi.w} + widen2(xw.y)));
+          nibs |= nibble4(o.x, o.y) << (8 * g4 + 4 * hf);
+        }
+        *reinterpret_cast<uint2*>(xp + 8 * g4) = o;
+      }
+      if (!BWD && a.bits_out) {
+        const unsigned other = (unsigned)__shfl_xor((int)nibs, 32);
+        if (hf == 0) *reinterpret_cast<unsigned*>(BITS + n * CP + tile * 4) = nibs | other;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- out
+  for (int u = tid; u < NP * CP; u += 512) {
+    const int q = u >> 7, c = (u & 127) * 8;
+    if ((q >> 2) < rows_in) *reinterpret_cast<uint4*>(a.out + (pix0 + q) * C + c) = *reinterpret_cast<const uint4*>(XT + (q + W) * XP + c);
+  }
+  if (a.a_out)                                                   // the stage-1 result on the strip's own rows, the stage-2 result
+    for (int u = tid; u < NP * PP; u += 512) {
+      const int q = u >> 5, c = (u & 31) * 8;
+      if ((q >> 2) < rows_in) {
+        *reinterpret_cast<uint4*>(a.a_out + (pix0 + q) * P + c) = *reinterpret_cast<const uint4*>(AT + (((q >> 2) + 1) * AW + (q & 3) + 1) * AP + c);
+        *reinterpret_cast<uint4*>(a.b_out + (pix0 + q) * P + c) = *reinterpret_cast<const uint4*>(BT + q * AP + c);
+      }
+    }
+  if (!BWD) {
+    if (a.bits_out && tid < 256 && (tid >> 5) < rows_in) reinterpret_cast<uint4*>(a.bits_out + pix0 * CP)[tid] = reinterpret_cast<const uint4*>(BITS)[tid];
+    if (a.abits_out && tid >= 256 && tid < 320 && ((tid - 256) >> 3) < rows_in)
+      reinterpret_cast<uint4*>(a.abits_out + pix0 * PP)[tid - 256] = reinterpret_cast<const uint4*>(MH + W * PP)[tid - 256];
+    if (a.bbits_out && tid >= 320 && tid < 384 && ((tid - 320) >> 3) < rows_in)
+      reinterpret_cast<uint4*>(a.bbits_out + pix0 * PP)[tid - 320] = reinterpret_cast<const uint4*>(MA)[tid - 320];
+  }
+}
+
+template <bool BWD>
+static int bneck3_launch(const Bneck3Args& a, hipStream_t s, const char* what) {
+  constexpr size_t lds = BWD ? G3::TOTAL_B : G3::TOTAL_F;
+  static_assert(lds <= 160 * 1024, "LDS");
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bneck3_kernel<BWD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("%s: hipFuncSetAttribute(%zu B LDS) failed: %s", what, lds, hipGetErrorString(e));
+      return 1;
+    }
+    attr = true;
+  }
+  const int nst = a.B * ((a.H + G3::R - 1) / G3::R);
+  hipLaunchKernelGGL(bneck3_kernel<BWD>, dim3(nst), dim3(512), lds, s, a);
+  return check_launch(what);
+}
+
+}  // namespace sedt
+
+using namespace sedt;
+
+extern "C" int sedt_bneck3_ok(int cin, int planes, int W, int stride, int dil, int has_downsample, int B, int H, int dtype) {
+  if (!(dtype == SEDT_BF16 && cin == G3::C && planes == G3::P && W == G3::W && stride == 1 && dil == 1 && !has_downsample)) return 0;
+  // every workgroup streams the block's 2.2 MB of weights for 32 pixels: pays while the strips cover the chip about once
+  const int nst = B * ((H + G3::R - 1) / G3::R);
+  return nst >= 192 && nst <= 512;
+}
+
+extern "C" int sedt_bneck3_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const float* s1,
+                               const float* b1, const float* s2, const float* b2, const float* s3, const float* b3, void* a_out, void* b_out,
+                               uint8_t* abits_out, uint8_t* bbits_out, uint8_t* bits_out, int B, int H, void* stream) {
+  SEDT_REQUIRE(x && y && w1_frag && w2_frag && w3_frag && s1 && b1 && s2 && b2 && s3 && b3, "bneck3_fwd: null pointer");
+  SEDT_REQUIRE(B >= 1 && H >= 1, "bneck3_fwd: B = %d, H = %d", B, H);
+  SEDT_REQUIRE((a_out == nullptr) == (b_out == nullptr) && (abits_out == nullptr) == (bbits_out == nullptr),
+               "bneck3_fwd: the two intermediates (their sign bits) come both or not at all");
+  Bneck3Args a{};
+  a.in = (const bf16_t*)x; a.out = (bf16_t*)y;
+  a.wA = (const u32x4*)w1_frag; a.wB = (const u32x4*)w2_frag; a.wC = (const u32x4*)w3_frag;
+  a.sA = s1; a.bA = b1; a.sB = s2; a.bB = b2; a.sC = s3; a.bC = b3;
+  a.a_out = (bf16_t*)a_out; a.b_out = (bf16_t*)b_out; a.abits_out = abits_out; a.bbits_out = bbits_out; a.bits_out = bits_out;
+  a.B = B; a.H = H;
+  return bneck3_launch<false>(a, reinterpret_cast<hipStream_t>(stream), "bneck3_fwd");
+}
+
+extern "C" int sedt_bneck3_bwd(const void* gy, void* gx, const void* w3t_frag, const void* w2t_frag, const void* w1t_frag, const uint8_t* abits,
+                               const uint8_t* bbits, const uint8_t* xbits, void* gb_out, void* ga_out, int B, int H, void* stream) {
+  SEDT_REQUIRE(gy && gx && w3t_frag && w2t_frag && w1t_frag && abits && bbits, "bneck3_bwd: null pointer");
+  SEDT_REQUIRE(B >= 1 && H >= 1, "bneck3_bwd: B = %d, H = %d", B, H);
+  SEDT_REQUIRE((gb_out == nullptr) == (ga_out == nullptr), "bneck3_bwd: the two intermediate gradients come both or not at all");
+  Bneck3Args a{};
+  a.in = (const bf16_t*)gy; a.out = (bf16_t*)gx;
+  a.wA = (const u32x4*)w3t_frag; a.wB = (const u32x4*)w2t_frag; a.wC = (const u32x4*)w1t_frag;
+  a.abits_in = abits; a.bbits_in = bbits; a.bits_in = xbits;
+  a.a_out = (bf16_t*)gb_out; a.b_out = (bf16_t*)ga_out;          // (stage 1 of the chain produces gb, stage 2 ga)
+  a.B = B; a.H = H;
+  return bneck3_launch<true>(a, reinterpret_cast<hipStream_t>(stream), "bneck3_bwd");
+}

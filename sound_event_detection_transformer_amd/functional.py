@@ -823,7 +823,7 @@ class StageFn(Function):
             g1 = ConvGeom(H, W, cin, pl, 1)
             g2 = ConvGeom(H, W, pl, pl, 3, blk.stride, blk.dil, blk.dil)
             g3 = ConvGeom(g2.Ho, g2.Wo, pl, 4 * pl, 1)
-            if ops.bneck_ok(dt, blk, W) and x.is_contiguous():
+            if ops.bneck_ok(dt, blk, W, B, H) and x.is_contiguous():
                 # the whole block in one launch, its intermediates never in HBM (csrc/bneck.hip)
                 cf = [packing.lookup_conv_frag(t[k]) for k in (0, 5, 10)]
                 if all(c is not None for c in cf):

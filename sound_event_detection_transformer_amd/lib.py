@@ -128,6 +128,9 @@ SIGNATURES = {
     'sedt_encoder_qkv_fwd': (_i, [_vp] * 12 + [_i, _i, _vp]),
     'sedt_encoder_attn_ffn_fwd': (_i, [_vp] * 20 + [_i, _i, _i, _f, _u32, _u32, _u32, _u32, _vp, _vp]),
     'sedt_bneck_ok': (_i, [_i] * 7),
+    'sedt_bneck3_ok': (_i, [_i] * 9),
+    'sedt_bneck3_fwd': (_i, [_vp] * 16 + [_i, _i, _vp]),
+    'sedt_bneck3_bwd': (_i, [_vp] * 10 + [_i, _i, _vp]),
     'sedt_bneck0_ok': (_i, [_i] * 7),
     'sedt_bneck2_ok': (_i, [_i] * 7),
     'sedt_bneck2_fwd': (_i, [_vp] * 17 + [_i, _i, _vp]),

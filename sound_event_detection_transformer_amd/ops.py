@@ -720,13 +720,18 @@ def encoder_attn_ffn_fwd(x, qk, v, kpm, w_o_frag, b_o, gamma2, beta2, w1_frag, b
 
 
 # The prediction heads in ONE launch each way (csrc/heads_slab.hip).  Default in the bf16 mode.
-FUSED_BNECK = int(_dev_env('SEDT_BNECK', '4'))      # 0 off, 1 layer1's identity blocks, 2 + layer2's, 3 + layer1's block 0, 4 + layer2's block 0 (forward)
+FUSED_BNECK = int(_dev_env('SEDT_BNECK', '5'))      # 0 off, 1 layer1's identity blocks, 2 + layer2's, 3 + layer1's block 0, 4 + layer2's block 0 (forward), 5 + layer3's identity blocks
 
 
-def bneck_ok(dtype, blk, W):
-    """the fused-Bottleneck envelope (csrc/bneck.hip): an identity block of layer1 (256/64 on 16 columns) or layer2 (512/128 on 8), bf16"""
-    return bool(int(FUSED_BNECK) >= (1 if blk.cin == 256 else 2) and dtype == BF16
-                and L.load().sedt_bneck_ok(blk.cin, blk.planes, W, blk.stride, blk.dil, int(blk.ds), dtype))
+def bneck_ok(dtype, blk, W, B=0, H=0):
+    """the fused-Bottleneck envelope: an identity block of layer1 (256/64 on 16 columns) or layer2 (512/128 on 8) (csrc/bneck.hip), or of
+    layer3 (1024/256 on 4 columns, csrc/bneck3.hip) while B * ceil(H / 8) strips cover the chip about once; bf16"""
+    if dtype != BF16:
+        return False
+    lvl = int(FUSED_BNECK)
+    if blk.cin == 1024:
+        return bool(lvl >= 5 and L.load().sedt_bneck3_ok(blk.cin, blk.planes, W, blk.stride, blk.dil, int(blk.ds), B, H, dtype))
+    return bool(lvl >= (1 if blk.cin == 256 else 2) and L.load().sedt_bneck_ok(blk.cin, blk.planes, W, blk.stride, blk.dil, int(blk.ds), dtype))
 
 
 def bneck_fwd(x, B, H, W, wf, sb, train=True, want_bits=True, want_ab=False):
@@ -748,8 +753,12 @@ def bneck_fwd(x, B, H, W, wf, sb, train=True, want_bits=True, want_ab=False):
         if want_bits:
             bits = torch.empty((M, C // 8), device=x.device, dtype=torch.uint8)
     (s1, b1), (s2, b2), (s3, b3) = sb
-    L.check(L.load().sedt_bneck_fwd(_p(x), _p(y), _p(wf[0]), _p(wf[1]), _p(wf[2]), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3), _p(a), _p(b),
-                                    _p(abits), _p(bbits), _p(bits), C, P, W, B, H, L.stream_ptr()), 'bneck_fwd')
+    if C == 1024:
+        L.check(L.load().sedt_bneck3_fwd(_p(x), _p(y), _p(wf[0]), _p(wf[1]), _p(wf[2]), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3), _p(a),
+                                         _p(b), _p(abits), _p(bbits), _p(bits), B, H, L.stream_ptr()), 'bneck3_fwd')
+    else:
+        L.check(L.load().sedt_bneck_fwd(_p(x), _p(y), _p(wf[0]), _p(wf[1]), _p(wf[2]), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3), _p(a),
+                                        _p(b), _p(abits), _p(bbits), _p(bits), C, P, W, B, H, L.stream_ptr()), 'bneck_fwd')
     return y, a, b, bits, abits, bbits
 
 
@@ -765,6 +774,11 @@ def bneck_bwd(gy, B, H, W, wt, abits, bbits, xbits, want_g=False, chain_only=Fal
     if want_g or chain_only:
         ga = torch.empty((M, C // 4), device=gy.device, dtype=torch.bfloat16)
         gb = torch.empty_like(ga) if want_g else None
+    if C == 1024:
+        assert not chain_only
+        L.check(L.load().sedt_bneck3_bwd(_p(gy), _p(gx), _p(wt[2]), _p(wt[1]), _p(wt[0]), _p(abits), _p(bbits), _p(xbits), _p(gb), _p(ga), B, H,
+                                         L.stream_ptr()), 'bneck3_bwd')
+        return gx, gb, ga
     L.check(L.load().sedt_bneck_bwd(_p(gy), _p(gx), _p(wt[2]), _p(wt[1]), None if chain_only else _p(wt[0]), _p(abits), _p(bbits),
                                     None if chain_only else _p(xbits), _p(gb), _p(ga), C, C // 4, W, B, H, L.stream_ptr()), 'bneck_bwd')
     return gx, gb, ga

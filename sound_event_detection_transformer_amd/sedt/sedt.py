@@ -118,9 +118,9 @@ class SEDT(nn.Module):
                         lin.append(getattr(self, name).weight)
                 if hasattr(self, 'feature_align'):
                     lin += [m.weight for m in self.feature_align.layers]
-                # identity Bottlenecks of layer1 / layer2 run as one fused kernel each way (csrc/bneck.hip): their packed operands
-                # fragment-major too
-                cfr = [w for layer in (body.layer1, body.layer2) for b in layer if b.downsample is None
+                # identity Bottlenecks of layer1 / layer2 / layer3 run as one fused kernel each way (csrc/bneck.hip, bneck3.hip): their
+                # packed operands fragment-major too
+                cfr = [w for layer in (body.layer1, body.layer2, body.layer3) for b in layer if b.downsample is None
                        for w in (b.conv1.weight, b.conv2.weight, b.conv3.weight)]
                 for b0 in (body.layer1[0], body.layer2[0]):     # the two projection blocks: fused forwards (bneck0 / bneck2_fwd_kernel)
                     cfr += [b0.conv1.weight, b0.conv2.weight, b0.conv3.weight, b0.downsample[0].weight]

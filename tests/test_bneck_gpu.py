@@ -23,7 +23,7 @@ def _stage(seed, which=1):
     from sound_event_detection_transformer_amd.sedt.backbone import ResNet50Body
     torch.manual_seed(seed)
     body = ResNet50Body(True).cuda()
-    layer = body.layer1 if which == 1 else body.layer2
+    layer = {1: body.layer1, 2: body.layer2, 3: body.layer3}[which]
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for b in layer:
@@ -46,17 +46,17 @@ def _stage(seed, which=1):
     return layer, plan
 
 
-def _run(layer, plan, x, B, H, fused, gy=None, mask_input=False):
+def _run(layer, plan, x, B, H, fused, gy=None, mask_input=False, W=16):
     from sound_event_detection_transformer_amd import functional as Fn, ops
     from sound_event_detection_transformer_amd.lib import BF16
     keep = ops.FUSED_BNECK
-    ops.FUSED_BNECK = 4 if fused else 0
+    ops.FUSED_BNECK = 5 if fused else 0
     try:
         xin = x.clone().requires_grad_(gy is not None)
         holder = {}
         for p in layer.parameters():
             p.grad = None
-        meta = dict(dt=BF16, B=B, H=H, W=16, blocks=[b.cfg for b in layer], mask_input=mask_input, grad_premasked=True, x_bits=None,
+        meta = dict(dt=BF16, B=B, H=H, W=W, blocks=[b.cfg for b in layer], mask_input=mask_input, grad_premasked=True, x_bits=None,
                     holder=holder)
         ts = [t for b in layer for t in b.tensors()]
         with plan:
@@ -124,7 +124,7 @@ def test_fused_layer2_bottlenecks_match_the_per_op_chain(B, H):
         assert rel(w1[n_], w0[n_]) < 6e-2, n_
 
 
-@pytest.mark.parametrize('which', [1, 2])
+@pytest.mark.parametrize('which', [1, 2, 3])
 def test_fused_bottleneck_kernels_against_torch(which):
     """the two entry points on their own against an f32 torch restatement of the block (conv / FrozenBN affine / ReLU), operands and the
     two intermediates rounded to bf16 as the kernels do; the masks of the input-gradient chain are the kernel's own sign bits"""
@@ -132,7 +132,7 @@ def test_fused_bottleneck_kernels_against_torch(which):
     from sound_event_detection_transformer_amd import ops, packing
     layer, plan = _stage(11, which)
     blk = layer[2]
-    W, C, P = (16, 256, 64) if which == 1 else (8, 512, 128)
+    W, C, P = {1: (16, 256, 64), 2: (8, 512, 128), 3: (4, 1024, 256)}[which]
     B, H = 2, 19
     g = torch.Generator().manual_seed(1)
     x = (0.5 * torch.randn(B * H * W, C, generator=g)).cuda().bfloat16().relu()
@@ -259,3 +259,23 @@ def test_fused_layer2_first_block_forward_against_torch(B, H):
     Y = F.relu(F.conv2d(Bt, w3) * s3 + b3 + I)
     assert Y.shape[2] == H2 and Y.shape[3] == 8
     assert rel(a, tok(A)) < 1e-2 and rel(b, tok(Bt)) < 1e-2 and rel(y, tok(Y)) < 1e-2
+
+
+def test_fused_layer3_bottlenecks_match_the_per_op_chain():
+    """layer3's five identity blocks (csrc/bneck3.hip: one 32-pixel strip per workgroup, all weights streamed per strip) inside the stage,
+    at a batch whose strips cover the chip once (the envelope: 192 <= B * ceil(H / 8) <= 512); block 0 (stride 2) stays per-op"""
+    from sound_event_detection_transformer_amd import ops
+    layer, plan = _stage(19, which=3)
+    B, H = 48, 63                                            # layer3's input is layer2's output: 63 x 8; behind block 0: 32 x 4
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B * H * 8, 512, generator=g).cuda().bfloat16().relu()
+    gy = torch.randn(B * 32 * 4, 1024, generator=g).cuda().bfloat16()
+    assert ops.bneck_ok(ops.BF16, layer[1].cfg, 4, B, 32) and not ops.bneck_ok(ops.BF16, layer[1].cfg, 4, 8, 32)
+    y1, gx1, _ = _run(layer, plan, x, B, H, True, gy, mask_input=True, W=8)
+    w1 = {n_: p.grad.clone() for n_, p in layer.named_parameters() if p.grad is not None}
+    y0, gx0, _ = _run(layer, plan, x, B, H, False, gy, mask_input=True, W=8)
+    w0 = {n_: p.grad.clone() for n_, p in layer.named_parameters() if p.grad is not None}
+    assert rel(y1, y0) < 2e-2 and rel(gx1, gx0) < 6e-2
+    assert set(w1) == set(w0) and len(w1) == 19              # 6 blocks x 3 convolutions + the downsample projection
+    for n_ in w0:
+        assert rel(w1[n_], w0[n_]) < 6e-2, n_

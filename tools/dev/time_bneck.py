@@ -10,8 +10,8 @@ from sound_event_detection_transformer_amd.sedt.backbone import ResNet50Body    
 runtime.set_compute_dtype('bf16')
 dev = torch.device('cuda')
 LAYER = int(os.environ.get('LAYER', 1))
-B, H = int(os.environ.get('B', 64)), int(os.environ.get('H', 125 if LAYER == 1 else 63))
-W, C, P = (16, 256, 64) if LAYER == 1 else (8, 512, 128)
+B, H = int(os.environ.get('B', 64)), int(os.environ.get('H', {1: 125, 2: 63, 3: 32}[LAYER]))
+W, C, P = {1: (16, 256, 64), 2: (8, 512, 128), 3: (4, 1024, 256)}[LAYER]
 g = torch.Generator().manual_seed(1)
 
 
@@ -39,7 +39,7 @@ def timeit(fn, reps=10):
 
 
 body = ResNet50Body(True).cuda()
-blk = body.layer1[1] if LAYER == 1 else body.layer2[1]
+blk = {1: body.layer1, 2: body.layer2, 3: body.layer3}[LAYER][1]
 ws = (blk.conv1.weight, blk.conv2.weight, blk.conv3.weight)
 convs = [(blk.conv1.weight, blk.bn1.tensors()), (blk.conv2.weight, blk.bn2.tensors()), (blk.conv3.weight, blk.bn3.tensors())]
 plan = packing.PackPlan(L.BF16, dev, convs, [], (), (), list(ws))
