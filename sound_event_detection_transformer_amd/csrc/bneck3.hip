@@ -7,7 +7,8 @@
 // 8 image rows x 4 columns = 32 pixels = one MFMA slab (plus the halo rows: 40 pixels), the 256 strips of the batch cover the chip
 // once, and every workgroup streams ALL 2.2 MB of the block's weights from L2 through registers (fragment-major, sedt_pack_frag) while
 // its activations never leave LDS.  That is 563 MB of L2 -> CU traffic per launch at the ~23-27 TB/s the chip sustains for this access
-// pattern (tools/probes/wstream.hip): a ~25 us floor, against 49 us forward / 52 us backward for the per-op launches.  No wave roles and
+// pattern (tools/probes/wstream.hip): a ~25 us floor (measured: 34 us forward, 33 us backward), against 49 us forward / 52 us backward
+// for the per-op launches inside the step.  No wave roles and
 // no strip loop here - one strip per workgroup, all eight waves compute; a wave's weight stream (34 chunks of 8 fragments over the
 // three stages) never drains.  Worth it only while the strips fill the chip about once (sedt_bneck3_ok): at larger batches the per-op
 // GEMMs amortise the weights over more rows than a 32-pixel strip can.
@@ -63,11 +64,21 @@ __global__ __launch_bounds__(512) void bneck3_kernel(const Bneck3Args a) {
   const long pix0 = ((long)clip * a.H + r0) * W;
   const int rows_in = min(R, a.H - r0);
 
-  u32x4 cur[8], alt[8];
+  // A wave's weights are ONE stream of 34 chunks of 8 fragments (8 KB each): 8 of stage 1, 18 of stage 2, 8 of stage 3.  Chunk g lives in
+  // ring[g % 3] and chunk g + 2 is issued when chunk g starts to be multiplied: 16 KB per wave = 128 KB per CU in flight, across the
+  // barriers and epilogues between the stages.  (Measured: the same 34 us per launch as with two buffers and one chunk ahead - the launch
+  // is bound by the L2 -> CU rate itself, ~33 B/clk/CU here, not by the depth of the prefetch.)
+  u32x4 ring[3][8];
   const u32x4* w1p = a.wA + (long)wave * 64 * 64;               // stages 1, 2: output tile = wave
   const u32x4* w2p = a.wB + (long)wave * 144 * 64;
   const u32x4* w3p = a.wC + (long)(4 * wave) * 16 * 64;         // stage 3: tiles 4 * wave + {0..3}, 16 fragments each, contiguous
-  slab::load_chunk<1>(cur, w1p, 0, 0, lane);
+  auto issue = [&](int g) {                                     // (g is a compile-time constant at every call site)
+    if (g < 8) slab::load_chunk<1>(ring[g % 3], w1p, 0, g * 8, lane);
+    else if (g < 26) slab::load_chunk<1>(ring[g % 3], w2p, 0, (g - 8) * 8, lane);
+    else if (g < 34) slab::load_chunk<1>(ring[g % 3], w3p, 0, (g - 26) * 8, lane);
+  };
+  issue(0);
+  issue(1);
   slab::issue_fence();
 
   // ---- tiles to LDS
@@ -112,7 +123,22 @@ __global__ __launch_bounds__(512) void bneck3_kernel(const Bneck3Args a) {
   {
     f32x16 acc[2];
     slab::zero_acc<2>(acc);
-    gemm_slabs<2, 64>(acc, XT, XP, w1p, lane, cur, alt, [&](u32x4(&d)[8]) { slab::load_chunk<1>(d, w2p, 0, 0, lane); });
+    const bf16_t* xrow1 = XT + n * XP + 8 * hf;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      issue(g + 2);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        bf16x8 xb[2];
+#pragma unroll
+        for (int s3 = 0; s3 < 2; ++s3) xb[s3] = *reinterpret_cast<const bf16x8*>(xrow1 + s3 * 32 * XP + (g * 8 + u) * 16);
+#pragma unroll
+        for (int s3 = 0; s3 < 2; ++s3)
+          acc[s3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[g % 3][u]), xb[s3], acc[s3], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     float4 sc[4], bi[4];
     if (!BWD) {
 #pragma unroll
@@ -158,10 +184,8 @@ __global__ __launch_bounds__(512) void bneck3_kernel(const Bneck3Args a) {
     const bf16_t* ctr = AT + (((n >> 2) + 1) * AW + (n & 3) + 1) * AP + 8 * hf;
 #pragma unroll
     for (int j = 0; j < 18; ++j) {
-      u32x4(&src)[8] = (j & 1) ? alt : cur;
-      u32x4(&dst)[8] = (j & 1) ? cur : alt;
-      if (j + 1 < 18) slab::load_chunk<1>(dst, w2p, 0, (j + 1) * 8, lane);
-      else slab::load_chunk<1>(dst, w3p, 0, 0, lane);           // (chunk 17 sits in alt: stage 3's first chunk lands in cur)
+      u32x4(&src)[8] = ring[(8 + j) % 3];
+      issue(8 + j + 2);
       __builtin_amdgcn_sched_barrier(0);
       const int tap = j >> 1, dr = tap / 3 - 1, dc = tap % 3 - 1;
       const int off = (BWD ? -(dr * AW + dc) : (dr * AW + dc)) * AP + (j & 1) * 128;       // the input gradient mirrors the taps
@@ -207,10 +231,9 @@ __global__ __launch_bounds__(512) void bneck3_kernel(const Bneck3Args a) {
       slab::zero_acc<1>(acc);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const int turn = 2 * t + c;                              // even turns sit in cur, odd in alt
-        u32x4(&src)[8] = (turn & 1) ? alt : cur;
-        u32x4(&dst)[8] = (turn & 1) ? cur : alt;
-        if (turn + 1 < 8) slab::load_chunk<1>(dst, w3p, 0, (turn + 1) * 8, lane);
+        const int turn = 2 * t + c;
+        u32x4(&src)[8] = ring[(26 + turn) % 3];
+        issue(26 + turn + 2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
