@@ -672,10 +672,12 @@ SLAB_ENC_BWD = _dev_env('SEDT_SLAB_ENC_BWD', '1') != '0'      # the input-gradie
 
 
 SLAB_MIN_WGS = 192      # slabs (= workgroups) below which the per-op chain fills the chip better (B = 32: 128 slabs; same-box A/B on C3)
+SLAB_MAX_WGS = 320      # ... and above which it wins again: every slab streams the layer's 3.4 MB of weights, the per-op GEMMs amortise them
+                        # over 64-128 rows per tile (C4, B = 200: 800 slabs, 17.0 ms with the slab encoder against 16.65 ms without)
 
 
 def encoder_slab_ok(dtype, D, H, S, FF, amask, B=None):
-    return bool(SLAB_ENC and dtype == BF16 and amask is None and (B is None or B * ((S + 31) // 32) >= SLAB_MIN_WGS)
+    return bool(SLAB_ENC and dtype == BF16 and amask is None and (B is None or SLAB_MIN_WGS <= B * ((S + 31) // 32) <= SLAB_MAX_WGS)
                 and L.load().sedt_encoder_slab_ok(D, H, S, FF, dtype))
 
 
