@@ -755,6 +755,41 @@ def kernel_report(dtype, dev):
     t = timeit(lambda: ops.conv_dgrad(dt, x1, B, g1, wb1, out=y1, mask=x1, ldm=64))
     mf("layer1 3x3 conv input gradient (direct kernel, taps flipped, ReLU mask)", 2.0 * B * 125 * 16 * 64 * 576, t,
        "the implicit GEMM it replaced: 37 us")
+    # the fused Bottlenecks (bneck.hip, bneck3.hip): an identity block of layer1 / layer2 / layer3 in one launch each way
+    if dtype == 'bf16':
+        from sound_event_detection_transformer_amd import packing
+        from sound_event_detection_transformer_amd.sedt.backbone import ResNet50Body
+        body = ResNet50Body(True).to(dev)
+        for name, layer, Hm, Wm in (('layer1', body.layer1, 125, 16), ('layer2', body.layer2, 63, 8), ('layer3', body.layer3, 32, 4)):
+            blk = layer[1]
+            if not ops.bneck_ok(dt, blk.cfg, Wm, B, Hm):
+                continue
+            ws = (blk.conv1.weight, blk.conv2.weight, blk.conv3.weight)
+            plan = packing.PackPlan(dt, dev, [(blk.conv1.weight, blk.bn1.tensors()), (blk.conv2.weight, blk.bn2.tensors()),
+                                              (blk.conv3.weight, blk.bn3.tensors())], [], (), (), list(ws))
+            plan.run()
+            torch.cuda.synchronize()
+            cf = [plan.conv_frag_table[w.data_ptr()] for w in ws]
+            sb = [plan.table[w.data_ptr()][2:] for w in ws]
+            Cb, Pb = blk.cfg.cin, blk.cfg.planes
+            Mb = B * Hm * Wm
+            xb_ = rnd(Mb, Cb).relu()
+            gyb = rnd(Mb, Cb)
+            trainable = name != 'layer1'                      # (layer1 is frozen in the reference: sign bits only; layer2 / 3 also keep a, b)
+            _, _, _, bits_, ab_, bb_ = ops.bneck_fwd(xb_, B, Hm, Wm, [c[0] for c in cf], sb, want_ab=False)
+            flop = 2.0 * Mb * (2 * Cb * Pb + 9 * Pb * Pb)
+            by_f = Mb * (2 * Cb * 2 + Cb // 8 + 2 * (Pb // 8) + (2 * Pb * 2 if trainable else 0))
+            by_b = Mb * (2 * Cb * 2 + Cb // 8 + 2 * (Pb // 8) + (2 * Pb * 2 if trainable else 0))
+            wbytes = 2.0 * (2 * Cb * Pb + 9 * Pb * Pb)
+            note = ("HBM-bound: x in, y out, sign bits%s; %d KB of weights stream from L2 per strip" % (' + a, b' if trainable else '', wbytes // 1024))
+            t = timeit(lambda: ops.bneck_fwd(xb_, B, Hm, Wm, [c[0] for c in cf], sb, want_ab=trainable))
+            hb("%s identity Bottleneck fwd, fused (1 launch; training form), %.1f GFLOP" % (name, flop / 1e9), by_f, t, note)
+            t = timeit(lambda: ops.bneck_fwd(xb_, B, Hm, Wm, [c[0] for c in cf], sb, train=False))
+            hb("%s identity Bottleneck fwd, fused, no-grad form (teacher / eval / frozen backbone)" % name, Mb * 2 * Cb * 2, t)
+            t = timeit(lambda: ops.bneck_bwd(gyb, B, Hm, Wm, [c[1] for c in cf], ab_, bb_, bits_, want_g=trainable))
+            hb("%s identity Bottleneck input-gradient chain, fused (1 launch)" % name, by_b, t,
+               "masks = the sign bits the forward wrote" + ("; gb, ga out for the weight-gradient GEMMs" if trainable else ""))
+            del plan
     # the stem in one launch each way (stem.hip): bytes = f32 input + pooled bf16 output + argmax bytes
     if ops.stem_pool_ok(dt, 64):
         xs = torch.randn(B, 1, 500, 64, device=dev)
