@@ -72,7 +72,9 @@ __device__ __forceinline__ uint4 load_chunk(const T* base, long off, int valid_e
   return r;
 }
 
-constexpr int X3P = 40;      // bf16 element pitch of the hi / lo images of the x3 mode (80-byte rows: 16-byte fragment reads of 16 rows conflict-free)
+constexpr int X3BK = 32;     // K block of the x3 mode (64 - 12 MFMAs per wave between two barriers, 74 KB of LDS, two workgroups per CU - measured
+                             // slower: 29.3 against 27.3 ms per C2 step)
+constexpr int X3P = X3BK + 8; // bf16 element pitch of the hi / lo images of the x3 mode (80-byte rows: 16-byte fragment reads of 16 rows conflict-free)
 
 // hi / lo split of 4 consecutive f32 values -> 4 + 4 bf16
 __device__ __forceinline__ void split4(const float* s, VecT<bf16_t, 4>& hi, VecT<bf16_t, 4>& lo) {
@@ -83,10 +85,13 @@ __device__ __forceinline__ void split4(const float* s, VecT<bf16_t, 4>& hi, VecT
   }
 }
 
-template <typename T, int BM, int BN, bool TRANS, bool X3 = false>
+// FAST: every chunk is a whole, 16-byte aligned chunk inside the problem (M % BM == N % BN == K % BK == 0, aligned operands) - the loads
+// are plain predicated 16-byte loads.  The general loader's per-chunk bounds / alignment branches made the staging code of an iteration
+// several thousand instructions long (round 4: that, not the memory system and not the matrix pipe, bounded the f32 and bf16x3 modes).
+template <typename T, int BM, int BN, bool TRANS, bool X3 = false, bool FAST = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int vecA, const int vecB) {
   static_assert(!X3 || sizeof(T) == 4, "the x3 mode splits f32 operands");
-  constexpr int BK = Cfg<T>::BK, PITCH = Cfg<T>::PITCH, EPC = Cfg<T>::EPC, KSTEP = Cfg<T>::KSTEP;
+  constexpr int BK = X3 ? X3BK : Cfg<T>::BK, PITCH = Cfg<T>::PITCH, EPC = Cfg<T>::EPC, KSTEP = Cfg<T>::KSTEP;
   constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* sA = reinterpret_cast<T*>(smem_raw);  // [2][BM*PITCH]
@@ -131,7 +136,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int
   constexpr int AU = (BK / UK) * (BM / EPC), BU = (BK / UK) * (BN / EPC);
   constexpr int TAP = TRANS ? (AU + 255) / 256 : 1, TBP = TRANS ? (BU + 255) / 256 : 1;
   constexpr int NRA = TRANS ? TAP * UK : APASS, NRB = TRANS ? TBP * UK : BPASS;
-  uint4 ra[NRA], rb[NRB];
+  // TWO register stages: tile it + 2 is loaded while tile it is multiplied and tile it + 1 waits in the other set - a global load has two
+  // iterations to land instead of one (round 4: with one stage every iteration exposed most of a memory round trip; the f32 / bf16x3 steps
+  // spend 90 % of their time in this kernel)
+  uint4 ra0[NRA], rb0[NRB], ra1[NRA], rb1[NRB];
 
   // per-thread row state (trans == 0)
   const int chunk = t % CPR, lrow = t / CPR;
@@ -171,31 +179,47 @@ __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int
     }
   }
 
-  auto load_tiles = [&](int kb) {
+  // trans == 0: element offsets of this thread's A rows for the tap the K walk is in (-1: padding) and of its B rows - recomputed when the
+  // walk enters a new tap, not per iteration (the gather arithmetic, integer divisions included, was most of an iteration's instructions)
+  long a_off[APASS], b_off[BPASS];
+  int w_tap = -1, w_c0 = 0, w_k0 = kb_begin * BK;               // the K walk: load_tiles is called for kb_begin, kb_begin + 1, ... in order
+  if constexpr (!TRANS) {
+    if (p.conv) { w_tap = w_k0 / p.Ci; w_c0 = w_k0 - w_tap * p.Ci; w_tap = -1 - w_tap; }     // (negative: offsets not computed yet)
+    else w_c0 = w_k0;
+#pragma unroll
+    for (int ps = 0; ps < BPASS; ++ps) b_off[ps] = (long)(n0 + lrow + ps * RPP) * p.ldb + chunk * EPC;
+    if (!p.conv) {
+#pragma unroll
+      for (int ps = 0; ps < APASS; ++ps) a_off[ps] = a_ok[ps] ? (long)a_n[ps] * p.lda + chunk * EPC : -1;
+    }
+  }
+  auto ld = [&](const T* base, long off, int valid, int vec) -> uint4 {
+    if constexpr (FAST) return *reinterpret_cast<const uint4*>(base + off);
+    else return load_chunk<T>(base, off, valid, vec);
+  };
+  auto load_tiles = [&](int kb, uint4(&ra)[NRA], uint4(&rb)[NRB]) {
     const int k0 = kb * BK;
     if constexpr (!TRANS) {
       // A: gathered rows
-      int kh = 0, kw = 0, c0 = k0;
-      if (p.conv) {
-        int tap = k0 / p.Ci;
-        c0 = k0 - tap * p.Ci;
-        kh = tap / p.KW;
-        kw = tap - kh * p.KW;
+      if (p.conv && w_tap < 0) {                                  // a new tap: this thread's row offsets
+        w_tap = -1 - w_tap;
+        const int kh = w_tap / p.KW, kw = w_tap - kh * p.KW;
+#pragma unroll
+        for (int ps = 0; ps < APASS; ++ps) {
+          const long pix = a_ok[ps] ? gather_pix(g, a_n[ps], a_ho[ps], a_wo[ps], kh, kw) : -1;
+          a_off[ps] = pix >= 0 ? pix * p.lda + chunk * EPC : -1;
+        }
       }
       const int kvalid = p.K - (k0 + chunk * EPC);  // elements of this chunk inside K
 #pragma unroll
-      for (int ps = 0; ps < APASS; ++ps) {
-        long pix = -1;
-        if (a_ok[ps]) pix = p.conv ? gather_pix(g, a_n[ps], a_ho[ps], a_wo[ps], kh, kw) : (long)a_n[ps];
-        ra[ps] = (pix >= 0) ? load_chunk<T>(Ag, pix * p.lda + c0 + chunk * EPC, kvalid, vecA)
-                            : make_uint4(0, 0, 0, 0);
-      }
+      for (int ps = 0; ps < APASS; ++ps) ra[ps] = (a_off[ps] >= 0) ? ld(Ag, a_off[ps] + w_c0, kvalid, vecA) : make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int ps = 0; ps < BPASS; ++ps) {
         int row = n0 + lrow + ps * RPP;
-        rb[ps] = (row < p.N) ? load_chunk<T>(Bg, (long)row * p.ldb + k0 + chunk * EPC, kvalid, vecB)
-                             : make_uint4(0, 0, 0, 0);
+        rb[ps] = (FAST || row < p.N) ? ld(Bg, b_off[ps] + k0, kvalid, vecB) : make_uint4(0, 0, 0, 0);
       }
+      w_c0 += BK;                                                 // (a K block never straddles a tap: Ci % BK == 0)
+      if (p.conv && w_c0 >= p.Ci) { w_c0 = 0; w_tap = -2 - w_tap; }
     } else {
       // A: dY[k][m], plain
 #pragma unroll
@@ -206,8 +230,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int
 #pragma unroll
         for (int kk = 0; kk < UK; ++kk) {
           int k = k0 + ku * UK + kk;
-          bool ok = (u < AU) && (k < p.K);
-          ra[ps * UK + kk] = ok ? load_chunk<T>(Ag, (long)k * p.lda + i, p.M - i, vecA) : make_uint4(0, 0, 0, 0);
+          bool ok = (u < AU) && (FAST || k < p.K);
+          ra[ps * UK + kk] = ok ? ld(Ag, (long)k * p.lda + i, p.M - i, vecA) : make_uint4(0, 0, 0, 0);
         }
       }
       // B: X gathered by pixel k and this thread's tap
@@ -219,7 +243,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int
 #pragma unroll
         for (int kk = 0; kk < UK; ++kk) {
           int k = k0 + ku * UK + kk;
-          bool ok = (u < BU) && (k < p.K) && (j < p.N);
+          bool ok = (u < BU) && (FAST || ((k < p.K) && (j < p.N)));
           long pix = -1;
           if (ok) {
             if (p.conv) {
@@ -232,13 +256,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int
           }
           // a chunk never straddles a tap (Ci % EPC == 0 is required when conv); plain: clip at N
           int valid = p.conv ? EPC : p.N - j;
-          rb[ps * UK + kk] = (pix >= 0) ? load_chunk<T>(Bg, pix * p.ldb + b_c[ps], valid, vecB) : make_uint4(0, 0, 0, 0);
+          rb[ps * UK + kk] = (pix >= 0) ? ld(Bg, pix * p.ldb + b_c[ps], valid, vecB) : make_uint4(0, 0, 0, 0);
         }
       }
     }
   };
 
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, const uint4(&ra)[NRA], const uint4(&rb)[NRB]) {
     T* dA = sA + buf * BM * PITCH;
     T* dB = sB + buf * BN * PITCH;
     if constexpr (X3) {
@@ -432,16 +456,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int
 
   // ======================================================================== main loop
   if (nkb > 0) {
-    load_tiles(kb_begin);
-    store_tiles(0);
+    load_tiles(kb_begin, ra0, rb0);
+    if (nkb > 1) load_tiles(kb_begin + 1, ra1, rb1);
+    store_tiles(0, ra0, rb0);
     __syncthreads();
-    for (int it = 0; it < nkb; ++it) {
-      const int cur = it & 1;
-      const bool more = (it + 1) < nkb;
-      if (more) load_tiles(kb_begin + it + 1);
-      compute(cur);
-      if (more) store_tiles(cur ^ 1);
+    // tile `it` is in LDS buffer it & 1, tile it + 1 in (or on its way to) the register set `nxt`, the set `fre` is free
+    auto body = [&](int it, uint4(&fa)[NRA], uint4(&fb)[NRB], const uint4(&na)[NRA], const uint4(&nb)[NRB]) {
+      if (it + 2 < nkb) load_tiles(kb_begin + it + 2, fa, fb);
+      compute(it & 1);
+      if (it + 1 < nkb) store_tiles((it & 1) ^ 1, na, nb);
       __syncthreads();
+    };
+    for (int it = 0; it < nkb; it += 2) {
+      body(it, ra0, rb0, ra1, rb1);
+      if (it + 1 < nkb) body(it + 1, ra1, rb1, ra0, rb0);
     }
   }
 
@@ -528,12 +556,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const SedtIgemm p, const int
 }
 
 // ---------------------------------------------------------------------------- host side
-template <typename T, int BM, int BN, bool TRANS, bool X3 = false>
+template <typename T, int BM, int BN, bool TRANS, bool X3 = false, bool FAST = false>
 static int launch_cfg(const SedtIgemm& p, int vecA, int vecB, hipStream_t st) {
-  SEDT_DESCRIBE("igemm_kernel<%s, %d, %d, %s%s>", sizeof(T) == 4 ? "float" : "__bf16", BM, BN, TRANS ? "true" : "false", X3 ? ", true" : "");
+  if constexpr (!FAST && sizeof(T) == 4 && BM == 64 && BN == 64) {
+    // whole, aligned tiles: the branch-free loader (f32 / bf16x3 only: the bf16 mode lives in the LDS-DMA family)
+    if (vecA && vecB && p.M % BM == 0 && p.N % BN == 0 && p.K % (X3 ? X3BK : Cfg<T>::BK) == 0 && (!p.conv || p.trans || p.Ci % (X3 ? X3BK : Cfg<T>::BK) == 0))
+      return launch_cfg<T, BM, BN, TRANS, X3, true>(p, vecA, vecB, st);
+  }
+  SEDT_DESCRIBE("igemm_kernel<%s, %d, %d, %s%s%s>", sizeof(T) == 4 ? "float" : "__bf16", BM, BN, TRANS ? "true" : "false", X3 ? ", true" : "",
+                FAST ? (X3 ? ", true" : ", false, true") : "");
   constexpr size_t lds = X3 ? (size_t)(BM + BN) * X3P * sizeof(bf16_t) * 2 * 2 : (size_t)(BM + BN) * Cfg<T>::PITCH * sizeof(T) * 2;
   static bool attr_set = false;  // idempotent; a benign race sets it twice
-  auto kern = igemm_kernel<T, BM, BN, TRANS, X3>;
+  auto kern = igemm_kernel<T, BM, BN, TRANS, X3, FAST>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -558,7 +592,7 @@ static int launch_typed(const SedtIgemm& p, hipStream_t st) {
   int vecA = aligned(p.A, p.lda), vecB = aligned(p.B, p.ldb);
   if (p.conv) {
     SEDT_REQUIRE(p.Ci % EPC == 0, "igemm: conv needs Ci %% %d == 0 (got %d)", EPC, p.Ci);
-    if (!p.trans) SEDT_REQUIRE(p.Ci % Cfg<T>::BK == 0, "igemm: conv needs Ci %% BK == 0 (Ci=%d, BK=%d)", p.Ci, Cfg<T>::BK);
+    if (!p.trans) SEDT_REQUIRE(p.Ci % (X3 ? X3BK : Cfg<T>::BK) == 0, "igemm: conv needs Ci %% BK == 0 (Ci=%d, BK=%d)", p.Ci, X3 ? X3BK : Cfg<T>::BK);
   }
   if (!p.trans) {
     // non-trans vector chunks run along k: k offsets are multiples of EPC, so K must be too (else scalar path)
