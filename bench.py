@@ -576,6 +576,17 @@ def family_report(step, rec, dtype, n_params, step_ms):
         w = work.setdefault(label, [0.0, 0.0])
         w[0] += flop
         w[1] += nb
+    # the fused Bottleneck launches of the recorded step (ops.PROFILE_FUSED: kernel-name prefix, flop, bytes)
+    from sound_event_detection_transformer_amd import ops as ops_
+    for name, flop, nb in ops_.PROFILE_FUSED:
+        alg_gemm_bytes += nb
+        label = match(name)
+        if label is None:
+            unmatched += 1
+            continue
+        w = work.setdefault(label, [0.0, 0.0])
+        w[0] += flop
+        w[1] += nb
     # the streaming kernels whose byte counts follow from the parameter count alone
     for k in times:
         if k.startswith('multi_adamw_kernel'):
@@ -970,6 +981,7 @@ def main():
               from sound_event_detection_transformer_amd import lib as L_
               from sound_event_detection_transformer_amd.engine import train_step
               ops.PROFILE = []
+              del ops.PROFILE_FUSED[:]
               train_step(ex['net'], ex['criterion'], ex['opt'], ex['x'], ex['targets'], ex['wm'], slice(ex['ns']), max_norm=0.1,
                          allreduce=bool(ex.get('eager_allreduce')))
               torch.cuda.synchronize()

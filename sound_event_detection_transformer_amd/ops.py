@@ -44,6 +44,7 @@ def _dev_env(name, default):
 
 RELU_BITS = _dev_env('SEDT_RELU_BITS', '1') != '0'      # developer A/B switch: 0 = the backward masks with the bf16 activations
 PROFILE = None   # bench.py sets this to a list: every GEMM launch then also records (argument block, dtype, shape, operands, hint)
+PROFILE_FUSED = []     # with PROFILE on: (kernel-name prefix, algorithmic flop, algorithmic bytes) of every fused-Bottleneck launch of the recorded step
 PROFILE_HINT = None   # how the un-profiled step launches the problem being recorded: 'conv3x3_c64_kernel' (direct kernel), 'igemm_group'
 
 
@@ -755,6 +756,11 @@ def bneck_fwd(x, B, H, W, wf, sb, train=True, want_bits=True, want_ab=False):
         if want_bits:
             bits = torch.empty((M, C // 8), device=x.device, dtype=torch.uint8)
     (s1, b1), (s2, b2), (s3, b3) = sb
+    if PROFILE is not None:
+        PROFILE_FUSED.append(('bneck3_kernel<false>' if C == 1024 else 'bneck_kernel<BG<%d, %d, %d>, false' % (C, P, W),
+                              2.0 * M * (2 * C * P + 9 * P * P),
+                              M * (2.0 * C * 2 + (C // 8 if bits is not None else 0) + (2 * (P // 8) if abits is not None else 0)
+                                   + (2 * P * 2 if a is not None else 0)) + 2.0 * (2 * C * P + 9 * P * P)))
     if C == 1024:
         L.check(L.load().sedt_bneck3_fwd(_p(x), _p(y), _p(wf[0]), _p(wf[1]), _p(wf[2]), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3), _p(a),
                                          _p(b), _p(abits), _p(bbits), _p(bits), B, H, L.stream_ptr()), 'bneck3_fwd')
@@ -776,6 +782,13 @@ def bneck_bwd(gy, B, H, W, wt, abits, bbits, xbits, want_g=False, chain_only=Fal
     if want_g or chain_only:
         ga = torch.empty((M, C // 4), device=gy.device, dtype=torch.bfloat16)
         gb = torch.empty_like(ga) if want_g else None
+    if PROFILE is not None:
+        P_ = C // 4
+        name = ('bneck3_kernel<true>' if C == 1024 else
+                'bneck_kernel<BG<%d, %d, %d>, true, %s>' % (C, P_, W, 'true' if chain_only else 'false'))
+        PROFILE_FUSED.append((name, 2.0 * M * ((1 if chain_only else 2) * C * P_ + 9 * P_ * P_),
+                              M * (C * 2.0 * (1 if chain_only else 2) + C // 8 + 2 * (P_ // 8) + ((2 if want_g else 1 if chain_only else 0) * P_ * 2))
+                              + 2.0 * (2 * C * P_ + 9 * P_ * P_)))
     if C == 1024:
         assert not chain_only
         L.check(L.load().sedt_bneck3_bwd(_p(gy), _p(gx), _p(wt[2]), _p(wt[1]), _p(wt[0]), _p(abits), _p(bbits), _p(xbits), _p(gb), _p(ga), B, H,
@@ -808,6 +821,9 @@ def bneck0_fwd(x, B, H, wf, sb, train=True, want_bits=True, want_ab=False):
         if want_bits:
             bits = torch.empty((M, 32), device=x.device, dtype=torch.uint8)
     (s1, b1), (s2, b2), (s3, b3), (sd, bd) = sb
+    if PROFILE is not None:
+        PROFILE_FUSED.append(('bneck0_fwd_kernel', 2.0 * M * (64 * 64 + 9 * 64 * 64 + 2 * 64 * 256),
+                              M * (64 * 2.0 + 256 * 2 + (32 if bits is not None else 0) + (16 if abits is not None else 0) + (256 if a is not None else 0))))
     L.check(L.load().sedt_bneck0_fwd(_p(x), _p(y), _p(wf[0]), _p(wf[1]), _p(wf[2]), _p(wf[3]), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3),
                                      _p(sd), _p(bd), _p(a), _p(b), _p(abits), _p(bbits), _p(bits), B, H, L.stream_ptr()), 'bneck0_fwd')
     return y, a, b, bits, abits, bbits
@@ -833,6 +849,9 @@ def bneck2_fwd(x, B, H, wf, sb, train=True, want_bits=True):
         if want_bits:
             bits = torch.empty((M2, 64), device=x.device, dtype=torch.uint8)
     (s1, b1), (s2, b2), (s3, b3), (sd, bd) = sb
+    if PROFILE is not None:
+        PROFILE_FUSED.append(('bneck2_fwd_kernel', 2.0 * (M * 256 * 128 + M2 * (9 * 128 * 128 + 128 * 512 + 256 * 512)),
+                              M * 256 * 2.0 + M2 * (512 * 2.0 + (64 if bits is not None else 0)) + ((M + M2) * 128 * 2.0 if a is not None else 0)))
     L.check(L.load().sedt_bneck2_fwd(_p(x), _p(y), _p(wf[0]), _p(wf[1]), _p(wf[2]), _p(wf[3]), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3),
                                      _p(sd), _p(bd), _p(a), _p(b), _p(bits), B, H, L.stream_ptr()), 'bneck2_fwd')
     return y, a, b, bits
