@@ -150,6 +150,11 @@ def test_fused_bottleneck_kernels_against_torch(which):
         gx, gb, ga = ops.bneck_bwd(gym, B, H, W, [c[1] for c in cf], abits, bbits, xbits, want_g=True)
         gx2, _, _ = ops.bneck_bwd(gym, B, H, W, [c[1] for c in cf], abits, bbits, xbits)
         assert torch.equal(gx, gx2)
+        # the no-grad form (no by-products) and the sign-bits-only training form write the same y
+        y_ng, a_ng, _, bits_ng, ab_ng, _ = ops.bneck_fwd(x, B, H, W, [c[0] for c in cf], sb, train=False)
+        y_sb, a_sb, _, _, ab_sb, bb_sb = ops.bneck_fwd(x, B, H, W, [c[0] for c in cf], sb)
+        assert torch.equal(y_ng, y) and a_ng is None and bits_ng is None and ab_ng is None
+        assert torch.equal(y_sb, y) and a_sb is None and torch.equal(ab_sb, abits) and torch.equal(bb_sb, bbits)
         torch.cuda.synchronize()
 
     def q(t):
