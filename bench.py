@@ -39,8 +39,8 @@ HBM_PEAK = 8.0e12
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c4', 'c5', 'eval'],
                     help="BASELINE.json configuration (default c2 = the headline metric); 'eval' = the validation body of "
                          "engine.get_sedt_predictions at the C2 shape (an extra, not a BASELINE metric)")
