@@ -127,7 +127,7 @@ class HeadsFn(Function):
         x = _as(hs, dt).view(Lh * B * Qp, d)
         tr = any(ctx.needs_input_grad)
         ctx.slab = None
-        if ops.heads_slab_ok(dt, d, wc.shape[0], 0 if wa is None else wa.shape[0]) and wc.is_contiguous() and w3.is_contiguous():
+        if ops.heads_slab_ok(dt, d, wc.shape[0], 0 if wa is None else wa.shape[0], hs.numel() // d) and wc.is_contiguous() and w3.is_contiguous():
             fr = [packing.lookup_frag(w) for w in (w1, w2)]
             if all(f is not None for f in fr):
                 # all heads in ONE launch (csrc/heads_slab.hip)

@@ -860,8 +860,11 @@ def bneck2_fwd(x, B, H, wf, sb, train=True, want_bits=True):
 SLAB_HEADS = _dev_env('SEDT_SLAB_HEADS', '1') != '0'
 
 
-def heads_slab_ok(dtype, D, C1, CA):
-    return bool(SLAB_HEADS and dtype == BF16 and L.load().sedt_heads_slab_ok(D, C1, CA, dtype))
+HEADS_SLAB_MAX_ROWS = 12288     # (C4: 25,200 head rows = 788 slabs ran 0.5 % slower than the per-op heads, same-box A/B; C2 / C3 / C5: 2,000 rows, -1.2 %)
+
+
+def heads_slab_ok(dtype, D, C1, CA, rows=0):
+    return bool(SLAB_HEADS and dtype == BF16 and rows <= HEADS_SLAB_MAX_ROWS and L.load().sedt_heads_slab_ok(D, C1, CA, dtype))
 
 
 def heads_fwd(x, wc, bc, w1f, b1, w2f, b2, w3, b3, wa, ba, Lh, B, Qp, train=True):
