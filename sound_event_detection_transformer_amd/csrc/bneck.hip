@@ -345,14 +345,6 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
             acc[s3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w3r[(NW3 > G::KS3 ? (t & 1) * G::KS3 : 0) + kk]), xb[s3],
                                                               acc[s3], 0, 0, 0);
         }
-        float4 sc[4], bi[4];
-        if (!BWD) {
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            sc[g4] = *reinterpret_cast<const float4*>(SB + 4 * P + tile * 32 + 8 * g4 + 4 * hf);
-            bi[g4] = *reinterpret_cast<const float4*>(SB + 4 * P + C + tile * 32 + 8 * g4 + 4 * hf);
-          }
-        }
         unsigned nibs[NS];                                       // fwd: this lane's sign nibbles of slab s3, nibble g4 at bits 8 * g4 (+ 4 * hf)
 #pragma unroll
         for (int s3 = 0; s3 < NS; ++s3) {
@@ -370,8 +362,11 @@ __global__ __launch_bounds__(512) void bneck_kernel(const BneckArgs a) {
               o.x = pack2(lo + widen2(xw.x)) & keep2(m4, 8 * g4);
               o.y = pack2(hi + widen2(xw.y)) & keep2(m4, 8 * g4 + 2);
             } else {
-              o.x = pack2(relu2(lo * f32x2{sc[g4].x, sc[g4].y} + f32x2{bi[g4].x, bi[g4].y} + widen2(xw.x)));
-              o.y = pack2(relu2(hi * f32x2{sc[g4].z, sc[g4].w} + f32x2{bi[g4].z, bi[g4].w} + widen2(xw.y)));
+              // (scale / bias read per use: eight float4 held across the slab loop pushed the 512-channel geometry into scratch)
+              const float4 sc = *reinterpret_cast<const float4*>(SB + 4 * P + tile * 32 + 8 * g4 + 4 * hf);
+              const float4 bi = *reinterpret_cast<const float4*>(SB + 4 * P + C + tile * 32 + 8 * g4 + 4 * hf);
+              o.x = pack2(relu2(lo * f32x2{sc.x, sc.y} + f32x2{bi.x, bi.y} + widen2(xw.x)));
+              o.y = pack2(relu2(hi * f32x2{sc.z, sc.w} + f32x2{bi.z, bi.w} + widen2(xw.y)));
               nibs[s3] |= nibble4(o.x, o.y) << (8 * g4 + 4 * hf);
             }
             *reinterpret_cast<uint2*>(xp + 8 * g4) = o;
@@ -874,12 +869,6 @@ __global__ __launch_bounds__(512) void bneck2_fwd_kernel(const Bneck2Args a) {
       load4(alt, 0, w2p + 8 * 64, lane);                         // units 2, 3
       load4(alt, 4, w2p + 12 * 64, lane);
       slab::issue_fence();
-      float4 sc[4], bi[4];
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        sc[g4] = *reinterpret_cast<const float4*>(SB + wave * 32 + 8 * g4 + 4 * hf);
-        bi[g4] = *reinterpret_cast<const float4*>(SB + P + wave * 32 + 8 * g4 + 4 * hf);
-      }
 #pragma unroll
       for (int s3 = 0; s3 < 5; ++s3) {
         const int p = s3 * 32 + n, trow = p >> 4, pc = p & 15, gr = 2 * r0o - 1 + trow;
@@ -888,9 +877,11 @@ __global__ __launch_bounds__(512) void bneck2_fwd_kernel(const Bneck2Args a) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const f32x2 lo = {acc[s3][4 * g4], acc[s3][4 * g4 + 1]}, hi = {acc[s3][4 * g4 + 2], acc[s3][4 * g4 + 3]};
+          const float4 sc = *reinterpret_cast<const float4*>(SB + wave * 32 + 8 * g4 + 4 * hf);
+          const float4 bi = *reinterpret_cast<const float4*>(SB + P + wave * 32 + 8 * g4 + 4 * hf);
           uint2 o;
-          o.x = pack2(relu2(lo * f32x2{sc[g4].x, sc[g4].y} + f32x2{bi[g4].x, bi[g4].y}));
-          o.y = pack2(relu2(hi * f32x2{sc[g4].z, sc[g4].w} + f32x2{bi[g4].z, bi[g4].w}));
+          o.x = pack2(relu2(lo * f32x2{sc.x, sc.y} + f32x2{bi.x, bi.y}));
+          o.y = pack2(relu2(hi * f32x2{sc.z, sc.w} + f32x2{bi.z, bi.w}));
           if (!inimg) o = make_uint2(0, 0);
           if (p < NPI) *reinterpret_cast<uint2*>(dst + 8 * g4) = o;
         }
