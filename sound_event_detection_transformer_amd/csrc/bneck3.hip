@@ -318,7 +318,9 @@ extern "C" int sedt_bneck3_ok(int cin, int planes, int W, int stride, int dil, i
   if (!(dtype == SEDT_BF16 && cin == G3::C && planes == G3::P && W == G3::W && stride == 1 && dil == 1 && !has_downsample)) return 0;
   // every workgroup streams the block's 2.2 MB of weights for 32 pixels: pays while the strips cover the chip about once
   const int nst = B * ((H + G3::R - 1) / G3::R);
-  return nst >= 192 && nst <= 512;
+  // (128 strips - C3, C5's teacher pass - measured 0.3-0.6 % SLOWER than the per-op launches: tools/dev/ab_bneck3_min.sh)
+  static int lo = [] { const char* e = dev_getenv("SEDT_BNECK3_MIN"); return e ? atoi(e) : 192; }();
+  return nst >= lo && nst <= 512;
 }
 
 extern "C" int sedt_bneck3_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const float* s1,
