@@ -352,6 +352,10 @@ int sedt_pack_frag(const SedtFragJob* jobs, int njobs, int nblocks, void* stream
  * the unfused chain: attention ((b*8 + h)*S + q)*S + k under seed_attn, out-proj row*256 + col under seed_o, hidden row*FF + col
  * under seed_h, FFN output row*256 + col under seed_f (each + *seed_ptr).  Envelope (sedt_encoder_slab_ok): bf16, d_model 256,
  * 8 heads, S <= 128, FF a multiple of 512. */
+/* Optional, before sedt_encoder_qkv_fwd (same thread): up to three regions (bytes 0 / null = none) the launch AFTER it will stream - the
+ * fragment-major weights of sedt_encoder_attn_ffn_fwd.  The qkv launch then touches one 128-byte line of them per load so that every XCD's
+ * L2 holds them when the streaming launch starts; consumed by that one call. */
+int sedt_encoder_qkv_prefetch(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2);
 int sedt_encoder_slab_ok(int D, int H, int S, int FF, int dtype);
 /* The input-gradient chain of the same layer, two launches around sedt_attention_bwd (weights as fragment-major W^T, the `wb` of
  * sedt_pack_frag):

@@ -471,7 +471,7 @@ class EncoderLayerFn(Function):
             _, wb_o = _prep_linear(dt, w_o, tr)
             _, wb1 = _prep_linear(dt, w1, tr)
             _, wb2 = _prep_linear(dt, w2, tr)
-            qk, v, by1 = ops.encoder_qkv_fwd(x, pos, g1, be1, fr[0][0], b_in, B, S, train=tr)
+            qk, v, by1 = ops.encoder_qkv_fwd(x, pos, g1, be1, fr[0][0], b_in, B, S, train=tr, prefetch=(fr[1][0], fr[2][0], fr[3][0]))
             split = ops.ffn_split_ok(dt, x.shape[1], w1.shape[0])
             if split:
                 # attention | out-proj | LayerNorm2 per 32-token slab, then the FFN pair tiled 128 rows x a quarter of the hidden features

@@ -682,7 +682,10 @@ def encoder_slab_ok(dtype, D, H, S, FF, amask, B=None):
                 and L.load().sedt_encoder_slab_ok(D, H, S, FF, dtype))
 
 
-def encoder_qkv_fwd(x, pos, gamma, beta, w_in_frag, b_in, B, S, train=True):
+ENC_PREFETCH = _dev_env('SEDT_ENC_PREFETCH', '1') != '0'
+
+
+def encoder_qkv_fwd(x, pos, gamma, beta, w_in_frag, b_in, B, S, train=True, prefetch=None):
     """xn = LayerNorm1(x); q | k = (xn + pos) Wqk^T + b; v = xn Wv^T + b.  x, pos [B*S, 256] bf16 contiguous; w_in_frag = the
     fragment-major in_proj_weight (packing.lookup_frag).  Returns (qk [B*S, 512], v [B*S, 256], (xn, xnp, mean, rstd) or None)"""
     _dev_check(x, pos, w_in_frag)
@@ -695,6 +698,9 @@ def encoder_qkv_fwd(x, pos, gamma, beta, w_in_frag, b_in, B, S, train=True):
         by = (torch.empty_like(x), torch.empty_like(x), torch.empty((M,), device=x.device, dtype=torch.float32),
               torch.empty((M,), device=x.device, dtype=torch.float32))
     s = by if by is not None else (None,) * 4
+    if prefetch and ENC_PREFETCH:             # the next launch's weights: touched by this one so that they are L2-resident when it streams them
+        pf = (list(prefetch) + [None] * 3)[:3]
+        L.load().sedt_encoder_qkv_prefetch(*[v_ for t_ in pf for v_ in (_p(t_), 0 if t_ is None else t_.numel() * t_.element_size())])
     L.check(L.load().sedt_encoder_qkv_fwd(_p(x), _p(pos), _p(gamma), _p(beta), _p(w_in_frag), _p(b_in), _p(qk), _p(v), _p(s[0]), _p(s[1]),
                                           _p(s[2]), _p(s[3]), B, S, L.stream_ptr()), 'encoder_qkv_fwd')
     return qk, v, by
