@@ -425,6 +425,9 @@ int sedt_bneck_bwd(const void* gy, void* gx, const void* w3t_frag, const void* w
  * stay in LDS - a ~25 us floor set by the L2 -> CU stream, which beats the three per-op launches only while the strips cover the chip
  * about once: sedt_bneck3_ok additionally wants 192 <= B * ceil(H / 8) <= 512.  Arguments as for sedt_bneck_fwd / sedt_bneck_bwd (cin,
  * planes, W implied); abits / bbits [M][32], bits [M][128]. */
+/* Optional, before sedt_bneck3_fwd / sedt_bneck3_bwd (same thread): the three weight operands the NEXT such launch will stream (the next
+ * block's); the launch touches them one 128-byte line per load so that they are L2-resident by then.  Consumed by that one call. */
+int sedt_bneck3_prefetch(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2);
 int sedt_bneck3_ok(int cin, int planes, int W, int stride, int dil, int has_downsample, int B, int H, int dtype);
 int sedt_bneck3_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const float* s1, const float* b1,
                     const float* s2, const float* b2, const float* s3, const float* b3, void* a_out, void* b_out, uint8_t* abits_out,

@@ -31,6 +31,9 @@ struct Bneck3Args {
   const uint8_t* abits_in; const uint8_t* bbits_in;      // bwd
   const uint8_t* bits_in;            // bwd: sign bits of the block input [M][128], or null (no mask)
   int B, H;
+  // the NEXT launch's weights (the next block's three fragment-major operands), touched here one 128-byte line per load so that every
+  // XCD's L2 holds them when its workgroups start to stream them in lockstep (cold, every chunk was an HBM-latency miss for all of them)
+  const uint32_t* pf[3]; int pf_lines[3];
 };
 
 struct G3 {
@@ -80,6 +83,14 @@ __global__ __launch_bounds__(512) void bneck3_kernel(const Bneck3Args a) {
   issue(0);
   issue(1);
   slab::issue_fence();
+  uint32_t pf_acc = 0;
+  {
+    // workgroups go round-robin over the 8 XCDs: the workgroups of one XCD (blockIdx % 8 equal) share the lines between them
+    const int slot = blockIdx.x >> 3, nslots = max(1, (int)(gridDim.x >> 3));
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      for (int j = slot * 512 + tid; j < a.pf_lines[r]; j += nslots * 512) pf_acc ^= a.pf[r][(long)j * 32];
+  }
 
   // ---- tiles to LDS
   {
@@ -283,6 +294,7 @@ __global__ __launch_bounds__(512) void bneck3_kernel(const Bneck3Args a) {
         *reinterpret_cast<uint4*>(a.b_out + (pix0 + q) * P + c) = *reinterpret_cast<const uint4*>(BT + q * AP + c);
       }
     }
+  if (pf_acc == 0x9e3779b9u && a.B < 0) a.out[0] = (bf16_t)1.f;       // (never: keeps the touching loads alive)
   if (!BWD) {
     if (a.bits_out && tid < 256 && (tid >> 5) < rows_in) reinterpret_cast<uint4*>(a.bits_out + pix0 * CP)[tid] = reinterpret_cast<const uint4*>(BITS)[tid];
     if (a.abits_out && tid >= 256 && tid < 320 && ((tid - 256) >> 3) < rows_in)
@@ -292,8 +304,16 @@ __global__ __launch_bounds__(512) void bneck3_kernel(const Bneck3Args a) {
   }
 }
 
+static thread_local const void* b3_pf_ptr[3] = {nullptr, nullptr, nullptr};
+static thread_local size_t b3_pf_bytes[3] = {0, 0, 0};
+
 template <bool BWD>
-static int bneck3_launch(const Bneck3Args& a, hipStream_t s, const char* what) {
+static int bneck3_launch(Bneck3Args& a, hipStream_t s, const char* what) {
+  for (int r = 0; r < 3; ++r) {                                  // (one-shot: consumed by this launch)
+    a.pf[r] = (const uint32_t*)b3_pf_ptr[r];
+    a.pf_lines[r] = (int)(b3_pf_bytes[r] / 128);
+    b3_pf_ptr[r] = nullptr; b3_pf_bytes[r] = 0;
+  }
   constexpr size_t lds = BWD ? G3::TOTAL_B : G3::TOTAL_F;
   static_assert(lds <= 160 * 1024, "LDS");
   static bool attr = false;
@@ -321,6 +341,13 @@ extern "C" int sedt_bneck3_ok(int cin, int planes, int W, int stride, int dil, i
   // (128 strips - C3, C5's teacher pass - measured 0.3-0.6 % SLOWER than the per-op launches: tools/dev/ab_bneck3_min.sh)
   static int lo = [] { const char* e = dev_getenv("SEDT_BNECK3_MIN"); return e ? atoi(e) : 192; }();
   return nst >= lo && nst <= 512;
+}
+
+// the weights the launch AFTER the next sedt_bneck3_fwd / sedt_bneck3_bwd will stream (the next block's operands): that launch touches them
+extern "C" int sedt_bneck3_prefetch(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2) {
+  b3_pf_ptr[0] = p0; b3_pf_ptr[1] = p1; b3_pf_ptr[2] = p2;
+  b3_pf_bytes[0] = p0 ? n0 : 0; b3_pf_bytes[1] = p1 ? n1 : 0; b3_pf_bytes[2] = p2 ? n2 : 0;
+  return 0;
 }
 
 extern "C" int sedt_bneck3_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const float* s1,

@@ -830,8 +830,11 @@ class StageFn(Function):
                     # a frozen block (layer1, backbone.py:60-62) keeps only the sign bits of its intermediates: the fused backward
                     # needs nothing else; a trainable one (layer2) keeps a and b as well, for its weight gradients
                     frozen = not (t[0].requires_grad or t[5].requires_grad or t[10].requires_grad)
+                    # (layer3: the launch also touches the NEXT block's operands, so that they are L2-resident when that block streams them)
+                    nx = [packing.lookup_conv_frag(T[i + k]) for k in (0, 5, 10)] if (cin == 1024 and i + 15 <= len(T)) else None
+                    nx = [c[0] for c in nx] if nx and all(c is not None for c in nx) else None
                     y, a, b, ybits, abits, bbits = ops.bneck_fwd(x, B, H, W, [c[0] for c in cf], ((s1, b1), (s2, b2), (s3, b3)),
-                                                                 train=any(ctx.needs_input_grad), want_bits=bool(tr), want_ab=not frozen)
+                                                                 train=any(ctx.needs_input_grad), want_bits=bool(tr), want_ab=not frozen, nxt=nx)
                     saved.append(dict(blk=blk, x=x, a=a, b=b, g1=g1, g2=g2, g3=g3, s=(s1, s2, s3), wb=(w1b, w2b, w3b), H=H, W=W, y=y,
                                       xbits=xbits, fused=[c[1] for c in cf], ab_bits=(abits, bbits)))
                     x, xbits = y, ybits
@@ -919,7 +922,10 @@ class StageFn(Function):
                     # the input-gradient chain in one launch; a trainable block (layer2) also takes the two intermediate gradients out
                     # of it for its three weight-gradient GEMMs (a frozen one - layer1, backbone.py:60-62 - needs neither)
                     train_w = t[0].requires_grad or t[5].requires_grad or t[10].requires_grad
-                    gx, gb, ga = ops.bneck_bwd(gp, B, r['H'], r['W'], r['fused'], *r['ab_bits'], r['xbits'] if mask_x else None, want_g=train_w)
+                    prev = saved[bi_ - 1] if bi_ > 0 else None          # (the block the backward visits next: its operands, layer3 only)
+                    nx = prev['fused'] if (prev is not None and prev.get('fused') is not None and blk.cin == 1024) else None
+                    gx, gb, ga = ops.bneck_bwd(gp, B, r['H'], r['W'], r['fused'], *r['ab_bits'], r['xbits'] if mask_x else None, want_g=train_w,
+                                               nxt=nx)
                     if t[10].requires_grad:
                         grads[base + 10] = ops.wgrad(dt, gp, r['b'], B, r['g3'], rowscale=s3, batch=rb, param=t[10])
                     if t[5].requires_grad:

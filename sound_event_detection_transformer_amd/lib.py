@@ -129,6 +129,7 @@ SIGNATURES = {
     'sedt_encoder_attn_ffn_fwd': (_i, [_vp] * 20 + [_i, _i, _i, _f, _u32, _u32, _u32, _u32, _vp, _vp]),
     'sedt_encoder_qkv_prefetch': (_i, [_vp, _sz, _vp, _sz, _vp, _sz]),
     'sedt_bneck_ok': (_i, [_i] * 7),
+    'sedt_bneck3_prefetch': (_i, [_vp, _sz, _vp, _sz, _vp, _sz]),
     'sedt_bneck3_ok': (_i, [_i] * 9),
     'sedt_bneck3_fwd': (_i, [_vp] * 16 + [_i, _i, _vp]),
     'sedt_bneck3_bwd': (_i, [_vp] * 10 + [_i, _i, _vp]),

@@ -743,7 +743,15 @@ def bneck_ok(dtype, blk, W, B=0, H=0):
     return bool(lvl >= (1 if blk.cin == 256 else 2) and L.load().sedt_bneck_ok(blk.cin, blk.planes, W, blk.stride, blk.dil, int(blk.ds), dtype))
 
 
-def bneck_fwd(x, B, H, W, wf, sb, train=True, want_bits=True, want_ab=False):
+BNECK_PREFETCH = _dev_env('SEDT_BNECK_PREFETCH', '1') != '0'
+
+
+def _bneck3_prefetch(nxt):
+    if nxt is not None and BNECK_PREFETCH:
+        L.load().sedt_bneck3_prefetch(*[v_ for t_ in nxt for v_ in (_p(t_), t_.numel() * t_.element_size())])
+
+
+def bneck_fwd(x, B, H, W, wf, sb, train=True, want_bits=True, want_ab=False, nxt=None):
     """x [B*H*W, C] bf16 contiguous; wf = the three fragment-major forward operands; sb = ((s1, b1), (s2, b2), (s3, b3)).
     Returns (y, a, b, ybits, abits, bbits).  Training: the sign bits of the two intermediates (all bneck_bwd needs of them; [M, P/8] bytes)
     and, on request, the sign bits of y; want_ab: the intermediates themselves as well (the weight-gradient GEMMs of a trainable block)"""
@@ -768,6 +776,7 @@ def bneck_fwd(x, B, H, W, wf, sb, train=True, want_bits=True, want_ab=False):
                               M * (2.0 * C * 2 + (C // 8 if bits is not None else 0) + (2 * (P // 8) if abits is not None else 0)
                                    + (2 * P * 2 if a is not None else 0)) + 2.0 * (2 * C * P + 9 * P * P)))
     if C == 1024:
+        _bneck3_prefetch(nxt)                  # (the next block's three operands: touched by this launch, L2-resident for the next)
         L.check(L.load().sedt_bneck3_fwd(_p(x), _p(y), _p(wf[0]), _p(wf[1]), _p(wf[2]), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3), _p(a),
                                          _p(b), _p(abits), _p(bbits), _p(bits), B, H, L.stream_ptr()), 'bneck3_fwd')
     else:
@@ -776,7 +785,7 @@ def bneck_fwd(x, B, H, W, wf, sb, train=True, want_bits=True, want_ab=False):
     return y, a, b, bits, abits, bbits
 
 
-def bneck_bwd(gy, B, H, W, wt, abits, bbits, xbits, want_g=False, chain_only=False):
+def bneck_bwd(gy, B, H, W, wt, abits, bbits, xbits, want_g=False, chain_only=False, nxt=None):
     """input gradient of the fused Bottleneck: gy [B*H*W, C] bf16 (already masked by [y > 0]); wt = the three fragment-major dgrad
     operands (conv1, conv2, conv3 order); abits / bbits from bneck_fwd; xbits = sign bits of the block input or None.
     Returns (gx, gb, ga): gb / ga [M, P] = the gradients of the two intermediates (want_g: a trainable block's weight gradients read them).
@@ -797,6 +806,7 @@ def bneck_bwd(gy, B, H, W, wt, abits, bbits, xbits, want_g=False, chain_only=Fal
                               + 2.0 * (2 * C * P_ + 9 * P_ * P_)))
     if C == 1024:
         assert not chain_only
+        _bneck3_prefetch(nxt)
         L.check(L.load().sedt_bneck3_bwd(_p(gy), _p(gx), _p(wt[2]), _p(wt[1]), _p(wt[0]), _p(abits), _p(bbits), _p(xbits), _p(gb), _p(ga), B, H,
                                          L.stream_ptr()), 'bneck3_bwd')
         return gx, gb, ga
