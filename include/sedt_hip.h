@@ -356,6 +356,9 @@ int sedt_pack_frag(const SedtFragJob* jobs, int njobs, int nblocks, void* stream
  * fragment-major weights of sedt_encoder_attn_ffn_fwd.  The qkv launch then touches one 128-byte line of them per load so that every XCD's
  * L2 holds them when the streaming launch starts; consumed by that one call. */
 int sedt_encoder_qkv_prefetch(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2);
+/* The same before sedt_multi_wgrad_reduce: the reduce launch that closes a layer's backward touches the weights the next layer's backward
+ * kernels will stream (sedt_encoder_ffn_bwd's). */
+int sedt_reduce_prefetch(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2);
 int sedt_encoder_slab_ok(int D, int H, int S, int FF, int dtype);
 /* The input-gradient chain of the same layer, two launches around sedt_attention_bwd (weights as fragment-major W^T, the `wb` of
  * sedt_pack_frag):

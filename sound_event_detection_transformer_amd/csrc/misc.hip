@@ -36,6 +36,9 @@ static inline unsigned nblk(long n, int per = 256) { return (unsigned)((n + per 
 struct ReduceJobs {
   int n;
   SedtReduceJob j[SEDT_MAX_REDUCE_JOBS];
+  // what the NEXT launch streams (sedt_reduce_prefetch: the next encoder layer's backward weights): touched by the first 256 blocks, one
+  // 128-byte line per load, so that every XCD's L2 holds them when that launch's workgroups stream them in lockstep
+  const uint32_t* pf[3]; int pf_lines[3];
 };
 
 // blocks of one job: taps == 1 (and 4 | Ci): 1024 consecutive elements per block, float4 per thread;
@@ -59,6 +62,14 @@ __host__ __device__ inline int reduce_job_blocks(const SedtReduceJob& J) {
 
 __global__ __launch_bounds__(256) void multi_wgrad_reduce_kernel(const ReduceJobs jobs) {
   __shared__ float tile[9][65];
+  if (blockIdx.x < 256 && jobs.pf_lines[0] + jobs.pf_lines[1] + jobs.pf_lines[2] > 0) {
+    // (blocks go round-robin over the 8 XCDs: 32 blocks per XCD share the lines; the values are never used)
+    const int slot = blockIdx.x >> 3, nslots = min(32, max(1, (int)(gridDim.x >> 3)));
+    uint32_t acc = 0;
+    for (int r = 0; r < 3; ++r)
+      for (int j = slot * 256 + threadIdx.x; j < jobs.pf_lines[r]; j += nslots * 256) acc ^= jobs.pf[r][(long)j * 32];
+    if (acc == 0x9e3779b9u && jobs.n < 0) tile[0][0] = 1.f;
+  }
   int lo = 0, hi = jobs.n - 1;
   while (lo < hi) {
     int mid = (lo + hi + 1) >> 1;
@@ -1252,10 +1263,25 @@ extern "C" int sedt_multi_pack(const SedtPackJob* jobs, int njobs, int nblocks, 
   return check_launch("multi_pack");
 }
 
+static thread_local const void* red_pf_ptr[3] = {nullptr, nullptr, nullptr};
+static thread_local size_t red_pf_bytes[3] = {0, 0, 0};
+
+// the weights the launch AFTER the next sedt_multi_wgrad_reduce will stream (up to three regions): that reduce launch touches them
+extern "C" int sedt_reduce_prefetch(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2) {
+  red_pf_ptr[0] = p0; red_pf_ptr[1] = p1; red_pf_ptr[2] = p2;
+  red_pf_bytes[0] = p0 ? n0 : 0; red_pf_bytes[1] = p1 ? n1 : 0; red_pf_bytes[2] = p2 ? n2 : 0;
+  return 0;
+}
+
 extern "C" int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, void* stream) {
   SEDT_REQUIRE(jobs && njobs > 0 && njobs <= SEDT_MAX_REDUCE_JOBS, "multi_wgrad_reduce: 1..%d jobs", SEDT_MAX_REDUCE_JOBS);
   ReduceJobs a;
   a.n = njobs;
+  for (int r = 0; r < 3; ++r) {                                  // (one-shot: consumed by this launch)
+    a.pf[r] = (const uint32_t*)red_pf_ptr[r];
+    a.pf_lines[r] = (int)(red_pf_bytes[r] / 128);
+    red_pf_ptr[r] = nullptr; red_pf_bytes[r] = 0;
+  }
   int blk = 0;
   for (int i = 0; i < njobs; ++i) {
     a.j[i] = jobs[i];

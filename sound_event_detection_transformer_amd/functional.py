@@ -489,6 +489,7 @@ class EncoderLayerFn(Function):
                                  ctxv=ctxv, lse=lse, dims=(B, H, S, S), kpm=kpm, amask=None, p=p, seeds=seeds[0:2])
                 sv['ffn'] = dict(x_in=x1n, h=h, p=p, seeds=seeds[2:4], wb1=wb1, wb2=wb2)
                 sv.update(x=x, x1=x1, m1=m1, r1=r1, m2=m2, r2=r2, slab=(fr[0][1], fr[1][1], fr[2][1], fr[3][1]))
+                ops.ENC_BWD_STACK.append((fr[3][1], fr[2][1], fr[1][1]))      # (what this layer's backward streams first: W2^T, W1^T, Wo^T)
             ctx.sv, ctx.cfg, ctx.P = sv, cfg, P
             return x2
         if cfg['pre_norm'] and ops.FUSED_ENC and ops.encoder_attn_ok(dt, x.shape[1], H, S, amask) and x.is_contiguous() and pos.is_contiguous():
@@ -568,7 +569,11 @@ class EncoderLayerFn(Function):
             gx, part1 = ops.encoder_qkv_bwd(dqk, dv, sv['x'], sv['m1'], sv['r1'], g1, gx1, wint, B, S)
             dgb1 = torch.empty((2 * E,), device=dev, dtype=torch.float32)
             rb.add_colsum(part1, part1.shape[0], 2 * E, dgb1)
-            rb.flush()
+            # the reduce launch that closes this layer touches the weights the NEXT layer's backward (the one below) streams first
+            st = ops.ENC_BWD_STACK
+            if st and st[-1][0] is w2t:
+                st.pop()
+            rb.flush(prefetch=st[-1] if st else None)
             ctx.sv = None
             return (gx, None, None, None, None, d_win, d_bin, d_wo, d_bo, d_w1, d_b1, d_w2, d_b2, dgb1[:E], dgb1[E:], dgb2[:E], dgb2[E:])
         if cfg['pre_norm']:

@@ -128,6 +128,7 @@ SIGNATURES = {
     'sedt_encoder_qkv_fwd': (_i, [_vp] * 12 + [_i, _i, _vp]),
     'sedt_encoder_attn_ffn_fwd': (_i, [_vp] * 20 + [_i, _i, _i, _f, _u32, _u32, _u32, _u32, _vp, _vp]),
     'sedt_encoder_qkv_prefetch': (_i, [_vp, _sz, _vp, _sz, _vp, _sz]),
+    'sedt_reduce_prefetch': (_i, [_vp, _sz, _vp, _sz, _vp, _sz]),
     'sedt_bneck_ok': (_i, [_i] * 7),
     'sedt_bneck3_prefetch': (_i, [_vp, _sz, _vp, _sz, _vp, _sz]),
     'sedt_bneck3_ok': (_i, [_i] * 9),

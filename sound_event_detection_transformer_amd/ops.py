@@ -381,11 +381,18 @@ class ReduceBatch(object):
         for i in range(0, len(self.jobs), L.MAX_REDUCE_JOBS):
             chunk = self.jobs[i:i + L.MAX_REDUCE_JOBS]
             arr = (L.SedtReduceJob * len(chunk))(*chunk)
+            if self.prefetch is not None and RED_PREFETCH and i + L.MAX_REDUCE_JOBS >= len(self.jobs):      # (the last launch of the batch)
+                pf = (list(self.prefetch) + [None] * 3)[:3]
+                L.load().sedt_reduce_prefetch(*[v_ for t_ in pf for v_ in (_p(t_), 0 if t_ is None else t_.numel() * t_.element_size())])
             L.check(L.load().sedt_multi_wgrad_reduce(arr, len(chunk), L.stream_ptr()), 'multi_wgrad_reduce')
         self.jobs, self.keep = [], []
 
-    def flush(self):
+    prefetch = None
+
+    def flush(self, prefetch=None):
+        """prefetch: up to three tensors (weights) the launch AFTER this batch's reduce launch will stream: that launch touches them"""
         from . import runtime
+        self.prefetch = prefetch
         if _co['on'] and not runtime.async_wgrad_on():
             for body in self.deferred:              # allocate slabs / build the argument blocks; the GEMMs are not launched:
                 body()                              # they ride along with later launches of the dgrad chain
@@ -683,6 +690,9 @@ def encoder_slab_ok(dtype, D, H, S, FF, amask, B=None):
 
 
 ENC_PREFETCH = _dev_env('SEDT_ENC_PREFETCH', '1') != '0'
+RED_PREFETCH = _dev_env('SEDT_RED_PREFETCH', '1') != '0'
+import collections as _collections
+ENC_BWD_STACK = _collections.deque(maxlen=32)     # fragment-major backward weights of the slab encoder layers whose backward is still to come
 
 
 def encoder_qkv_fwd(x, pos, gamma, beta, w_in_frag, b_in, B, S, train=True, prefetch=None):

@@ -249,6 +249,8 @@ class PlanSet(object):
         self._cur = self.current()
         self._cur.run(self._key3)
         _active.append(self._cur)
+        from . import ops
+        ops.ENC_BWD_STACK.clear()             # (a model forward starts: no encoder backward of an earlier forward is pending any more)
         return self._cur
 
     def __exit__(self, *a):

@@ -10,7 +10,7 @@ if [ "$mode" = cpu ]; then
   python -m pytest tests -x -q -m "not gpu" || exit 1
 else
   mkdir -p gpurun_out
-  python -m pytest tests -x -q -m gpu 2>&1 | tail -3 || exit 1
+  python -m pytest tests -x -q -m gpu 2>&1 | tail -25 || exit 1
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 || exit 1
   python bench.py > gpurun_out/verify_bench.json 2> gpurun_out/verify_bench.err || { tail -5 gpurun_out/verify_bench.err; exit 1; }
   cut -c1-200 gpurun_out/verify_bench.json
