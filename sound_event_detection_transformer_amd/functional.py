@@ -731,7 +731,10 @@ class DecoderLayerFn(Function):
             g_qk, _, g_vs, d_swin, d_sbin, d_swo, d_sbo = _mha_bwd(dt, sv['sa'], g_a, sw_in, sw_o, batch=rb, g_dropped=g_ad)
             gtgt = ops.add(dt, ops.add(dt, g_qk, g_vs), g_a)
             g_qpos = ops.add(dt, g_qpos, g_qk)
-        rb.flush()
+        # the first decoder layer's backward is the last thing before the encoder's: its reduce launch touches the weights the top encoder
+        # layer's backward streams first (only LayerNorm launches follow it)
+        st = ops.ENC_BWD_STACK
+        rb.flush(prefetch=st[-1] if (st and cfg.get('layer_idx', 0) == 0) else None)
         ctx.sv = None
         return (gtgt, g_mem, g_mem_pos, g_qpos, None, None, None,
                 d_swin, d_sbin, d_swo, d_sbo, d_cwin, d_cbin, d_cwo, d_cbo, d_w1, d_b1, d_w2, d_b2,

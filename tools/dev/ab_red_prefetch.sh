@@ -1,4 +1,4 @@
-# developer A/B: the reduce launch closing an encoder layer's backward touching the next layer's backward weights (SEDT_RED_PREFETCH)
+# developer A/B: the reduce launches closing a decoder / encoder layer's backward touching the next encoder layer's backward weights
 export SEDT_DEV=1
 for v in 0 1 0 1; do
   echo -n "RED_PREFETCH=$v: "
