@@ -889,6 +889,8 @@ class StageFn(Function):
             x, H, W, xbits = y, g2.Ho, g2.Wo, ybits
         if meta.get('holder') is not None:
             meta['holder']['bits'] = xbits
+        if tr and saved and saved[-1].get('fused') is not None:
+            ops.STAGE_BWD_STACK.append(tuple(saved[-1]['fused'][:3]))      # (what this stage's backward streams first: its last block's operands)
         ctx.saved, ctx.meta, ctx.T = saved, meta, T
         ctx.out_hw = (H, W)
         return x
@@ -965,6 +967,10 @@ class StageFn(Function):
                 gp = ops.conv_dgrad(dt, ga, B, r['g1'], w1b, res=side, ldr=side.stride(0), **ep)
             else:
                 gp = None
-        rb.flush()
+        # the reduce launch that closes this stage touches the weights the stage BELOW streams first in its backward
+        st = ops.STAGE_BWD_STACK
+        if st and saved and saved[-1].get('fused') is not None and st[-1][0] is saved[-1]['fused'][0]:
+            st.pop()
+        rb.flush(prefetch=st[-1] if st else None)
         ctx.saved = None
         return (gp, None) + tuple(grads)

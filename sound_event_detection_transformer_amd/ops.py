@@ -692,6 +692,7 @@ def encoder_slab_ok(dtype, D, H, S, FF, amask, B=None):
 ENC_PREFETCH = _dev_env('SEDT_ENC_PREFETCH', '1') != '0'
 RED_PREFETCH = _dev_env('SEDT_RED_PREFETCH', '1') != '0'
 import collections as _collections
+STAGE_BWD_STACK = _collections.deque(maxlen=8)    # the same for the ResNet stages whose last block is a fused Bottleneck
 ENC_BWD_STACK = _collections.deque(maxlen=32)     # fragment-major backward weights of the slab encoder layers whose backward is still to come
 
 
