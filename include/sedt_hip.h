@@ -143,6 +143,16 @@ int sedt_wgrad_reduce(const float* slab, int splitk, int R, int taps, int Ci, co
 int sedt_wgrad_reduce_bias(const float* slab, int splitk, int R, int taps, int Ci, const float* rowscale, float* out,
                            const float* colsum_slab, float* bias_out, void* stream);
 
+/* A prefetch hint, passed BY THE LAUNCH THAT CONSUMES IT (the library keeps no pointers between calls): up to three regions (null /
+ * bytes 0 = none) that the launch AFTER this one will stream - fragment-major weights.  The launch touches one 128-byte line of them
+ * per load so that every XCD's L2 holds them when the streaming launch starts.  Taken by sedt_encoder_qkv_fwd (the weights of
+ * sedt_encoder_attn_ffn_fwd), sedt_bneck3_fwd / sedt_bneck3_bwd (the next block's operands) and sedt_multi_wgrad_reduce (what the next
+ * layer's backward streams first); `pf` may be null. */
+typedef struct SedtPrefetch {
+  const void* ptr[3];
+  size_t bytes[3];
+} SedtPrefetch;
+
 /* up to SEDT_MAX_REDUCE_JOBS split-K reductions in ONE launch (jobs are copied into the kernel arguments, so a captured
  * graph holds them by value).  `jobs` is a HOST array; fields as the arguments of sedt_wgrad_reduce_bias. */
 #define SEDT_MAX_REDUCE_JOBS 40
@@ -155,7 +165,7 @@ typedef struct SedtReduceJob {
   int32_t splitk, R, taps, Ci;
   int32_t blk0, pad_;     /* blk0 is filled by the library */
 } SedtReduceJob;
-int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, void* stream);
+int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, const SedtPrefetch* pf, void* stream);
 
 /* ------------------------------------------------------------------ linear layers with N <= 16 outputs (the SEDT heads,
  * sedt/sedt.py:36-38, 90-95, 398-409): direct kernels on the f32 MASTER weight w[N][K] (no packing).
@@ -352,13 +362,7 @@ int sedt_pack_frag(const SedtFragJob* jobs, int njobs, int nblocks, void* stream
  * the unfused chain: attention ((b*8 + h)*S + q)*S + k under seed_attn, out-proj row*256 + col under seed_o, hidden row*FF + col
  * under seed_h, FFN output row*256 + col under seed_f (each + *seed_ptr).  Envelope (sedt_encoder_slab_ok): bf16, d_model 256,
  * 8 heads, S <= 128, FF a multiple of 512. */
-/* Optional, before sedt_encoder_qkv_fwd (same thread): up to three regions (bytes 0 / null = none) the launch AFTER it will stream - the
- * fragment-major weights of sedt_encoder_attn_ffn_fwd.  The qkv launch then touches one 128-byte line of them per load so that every XCD's
- * L2 holds them when the streaming launch starts; consumed by that one call. */
-int sedt_encoder_qkv_prefetch(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2);
-/* The same before sedt_multi_wgrad_reduce: the reduce launch that closes a layer's backward touches the weights the next layer's backward
- * kernels will stream (sedt_encoder_ffn_bwd's). */
-int sedt_reduce_prefetch(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2);
+/* (SedtPrefetch: declared with sedt_multi_wgrad_reduce above) */
 int sedt_encoder_slab_ok(int D, int H, int S, int FF, int dtype);
 /* The input-gradient chain of the same layer, two launches around sedt_attention_bwd (weights as fragment-major W^T, the `wb` of
  * sedt_pack_frag):
@@ -428,15 +432,13 @@ int sedt_bneck_bwd(const void* gy, void* gx, const void* w3t_frag, const void* w
  * stay in LDS - a ~25 us floor set by the L2 -> CU stream, which beats the three per-op launches only while the strips cover the chip
  * about once: sedt_bneck3_ok additionally wants 192 <= B * ceil(H / 8) <= 512.  Arguments as for sedt_bneck_fwd / sedt_bneck_bwd (cin,
  * planes, W implied); abits / bbits [M][32], bits [M][128]. */
-/* Optional, before sedt_bneck3_fwd / sedt_bneck3_bwd (same thread): the three weight operands the NEXT such launch will stream (the next
- * block's); the launch touches them one 128-byte line per load so that they are L2-resident by then.  Consumed by that one call. */
-int sedt_bneck3_prefetch(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2);
 int sedt_bneck3_ok(int cin, int planes, int W, int stride, int dil, int has_downsample, int B, int H, int dtype);
 int sedt_bneck3_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const float* s1, const float* b1,
                     const float* s2, const float* b2, const float* s3, const float* b3, void* a_out, void* b_out, uint8_t* abits_out,
-                    uint8_t* bbits_out, uint8_t* bits_out, int B, int H, void* stream);
+                    uint8_t* bbits_out, uint8_t* bits_out, int B, int H, const SedtPrefetch* pf, void* stream);
 int sedt_bneck3_bwd(const void* gy, void* gx, const void* w3t_frag, const void* w2t_frag, const void* w1t_frag, const uint8_t* abits,
-                    const uint8_t* bbits, const uint8_t* xbits, void* gb_out, void* ga_out, int B, int H, void* stream);
+                    const uint8_t* bbits, const uint8_t* xbits, void* gb_out, void* ga_out, int B, int H, const SedtPrefetch* pf,
+                    void* stream);
 
 /* The first Bottleneck of layer1 (64 -> 64 -> 64 -> 256, 1x1 projection 64 -> 256 on the skip path, stride 1, map 16 columns wide) in ONE
  * forward launch (csrc/bneck.hip: bneck0_fwd_kernel): a = relu(s1 (x W1^T) + b1); b = relu(s2 conv3x3(a, W2) + b2);
@@ -508,7 +510,7 @@ int sedt_encoder_qkv_bwd(const void* dqk, const void* dv, const void* x, const f
                          void* stream);
 int sedt_encoder_qkv_fwd(const void* x, const void* pos, const float* gamma, const float* beta, const void* w_in_frag,
                          const float* b_in, void* qk, void* v, void* xn, void* xnp, float* mean, float* rstd, int B, int S,
-                         void* stream);
+                         const SedtPrefetch* pf, void* stream);
 int sedt_encoder_attn_ffn_fwd(const void* x, const void* qk, const void* v, const uint8_t* kpm, const void* w_o_frag,
                               const float* b_o, const float* gamma2, const float* beta2, const void* w1_frag, const float* b1,
                               const void* w2_frag, const float* b2, void* x2, void* ctx, float* lse, void* x1, float* mean2,

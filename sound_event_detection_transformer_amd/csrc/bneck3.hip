@@ -304,15 +304,11 @@ __global__ __launch_bounds__(512) void bneck3_kernel(const Bneck3Args a) {
   }
 }
 
-static thread_local const void* b3_pf_ptr[3] = {nullptr, nullptr, nullptr};
-static thread_local size_t b3_pf_bytes[3] = {0, 0, 0};
-
 template <bool BWD>
-static int bneck3_launch(Bneck3Args& a, hipStream_t s, const char* what) {
-  for (int r = 0; r < 3; ++r) {                                  // (one-shot: consumed by this launch)
-    a.pf[r] = (const uint32_t*)b3_pf_ptr[r];
-    a.pf_lines[r] = (int)(b3_pf_bytes[r] / 128);
-    b3_pf_ptr[r] = nullptr; b3_pf_bytes[r] = 0;
+static int bneck3_launch(Bneck3Args& a, const SedtPrefetch* pf, hipStream_t s, const char* what) {
+  for (int r = 0; r < 3; ++r) {                                  // the next block's operands: touched by this launch
+    a.pf[r] = pf ? (const uint32_t*)pf->ptr[r] : nullptr;
+    a.pf_lines[r] = (pf && pf->ptr[r]) ? (int)(pf->bytes[r] / 128) : 0;
   }
   constexpr size_t lds = BWD ? G3::TOTAL_B : G3::TOTAL_F;
   static_assert(lds <= 160 * 1024, "LDS");
@@ -343,16 +339,9 @@ extern "C" int sedt_bneck3_ok(int cin, int planes, int W, int stride, int dil, i
   return nst >= lo && nst <= 512;
 }
 
-// the weights the launch AFTER the next sedt_bneck3_fwd / sedt_bneck3_bwd will stream (the next block's operands): that launch touches them
-extern "C" int sedt_bneck3_prefetch(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2) {
-  b3_pf_ptr[0] = p0; b3_pf_ptr[1] = p1; b3_pf_ptr[2] = p2;
-  b3_pf_bytes[0] = p0 ? n0 : 0; b3_pf_bytes[1] = p1 ? n1 : 0; b3_pf_bytes[2] = p2 ? n2 : 0;
-  return 0;
-}
-
 extern "C" int sedt_bneck3_fwd(const void* x, void* y, const void* w1_frag, const void* w2_frag, const void* w3_frag, const float* s1,
                                const float* b1, const float* s2, const float* b2, const float* s3, const float* b3, void* a_out, void* b_out,
-                               uint8_t* abits_out, uint8_t* bbits_out, uint8_t* bits_out, int B, int H, void* stream) {
+                               uint8_t* abits_out, uint8_t* bbits_out, uint8_t* bits_out, int B, int H, const SedtPrefetch* pf, void* stream) {
   SEDT_REQUIRE(x && y && w1_frag && w2_frag && w3_frag && s1 && b1 && s2 && b2 && s3 && b3, "bneck3_fwd: null pointer");
   SEDT_REQUIRE(B >= 1 && H >= 1, "bneck3_fwd: B = %d, H = %d", B, H);
   SEDT_REQUIRE((a_out == nullptr) == (b_out == nullptr) && (abits_out == nullptr) == (bbits_out == nullptr),
@@ -363,11 +352,12 @@ extern "C" int sedt_bneck3_fwd(const void* x, void* y, const void* w1_frag, cons
   a.sA = s1; a.bA = b1; a.sB = s2; a.bB = b2; a.sC = s3; a.bC = b3;
   a.a_out = (bf16_t*)a_out; a.b_out = (bf16_t*)b_out; a.abits_out = abits_out; a.bbits_out = bbits_out; a.bits_out = bits_out;
   a.B = B; a.H = H;
-  return bneck3_launch<false>(a, reinterpret_cast<hipStream_t>(stream), "bneck3_fwd");
+  return bneck3_launch<false>(a, pf, reinterpret_cast<hipStream_t>(stream), "bneck3_fwd");
 }
 
 extern "C" int sedt_bneck3_bwd(const void* gy, void* gx, const void* w3t_frag, const void* w2t_frag, const void* w1t_frag, const uint8_t* abits,
-                               const uint8_t* bbits, const uint8_t* xbits, void* gb_out, void* ga_out, int B, int H, void* stream) {
+                               const uint8_t* bbits, const uint8_t* xbits, void* gb_out, void* ga_out, int B, int H, const SedtPrefetch* pf,
+                               void* stream) {
   SEDT_REQUIRE(gy && gx && w3t_frag && w2t_frag && w1t_frag && abits && bbits, "bneck3_bwd: null pointer");
   SEDT_REQUIRE(B >= 1 && H >= 1, "bneck3_bwd: B = %d, H = %d", B, H);
   SEDT_REQUIRE((gb_out == nullptr) == (ga_out == nullptr), "bneck3_bwd: the two intermediate gradients come both or not at all");
@@ -377,5 +367,5 @@ extern "C" int sedt_bneck3_bwd(const void* gy, void* gx, const void* w3t_frag, c
   a.abits_in = abits; a.bbits_in = bbits; a.bits_in = xbits;
   a.a_out = (bf16_t*)gb_out; a.b_out = (bf16_t*)ga_out;          // (stage 1 of the chain produces gb, stage 2 ga)
   a.B = B; a.H = H;
-  return bneck3_launch<true>(a, reinterpret_cast<hipStream_t>(stream), "bneck3_bwd");
+  return bneck3_launch<true>(a, pf, reinterpret_cast<hipStream_t>(stream), "bneck3_bwd");
 }

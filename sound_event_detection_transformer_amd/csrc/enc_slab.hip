@@ -838,29 +838,18 @@ extern "C" int sedt_encoder_slab_ok(int D, int H, int S, int FF, int dtype) {
   return dtype == SEDT_BF16 && D == ES_D && H == ES_H && S >= 1 && S <= ES_LK && FF >= 512 && FF % 512 == 0;
 }
 
-static thread_local const void* enc_pf_ptr[3] = {nullptr, nullptr, nullptr};
-static thread_local size_t enc_pf_bytes[3] = {0, 0, 0};
-
-// the weights the launch after the next sedt_encoder_qkv_fwd will stream (up to three regions; bytes 0 = none): that launch touches them
-extern "C" int sedt_encoder_qkv_prefetch(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2) {
-  enc_pf_ptr[0] = p0; enc_pf_ptr[1] = p1; enc_pf_ptr[2] = p2;
-  enc_pf_bytes[0] = p0 ? n0 : 0; enc_pf_bytes[1] = p1 ? n1 : 0; enc_pf_bytes[2] = p2 ? n2 : 0;
-  return 0;
-}
-
 extern "C" int sedt_encoder_qkv_fwd(const void* x, const void* pos, const float* gamma, const float* beta, const void* w_in_frag,
                                     const float* b_in, void* qk, void* v, void* xn, void* xnp, float* mean, float* rstd, int B, int S,
-                                    void* stream) {
+                                    const SedtPrefetch* pf, void* stream) {
   SEDT_REQUIRE(x && pos && gamma && beta && w_in_frag && b_in && qk && v, "encoder_qkv_fwd: null pointer");
   SEDT_REQUIRE(B >= 1 && S >= 1 && S <= ES_LK, "encoder_qkv_fwd: S = %d outside 1..%d", S, ES_LK);
   const bool train = xn != nullptr;
   SEDT_REQUIRE(!train || (xnp && mean && rstd), "encoder_qkv_fwd: the training by-products come all or none");
   EncQkvArgs a{(const bf16_t*)x, (const bf16_t*)pos, gamma, beta, (const u32x4*)w_in_frag, b_in, (bf16_t*)qk, (bf16_t*)v,
                (bf16_t*)xn, (bf16_t*)xnp, mean, rstd, B, S, {nullptr, nullptr, nullptr}, {0, 0, 0}};
-  for (int r = 0; r < 3; ++r) {                                  // (one-shot: consumed by this launch)
-    a.pf[r] = (const uint32_t*)enc_pf_ptr[r];
-    a.pf_lines[r] = (int)(enc_pf_bytes[r] / 128);
-    enc_pf_ptr[r] = nullptr; enc_pf_bytes[r] = 0;
+  for (int r = 0; r < 3 && pf; ++r) {                            // the weights the NEXT launch streams: touched by this one
+    a.pf[r] = (const uint32_t*)pf->ptr[r];
+    a.pf_lines[r] = pf->ptr[r] ? (int)(pf->bytes[r] / 128) : 0;
   }
   constexpr size_t lds = (size_t)(2 * 32 * XP + 32 * ES_QP) * sizeof(bf16_t);
   static bool attr = false;

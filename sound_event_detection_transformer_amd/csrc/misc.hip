@@ -36,7 +36,7 @@ static inline unsigned nblk(long n, int per = 256) { return (unsigned)((n + per 
 struct ReduceJobs {
   int n;
   SedtReduceJob j[SEDT_MAX_REDUCE_JOBS];
-  // what the NEXT launch streams (sedt_reduce_prefetch: the next encoder layer's backward weights): touched by the first 256 blocks, one
+  // what the NEXT launch streams (SedtPrefetch: the next encoder layer's backward weights): touched by the first 256 blocks, one
   // 128-byte line per load, so that every XCD's L2 holds them when that launch's workgroups stream them in lockstep
   const uint32_t* pf[3]; int pf_lines[3];
 };
@@ -961,7 +961,7 @@ extern "C" int sedt_version(void) { return 1; }
   else if ((dtype) == SEDT_BF16) { CALL_BF16; }                \
   else { set_error("unsupported dtype %d", (int)(dtype)); return 1; }
 
-extern "C" int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, void* stream);
+
 
 extern "C" int sedt_wgrad_reduce_bias(const float* slab, int splitk, int R, int taps, int Ci, const float* rowscale,
                                       float* out, const float* colsum_slab, float* bias_out, void* stream) {
@@ -970,7 +970,7 @@ extern "C" int sedt_wgrad_reduce_bias(const float* slab, int splitk, int R, int 
   SedtReduceJob j = {};
   j.slab = slab; j.out = out; j.rowscale = rowscale; j.colsum_slab = colsum_slab; j.bias_out = bias_out;
   j.splitk = splitk; j.R = R; j.taps = taps; j.Ci = Ci;
-  return sedt_multi_wgrad_reduce(&j, 1, stream);      // one job of the grouped kernel (vector / LDS-transposing paths)
+  return sedt_multi_wgrad_reduce(&j, 1, nullptr, stream);      // one job of the grouped kernel (vector / LDS-transposing paths)
 }
 
 extern "C" int sedt_wgrad_reduce(const float* slab, int splitk, int R, int taps, int Ci, const float* rowscale,
@@ -1263,24 +1263,13 @@ extern "C" int sedt_multi_pack(const SedtPackJob* jobs, int njobs, int nblocks, 
   return check_launch("multi_pack");
 }
 
-static thread_local const void* red_pf_ptr[3] = {nullptr, nullptr, nullptr};
-static thread_local size_t red_pf_bytes[3] = {0, 0, 0};
-
-// the weights the launch AFTER the next sedt_multi_wgrad_reduce will stream (up to three regions): that reduce launch touches them
-extern "C" int sedt_reduce_prefetch(const void* p0, size_t n0, const void* p1, size_t n1, const void* p2, size_t n2) {
-  red_pf_ptr[0] = p0; red_pf_ptr[1] = p1; red_pf_ptr[2] = p2;
-  red_pf_bytes[0] = p0 ? n0 : 0; red_pf_bytes[1] = p1 ? n1 : 0; red_pf_bytes[2] = p2 ? n2 : 0;
-  return 0;
-}
-
-extern "C" int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, void* stream) {
+extern "C" int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, const SedtPrefetch* pf, void* stream) {
   SEDT_REQUIRE(jobs && njobs > 0 && njobs <= SEDT_MAX_REDUCE_JOBS, "multi_wgrad_reduce: 1..%d jobs", SEDT_MAX_REDUCE_JOBS);
   ReduceJobs a;
   a.n = njobs;
-  for (int r = 0; r < 3; ++r) {                                  // (one-shot: consumed by this launch)
-    a.pf[r] = (const uint32_t*)red_pf_ptr[r];
-    a.pf_lines[r] = (int)(red_pf_bytes[r] / 128);
-    red_pf_ptr[r] = nullptr; red_pf_bytes[r] = 0;
+  for (int r = 0; r < 3; ++r) {                                  // what the NEXT launch streams: touched by this one
+    a.pf[r] = pf ? (const uint32_t*)pf->ptr[r] : nullptr;
+    a.pf_lines[r] = (pf && pf->ptr[r]) ? (int)(pf->bytes[r] / 128) : 0;
   }
   int blk = 0;
   for (int i = 0; i < njobs; ++i) {

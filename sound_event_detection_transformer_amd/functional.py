@@ -489,7 +489,11 @@ class EncoderLayerFn(Function):
                                  ctxv=ctxv, lse=lse, dims=(B, H, S, S), kpm=kpm, amask=None, p=p, seeds=seeds[0:2])
                 sv['ffn'] = dict(x_in=x1n, h=h, p=p, seeds=seeds[2:4], wb1=wb1, wb2=wb2)
                 sv.update(x=x, x1=x1, m1=m1, r1=r1, m2=m2, r2=r2, slab=(fr[0][1], fr[1][1], fr[2][1], fr[3][1]))
-                ops.ENC_BWD_STACK.append((fr[3][1], fr[2][1], fr[1][1]))      # (what this layer's backward streams first: W2^T, W1^T, Wo^T)
+                # the backward of the layer BELOW runs right after this layer's: its first operands get touched by this layer's closing
+                # reduce launch.  This layer leaves (W2^T, W1^T, Wo^T) - what its own backward streams first - for the layer above
+                chain = cfg.get('chain')
+                if chain is not None:
+                    sv['bwd_next'], chain.top = chain.top, (fr[3][1], fr[2][1], fr[1][1])
             ctx.sv, ctx.cfg, ctx.P = sv, cfg, P
             return x2
         if cfg['pre_norm'] and ops.FUSED_ENC and ops.encoder_attn_ok(dt, x.shape[1], H, S, amask) and x.is_contiguous() and pos.is_contiguous():
@@ -570,10 +574,7 @@ class EncoderLayerFn(Function):
             dgb1 = torch.empty((2 * E,), device=dev, dtype=torch.float32)
             rb.add_colsum(part1, part1.shape[0], 2 * E, dgb1)
             # the reduce launch that closes this layer touches the weights the NEXT layer's backward (the one below) streams first
-            st = ops.ENC_BWD_STACK
-            if st and st[-1][0] is w2t:
-                st.pop()
-            rb.flush(prefetch=st[-1] if st else None)
+            rb.flush(prefetch=sv.get('bwd_next'))
             ctx.sv = None
             return (gx, None, None, None, None, d_win, d_bin, d_wo, d_bo, d_w1, d_b1, d_w2, d_b2, dgb1[:E], dgb1[E:], dgb2[:E], dgb2[E:])
         if cfg['pre_norm']:
@@ -677,6 +678,8 @@ class DecoderLayerFn(Function):
             f, sv['ffn'] = _ffn_fwd(dt, t2, w1, b1, w2, b2, t2, p, seeds[4:6], tr)
             t3, _, m3, r3 = ops.layernorm_fwd(dt, f, g3, be3)
             sv.update(a=a, c=c, f=f, m1=m1, r1=r1, m2=m2, r2=r2, m3=m3, r3=r3)
+        if tr and cfg.get('chain') is not None and cfg.get('layer_idx', 0) == 0:
+            sv['bwd_next'] = cfg['chain'].top       # (the top encoder layer's backward operands: ops.BackwardChain)
         ctx.sv, ctx.cfg, ctx.P = sv, cfg, P
         return t3
 
@@ -733,8 +736,7 @@ class DecoderLayerFn(Function):
             g_qpos = ops.add(dt, g_qpos, g_qk)
         # the first decoder layer's backward is the last thing before the encoder's: its reduce launch touches the weights the top encoder
         # layer's backward streams first (only LayerNorm launches follow it)
-        st = ops.ENC_BWD_STACK
-        rb.flush(prefetch=st[-1] if (st and cfg.get('layer_idx', 0) == 0) else None)
+        rb.flush(prefetch=sv.get('bwd_next'))
         ctx.sv = None
         return (gtgt, g_mem, g_mem_pos, g_qpos, None, None, None,
                 d_swin, d_sbin, d_swo, d_sbo, d_cwin, d_cbin, d_cwo, d_cbo, d_w1, d_b1, d_w2, d_b2,
@@ -838,6 +840,12 @@ class StageFn(Function):
                     # a frozen block (layer1, backbone.py:60-62) keeps only the sign bits of its intermediates: the fused backward
                     # needs nothing else; a trainable one (layer2) keeps a and b as well, for its weight gradients
                     frozen = not (t[0].requires_grad or t[5].requires_grad or t[10].requires_grad)
+                    # the fused input-gradient chain needs the sign bits of the block input whenever that gradient is masked; without
+                    # them (RELU_BITS off) the backward is the per-op chain, which reads a and b: keep them then
+                    first_ = blk is blocks[0]
+                    mask_x_ = (not first_) or meta['mask_input']
+                    if mask_x_ and xbits is None:
+                        frozen = False
                     # (layer3: the launch also touches the NEXT block's operands, so that they are L2-resident when that block streams them)
                     nx = [packing.lookup_conv_frag(T[i + k]) for k in (0, 5, 10)] if (cin == 1024 and i + 15 <= len(T)) else None
                     nx = [c[0] for c in nx] if nx and all(c is not None for c in nx) else None
@@ -889,8 +897,12 @@ class StageFn(Function):
             x, H, W, xbits = y, g2.Ho, g2.Wo, ybits
         if meta.get('holder') is not None:
             meta['holder']['bits'] = xbits
-        if tr and saved and saved[-1].get('fused') is not None:
-            ops.STAGE_BWD_STACK.append(tuple(saved[-1]['fused'][:3]))      # (what this stage's backward streams first: its last block's operands)
+        ctx.bwd_next = None
+        chain = meta.get('chain')
+        if tr and chain is not None:
+            ctx.bwd_next = chain.top                    # (the stage below: its backward follows this stage's, ops.BackwardChain)
+            if saved and saved[-1].get('fused') is not None:
+                chain.top = tuple(saved[-1]['fused'][:3])      # what this stage's backward streams first: its last block's operands
         ctx.saved, ctx.meta, ctx.T = saved, meta, T
         ctx.out_hw = (H, W)
         return x
@@ -916,6 +928,9 @@ class StageFn(Function):
             w1b, w2b, w3b = r['wb']
             first = bi_ == 0
             want_gx = (not first) or need_x_grad
+            if not want_gx and not any(t[k].requires_grad for k in range(0, n, 5)):
+                gp = None               # a frozen first block whose input needs no gradient: nothing to compute (and a fused forward
+                continue                # kept no intermediates for the per-op code below)
             if r.get('chain') is not None and want_gx:
                 # layer1's block 0, frozen: gy -> gb -> ga in one launch (sign bits of b, a from the fused forward), then the input-gradient
                 # GEMMs of the projection and of conv1 (its residual operand); the stem's output needs no mask here (StemFn masks by its own
@@ -968,9 +983,6 @@ class StageFn(Function):
             else:
                 gp = None
         # the reduce launch that closes this stage touches the weights the stage BELOW streams first in its backward
-        st = ops.STAGE_BWD_STACK
-        if st and saved and saved[-1].get('fused') is not None and st[-1][0] is saved[-1]['fused'][0]:
-            st.pop()
-        rb.flush(prefetch=st[-1] if st else None)
+        rb.flush(prefetch=ctx.bwd_next)
         ctx.saved = None
         return (gp, None) + tuple(grads)

@@ -85,6 +85,21 @@ class SedtDecLayer(C.Structure):
                 ('pad_', C.c_int32), ('seed_ptr', C.c_void_p)]
 
 
+class SedtPrefetch(C.Structure):
+    _fields_ = [('ptr', C.c_void_p * 3), ('bytes', C.c_size_t * 3)]
+
+
+def prefetch_arg(tensors):
+    """a SedtPrefetch* for up to three tensors (None entries allowed) the launch AFTER the one given this hint will stream, or None"""
+    ts = [t for t in (tensors or ()) if t is not None][:3]
+    if not ts:
+        return None
+    a = SedtPrefetch()
+    for i, t in enumerate(ts):
+        a.ptr[i], a.bytes[i] = t.data_ptr(), t.numel() * t.element_size()
+    return C.byref(a)
+
+
 MAX_REDUCE_JOBS = 40
 _vp, _i, _i64, _f, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint32, C.c_size_t
 
@@ -100,7 +115,7 @@ SIGNATURES = {
     'sedt_igemm_describe': (_i, [C.POINTER(SedtIgemm), _i, _i, C.c_char_p, _i]),
     'sedt_wgrad_reduce': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sedt_wgrad_reduce_bias': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    'sedt_multi_wgrad_reduce': (_i, [C.POINTER(SedtReduceJob), _i, _vp]),
+    'sedt_multi_wgrad_reduce': (_i, [C.POINTER(SedtReduceJob), _i, C.POINTER(SedtPrefetch), _vp]),
     'sedt_skinny_linear_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     'sedt_skinny_linear_bwd_scratch': (_sz, [_i]),
     'sedt_skinny_linear_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -125,15 +140,12 @@ SIGNATURES = {
                                _vp, _i, _vp]),
     'sedt_pack_frag': (_i, [_vp, _i, _i, _vp]),
     'sedt_encoder_slab_ok': (_i, [_i, _i, _i, _i, _i]),
-    'sedt_encoder_qkv_fwd': (_i, [_vp] * 12 + [_i, _i, _vp]),
+    'sedt_encoder_qkv_fwd': (_i, [_vp] * 12 + [_i, _i, C.POINTER(SedtPrefetch), _vp]),
     'sedt_encoder_attn_ffn_fwd': (_i, [_vp] * 20 + [_i, _i, _i, _f, _u32, _u32, _u32, _u32, _vp, _vp]),
-    'sedt_encoder_qkv_prefetch': (_i, [_vp, _sz, _vp, _sz, _vp, _sz]),
-    'sedt_reduce_prefetch': (_i, [_vp, _sz, _vp, _sz, _vp, _sz]),
     'sedt_bneck_ok': (_i, [_i] * 7),
-    'sedt_bneck3_prefetch': (_i, [_vp, _sz, _vp, _sz, _vp, _sz]),
     'sedt_bneck3_ok': (_i, [_i] * 9),
-    'sedt_bneck3_fwd': (_i, [_vp] * 16 + [_i, _i, _vp]),
-    'sedt_bneck3_bwd': (_i, [_vp] * 10 + [_i, _i, _vp]),
+    'sedt_bneck3_fwd': (_i, [_vp] * 16 + [_i, _i, C.POINTER(SedtPrefetch), _vp]),
+    'sedt_bneck3_bwd': (_i, [_vp] * 10 + [_i, _i, C.POINTER(SedtPrefetch), _vp]),
     'sedt_bneck0_ok': (_i, [_i] * 7),
     'sedt_bneck2_ok': (_i, [_i] * 7),
     'sedt_bneck2_fwd': (_i, [_vp] * 17 + [_i, _i, _vp]),
@@ -214,9 +226,32 @@ def load():
     return lib
 
 
+LAUNCH_LOG = None     # a collections.Counter while a launch_log() scope is open: entry-point name -> launches that returned 0
+
+
+class launch_log(object):
+    """count the C-ABI launches issued inside the scope, by entry point (the name every ops.* wrapper passes to check()): the parity
+    tests assert with it WHICH kernel family a model-level run dispatched (tests/test_headline_parity_gpu.py), so a fill rule that
+    silently sends a test batch down another path cannot make a parity claim about kernels that never ran.
+    ``with lib.launch_log() as log: ...; log['encoder_qkv_fwd']``"""
+
+    def __enter__(self):
+        import collections
+        global LAUNCH_LOG
+        self.prev, LAUNCH_LOG = LAUNCH_LOG, collections.Counter()
+        return LAUNCH_LOG
+
+    def __exit__(self, *exc):
+        global LAUNCH_LOG
+        LAUNCH_LOG = self.prev
+        return False
+
+
 def check(status, what=''):
     if status != 0:
         raise RuntimeError(f'{what}: {load().sedt_last_error().decode()}')
+    if LAUNCH_LOG is not None:
+        LAUNCH_LOG[what] += 1
 
 
 def stream_ptr():

@@ -139,7 +139,7 @@ class WgradPool(object):
         while self.reduces:
             chunk, self.reduces = self.reduces[:L.MAX_REDUCE_JOBS], self.reduces[L.MAX_REDUCE_JOBS:]
             arr = (L.SedtReduceJob * len(chunk))(*chunk)
-            L.check(lib.sedt_multi_wgrad_reduce(arr, len(chunk), L.stream_ptr()), 'multi_wgrad_reduce')
+            L.check(lib.sedt_multi_wgrad_reduce(arr, len(chunk), None, L.stream_ptr()), 'multi_wgrad_reduce')
         self.keep = []
 
 
@@ -179,6 +179,10 @@ def igemm(dtype, M, N, K, A, lda, B, ldb, Cout, ldc, **kw):
         return
     if PROFILE is not None:     # the operand tensors are kept alive so that the launch can be replayed for timing
         PROFILE.append((a, L.gemm_dtype(dtype), (M, N, K, trans, 0 if conv is None else 1), (A, B, Cout, kw), PROFILE_HINT))
+    if L.LAUNCH_LOG is not None:     # (lib.launch_log(): also which kernel instance the dispatcher picks for this problem)
+        buf = C.create_string_buffer(160)
+        if L.load().sedt_igemm_describe(C.byref(a), L.gemm_dtype(dtype), 0, buf, 160) == 0:
+            L.LAUNCH_LOG['igemm:' + buf.value.decode().split('(')[0]] += 1
     L.check(L.load().sedt_igemm(C.byref(a), L.gemm_dtype(dtype), L.stream_ptr()), 'sedt_igemm')
 
 
@@ -381,10 +385,10 @@ class ReduceBatch(object):
         for i in range(0, len(self.jobs), L.MAX_REDUCE_JOBS):
             chunk = self.jobs[i:i + L.MAX_REDUCE_JOBS]
             arr = (L.SedtReduceJob * len(chunk))(*chunk)
+            pf = None
             if self.prefetch is not None and RED_PREFETCH and i + L.MAX_REDUCE_JOBS >= len(self.jobs):      # (the last launch of the batch)
-                pf = (list(self.prefetch) + [None] * 3)[:3]
-                L.load().sedt_reduce_prefetch(*[v_ for t_ in pf for v_ in (_p(t_), 0 if t_ is None else t_.numel() * t_.element_size())])
-            L.check(L.load().sedt_multi_wgrad_reduce(arr, len(chunk), L.stream_ptr()), 'multi_wgrad_reduce')
+                pf = L.prefetch_arg(self.prefetch)
+            L.check(L.load().sedt_multi_wgrad_reduce(arr, len(chunk), pf, L.stream_ptr()), 'multi_wgrad_reduce')
         self.jobs, self.keep = [], []
 
     prefetch = None
@@ -691,9 +695,19 @@ def encoder_slab_ok(dtype, D, H, S, FF, amask, B=None):
 
 ENC_PREFETCH = _dev_env('SEDT_ENC_PREFETCH', '1') != '0'
 RED_PREFETCH = _dev_env('SEDT_RED_PREFETCH', '1') != '0'
-import collections as _collections
-STAGE_BWD_STACK = _collections.deque(maxlen=8)    # the same for the ResNet stages whose last block is a fused Bottleneck
-ENC_BWD_STACK = _collections.deque(maxlen=32)     # fragment-major backward weights of the slab encoder layers whose backward is still to come
+
+
+class BackwardChain(object):
+    """what the backward that runs AFTER a node's own will stream first, handed from node to node while one forward is traced (backward
+    order is the reverse of forward order): a node's forward reads ``top`` - the operands of the node before it, whose backward follows
+    its own - keeps it on its autograd ctx, and leaves its own operands in ``top`` for the node after it.  The reduce launch that closes
+    the node's backward then touches those operands (SedtPrefetch) so that they are L2-resident when the next backward streams them.
+    One chain object per model forward (sedt.backbone.ResNet50Body.forward, sedt.transformer.Transformer.forward): no module- or
+    process-level state, nothing survives the forward that created it"""
+    __slots__ = ('top',)
+
+    def __init__(self):
+        self.top = None
 
 
 def encoder_qkv_fwd(x, pos, gamma, beta, w_in_frag, b_in, B, S, train=True, prefetch=None):
@@ -709,11 +723,10 @@ def encoder_qkv_fwd(x, pos, gamma, beta, w_in_frag, b_in, B, S, train=True, pref
         by = (torch.empty_like(x), torch.empty_like(x), torch.empty((M,), device=x.device, dtype=torch.float32),
               torch.empty((M,), device=x.device, dtype=torch.float32))
     s = by if by is not None else (None,) * 4
-    if prefetch and ENC_PREFETCH:             # the next launch's weights: touched by this one so that they are L2-resident when it streams them
-        pf = (list(prefetch) + [None] * 3)[:3]
-        L.load().sedt_encoder_qkv_prefetch(*[v_ for t_ in pf for v_ in (_p(t_), 0 if t_ is None else t_.numel() * t_.element_size())])
+    # the next launch's weights: touched by this one so that they are L2-resident when it streams them
+    pf = L.prefetch_arg(prefetch) if (prefetch and ENC_PREFETCH) else None
     L.check(L.load().sedt_encoder_qkv_fwd(_p(x), _p(pos), _p(gamma), _p(beta), _p(w_in_frag), _p(b_in), _p(qk), _p(v), _p(s[0]), _p(s[1]),
-                                          _p(s[2]), _p(s[3]), B, S, L.stream_ptr()), 'encoder_qkv_fwd')
+                                          _p(s[2]), _p(s[3]), B, S, pf, L.stream_ptr()), 'encoder_qkv_fwd')
     return qk, v, by
 
 
@@ -758,8 +771,7 @@ BNECK_PREFETCH = _dev_env('SEDT_BNECK_PREFETCH', '1') != '0'
 
 
 def _bneck3_prefetch(nxt):
-    if nxt is not None and BNECK_PREFETCH:
-        L.load().sedt_bneck3_prefetch(*[v_ for t_ in nxt for v_ in (_p(t_), t_.numel() * t_.element_size())])
+    return L.prefetch_arg(nxt) if (nxt is not None and BNECK_PREFETCH) else None
 
 
 def bneck_fwd(x, B, H, W, wf, sb, train=True, want_bits=True, want_ab=False, nxt=None):
@@ -787,9 +799,9 @@ def bneck_fwd(x, B, H, W, wf, sb, train=True, want_bits=True, want_ab=False, nxt
                               M * (2.0 * C * 2 + (C // 8 if bits is not None else 0) + (2 * (P // 8) if abits is not None else 0)
                                    + (2 * P * 2 if a is not None else 0)) + 2.0 * (2 * C * P + 9 * P * P)))
     if C == 1024:
-        _bneck3_prefetch(nxt)                  # (the next block's three operands: touched by this launch, L2-resident for the next)
+        # (nxt = the next block's three operands: touched by this launch, L2-resident for the next)
         L.check(L.load().sedt_bneck3_fwd(_p(x), _p(y), _p(wf[0]), _p(wf[1]), _p(wf[2]), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3), _p(a),
-                                         _p(b), _p(abits), _p(bbits), _p(bits), B, H, L.stream_ptr()), 'bneck3_fwd')
+                                         _p(b), _p(abits), _p(bbits), _p(bits), B, H, _bneck3_prefetch(nxt), L.stream_ptr()), 'bneck3_fwd')
     else:
         L.check(L.load().sedt_bneck_fwd(_p(x), _p(y), _p(wf[0]), _p(wf[1]), _p(wf[2]), _p(s1), _p(b1), _p(s2), _p(b2), _p(s3), _p(b3), _p(a),
                                         _p(b), _p(abits), _p(bbits), _p(bits), C, P, W, B, H, L.stream_ptr()), 'bneck_fwd')
@@ -817,9 +829,8 @@ def bneck_bwd(gy, B, H, W, wt, abits, bbits, xbits, want_g=False, chain_only=Fal
                               + 2.0 * (2 * C * P_ + 9 * P_ * P_)))
     if C == 1024:
         assert not chain_only
-        _bneck3_prefetch(nxt)
         L.check(L.load().sedt_bneck3_bwd(_p(gy), _p(gx), _p(wt[2]), _p(wt[1]), _p(wt[0]), _p(abits), _p(bbits), _p(xbits), _p(gb), _p(ga), B, H,
-                                         L.stream_ptr()), 'bneck3_bwd')
+                                         _bneck3_prefetch(nxt), L.stream_ptr()), 'bneck3_bwd')
         return gx, gb, ga
     L.check(L.load().sedt_bneck_bwd(_p(gy), _p(gx), _p(wt[2]), _p(wt[1]), None if chain_only else _p(wt[0]), _p(abits), _p(bbits),
                                     None if chain_only else _p(xbits), _p(gb), _p(ga), C, C // 4, W, B, H, L.stream_ptr()), 'bneck_bwd')

@@ -249,9 +249,6 @@ class PlanSet(object):
         self._cur = self.current()
         self._cur.run(self._key3)
         _active.append(self._cur)
-        from . import ops
-        ops.ENC_BWD_STACK.clear()             # (a model forward starts: no encoder backward of an earlier forward is pending any more)
-        ops.STAGE_BWD_STACK.clear()
         return self._cur
 
     def __exit__(self, *a):

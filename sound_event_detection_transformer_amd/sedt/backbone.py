@@ -104,13 +104,15 @@ class ResNet50Body(nn.Module):
         H, W = (T - 1) // 2 + 1, (Fq - 1) // 2 + 1            # conv1 7x7 s2 p3
         H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1              # maxpool 3x3 s2 p1
         bits = None                                           # sign bits of the running stage output (functional.StageFn)
+        chain = ops.BackwardChain()                           # (a stage's closing reduce launch touches what the stage below streams first)
         for li, layer in enumerate((self.layer1, self.layer2, self.layer3, self.layer4)):
             blocks = [b.cfg for b in layer]
             # consumers of a stage output (the next stage, or SEDT.input_proj) return gradients already masked by the
             # stage's final ReLU, so the stage backward need not mask again (premasked=False -> standalone use)
             holder = {}
             meta = dict(dt=dt, B=B, H=H, W=W, blocks=blocks, mask_input=li > 0,
-                        grad_premasked=True if li < 3 else (premasked or self.premasked_consumer), x_bits=bits, holder=holder)
+                        grad_premasked=True if li < 3 else (premasked or self.premasked_consumer), x_bits=bits, holder=holder,
+                        chain=chain)
             ts = [t for b in layer for t in b.tensors()]
             tok = Fn.StageFn.apply(tok, meta, *ts)
             bits = holder.get('bits')

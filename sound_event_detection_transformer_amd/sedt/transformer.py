@@ -45,9 +45,10 @@ class TransformerEncoderLayer(nn.Module):
                 self.linear1.bias, self.linear2.weight, self.linear2.bias, self.norm1.weight, self.norm1.bias,
                 self.norm2.weight, self.norm2.bias)
 
-    def forward_tokens(self, x, pos, kpm, B, S, src_mask=None):
+    def forward_tokens(self, x, pos, kpm, B, S, src_mask=None, chain=None):
+        """chain (ops.BackwardChain or None): links this layer's backward to the one that runs after it (weight prefetch hints)"""
         cfg = dict(dt=runtime.compute_dtype(), B=B, S=S, H=self.nhead, dropout=self.p, training=self.training,
-                   pre_norm=self.normalize_before)
+                   pre_norm=self.normalize_before, chain=chain)
         return Fn.EncoderLayerFn.apply(x, pos, kpm, src_mask, cfg, *self.params())
 
     def forward(self, src, src_mask: Optional[Tensor] = None, src_key_padding_mask: Optional[Tensor] = None,
@@ -87,13 +88,13 @@ class TransformerDecoderLayer(nn.Module):
                 self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.norm3.weight, self.norm3.bias)
 
     def forward_tokens(self, tgt, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask=None, kv_fused=False, out=None, acc=None, share=None,
-                       layer_idx=0):
+                       layer_idx=0, chain=None):
         """kv_fused: mem_pos is mem + a constant (the decoder's own sine position add): the key and value input gradients
         of the cross-attention are returned as ONE tensor on `mem` (one K = 2E GEMM) and nothing on `mem_pos`.
         acc: (GradAccumulator for mem, GradAccumulator for qpos) shared by the layers of one decoder pass, or None"""
         cfg = dict(kv_fused=kv_fused, dt=runtime.compute_dtype(), B=B, S=S, Q=Q, H=self.nhead, dropout=self.p, training=self.training,
                    pre_norm=self.normalize_before, out=out, acc_mem=None if acc is None else acc[0],
-                   acc_qpos=None if acc is None else acc[1], share=share, layer_idx=layer_idx)
+                   acc_qpos=None if acc is None else acc[1], share=share, layer_idx=layer_idx, chain=chain)
         return Fn.DecoderLayerFn.apply(tgt, mem, mem_pos, qpos, kpm, tgt_mask, cfg, *self.params())
 
 
@@ -108,9 +109,9 @@ class TransformerEncoder(nn.Module):
         self.num_layers = num_layers
         self.norm = norm
 
-    def forward_tokens(self, x, pos, kpm, B, S):
+    def forward_tokens(self, x, pos, kpm, B, S, chain=None):
         for layer in self.layers:
-            x = layer.forward_tokens(x, pos, kpm, B, S)
+            x = layer.forward_tokens(x, pos, kpm, B, S, chain=chain)
         if self.norm is not None:
             x = Fn.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, runtime.compute_dtype())
         return x
@@ -124,7 +125,7 @@ class TransformerDecoder(nn.Module):
         self.norm = norm
         self.return_intermediate = return_intermediate
 
-    def forward_tokens(self, tgt, mem, pos, qpos, kpm, B, S, Q, tgt_mask=None):
+    def forward_tokens(self, tgt, mem, pos, qpos, kpm, B, S, Q, tgt_mask=None, chain=None):
         """returns (L, B, Q, d): the shared LayerNorm applied to every layer's output (transformer.py:134-147)"""
         dt = runtime.compute_dtype()
         mem_pos = Fn.AddFn.apply(mem, pos, 0, dt)              # key input of every cross-attention
@@ -143,7 +144,8 @@ class TransformerDecoder(nn.Module):
         share = {} if (stack is not None and acc is not None) else None      # (see functional.StackViewFn)
         for li, layer in enumerate(self.layers):
             out = layer.forward_tokens(out, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask, kv_fused=not pos.requires_grad,
-                                       out=None if stack is None else stack[li * R:(li + 1) * R], acc=acc, share=share, layer_idx=li)
+                                       out=None if stack is None else stack[li * R:(li + 1) * R], acc=acc, share=share, layer_idx=li,
+                                       chain=chain)
             outs.append(out)
         if self.return_intermediate:
             stacked = Fn.StackViewFn.apply(stack, share, *outs) if stack is not None else (torch.cat(outs) if n > 1 else outs[0])
@@ -210,12 +212,14 @@ class Transformer(nn.Module):
             qpos = Fn.BroadcastRowsFn.apply(query_embed, tgt, B, dt)        # (Q,C) -> [B*Q, C] in the compute dtype, one launch
         if tgt is None:
             tgt = self._zero_tokens(B * Q, C, src.device)
-        memory = self.encoder.forward_tokens(x, pos, kpm, B, S)
+        from .. import ops
+        chain = ops.BackwardChain()          # (a layer's closing reduce launch touches what the layer below streams first in its backward)
+        memory = self.encoder.forward_tokens(x, pos, kpm, B, S, chain=chain)
         # the encoder output as a token matrix, kept on request: engine's data-parallel steppers cut the backward here (gradients of
         # decoder + heads are all-reduced while the encoder's backward runs)
         self.cut_memory = memory if getattr(self, 'keep_cut', False) else None
         tmask = decoder_mask.float().contiguous() if (self.self_sup and decoder_mask is not None) else None
-        hs = self.decoder.forward_tokens(tgt, memory, pos, qpos, kpm, B, S, Q, tmask)
+        hs = self.decoder.forward_tokens(tgt, memory, pos, qpos, kpm, B, S, Q, tmask, chain=chain)
         if self.self_sup:
             return hs, memory.view(B, H, W, C).permute(0, 3, 1, 2)
         return hs, memory.view(B, S, C)

@@ -72,7 +72,7 @@ def _run(layer, plan, x, B, H, fused, gy=None, mask_input=False, W=16):
         ops.FUSED_BNECK = keep
 
 
-@pytest.mark.parametrize('B,H', [(2, 125), (3, 13), (1, 8), (2, 1), (1, 32)])
+@pytest.mark.parametrize('B,H', [(2, 125), (3, 13), (1, 8), (2, 1), (1, 32), (40, 125), (50, 125)])
 def test_fused_bottleneck_matches_the_per_op_chain(B, H):
     from sound_event_detection_transformer_amd import ops
     layer, plan = _stage(5)
@@ -99,7 +99,7 @@ def test_fused_bottleneck_matches_the_per_op_chain(B, H):
     assert layer[2].conv2.weight.grad is not None
 
 
-@pytest.mark.parametrize('B,H', [(2, 125), (3, 13), (1, 17)])
+@pytest.mark.parametrize('B,H', [(2, 125), (3, 13), (1, 17), (70, 125)])
 def test_fused_layer2_bottlenecks_match_the_per_op_chain(B, H):
     """layer2 trains: the fused forward keeps a and b, the fused input-gradient chain hands the two intermediate gradients to the
     weight-gradient GEMMs.  Block 0 (stride 2, downsample) stays per-op; the map behind it is ceil(H / 2) x 8"""
@@ -124,8 +124,14 @@ def test_fused_layer2_bottlenecks_match_the_per_op_chain(B, H):
         assert rel(w1[n_], w0[n_]) < 6e-2, n_
 
 
-@pytest.mark.parametrize('which', [1, 2, 3])
-def test_fused_bottleneck_kernels_against_torch(which):
+# (which, B, H).  The small cases run ONE strip per workgroup (spw = ceil(B * ceil(H / 8) / 256) = 1); the production strip walk - a
+# workgroup takes spw consecutive strips, prefetching strip s + 1's tile while strip s computes, rotating the weight chunks across
+# strips and crossing clip boundaries - needs more than 256 strips: C2 runs layer1 at spw = 4 (B = 64, 16 strips per clip), C4 at
+# spw = 13 (B = 200), which does not divide the strips of a clip.  (1, 40, 125): 640 strips, spw 3 (16 per clip); (1, 70, 125): 1120,
+# spw 5; (2, 70, 63): 560 strips of layer2's 63 x 8 map, spw 3 (8 per clip); (2, 100, 63): 800, spw 4; (1, 200, 13): spw 2 with 2 strips
+# per clip, the second one partial (13 = 8 + 5 rows)
+@pytest.mark.parametrize('which,B,H', [(1, 2, 19), (2, 2, 19), (3, 2, 19), (1, 40, 125), (1, 70, 125), (2, 70, 63), (2, 100, 63), (1, 200, 13)])
+def test_fused_bottleneck_kernels_against_torch(which, B, H):
     """the two entry points on their own against an f32 torch restatement of the block (conv / FrozenBN affine / ReLU), operands and the
     two intermediates rounded to bf16 as the kernels do; the masks of the input-gradient chain are the kernel's own sign bits"""
     import torch.nn.functional as F
@@ -133,7 +139,6 @@ def test_fused_bottleneck_kernels_against_torch(which):
     layer, plan = _stage(11, which)
     blk = layer[2]
     W, C, P = {1: (16, 256, 64), 2: (8, 512, 128), 3: (4, 1024, 256)}[which]
-    B, H = 2, 19
     g = torch.Generator().manual_seed(1)
     x = (0.5 * torch.randn(B * H * W, C, generator=g)).cuda().bfloat16().relu()
     gy = torch.randn(B * H * W, C, generator=g).cuda().bfloat16()
@@ -182,14 +187,14 @@ def test_fused_bottleneck_kernels_against_torch(which):
     assert rel(gb, tok(GB)) < 1e-2 and rel(ga, tok(GA)) < 1e-2 and rel(gx, tok(GX)) < 1e-2
 
 
-def test_fused_first_block_forward_against_torch():
+@pytest.mark.parametrize('B,H', [(3, 21), (40, 125), (70, 125)])
+def test_fused_first_block_forward_against_torch(B, H):
     """layer1's block 0 (projection skip) in one forward launch against the f32 torch restatement; the skip path is rounded to bf16 before
-    the sum, as the per-op chain stores it"""
+    the sum, as the per-op chain stores it.  (40, 125) / (70, 125): 3 / 5 consecutive strips per workgroup (see the note above)"""
     import torch.nn.functional as F
     from sound_event_detection_transformer_amd import ops, packing
     layer, plan = _stage(13, 1)
     blk = layer[0]
-    B, H = 3, 21
     g = torch.Generator().manual_seed(2)
     x = (0.7 * torch.randn(B * H * 16, 64, generator=g)).cuda().bfloat16().relu()
     ws = (blk.conv1.weight, blk.conv2.weight, blk.conv3.weight, blk.downsample[0].weight)
@@ -226,10 +231,11 @@ def test_fused_first_block_forward_against_torch():
     assert rel(a, tok(A)) < 1e-2 and rel(b, tok(Bt)) < 1e-2 and rel(y, tok(Y)) < 1e-2
 
 
-@pytest.mark.parametrize('B,H', [(2, 125), (3, 21), (1, 8), (2, 1), (1, 32)])
+@pytest.mark.parametrize('B,H', [(2, 125), (3, 21), (1, 8), (2, 1), (1, 32), (40, 125), (70, 125)])
 def test_fused_layer2_first_block_forward_against_torch(B, H):
     """layer2's block 0 (3x3 stride 2, stride-2 projection skip) in one forward launch against the f32 torch restatement: odd and even input
-    heights (the last output row then reads a zero row below the image), fewer output rows than a strip"""
+    heights (the last output row then reads a zero row below the image), fewer output rows than a strip; (40, 125) / (70, 125): 640 / 1120
+    strips of 4 output rows = 3 / 5 consecutive strips per workgroup, 16 strips per clip"""
     import torch.nn.functional as F
     from sound_event_detection_transformer_amd import ops, packing
     layer, plan = _stage(17, 2)
