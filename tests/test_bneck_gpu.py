@@ -15,6 +15,11 @@ def rel(got, ref):
     return ((got - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
 
 
+def cos(a, b):
+    a, b = a.detach().double().flatten(), b.detach().double().flatten()
+    return float((a * b).sum() / (a.norm() * b.norm() + 1e-300))
+
+
 def _stage(seed, which=1):
     """layer1 (frozen) or layer2 (trainable) of the backbone with seeded weights and non-trivial FrozenBN statistics, and the pack plan of
     its convolutions"""
@@ -83,7 +88,10 @@ def test_fused_bottleneck_matches_the_per_op_chain(B, H):
     y1, gx1, bits1 = _run(layer, plan, x, B, H, True, gy)
     y0, gx0, bits0 = _run(layer, plan, x, B, H, False, gy)
     assert rel(y1, y0) < 2e-2
-    assert rel(gx1, gx0) < 2e-2
+    # the two runs round a and b independently: a ReLU mask bit flips where a pre-activation is within rounding of zero, and a flipped
+    # unit moves its whole term.  Over 80 k+ pixels the max-norm then finds such an element (observed 4.6e-2 at B = 40, 8e-3 at B = 2);
+    # the direction is the check that scales - and the kernel-level test below, where both sides use the SAME masks, holds 1e-2
+    assert rel(gx1, gx0) < (2e-2 if B * H < 1000 else 8e-2) and cos(gx1, gx0) > 0.9995
     # the sign bits are those of the y this path wrote: bit c % 8 of byte c / 8
     want = (y1.float() > 0).view(-1, 32, 8).to(torch.uint8)
     packed = (want << torch.arange(8, device='cuda', dtype=torch.uint8)).sum(-1).to(torch.uint8)
@@ -95,7 +103,7 @@ def test_fused_bottleneck_matches_the_per_op_chain(B, H):
     for p in layer[2].parameters():
         p.requires_grad_(True)
     y3, gx3, _ = _run(layer, plan, x, B, H, True, gy)
-    assert torch.equal(y3, y1) and rel(gx3, gx0) < 2e-2
+    assert torch.equal(y3, y1) and rel(gx3, gx0) < (2e-2 if B * H < 1000 else 8e-2) and cos(gx3, gx0) > 0.9995
     assert layer[2].conv2.weight.grad is not None
 
 
@@ -119,9 +127,9 @@ def test_fused_layer2_bottlenecks_match_the_per_op_chain(B, H):
     # the two runs round their intermediates independently, so a ReLU mask bit flips where a pre-activation is within rounding of zero
     # (~1e-3 of the elements): a whole term of an input-gradient / weight-gradient sum that has only ~1e3 terms here.  6e-2 covers that
     # (observed 3.3e-2 / 2.6e-2); the kernel-level tests below, where both sides use the SAME masks, hold 1e-2
-    assert rel(gx1, gx0) < 6e-2
+    assert rel(gx1, gx0) < (6e-2 if B * H < 1000 else 1e-1) and cos(gx1, gx0) > 0.999
     for n_ in w0:
-        assert rel(w1[n_], w0[n_]) < 6e-2, n_
+        assert rel(w1[n_], w0[n_]) < 6e-2 and cos(w1[n_], w0[n_]) > 0.999, n_
 
 
 # (which, B, H).  The small cases run ONE strip per workgroup (spw = ceil(B * ceil(H / 8) / 256) = 1); the production strip walk - a
