@@ -41,6 +41,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--settle', type=int, default=100,
+                    help='captured steps only: un-timed replays right after the capture, before --warmup (the first replays run slow)')
     ap.add_argument('--config', default='c2', choices=['c2', 'c3', 'c4', 'c5', 'eval'],
                     help="BASELINE.json configuration (default c2 = the headline metric); 'eval' = the validation body of "
                          "engine.get_sedt_predictions at the C2 shape (an extra, not a BASELINE metric)")
@@ -875,15 +877,25 @@ def other_configs(args, dev, keep_alive, replays=10):
     return res
 
 
-def pmc_traffic(config):
-    """HBM-side bytes per step from the committed PMC profile of this config (profiles/rNN_pmc_<config>.json, newest round), or None"""
-    for rnd in ('r04', 'r03', 'r02'):
+def pmc_traffic(config, stamp, kernels_per_step):
+    """(profile dict or None, reason or None): HBM-side bytes per step from the committed PMC profile of this config (newest
+    profiles/rNN_pmc_<config>.json) - but only when that profile was taken ON THIS BUILD: its `build_stamp` must equal the running
+    sources' stamp (_build.source_stamp) and, when the per-family trace of this run is available, its kernel count per step must
+    equal the running step's.  A stale profile yields (None, why)"""
+    for rnd in ('r05', 'r04', 'r03', 'r02'):
+        path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_{config}.json')
         try:
-            with open(os.path.join(ROOT, 'profiles', f'{rnd}_pmc_{config}.json')) as f:
-                return json.load(f)
+            with open(path) as f:
+                prof = json.load(f)
         except Exception:
             continue
-    return None
+        name = os.path.relpath(path, ROOT)
+        if prof.get('build_stamp') != stamp:
+            return None, f"{name} was taken on build {prof.get('build_stamp', '(unstamped)')}, this is build {stamp}"
+        if kernels_per_step is not None and abs(prof.get('kernels_per_step', -1) - kernels_per_step) > 4:     # (the in-process trace also counts a few copies)
+            return None, f"{name} holds {prof.get('kernels_per_step')} kernels per step, this run launches {kernels_per_step:g}"
+        return prof, None
+    return None, 'no PMC profile of this configuration under profiles/'
 
 
 def main():
@@ -918,6 +930,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # the first replays after a capture run a few percent slow (clocks, caches, the allocator's first touches): a stated number of
+    # un-timed settle replays BEFORE the --warmup / --steps the caller asked for, so that a short timed region (the driver's
+    # --steps 20 --warmup 5) reads the same steady state as a long one
+    settle = args.settle if graphed else 0
+    for _ in range(settle):
+        step()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -1040,7 +1058,12 @@ def main():
     if rank == 0:
         peak = MFMA_PEAK[args.dtype]
         ach = flop_step / (dev_ms * 1e-3)
-        traffic = pmc_traffic(args.config)
+        from sound_event_detection_transformer_amd import _build
+        stamp = _build.source_stamp()
+        kps = None
+        if fam and fam.get('families'):
+            kps = round(sum(r['launches'] for r in fam['families']), 1)
+        traffic, traffic_why = pmc_traffic(args.config, stamp, kps)
         dom = None
         if fam and fam.get('families'):
             dom = next((r for r in fam['families'] if 'frac' in r), None)
@@ -1050,7 +1073,7 @@ def main():
                                                           "; see gemm_family and kernels"),
                 "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                 "traffic": None if traffic is None else traffic.get('hbm_bytes_per_step'),
-                "traffic_source": None if traffic is None else traffic.get('source'),
+                "traffic_source": traffic_why if traffic is None else traffic.get('source'),
                 "algorithmic_flop_per_launch": flop_step, "launch": "one step = one replay of the step's HIP graph(s)",
                 "avg_launch_ms_hip_events": round(dev_ms, 4), "gemm_family": gemm}
         if fam is not None:
@@ -1078,7 +1101,7 @@ def main():
                "config": {"workload": what, "name": args.config, "global_batch": world * clips, "parallelism": f"dp{world}"},
                "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "hip_graph": graphed,
                "rccl_world": rccl_world, "ms_per_step_per_rank": [round(v / args.steps * 1e3, 3) for v in per_rank],
-               "exposed_comm": exposed}
+               "exposed_comm": exposed, "settle_replays": settle, "build_stamp": stamp, "kernels_per_step": kps}
         if others is not None:
             out["other_configs"] = others
         if ex.get('graph_fallback'):

@@ -22,6 +22,25 @@ if os.environ.get('SEDT_DEV_BUILD') == '1':
     OBJ = os.path.join(HERE, '..', 'build', 'dev', 'obj')
 
 
+def source_stamp():
+    """sha256 (16 hex digits) over everything that decides which kernels a step launches and what they do: csrc/*, the C-ABI header and
+    the package's Python sources.  bench.py prints it (`build_stamp`); tools/pmc_step_summary.py writes it into profiles/rNN_pmc_*.json,
+    and bench.py reports the profile's HBM traffic only while the stamps agree (a stale profile gives `traffic: null` + the reason)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.hip', '.h', '.cpp'))]
+    files.append(os.path.join(HERE, '..', 'include', 'sedt_hip.h'))
+    for d, _, fs in sorted(os.walk(HERE)):
+        if '__pycache__' in d or os.sep + 'csrc' in d:
+            continue
+        files += [os.path.join(d, f) for f in sorted(fs) if f.endswith('.py')]
+    for f in files:
+        h.update(os.path.relpath(f, HERE).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _headers():
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     return hs + [os.path.join(HERE, '..', 'include', 'sedt_hip.h'), os.path.abspath(__file__)]

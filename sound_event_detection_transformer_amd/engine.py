@@ -395,6 +395,12 @@ class GraphedTrainStep(_GraphedBase):
         # flat mode: gradients go through ONE flat buffer and the optimizer is its own graph (data parallel: the all-reduce sits
         # in between; accumulation: micro-batches add into the buffer and only every accum_steps-th call runs the optimizer)
         self.flat_mode = self.dp or self.accum_steps > 1
+        if self.mix and mask_weak is None and self.flat_mode:
+            # without a weak mask mixup_data DROPS clips on some draws (a merged pair without events, the unlabelled remainder:
+            # utilities/mixup.py:104-122): such a batch cannot go through the captured schedule, and bailing out of it on ONE rank
+            # in the middle of an epoch would leave the other ranks waiting in the collective.  Refused up front
+            raise ValueError('mix-up under the data-parallel / accumulation schedule needs mask_weak (an empty slice(B, B) will do): '
+                             'mixup_data then keeps the batch size on every draw')
         self.grad_dtype = grad_dtype
         self._plan_segments(net, optimizer, dp_cuts if (self.dp and overlap_allreduce and device_matching) else 'none')
         dev = example_input.device

@@ -387,6 +387,30 @@ def test_graphed_train_step_takes_the_eager_step_when_mixup_shrinks_the_batch(pk
         assert rel(res['graph'][1][k], res['eager'][1][k]) < 2e-3, k
 
 
+def test_mixup_without_a_weak_mask_is_refused_under_the_flat_gradient_schedule(pkg):
+    """a batch that mix-up shrinks cannot bypass the captured data-parallel / accumulation schedule, and finding that out on one rank
+    in the middle of an epoch would hang the others in the collective: the combination is refused at construction; an empty
+    weak mask makes mixup_data keep the batch size, and that construction goes through"""
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import GraphedTrainStep
+    runtime.set_compute_dtype('bf16')
+    try:
+        B = 4
+        x = torch.randn(B, 1, 496, 64, generator=torch.Generator().manual_seed(1)).cuda()
+        tg = GI.sparse_targets(B, 2)
+        model, crit, opt = _sup_model(sedt, 2026)
+        with pytest.raises(ValueError, match='mask_weak'):
+            GraphedTrainStep(model, crit, opt, x, tg, None, slice(B), mix_up_ratio=0.6, accum_steps=2, warmup=1)
+        stepper = GraphedTrainStep(model, crit, opt, x, tg, slice(B, B), slice(B), mix_up_ratio=0.6, accum_steps=2, warmup=1)
+        np.random.seed(3)
+        for _ in range(2):
+            stepper(x, tg)
+        torch.cuda.synchronize()
+        assert int(stepper.nonfinite.item()) == 0
+    finally:
+        runtime.set_compute_dtype('f32')
+
+
 def test_c5_full_size_semi_step_with_mixup_properties(pkg):
     """BASELINE config C5 as its recipe runs it (train_ss_sedt.py --mix_up_ratio 0.6 --freq_mask --time_mask): 16 synthetic + 16 weak
     + 32 unlabelled clips, E=6, Q=20, bf16, dropout on.  Per step BOTH views are produced on the device from raw mel amplitudes by
