@@ -690,17 +690,6 @@ def kernel_report(dtype, dev):
     t = timeit(block)
     mf("encoder self-attn block fwd (LN1 + pos -> QKV -> attention -> out-proj + dropout + residual)", 83.9e6 * B, t,
        "4 launches (LayerNorm, grouped QK|V projection, attention core, out-proj); north_star target >= 0.60")
-    if ops.encoder_attn_ok(dt, E, H, S, None):
-        def fused(train):
-            ctx, _, _ = ops.encoder_attn_fwd(dt, x, pos, gam, bet, w_in, b_in, B, S, H, None, 0.1, 7, None, train=train)
-            return ops.linear(dt, ctx, w_o, bias=b_o, drop_p=0.1, seed=3, res=x, ldr=x.stride(0))
-        t = timeit(lambda: fused(True))
-        mf("encoder self-attn block fwd, FUSED head (LN1+QKV+attention in one launch, by-products for backward written) + out-proj",
-           83.9e6 * B, t, "2 launches; opt-in (SEDT_FUSED_ENC=1): slower than the 4-launch form today, DESIGN.md 4")
-        t = timeit(lambda: fused(False))
-        mf("encoder self-attn block fwd, FUSED head, no-grad form (teacher / eval) + out-proj", 83.9e6 * B, t, "2 launches; opt-in")
-        t = timeit(lambda: ops.encoder_attn_fwd(dt, x, pos, gam, bet, w_in, b_in, B, S, H, None, 0.1, 7, None, train=False))
-        mf("  fused head alone, no-grad (sedt_encoder_attn_fwd)", (83.9e6 - 16.8e6) * B, t)
     xn0, xnp0, _, _ = ops.layernorm_fwd(dt, x, gam, bet, add_t=pos)
     t = timeit(lambda: ops.linear_group(dt, [(xnp0, w_in[:2 * E], dict(bias=b_in[:2 * E])), (xn0, w_in[2 * E:], dict(bias=b_in[2 * E:]))]))
     mf("  QK | V projections (one grouped launch, 8192 x 256 x 768)", 2.0 * M * E * 3 * E, t)

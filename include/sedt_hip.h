@@ -371,37 +371,6 @@ int sedt_encoder_slab_ok(int D, int H, int S, int FF, int dtype);
  *   sedt_encoder_qkv_bwd:  gx = LayerNorm1'(dq|dk Wqk + dv Wv) + gx1
  * g2, gh, g1 are the left operands of the weight-gradient GEMMs of linear2, linear1, out_proj; ln_part [slabs][512] = per-slab
  * sums of (dy * xhat | dy) whose column sums are the LayerNorm gamma / beta gradients (slabs = B * ceil(S / 32)). */
-/* One pre-norm decoder layer (sedt/transformer.py:263-284) in ONE launch, a workgroup per clip (csrc/dec_slab.hip): the Q <= 32 query
- * rows of a clip stay in LDS from LayerNorm1 to the FFN output, the layer's weights stream fragment-major (sedt_pack_frag), the 8
- * waves are the 8 heads of both attention cores.  Outside stays the K | V projection of the encoder memory: kc / vc [B*S][ldk / ldv]
- * (bf16, row strides in elements) are its outputs.  s_win = in_proj_weight [768][256] of self_attn, c_wq = the first 256 rows of
- * multihead_attn.in_proj_weight (its query projection; c_bq = the first 256 entries of its bias), all weights as fragment-major W.
- * tgt, qpos, out, t1 [B*Q][256] bf16 contiguous (t1 is always written: the cross out-projection re-reads it); amask = additive
- * self-attention mask [Q][Q] f32 (SP-SEDT) or null; kpm [B][S] or null.  Training by-products (all or none; null = no-grad forward),
- * exactly what the per-op backward kernels read: tn, tnp, m1, r1, qk_s [B*Q][512], v_s, ctx_s, lse_s [B][8][Q]; t1np, m2, r2, q_c,
- * ctx_c, lse_c; t2, m3, r3, t2n, h [B*Q][FF].  seed[6] = self attention, self out-proj, cross attention, cross out-proj, hidden,
- * FFN output (each + *seed_ptr); element indices as in the per-op kernels.  Envelope (sedt_decoder_slab_ok): bf16, d_model 256,
- * 8 heads, Q <= 32, S <= 128, FF a multiple of 512. */
-typedef struct SedtDecLayer {
-  const void* tgt; const void* qpos;
-  const void* kc; int64_t ldk; const void* vc; int64_t ldv;
-  const uint8_t* kpm; const float* amask;
-  const void* s_win; const float* s_bin; const void* s_wo; const float* s_bo;
-  const void* c_wq; const float* c_bq; const void* c_wo; const float* c_bo;
-  const void* w1; const float* b1; const void* w2; const float* b2;
-  const float* g1; const float* be1; const float* g2; const float* be2; const float* g3; const float* be3;
-  void* out; void* t1;
-  void* tn; void* tnp; float* m1; float* r1; void* qk_s; void* v_s; void* ctx_s; float* lse_s;
-  void* t1np; float* m2; float* r2; void* q_c; void* ctx_c; float* lse_c;
-  void* t2; float* m3; float* r3; void* t2n; void* h;
-  int32_t B, Q, S, FF;
-  float drop_p;
-  uint32_t seed[6];
-  int32_t pad_;
-  const uint32_t* seed_ptr;
-} SedtDecLayer;
-int sedt_decoder_slab_ok(int D, int H, int Q, int S, int FF, int dtype);
-int sedt_decoder_layer_fwd(const SedtDecLayer* args, void* stream);
 
 /* An identity Bottleneck of ResNet layer1 / layer2 (torchvision v1.5 block behind sedt/backbone.py:97-113; cin -> planes -> planes -> cin,
  * stride 1, no downsample branch) in ONE launch, and its input-gradient chain in one more (csrc/bneck.hip; a workgroup per strip of 8
@@ -483,28 +452,6 @@ int sedt_encoder_ffn_bwd(const void* gx2, const void* h, const void* x1, const f
                          const float* gamma2, const void* w2t_frag, const void* w1t_frag, const void* wot_frag, void* g2, void* gh,
                          void* gx1, void* g1, void* gctx, float* ln_part, int B, int S, int FF, float drop_p, uint32_t seed_f,
                          uint32_t seed_o, const uint32_t* seed_ptr, void* stream);
-/* The FFN pair tiled in two dimensions (csrc/ffn_split.hip): a workgroup = 128 rows x a quarter of the hidden features; the four
- * workgroups of a row block leave f32 partial sums in `part` (sedt_ffn_split_part_floats(M) floats) and the last to arrive - ticket
- * counters cnt[sedt_ffn_split_blocks(M)], uint32, ZERO before the first launch, re-armed by the kernel - adds them in a fixed order.
- *   sedt_ffn_split_fwd: x2 = x1 + drop(drop(relu(x1n W1^T + b1)) W2^T + b2); h [M][FF] written when non-null (training)
- *   sedt_ffn_split_bwd: g2 = dropout'(gx2) (written when drop_p > 0); gh = (g2 W2) [h > 0] / (1 - p); g_x1n = gh W1
- * with sedt_encoder_attn_fwd2 (the encoder kernel stopped after LayerNorm2; x1, x1n always written) in front of the forward and
- * sedt_encoder_ln2_bwd (gx1 = LayerNorm2'(g_x1n) + gx2; g1 = dropout'(gx1); gctx = g1 Wo) behind the backward.  Weights fragment-
- * major (W for the forward, W^T for the backward).  Envelope (sedt_ffn_split_ok): bf16, d = 256, FF a multiple of 1024. */
-int sedt_ffn_split_ok(int D, int FF, int dtype);
-size_t sedt_ffn_split_part_floats(int M);
-int sedt_ffn_split_blocks(int M);
-int sedt_ffn_split_fwd(const void* x1n, const void* x1, const void* w1_frag, const float* b1, const void* w2_frag, const float* b2, void* h,
-                       void* x2, float* part, uint32_t* cnt, int M, int FF, float drop_p, uint32_t seed_h, uint32_t seed_f,
-                       const uint32_t* seed_ptr, void* stream);
-int sedt_ffn_split_bwd(const void* gx2, const void* h, const void* w2t_frag, const void* w1t_frag, void* g2, void* gh, void* g_x1n,
-                       float* part, uint32_t* cnt, int M, int FF, float drop_p, uint32_t seed_f, const uint32_t* seed_ptr, void* stream);
-int sedt_encoder_attn_fwd2(const void* x, const void* qk, const void* v, const uint8_t* kpm, const void* w_o_frag, const float* b_o,
-                           const float* gamma2, const float* beta2, void* x1, void* x1n, void* ctx, float* lse, float* mean2, float* rstd2,
-                           int B, int S, float drop_p, uint32_t seed_attn, uint32_t seed_o, const uint32_t* seed_ptr, void* stream);
-int sedt_encoder_ln2_bwd(const void* gx1n, const void* gx2, const void* x1, const float* mean2, const float* rstd2, const float* gamma2,
-                         const void* wot_frag, void* gx1, void* g1, void* gctx, float* ln_part, int B, int S, float drop_p, uint32_t seed_o,
-                         const uint32_t* seed_ptr, void* stream);
 int sedt_encoder_qkv_bwd(const void* dqk, const void* dv, const void* x, const float* mean1, const float* rstd1,
                          const float* gamma1, const void* gx1, const void* wint_frag, void* gx, float* ln_part, int B, int S,
                          void* stream);
@@ -681,20 +628,6 @@ int sedt_postprocess(const float* logits, const float* boxes, const float* tags,
 int sedt_pseudo_labels(const float* logits, const float* boxes, const float* at, const float* thr, float min_len, int B,
                        int Q, int C, int del_overlap, int64_t* lab_cat, float* box_cat, int32_t* lab_off, int32_t* box_off,
                        int32_t* counter, int cap, void* stream);
-
-/* ------------------------------------------------------------------ fused head of the pre-norm encoder layer
- * (sedt/transformer.py:196-199): xn = LayerNorm1(x); q = k = (xn + pos) Wqk^T + b; v = xn Wv^T + b;
- * ctx = dropout(softmax(q k^T / sqrt(32) + key padding)) v - LayerNorm, the three projections and the attention core in ONE
- * launch (workgroup = clip x pair of heads; the normalised slab stays in registers as MFMA A fragments, weights stream from
- * L2 as B fragments, Q/K/V go straight into the LDS images of the attention core).  x, pos, ctx [B*S][256] bf16 contiguous,
- * w_in [768][256] bf16 (packed in_proj_weight), b_in [768] f32, lse [B][8][S].  Training by-products (all or none): xn, xnp
- * [B*S][256] bf16, mean / rstd [B*S] f32, qk [B*S][512] bf16 (q | k), v [B*S][256] bf16 - what sedt_layernorm_bwd,
- * sedt_attention_bwd and the weight-gradient GEMMs read.  Dropout hash identical to sedt_attention_fwd (same seed -> same
- * mask in sedt_attention_bwd).  Envelope: bf16, D = 256, H = 8, S <= 128. */
-int sedt_encoder_attn_fwd(const void* x, const void* pos, const float* gamma, const float* beta, const void* w_in,
-                          const float* b_in, void* ctx, float* lse, void* xn, void* xnp, float* mean, float* rstd, void* qk,
-                          void* v, const uint8_t* kpm, int B, int S, int D, int H, float drop_p, uint32_t seed,
-                          const uint32_t* seed_ptr, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ input side on the device (utilities/BoxTransforms.py,
  * utilities/mixup.py)

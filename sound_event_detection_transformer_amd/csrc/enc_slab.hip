@@ -148,7 +148,6 @@ struct EncAttnFfnArgs {
   uint32_t thresh, seed_attn, seed_o, seed_h, seed_f;
   const uint32_t* seed_ptr;
   int dbg;                                           // developer builds: phase ablation (WRONG results); always 0 in the product library
-  int no_ffn;                                        // stop after LayerNorm2: x1, x1n (always written then) feed the 2-D tiled FFN (ffn_split.hip)
 };
 
 template <bool TRAIN>
@@ -300,7 +299,7 @@ __global__ __launch_bounds__(512) void enc_attn_ffn_kernel(const EncAttnFfnArgs 
   if (TRAIN && !(dbg & 4)) slab::tile_to_global(CTX, XP, a.ctx + row0 * ES_D, ES_D, nvalid, ES_D, tid, 512);
 
   // ---- phase C: x1 = x + dropout(ctx Wo^T + bo): wave w computes feature tile w; linear1's first chunk follows in the stream
-  const int FF = a.FF, nchunk = ((dbg & 2) || a.no_ffn) ? 0 : FF / 512;
+  const int FF = a.FF, nchunk = (dbg & 2) ? 0 : FF / 512;
   {
     f32x16 acc[1];
     slab::zero_acc(acc);
@@ -336,7 +335,7 @@ __global__ __launch_bounds__(512) void enc_attn_ffn_kernel(const EncAttnFfnArgs 
     }
   }
   __syncthreads();
-  if ((TRAIN || a.no_ffn) && !(dbg & 4)) slab::tile_to_global(X1, XP, a.x1 + row0 * ES_D, ES_D, nvalid, ES_D, tid, 512);
+  if (TRAIN && !(dbg & 4)) slab::tile_to_global(X1, XP, a.x1 + row0 * ES_D, ES_D, nvalid, ES_D, tid, 512);
 
   // ---- phase D: x1n = LayerNorm2(x1)
   slab::slab_layernorm(
@@ -346,12 +345,11 @@ __global__ __launch_bounds__(512) void enc_attn_ffn_kernel(const EncAttnFfnArgs 
 #pragma unroll
         for (int e = 0; e < 4; ++e) o.v[e] = (bf16_t)y[e];
         *reinterpret_cast<VecT<bf16_t, 4>*>(X1N + r * XP + lane * 4) = o;
-        if ((TRAIN || a.no_ffn) && r < nvalid) {
+        if (TRAIN && r < nvalid) {
           *reinterpret_cast<VecT<bf16_t, 4>*>(a.x1n + (row0 + r) * ES_D + lane * 4) = o;
           if (TRAIN && lane == 0) { a.mean2[row0 + r] = mu; a.rstd2[row0 + r] = rs; }
         }
       });
-  if (a.no_ffn) return;
   __syncthreads();
 
   // ---- phase E: the FFN pair, hidden in chunks of 512 through LDS (double-buffered); wave w owns output tile w of linear2
@@ -633,71 +631,6 @@ __global__ __launch_bounds__(512) void enc_ffn_bwd_kernel(const EncFfnBwdArgs a)
   slab::tile_to_global(GX, XP, a.gctx + row0 * ES_D, ES_D, nvalid, ES_D, tid, 512);
 }
 
-// the tail of enc_ffn_bwd_kernel on its own - for the 2-D tiled FFN backward (ffn_split.hip), which delivers g_x1n:
-//   gx1 = LayerNorm2'(g_x1n) + gx2; g1 = dropout'(gx1); gctx = g1 Wo
-struct EncLn2BwdArgs {
-  const bf16_t* gx1n; const bf16_t* gx2;
-  const bf16_t* x1; const float* mean2; const float* rstd2; const float* gamma2;
-  const u32x4* wot;
-  bf16_t* gx1; bf16_t* g1; bf16_t* gctx;
-  float* ln_part;
-  int B, S;
-  float drop_p;
-  uint32_t thresh, seed_o;
-  const uint32_t* seed_ptr;
-};
-
-__global__ __launch_bounds__(512) void enc_ln2_bwd_kernel(const EncLn2BwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* G1 = reinterpret_cast<bf16_t*>(smem);                    // [32][XP]
-  bf16_t* OUT = G1 + 32 * XP;                                      // [32][XP]
-  float* RED = reinterpret_cast<float*>(OUT + 32 * XP);            // [8][512]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 31, hf = lane >> 5;
-  const int S = a.S, SL = (S + 31) >> 5;
-  const int b = blockIdx.x / SL, s0 = (blockIdx.x - b * SL) * 32;
-  const int nvalid = min(32, S - s0);
-  const long row0 = (long)b * S + s0;
-  const float inv_keep = a.thresh ? 1.f / (1.f - a.drop_p) : 1.f;
-  const uint32_t sd = a.seed_o + (a.seed_ptr ? *a.seed_ptr : 0u);
-  slab::u32x4 wa[8], wb[8];
-  slab::load_chunk<1>(wa, a.wot + (long)wave * 64L * 16, 0, 0, lane);
-  slab::load_chunk<1>(wb, a.wot + (long)wave * 64L * 16, 0, 8, lane);
-  slab::issue_fence();
-  slab_layernorm_bwd(
-      wave, lane, tid, nvalid, row0, a.gamma2, a.mean2, a.rstd2, a.x1, a.gx2, [&](int r) { return a.gx1n + (row0 + r) * ES_D; },
-      [&](int r, const float* o) {
-        const long base = (row0 + r) * ES_D + lane * 4;
-        VecT<bf16_t, 4> ov, od;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ov.v[e] = (bf16_t)o[e];
-        *reinterpret_cast<VecT<bf16_t, 4>*>(a.gx1 + base) = ov;
-        uint32_t keep = 0xfu;
-        if (a.thresh) keep = drop_keep4(slab::inner0(sd), 0u, sd, (uint64_t)base, a.thresh);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) od.v[e] = (keep >> e & 1u) ? (a.thresh ? (bf16_t)((float)ov.v[e] * inv_keep) : ov.v[e]) : (bf16_t)0.f;
-        if (a.g1) *reinterpret_cast<VecT<bf16_t, 4>*>(a.g1 + base) = od;
-        *reinterpret_cast<VecT<bf16_t, 4>*>(G1 + r * XP + lane * 4) = od;
-      },
-      RED, a.ln_part + (long)blockIdx.x * 512);
-  for (int r = nvalid + wave; r < 32; r += 8) *reinterpret_cast<VecT<bf16_t, 4>*>(G1 + r * XP + lane * 4) = VecT<bf16_t, 4>{};
-  __syncthreads();
-  {
-    f32x16 acc[1];
-    slab::zero_acc(acc);
-    slab::wave_gemm_small(acc, G1, XP, lane, wa, wb, [&](slab::u32x4(&)[8]) {}, [&](slab::u32x4(&)[8]) {});
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const int f = wave * 32 + 8 * g4 + 4 * hf;
-      VecT<bf16_t, 4> o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o.v[e] = (bf16_t)acc[0][4 * g4 + e];
-      *reinterpret_cast<VecT<bf16_t, 4>*>(OUT + n * XP + f) = o;
-    }
-  }
-  __syncthreads();
-  slab::tile_to_global(OUT, XP, a.gctx + row0 * ES_D, ES_D, nvalid, ES_D, tid, 512);
-}
-
 struct EncQkvBwdArgs {
   const bf16_t* dqk; const bf16_t* dv;                // [B*S][512], [B*S][256]
   const bf16_t* x; const float* mean1; const float* rstd1; const float* gamma1;
@@ -868,7 +801,7 @@ static int enc_attn_ffn_launch(const void* x, const void* qk, const void* v, con
                                const float* b1, const void* w2_frag, const float* b2, void* x2, void* ctx, float* lse,
                                void* x1, float* mean2, float* rstd2, void* x1n, void* h, int B, int S, int FF,
                                float drop_p, uint32_t seed_attn, uint32_t seed_o, uint32_t seed_h, uint32_t seed_f,
-                               const uint32_t* seed_ptr, void* stream, int no_ffn);
+                               const uint32_t* seed_ptr, void* stream);
 
 extern "C" int sedt_encoder_attn_ffn_fwd(const void* x, const void* qk, const void* v, const uint8_t* kpm, const void* w_o_frag,
                                          const float* b_o, const float* gamma2, const float* beta2, const void* w1_frag,
@@ -878,20 +811,7 @@ extern "C" int sedt_encoder_attn_ffn_fwd(const void* x, const void* qk, const vo
                                          const uint32_t* seed_ptr, void* stream) {
   SEDT_REQUIRE(w1_frag && b1 && w2_frag && b2 && x2, "encoder_attn_ffn_fwd: null pointer");
   return enc_attn_ffn_launch(x, qk, v, kpm, w_o_frag, b_o, gamma2, beta2, w1_frag, b1, w2_frag, b2, x2, ctx, lse, x1, mean2, rstd2, x1n, h, B, S,
-                             FF, drop_p, seed_attn, seed_o, seed_h, seed_f, seed_ptr, stream, 0);
-}
-
-// the same kernel stopped after LayerNorm2 (attention, out-proj + residual, LayerNorm2): x1 and x1n are always written, the FFN pair
-// follows as sedt_ffn_split_fwd.  Training by-products: ctx, lse, mean2, rstd2 (all or none)
-extern "C" int sedt_encoder_attn_fwd2(const void* x, const void* qk, const void* v, const uint8_t* kpm, const void* w_o_frag, const float* b_o,
-                                      const float* gamma2, const float* beta2, void* x1, void* x1n, void* ctx, float* lse, float* mean2,
-                                      float* rstd2, int B, int S, float drop_p, uint32_t seed_attn, uint32_t seed_o,
-                                      const uint32_t* seed_ptr, void* stream) {
-  SEDT_REQUIRE(x1 && x1n, "encoder_attn_fwd2: null pointer");
-  SEDT_REQUIRE((ctx == nullptr) == (lse == nullptr) && (ctx == nullptr) == (mean2 == nullptr) && (ctx == nullptr) == (rstd2 == nullptr),
-               "encoder_attn_fwd2: the training by-products come all or none");
-  return enc_attn_ffn_launch(x, qk, v, kpm, w_o_frag, b_o, gamma2, beta2, nullptr, nullptr, nullptr, nullptr, nullptr, ctx, lse, x1, mean2, rstd2,
-                             x1n, nullptr, B, S, 1024, drop_p, seed_attn, seed_o, 0u, 0u, seed_ptr, stream, 1);
+                             FF, drop_p, seed_attn, seed_o, seed_h, seed_f, seed_ptr, stream);
 }
 
 static int enc_attn_ffn_launch(const void* x, const void* qk, const void* v, const uint8_t* kpm, const void* w_o_frag,
@@ -899,14 +819,13 @@ static int enc_attn_ffn_launch(const void* x, const void* qk, const void* v, con
                                const float* b1, const void* w2_frag, const float* b2, void* x2, void* ctx, float* lse,
                                void* x1, float* mean2, float* rstd2, void* x1n, void* h, int B, int S, int FF,
                                float drop_p, uint32_t seed_attn, uint32_t seed_o, uint32_t seed_h, uint32_t seed_f,
-                               const uint32_t* seed_ptr, void* stream, int no_ffn) {
+                               const uint32_t* seed_ptr, void* stream) {
   SEDT_REQUIRE(x && qk && v && w_o_frag && b_o && gamma2 && beta2, "encoder_attn_ffn_fwd: null pointer");
   SEDT_REQUIRE(B >= 1 && S >= 1 && S <= ES_LK && FF >= 512 && FF % 512 == 0, "encoder_attn_ffn_fwd: S = %d / FF = %d outside the envelope", S, FF);
   SEDT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "encoder_attn_ffn_fwd: drop_p out of range");
   const bool train = ctx != nullptr;
-  SEDT_REQUIRE(!train || (lse && x1 && mean2 && rstd2 && x1n && (h || no_ffn)), "encoder_attn_ffn_fwd: the training by-products come all or none");
+  SEDT_REQUIRE(!train || (lse && x1 && mean2 && rstd2 && x1n && h), "encoder_attn_ffn_fwd: the training by-products come all or none");
   EncAttnFfnArgs a;
-  a.no_ffn = no_ffn;
   a.x = (const bf16_t*)x; a.qk = (const bf16_t*)qk; a.v = (const bf16_t*)v; a.kpm = kpm;
   a.w_o = (const u32x4*)w_o_frag; a.b_o = b_o; a.gamma2 = gamma2; a.beta2 = beta2;
   a.w1 = (const u32x4*)w1_frag; a.b1 = b1; a.w2 = (const u32x4*)w2_frag; a.b2 = b2;
@@ -976,20 +895,3 @@ extern "C" int sedt_encoder_qkv_bwd(const void* dqk, const void* dv, const void*
   return check_launch("encoder_qkv_bwd");
 }
 
-extern "C" int sedt_encoder_ln2_bwd(const void* gx1n, const void* gx2, const void* x1, const float* mean2, const float* rstd2,
-                                    const float* gamma2, const void* wot_frag, void* gx1, void* g1, void* gctx, float* ln_part, int B, int S,
-                                    float drop_p, uint32_t seed_o, const uint32_t* seed_ptr, void* stream) {
-  SEDT_REQUIRE(gx1n && gx2 && x1 && mean2 && rstd2 && gamma2 && wot_frag && gx1 && gctx && ln_part, "encoder_ln2_bwd: null pointer");
-  SEDT_REQUIRE(B >= 1 && S >= 1 && S <= ES_LK, "encoder_ln2_bwd: S = %d outside 1..%d", S, ES_LK);
-  SEDT_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (drop_p == 0.f || g1), "encoder_ln2_bwd: drop_p / g1");
-  EncLn2BwdArgs a{(const bf16_t*)gx1n, (const bf16_t*)gx2, (const bf16_t*)x1, mean2, rstd2, gamma2, (const u32x4*)wot_frag, (bf16_t*)gx1,
-                  (bf16_t*)g1, (bf16_t*)gctx, ln_part, B, S, drop_p, drop_p > 0.f ? drop_threshold(drop_p) : 0u, seed_o, seed_ptr};
-  constexpr size_t lds = (size_t)2 * 32 * XP * sizeof(bf16_t) + 8 * 512 * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    if (set_lds(enc_ln2_bwd_kernel, lds, "encoder_ln2_bwd")) return 1;
-    attr = true;
-  }
-  hipLaunchKernelGGL(enc_ln2_bwd_kernel, dim3(B * ((S + 31) / 32)), dim3(512), lds, reinterpret_cast<hipStream_t>(stream), a);
-  return check_launch("encoder_ln2_bwd");
-}

@@ -472,15 +472,8 @@ class EncoderLayerFn(Function):
             _, wb1 = _prep_linear(dt, w1, tr)
             _, wb2 = _prep_linear(dt, w2, tr)
             qk, v, by1 = ops.encoder_qkv_fwd(x, pos, g1, be1, fr[0][0], b_in, B, S, train=tr, prefetch=(fr[1][0], fr[2][0], fr[3][0]))
-            split = ops.ffn_split_ok(dt, x.shape[1], w1.shape[0])
-            if split:
-                # attention | out-proj | LayerNorm2 per 32-token slab, then the FFN pair tiled 128 rows x a quarter of the hidden features
-                x1_, x1n_, bya = ops.encoder_attn_fwd2(x, qk, v, kpm, fr[1][0], b_o, g2, be2, B, S, p, seeds[0:2], sp, train=tr)
-                x2, h_ = ops.ffn_split_fwd(x1n_, x1_, fr[2][0], b1, fr[3][0], b2, w1.shape[0], p, seeds[2:4], sp, train=tr)
-                by2 = (bya[0], bya[1], x1_, bya[2], bya[3], x1n_, h_) if tr else None
-            else:
-                x2, by2 = ops.encoder_attn_ffn_fwd(x, qk, v, kpm, fr[1][0], b_o, g2, be2, fr[2][0], b1, fr[3][0], b2, B, S, w1.shape[0],
-                                                   p, seeds, sp, train=tr)
+            x2, by2 = ops.encoder_attn_ffn_fwd(x, qk, v, kpm, fr[1][0], b_o, g2, be2, fr[2][0], b1, fr[3][0], b2, B, S, w1.shape[0],
+                                               p, seeds, sp, train=tr)
             if tr:
                 xn, xnp, m1, r1 = by1
                 ctxv, lse, x1, m2, r2, x1n, h = by2
@@ -496,25 +489,9 @@ class EncoderLayerFn(Function):
                     sv['bwd_next'], chain.top = chain.top, (fr[3][1], fr[2][1], fr[1][1])
             ctx.sv, ctx.cfg, ctx.P = sv, cfg, P
             return x2
-        if cfg['pre_norm'] and ops.FUSED_ENC and ops.encoder_attn_ok(dt, x.shape[1], H, S, amask) and x.is_contiguous() and pos.is_contiguous():
-            # LayerNorm1 + Q|K|V projections + attention core in ONE launch (csrc/attn_mfma.hip); the by-products the unfused
-            # backward kernels read are written only when a backward will follow
-            wf, wb_in = _prep_linear(dt, w_in, tr)
-            wf_o, wb_o = _prep_linear(dt, w_o, tr)
-            sp = runtime.seed_ptr(x.device) if p > 0 else None
-            ctxv, lse, by = ops.encoder_attn_fwd(dt, x, pos, g1, be1, wf, b_in, B, S, H, kpm, p, seeds[0], sp, train=tr)
-            x1 = ops.linear(dt, ctxv, wf_o, bias=b_o, drop_p=p, seed=seeds[1], seed_ptr=sp, res=x, ldr=x.stride(0))
-            if tr:
-                xn, xnp, m1, r1, qk, v = by
-                E = x.shape[1]
-                sv['mha'] = dict(wb_in=wb_in, wb_o=wb_o, q_in=xnp, k_in=xnp, v_in=xn, same_qk=True, qk=qk, q=qk[:, :E], k=qk[:, E:], v=v,
-                                 ctxv=ctxv, lse=lse, dims=(B, H, S, S), kpm=kpm, amask=None, p=p, seeds=seeds[0:2])
-            else:
-                m1 = r1 = None
-        elif cfg['pre_norm']:
+        if cfg['pre_norm']:
             xn, xnp, m1, r1 = ops.layernorm_fwd(dt, x, g1, be1, add_t=pos)
             x1, sv['mha'] = _mha_fwd(dt, xnp, xnp, xn, True, w_in, b_in, w_o, b_o, x, B, H, S, S, kpm, amask, p, seeds[0:2], tr)
-        if cfg['pre_norm']:
             x1n, _, m2, r2 = ops.layernorm_fwd(dt, x1, g2, be2)
             x2, sv['ffn'] = _ffn_fwd(dt, x1n, w1, b1, w2, b2, x1, p, seeds[2:4], tr)
             sv.update(x=x, x1=x1, m1=m1, r1=r1, m2=m2, r2=r2)
@@ -545,13 +522,8 @@ class EncoderLayerFn(Function):
             dev = gx2.device
             sp = runtime.seed_ptr(dev) if p > 0 else None
             E = gx2.shape[1]
-            if ops.ffn_split_ok(dt, E, ff['h'].shape[1]):
-                g2d, gh, gx1n = ops.ffn_split_bwd(gx2.contiguous(), ff['h'], w2t, w1t, p, ff['seeds'][1], sp)
-                gx1, g1d, gctx, part2 = ops.encoder_ln2_bwd(gx1n, gx2.contiguous(), sv['x1'], sv['m2'], sv['r2'], g2, wot, B, S, p,
-                                                            mh['seeds'][1], sp)
-            else:
-                g2d, gh, gx1, g1d, gctx, part2 = ops.encoder_ffn_bwd(gx2.contiguous(), ff['h'], sv['x1'], sv['m2'], sv['r2'], g2, w2t, w1t, wot,
-                                                                     B, S, p, (ff['seeds'][1], mh['seeds'][1]), sp)
+            g2d, gh, gx1, g1d, gctx, part2 = ops.encoder_ffn_bwd(gx2.contiguous(), ff['h'], sv['x1'], sv['m2'], sv['r2'], g2, w2t, w1t, wot,
+                                                                 B, S, p, (ff['seeds'][1], mh['seeds'][1]), sp)
             d_b2 = torch.empty((E,), device=dev, dtype=torch.float32)
             d_w2 = ops.linear_wgrad(dt, g2d, ff['h'], bias_out=d_b2, batch=rb, param=w2)
             d_b1 = torch.empty((gh.shape[1],), device=dev, dtype=torch.float32)
@@ -614,55 +586,9 @@ class DecoderLayerFn(Function):
         tgt, mem, mem_pos, qpos = _as(tgt, dt), _as(mem, dt), _as(mem_pos, dt), _as(qpos, dt)
         sv = {}
         tr = any(ctx.needs_input_grad)
-        fr = None
-        if cfg['pre_norm'] and ops.decoder_slab_ok(dt, tgt.shape[1], H, Q, S, w1.shape[0]) and qpos.shape == tgt.shape:
-            fr = [packing.lookup_frag(w) for w in (sw_in, sw_o, cw_in, cw_o, w1, w2)]
-            fr = fr if all(f is not None for f in fr) else None
-        if fr is not None:
-            # the whole layer in ONE launch, a workgroup per clip (csrc/dec_slab.hip); the K | V projection of the memory stays a GEMM
-            E = tgt.shape[1]
-            sp = runtime.seed_ptr(tgt.device) if p > 0 else None
-            cwf, cwb_in = _prep_linear(dt, cw_in, tr)
-            _, swb_in = _prep_linear(dt, sw_in, tr)
-            _, swb_o = _prep_linear(dt, sw_o, tr)
-            _, cwb_o = _prep_linear(dt, cw_o, tr)
-            _, wb1 = _prep_linear(dt, w1, tr)
-            _, wb2 = _prep_linear(dt, w2, tr)
-            k_c, v_c = ops.linear_group(dt, [(mem_pos, cwf[E:2 * E], dict(bias=cb_in[E:2 * E])), (mem, cwf[2 * E:], dict(bias=cb_in[2 * E:]))])
-            tmask = tgt_mask.contiguous() if tgt_mask is not None else None
-            t3, by = ops.decoder_layer_fwd(tgt.contiguous(), qpos.contiguous(), k_c, v_c, kpm, tmask, [f[0] for f in fr],
-                                           (sb_in, sb_o, cb_in, cb_o, b1, b2, g1, be1, g2, be2, g3, be3), B, Q, S, w1.shape[0], p, seeds, sp,
-                                           train=tr, out=cfg.get('out'))
-            if tr:
-                sv['sa'] = dict(wb_in=swb_in, wb_o=swb_o, q_in=by['tnp'], k_in=by['tnp'], v_in=by['tn'], same_qk=True, qk=by['qk_s'],
-                                q=by['qk_s'][:, :E], k=by['qk_s'][:, E:], v=by['v_s'], ctxv=by['ctx_s'], lse=by['lse_s'], dims=(B, H, Q, Q),
-                                kpm=None, amask=tmask, p=p, seeds=seeds[0:2])
-                sv['ca'] = dict(wb_in=cwb_in, wb_o=cwb_o, q_in=by['t1np'], k_in=mem_pos, v_in=mem, same_qk=False, qk=None, q=by['q_c'], k=k_c,
-                                v=v_c, ctxv=by['ctx_c'], lse=by['lse_c'], dims=(B, H, Q, S), kpm=kpm, amask=None, p=p, seeds=seeds[2:4])
-                sv['ffn'] = dict(x_in=by['t2n'], h=by['h'], p=p, seeds=seeds[4:6], wb1=wb1, wb2=wb2)
-                sv.update(tgt=tgt, t1=by['t1'], t2=by['t2'], m1=by['m1'], r1=by['r1'], m2=by['m2'], r2=by['r2'], m3=by['m3'], r3=by['r3'])
-            ctx.sv, ctx.cfg, ctx.P = sv, cfg, P
-            return t3
-        if cfg['pre_norm'] and ops.FUSED_DEC_SA and ops.encoder_attn_ok(dt, tgt.shape[1], H, Q, tgt_mask) and tgt.is_contiguous() \
-                and qpos.is_contiguous() and qpos.shape == tgt.shape:
-            # self-attention of the Q queries of a clip: LayerNorm1 + Q|K|V projections + attention core in ONE launch - the kernel
-            # built for the encoder (csrc/attn_mfma.hip: enc_attn_fused_kernel) with S = Q.  At M = B*Q rows the three launches it
-            # replaces are pure launch latency
-            wf, wb_in = _prep_linear(dt, sw_in, tr)
-            wf_o, wb_o = _prep_linear(dt, sw_o, tr)
-            sp = runtime.seed_ptr(tgt.device) if p > 0 else None
-            ctxv, lse, by = ops.encoder_attn_fwd(dt, tgt, qpos, g1, be1, wf, sb_in, B, Q, H, None, p, seeds[0], sp, train=tr)
-            t1 = ops.linear(dt, ctxv, wf_o, bias=sb_o, drop_p=p, seed=seeds[1], seed_ptr=sp, res=tgt, ldr=tgt.stride(0))
-            m1 = r1 = None
-            if tr:
-                tn, tnp, m1, r1, qk, v = by
-                E = tgt.shape[1]
-                sv['sa'] = dict(wb_in=wb_in, wb_o=wb_o, q_in=tnp, k_in=tnp, v_in=tn, same_qk=True, qk=qk, q=qk[:, :E], k=qk[:, E:], v=v,
-                                ctxv=ctxv, lse=lse, dims=(B, H, Q, Q), kpm=None, amask=None, p=p, seeds=seeds[0:2])
-        elif cfg['pre_norm']:
+        if cfg['pre_norm']:
             tn, tnp, m1, r1 = ops.layernorm_fwd(dt, tgt, g1, be1, add_t=qpos)
             t1, sv['sa'] = _mha_fwd(dt, tnp, tnp, tn, True, sw_in, sb_in, sw_o, sb_o, tgt, B, H, Q, Q, None, tgt_mask, p, seeds[0:2], tr)
-        if cfg['pre_norm']:
             t1n, t1np, m2, r2 = ops.layernorm_fwd(dt, t1, g2, be2, add_t=qpos)
             t2, sv['ca'] = _mha_fwd(dt, t1np, mem_pos, mem, False, cw_in, cb_in, cw_o, cb_o, t1, B, H, Q, S, kpm, None, p, seeds[2:4], tr)
             t2n, _, m3, r3 = ops.layernorm_fwd(dt, t2, g3, be3)

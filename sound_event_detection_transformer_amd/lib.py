@@ -74,17 +74,6 @@ class SedtMatch(C.Structure):
                 ('ft_seed', C.c_uint32), ('seed_ptr', C.c_void_p), ('split', C.c_void_p), ('Qs', C.c_int32), ('q0', C.c_int32)]
 
 
-class SedtDecLayer(C.Structure):
-    _fields_ = [('tgt', C.c_void_p), ('qpos', C.c_void_p), ('kc', C.c_void_p), ('ldk', C.c_int64), ('vc', C.c_void_p), ('ldv', C.c_int64),
-                ('kpm', C.c_void_p), ('amask', C.c_void_p)] + \
-               [(n, C.c_void_p) for n in ('s_win', 's_bin', 's_wo', 's_bo', 'c_wq', 'c_bq', 'c_wo', 'c_bo', 'w1', 'b1', 'w2', 'b2',
-                                           'g1', 'be1', 'g2', 'be2', 'g3', 'be3', 'out', 't1',
-                                           'tn', 'tnp', 'm1', 'r1', 'qk_s', 'v_s', 'ctx_s', 'lse_s', 't1np', 'm2', 'r2', 'q_c', 'ctx_c', 'lse_c',
-                                           't2', 'm3', 'r3', 't2n', 'h')] + \
-               [('B', C.c_int32), ('Q', C.c_int32), ('S', C.c_int32), ('FF', C.c_int32), ('drop_p', C.c_float), ('seed', C.c_uint32 * 6),
-                ('pad_', C.c_int32), ('seed_ptr', C.c_void_p)]
-
-
 class SedtPrefetch(C.Structure):
     _fields_ = [('ptr', C.c_void_p * 3), ('bytes', C.c_size_t * 3)]
 
@@ -136,8 +125,6 @@ SIGNATURES = {
                                 _vp, _i, _vp]),
     'sedt_attention_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp,
                                 _i64, _vp, _i64, _i, _i, _i, _i, _f, _u32, _vp, _i, _vp]),
-    'sedt_encoder_attn_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _u32,
-                               _vp, _i, _vp]),
     'sedt_pack_frag': (_i, [_vp, _i, _i, _vp]),
     'sedt_encoder_slab_ok': (_i, [_i, _i, _i, _i, _i]),
     'sedt_encoder_qkv_fwd': (_i, [_vp] * 12 + [_i, _i, C.POINTER(SedtPrefetch), _vp]),
@@ -156,15 +143,6 @@ SIGNATURES = {
     'sedt_heads_fwd': (_i, [_vp] * 16 + [_i] * 5 + [_vp]),
     'sedt_heads_bwd_part_floats': (_sz, [_i] * 5),
     'sedt_heads_bwd': (_i, [_vp] * 17 + [_i] * 5 + [_vp]),
-    'sedt_decoder_slab_ok': (_i, [_i, _i, _i, _i, _i, _i]),
-    'sedt_decoder_layer_fwd': (_i, [C.POINTER(SedtDecLayer), _vp]),
-    'sedt_ffn_split_ok': (_i, [_i, _i, _i]),
-    'sedt_ffn_split_part_floats': (_sz, [_i]),
-    'sedt_ffn_split_blocks': (_i, [_i]),
-    'sedt_ffn_split_fwd': (_i, [_vp] * 10 + [_i, _i, _f, _u32, _u32, _vp, _vp]),
-    'sedt_ffn_split_bwd': (_i, [_vp] * 9 + [_i, _i, _f, _u32, _vp, _vp]),
-    'sedt_encoder_attn_fwd2': (_i, [_vp] * 14 + [_i, _i, _f, _u32, _u32, _vp, _vp]),
-    'sedt_encoder_ln2_bwd': (_i, [_vp] * 11 + [_i, _i, _f, _u32, _vp, _vp]),
     'sedt_encoder_ffn_bwd': (_i, [_vp] * 15 + [_i, _i, _i, _f, _u32, _u32, _vp, _vp]),
     'sedt_encoder_qkv_bwd': (_i, [_vp] * 10 + [_i, _i, _vp]),
     'sedt_posenc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

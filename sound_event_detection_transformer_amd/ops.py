@@ -639,44 +639,6 @@ def attention_bwd(dtype, q, k, v, o, do, lse, B, H, Lq, Lk, dq, dk, dv, kpm=None
 NO_RIDE = _dev_env('SEDT_CO_NORIDE', '0') == '1'      # experiment: park all wgrads until the end of the backward, no riders
 CONV3_DIRECT = _dev_env('SEDT_CONV3_DIRECT', '1') != '0'   # direct 3x3 kernel for the layer1 conv2 geometry (conv3x3_c64.hip)
 STEM_DIRECT = _dev_env('SEDT_STEM_DIRECT', '1') != '0'     # one-launch stem forward / backward (stem.hip)
-# The fused encoder head (LN1 + QKV + attention in one launch) is correct (tests/test_ops_gpu.py) and, as measured on the
-# MI355X, level with the three launches it replaces (30.6 vs 32.7 us no-grad, 32.2 in training form) but not ahead: one
-# workgroup per CU runs its phases strictly in sequence.  Opt in with SEDT_FUSED_ENC=1.
-FUSED_ENC = _dev_env('SEDT_FUSED_ENC', '0') == '1'
-# the same kernel for the decoder's self-attention over the Q queries of a clip (S = Q <= 32): three launches -> one.  Correct (tests)
-# and slower: its fixed skeleton (~18 us, see above) exceeds the three latency-bound launches it replaces - C2 5.49 -> 5.57 ms, C3
-# 4.55 -> 4.59 ms (same-box A/B).  Opt in with SEDT_FUSED_DEC_SA=1.
-FUSED_DEC_SA = _dev_env('SEDT_FUSED_DEC_SA', '0') == '1'
-
-
-def encoder_attn_ok(dtype, D, H, S, amask):
-    """envelope of the fused LayerNorm + QKV + attention kernel (csrc/attn_mfma.hip: enc_attn_fused_kernel)"""
-    return dtype == BF16 and D == 256 and H == 8 and S <= 128 and amask is None
-
-
-def encoder_attn_fwd(dtype, x, pos, gamma, beta, w_in, b_in, B, S, H, kpm=None, drop_p=0.0, seed=0, seed_ptr=None, train=True):
-    """pre-norm encoder self-attention up to the context in ONE launch.  x, pos [B*S, 256] bf16 contiguous; w_in [768, 256]
-    bf16 (packed in_proj_weight); returns (ctx, lse, saved) with saved = (xn, xnp, mean, rstd, qk, v) when train else None"""
-    _dev_check(x, pos, w_in)
-    M, D = x.shape
-    assert x.is_contiguous() and pos.is_contiguous() and w_in.is_contiguous() and pos.shape == x.shape and M == B * S
-    ctx = torch.empty((M, D), device=x.device, dtype=x.dtype)
-    lse = torch.empty((B, H, S), device=x.device, dtype=torch.float32)
-    saved = None
-    if train:
-        xn, xnp = torch.empty_like(x), torch.empty_like(x)
-        mean = torch.empty((M,), device=x.device, dtype=torch.float32)
-        rstd = torch.empty_like(mean)
-        qk = torch.empty((M, 2 * D), device=x.device, dtype=x.dtype)
-        v = torch.empty((M, D), device=x.device, dtype=x.dtype)
-        saved = (xn, xnp, mean, rstd, qk, v)
-    s = saved if saved is not None else (None,) * 6
-    L.check(L.load().sedt_encoder_attn_fwd(_p(x), _p(pos), _p(gamma), _p(beta), _p(w_in), _p(b_in), _p(ctx), _p(lse), _p(s[0]), _p(s[1]),
-                                           _p(s[2]), _p(s[3]), _p(s[4]), _p(s[5]), _p(kpm), B, S, D, H, drop_p, seed & 0xffffffff,
-                                           _p(seed_ptr), dtype, L.stream_ptr()), 'encoder_attn_fwd')
-    return ctx, lse, saved
-
-
 # The pre-norm encoder layer on the x-stationary slab kernels (csrc/enc_slab.hip: two launches per layer instead of seven; a workgroup
 # owns 32 tokens, only weights stream).  Default in the bf16 mode; SLAB_ENC = False (tests, A/B) keeps the per-op chain.
 SLAB_ENC = _dev_env('SEDT_SLAB_ENC', '1') != '0'
@@ -933,141 +895,6 @@ def heads_bwd(x, h1, h2, box, at, g_cls, g_box, g_at, wc, w3, wa, w2t, w1t, Lh, 
     L.check(L.load().sedt_heads_bwd(_p(x), _p(h1), _p(h2), _p(box), _p(at), _p(g_cls), _p(g_box), _p(g_at), _p(wc), _p(w3), _p(wa), _p(w2t),
                                     _p(w1t), _p(dhs), _p(g_h1), _p(g_h2), _p(part), Lh, B, Qp, C1, CA, L.stream_ptr()), 'heads_bwd')
     return dhs, g_h1, g_h2, part
-
-
-# One pre-norm decoder layer in ONE launch, a workgroup per clip (csrc/dec_slab.hip).  Default in the bf16 mode.
-# Measured level with the per-op chain, not ahead (B = 64, Q = 11: 59 us + 12 us for the K | V projection against 73 us; same-box A/B of
-# the C2 / C3 steps: +0.2 / +0.8 %): per clip the chain of phases is a chain of memory round trips whichever way it is launched, and
-# B = 16 takes as long as B = 64.  Correct and tested (tests/test_slab_gpu.py); opt-in: ops.SLAB_DEC = True.
-SLAB_DEC = _dev_env('SEDT_SLAB_DEC', '0') == '1'
-
-
-def decoder_slab_ok(dtype, D, H, Q, S, FF):
-    return bool(SLAB_DEC and dtype == BF16 and L.load().sedt_decoder_slab_ok(D, H, Q, S, FF, dtype))
-
-
-def decoder_layer_fwd(tgt, qpos, kc, vc, kpm, amask, frags, vecs, B, Q, S, FF, drop_p=0.0, seeds=(0,) * 6, seed_ptr=None, train=True, out=None):
-    """frags = fragment-major (self in_proj, self out_proj, cross in_proj, cross out_proj, linear1, linear2); vecs = (self in_proj bias,
-    self out bias, cross in_proj bias, cross out bias, b1, b2, g1, be1, g2, be2, g3, be3) f32.  kc / vc: the projected memory keys /
-    values [B*S, >= 256] (row-strided views).  Returns (out [B*Q, 256], by-products dict or None)"""
-    _dev_check(tgt, qpos, kc, vc)
-    M, D = tgt.shape
-    assert tgt.is_contiguous() and qpos.is_contiguous() and qpos.shape == tgt.shape and M == B * Q and tgt.dtype == torch.bfloat16
-    assert kc.stride(1) == 1 and vc.stride(1) == 1 and kc.shape[0] == B * S and vc.shape[0] == B * S
-    dev = tgt.device
-    bf = lambda *sh: torch.empty(sh, device=dev, dtype=torch.bfloat16)
-    f32 = lambda *sh: torch.empty(sh, device=dev, dtype=torch.float32)
-    if out is None:
-        out = bf(M, D)
-    assert out.is_contiguous() and out.shape == (M, D)
-    a = L.SedtDecLayer()
-    keep = [tgt, qpos, kc, vc, kpm, amask, out]
-    a.tgt, a.qpos, a.kc, a.ldk, a.vc, a.ldv = tgt.data_ptr(), qpos.data_ptr(), kc.data_ptr(), kc.stride(0), vc.data_ptr(), vc.stride(0)
-    a.kpm = kpm.data_ptr() if kpm is not None else None
-    if amask is not None:
-        assert amask.dtype == torch.float32 and amask.is_contiguous() and amask.shape == (Q, Q)
-        a.amask = amask.data_ptr()
-    a.s_win, a.s_wo, a.c_wq, a.c_wo, a.w1, a.w2 = (f.data_ptr() for f in frags)
-    (a.s_bin, a.s_bo, a.c_bq, a.c_bo, a.b1, a.b2, a.g1, a.be1, a.g2, a.be2, a.g3, a.be3) = (v.data_ptr() for v in vecs)
-    a.out = out.data_ptr()
-    by = None
-    t1 = bf(M, D)
-    a.t1 = t1.data_ptr()
-    if train:
-        by = dict(tn=bf(M, D), tnp=bf(M, D), m1=f32(M), r1=f32(M), qk_s=bf(M, 2 * D), v_s=bf(M, D), ctx_s=bf(M, D), lse_s=f32(B, 8, Q),
-                  t1np=bf(M, D), m2=f32(M), r2=f32(M), q_c=bf(M, D), ctx_c=bf(M, D), lse_c=f32(B, 8, Q), t2=bf(M, D), m3=f32(M), r3=f32(M),
-                  t2n=bf(M, D), h=bf(M, FF))
-        for k_, v_ in by.items():
-            setattr(a, k_, v_.data_ptr())
-        by['t1'] = t1
-    a.B, a.Q, a.S, a.FF, a.drop_p = B, Q, S, FF, drop_p
-    for i in range(6):
-        a.seed[i] = seeds[i] & 0xffffffff
-    a.seed_ptr = seed_ptr.data_ptr() if seed_ptr is not None else None
-    L.check(L.load().sedt_decoder_layer_fwd(C.byref(a), L.stream_ptr()), 'decoder_layer_fwd')
-    del keep
-    return out, by
-
-
-# The FFN pair tiled in two dimensions (csrc/ffn_split.hip: 128 rows x a quarter of the hidden features per workgroup, in-launch reduction
-# over the quarters) behind the encoder's attention kernel.  Correct, bit-reproducible (tests/test_slab_gpu.py) and SLOWER than the FFN
-# inside the slab kernel: 58 us against ~35 us at M = 8192 (phase ablation, tools/dev/time_ffn_split.py: GEMMs 14 us, the dropout hashes
-# of the 16.8 M hidden elements 12 us - the same in either tiling -, the 16-byte write-through stores of the f32 partial sums and their
-# reduction 26 us; C2 step 5.37 -> 5.45 ms).  Opt-in: ops.SLAB_FFN_SPLIT = True.
-SLAB_FFN_SPLIT = _dev_env('SEDT_SLAB_FFN_SPLIT', '0') == '1'
-_FFN_CNT = {}
-
-
-def _ffn_counters(device, nblocks):
-    """the arrival counters of the split-FFN kernels: zero once, re-armed by every launch (launches are ordered on the training stream)"""
-    key = str(device)
-    c = _FFN_CNT.get(key)
-    if c is None or c.numel() < nblocks:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError('the split-FFN counters must exist before a capture (run one eager step first)')
-        c = _FFN_CNT[key] = torch.zeros(max(nblocks, 1024), device=device, dtype=torch.int32)
-    return c
-
-
-def ffn_split_ok(dtype, D, FF):
-    return bool(SLAB_FFN_SPLIT and dtype == BF16 and L.load().sedt_ffn_split_ok(D, FF, dtype))
-
-
-def encoder_attn_fwd2(x, qk, v, kpm, w_o_frag, b_o, gamma2, beta2, B, S, drop_p=0.0, seeds=(0, 0), seed_ptr=None, train=True):
-    """attention + out-proj + residual + LayerNorm2 per 32-token slab (the encoder kernel stopped before the FFN).  Returns (x1, x1n,
-    (ctx, lse, mean2, rstd2) or None)"""
-    _dev_check(x, qk, v)
-    M, D = x.shape
-    x1, x1n = torch.empty_like(x), torch.empty_like(x)
-    by = None
-    if train:
-        f32 = dict(device=x.device, dtype=torch.float32)
-        by = (torch.empty_like(x), torch.empty((B, 8, S), **f32), torch.empty((M,), **f32), torch.empty((M,), **f32))
-    s = by if by is not None else (None,) * 4
-    L.check(L.load().sedt_encoder_attn_fwd2(_p(x), _p(qk), _p(v), _p(kpm), _p(w_o_frag), _p(b_o), _p(gamma2), _p(beta2), _p(x1), _p(x1n),
-                                            _p(s[0]), _p(s[1]), _p(s[2]), _p(s[3]), B, S, drop_p, seeds[0] & 0xffffffff,
-                                            seeds[1] & 0xffffffff, _p(seed_ptr), L.stream_ptr()), 'encoder_attn_fwd2')
-    return x1, x1n, by
-
-
-def ffn_split_fwd(x1n, x1, w1_frag, b1, w2_frag, b2, FF, drop_p=0.0, seeds=(0, 0), seed_ptr=None, train=True, out=None):
-    """x2 = x1 + drop(drop(relu(x1n W1^T + b1)) W2^T + b2); seeds = (hidden, output).  Returns (x2, h or None)"""
-    _dev_check(x1n, x1)
-    M, D = x1n.shape
-    lib = L.load()
-    x2 = out if out is not None else torch.empty_like(x1)
-    h = torch.empty((M, FF), device=x1.device, dtype=x1.dtype) if train else None
-    part = torch.empty((lib.sedt_ffn_split_part_floats(M),), device=x1.device, dtype=torch.float32)
-    cnt = _ffn_counters(x1.device, lib.sedt_ffn_split_blocks(M))
-    L.check(lib.sedt_ffn_split_fwd(_p(x1n), _p(x1), _p(w1_frag), _p(b1), _p(w2_frag), _p(b2), _p(h), _p(x2), _p(part), _p(cnt), M, FF, drop_p,
-                                   seeds[0] & 0xffffffff, seeds[1] & 0xffffffff, _p(seed_ptr), L.stream_ptr()), 'ffn_split_fwd')
-    return x2, h
-
-
-def ffn_split_bwd(gx2, h, w2t_frag, w1t_frag, drop_p=0.0, seed_f=0, seed_ptr=None):
-    """returns (g2, gh, g_x1n): g2 = dropout'(gx2) (gx2 itself when drop_p == 0), gh = (g2 W2) [h > 0] / (1 - p), g_x1n = gh W1"""
-    _dev_check(gx2, h)
-    M, D = gx2.shape
-    FF = h.shape[1]
-    lib = L.load()
-    g2 = torch.empty_like(gx2) if drop_p > 0 else None
-    gh, gx1n = torch.empty_like(h), torch.empty_like(gx2)
-    part = torch.empty((lib.sedt_ffn_split_part_floats(M),), device=gx2.device, dtype=torch.float32)
-    cnt = _ffn_counters(gx2.device, lib.sedt_ffn_split_blocks(M))
-    L.check(lib.sedt_ffn_split_bwd(_p(gx2), _p(h), _p(w2t_frag), _p(w1t_frag), _p(g2), _p(gh), _p(gx1n), _p(part), _p(cnt), M, FF, drop_p,
-                                   seed_f & 0xffffffff, _p(seed_ptr), L.stream_ptr()), 'ffn_split_bwd')
-    return (g2 if g2 is not None else gx2), gh, gx1n
-
-
-def encoder_ln2_bwd(gx1n, gx2, x1, mean2, rstd2, gamma2, wot_frag, B, S, drop_p=0.0, seed_o=0, seed_ptr=None):
-    """gx1 = LayerNorm2'(g_x1n) + gx2; g1 = dropout'(gx1); gctx = g1 Wo.  Returns (gx1, g1, gctx, ln_part)"""
-    M, D = gx2.shape
-    gx1, gctx = torch.empty_like(gx2), torch.empty_like(gx2)
-    g1 = torch.empty_like(gx2) if drop_p > 0 else None
-    part = torch.empty((B * ((S + 31) // 32), 2 * D), device=gx2.device, dtype=torch.float32)
-    L.check(L.load().sedt_encoder_ln2_bwd(_p(gx1n), _p(gx2), _p(x1), _p(mean2), _p(rstd2), _p(gamma2), _p(wot_frag), _p(gx1), _p(g1), _p(gctx),
-                                          _p(part), B, S, drop_p, seed_o & 0xffffffff, _p(seed_ptr), L.stream_ptr()), 'encoder_ln2_bwd')
-    return gx1, (g1 if g1 is not None else gx1), gctx, part
 
 
 def encoder_ffn_bwd(gx2, h, x1, mean2, rstd2, gamma2, w2t_frag, w1t_frag, wot_frag, B, S, drop_p=0.0, seeds=(0, 0), seed_ptr=None):

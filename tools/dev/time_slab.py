@@ -65,18 +65,7 @@ for p_ in (0.1, 0.0):
 x2, by2 = ops.encoder_attn_ffn_fwd(x, qk, v, None, fr[1][0], b_o, gam2, bet2, fr[2][0], b1, fr[3][0], b2, B, S, FF, 0.1, (7, 3, 5, 6), None,
                                    train=True)
 ctx, lse, x1, m2, r2, x1n, h = by2
-x1b, x1nb, _ = ops.encoder_attn_fwd2(x, qk, v, None, fr[1][0], b_o, gam2, bet2, B, S, 0.1, (7, 3), None, train=True)
-t = timeit(lambda: ops.encoder_attn_fwd2(x, qk, v, None, fr[1][0], b_o, gam2, bet2, B, S, 0.1, (7, 3), None, train=True))
-print('enc_attn_fwd2 (attention + out-proj + LN2) %7.2f us' % t)
-for tr in (True, False):
-    t = timeit(lambda: ops.ffn_split_fwd(x1nb, x1b, fr[2][0], b1, fr[3][0], b2, FF, 0.1, (5, 6), None, train=tr))
-    print('ffn_split_fwd train=%d  %7.2f us' % (tr, t))
 gx2 = rnd(M, E)
-t = timeit(lambda: ops.ffn_split_bwd(gx2, h, fr[3][1], fr[2][1], 0.1, 6, None))
-print('ffn_split_bwd          %7.2f us' % t)
-_, _, gx1n_ = ops.ffn_split_bwd(gx2, h, fr[3][1], fr[2][1], 0.1, 6, None)
-t = timeit(lambda: ops.encoder_ln2_bwd(gx1n_, gx2, x1, m2, r2, gam2, fr[1][1], B, S, 0.1, 3, None))
-print('enc_ln2_bwd            %7.2f us' % t)
 if hasattr(ops, 'encoder_ffn_bwd'):
     t = timeit(lambda: ops.encoder_ffn_bwd(gx2, h, x1, m2, r2, gam2, fr[3][1], fr[2][1], fr[1][1], B, S, 0.1, (6, 3), None))
     print('enc_ffn_bwd            %7.2f us' % t)
@@ -91,28 +80,3 @@ t = timeit(lambda: ops.linear(dt, h, w2b, bias=b2, drop_p=0.1, seed=6, res=x1, l
 print('per-op linear2         %7.2f us' % t)
 t = timeit(lambda: ops.attention_fwd(dt, qk[:, :E], qk[:, E:], v, B, H, S, S, None, None, 0.1, 7, None))
 print('per-op attention core  %7.2f us' % t)
-
-if os.environ.get('ONLY_DEC'):
-    pass
-# ---- decoder layer: one launch per clip-workgroup vs the per-op chain
-from sound_event_detection_transformer_amd.sedt.transformer import TransformerDecoderLayer   # noqa: E402
-from sound_event_detection_transformer_amd import runtime   # noqa: E402
-runtime.set_compute_dtype('bf16')
-Q = int(os.environ.get('Q', 11))
-layer = TransformerDecoderLayer(256, 8, 2048, 0.1, 'relu', True).cuda().train()
-a_, c_ = layer.self_attn, layer.multihead_attn
-lin = [a_.in_proj_weight, a_.out_proj.weight, c_.in_proj_weight, c_.out_proj.weight, layer.linear1.weight, layer.linear2.weight]
-dplan = packing.PackPlan(dt, dev, [], lin, (), lin)
-tgt, qpos, mem, mp = rnd(B * Q, E), rnd(B * Q, E), rnd(M, E), rnd(M, E)
-with dplan:
-    for mode in (True, False):
-        ops.SLAB_DEC = mode
-        with torch.no_grad():
-            t = timeit(lambda: layer.forward_tokens(tgt, mem, mp, qpos, None, B, S, Q))
-        print('decoder layer fwd no-grad, %s %7.2f us' % ('slab (K|V projection + 1 launch)' if mode else 'per-op chain', t))
-    tg = tgt.clone().requires_grad_(True)
-    for mode in (True, False):
-        ops.SLAB_DEC = mode
-        t = timeit(lambda: layer.forward_tokens(tg, mem, mp, qpos, None, B, S, Q))
-        print('decoder layer fwd training form, %s %7.2f us' % ('slab' if mode else 'per-op chain', t))
-    ops.SLAB_DEC = False
