@@ -113,7 +113,8 @@ typedef struct SedtIgemm {
   uint8_t* bits_out;      /* or null: sign bits of the stored output (see "1-bit ReLU masks") */
   int64_t ldbits;         /* bytes per row of bits_out */
   int32_t mask_bits;      /* != 0: `mask` is a bit image, ldm in bytes */
-  int32_t pad_;
+  int32_t f32ep;          /* bf16 operands with an f32 epilogue (the fast bf16x3 mode, sedt_split3): C (out_f32 must be set), res and a
+                             non-bit mask are f32 tensors (ldc / ldr / ldm in f32 elements); trans == 0, LDS-DMA kernels only */
 } SedtIgemm;
 
 int sedt_igemm(const SedtIgemm* args, int dtype, void* stream);
@@ -153,6 +154,20 @@ typedef struct SedtPrefetch {
   size_t bytes[3];
 } SedtPrefetch;
 
+/* Operand preparation of the fast bf16x3 mode (csrc/split3.hip): src f32 [rows][cols] (row stride ld) -> dst bf16 [rows][3 * cols] =
+ * [hi | lo | hi] (pattern 0: an activation / gradient operand) or [hi | hi | lo] (pattern 1: a weight operand; rows = Cout * taps,
+ * cols = Cin), hi = bf16(x), lo = bf16(x - hi).  A bf16 GEMM over the tripled contraction axis (a convolution: Ci' = 3 Ci) then yields
+ * hi hi + lo hi + hi lo in its f32 accumulator: an f32 product to ~2^-16 at bf16 MFMA rate (with SedtIgemm.f32ep for the epilogue).
+ * Up to 4 jobs per launch (HOST array, copied into the kernel arguments).  cols and ld multiples of 4, src 16-byte aligned. */
+typedef struct SedtSplitJob {
+  const float* src;
+  int64_t ld;
+  void* dst;
+  int32_t rows, cols, pattern;
+  int32_t blk0;           /* filled by the library */
+} SedtSplitJob;
+int sedt_split3(const SedtSplitJob* jobs, int njobs, void* stream);
+
 /* up to SEDT_MAX_REDUCE_JOBS split-K reductions in ONE launch (jobs are copied into the kernel arguments, so a captured
  * graph holds them by value).  `jobs` is a HOST array; fields as the arguments of sedt_wgrad_reduce_bias. */
 #define SEDT_MAX_REDUCE_JOBS 40
@@ -163,7 +178,8 @@ typedef struct SedtReduceJob {
   const float* colsum_slab;
   float* bias_out;
   int32_t splitk, R, taps, Ci;
-  int32_t blk0, pad_;     /* blk0 is filled by the library */
+  int32_t blk0;           /* filled by the library */
+  int32_t cs_splitk;      /* slices of colsum_slab when they differ from splitk (0 = splitk) */
 } SedtReduceJob;
 int sedt_multi_wgrad_reduce(const SedtReduceJob* jobs, int njobs, const SedtPrefetch* pf, void* stream);
 

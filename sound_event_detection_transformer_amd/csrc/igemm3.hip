@@ -75,9 +75,14 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   constexpr int NCH = (BM * CPR + NT - 1) / NT;        // chunks per thread
   constexpr bool PARTIAL = BM * CPR % NT != 0;         // more threads than chunks (64x64 tile, 1024 threads): the upper threads idle
   static_assert(!PARTIAL || NCH == 1, "epilogue chunks must divide evenly, or be fewer than the threads");
-  const bf16_t* resT = reinterpret_cast<const bf16_t*>(p.res);
+  // f32ep (the bf16x3 mode, see sedt_split3): C, res and a non-bit mask are f32 tensors; they are read in the epilogue itself (no
+  // register prefetch: eight floats per chunk would double this kernel's epilogue registers for a mode that is MFMA-bound anyway)
+  const bool f32ep = p.f32ep != 0;
+  const bf16_t* resT = f32ep ? nullptr : reinterpret_cast<const bf16_t*>(p.res);
   const bool mbits = p.mask_bits != 0;                 // the mask is a 1-bit image: one BYTE per 8-column chunk
-  const bf16_t* maskT = mbits ? nullptr : reinterpret_cast<const bf16_t*>(p.mask);
+  const bf16_t* maskT = (mbits || f32ep) ? nullptr : reinterpret_cast<const bf16_t*>(p.mask);
+  const float* resF = f32ep ? reinterpret_cast<const float*>(p.res) : nullptr;
+  const float* maskF = (f32ep && !mbits) ? reinterpret_cast<const float*>(p.mask) : nullptr;
   const uint8_t* maskB = mbits ? reinterpret_cast<const uint8_t*>(p.mask) : nullptr;
   bf16x8 res_pf[NCH], mask_pf[NCH];
   uint32_t mbit_pf[NCH];
@@ -460,6 +465,13 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
     }
+    if (resF) {
+      int rrow = row;
+      if (p.res_mod > 0) rrow = row % p.res_mod;
+      const float4 r0 = *reinterpret_cast<const float4*>(resF + (long)rrow * p.ldr + col);
+      const float4 r1 = *reinterpret_cast<const float4*>(resF + (long)rrow * p.ldr + col + 4);
+      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
     if (relu_post) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -469,6 +481,13 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ((float)mv[e] > 0.f) ? v[e] : 0.f;
     }
+    if (maskF) {
+      const float4 q0 = *reinterpret_cast<const float4*>(maskF + (long)row * p.ldm + col);
+      const float4 q1 = *reinterpret_cast<const float4*>(maskF + (long)row * p.ldm + col + 4);
+      const float mv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
+    }
     if (maskB) {
       const uint32_t mb = mbit_pf[c];
 #pragma unroll
@@ -477,6 +496,18 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     if (p.alpha != 1.f) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+    }
+    if (f32ep) {
+      float* outF = reinterpret_cast<float*>(p.C) + (long)row * p.ldc + col;
+      *reinterpret_cast<float4*>(outF) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(outF + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      if (p.bits_out) {
+        uint32_t ob = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ob |= (v[e] > 0.f ? 1u : 0u) << e;
+        p.bits_out[(long)row * p.ldbits + (col >> 3)] = (uint8_t)ob;
+      }
+      continue;
     }
     bf16x8 o;
 #pragma unroll
@@ -817,11 +848,13 @@ int igemm_lds_try(const SedtIgemm& p, hipStream_t st) {
   if (p.trans) {
     return wgrad_lds_try(p, st);
   }
-  if (p.out_f32 || p.splitk > 1 || p.act == SEDT_ACT_SIGMOID) return -1;
+  if ((p.out_f32 != 0) != (p.f32ep != 0) || p.splitk > 1 || p.act == SEDT_ACT_SIGMOID) return -1;      // f32 C only with the f32 epilogue
+  if (p.f32ep && ((p.ldr & 3) || (p.ldm & 3) || (reinterpret_cast<uintptr_t>(p.res) & 15) ||
+                  (!p.mask_bits && (reinterpret_cast<uintptr_t>(p.mask) & 15)))) return -1;
   if ((p.K & 7) || (p.N & 7) || (p.lda & 7) || (p.ldb & 7) || (p.ldc & 7)) return -1;
   if (!al16(p.A) || !al16(p.B) || !al16(p.C)) return -1;
-  if (p.res && (!al16(p.res) || (p.ldr & 7))) return -1;
-  if (p.mask && !p.mask_bits && (!al16(p.mask) || (p.ldm & 7))) return -1;
+  if (!p.f32ep && p.res && (!al16(p.res) || (p.ldr & 7))) return -1;
+  if (!p.f32ep && p.mask && !p.mask_bits && (!al16(p.mask) || (p.ldm & 7))) return -1;
   if (p.conv && (p.Ci % BK2)) return -1;
   // bytes addressable through the A descriptor: every gathered pixel row + one K tile past its start
   long a_rows = p.conv ? (long)((p.M + (long)p.Ho * p.Wo - 1) / ((long)p.Ho * p.Wo)) * p.Hi * p.Wi : (long)p.M;

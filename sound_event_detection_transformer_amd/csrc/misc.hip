@@ -89,14 +89,15 @@ __global__ __launch_bounds__(256) void multi_wgrad_reduce_kernel(const ReduceJob
       float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
       if (col < J.R) {
         const float* cp = J.colsum_slab + col;
+        const int csk = J.cs_splitk > 0 ? J.cs_splitk : J.splitk;      // (the column sums may have fewer slices than the slabs: bf16x3)
         int z = zg;
-        for (; z + 12 < J.splitk; z += 16) {
+        for (; z + 12 < csk; z += 16) {
           b0 += cp[(long)z * J.R];
           b1 += cp[(long)(z + 4) * J.R];
           b2 += cp[(long)(z + 8) * J.R];
           b3 += cp[(long)(z + 12) * J.R];
         }
-        for (; z < J.splitk; z += 4) b0 += cp[(long)z * J.R];
+        for (; z < csk; z += 4) b0 += cp[(long)z * J.R];
       }
       csum[zg][threadIdx.x & 63] = (b0 + b1) + (b2 + b3);
       __syncthreads();

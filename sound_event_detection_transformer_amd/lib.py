@@ -41,14 +41,14 @@ class SedtIgemm(C.Structure):
         ('splitk', C.c_int32), ('slab', C.c_void_p),
         ('tile_m', C.c_int32), ('tile_n', C.c_int32),
         ('colsum_out', C.c_void_p),
-        ('bits_out', C.c_void_p), ('ldbits', C.c_int64), ('mask_bits', C.c_int32), ('pad_', C.c_int32),
+        ('bits_out', C.c_void_p), ('ldbits', C.c_int64), ('mask_bits', C.c_int32), ('f32ep', C.c_int32),
     ]
 
 
 class SedtReduceJob(C.Structure):
     _fields_ = [('slab', C.c_void_p), ('rowscale', C.c_void_p), ('out', C.c_void_p), ('colsum_slab', C.c_void_p),
                 ('bias_out', C.c_void_p), ('splitk', C.c_int32), ('R', C.c_int32), ('taps', C.c_int32), ('Ci', C.c_int32),
-                ('blk0', C.c_int32), ('pad_', C.c_int32)]
+                ('blk0', C.c_int32), ('cs_splitk', C.c_int32)]
 
 
 CRIT_MAXL = 8
@@ -72,6 +72,11 @@ class SedtMatch(C.Structure):
                 ('fl', C.c_int32), ('fine_tune', C.c_int32), ('normalize', C.c_int32), ('alpha_fl', C.c_float),
                 ('gamma_fl', C.c_float), ('epsilon', C.c_float), ('alpha', C.c_float), ('ft_rand', C.c_void_p),
                 ('ft_seed', C.c_uint32), ('seed_ptr', C.c_void_p), ('split', C.c_void_p), ('Qs', C.c_int32), ('q0', C.c_int32)]
+
+
+class SedtSplitJob(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('ld', C.c_int64), ('dst', C.c_void_p), ('rows', C.c_int32), ('cols', C.c_int32),
+                ('pattern', C.c_int32), ('blk0', C.c_int32)]
 
 
 class SedtPrefetch(C.Structure):
@@ -104,6 +109,7 @@ SIGNATURES = {
     'sedt_igemm_describe': (_i, [C.POINTER(SedtIgemm), _i, _i, C.c_char_p, _i]),
     'sedt_wgrad_reduce': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sedt_wgrad_reduce_bias': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'sedt_split3': (_i, [C.POINTER(SedtSplitJob), _i, _vp]),
     'sedt_multi_wgrad_reduce': (_i, [C.POINTER(SedtReduceJob), _i, C.POINTER(SedtPrefetch), _vp]),
     'sedt_skinny_linear_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     'sedt_skinny_linear_bwd_scratch': (_sz, [_i]),

@@ -134,7 +134,7 @@ class WgradPool(object):
         lib = L.load()
         while self.gemms:
             chunk, self.gemms = self.gemms[:10], self.gemms[10:]
-            arr = (L.SedtIgemm * len(chunk))(*[a for a, _ in chunk])
+            arr = (L.SedtIgemm * len(chunk))(*[c[0] for c in chunk])
             L.check(lib.sedt_wgrad_group(arr, len(chunk), L.gemm_dtype(self.dtype), L.stream_ptr()), 'wgrad_group')
         while self.reduces:
             chunk, self.reduces = self.reduces[:L.MAX_REDUCE_JOBS], self.reduces[L.MAX_REDUCE_JOBS:]
@@ -165,8 +165,108 @@ class coschedule(object):
         return False
 
 
+# ---- the fast bf16x3 mode (csrc/split3.hip): an f32-mode GEMM whose shape fits the LDS-DMA kernels runs as ONE bf16 GEMM over a three
+# times longer contraction axis, on operands split once into bf16 [hi | lo | hi] / [hi | hi | lo] images, with an f32 epilogue.
+# X3_FAST = False keeps every contraction of the mode on the register-staged generic kernel (csrc/igemm.hip, the round-4 form).
+X3_FAST = _dev_env('SEDT_X3_FAST', '1') != '0'
+
+
+# An activation / gradient is a GEMM operand twice per step (x: its layer's forward and weight gradient; dY: input and weight gradient):
+# its [hi | lo | hi] image is kept from the first use to the second.  Keyed by (pointer, rows, cols, row stride); an entry holds the
+# SOURCE tensor as well, so the caching allocator cannot hand that memory to another tensor while the entry lives (a key can only ever
+# mean one tensor's contents - nothing on this path rewrites a GEMM operand in place).  Emptied when a model forward starts
+# (packing.PlanSet / PackPlan) and by the optimizer step.
+X3_CACHE = {}
+X3_CACHE_ON = _dev_env('SEDT_X3_CACHE', '1') != '0'
+
+
+def x3_cache_clear():
+    X3_CACHE.clear()
+
+
+def _split3(jobs):
+    """jobs: (tensor, element offset of the view's first element, rows, cols, row stride, pattern); one launch for up to four.  Returns the
+    bf16 [rows, 3 * cols] images"""
+    outs, todo = [None] * len(jobs), []
+    for i, (t, off, rows, cols, ld, pattern) in enumerate(jobs):
+        key = (t.data_ptr() + 4 * off, rows, cols, ld)
+        hit = X3_CACHE.get(key) if (pattern == 0 and X3_CACHE_ON) else None
+        if hit is not None:
+            outs[i] = hit[1]
+            continue
+        d = torch.empty((rows, 3 * cols), device=t.device, dtype=torch.bfloat16)
+        outs[i] = d
+        todo.append((i, key))
+        if pattern == 0 and X3_CACHE_ON:
+            X3_CACHE[key] = (t, d)
+    if todo:
+        arr = (L.SedtSplitJob * len(todo))()
+        for n, (i, key) in enumerate(todo):
+            t, off, rows, cols, ld, pattern = jobs[i]
+            arr[n].src, arr[n].ld, arr[n].dst = key[0], ld, outs[i].data_ptr()
+            arr[n].rows, arr[n].cols, arr[n].pattern = rows, cols, pattern
+        L.check(L.load().sedt_split3(arr, len(todo), L.stream_ptr()), 'split3')
+    return outs
+
+
+def _x3_rows(M, conv):
+    """rows of the gathered operand: the pixels of the B images behind the M output rows (conv = igemm_args' geometry tuple)"""
+    if conv is None:
+        return M
+    Hi, Wi, _, Ho, Wo = conv[:5]
+    return (M // (Ho * Wo)) * Hi * Wi
+
+
+def _x3_fast_ok(M, N, K, A, lda, B, ldb, Cout, ldc, kw):
+    """envelope of the LDS-DMA forward / dgrad kernels on the tripled contraction (igemm_lds_try, csrc/igemm3.hip) with f32 epilogue operands"""
+    conv = kw.get('conv')
+    if not X3_FAST or kw.get('trans', 0) or kw.get('splitk', 1) > 1 or kw.get('act', ACT_NONE) == ACT_SIGMOID or kw.get('slab') is not None:
+        return False
+    if Cout is None or Cout.dtype != torch.float32 or A.dtype != torch.float32 or B.dtype != torch.float32:
+        return False
+    Ci = conv[2] if conv is not None else K
+    if K % 64 or Ci % 64 or N % 8 or ldc % 8 or lda % 4 or ldb % 4 or A.data_ptr() % 16 or B.data_ptr() % 16 or Cout.data_ptr() % 16:
+        return False
+    if conv is not None:
+        taps = conv[5] * conv[6]
+        if ldb != K or taps * Ci != K or taps > 32 or M % (conv[3] * conv[4]):
+            return False
+        if kw.get('transposed', 0) and (conv[7] != conv[8] or (3 * Ci) % conv[7]):
+            return False
+    res, mask = kw.get('res'), kw.get('mask')
+    if res is not None and (res.dtype != torch.float32 or res.data_ptr() % 16 or kw.get('ldr', 0) % 4):
+        return False
+    if mask is not None and not kw.get('mask_bits') and (mask.dtype != torch.float32 or mask.data_ptr() % 16 or kw.get('ldm', 0) % 4):
+        return False
+    rows = _x3_rows(M, conv)
+    return rows * 3 * Ci * 2 < (1 << 31) and N * 3 * K * 2 < (1 << 31)
+
+
+def _igemm_x3_fast(M, N, K, A, lda, B, ldb, Cout, ldc, kw):
+    conv = kw.get('conv')
+    Ci = conv[2] if conv is not None else K
+    rows = _x3_rows(M, conv)
+    wjob = (B, 0, N * (K // Ci), Ci, Ci, 1) if conv is not None else (B, 0, N, K, ldb, 1)
+    A3, B3 = _split3([(A, 0, rows, Ci, lda, 0), wjob])
+    kw = dict(kw)
+    if conv is not None:
+        kw['conv'] = (conv[0], conv[1], 3 * Ci) + tuple(conv[3:])
+    kw['out_f32'] = 1
+    a = igemm_args(M, N, 3 * K, A3, 3 * Ci, B3, 3 * K, Cout, ldc, **kw)
+    a.f32ep = 1
+    if PROFILE is not None:
+        PROFILE.append((a, BF16, (M, N, 3 * K, 0, 0 if conv is None else 1), (A, B, Cout, kw, A3, B3), PROFILE_HINT))
+    if L.LAUNCH_LOG is not None:
+        buf = C.create_string_buffer(160)
+        if L.load().sedt_igemm_describe(C.byref(a), BF16, 0, buf, 160) == 0:
+            L.LAUNCH_LOG['igemm_x3:' + buf.value.decode()] += 1
+    L.check(L.load().sedt_igemm(C.byref(a), BF16, L.stream_ptr()), 'sedt_igemm_x3')
+
+
 def igemm(dtype, M, N, K, A, lda, B, ldb, Cout, ldc, **kw):
     """raw implicit GEMM call (arguments as igemm_args)"""
+    if dtype == F32 and L.GEMM_X3 and _x3_fast_ok(M, N, K, A, lda, B, ldb, Cout, ldc, kw):
+        return _igemm_x3_fast(M, N, K, A, lda, B, ldb, Cout, ldc, kw)
     a = igemm_args(M, N, K, A, lda, B, ldb, Cout, ldc, **kw)
     conv, trans = kw.get('conv'), kw.get('trans', 0)
     if _co['on'] and POOL.gemms and not trans and dtype == BF16:
@@ -265,7 +365,7 @@ def linear_group(dtype, items):
             out = torch.empty((M, N), device=x.device, dtype=torch.float32 if out_f32 else TORCH_DTYPE[dtype])
         outs.append(out)
         args.append(((M, N, K, x, x.stride(0), w, w.stride(0), out, out.stride(0)), dict(out_f32=int(out_f32), **kw)))
-    if len(args) == 1 or PROFILE is not None or (_co['on'] and POOL.gemms):
+    if len(args) == 1 or PROFILE is not None or (_co['on'] and POOL.gemms) or (dtype == F32 and L.GEMM_X3 and X3_FAST):
         global PROFILE_HINT
         PROFILE_HINT = 'igemm_group' if len(args) > 1 else None
         for a, kw in args:
@@ -340,9 +440,10 @@ class ReduceBatch(object):
         self.jobs, self.keep, self.deferred, self.operands = [], [], [], []
         self.group, self.group_dtype = [], None
 
-    def add_gemm(self, dtype, args, shape):
-        """a weight-gradient GEMM to be issued with the others of this batch in one grouped launch"""
-        self.group.append((args, shape))
+    def add_gemm(self, dtype, args, shape, code=None):
+        """a weight-gradient GEMM to be issued with the others of this batch in one grouped launch.  code: the dtype code the entry point
+        gets when it is not gemm_dtype(dtype) - the fast bf16x3 problems are bf16 problems on split operands"""
+        self.group.append((args, shape, L.gemm_dtype(dtype) if code is None else code))
         self.group_dtype = dtype
 
     def _launch_group(self):
@@ -350,21 +451,28 @@ class ReduceBatch(object):
             return
         lib = L.load()
         if PROFILE is not None:                       # bench.py replays every GEMM on its own for the per-launch timing
-            for a, shape in self.group:
-                L.check(lib.sedt_igemm(C.byref(a), L.gemm_dtype(self.group_dtype), L.stream_ptr()), 'sedt_igemm')
-                PROFILE.append((a, L.gemm_dtype(self.group_dtype), shape, (list(self.keep), list(self.operands)), 'wgrad_group'))
+            for a, shape, code in self.group:
+                L.check(lib.sedt_igemm(C.byref(a), code, L.stream_ptr()), 'sedt_igemm')
+                PROFILE.append((a, code, shape, (list(self.keep), list(self.operands)), 'wgrad_group'))
         else:
-            arr = (L.SedtIgemm * len(self.group))(*[a for a, _ in self.group])
-            L.check(lib.sedt_wgrad_group(arr, len(self.group), L.gemm_dtype(self.group_dtype), L.stream_ptr()), 'wgrad_group')
+            i = 0
+            while i < len(self.group):                # runs of equal dtype code: one grouped launch each
+                j = i
+                while j < len(self.group) and self.group[j][2] == self.group[i][2]:
+                    j += 1
+                arr = (L.SedtIgemm * (j - i))(*[g[0] for g in self.group[i:j]])
+                L.check(lib.sedt_wgrad_group(arr, j - i, self.group[i][2], L.stream_ptr()), 'wgrad_group')
+                i = j
         self.group = []
 
     def defer(self, body, operands):
         self.deferred.append(body)
         self.operands.extend(t for t in operands if t is not None)
 
-    def add(self, slab, sk, R, taps, Ci, rowscale, out, cs, bias_out):
+    def add(self, slab, sk, R, taps, Ci, rowscale, out, cs, bias_out, cs_splitk=0):
         j = L.SedtReduceJob()
         j.slab, j.out, j.splitk, j.R, j.taps, j.Ci = slab.data_ptr(), out.data_ptr(), sk, R, taps, Ci
+        j.cs_splitk = cs_splitk
         j.rowscale = rowscale.data_ptr() if rowscale is not None else None
         j.colsum_slab = cs.data_ptr() if cs is not None else None
         j.bias_out = bias_out.data_ptr() if (cs is not None and bias_out is not None) else None
@@ -449,6 +557,18 @@ def _sink(param, shape):
     return v.view(shape) if v is not None and v.numel() == int(np.prod(shape)) else None
 
 
+def _x3_wgrad_ok(dy, x, g, B):
+    """envelope of the LDS-DMA weight-gradient kernels (wgrad_lds_envelope + wgrad3_conv_ok, csrc/wgrad3.hip) on the split operands"""
+    if not X3_FAST or dy.dtype != torch.float32 or x.dtype != torch.float32:
+        return False
+    Co, Ci = g.Co, g.Ci
+    if Co % 8 or Ci % 8 or dy.stride(0) % 4 or x.stride(0) % 4 or dy.data_ptr() % 16 or x.data_ptr() % 16:
+        return False
+    if not g.plain and ((64 % g.Wo) != 0 or g.Ho * g.Wo < 64 or g.Ho < 64 // g.Wo):
+        return False
+    return B * g.Ho * g.Wo * 3 * Co * 2 < (1 << 31) and B * g.Hi * g.Wi * 3 * Ci * 2 < (1 << 31)
+
+
 def wgrad(dtype, dy, x, B, g, rowscale=None, out=None, bias_out=None, batch=None, param=None):
     """dW (Co, Ci, KH, KW) f32 = sum over pixels dy[pix][co] * gather(x)[pix][tap][ci] (* rowscale[co]).
     bias_out (f32 [Co]): also receives sum over pixels of dy (fused into the wgrad kernel when it can, else a colsum).
@@ -464,8 +584,29 @@ def wgrad(dtype, dy, x, B, g, rowscale=None, out=None, bias_out=None, batch=None
         out = torch.empty((g.Co, g.Ci, g.KH, g.KW), device=dy.device, dtype=torch.float32)
 
     def body():
-        slab = torch.empty((sk, Mo, No), device=dy.device, dtype=torch.float32)
         conv = None if g.plain else _geom_tuple(g)
+        if dtype == F32 and L.GEMM_X3 and _x3_wgrad_ok(dy, x, g, B):
+            # fast bf16x3 (csrc/split3.hip): both operands split once, hi hi + lo hi as ONE problem over [dY_hi | dY_lo], hi lo as a second,
+            # 3 sk slabs of [Co][taps Ci] for the reduce launch
+            sk3 = max(1, lib.sedt_igemm_splitk(2 * Mo, No, Kp, BF16))
+            rows_x = B * g.Hi * g.Wi
+            dy3, x3 = _split3([(dy, 0, Kp, Mo, dy.stride(0), 0), (x, 0, rows_x, g.Ci, x.stride(0), 0)])
+            slab = torch.empty((3 * sk3, Mo, No), device=dy.device, dtype=torch.float32)
+            cs = torch.empty((2 * sk3, Mo), device=dy.device, dtype=torch.float32) if bias_out is not None else None
+            a1 = igemm_args(2 * Mo, No, Kp, dy3, 3 * Mo, x3, 3 * g.Ci, slab, No, trans=1, conv=conv, out_f32=1, splitk=sk3, slab=slab,
+                            colsum_out=cs)
+            x3lo, slab2 = x3[:, g.Ci:2 * g.Ci], slab[2 * sk3:]
+            a2 = igemm_args(Mo, No, Kp, dy3, 3 * Mo, x3lo, 3 * g.Ci, slab2, No, trans=1, conv=conv, out_f32=1, splitk=sk3, slab=slab2)
+            tb = batch if batch is not None else ReduceBatch()
+            tb.add_gemm(dtype, a1, (2 * Mo, No, Kp, 1, 0 if conv is None else 1), code=BF16)
+            tb.add_gemm(dtype, a2, (Mo, No, Kp, 1, 0 if conv is None else 1), code=BF16)
+            tb.add(slab, 3 * sk3, Mo, g.taps, g.Ci, rowscale, out, cs, bias_out, cs_splitk=2 * sk3)
+            tb.keep.append((dy3, x3, None, None, None))
+            if batch is None:
+                tb._launch_group()
+                tb._launch()
+            return
+        slab = torch.empty((sk, Mo, No), device=dy.device, dtype=torch.float32)
         fused = bias_out is not None and _fused_bias_ok(dtype, dy, x, g)
         cs = torch.empty((sk, Mo), device=dy.device, dtype=torch.float32) if fused else None
         if batch is not None:

@@ -218,6 +218,8 @@ class FusedAdamW(torch.optim.Optimizer):
         """from_flat: read the gradients from the flat buffer filled by gather_grads() (and all-reduced by the caller)"""
         if closure is not None:
             raise NotImplementedError
+        from . import ops
+        ops.x3_cache_clear()                      # (the backward is over: the bf16x3 operand images of this step can go)
         if self._static is None:
             self._build()
         ps = self._ps

@@ -210,6 +210,8 @@ class PackPlan(object):
             L.check(lib.sedt_pack_frag(L.p(self._dev_fj), len(self._fj), self._fr_blocks, L.stream_ptr()), 'pack_frag')
 
     def __enter__(self):
+        from . import ops
+        ops.x3_cache_clear()                      # (a forward starts: no operand image of an earlier step is needed any more)
         self.run()
         _active.append(self)
         return self
@@ -246,6 +248,8 @@ class PlanSet(object):
         return self.plans[-1]
 
     def __enter__(self):
+        from . import ops
+        ops.x3_cache_clear()
         self._cur = self.current()
         self._cur.run(self._key3)
         _active.append(self._cur)

@@ -303,13 +303,14 @@ def test_graphed_semi_step_with_mixup_matches_eager(pkg):
             losses.append(float(total))
         res[mode] = (losses, {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()},
                      {k: v.detach().float().cpu().clone() for k, v in ema.shadow.items()})
-    runtime.set_compute_dtype('f32')
+    x3 = runtime.compute_mode() == 'bf16x3'      # (the --x3 run: LDS-DMA kernels, whose summation order follows the row count - the fused
+    runtime.set_compute_dtype('f32')             # student forward of the graph and the eager step's two passes differ in the last bit)
     assert len(set(splits)) > 1, splits                                   # the split really was data
-    np.testing.assert_allclose(res['graph'][0], res['eager'][0], rtol=1e-4)
+    np.testing.assert_allclose(res['graph'][0], res['eager'][0], rtol=2e-3 if x3 else 1e-4)
     for k in res['eager'][1]:
-        assert rel(res['graph'][1][k], res['eager'][1][k]) < 2e-3, k
+        assert rel(res['graph'][1][k], res['eager'][1][k]) < (1e-2 if x3 else 2e-3), k
     for k in res['eager'][2]:
-        assert rel(res['graph'][2][k], res['eager'][2][k]) < 2e-3, k
+        assert rel(res['graph'][2][k], res['eager'][2][k]) < (1e-2 if x3 else 2e-3), k
 
 
 def test_graphed_train_step_with_mixup_matches_eager(pkg):

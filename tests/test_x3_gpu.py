@@ -54,6 +54,79 @@ def test_x3_gemm_error_sits_between_bf16_and_f32():
     assert ((got - refc).abs().max() / refc.abs().max()).item() < 3e-5
 
 
+def test_x3_fast_path_on_the_lds_dma_kernels_against_f64():
+    """the FAST form of the mode (csrc/split3.hip: operands split once into bf16 [hi | lo | hi] / [hi | hi | lo] images, ONE bf16 GEMM over
+    the tripled contraction on the LDS-DMA kernels, f32 epilogue): a linear layer with every epilogue operand, a dilated 3x3 convolution,
+    a stride-2 3x3 input gradient and two weight gradients (plain with the fused bias sums; 3x3 conv), each against f64 at the mode's
+    3e-5 - and each must have gone through the fast path (launch log), not the generic kernel"""
+    import torch.nn.functional as F
+    from sound_event_detection_transformer_amd import ops, lib as L
+    g = torch.Generator().manual_seed(8)
+
+    def rel(got, ref):
+        return ((got.double() - ref).abs().max() / ref.abs().max()).item()
+
+    L.GEMM_X3 = True
+    try:
+        with L.launch_log() as log:
+            # ---- linear: y = relu(x W^T * scale + bias + res) masked by the bits of m, sign bits out
+            M, N, K = 8192, 256, 2048
+            x = torch.randn(M, K, generator=g).cuda()
+            w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+            bias, scale = torch.randn(N, generator=g).cuda(), (1 + 0.1 * torch.randn(N, generator=g)).cuda()
+            res = torch.randn(M, N, generator=g).cuda()
+            bits = torch.empty((M, N // 8), dtype=torch.uint8, device='cuda')
+            y = ops.linear(L.F32, x, w, bias=bias, scale=scale, res=res, ldr=N, act=ops.ACT_RELU, act_post_res=1, bits_out=bits)
+            ref = torch.relu((x.double() @ w.double().t()) * scale.double() + bias.double() + res.double())
+            assert rel(y, ref) < 3e-5
+            want = (y > 0).view(M, N // 8, 8).to(torch.uint8)
+            assert torch.equal(bits, (want << torch.arange(8, device='cuda', dtype=torch.uint8)).sum(-1).to(torch.uint8))
+            # ... and a dgrad-style call: f32 mask tensor, alpha
+            mk = torch.randn(M, N, generator=g).cuda()
+            y2 = ops.linear(L.F32, x, w, mask=mk, ldm=N, alpha=0.5)
+            assert rel(y2, 0.5 * (x.double() @ w.double().t()) * (mk > 0)) < 3e-5
+            # ---- dilated 3x3 convolution, FrozenBN affine + ReLU (the layer4 conv2 geometry at a small batch)
+            B, H, W, Ci, Co = 3, 32, 4, 512, 512
+            geo = ops.ConvGeom(H, W, Ci, Co, 3, 1, 2, 2)
+            xi = torch.randn(B * H * W, Ci, generator=g).cuda()
+            wc = (torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5).cuda()
+            wf, wb = ops.pack_conv(L.F32, wc)
+            yc = ops.conv_fwd(L.F32, xi, B, geo, wf, scale=scale.repeat(2), bias=bias.repeat(2), act=ops.ACT_RELU)
+            xn = xi.view(B, H, W, Ci).permute(0, 3, 1, 2).double()
+            refc = torch.relu(F.conv2d(xn, wc.double(), padding=2, dilation=2) * scale.repeat(2).double().view(1, -1, 1, 1)
+                              + bias.repeat(2).double().view(1, -1, 1, 1))
+            assert rel(yc.view(B, H, W, Co).permute(0, 3, 1, 2), refc) < 3e-5
+            # ---- stride-2 3x3 input gradient (the layer3 block 0 geometry: 63 x 8 -> 32 x 4)
+            g2 = ops.ConvGeom(63, 8, 256, 256, 3, 2, 1, 1)
+            w2 = (torch.randn(256, 256, 3, 3, generator=g) / (9 * 256) ** 0.5).cuda()
+            _, w2b = ops.pack_conv(L.F32, w2)
+            dy = torch.randn(B * g2.Ho * g2.Wo, 256, generator=g).cuda()
+            dx = ops.conv_dgrad(L.F32, dy, B, g2, w2b)
+            dyn = dy.view(B, g2.Ho, g2.Wo, 256).permute(0, 3, 1, 2).double()
+            refd = F.conv_transpose2d(dyn, w2.double(), stride=2, padding=1, output_padding=(0, 1))
+            assert refd.shape[2:] == (63, 8)
+            assert rel(dx.view(B, 63, 8, 256).permute(0, 3, 1, 2), refd) < 3e-5
+            # ---- weight gradients: plain (+ fused bias column sums), and the dilated 3x3
+            gy = torch.randn(M, N, generator=g).cuda()
+            db = torch.empty(N, device='cuda')
+            rb = ops.ReduceBatch()
+            dw = ops.linear_wgrad(L.F32, gy, x, bias_out=db, batch=rb)
+            gyc = torch.randn(B * H * W, Co, generator=g).cuda()
+            dwc = ops.wgrad(L.F32, gyc, xi, B, geo, rowscale=scale.repeat(2), batch=rb)
+            rb.flush()
+            assert rel(dw, gy.double().t() @ x.double()) < 3e-5 and rel(db, gy.double().sum(0)) < 3e-5
+            gn = gyc.view(B, H, W, Co).permute(0, 3, 1, 2).double()
+            refw = torch.nn.grad.conv2d_weight(xn, wc.shape, gn, padding=2, dilation=2) * scale.repeat(2).double().view(-1, 1, 1, 1)
+            assert rel(dwc, refw) < 3e-5
+            dw1 = ops.linear_wgrad(L.F32, gy, x)                      # (no batch: launched on the spot)
+            assert rel(dw1, gy.double().t() @ x.double()) < 3e-5
+        torch.cuda.synchronize()
+    finally:
+        L.GEMM_X3 = False
+    assert log['sedt_igemm_x3'] == 4 and log['split3'] == 4 + 3 and log['wgrad_group'] == 2 and log['sedt_igemm'] == 0, dict(log)
+    assert all(k.split(':')[1].startswith('igemm3') for k in log if k.startswith('igemm_x3:')), dict(log)
+
+
 # the checks of the f32-mode modules that pin individual GRADIENT ELEMENTS (or their norms to 2e-3, or directions to cosine 1 - 5e-6): a product
 # error of 2^-16 is 256 x the exact-f32 one, and through a 60-layer backward with heavy cancellation it shows at 2-4e-3 on single
 # elements - measured below (test_x3_gradients_against_the_oracle) instead of asserted at the f32 mode's tolerances
