@@ -115,6 +115,8 @@ typedef struct SedtIgemm {
   int32_t mask_bits;      /* != 0: `mask` is a bit image, ldm in bytes */
   int32_t f32ep;          /* bf16 operands with an f32 epilogue (the fast bf16x3 mode, sedt_split3): C (out_f32 must be set), res and a
                              non-bit mask are f32 tensors (ldc / ldr / ldm in f32 elements); trans == 0, LDS-DMA kernels only */
+  void* split_out;        /* f32ep only, or null: bf16 [M][3 N] = the [hi | lo | hi] operand image (sedt_split3, pattern 0) of the stored
+                             output, written by the epilogue - the GEMMs that consume this output then need no split pass */
 } SedtIgemm;
 
 int sedt_igemm(const SedtIgemm* args, int dtype, void* stream);

@@ -507,6 +507,18 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
         for (int e = 0; e < 8; ++e) ob |= (v[e] > 0.f ? 1u : 0u) << e;
         p.bits_out[(long)row * p.ldbits + (col >> 3)] = (uint8_t)ob;
       }
+      if (p.split_out) {        // the [hi | lo | hi] operand image of what was stored (sedt_split3, pattern 0) for the GEMMs that consume it
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          hi[e] = (bf16_t)v[e];
+          lo[e] = (bf16_t)(v[e] - (float)hi[e]);
+        }
+        bf16_t* sp = reinterpret_cast<bf16_t*>(p.split_out) + (long)row * (3L * p.N) + col;
+        *reinterpret_cast<bf16x8*>(sp) = hi;
+        *reinterpret_cast<bf16x8*>(sp + p.N) = lo;
+        *reinterpret_cast<bf16x8*>(sp + 2L * p.N) = hi;
+      }
       continue;
     }
     bf16x8 o;

@@ -41,7 +41,7 @@ class SedtIgemm(C.Structure):
         ('splitk', C.c_int32), ('slab', C.c_void_p),
         ('tile_m', C.c_int32), ('tile_n', C.c_int32),
         ('colsum_out', C.c_void_p),
-        ('bits_out', C.c_void_p), ('ldbits', C.c_int64), ('mask_bits', C.c_int32), ('f32ep', C.c_int32),
+        ('bits_out', C.c_void_p), ('ldbits', C.c_int64), ('mask_bits', C.c_int32), ('f32ep', C.c_int32), ('split_out', C.c_void_p),
     ]
 
 

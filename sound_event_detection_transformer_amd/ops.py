@@ -178,6 +178,7 @@ X3_FAST = _dev_env('SEDT_X3_FAST', '1') != '0'
 # (packing.PlanSet / PackPlan) and by the optimizer step.
 X3_CACHE = {}
 X3_CACHE_ON = _dev_env('SEDT_X3_CACHE', '1') != '0'
+X3_SPLIT_OUT = _dev_env('SEDT_X3_SPLIT_OUT', '1') != '0'      # GEMM epilogues write the operand image of outputs that feed GEMMs again
 
 
 def x3_cache_clear():
@@ -254,6 +255,14 @@ def _igemm_x3_fast(M, N, K, A, lda, B, ldb, Cout, ldc, kw):
     kw['out_f32'] = 1
     a = igemm_args(M, N, 3 * K, A3, 3 * Ci, B3, 3 * K, Cout, ldc, **kw)
     a.f32ep = 1
+    # outputs that feed GEMMs again - a ReLU'd activation (the Bottleneck chain, the FFN's hidden layer, the box MLP) or a masked
+    # gradient (the dgrad chain: the next input gradient AND a weight gradient read it) - leave their operand image from the epilogue:
+    # the consumers find it in the cache instead of running a split pass (read 4 B + write 6 B per element and a launch saved)
+    img = None
+    if X3_CACHE_ON and X3_SPLIT_OUT and (kw.get('act', ACT_NONE) == ACT_RELU or kw.get('mask') is not None) and N % 8 == 0:
+        img = torch.empty((M, 3 * N), device=Cout.device, dtype=torch.bfloat16)
+        a.split_out = img.data_ptr()
+        X3_CACHE[(Cout.data_ptr(), M, N, ldc)] = (Cout, img)
     if PROFILE is not None:
         PROFILE.append((a, BF16, (M, N, 3 * K, 0, 0 if conv is None else 1), (A, B, Cout, kw, A3, B3), PROFILE_HINT))
     if L.LAUNCH_LOG is not None:

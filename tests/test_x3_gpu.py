@@ -81,6 +81,11 @@ def test_x3_fast_path_on_the_lds_dma_kernels_against_f64():
             assert rel(y, ref) < 3e-5
             want = (y > 0).view(M, N // 8, 8).to(torch.uint8)
             assert torch.equal(bits, (want << torch.arange(8, device='cuda', dtype=torch.uint8)).sum(-1).to(torch.uint8))
+            # the epilogue left the [hi | lo | hi] operand image of this ReLU'd output for its consumers: exactly what a split pass gives
+            img = ops.X3_CACHE[(y.data_ptr(), M, N, N)][1]
+            hi = y.bfloat16()
+            lo = (y - hi.float()).bfloat16()
+            assert torch.equal(img, torch.cat([hi, lo, hi], 1))
             # ... and a dgrad-style call: f32 mask tensor, alpha
             mk = torch.randn(M, N, generator=g).cuda()
             y2 = ops.linear(L.F32, x, w, mask=mk, ldm=N, alpha=0.5)
@@ -123,7 +128,9 @@ def test_x3_fast_path_on_the_lds_dma_kernels_against_f64():
         torch.cuda.synchronize()
     finally:
         L.GEMM_X3 = False
-    assert log['sedt_igemm_x3'] == 4 and log['split3'] == 4 + 3 and log['wgrad_group'] == 2 and log['sedt_igemm'] == 0, dict(log)
+    # (split passes: one per forward / dgrad call - its weight operand at least -, fewer than one per weight gradient: x, xi and gy images
+    # are found in the step's operand-image cache)
+    assert log['sedt_igemm_x3'] == 4 and 4 <= log['split3'] <= 7 and log['wgrad_group'] == 2 and log['sedt_igemm'] == 0, dict(log)
     assert all(k.split(':')[1].startswith('igemm3') for k in log if k.startswith('igemm_x3:')), dict(log)
 
 
