@@ -86,18 +86,29 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   const uint8_t* maskB = mbits ? reinterpret_cast<const uint8_t*>(p.mask) : nullptr;
   bf16x8 res_pf[NCH], mask_pf[NCH];
   uint32_t mbit_pf[NCH];
+  // omap (conv problems only): GEMM row (n, ho, wo) of the problem's Ho x Wo output grid lands on pixel (ho * o_sh + o_h0, wo * o_sw + o_w0)
+  // of an o_Hi x o_Wi image - C, res, mask and bits_out are all indexed by that pixel.  One parity class of a stride-2 input
+  // gradient writes every second row / column of dx this way (ops.conv_dgrad).
+  auto out_row = [&](const int row) -> long {
+    if (!p.omap) return row;
+    const int hw = p.Ho * p.Wo;
+    const int n = row / hw, rem = row - n * hw;
+    const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    return ((long)n * p.o_Hi + ho * p.o_sh + p.o_h0) * p.o_Wi + wo * p.o_sw + p.o_w0;
+  };
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int u = t + c * NT;
     const int row = m0 + u / CPR, col = n0 + (u % CPR) * 8;
     if (row < p.M && col < p.N && (!PARTIAL || u < BM * CPR)) {
+      const long orow = out_row(row);
       if (resT) {
-        int rrow = row;
-        if (p.res_mod > 0) rrow = row % p.res_mod;          // uniform branch: the common case pays no integer division
-        res_pf[c] = *reinterpret_cast<const bf16x8*>(resT + (long)rrow * p.ldr + col);
+        long rrow = orow;
+        if (p.res_mod > 0) rrow = orow % p.res_mod;          // uniform branch: the common case pays no integer division
+        res_pf[c] = *reinterpret_cast<const bf16x8*>(resT + rrow * p.ldr + col);
       }
-      if (maskT) mask_pf[c] = *reinterpret_cast<const bf16x8*>(maskT + (long)row * p.ldm + col);
-      if (maskB) mbit_pf[c] = maskB[(long)row * p.ldm + (col >> 3)];
+      if (maskT) mask_pf[c] = *reinterpret_cast<const bf16x8*>(maskT + orow * p.ldm + col);
+      if (maskB) mbit_pf[c] = maskB[orow * p.ldm + (col >> 3)];
     }
   }
 
@@ -170,6 +181,10 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
 #pragma unroll
     for (int i = 0; i < GA; ++i) a_cur[i] = (!CONV || (a_mask[i] & (1u << tap))) ? a_off[i] + tapdelta0 : OOB;
   }
+  // btap (conv problems only): the B rows hold MORE taps than this problem walks - tap t of the walk reads the channel run that starts
+  // at element btap[t] of a B row (a parity class of a stride-2 input gradient uses 1, 2 or 4 of the nine tap blocks of the packed
+  // dgrad weight, in place).  cur_bt = that start for the current tap (wave-uniform)
+  int cur_bt = (CONV && p.btap_on) ? p.btap[tap] : 0;
   auto advance = [&]() {
     k0 += BK2;
     if (!CONV) return;
@@ -185,13 +200,14 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       const unsigned tapbit = 1u << tap;
 #pragma unroll
       for (int i = 0; i < GA; ++i) a_cur[i] = (a_mask[i] & tapbit) ? a_off[i] + tapdelta : OOB;
+      if (p.btap_on) cur_bt = p.btap[tap & 3];
     }
   };
 
   // one LDS-DMA piece of the tile at the current K position: pieces 0..GA-1 are A rows, GA..GA+GB-1 are B rows
   auto issue_piece = [&](const int stage, const int i) {      // literal stage / piece only: folds to immediates
     unsigned char* st = ring + stage * STAGE_BYTES;
-    const unsigned kb2 = (unsigned)(k0 * 2);
+    const unsigned kb2 = (CONV && p.btap_on) ? (unsigned)((cur_bt + c0) * 2) : (unsigned)(k0 * 2);
     if (i < GA) {
       const unsigned koff = CONV ? (unsigned)(c0 * 2) : kb2;    // (an out-of-range a_cur stays out of range: c0 * 2 < 2^31)
       unsigned voff = a_cur[i] + koff;
@@ -426,6 +442,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     const int trow = u / CPR, cc = (u % CPR) * 8;
     const int row = m0 + trow, col = n0 + cc;
     if (row >= p.M || !col_ok || (PARTIAL && u >= BM * CPR)) continue;
+    const long orow = out_row(row);
     float v[8];
     {
       const float4 x0 = *reinterpret_cast<const float4*>(Cs + trow * CP + cc);
@@ -450,7 +467,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     }
     if (p.drop_p > 0.f) {
       // drop_keep of 8 consecutive elements: the (seed, high word) part of the hash once, one outer hash per pair
-      const uint64_t h0 = ((uint64_t)row * (uint64_t)p.N + col) >> 1;
+      const uint64_t h0 = ((uint64_t)orow * (uint64_t)p.N + col) >> 1;
       const uint32_t lo = (uint32_t)h0;
       const uint32_t inner = mix32(seed ^ ((uint32_t)(h0 >> 32) * 0x9E3779B9U) ^ 0x85ebca6bU);
 #pragma unroll
@@ -466,10 +483,10 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
     }
     if (resF) {
-      int rrow = row;
-      if (p.res_mod > 0) rrow = row % p.res_mod;
-      const float4 r0 = *reinterpret_cast<const float4*>(resF + (long)rrow * p.ldr + col);
-      const float4 r1 = *reinterpret_cast<const float4*>(resF + (long)rrow * p.ldr + col + 4);
+      long rrow = orow;
+      if (p.res_mod > 0) rrow = orow % p.res_mod;
+      const float4 r0 = *reinterpret_cast<const float4*>(resF + rrow * p.ldr + col);
+      const float4 r1 = *reinterpret_cast<const float4*>(resF + rrow * p.ldr + col + 4);
       v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
     }
     if (relu_post) {
@@ -482,8 +499,8 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       for (int e = 0; e < 8; ++e) v[e] = ((float)mv[e] > 0.f) ? v[e] : 0.f;
     }
     if (maskF) {
-      const float4 q0 = *reinterpret_cast<const float4*>(maskF + (long)row * p.ldm + col);
-      const float4 q1 = *reinterpret_cast<const float4*>(maskF + (long)row * p.ldm + col + 4);
+      const float4 q0 = *reinterpret_cast<const float4*>(maskF + orow * p.ldm + col);
+      const float4 q1 = *reinterpret_cast<const float4*>(maskF + orow * p.ldm + col + 4);
       const float mv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
@@ -498,14 +515,14 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
     }
     if (f32ep) {
-      float* outF = reinterpret_cast<float*>(p.C) + (long)row * p.ldc + col;
+      float* outF = reinterpret_cast<float*>(p.C) + orow * p.ldc + col;
       *reinterpret_cast<float4*>(outF) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<float4*>(outF + 4) = make_float4(v[4], v[5], v[6], v[7]);
       if (p.bits_out) {
         uint32_t ob = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) ob |= (v[e] > 0.f ? 1u : 0u) << e;
-        p.bits_out[(long)row * p.ldbits + (col >> 3)] = (uint8_t)ob;
+        p.bits_out[orow * p.ldbits + (col >> 3)] = (uint8_t)ob;
       }
       if (p.split_out) {        // the [hi | lo | hi] operand image of what was stored (sedt_split3, pattern 0) for the GEMMs that consume it
         bf16x8 hi, lo;
@@ -514,7 +531,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
           hi[e] = (bf16_t)v[e];
           lo[e] = (bf16_t)(v[e] - (float)hi[e]);
         }
-        bf16_t* sp = reinterpret_cast<bf16_t*>(p.split_out) + (long)row * (3L * p.N) + col;
+        bf16_t* sp = reinterpret_cast<bf16_t*>(p.split_out) + orow * (3L * p.N) + col;
         *reinterpret_cast<bf16x8*>(sp) = hi;
         *reinterpret_cast<bf16x8*>(sp + p.N) = lo;
         *reinterpret_cast<bf16x8*>(sp + 2L * p.N) = hi;
@@ -524,12 +541,12 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     bf16x8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-    *reinterpret_cast<bf16x8*>(outT + (long)row * p.ldc + col) = o;
+    *reinterpret_cast<bf16x8*>(outT + orow * p.ldc + col) = o;
     if (p.bits_out) {                               // sign bits of what was stored: the backward's ReLU mask at 1/16 of the bytes
       uint32_t ob = 0;
 #pragma unroll
       for (int e = 0; e < 8; ++e) ob |= ((float)o[e] > 0.f ? 1u : 0u) << e;
-      p.bits_out[(long)row * p.ldbits + (col >> 3)] = (uint8_t)ob;
+      p.bits_out[orow * p.ldbits + (col >> 3)] = (uint8_t)ob;
     }
   }
 }
@@ -713,7 +730,7 @@ int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
     plan3.on = false;
     if (r != 0 || !got.ok || got.bm != 64 || got.bn != 64 || (got.s != 2 && got.s != 3)) return -1;
     if (i == 0) S = got.s;
-    if (got.s != S) return -1;
+    if (got.s < S) S = got.s;               // mixed depths: the shallower ring serves every K
     g.p[i] = p;
     g.a_bytes[i] = got.a_bytes;
     g.b_bytes[i] = got.b_bytes;
@@ -872,6 +889,11 @@ int igemm_lds_try(const SedtIgemm& p, hipStream_t st) {
   long a_rows = p.conv ? (long)((p.M + (long)p.Ho * p.Wo - 1) / ((long)p.Ho * p.Wo)) * p.Hi * p.Wi : (long)p.M;
   long a_bytes = ((a_rows - 1) * p.lda + (p.conv ? p.Ci : p.K)) * 2;
   long b_bytes = ((long)(p.N - 1) * p.ldb + p.K) * 2;
+  if (p.btap_on) {
+    if (!p.conv || p.KH * p.KW > 4) return -1;
+    b_bytes = (long)p.N * p.ldb * 2;                 // (the tap table points anywhere inside a B row)
+  }
+  if (p.omap && !p.conv) return -1;
   if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31) || a_bytes <= 0 || b_bytes <= 0) return -1;
   int bm = p.tile_m, bn = p.tile_n;
   // measured (tools/tune_igemm.py on MI355X): occupancy beats prefetch depth at every SEDT shape - the 64x64 tile with a

@@ -41,7 +41,9 @@ class SedtIgemm(C.Structure):
         ('splitk', C.c_int32), ('slab', C.c_void_p),
         ('tile_m', C.c_int32), ('tile_n', C.c_int32),
         ('colsum_out', C.c_void_p),
-        ('bits_out', C.c_void_p), ('ldbits', C.c_int64), ('mask_bits', C.c_int32), ('f32ep', C.c_int32), ('split_out', C.c_void_p),
+        ('bits_out', C.c_void_p), ('ldbits', C.c_int64), ('mask_bits', C.c_int32), ('f32ep', C.c_int32),
+        ('omap', C.c_int32), ('o_Hi', C.c_int32), ('o_Wi', C.c_int32), ('o_sh', C.c_int32), ('o_sw', C.c_int32), ('o_h0', C.c_int32),
+        ('o_w0', C.c_int32), ('btap_on', C.c_int32), ('btap', C.c_int32 * 4), ('split_out', C.c_void_p),
     ]
 
 

@@ -417,11 +417,52 @@ def conv_fwd(dtype, x, B, g, wf, out=None, **ep):
     return out
 
 
+# The input gradient of a stride-2 3x3 convolution (layer2 / layer3 block 0) by OUTPUT PARITY.  The transposed gather of the plain form walks
+# all nine taps for every input pixel, but a pixel (hi, wi) only ever receives taps with kh = hi + 1 and kw = wi + 1 (mod 2): three of four
+# (tap, pixel) pairs multiply rows of zeros.  Split by the parity of (hi, wi) the problem is four small REGULAR convolutions over dY - 1, 2,
+# 2 and 4 taps - whose outputs interleave in dx: one grouped launch (sedt_igemm_group) of four problems that read their tap blocks of the
+# packed dgrad weight in place (SedtIgemm.btap) and write every second row / column of dx (SedtIgemm.omap), epilogue operands (residual,
+# ReLU mask bits) indexed by the dx pixel.  A quarter of the MFMAs, the same sums in the same order.
+S2_PARITY = _dev_env('SEDT_S2_PARITY', '1') != '0'
+
+
+def _dgrad_s2_ok(dtype, dy, g, wb, out, ep):
+    return (S2_PARITY and dtype == BF16 and PROFILE is None and not _co['on'] and g.KH == 3 and g.KW == 3 and g.sh == 2 and g.sw == 2
+            and g.ph == 1 and g.pw == 1 and g.dh == 1 and g.dw == 1 and g.Co % 64 == 0 and g.Ci % 8 == 0 and wb.stride(0) == 9 * g.Co
+            and dy.stride(0) % 8 == 0 and out.stride(0) % 8 == 0 and set(ep) <= {'mask', 'ldm', 'mask_bits', 'res', 'ldr', 'alpha'})
+
+
+def _conv_dgrad_s2(dy, B, g, wb, out, ep):
+    jobs = []
+    for ph_ in (0, 1):                                   # parity of the input row hi = 2a + ph_
+        nh, khs = (g.Hi + 1 - ph_) // 2, ([1] if ph_ == 0 else [0, 2])
+        for pw_ in (0, 1):
+            nw, kws = (g.Wi + 1 - pw_) // 2, ([1] if pw_ == 0 else [0, 2])
+            if nh == 0 or nw == 0:
+                continue
+            # a "transposed" stride-1 gather over the dY grid: tap (i, j) of the walk reads dY[a + ph_ - i][b + pw_ - j], i.e. the original
+            # taps in ascending (kh, kw) order - rows / columns beyond the grid are masked by the kernel
+            conv = (g.Ho, g.Wo, g.Co, nh, nw, len(khs), len(kws), 1, 1, ph_, pw_, 1, 1)
+            taps = [(kh, kw) for kh in khs for kw in kws]
+            a = igemm_args(B * nh * nw, g.Ci, len(taps) * g.Co, dy, dy.stride(0), wb, wb.stride(0), out, out.stride(0), conv=conv,
+                           transposed=1, tile=(64, 64), **ep)
+            a.omap, a.o_Hi, a.o_Wi, a.o_sh, a.o_sw, a.o_h0, a.o_w0 = 1, g.Hi, g.Wi, 2, 2, ph_, pw_
+            a.btap_on = 1
+            for t_, (kh, kw) in enumerate(taps):
+                a.btap[t_] = (kh * 3 + kw) * g.Co
+            jobs.append(a)
+    arr = (L.SedtIgemm * len(jobs))(*jobs)
+    L.check(L.load().sedt_igemm_group(arr, len(jobs), BF16, L.stream_ptr()), 'igemm_group_s2')
+    return out
+
+
 def conv_dgrad(dtype, dy, B, g, wb, out=None, **ep):
     """dx [B*Hi*Wi, Ci] = conv_transpose(dy [B*Ho*Wo, Co]); wb packed [Ci][taps][Co] (BN scale folded in)"""
     M = B * g.Hi * g.Wi
     if out is None:
         out = torch.empty((M, g.Ci), device=dy.device, dtype=TORCH_DTYPE[dtype])
+    if _dgrad_s2_ok(dtype, dy, g, wb, out, ep):
+        return _conv_dgrad_s2(dy, B, g, wb, out, ep)
     if _conv3_c64_ok(dtype, dy, g, ep, out) and 'scale' not in ep and 'bias' not in ep:
         return _conv3_c64(dy, B, g, wb, 1, out, ep)       # the input gradient of a stride-1 3x3 conv is the same conv, taps flipped
     conv = None if g.plain else _geom_tuple(g, transposed=True)
