@@ -398,6 +398,13 @@ int attn_bwd_mfma_try(const void* q, int64_t ldq, const void* k, int64_t ldk, co
                       int64_t ldo, const void* dout, int64_t lddo, const float* lse, const uint8_t* kpm, const float* amask,
                       void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv, int B, int H, int Lq, int Lk,
                       float drop_p, uint32_t seed, const uint32_t* seed_ptr, hipStream_t st);
+int attn_f32_fwd_try(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo, float* lse,
+                     const uint8_t* kpm, const float* amask, int B, int H, int Lq, int Lk, float drop_p, uint32_t seed,
+                     const uint32_t* seed_ptr, hipStream_t st);
+int attn_f32_bwd_try(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o, int64_t ldo,
+                     const void* dout, int64_t lddo, const float* lse, const uint8_t* kpm, const float* amask, void* dq, int64_t lddq,
+                     void* dk, int64_t lddk, void* dv, int64_t lddv, int B, int H, int Lq, int Lk, float drop_p, uint32_t seed,
+                     const uint32_t* seed_ptr, hipStream_t st);
 static bool use_attn_mfma() {
   static int v = -1;
   if (v < 0) {
@@ -479,6 +486,10 @@ extern "C" int sedt_attention_fwd(const void* q, int64_t ldq, const void* k, int
     int r = attn_fwd_mfma_try(q, ldq, k, ldk, v, ldv, o, ldo, lse, kpm, amask, B, H, Lq, Lk, drop_p, seed, seed_ptr, S(stream));
     if (r >= 0) return r;
   }
+  if (dtype == SEDT_F32) {                               // exact-f32 MFMA kernels (attn_f32_mfma.hip): Lq, Lk <= 128
+    int r = attn_f32_fwd_try(q, ldq, k, ldk, v, ldv, o, ldo, lse, kpm, amask, B, H, Lq, Lk, drop_p, seed, seed_ptr, S(stream));
+    if (r >= 0) return r;
+  }
   const int LkPad = (Lk + 63) & ~63;
   size_t lds = ((size_t)2 * Lk * KP + 4 * LkPad) * sizeof(float);
   SEDT_REQUIRE(lds <= 160 * 1024, "attention_fwd: Lk=%d needs %zu B of LDS", Lk, lds);
@@ -509,6 +520,11 @@ extern "C" int sedt_attention_bwd(const void* q, int64_t ldq, const void* k, int
   if (dtype == SEDT_BF16 && use_attn_mfma()) {
     int r = attn_bwd_mfma_try(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, kpm, amask, dq, lddq, dk, lddk, dv, lddv, B, H, Lq,
                               Lk, drop_p, seed, seed_ptr, S(stream));
+    if (r >= 0) return r;
+  }
+  if (dtype == SEDT_F32) {
+    int r = attn_f32_bwd_try(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, lse, kpm, amask, dq, lddq, dk, lddk, dv, lddv, B, H, Lq, Lk,
+                             drop_p, seed, seed_ptr, S(stream));
     if (r >= 0) return r;
   }
   const int LmPad = (std::max(Lq, Lk) + 63) & ~63;
