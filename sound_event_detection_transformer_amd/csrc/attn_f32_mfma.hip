@@ -45,7 +45,7 @@ __device__ __forceinline__ f32x16 mm32(const float* A, int arow0, const float* B
 }
 }  // namespace af
 
-template <int NTK, bool AMASK>
+template <int NTK, bool AMASK, bool DROP>
 __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ k, long ldk,
                                                            const float* __restrict__ v, long ldv, float* __restrict__ o, long ldo,
                                                            float* __restrict__ lse, const uint8_t* __restrict__ kpm,
@@ -57,11 +57,13 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restri
   float* Qs = lds_af;
   float* Ks = Qs + LqP * PT;
   float* Vs = Ks + LkP * PT;
+  float* Kb = Vs + LkP * PT;                         // [LkP] additive key bias: -inf for padded keys and keys beyond Lk
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
   stage(Qs, q + (long)b * Lq * ldq + h * DH, ldq, Lq, LqP, tid);
   stage(Ks, k + (long)b * Lk * ldk + h * DH, ldk, Lk, LkP, tid);
   stage(Vs, v + (long)b * Lk * ldv + h * DH, ldv, Lk, LkP, tid);
+  for (int j = tid; j < LkP; j += 256) Kb[j] = (j >= Lk || (kpm && kpm[(long)b * Lk + j])) ? -INFINITY : 0.f;
   __syncthreads();
   if (wave * 32 >= Lq) return;                       // (no barrier below)
   const int i = wave * 32 + l31;                     // this lane's query
@@ -75,9 +77,8 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = 32 * t + rowmap(r, half);
-      float a = s[t][r] * scale;
+      float a = s[t][r] * scale + Kb[j];
       if (AMASK && qok && j < Lk) a += amask[(long)i * Lk + j];
-      if (j >= Lk || (kpm && kpm[(long)b * Lk + j])) a = -INFINITY;
       s[t][r] = a;
       m = fmaxf(m, a);
     }
@@ -98,15 +99,28 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restri
   f32x16 oacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+  // (all sixteen V rows of a tile are read BEFORE the element loop and the loop is branch-free: with a load or a branch per element the
+  // compiler waits lgkmcnt(0) in front of every MFMA - one exposed LDS round trip per instruction)
+  const uint64_t ibase = ((uint64_t)bh * Lq + (qok ? i : 0)) * Lk;
 #pragma unroll
-  for (int t = 0; t < NTK; ++t)
+  for (int t = 0; t < NTK; ++t) {
+    float va[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) va[r] = Vs[(32 * t + rowmap(r, half)) * PT + l31];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int j = 32 * t + rowmap(r, half);
       float pv = s[t][r] * inv;
-      if (thresh) pv = (qok && j < Lk && drop_keep(sd, ((uint64_t)bh * Lq + i) * Lk + j, thresh)) ? pv * inv_keep : 0.f;
-      oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[j * PT + l31], pv, oacc, 0, 0, 0);      // O^T[d][query] += V[j][d] P[query][j]
+      if (DROP) {
+        const int j = 32 * t + rowmap(r, half);
+        const bool keep = drop_keep(sd, ibase + (uint64_t)min(j, Lk - 1), thresh);
+        pv = keep ? pv * inv_keep : 0.f;
+      }
+      s[t][r] = pv;
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(va[r], s[t][r], oacc, 0, 0, 0);            // O^T[d][query] += V[j][d] P[query][j]
+  }
   if (qok) {
     float* op = o + ((long)b * Lq + i) * ldo + h * DH;
 #pragma unroll
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_f32_fwd_kernel(const float* __restri
 }
 
 // blockIdx.y == 0: dQ (a wave = 32 queries against every key tile); blockIdx.y == 1: dK, dV (a wave = 32 keys against every query tile)
-template <int NTQ, int NTK, bool AMASK>
+template <int NTQ, int NTK, bool AMASK, bool DROP>
 __global__ __launch_bounds__(256) void attn_f32_bwd_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ k, long ldk,
                                                            const float* __restrict__ v, long ldv, const float* __restrict__ o, long ldo,
                                                            const float* __restrict__ dout, long lddo, const float* __restrict__ lse,
@@ -133,6 +147,7 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_kernel(const float* __restri
   float* Ds = Vs + LkP * PT;
   float* Ls = Ds + LqP * PT;       // [LqP] log-sum-exp
   float* De = Ls + LqP;            // [LqP] delta = dO . O
+  float* Kb = De + LqP;            // [LkP] additive key bias: -inf for padded keys and keys beyond Lk
   const int bh = blockIdx.x, b = bh / H, h = bh - b * H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
   stage(Qs, q + (long)b * Lq * ldq + h * DH, ldq, Lq, LqP, tid);
@@ -140,12 +155,17 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_kernel(const float* __restri
   stage(Vs, v + (long)b * Lk * ldv + h * DH, ldv, Lk, LkP, tid);
   stage(Ds, dout + (long)b * Lq * lddo + h * DH, lddo, Lq, LqP, tid);
   __syncthreads();
+  for (int j = tid; j < LkP; j += 256) Kb[j] = (j >= Lk || (kpm && kpm[(long)b * Lk + j])) ? -INFINITY : 0.f;
   for (int i = tid; i < LqP; i += 256) {
     float a = 0.f, l = 0.f;
     if (i < Lq) {
-      const float* op = o + ((long)b * Lq + i) * ldo + h * DH;
+      const float4* op = reinterpret_cast<const float4*>(o + ((long)b * Lq + i) * ldo + h * DH);
+      float4 ov[8];
 #pragma unroll
-      for (int d = 0; d < DH; ++d) a += Ds[i * PT + d] * op[d];
+      for (int d = 0; d < 8; ++d) ov[d] = op[d];
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+        a += Ds[i * PT + 4 * d] * ov[d].x + Ds[i * PT + 4 * d + 1] * ov[d].y + Ds[i * PT + 4 * d + 2] * ov[d].z + Ds[i * PT + 4 * d + 3] * ov[d].w;
       l = lse[((long)b * H + h) * Lq + i];
     }
     De[i] = a;
@@ -159,6 +179,7 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_kernel(const float* __restri
     const int i = wave * 32 + l31;
     const bool qok = i < Lq;
     const float li = Ls[i], di = De[i];
+    const uint64_t ibase = ((uint64_t)bh * Lq + (qok ? i : 0)) * Lk;
     f32x16 gq;
 #pragma unroll
     for (int r = 0; r < 16; ++r) gq[r] = 0.f;
@@ -167,18 +188,25 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_kernel(const float* __restri
       if (32 * t >= Lk) break;
       const f32x16 st = mm32(Ks, 32 * t, Qs, 32 * wave, l31, half);      // S^T  [key][query]
       const f32x16 pt = mm32(Vs, 32 * t, Ds, 32 * wave, l31, half);      // dP^T [key][query]
+      float ka[16], kb[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        ka[r] = Ks[(32 * t + rowmap(r, half)) * PT + l31];
+        kb[r] = Kb[32 * t + rowmap(r, half)];
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = 32 * t + rowmap(r, half);
-        float a = st[r] * scale;
+        float a = st[r] * scale + kb[r];
         if (AMASK && qok && j < Lk) a += amask[(long)i * Lk + j];
-        if (j >= Lk || (kpm && kpm[(long)b * Lk + j])) a = -INFINITY;
         const float p = qok ? __expf(a - li) : 0.f;
         float dp = pt[r];
-        if (thresh) dp = (qok && j < Lk && drop_keep(sd, ((uint64_t)bh * Lq + i) * Lk + j, thresh)) ? dp * inv_keep : 0.f;
-        const float ds = p * (dp - di);
-        gq = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[j * PT + l31], ds, gq, 0, 0, 0);       // dQ^T[d][query] += K[j][d] dS[query][j]
+        if (DROP) dp = drop_keep(sd, ibase + (uint64_t)min(j, Lk - 1), thresh) ? dp * inv_keep : 0.f;
+        ds[r] = p * (dp - di);
       }
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        gq = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[r], ds[r], gq, 0, 0, 0);               // dQ^T[d][query] += K[j][d] dS[query][j]
     }
     if (qok) {
       float* gp = dq + ((long)b * Lq + i) * lddq + h * DH;
@@ -193,7 +221,8 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_kernel(const float* __restri
   if (wave >= NTK || wave * 32 >= Lk) return;
   const int j = wave * 32 + l31;
   const bool kok = j < Lk;
-  const bool padded = !kok || (kpm && kpm[(long)b * Lk + j]);
+  const int jc = kok ? j : 0;
+  const float kbias = Kb[j];
   f32x16 gk, gv;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { gk[r] = 0.f; gv[r] = 0.f; }
@@ -202,23 +231,35 @@ __global__ __launch_bounds__(256) void attn_f32_bwd_kernel(const float* __restri
     if (32 * u >= Lq) break;
     const f32x16 su = mm32(Qs, 32 * u, Ks, 32 * wave, l31, half);        // S  [query][key]
     const f32x16 pu = mm32(Ds, 32 * u, Vs, 32 * wave, l31, half);        // dP [query][key]
+    float qa[16], da[16], ls[16], de[16], ds[16], pd[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = 32 * u + rowmap(r, half);
+      qa[r] = Qs[i * PT + l31];
+      da[r] = Ds[i * PT + l31];
+      ls[r] = Ls[i];
+      de[r] = De[i];
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = 32 * u + rowmap(r, half);
       const bool live = i < Lq && kok;
-      float a = su[r] * scale;
+      float a = su[r] * scale + kbias;
       if (AMASK && live) a += amask[(long)i * Lk + j];
-      if (padded) a = -INFINITY;
-      const float p = live ? __expf(a - Ls[i]) : 0.f;
-      float dp = pu[r], pd = p;
-      if (thresh) {
-        const bool keep = live && drop_keep(sd, ((uint64_t)bh * Lq + i) * Lk + j, thresh);
+      const float p = live ? __expf(a - ls[r]) : 0.f;
+      float dp = pu[r];
+      pd[r] = p;
+      if (DROP) {
+        const bool keep = drop_keep(sd, ((uint64_t)bh * Lq + min(i, Lq - 1)) * Lk + jc, thresh);
         dp = keep ? dp * inv_keep : 0.f;
-        pd = keep ? p * inv_keep : 0.f;
+        pd[r] = keep ? p * inv_keep : 0.f;
       }
-      const float ds = p * (dp - De[i]);
-      gk = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[i * PT + l31], ds, gk, 0, 0, 0);         // dK^T[d][key] += Q[i][d] dS[i][key]
-      gv = __builtin_amdgcn_mfma_f32_32x32x2f32(Ds[i * PT + l31], pd, gv, 0, 0, 0);         // dV^T[d][key] += dO[i][d] Pd[i][key]
+      ds[r] = p * (dp - de[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      gk = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[r], ds[r], gk, 0, 0, 0);                 // dK^T[d][key] += Q[i][d] dS[i][key]
+      gv = __builtin_amdgcn_mfma_f32_32x32x2f32(da[r], pd[r], gv, 0, 0, 0);                 // dV^T[d][key] += dO[i][d] Pd[i][key]
     }
   }
   if (kok) {
@@ -262,27 +303,25 @@ int attn_f32_fwd_try(const void* q, int64_t ldq, const void* k, int64_t ldk, con
                      const uint32_t* seed_ptr, hipStream_t st) {
   if (!af_on() || Lq > 128 || Lk > 128 || Lq < 1 || Lk < 1) return -1;
   if (!af_aligned(q, ldq) || !af_aligned(k, ldk) || !af_aligned(v, ldv) || !af_aligned(o, ldo)) return -1;
-  const int ntk = (Lk + 31) / 32, LqP = (Lq + 31) & ~31;
-  const size_t lds = (size_t)(LqP + 2 * ntk * 32) * af::PT * sizeof(float);
+  const int ntk = Lk <= 32 ? 1 : 4, LqP = (Lq + 31) & ~31;             // instances: one key tile (the decoder's self-attention) or four
+  const size_t lds = ((size_t)(LqP + 2 * ntk * 32) * af::PT + ntk * 32) * sizeof(float);
   const float scale = 1.f / sqrtf((float)af::DH);
   const uint32_t th = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
   const float ik = 1.f / (1.f - drop_p);
   dim3 grid(B * H), block(256);
-#define SEDT_AFF1(NT_, AM_)                                                                                                          \
-  {                                                                                                                                  \
-    static bool done = false;                                                                                                        \
-    if (af_set_lds(attn_f32_fwd_kernel<NT_, AM_>, done, "attention_fwd (f32 mfma)")) return 1;                                       \
-    hipLaunchKernelGGL((attn_f32_fwd_kernel<NT_, AM_>), grid, block, lds, st, (const float*)q, (long)ldq, (const float*)k, (long)ldk, \
-                       (const float*)v, (long)ldv, (float*)o, (long)ldo, lse, kpm, amask, H, Lq, Lk, scale, th, ik, seed, seed_ptr);   \
+#define SEDT_AFF1(NT_, AM_, DR_)                                                                                                          \
+  {                                                                                                                                       \
+    static bool done = false;                                                                                                             \
+    if (af_set_lds(attn_f32_fwd_kernel<NT_, AM_, DR_>, done, "attention_fwd (f32 mfma)")) return 1;                                       \
+    hipLaunchKernelGGL((attn_f32_fwd_kernel<NT_, AM_, DR_>), grid, block, lds, st, (const float*)q, (long)ldq, (const float*)k, (long)ldk, \
+                       (const float*)v, (long)ldv, (float*)o, (long)ldo, lse, kpm, amask, H, Lq, Lk, scale, th, ik, seed, seed_ptr);        \
   }
-#define SEDT_AFF(NT_)                                          \
-  case NT_:                                                    \
-    if (amask) SEDT_AFF1(NT_, true) else SEDT_AFF1(NT_, false) \
-    break;
-  switch (ntk) {
-    SEDT_AFF(1) SEDT_AFF(2) SEDT_AFF(3) SEDT_AFF(4)
-    default: return -1;
+#define SEDT_AFF(NT_)                                                        \
+  if (ntk == NT_) {                                                          \
+    if (amask) { if (th) SEDT_AFF1(NT_, true, true) else SEDT_AFF1(NT_, true, false) } \
+    else { if (th) SEDT_AFF1(NT_, false, true) else SEDT_AFF1(NT_, false, false) }     \
   }
+  SEDT_AFF(1) SEDT_AFF(4)
 #undef SEDT_AFF
 #undef SEDT_AFF1
   return check_launch("attention_fwd_f32_mfma");
@@ -299,23 +338,24 @@ int attn_f32_bwd_try(const void* q, int64_t ldq, const void* k, int64_t ldk, con
   const int ntq = (Lq + 31) / 32, ntk = (Lk + 31) / 32;
   // instances: the query side 1 tile (the decoder's Q = 11 / 21 queries) or 4 (encoder), the key side 1 or 4
   const int NQ = ntq <= 1 ? 1 : 4, NK = ntk <= 1 ? 1 : 4;
-  const size_t lds = ((size_t)(2 * NQ * 32 + 2 * NK * 32) * af::PT + 2 * NQ * 32) * sizeof(float);
+  const size_t lds = ((size_t)(2 * NQ * 32 + 2 * NK * 32) * af::PT + 2 * NQ * 32 + NK * 32) * sizeof(float);
   const float scale = 1.f / sqrtf((float)af::DH);
   const uint32_t th = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
   const float ik = 1.f / (1.f - drop_p);
   dim3 grid(B * H, 2), block(256);
-#define SEDT_AFB1(NQ_, NK_, AM_)                                                                                                        \
-  {                                                                                                                                     \
-    static bool done = false;                                                                                                           \
-    if (af_set_lds(attn_f32_bwd_kernel<NQ_, NK_, AM_>, done, "attention_bwd (f32 mfma)")) return 1;                                     \
-    hipLaunchKernelGGL((attn_f32_bwd_kernel<NQ_, NK_, AM_>), grid, block, lds, st, (const float*)q, (long)ldq, (const float*)k,          \
-                       (long)ldk, (const float*)v, (long)ldv, (const float*)o, (long)ldo, (const float*)dout, (long)lddo, lse, kpm,      \
-                       amask, (float*)dq, (long)lddq, (float*)dk, (long)lddk, (float*)dv, (long)lddv, H, Lq, Lk, scale, th, ik, seed,    \
-                       seed_ptr);                                                                                                        \
+#define SEDT_AFB1(NQ_, NK_, AM_, DR_)                                                                                                    \
+  {                                                                                                                                      \
+    static bool done = false;                                                                                                            \
+    if (af_set_lds(attn_f32_bwd_kernel<NQ_, NK_, AM_, DR_>, done, "attention_bwd (f32 mfma)")) return 1;                                 \
+    hipLaunchKernelGGL((attn_f32_bwd_kernel<NQ_, NK_, AM_, DR_>), grid, block, lds, st, (const float*)q, (long)ldq, (const float*)k,      \
+                       (long)ldk, (const float*)v, (long)ldv, (const float*)o, (long)ldo, (const float*)dout, (long)lddo, lse, kpm,       \
+                       amask, (float*)dq, (long)lddq, (float*)dk, (long)lddk, (float*)dv, (long)lddv, H, Lq, Lk, scale, th, ik, seed,     \
+                       seed_ptr);                                                                                                         \
   }
-#define SEDT_AFB(NQ_, NK_)                                             \
-  if (NQ == NQ_ && NK == NK_) {                                        \
-    if (amask) SEDT_AFB1(NQ_, NK_, true) else SEDT_AFB1(NQ_, NK_, false) \
+#define SEDT_AFB(NQ_, NK_)                                                                       \
+  if (NQ == NQ_ && NK == NK_) {                                                                  \
+    if (amask) { if (th) SEDT_AFB1(NQ_, NK_, true, true) else SEDT_AFB1(NQ_, NK_, true, false) } \
+    else { if (th) SEDT_AFB1(NQ_, NK_, false, true) else SEDT_AFB1(NQ_, NK_, false, false) }     \
   }
   SEDT_AFB(1, 1) SEDT_AFB(1, 4) SEDT_AFB(4, 1) SEDT_AFB(4, 4)
 #undef SEDT_AFB

@@ -427,12 +427,25 @@ S2_PARITY = _dev_env('SEDT_S2_PARITY', '1') != '0'
 
 
 def _dgrad_s2_ok(dtype, dy, g, wb, out, ep):
-    return (S2_PARITY and dtype == BF16 and PROFILE is None and not _co['on'] and g.KH == 3 and g.KW == 3 and g.sh == 2 and g.sw == 2
+    """bf16, or the fast bf16x3 form of the f32 mode (split operand images, f32 epilogue)"""
+    x3 = dtype == F32 and L.GEMM_X3 and X3_FAST
+    if not (dtype == BF16 or x3):
+        return False
+    if x3 and not (dy.dtype == torch.float32 and out.dtype == torch.float32 and dy.data_ptr() % 16 == 0 and dy.stride(0) % 4 == 0
+                   and (ep.get('res') is None or ep['res'].dtype == torch.float32)
+                   and (ep.get('mask') is None or ep.get('mask_bits') or ep['mask'].dtype == torch.float32)):
+        return False
+    return (S2_PARITY and PROFILE is None and not _co['on'] and g.KH == 3 and g.KW == 3 and g.sh == 2 and g.sw == 2
             and g.ph == 1 and g.pw == 1 and g.dh == 1 and g.dw == 1 and g.Co % 64 == 0 and g.Ci % 8 == 0 and wb.stride(0) == 9 * g.Co
             and dy.stride(0) % 8 == 0 and out.stride(0) % 8 == 0 and set(ep) <= {'mask', 'ldm', 'mask_bits', 'res', 'ldr', 'alpha'})
 
 
-def _conv_dgrad_s2(dy, B, g, wb, out, ep):
+def _conv_dgrad_s2(dy, B, g, wb, out, ep, x3=False):
+    Co = g.Co
+    if x3:                                               # operand images: dY [pixels][3 Co] = [hi | lo | hi], the weight [Ci][9][3 Co] = [hi | hi | lo] per tap
+        dy, wb = _split3([(dy, 0, B * g.Ho * g.Wo, g.Co, dy.stride(0), 0), (wb, 0, g.Ci * 9, g.Co, g.Co, 1)])
+        wb = wb.view(g.Ci, 27 * g.Co)
+        Co = 3 * g.Co
     jobs = []
     for ph_ in (0, 1):                                   # parity of the input row hi = 2a + ph_
         nh, khs = (g.Hi + 1 - ph_) // 2, ([1] if ph_ == 0 else [0, 2])
@@ -442,14 +455,14 @@ def _conv_dgrad_s2(dy, B, g, wb, out, ep):
                 continue
             # a "transposed" stride-1 gather over the dY grid: tap (i, j) of the walk reads dY[a + ph_ - i][b + pw_ - j], i.e. the original
             # taps in ascending (kh, kw) order - rows / columns beyond the grid are masked by the kernel
-            conv = (g.Ho, g.Wo, g.Co, nh, nw, len(khs), len(kws), 1, 1, ph_, pw_, 1, 1)
+            conv = (g.Ho, g.Wo, Co, nh, nw, len(khs), len(kws), 1, 1, ph_, pw_, 1, 1)
             taps = [(kh, kw) for kh in khs for kw in kws]
-            a = igemm_args(B * nh * nw, g.Ci, len(taps) * g.Co, dy, dy.stride(0), wb, wb.stride(0), out, out.stride(0), conv=conv,
-                           transposed=1, tile=(64, 64), **ep)
+            a = igemm_args(B * nh * nw, g.Ci, len(taps) * Co, dy, dy.stride(0), wb, wb.stride(0), out, out.stride(0), conv=conv,
+                           transposed=1, tile=(64, 64), out_f32=int(x3), **ep)
             a.omap, a.o_Hi, a.o_Wi, a.o_sh, a.o_sw, a.o_h0, a.o_w0 = 1, g.Hi, g.Wi, 2, 2, ph_, pw_
-            a.btap_on = 1
+            a.btap_on, a.f32ep = 1, int(x3)
             for t_, (kh, kw) in enumerate(taps):
-                a.btap[t_] = (kh * 3 + kw) * g.Co
+                a.btap[t_] = (kh * 3 + kw) * Co
             jobs.append(a)
     arr = (L.SedtIgemm * len(jobs))(*jobs)
     L.check(L.load().sedt_igemm_group(arr, len(jobs), BF16, L.stream_ptr()), 'igemm_group_s2')
@@ -462,7 +475,7 @@ def conv_dgrad(dtype, dy, B, g, wb, out=None, **ep):
     if out is None:
         out = torch.empty((M, g.Ci), device=dy.device, dtype=TORCH_DTYPE[dtype])
     if _dgrad_s2_ok(dtype, dy, g, wb, out, ep):
-        return _conv_dgrad_s2(dy, B, g, wb, out, ep)
+        return _conv_dgrad_s2(dy, B, g, wb, out, ep, x3=dtype == F32)
     if _conv3_c64_ok(dtype, dy, g, ep, out) and 'scale' not in ep and 'bias' not in ep:
         return _conv3_c64(dy, B, g, wb, 1, out, ep)       # the input gradient of a stride-1 3x3 conv is the same conv, taps flipped
     conv = None if g.plain else _geom_tuple(g, transposed=True)

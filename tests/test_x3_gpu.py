@@ -106,11 +106,15 @@ def test_x3_fast_path_on_the_lds_dma_kernels_against_f64():
             w2 = (torch.randn(256, 256, 3, 3, generator=g) / (9 * 256) ** 0.5).cuda()
             _, w2b = ops.pack_conv(L.F32, w2)
             dy = torch.randn(B * g2.Ho * g2.Wo, 256, generator=g).cuda()
-            dx = ops.conv_dgrad(L.F32, dy, B, g2, w2b)
+            # (by output parity - ops._conv_dgrad_s2 - with a residual and an f32 ReLU mask indexed by the dx pixel)
+            res2 = torch.randn(B * 63 * 8, 256, generator=g).cuda()
+            mk2 = torch.randn(B * 63 * 8, 256, generator=g).cuda()
+            dx = ops.conv_dgrad(L.F32, dy, B, g2, w2b, res=res2, ldr=256, mask=mk2, ldm=256)
             dyn = dy.view(B, g2.Ho, g2.Wo, 256).permute(0, 3, 1, 2).double()
             refd = F.conv_transpose2d(dyn, w2.double(), stride=2, padding=1, output_padding=(0, 1))
             assert refd.shape[2:] == (63, 8)
-            assert rel(dx.view(B, 63, 8, 256).permute(0, 3, 1, 2), refd) < 3e-5
+            refd = (refd.permute(0, 2, 3, 1).reshape(-1, 256) + res2.double()) * (mk2 > 0)
+            assert rel(dx, refd) < 3e-5
             # ---- weight gradients: plain (+ fused bias column sums), and the dilated 3x3
             gy = torch.randn(M, N, generator=g).cuda()
             db = torch.empty(N, device='cuda')
@@ -130,7 +134,7 @@ def test_x3_fast_path_on_the_lds_dma_kernels_against_f64():
         L.GEMM_X3 = False
     # (split passes: one per forward / dgrad call - its weight operand at least -, fewer than one per weight gradient: x, xi and gy images
     # are found in the step's operand-image cache)
-    assert log['sedt_igemm_x3'] == 4 and 4 <= log['split3'] <= 7 and log['wgrad_group'] == 2 and log['sedt_igemm'] == 0, dict(log)
+    assert log['sedt_igemm_x3'] == 3 and log['igemm_group_s2'] == 1 and 4 <= log['split3'] <= 7 and log['wgrad_group'] == 2 and log['sedt_igemm'] == 0, dict(log)
     assert all(k.split(':')[1].startswith('igemm3') for k in log if k.startswith('igemm_x3:')), dict(log)
 
 
