@@ -176,10 +176,6 @@ typedef struct SedtSplitJob {
   int32_t blk0;           /* filled by the library */
 } SedtSplitJob;
 int sedt_split3(const SedtSplitJob* jobs, int njobs, void* stream);
-/* the same over a DEVICE job table with blk0 filled by the caller (job i owns blocks blk0[i] .. blk0[i] + sedt_split3_blocks(rows, cols) - 1,
- * ascending): every weight operand of a model in one launch */
-int sedt_split3_blocks(int rows, int cols);
-int sedt_split3_table(const SedtSplitJob* dev_jobs, int njobs, int nblocks, void* stream);
 
 /* up to SEDT_MAX_REDUCE_JOBS split-K reductions in ONE launch (jobs are copied into the kernel arguments, so a captured
  * graph holds them by value).  `jobs` is a HOST array; fields as the arguments of sedt_wgrad_reduce_bias. */

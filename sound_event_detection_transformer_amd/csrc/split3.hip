@@ -44,43 +44,9 @@ __global__ __launch_bounds__(256) void split3_kernel(const SplitJobs jobs) {
   *reinterpret_cast<VecT<bf16_t, 4>*>(d + 2L * J.cols) = J.pattern ? lo : hi;
 }
 
-// the same over a DEVICE job table (all weights of a model in one launch: packing.PackPlan); blk0 ascending, binary search per block
-__global__ __launch_bounds__(256) void split3_table_kernel(const SedtSplitJob* __restrict__ jobs, int njobs) {
-  int lo = 0, hi = njobs - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (jobs[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
-  }
-  const SedtSplitJob J = jobs[lo];
-  const long q = ((long)(blockIdx.x - J.blk0) * 256 + threadIdx.x) * 4;
-  if (q >= (long)J.rows * J.cols) return;
-  const long row = q / J.cols;
-  const int c = (int)(q - row * J.cols);
-  const float4 x = *reinterpret_cast<const float4*>(J.src + row * J.ld + c);
-  const float xv[4] = {x.x, x.y, x.z, x.w};
-  VecT<bf16_t, 4> hi4, lo4;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    hi4.v[e] = (bf16_t)xv[e];
-    lo4.v[e] = (bf16_t)(xv[e] - (float)hi4.v[e]);
-  }
-  bf16_t* d = reinterpret_cast<bf16_t*>(J.dst) + row * (3L * J.cols) + c;
-  *reinterpret_cast<VecT<bf16_t, 4>*>(d) = hi4;
-  *reinterpret_cast<VecT<bf16_t, 4>*>(d + J.cols) = J.pattern ? hi4 : lo4;
-  *reinterpret_cast<VecT<bf16_t, 4>*>(d + 2L * J.cols) = J.pattern ? lo4 : hi4;
-}
-
 }  // namespace sedt
 
 using namespace sedt;
-
-extern "C" int sedt_split3_blocks(int rows, int cols) { return (int)(((long)rows * cols / 4 + 255) / 256); }
-
-extern "C" int sedt_split3_table(const SedtSplitJob* dev_jobs, int njobs, int nblocks, void* stream) {
-  SEDT_REQUIRE(dev_jobs && njobs >= 1 && nblocks >= 1, "split3_table: bad arguments");
-  hipLaunchKernelGGL(split3_table_kernel, dim3(nblocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dev_jobs, njobs);
-  return check_launch("split3_table");
-}
 
 extern "C" int sedt_split3(const SedtSplitJob* jobs, int njobs, void* stream) {
   SEDT_REQUIRE(jobs && njobs >= 1 && njobs <= SPLIT_MAXJ, "split3: 1..%d jobs", SPLIT_MAXJ);

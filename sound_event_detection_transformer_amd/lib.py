@@ -112,8 +112,6 @@ SIGNATURES = {
     'sedt_wgrad_reduce': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sedt_wgrad_reduce_bias': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'sedt_split3': (_i, [C.POINTER(SedtSplitJob), _i, _vp]),
-    'sedt_split3_blocks': (_i, [_i, _i]),
-    'sedt_split3_table': (_i, [_vp, _i, _i, _vp]),
     'sedt_multi_wgrad_reduce': (_i, [C.POINTER(SedtReduceJob), _i, C.POINTER(SedtPrefetch), _vp]),
     'sedt_skinny_linear_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     'sedt_skinny_linear_bwd_scratch': (_sz, [_i]),

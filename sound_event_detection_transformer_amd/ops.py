@@ -179,18 +179,10 @@ X3_FAST = _dev_env('SEDT_X3_FAST', '1') != '0'
 X3_CACHE = {}
 X3_CACHE_ON = _dev_env('SEDT_X3_CACHE', '1') != '0'
 X3_SPLIT_OUT = _dev_env('SEDT_X3_SPLIT_OUT', '1') != '0'      # GEMM epilogues write the operand image of outputs that feed GEMMs again
-X3_PLAN_WEIGHTS = _dev_env('SEDT_X3_PLAN_WEIGHTS', '1') != '0'  # the model's PackPlan prepares every weight image in one launch per forward
 
 
-X3_WPLANS = []       # the PackPlans whose weight images are current: every plan run since the last optimizer step (a backward runs after its
-                     # forward's plan scope has closed, and the mean-teacher step interleaves two plans)
-
-
-def x3_cache_clear(weights=False):
-    """weights: also forget the plans' weight images (the optimizer step: the weights change)"""
+def x3_cache_clear():
     X3_CACHE.clear()
-    if weights:
-        del X3_WPLANS[:]
 
 
 def _split3(jobs):
@@ -203,15 +195,6 @@ def _split3(jobs):
         if hit is not None:
             outs[i] = hit[1]
             continue
-        if pattern == 1 and X3_PLAN_WEIGHTS:
-            img = None
-            for plan in reversed(X3_WPLANS):
-                img = plan.x3_lookup(key[0], rows, cols, ld)
-                if img is not None:
-                    break
-            if img is not None:
-                outs[i] = img
-                continue
         d = torch.empty((rows, 3 * cols), device=t.device, dtype=torch.bfloat16)
         outs[i] = d
         todo.append((i, key))

@@ -219,7 +219,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             raise NotImplementedError
         from . import ops
-        ops.x3_cache_clear(weights=True)          # (the backward is over: the bf16x3 operand images of this step can go)
+        ops.x3_cache_clear()                      # (the backward is over: the bf16x3 operand images of this step can go)
         if self._static is None:
             self._build()
         ps = self._ps

@@ -17,8 +17,6 @@ _PK = np.dtype([('w', np.uint64), ('bnscale', np.uint64), ('wf', np.uint64), ('w
                 ('ne', np.int32), ('Cout', np.int32), ('Cin', np.int32), ('taps', np.int32)])
 _FJ = np.dtype([('w', np.uint64), ('wf', np.uint64), ('wb', np.uint64), ('N', np.int32), ('K', np.int32), ('blk0', np.int32),
                 ('src_bf16', np.int32)])
-_SJ = np.dtype([('src', np.uint64), ('ld', np.int64), ('dst', np.uint64), ('rows', np.int32), ('cols', np.int32), ('pattern', np.int32),
-                ('blk0', np.int32)])
 _CHUNK = 32768
 
 _active = []          # stack of plans whose prepared tensors are valid right now (inside a model forward)
@@ -136,80 +134,6 @@ class PackPlan(object):
         self._host_pk = torch.empty(max(self._pk.nbytes, 8), dtype=torch.uint8).pin_memory()
         self._last = None
         self._init_frags(frags if dt == BF16 else (), device, conv_frags if dt == BF16 else ())
-        self._x3 = None                       # (built on the first run in the fast bf16x3 mode)
-
-    # ---- fast bf16x3 mode: every weight operand's [hi | hi | lo] image in ONE launch per forward (a convolution: per-tap channel runs)
-    def _init_x3(self):
-        rows = []                             # (index into self._entries, which: 0 forward operand / 1 dgrad operand, rows, cols)
-        total = 0
-        for i, (w, wf, wb, sc, bi) in enumerate(self._entries):
-            Co, Ci = w.shape[0], w.shape[1]
-            taps = w.numel() // (Co * Ci)
-            if wf is None and wb is None:
-                continue
-            if Ci % 4 == 0:
-                rows.append((i, 0, Co * taps, Ci))
-                total += 3 * w.numel()
-            if wb is not None and Co % 4 == 0:
-                rows.append((i, 1, Ci * taps, Co))
-                total += 3 * w.numel()
-        self._x3_rows = rows
-        self._x3_buf = torch.empty(max(total, 8), device=self.device, dtype=torch.bfloat16)
-        self._x3_jobs = np.zeros(len(rows), _SJ)
-        lib = L.load()
-        off, blk, base = 0, 0, self._x3_buf.data_ptr()
-        self._x3_imgs = []
-        for r, (i, which, nr, nc) in enumerate(rows):
-            j = self._x3_jobs[r]
-            j['dst'], j['rows'], j['cols'], j['ld'], j['pattern'], j['blk0'] = base + 2 * off, nr, nc, nc, 1, blk
-            self._x3_imgs.append(self._x3_buf[off:off + 3 * nr * nc].view(nr, 3 * nc))
-            off += 3 * nr * nc
-            blk += lib.sedt_split3_blocks(nr, nc)
-        self._x3_blocks = blk
-        self._x3_dev = torch.empty(max(self._x3_jobs.nbytes, 8), dtype=torch.uint8, device=self.device)
-        self._x3_host = torch.empty(max(self._x3_jobs.nbytes, 8), dtype=torch.uint8).pin_memory()
-        self._x3_key = None
-        self._x3 = {}
-
-    def _run_x3(self):
-        if self._x3 is None:
-            self._init_x3()
-        if not len(self._x3_jobs):
-            return
-        srcs = []
-        for (i, which, nr, nc) in self._x3_rows:
-            w, wf, wb, sc, bi = self._entries[i]
-            t = (wf if wf is not None else w) if which == 0 else wb
-            srcs.append(t.data_ptr())
-        key = tuple(srcs)
-        if key != self._x3_key:
-            self._x3_jobs['src'] = np.asarray(srcs, np.uint64)
-            self._x3_host.numpy()[:self._x3_jobs.nbytes] = self._x3_jobs.view(np.uint8)
-            self._x3_dev.copy_(self._x3_host, non_blocking=True)
-            self._x3_key = key
-            # (pointer, rows, cols) -> image, plus the address ranges for row-slice views (in_proj_weight[:2E] ...)
-            self._x3 = {(p_, nr, nc): img for p_, (i, which, nr, nc), img in zip(srcs, self._x3_rows, self._x3_imgs)}
-            self._x3_ranges = sorted((p_, p_ + 4 * nr * nc, nr, nc, img) for p_, (i, which, nr, nc), img in zip(srcs, self._x3_rows, self._x3_imgs))
-        L.check(L.load().sedt_split3_table(L.p(self._x3_dev), len(self._x3_jobs), self._x3_blocks, L.stream_ptr()), 'split3_table')
-        from . import ops
-        if self not in ops.X3_WPLANS:
-            ops.X3_WPLANS.append(self)
-
-    def x3_lookup(self, ptr, rows, cols, ld):
-        if not self._x3 or ld != cols:
-            return None
-        hit = self._x3.get((ptr, rows, cols))
-        if hit is not None:
-            return hit
-        import bisect
-        k = bisect.bisect_right(self._x3_ranges, (ptr, float('inf'))) - 1
-        if k >= 0:
-            lo, hi, nr, nc, img = self._x3_ranges[k]
-            if lo <= ptr < hi and nc == cols and (ptr - lo) % (4 * cols) == 0:
-                r0 = (ptr - lo) // (4 * cols)
-                if r0 + rows <= nr:
-                    return img[r0:r0 + rows]
-        return None
 
     def _init_frags(self, frags, device, conv_frags):
         self.frag_table, self._fr_params, self._fr_entries = {}, [], []
@@ -284,13 +208,6 @@ class PackPlan(object):
         L.check(lib.sedt_multi_pack(L.p(self._dev_pk), len(self._pk), self._nblocks, self.dt, L.stream_ptr()), 'multi_pack')
         if len(self._fj):
             L.check(lib.sedt_pack_frag(L.p(self._dev_fj), len(self._fj), self._fr_blocks, L.stream_ptr()), 'pack_frag')
-        from . import ops
-        if self.dt == F32 and L.GEMM_X3 and ops.X3_FAST and ops.X3_PLAN_WEIGHTS:
-            self._run_x3()
-        elif self._x3:
-            self._x3 = {}
-            if self in ops.X3_WPLANS:
-                ops.X3_WPLANS.remove(self)
 
     def __enter__(self):
         from . import ops
