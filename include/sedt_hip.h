@@ -119,9 +119,9 @@ typedef struct SedtIgemm {
   int32_t omap;           /* != 0: GEMM row (n, ho, wo) of the Ho x Wo grid is pixel (ho * o_sh + o_h0, wo * o_sw + o_w0) of an o_Hi x o_Wi
                              image: C, res, mask, bits_out are indexed by that pixel */
   int32_t o_Hi, o_Wi, o_sh, o_sw, o_h0, o_w0;
-  int32_t btap_on;        /* != 0: tap t of the (<= 4-tap) walk reads the Ci channels starting at element btap[t] of a B row (ldb spans
+  int32_t btap_on;        /* != 0: tap t of the (<= 8-tap) walk reads the Ci channels starting at element btap[t] of a B row (ldb spans
                              all the taps the packed weight holds) */
-  int32_t btap[4];
+  int32_t btap[8];
   void* split_out;        /* f32ep only, or null: bf16 [M][3 N] = the [hi | lo | hi] operand image (sedt_split3, pattern 0) of the stored
                              output, written by the epilogue - the GEMMs that consume this output then need no split pass */
 } SedtIgemm;

@@ -183,6 +183,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   }
   // btap (conv problems only): the B rows hold MORE taps than this problem walks - tap t of the walk reads the channel run that starts
   // at element btap[t] of a B row (a parity class of a stride-2 input gradient uses 1, 2 or 4 of the nine tap blocks of the packed
+  // dgrad weight, a column half of layer4's dilated 3x3 six,
   // dgrad weight, in place).  cur_bt = that start for the current tap (wave-uniform)
   int cur_bt = (CONV && p.btap_on) ? p.btap[tap] : 0;
   auto advance = [&]() {
@@ -200,7 +201,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       const unsigned tapbit = 1u << tap;
 #pragma unroll
       for (int i = 0; i < GA; ++i) a_cur[i] = (a_mask[i] & tapbit) ? a_off[i] + tapdelta : OOB;
-      if (p.btap_on) cur_bt = p.btap[tap & 3];
+      if (p.btap_on) cur_bt = p.btap[tap & 7];
     }
   };
 
@@ -655,6 +656,34 @@ __global__ __launch_bounds__(256) void igemm3_group_kernel(const IgemmGroup g) {
   igemm3_body<64, 64, S>(g.p[i], g.a_bytes[i], g.b_bytes[i], (int)blockIdx.x - g.blk0[i]);
 }
 
+// two or more problems of ONE ping-pong configuration in one launch (the column halves of layer4's dilated 3x3 convolutions: 128 tiles of
+// 128x128 each - launched alone, either half would leave half the chip idle)
+template <int BM, int BN, int S>
+__global__ __launch_bounds__(512) void igemm3_w8_group_kernel(const IgemmGroup g) {
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.blk0[i + 1]) ++i;
+  igemm3_body<BM, BN, S, 8, 1>(g.p[i], g.a_bytes[i], g.b_bytes[i], (int)blockIdx.x - g.blk0[i]);
+}
+
+template <int BM, int BN, int S>
+static int launch3_w8_group(const IgemmGroup& g, int nblk, hipStream_t st) {
+  constexpr size_t ring = (size_t)S * (BM + BN) * ROWB;
+  constexpr size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);
+  constexpr size_t lds = ring > ctile ? ring : ctile;
+  static bool attr_set = false;
+  auto kern = igemm3_w8_group_kernel<BM, BN, S>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("igemm3 w8 group: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, st, g);
+  return check_launch("igemm3_w8_group");
+}
+
 template <int BM, int BN, int S>
 static int launch3_co(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st, const WgradGroup& g) {
   constexpr size_t ring = (size_t)S * (BM + BN) * ROWB;
@@ -720,7 +749,7 @@ int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
   if (!on || njobs < 2 || njobs > IG_MAXG) return -1;
   IgemmGroup g;
   g.n = njobs;
-  int blk = 0, S = 0;
+  int blk = 0, S = 0, big = 0;
   for (int i = 0; i < njobs; ++i) {
     const SedtIgemm& p = jobs[i];
     if (p.trans) return -1;
@@ -728,16 +757,21 @@ int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
     const int r = igemm_lds_try(p, st);
     const Igemm3Plan got = plan3;
     plan3.on = false;
-    if (r != 0 || !got.ok || got.bm != 64 || got.bn != 64 || (got.s != 2 && got.s != 3)) return -1;
+    if (r != 0 || !got.ok) return -1;
+    const bool b128 = got.bm == 128 && got.bn == 128 && got.s == 3;           // (requested by the caller's tile hint)
+    if (!b128 && (got.bm != 64 || got.bn != 64 || (got.s != 2 && got.s != 3))) return -1;
+    if (i == 0) big = b128;
+    if ((int)b128 != big) return -1;
     if (i == 0) S = got.s;
     if (got.s < S) S = got.s;               // mixed depths: the shallower ring serves every K
     g.p[i] = p;
     g.a_bytes[i] = got.a_bytes;
     g.b_bytes[i] = got.b_bytes;
     g.blk0[i] = blk;
-    blk += ((p.N + 63) / 64) * ((p.M + 63) / 64);
+    blk += big ? ((p.N + 127) / 128) * ((p.M + 127) / 128) : ((p.N + 63) / 64) * ((p.M + 63) / 64);
   }
   g.blk0[njobs] = blk;
+  if (big) return launch3_w8_group<128, 128, 3>(g, blk, st);
   if (S == 3) {
     constexpr size_t lds = (size_t)3 * (64 + 64) * ROWB;
     static bool attr_set = false;
@@ -890,7 +924,7 @@ int igemm_lds_try(const SedtIgemm& p, hipStream_t st) {
   long a_bytes = ((a_rows - 1) * p.lda + (p.conv ? p.Ci : p.K)) * 2;
   long b_bytes = ((long)(p.N - 1) * p.ldb + p.K) * 2;
   if (p.btap_on) {
-    if (!p.conv || p.KH * p.KW > 4) return -1;
+    if (!p.conv || p.KH * p.KW > 8) return -1;
     b_bytes = (long)p.N * p.ldb * 2;                 // (the tap table points anywhere inside a B row)
   }
   if (p.omap && !p.conv) return -1;

@@ -408,6 +408,8 @@ def conv_fwd(dtype, x, B, g, wf, out=None, **ep):
         out = torch.empty((M, g.Co), device=x.device, dtype=TORCH_DTYPE[dtype])
     if _conv3_c64_ok(dtype, x, g, ep, out):
         return _conv3_c64(x, B, g, wf, 0, out, ep)
+    if _dil_halves_ok(dtype, x, g, wf, out, ep, False):
+        return _conv_dil_halves(x, B, g, wf, out, ep, False, dtype == F32)
     conv = None if g.plain else _geom_tuple(g)
     global PROFILE_HINT
     if PROFILE is not None and _conv3_c64_ok(dtype, x, g, ep, out, True):
@@ -469,6 +471,61 @@ def _conv_dgrad_s2(dy, B, g, wb, out, ep, x3=False):
     return out
 
 
+# layer4's dilated 3x3 convolutions (dilation 2, padding 2) run on a map of FOUR columns: the left tap column (kw = 0) lands inside the image
+# only for output columns 2, 3 and the right one (kw = 2) only for columns 0, 1 - a third of the tap walk multiplies zero rows.  Split by
+# column half, each half is a regular 3 x 2-tap convolution over all four input columns with its own six tap blocks of the packed
+# weight (SedtIgemm.btap) and its own two output columns (SedtIgemm.omap): two problems of 128 tiles of 128x128 in ONE grouped ping-pong
+# launch (igemm3_w8_group_kernel), 2/3 of the K loop each.  Forward and input gradient (the mirror image) alike.
+DIL_HALVES = _dev_env('SEDT_DIL_HALVES', '1') != '0'
+
+
+def _dil_halves_ok(dtype, t, g, w, out, ep, transposed):
+    x3 = dtype == F32 and L.GEMM_X3 and X3_FAST
+    if not (DIL_HALVES and (dtype == BF16 or x3) and PROFILE is None and not _co['on']):
+        return False
+    d = g.dh
+    cin, cout = (g.Co, g.Ci) if transposed else (g.Ci, g.Co)          # channels of the gathered tensor / of the output
+    if not (g.KH == 3 and g.KW == 3 and g.sh == 1 and g.sw == 1 and g.dw == d and d >= 1 and g.ph == d and g.pw == d and g.Wi == 2 * d
+            and g.Wo == g.Wi and g.Ho == g.Hi and cin % 64 == 0 and cout % 128 == 0 and w.stride(0) == 9 * cin and t.stride(0) % 8 == 0
+            and out.stride(0) % 8 == 0):
+        return False
+    if x3 and not (t.dtype == torch.float32 and out.dtype == torch.float32 and t.data_ptr() % 16 == 0 and t.stride(0) % 4 == 0
+                   and all(ep.get(k_) is None or ep[k_].dtype == torch.float32 for k_ in ('res',))
+                   and (ep.get('mask') is None or ep.get('mask_bits') or ep['mask'].dtype == torch.float32)):
+        return False
+    # (the halves pay while the two problems fill the chip with 128x128 tiles)
+    B_rows = t.shape[0]
+    return set(ep) <= {'scale', 'bias', 'act', 'mask', 'ldm', 'mask_bits', 'res', 'ldr', 'alpha', 'bits_out', 'act_post_res'} \
+        and (B_rows // 2 // 128) * (cout // 128) >= 96
+
+
+def _conv_dil_halves(t, B, g, w, out, ep, transposed, x3):
+    """t = x (forward) or dY (input gradient); w = the packed forward / dgrad operand [cout][9][cin]"""
+    d = g.dh
+    cin, cout = (g.Co, g.Ci) if transposed else (g.Ci, g.Co)
+    C = cin
+    if x3:
+        t, w = _split3([(t, 0, B * g.Hi * g.Wi, cin, t.stride(0), 0), (w, 0, cout * 9, cin, cin, 1)])
+        w = w.view(cout, 27 * cin)
+        C = 3 * cin
+    jobs = []
+    for half in (0, 1):
+        # forward: output columns [0, d) see taps kw in {1, 2}, columns [d, 2d) taps {0, 1}; the input gradient mirrors it
+        kw0 = (1 - half) if not transposed else half
+        conv = (g.Hi, g.Wi, C, g.Ho, d, 3, 2, 1, 1, d, (d if transposed else 0), d, d)
+        a = igemm_args(B * g.Ho * d, cout, 6 * C, t, t.stride(0), w, w.stride(0), out, out.stride(0), conv=conv, transposed=int(transposed),
+                       tile=(128, 128), out_f32=int(x3), **ep)
+        a.omap, a.o_Hi, a.o_Wi, a.o_sh, a.o_sw, a.o_h0, a.o_w0 = 1, g.Ho, g.Wo, 1, 1, 0, half * d
+        a.btap_on, a.f32ep = 1, int(x3)
+        for kh in range(3):
+            for j in range(2):
+                a.btap[kh * 2 + j] = (kh * 3 + kw0 + j) * C
+        jobs.append(a)
+    arr = (L.SedtIgemm * 2)(*jobs)
+    L.check(L.load().sedt_igemm_group(arr, 2, BF16, L.stream_ptr()), 'igemm_group_dil')
+    return out
+
+
 def conv_dgrad(dtype, dy, B, g, wb, out=None, **ep):
     """dx [B*Hi*Wi, Ci] = conv_transpose(dy [B*Ho*Wo, Co]); wb packed [Ci][taps][Co] (BN scale folded in)"""
     M = B * g.Hi * g.Wi
@@ -476,6 +533,8 @@ def conv_dgrad(dtype, dy, B, g, wb, out=None, **ep):
         out = torch.empty((M, g.Ci), device=dy.device, dtype=TORCH_DTYPE[dtype])
     if _dgrad_s2_ok(dtype, dy, g, wb, out, ep):
         return _conv_dgrad_s2(dy, B, g, wb, out, ep, x3=dtype == F32)
+    if _dil_halves_ok(dtype, dy, g, wb, out, ep, True):
+        return _conv_dil_halves(dy, B, g, wb, out, ep, True, dtype == F32)
     if _conv3_c64_ok(dtype, dy, g, ep, out) and 'scale' not in ep and 'bias' not in ep:
         return _conv3_c64(dy, B, g, wb, 1, out, ep)       # the input gradient of a stride-1 3x3 conv is the same conv, taps flipped
     conv = None if g.plain else _geom_tuple(g, transposed=True)

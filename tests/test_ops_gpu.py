@@ -793,3 +793,44 @@ def test_stride2_dgrad_by_output_parity_equals_the_transposed_gather(ops, B, Hi,
     # same products, same order of the non-zero taps; the two kernels run different tiles (64x64 against 128x128 with two K groups), so an
     # f32 sum may differ in its last bit and land on the neighbouring bf16 value: one bf16 step of the largest entry = 2^-8 = 3.9e-3 of it
     assert ((out[True].float() - out[False].float()).abs().max().item()) < 8e-3 * scale
+
+
+@pytest.mark.parametrize('H', [32, 31])
+def test_dilated_conv_by_column_halves_equals_the_plain_gather(ops, H):
+    """layer4's dilated 3x3 (dilation 2, padding 2, four columns) as two column halves of six taps each in one grouped ping-pong launch
+    (ops._conv_dil_halves) against the nine-tap gather it replaces and against torch in f32 on the bf16-rounded operands: forward with
+    FrozenBN + ReLU, input gradient with the 1-bit ReLU mask; URBAN-SED (32 rows) and DCASE (31 rows) maps at C2's batch"""
+    import torch.nn.functional as F
+    from sound_event_detection_transformer_amd import lib as L
+    B, W, C = 64, 4, 512
+    g = torch.Generator().manual_seed(H)
+    geo = ops.ConvGeom(H, W, C, C, 3, 1, 2, 2)
+    w = (torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5).cuda()
+    sc, bi = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    wf, wb = ops.pack_conv(L.BF16, w, bnscale=sc)
+    x = torch.randn(B * H * W, C, generator=g).cuda().bfloat16()
+    dy = torch.randn(B * H * W, C, generator=g).cuda().bfloat16()
+    bits = torch.randint(0, 256, (B * H * W, C // 8), generator=g, dtype=torch.uint8).cuda()
+    out = {}
+    for halves in (True, False):
+        keep, ops.DIL_HALVES = ops.DIL_HALVES, halves
+        try:
+            with L.launch_log() as log:
+                y = ops.conv_fwd(L.BF16, x, B, geo, wf, scale=sc, bias=bi, act=ops.ACT_RELU)
+                dx = ops.conv_dgrad(L.BF16, dy, B, geo, wb, mask=bits, ldm=bits.stride(0), mask_bits=True)
+            torch.cuda.synchronize()
+        finally:
+            ops.DIL_HALVES = keep
+        assert log['igemm_group_dil'] == (2 if halves else 0) and log['sedt_igemm'] == (0 if halves else 2), dict(log)
+        out[halves] = (y, dx)
+    wq = w.bfloat16().float()
+    xn = x.float().view(B, H, W, C).permute(0, 3, 1, 2)
+    ref_y = F.relu(F.conv2d(xn, wq, padding=2, dilation=2) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1)).permute(0, 2, 3, 1).reshape(-1, C)
+    wsq = (w * sc.view(-1, 1, 1, 1)).bfloat16().float()                    # (the dgrad operand carries the BN scale)
+    keepm = ((bits.view(-1, C // 8, 1) >> torch.arange(8, device='cuda', dtype=torch.uint8)) & 1).bool().view(-1, C)
+    ref_dx = F.conv_transpose2d(dy.float().view(B, H, W, C).permute(0, 3, 1, 2), wsq, padding=2, dilation=2).permute(0, 2, 3, 1).reshape(-1, C)
+    ref_dx = ref_dx * keepm
+    for got, ref in ((out[True][0], ref_y), (out[True][1], ref_dx)):
+        assert (got.float() - ref).abs().max().item() < 1e-2 * ref.abs().max().item()
+    for a_, b_ in zip(out[True], out[False]):
+        assert (a_.float() - b_.float()).abs().max().item() < 8e-3 * b_.float().abs().max().item()
