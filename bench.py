@@ -819,7 +819,7 @@ def kernel_report(dtype, dev):
     return out
 
 
-def other_configs(args, dev, keep_alive, replays=10):
+def other_configs(args, dev, keep_alive, replays=20, settle=30):
     """BASELINE.json's configs[2..4] (C3 DCASE weak+strong step, C4 SP-SEDT pre-training step, C5 mean-teacher step with its
     mix-up) and the headline config in the f32 parity mode on this GPU, each captured and timed for a bounded number of replays AFTER
     the headline's timed region, so that they appear in the driver's record too.  Per-rank figures on one GPU; never allowed to cost the headline (errors are reported in
@@ -842,7 +842,7 @@ def other_configs(args, dev, keep_alive, replays=10):
                 a.config, a.dtype = 'c2', 'bf16x3'
                 runtime.set_compute_dtype('bf16x3')
             step, clips, flop, what, _, ex = build_workload(a, dev, 0, 1)
-            for _ in range(3):
+            for _ in range(settle):              # (the first replays after a capture run slow: the same settle policy as the headline)
                 step()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -856,7 +856,7 @@ def other_configs(args, dev, keep_alive, replays=10):
             ms = e0.elapsed_time(e1) / replays
             res[name] = {"ms_per_step": round(wall * 1e3, 3), "ms_per_step_hip_events": round(ms, 3), "clips_per_step": clips,
                          "clips_s": round(clips / wall, 1), "dtype": a.dtype, "frac": round(flop / wall / MFMA_PEAK[a.dtype], 4),
-                         "peak_tflops": MFMA_PEAK[a.dtype] / 1e12, "replays": replays, "workload": what}
+                         "peak_tflops": MFMA_PEAK[a.dtype] / 1e12, "replays": replays, "settle_replays": settle, "workload": what}
             del step, ex
         except Exception as e:                   # noqa: BLE001
             res[name] = {"error": repr(e)[:200]}
