@@ -199,6 +199,8 @@ def _split3(jobs):
         outs[i] = d
         todo.append((i, key))
         if pattern == 0 and X3_CACHE_ON:
+            if len(X3_CACHE) >= 1024:           # (op-level callers outside a model forward never reach a clearing point: bound what is held)
+                X3_CACHE.clear()
             X3_CACHE[key] = (t, d)
     if todo:
         arr = (L.SedtSplitJob * len(todo))()
