@@ -808,6 +808,59 @@ def kernel_report(dtype, dev):
            "the max-pool backward -> weight-gradient GEMM chain it replaced: 122 us")
     t = timeit(lambda: ops.layernorm_fwd(dt, x, gam, bet))
     hb("LayerNorm fwd 8192 x 256 (sedt_layernorm_fwd)", 2.0 * M * E * es, t)
+    if dt == L.BF16:
+        # ---- round 5: zero-tap elimination (the same problem with the plain nine-tap gather beside it) and the parity-grade bf16x3 pieces
+        def ab(flag, fn):
+            res = []
+            for on in (True, False):
+                keep = getattr(ops, flag)
+                setattr(ops, flag, on)
+                try:
+                    res.append(timeit(fn))
+                finally:
+                    setattr(ops, flag, keep)
+            return res
+        C4_ = 512
+        g4 = ops.ConvGeom(32, 4, C4_, C4_, 3, 1, 2, 2)
+        x4, w4 = rnd(B * 128, C4_), torch.randn(C4_, C4_, 3, 3, device=dev) / 68
+        sc4, bi4 = torch.ones(C4_, device=dev), torch.zeros(C4_, device=dev)
+        wf4, wb4 = ops.pack_conv(dt, w4, bnscale=sc4)
+        t1, t0 = ab('DIL_HALVES', lambda: ops.conv_fwd(dt, x4, B, g4, wf4, scale=sc4, bias=bi4, act=L.ACT_RELU))
+        mf("layer4 dilated 3x3 fwd by column halves (2 x 6-tap problems, one grouped 128x128 launch; useful flops = 2/3 of the 9-tap walk)",
+           2.0 * B * 128 * C4_ * 6 * C4_, t1, "the plain nine-tap gather: %.1f us" % (t0 * 1e6))
+        g3 = ops.ConvGeom(63, 8, 256, 256, 3, 2, 1, 1)
+        w3 = torch.randn(256, 256, 3, 3, device=dev) / 48
+        _, wb3 = ops.pack_conv(dt, w3)
+        dy3 = rnd(B * g3.Ho * g3.Wo, 256)
+        t1, t0 = ab('S2_PARITY', lambda: ops.conv_dgrad(dt, dy3, B, g3, wb3))
+        mf("layer3 block 0 stride-2 3x3 input gradient by output parity (4 grouped problems; useful flops = 1/4 of the transposed gather's)",
+           2.0 * B * 63 * 8 * 256 * 9 * 256 / 4, t1, "the transposed nine-tap gather: %.1f us" % (t0 * 1e6))
+        # bf16x3: f32 tensors, one bf16 GEMM over the tripled contraction; priced against a third of the bf16 peak (three MFMAs per product)
+        xf, wf32 = torch.randn(M, FF, device=dev), torch.randn(E, FF, device=dev) / 45
+        keep3 = L.GEMM_X3
+        L.GEMM_X3 = True
+        try:
+            def x3lin():
+                ops.x3_cache_clear()
+                return ops.linear(L.F32, xf, wf32)
+            t = timeit(x3lin)
+            out.append({"kernel": "bf16x3 linear 8192 x 256 x 2048 (split pass + ONE bf16 GEMM over K' = 6144, f32 epilogue)", "us": round(t * 1e6, 2),
+                        "achieved": round(2.0 * M * E * FF / t / 1e12, 1), "unit": "TFLOP/s (f32-grade products)", "peak": round(peak / 3e12, 1),
+                        "frac": round(2.0 * M * E * FF / t / (peak / 3), 4), "bound": "mfma",
+                        "note": "peak = a third of the dense bf16 peak: hi.hi + lo.hi + hi.lo"})
+            qf, kf, vf = torch.randn(M, E, device=dev), torch.randn(M, E, device=dev), torch.randn(M, E, device=dev)
+            t = timeit(lambda: ops.attention_fwd(L.F32, qf, kf, vf, B, H, S, S, None, None, 0.1, 7, None))
+            out.append({"kernel": "f32 attention core fwd on v_mfma_f32_32x32x2_f32 (512 heads x 128x128x32, dropout 0.1)", "us": round(t * 1e6, 2),
+                        "achieved": round(4.0 * S * S * 32 * B * H / t / 1e12, 1), "unit": "TFLOP/s", "peak": MFMA_PEAK['f32'] / 1e12,
+                        "frac": round(4.0 * S * S * 32 * B * H / t / MFMA_PEAK['f32'], 4), "bound": "mfma", "note": "exact f32 matrix rate (157 TF)"})
+            def split_only():
+                ops.x3_cache_clear()
+                return ops._split3([(xf, 0, M, FF, FF, 0)])
+            t = timeit(split_only)
+            hb("bf16x3 operand image 8192 x 2048 (sedt_split3: f32 -> [hi | lo | hi])", 10.0 * M * FF, t, "4 B read + 6 B written per element")
+        finally:
+            L.GEMM_X3 = keep3
+            ops.x3_cache_clear()
     n = 32579869
     p = torch.nn.Parameter(torch.zeros(n, device=dev))
     p.grad = torch.full((n,), 1e-3, device=dev)
