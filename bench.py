@@ -857,7 +857,7 @@ def kernel_report(dtype, dev):
                 ops.x3_cache_clear()
                 return ops._split3([(xf, 0, M, FF, FF, 0)])
             t = timeit(split_only)
-            hb("bf16x3 operand image 8192 x 2048 (sedt_split3: f32 -> [hi | lo | hi])", 10.0 * M * FF, t, "4 B read + 6 B written per element")
+            hb("bf16x3 operand image 8192 x 2048 (sedt_split3: f32 -> [hi | lo])", 8.0 * M * FF, t, "4 B read + 4 B written per element")
         finally:
             L.GEMM_X3 = keep3
             ops.x3_cache_clear()

@@ -122,8 +122,11 @@ typedef struct SedtIgemm {
   int32_t btap_on;        /* != 0: tap t of the (<= 8-tap) walk reads the Ci channels starting at element btap[t] of a B row (ldb spans
                              all the taps the packed weight holds) */
   int32_t btap[8];
-  void* split_out;        /* f32ep only, or null: bf16 [M][3 N] = the [hi | lo | hi] operand image (sedt_split3, pattern 0) of the stored
+  void* split_out;        /* f32ep only, or null: bf16 [M][2 N] = the [hi | lo] operand image (sedt_split3, pattern 0) of the stored
                              output, written by the epilogue - the GEMMs that consume this output then need no split pass */
+  int32_t awrap;          /* bf16x3, trans == 0: the A rows hold [hi | lo] = 2 awrap channels while the contraction walks 3 awrap per pixel
+                             (K = 3 awrap, a convolution: Ci = 3 awrap): the last third re-reads hi.  0 = off */
+  int32_t pad2_;
 } SedtIgemm;
 
 int sedt_igemm(const SedtIgemm* args, int dtype, void* stream);
@@ -163,11 +166,13 @@ typedef struct SedtPrefetch {
   size_t bytes[3];
 } SedtPrefetch;
 
-/* Operand preparation of the fast bf16x3 mode (csrc/split3.hip): src f32 [rows][cols] (row stride ld) -> dst bf16 [rows][3 * cols] =
- * [hi | lo | hi] (pattern 0: an activation / gradient operand) or [hi | hi | lo] (pattern 1: a weight operand; rows = Cout * taps,
- * cols = Cin), hi = bf16(x), lo = bf16(x - hi).  A bf16 GEMM over the tripled contraction axis (a convolution: Ci' = 3 Ci) then yields
- * hi hi + lo hi + hi lo in its f32 accumulator: an f32 product to ~2^-16 at bf16 MFMA rate (with SedtIgemm.f32ep for the epilogue).
- * Up to 4 jobs per launch (HOST array, copied into the kernel arguments).  cols and ld multiples of 4, src 16-byte aligned. */
+/* Operand preparation of the fast bf16x3 mode (csrc/split3.hip): src f32 [rows][cols] (row stride ld) -> bf16, hi = bf16(x), lo = bf16(x - hi):
+ *   pattern 0 (an activation / gradient operand): dst [rows][2 * cols] = [hi | lo] - the bytes of the f32 tensor;
+ *   pattern 1 (a weight operand; rows = Cout * taps, cols = Cin): dst [rows][3 * cols] = [hi | hi | lo].
+ * A bf16 GEMM whose contraction walks hi, lo, hi of the activation (SedtIgemm.awrap: the last third wraps back onto hi) against
+ * [hi | hi | lo] of the weight yields hi hi + lo hi + hi lo in its f32 accumulator: an f32 product to ~2^-16 at bf16 MFMA rate (with
+ * SedtIgemm.f32ep for the epilogue).  Up to 4 jobs per launch (HOST array, copied into the kernel arguments).  cols and ld multiples of 4,
+ * src 16-byte aligned. */
 typedef struct SedtSplitJob {
   const float* src;
   int64_t ld;

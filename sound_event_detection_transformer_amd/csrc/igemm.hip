@@ -647,7 +647,7 @@ extern "C" int sedt_igemm(const SedtIgemm* args, int dtype, void* stream) {
   SEDT_REQUIRE(args->A && args->B && (args->C || args->splitk > 1), "igemm: null operand");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype != SEDT_BF16)
-    SEDT_REQUIRE(!args->omap && !args->btap_on && !args->f32ep, "igemm: omap / btap / f32ep are features of the bf16 LDS-DMA kernels");
+    SEDT_REQUIRE(!args->omap && !args->btap_on && !args->f32ep && !args->awrap, "igemm: omap / btap / f32ep / awrap are features of the bf16 LDS-DMA kernels");
   if (dtype == SEDT_F32) {
     SEDT_REQUIRE(args->colsum_out == nullptr, "igemm: colsum_out is a bf16-only feature");
     return launch_typed<float>(*args, st);
@@ -662,8 +662,8 @@ extern "C" int sedt_igemm(const SedtIgemm* args, int dtype, void* stream) {
       if (r >= 0) return r;
     }
     SEDT_REQUIRE(args->colsum_out == nullptr, "igemm: colsum_out needs the bf16 LDS-DMA wgrad kernel (M,N,lda,ldb %% 8 == 0)");
-    SEDT_REQUIRE(!args->omap && !args->btap_on && !args->f32ep,
-                 "igemm: omap / btap / f32ep problem outside the LDS-DMA envelope (M %d N %d K %d)", args->M, args->N, args->K);
+    SEDT_REQUIRE(!args->omap && !args->btap_on && !args->f32ep && !args->awrap,
+                 "igemm: omap / btap / f32ep / awrap problem outside the LDS-DMA envelope (M %d N %d K %d)", args->M, args->N, args->K);
     return launch_typed<bf16_t>(*args, st);
   }
   set_error("igemm: unsupported dtype %d", dtype);

@@ -210,7 +210,9 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     unsigned char* st = ring + stage * STAGE_BYTES;
     const unsigned kb2 = (CONV && p.btap_on) ? (unsigned)((cur_bt + c0) * 2) : (unsigned)(k0 * 2);
     if (i < GA) {
-      const unsigned koff = CONV ? (unsigned)(c0 * 2) : kb2;    // (an out-of-range a_cur stays out of range: c0 * 2 < 2^31)
+      unsigned koff = CONV ? (unsigned)(c0 * 2) : (unsigned)(k0 * 2);    // (an out-of-range a_cur stays out of range: c0 * 2 < 2^31)
+      // awrap (bf16x3): the A rows hold [hi | lo] (2 awrap channels) and the walk over 3 awrap reads hi again for its last third
+      if (p.awrap && (CONV ? c0 : k0) >= 2 * p.awrap) koff -= 4u * (unsigned)p.awrap;
       unsigned voff = a_cur[i] + koff;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(st + ((i * NW + wave) * 8) * ROWB), 16, voff, 0, 0, 0);
     } else {
@@ -525,17 +527,16 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
         for (int e = 0; e < 8; ++e) ob |= (v[e] > 0.f ? 1u : 0u) << e;
         p.bits_out[orow * p.ldbits + (col >> 3)] = (uint8_t)ob;
       }
-      if (p.split_out) {        // the [hi | lo | hi] operand image of what was stored (sedt_split3, pattern 0) for the GEMMs that consume it
+      if (p.split_out) {        // the [hi | lo] operand image of what was stored (sedt_split3, pattern 0) for the GEMMs that consume it
         bf16x8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           hi[e] = (bf16_t)v[e];
           lo[e] = (bf16_t)(v[e] - (float)hi[e]);
         }
-        bf16_t* sp = reinterpret_cast<bf16_t*>(p.split_out) + orow * (3L * p.N) + col;
+        bf16_t* sp = reinterpret_cast<bf16_t*>(p.split_out) + orow * (2L * p.N) + col;
         *reinterpret_cast<bf16x8*>(sp) = hi;
         *reinterpret_cast<bf16x8*>(sp + p.N) = lo;
-        *reinterpret_cast<bf16x8*>(sp + 2L * p.N) = hi;
       }
       continue;
     }
@@ -921,7 +922,8 @@ int igemm_lds_try(const SedtIgemm& p, hipStream_t st) {
   if (p.conv && (p.Ci % BK2)) return -1;
   // bytes addressable through the A descriptor: every gathered pixel row + one K tile past its start
   long a_rows = p.conv ? (long)((p.M + (long)p.Ho * p.Wo - 1) / ((long)p.Ho * p.Wo)) * p.Hi * p.Wi : (long)p.M;
-  long a_bytes = ((a_rows - 1) * p.lda + (p.conv ? p.Ci : p.K)) * 2;
+  long a_bytes = ((a_rows - 1) * p.lda + (p.awrap ? 2 * p.awrap : (p.conv ? p.Ci : p.K))) * 2;
+  if (p.awrap && 3 * p.awrap != (p.conv ? p.Ci : p.K)) return -1;
   long b_bytes = ((long)(p.N - 1) * p.ldb + p.K) * 2;
   if (p.btap_on) {
     if (!p.conv || p.KH * p.KW > 8) return -1;

@@ -187,7 +187,7 @@ def x3_cache_clear():
 
 def _split3(jobs):
     """jobs: (tensor, element offset of the view's first element, rows, cols, row stride, pattern); one launch for up to four.  Returns the
-    bf16 [rows, 3 * cols] images"""
+    bf16 images: [rows, 2 * cols] = [hi | lo] for pattern 0 (activations / gradients), [rows, 3 * cols] = [hi | hi | lo] for pattern 1 (weights)"""
     outs, todo = [None] * len(jobs), []
     for i, (t, off, rows, cols, ld, pattern) in enumerate(jobs):
         key = (t.data_ptr() + 4 * off, rows, cols, ld)
@@ -195,7 +195,7 @@ def _split3(jobs):
         if hit is not None:
             outs[i] = hit[1]
             continue
-        d = torch.empty((rows, 3 * cols), device=t.device, dtype=torch.bfloat16)
+        d = torch.empty((rows, (3 if pattern else 2) * cols), device=t.device, dtype=torch.bfloat16)
         outs[i] = d
         todo.append((i, key))
         if pattern == 0 and X3_CACHE_ON:
@@ -234,7 +234,7 @@ def _x3_fast_ok(M, N, K, A, lda, B, ldb, Cout, ldc, kw):
         taps = conv[5] * conv[6]
         if ldb != K or taps * Ci != K or taps > 32 or M % (conv[3] * conv[4]):
             return False
-        if kw.get('transposed', 0) and (conv[7] != conv[8] or (3 * Ci) % conv[7]):
+        if kw.get('transposed', 0) and (conv[7] != conv[8] or (2 * Ci) % conv[7]):
             return False
     res, mask = kw.get('res'), kw.get('mask')
     if res is not None and (res.dtype != torch.float32 or res.data_ptr() % 16 or kw.get('ldr', 0) % 4):
@@ -255,14 +255,14 @@ def _igemm_x3_fast(M, N, K, A, lda, B, ldb, Cout, ldc, kw):
     if conv is not None:
         kw['conv'] = (conv[0], conv[1], 3 * Ci) + tuple(conv[3:])
     kw['out_f32'] = 1
-    a = igemm_args(M, N, 3 * K, A3, 3 * Ci, B3, 3 * K, Cout, ldc, **kw)
-    a.f32ep = 1
+    a = igemm_args(M, N, 3 * K, A3, 2 * Ci, B3, 3 * K, Cout, ldc, **kw)
+    a.f32ep, a.awrap = 1, Ci                 # (the A image is [hi | lo]: the walk over 3 Ci wraps back onto hi)
     # outputs that feed GEMMs again - a ReLU'd activation (the Bottleneck chain, the FFN's hidden layer, the box MLP) or a masked
     # gradient (the dgrad chain: the next input gradient AND a weight gradient read it) - leave their operand image from the epilogue:
     # the consumers find it in the cache instead of running a split pass (read 4 B + write 6 B per element and a launch saved)
     img = None
     if X3_CACHE_ON and X3_SPLIT_OUT and (kw.get('act', ACT_NONE) == ACT_RELU or kw.get('mask') is not None) and N % 8 == 0:
-        img = torch.empty((M, 3 * N), device=Cout.device, dtype=torch.bfloat16)
+        img = torch.empty((M, 2 * N), device=Cout.device, dtype=torch.bfloat16)
         a.split_out = img.data_ptr()
         X3_CACHE[(Cout.data_ptr(), M, N, ldc)] = (Cout, img)
     if PROFILE is not None:
@@ -446,7 +446,7 @@ def _dgrad_s2_ok(dtype, dy, g, wb, out, ep):
 
 def _conv_dgrad_s2(dy, B, g, wb, out, ep, x3=False):
     Co = g.Co
-    if x3:                                               # operand images: dY [pixels][3 Co] = [hi | lo | hi], the weight [Ci][9][3 Co] = [hi | hi | lo] per tap
+    if x3:                                               # operand images: dY [pixels][2 Co] = [hi | lo], the weight [Ci][9][3 Co] = [hi | hi | lo] per tap
         dy, wb = _split3([(dy, 0, B * g.Ho * g.Wo, g.Co, dy.stride(0), 0), (wb, 0, g.Ci * 9, g.Co, g.Co, 1)])
         wb = wb.view(g.Ci, 27 * g.Co)
         Co = 3 * g.Co
@@ -464,7 +464,7 @@ def _conv_dgrad_s2(dy, B, g, wb, out, ep, x3=False):
             a = igemm_args(B * nh * nw, g.Ci, len(taps) * Co, dy, dy.stride(0), wb, wb.stride(0), out, out.stride(0), conv=conv,
                            transposed=1, tile=(64, 64), out_f32=int(x3), **ep)
             a.omap, a.o_Hi, a.o_Wi, a.o_sh, a.o_sw, a.o_h0, a.o_w0 = 1, g.Hi, g.Wi, 2, 2, ph_, pw_
-            a.btap_on, a.f32ep = 1, int(x3)
+            a.btap_on, a.f32ep, a.awrap = 1, int(x3), (g.Co if x3 else 0)
             for t_, (kh, kw) in enumerate(taps):
                 a.btap[t_] = (kh * 3 + kw) * Co
             jobs.append(a)
@@ -518,7 +518,7 @@ def _conv_dil_halves(t, B, g, w, out, ep, transposed, x3):
         a = igemm_args(B * g.Ho * d, cout, 6 * C, t, t.stride(0), w, w.stride(0), out, out.stride(0), conv=conv, transposed=int(transposed),
                        tile=(128, 128), out_f32=int(x3), **ep)
         a.omap, a.o_Hi, a.o_Wi, a.o_sh, a.o_sw, a.o_h0, a.o_w0 = 1, g.Ho, g.Wo, 1, 1, 0, half * d
-        a.btap_on, a.f32ep = 1, int(x3)
+        a.btap_on, a.f32ep, a.awrap = 1, int(x3), (cin if x3 else 0)
         for kh in range(3):
             for j in range(2):
                 a.btap[kh * 2 + j] = (kh * 3 + kw0 + j) * C
@@ -717,10 +717,10 @@ def wgrad(dtype, dy, x, B, g, rowscale=None, out=None, bias_out=None, batch=None
             dy3, x3 = _split3([(dy, 0, Kp, Mo, dy.stride(0), 0), (x, 0, rows_x, g.Ci, x.stride(0), 0)])
             slab = torch.empty((3 * sk3, Mo, No), device=dy.device, dtype=torch.float32)
             cs = torch.empty((2 * sk3, Mo), device=dy.device, dtype=torch.float32) if bias_out is not None else None
-            a1 = igemm_args(2 * Mo, No, Kp, dy3, 3 * Mo, x3, 3 * g.Ci, slab, No, trans=1, conv=conv, out_f32=1, splitk=sk3, slab=slab,
+            a1 = igemm_args(2 * Mo, No, Kp, dy3, 2 * Mo, x3, 2 * g.Ci, slab, No, trans=1, conv=conv, out_f32=1, splitk=sk3, slab=slab,
                             colsum_out=cs)
             x3lo, slab2 = x3[:, g.Ci:2 * g.Ci], slab[2 * sk3:]
-            a2 = igemm_args(Mo, No, Kp, dy3, 3 * Mo, x3lo, 3 * g.Ci, slab2, No, trans=1, conv=conv, out_f32=1, splitk=sk3, slab=slab2)
+            a2 = igemm_args(Mo, No, Kp, dy3, 2 * Mo, x3lo, 2 * g.Ci, slab2, No, trans=1, conv=conv, out_f32=1, splitk=sk3, slab=slab2)
             tb = batch if batch is not None else ReduceBatch()
             tb.add_gemm(dtype, a1, (2 * Mo, No, Kp, 1, 0 if conv is None else 1), code=BF16)
             tb.add_gemm(dtype, a2, (Mo, No, Kp, 1, 0 if conv is None else 1), code=BF16)

@@ -55,8 +55,8 @@ def test_x3_gemm_error_sits_between_bf16_and_f32():
 
 
 def test_x3_fast_path_on_the_lds_dma_kernels_against_f64():
-    """the FAST form of the mode (csrc/split3.hip: operands split once into bf16 [hi | lo | hi] / [hi | hi | lo] images, ONE bf16 GEMM over
-    the tripled contraction on the LDS-DMA kernels, f32 epilogue): a linear layer with every epilogue operand, a dilated 3x3 convolution,
+    """the FAST form of the mode (csrc/split3.hip: operands split once into bf16 [hi | lo] / [hi | hi | lo] images, ONE bf16 GEMM whose
+    contraction walks hi, lo, hi of the activation on the LDS-DMA kernels, f32 epilogue): a linear layer with every epilogue operand, a dilated 3x3 convolution,
     a stride-2 3x3 input gradient and two weight gradients (plain with the fused bias sums; 3x3 conv), each against f64 at the mode's
     3e-5 - and each must have gone through the fast path (launch log), not the generic kernel"""
     import torch.nn.functional as F
@@ -81,11 +81,14 @@ def test_x3_fast_path_on_the_lds_dma_kernels_against_f64():
             assert rel(y, ref) < 3e-5
             want = (y > 0).view(M, N // 8, 8).to(torch.uint8)
             assert torch.equal(bits, (want << torch.arange(8, device='cuda', dtype=torch.uint8)).sum(-1).to(torch.uint8))
-            # the epilogue left the [hi | lo | hi] operand image of this ReLU'd output for its consumers: exactly what a split pass gives
+            # the epilogue left the [hi | lo] operand image of this ReLU'd output for its consumers: exactly what a split pass gives
             img = ops.X3_CACHE[(y.data_ptr(), M, N, N)][1]
             hi = y.bfloat16()
             lo = (y - hi.float()).bfloat16()
-            assert torch.equal(img, torch.cat([hi, lo, hi], 1))
+            assert torch.equal(img, torch.cat([hi, lo], 1))
+            (img2,) = ops._split3([(res, 0, M, N, N, 0)])
+            rh = res.bfloat16()
+            assert torch.equal(img2, torch.cat([rh, (res - rh.float()).bfloat16()], 1))
             # ... and a dgrad-style call: f32 mask tensor, alpha
             mk = torch.randn(M, N, generator=g).cuda()
             y2 = ops.linear(L.F32, x, w, mask=mk, ldm=N, alpha=0.5)
