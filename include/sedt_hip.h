@@ -130,6 +130,9 @@ typedef struct SedtIgemm {
 } SedtIgemm;
 
 int sedt_igemm(const SedtIgemm* args, int dtype, void* stream);
+/* sizeof of an argument struct as THIS library was compiled (0 SedtIgemm, 1 SedtReduceJob, 2 SedtSplitJob, 3 SedtPrefetch, 4 SedtCriterion,
+ * 5 SedtMatch, 6 SedtChunk, 7 SedtBnJob, 8 SedtPackJob, 9 SedtFragJob; -1 otherwise): lets a binding verify its mirror of the structs */
+int sedt_sizeof(int which);
 /* njobs (<= 8 per launch) independent trans == 0 problems - e.g. the q / k / v projections of an attention block; one
  * launch when every problem resolves to the 64x64 2-stage bf16 kernel, otherwise njobs sedt_igemm calls.  HOST array. */
 int sedt_igemm_group(const SedtIgemm* jobs, int njobs, int dtype, void* stream);

@@ -83,3 +83,23 @@ extern "C" int sedt_hungarian_batch(const float* cost, int nlayers, int nclips, 
   }
   return 0;
 }
+
+// sizeof of the argument structs of the ABI, by index (0 SedtIgemm, 1 SedtReduceJob, 2 SedtSplitJob, 3 SedtPrefetch, 4 SedtCriterion,
+// 5 SedtMatch, 6 SedtChunk, 7 SedtBnJob, 8 SedtPackJob, 9 SedtFragJob; -1 otherwise): a binding checks its own mirror of each struct
+// against the library it loaded (tests/test_abi_cpu.py does for lib.py / packing.py / optim.py) - field drift between the header and a
+// hand-written ctypes / numpy mirror is otherwise silent until a kernel reads garbage.
+extern "C" int sedt_sizeof(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(SedtIgemm);
+    case 1: return (int)sizeof(SedtReduceJob);
+    case 2: return (int)sizeof(SedtSplitJob);
+    case 3: return (int)sizeof(SedtPrefetch);
+    case 4: return (int)sizeof(SedtCriterion);
+    case 5: return (int)sizeof(SedtMatch);
+    case 6: return (int)sizeof(SedtChunk);
+    case 7: return (int)sizeof(SedtBnJob);
+    case 8: return (int)sizeof(SedtPackJob);
+    case 9: return (int)sizeof(SedtFragJob);
+    default: return -1;
+  }
+}

@@ -103,6 +103,7 @@ _vp, _i, _i64, _f, _u32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_ui
 SIGNATURES = {
     'sedt_last_error': (C.c_char_p, []),
     'sedt_version': (_i, []),
+    'sedt_sizeof': (_i, [_i]),
     'sedt_igemm': (_i, [C.POINTER(SedtIgemm), _i, _vp]),
     'sedt_igemm_group': (_i, [C.POINTER(SedtIgemm), _i, _i, _vp]),
     'sedt_wgrad_group': (_i, [C.POINTER(SedtIgemm), _i, _i, _vp]),
