@@ -62,6 +62,7 @@ def parse():
                     help='data parallel: where the backward is cut so that the all-reduce of one segment overlaps the backward of the '
                          'next (engine.dp_segment_plan); none = one all-reduce after the backward')
     ap.add_argument('--bf16-buckets', action='store_true', help='data parallel: bf16 flat gradient buffer (half the all-reduce bytes)')
+    ap.add_argument('--async-wgrad', action='store_true', help='experiment: weight gradients as a parallel graph branch (second stream)')
     ap.add_argument('--no-other-configs', action='store_true',
                     help='default c2 line only: skip the bounded c3 / c4 / c5 measurements attached as "other_configs"')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -247,7 +248,7 @@ def build_workload(args, dev, rank, world):
                     raise RuntimeError('--force-graph-fallback (readiness test)')
                 g = GraphedTrainStep(net, criterion, opt, x, targets, wm, slice(ns), max_norm=0.1, device_matching=not args.host_matching,
                                      overlap_allreduce=not args.no_overlap, mix_up_ratio=mix, dp_cuts=args.dp_cuts,
-                                     grad_dtype=torch.bfloat16 if args.bf16_buckets else None)
+                                     grad_dtype=torch.bfloat16 if args.bf16_buckets else None, async_wgrad=args.async_wgrad)
             except Exception as e:                      # noqa: BLE001
                 if world == 1:
                     raise
