@@ -141,6 +141,40 @@ def test_x3_fast_path_on_the_lds_dma_kernels_against_f64():
     assert all(k.split(':')[1].startswith('igemm3') for k in log if k.startswith('igemm_x3:')), dict(log)
 
 
+def test_x3_dilated_conv_by_column_halves_against_f64():
+    """layer4's dilated 3x3 at C2's batch in the fast bf16x3 mode: forward and input gradient as two six-tap column halves each
+    (ops._conv_dil_halves with operand images, SedtIgemm.awrap / btap / omap / f32ep together) against f64"""
+    import torch.nn.functional as F
+    from sound_event_detection_transformer_amd import ops, lib as L
+    g = torch.Generator().manual_seed(12)
+    B, H, W, C = 64, 32, 4, 512
+    geo = ops.ConvGeom(H, W, C, C, 3, 1, 2, 2)
+    w = (torch.randn(C, C, 3, 3, generator=g) / (9 * C) ** 0.5).cuda()
+    sc, bi = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    x = torch.randn(B * H * W, C, generator=g).cuda()
+    dy = torch.randn(B * H * W, C, generator=g).cuda()
+    mk = torch.randn(B * H * W, C, generator=g).cuda()
+    L.GEMM_X3 = True
+    try:
+        wf, wb = ops.pack_conv(L.F32, w, bnscale=sc)
+        with L.launch_log() as log:
+            y = ops.conv_fwd(L.F32, x, B, geo, wf, scale=sc, bias=bi, act=ops.ACT_RELU)
+            dx = ops.conv_dgrad(L.F32, dy, B, geo, wb, mask=mk, ldm=C)
+        torch.cuda.synchronize()
+    finally:
+        L.GEMM_X3 = False
+        ops.x3_cache_clear()
+    assert log['igemm_group_dil'] == 2 and log['sedt_igemm'] == 0 and log['sedt_igemm_x3'] == 0, dict(log)
+    xn = x.double().view(B, H, W, C).permute(0, 3, 1, 2)
+    ref_y = torch.relu(F.conv2d(xn, w.double(), padding=2, dilation=2) * sc.double().view(1, -1, 1, 1) + bi.double().view(1, -1, 1, 1))
+    ref_y = ref_y.permute(0, 2, 3, 1).reshape(-1, C)
+    ws = w.double() * sc.double().view(-1, 1, 1, 1)
+    ref_dx = F.conv_transpose2d(dy.double().view(B, H, W, C).permute(0, 3, 1, 2), ws, padding=2, dilation=2).permute(0, 2, 3, 1).reshape(-1, C)
+    ref_dx = ref_dx * (mk > 0)
+    for got, ref in ((y, ref_y), (dx, ref_dx)):
+        assert ((got.double() - ref).abs().max() / ref.abs().max()).item() < 3e-5
+
+
 # the checks of the f32-mode modules that pin individual GRADIENT ELEMENTS (or their norms to 2e-3, or directions to cosine 1 - 5e-6): a product
 # error of 2^-16 is 256 x the exact-f32 one, and through a 60-layer backward with heavy cancellation it shows at 2-4e-3 on single
 # elements - measured below (test_x3_gradients_against_the_oracle) instead of asserted at the f32 mode's tolerances
