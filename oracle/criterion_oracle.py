@@ -160,7 +160,11 @@ class SetCriterion(nn.Module):
             for j, l in enumerate(targets[i]["labels"]):
                 gt[i, l] += targets[i]['ratio'][j] if 'ratio' in targets[i] else 1
         gt = gt.clamp(0, 1)
-        return {'loss_weak': weak_focal_loss(pred, gt) if fl else F.binary_cross_entropy(pred, gt)}
+        losses = {'loss_weak': weak_focal_loss(pred, gt) if fl else F.binary_cross_entropy(pred, gt)}
+        if 'at_p' in outputs:        # sedt.py:182-185 (--pooling): plain BCE of the pooled probabilities on the weak clips;
+            # weak_mask None indexes with None = a new leading axis over ALL rows (at_p then needs as many rows as gt)
+            losses['loss_weak_p'] = F.binary_cross_entropy(outputs['at_p'][weak_mask], gt[weak_mask])
+        return losses
 
     def loss_labels(self, outputs, targets, indices, num_boxes, strong_mask, weak_mask, coef, log=True, fl=False):
         src_logits = outputs['pred_logits'][strong_mask]
@@ -262,13 +266,15 @@ class PostProcess(nn.Module):
 
 
 def build_oracle_criterion(num_classes=10, dec_layers=3, dec_at=True, aux_loss=True, self_sup=False,
-                           feature_recon=True, eos_coef=0.1, epsilon=1., alpha=1.):
+                           feature_recon=True, eos_coef=0.1, epsilon=1., alpha=1., pooling=None, weak_loss_p_coef=1.):
     """sedt/__init__.py:39-61."""
     wd = {'loss_ce': 1., 'loss_bbox': 5., 'loss_giou': 2.}
     losses = ['labels', 'boxes', 'cardinality']
     if not self_sup and dec_at:
         wd['loss_weak'] = 1.
         losses.append('weak')
+    if not self_sup and pooling:         # __init__.py:44-45
+        wd['loss_weak_p'] = weak_loss_p_coef
     if self_sup and feature_recon:
         losses.append('feature')
         wd['loss_feature'] = 1

@@ -417,19 +417,35 @@ class MLP(nn.Module):
 
 
 class SEDT(nn.Module):
-    """sedt.py:17-131 (pooling variants :47-61,96-119 out of scope: default --pooling None)."""
+    """sedt.py:17-131, including the --pooling variants (:47-61 construction, :96-119 forward)."""
 
-    def __init__(self, backbone, transformer, num_classes, num_queries, aux_loss=False, dec_at=False):
+    def __init__(self, backbone, transformer, num_classes, num_queries, aux_loss=False, dec_at=False, pooling=None):
         super().__init__()
         self.num_queries, self.transformer = num_queries, transformer
         d = transformer.d_model
         self.class_embed = nn.Linear(d, num_classes + 1)
         self.bbox_embed = MLP(d, d, 2, 3)
         self.input_proj = nn.Conv2d(backbone.num_channels, d, kernel_size=1)
-        self.backbone, self.aux_loss, self.dec_at = backbone, aux_loss, dec_at
+        self.backbone, self.aux_loss, self.dec_at, self.pooling = backbone, aux_loss, dec_at, pooling
         self.query_embed = nn.Embedding(num_queries + (1 if dec_at else 0), d)
         if dec_at:
             self.weak_class_embed = nn.Linear(d, num_classes)
+        if pooling is not None and 'attn' in pooling:      # sedt.py:52-61
+            self.attn_dense_softmax = nn.Linear(d, num_classes)
+
+    def _pool(self, hs_last, logits_last, boxes_last):
+        """sedt.py:96-106 / :112-119: clip-level probabilities from the event queries' class probabilities."""
+        y = F.softmax(logits_last, -1)[:, :, :-1]                        # [B, Q, C]
+        if self.dec_at and 'weighted_sum' in self.pooling:               # :98-100 (only the dec_at branch has it)
+            return (y * boxes_last[:, :, 1][:, :, None]).sum(1).clip(0, 1)
+        if 'attn' in self.pooling:                                       # :53-60
+            sof = torch.clamp(F.softmax(self.attn_dense_softmax(hs_last), -1), min=1e-7, max=1)
+            return (sof * y).sum(1) / sof.sum(1)
+        if 'max' in self.pooling:                                        # AdaptiveMaxPool2d((1, None)) over the query axis
+            return y.max(1)[0].squeeze()
+        if 'avg' in self.pooling:                                        # AdaptiveAvgPool2d((1, None))
+            return y.mean(1).squeeze()
+        raise AttributeError("'SEDT' object has no attribute 'pooling_func'")     # what the reference does here
 
     def forward(self, samples):
         if isinstance(samples, (list, torch.Tensor)):
@@ -438,6 +454,7 @@ class SEDT(nn.Module):
         src, mask = features[-1].decompose()
         hs, _ = self.transformer(self.input_proj(src), mask, self.query_embed.weight, pos[-1])
         out = {}
+        q0 = 1 if self.dec_at else 0
         if self.dec_at:
             outputs_class = self.class_embed(hs[:, :, 1:, :])
             outputs_coord = self.bbox_embed(hs[:, :, 1:, :]).sigmoid()
@@ -446,6 +463,8 @@ class SEDT(nn.Module):
             outputs_class = self.class_embed(hs)
             outputs_coord = self.bbox_embed(hs).sigmoid()
         out['pred_logits'], out['pred_boxes'] = outputs_class[-1], outputs_coord[-1]
+        if self.pooling is not None:
+            out['at_p'] = self._pool(hs[-1, :, q0:, :], outputs_class[-1], outputs_coord[-1])
         if self.aux_loss:
             out['aux_outputs'] = [{'pred_logits': a, 'pred_boxes': b}
                                   for a, b in zip(outputs_class[:-1], outputs_coord[:-1])]
@@ -512,14 +531,14 @@ class SPSEDT(SEDT):
 # --------------------------------------------------------------------------
 def build_oracle_model(num_classes=10, num_queries=10, enc_layers=3, dec_layers=3, dec_at=True, aux_loss=True,
                        pre_norm=True, dropout=0.1, hidden_dim=256, nheads=8, dim_feedforward=2048, dilation=True,
-                       self_sup=False, num_patches=10, feature_recon=True, train_backbone=True):
+                       self_sup=False, num_patches=10, feature_recon=True, train_backbone=True, pooling=None):
     """sedt/__init__.py:8-38 (model part)."""
     backbone = Joiner(BackboneBase(train_backbone, dilation), PositionEmbeddingSine(hidden_dim, normalize=True))
     transformer = Transformer(hidden_dim, nheads, enc_layers, dec_layers, dim_feedforward, dropout, pre_norm,
                               True, self_sup)
     if self_sup:
         return SPSEDT(backbone, transformer, 1, num_queries, aux_loss, feature_recon, num_patches=num_patches)
-    return SEDT(backbone, transformer, num_classes, num_queries, aux_loss, dec_at)
+    return SEDT(backbone, transformer, num_classes, num_queries, aux_loss, dec_at, pooling)
 
 
 def seeded_state_dict(template: dict, seed: int) -> dict:

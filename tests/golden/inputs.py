@@ -112,3 +112,18 @@ def query_clips():
     c = QUERY
     return [clip_input(1, c['T'], c['seeds'][0])[0] * 1.7 - 0.3, clip_input(1, c['T'], c['seeds'][1])[0] * 0.6 + 2.0,
             clip_input(1, c['short_clip_T'], 503)[0]]
+
+
+# G16: the --pooling variants (sedt.py:47-61, 96-119, 182-185): 2 strong + 2 weak clips, dec_at model
+POOL = dict(n_strong=2, n_weak=2, T=248, seed_w=1600, seed_x=163, seed_t=164, modes=('max', 'avg', 'attn', 'weighted_sum'))
+
+
+def pool_batch():
+    c = POOL
+    B = c['n_strong'] + c['n_weak']
+    x = clip_input(B, c['T'], c['seed_x'])
+    targets = synthetic_targets(B, c['seed_t'], 10)
+    for t in targets[c['n_strong']:]:
+        t['boxes'] = torch.zeros(0, 2)
+    return x, targets
+

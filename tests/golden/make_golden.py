@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 from oracle import sedt_oracle as O              # noqa: E402
 from oracle.criterion_oracle import synthetic_targets  # noqa: E402
 sys.path.insert(0, HERE)
-from inputs import g9_inputs as _g9_inputs, g10_inputs as _g10_inputs, g11_inputs as _g11_inputs, SEMI, semi_batch as _semi_batch, SEMI_MIX, SUP_MIX, semi_mix_batch as _semi_mix_batch, sup_mix_batch as _sup_mix_batch  # noqa: E402
+from inputs import g9_inputs as _g9_inputs, g10_inputs as _g10_inputs, g11_inputs as _g11_inputs, SEMI, semi_batch as _semi_batch, SEMI_MIX, SUP_MIX, semi_mix_batch as _semi_mix_batch, sup_mix_batch as _sup_mix_batch, POOL, pool_batch as _pool_batch  # noqa: E402
 
 
 # ----------------------------------------------------------------------------- shim
@@ -809,6 +809,53 @@ def g14_query_patches(out, rbt):
     print('G14 ok', {k: v.shape for k, v in res.items() if k.endswith('_rows')}, res['c2_free_rows'][:, 1] - res['c2_free_rows'][:, 0])
 
 
+G16_GRADS = ('class_embed.weight', 'class_embed.bias', 'bbox_embed.layers.2.weight', 'weak_class_embed.weight',
+             'transformer.decoder.layers.2.linear2.weight', 'attn_dense_softmax.weight', 'attn_dense_softmax.bias')
+
+
+def g16_pooling(out, rsedt):
+    """G16: the reference's SEDT with --pooling max / avg / attn / weighted_sum (dec_at model): the pooled clip-level output
+    ``at_p`` in eval mode, and a train-mode (dropout 0) loss + backward through SetCriterion with a strong | weak split
+    (loss_weak_p, sedt.py:182-185).  'max_nomask': weak_mask None on an all-strong batch (gt[None] / at_p[None])."""
+    c = POOL
+    ns, B = c['n_strong'], c['n_strong'] + c['n_weak']
+    x, targets = _pool_batch()
+    res = {}
+    for i, mode in enumerate(c['modes'] + ('max_nomask',)):
+        pooling = mode.split('_nomask')[0]
+        args = ref_args(dropout=0.0, enc_layers=3, num_queries=10, pooling=pooling, weak_loss_p_coef=0.7)
+        model, criterion, _ = rsedt.build_model(args)
+        seeded_load(model, c['seed_w'] + (0 if mode == 'max_nomask' else i))
+        nomask = mode.endswith('_nomask')
+        xs, ts = (x[:ns], targets[:ns]) if nomask else (x, targets)
+        model.eval()
+        with torch.no_grad():
+            o = model(xs)
+        res[f'{mode}_eval_at_p'] = npy(o['at_p'])
+        res[f'{mode}_eval_at'] = npy(o['at'])
+        model.train()
+        o = model(xs)
+        loss_dict, _ = criterion(o, ts, None if nomask else slice(ns, B), slice(ns), False, False)
+        wd = criterion.weight_dict
+        total = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+        model.zero_grad()
+        total.backward()
+        res[f'{mode}_train_at_p'] = npy(o['at_p'])
+        res[f'{mode}_train_total'] = np.float32(total.item())
+        for k, v in loss_dict.items():
+            res[f'{mode}_train_loss_{k}'] = np.float32(v.item())
+        params = dict(model.named_parameters())
+        names = [n for n, p in params.items() if p.requires_grad]
+        res[f'{mode}_train_gradnames'] = np.array(names)
+        res[f'{mode}_train_gradnorm'] = np.array([0.0 if params[n].grad is None else params[n].grad.norm().item() for n in names],
+                                                 np.float32)
+        for n in G16_GRADS:
+            if n in params and params[n].grad is not None:
+                res[f'{mode}_train_grad::{n}'] = digest(params[n].grad, 32)
+    np.savez_compressed(os.path.join(out, 'g16_pooling.npz'), **res)
+    print('G16 ok', {m: (float(res[f'{m}_train_loss_loss_weak_p']), float(res[f'{m}_train_total'])) for m in c['modes'] + ('max_nomask',)})
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='', help='comma list of fixtures to (re)generate, e.g. g9,g12 (default: all)')
@@ -833,6 +880,8 @@ if __name__ == '__main__':
         g9_criterion_variants(out, rsedt)
     if on('g10'):
         g10_postprocess(out, rsedt)
+    if on('g16'):
+        g16_pooling(out, rsedt)
     if want & {'g11', 'g12', 'g13', 'g14', 'g15'} or not want:
         rengine, rmixup, rbt = import_reference_engine()
         if on('g14'):

@@ -170,3 +170,52 @@ def test_g4_spsedt(golden_dir):
     assert names == [n for n, p in model.named_parameters() if p.requires_grad]
     gn = np.array([params[n].grad.norm().item() for n in names], dtype=np.float32)
     np.testing.assert_allclose(gn, g['train_gradnorm'], rtol=2e-3, atol=1e-5)
+
+
+G16_MODES = ('max', 'avg', 'attn', 'weighted_sum', 'max_nomask')
+
+
+@pytest.mark.parametrize('mode', G16_MODES)
+def test_g16_pooling(golden_dir, mode):
+    """--pooling variants (sedt.py:47-61, 96-119) and loss_weak_p (sedt.py:182-185) of the oracle against the reference's
+    own outputs, losses and gradients on a strong | weak batch"""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import inputs as GI
+    g = np.load(os.path.join(golden_dir, 'g16_pooling.npz'))
+    c = GI.POOL
+    ns, B = c['n_strong'], c['n_strong'] + c['n_weak']
+    nomask = mode.endswith('_nomask')
+    pooling = mode.split('_nomask')[0]
+    i = 0 if nomask else c['modes'].index(mode)
+    model = _load(O.build_oracle_model(10, 10, 3, 3, True, True, True, dropout=0.0, pooling=pooling), c['seed_w'] + i)
+    x, targets = GI.pool_batch()
+    if nomask:
+        x, targets = x[:ns], targets[:ns]
+    model.eval()
+    with torch.no_grad():
+        o = model(x)
+    np.testing.assert_allclose(o['at_p'].numpy(), g[f'{mode}_eval_at_p'], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(o['at'].numpy(), g[f'{mode}_eval_at'], rtol=2e-4, atol=5e-5)
+    model.train()
+    crit = build_oracle_criterion(10, 3, True, True, pooling=pooling, weak_loss_p_coef=0.7)
+    o = model(x)
+    ld, _ = crit(o, targets, None if nomask else slice(ns, B), slice(ns))
+    assert 'loss_weak_p' in ld
+    total = sum(ld[k] * crit.weight_dict[k] for k in ld if k in crit.weight_dict)
+    total.backward()
+    np.testing.assert_allclose(o['at_p'].detach().numpy(), g[f'{mode}_train_at_p'], rtol=2e-4, atol=2e-6)
+    assert abs(total.item() - float(g[f'{mode}_train_total'])) < 1e-3 * abs(float(g[f'{mode}_train_total']))
+    keys = {k[len(mode) + 12:] for k in g.files if k.startswith(f'{mode}_train_loss_')}
+    assert set(ld) == keys
+    for k, v in ld.items():
+        assert abs(v.item() - float(g[f'{mode}_train_loss_{k}'])) < 1e-3 * max(1.0, abs(v.item())), k
+    params = dict(model.named_parameters())
+    names = [str(n) for n in g[f'{mode}_train_gradnames']]
+    assert names == [n for n, p in model.named_parameters() if p.requires_grad]
+    gn = np.array([0.0 if params[n].grad is None else params[n].grad.norm().item() for n in names], dtype=np.float32)
+    np.testing.assert_allclose(gn, g[f'{mode}_train_gradnorm'], rtol=2e-3, atol=1e-5)
+    for key in g.files:
+        if key.startswith(f'{mode}_train_grad::'):
+            ref = g[key]
+            np.testing.assert_allclose(_digest(params[key.split('::')[1]].grad, 32), ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max())
