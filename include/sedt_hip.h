@@ -523,15 +523,19 @@ int sedt_multi_adamw(const SedtChunk* table, int nchunks, const float* sumsq, fl
  * outputs; layer_of[d] is the slice that dense layer d reads.  One launch writes
  *   out[4d+0..3] = loss_ce, loss_bbox, loss_giou, cardinality_error of dense layer d (unweighted, as the reference logs)
  *   out[4L] = class-error hits, out[4L+1] = matched count, out[4L+2] = loss_weak,
- *   out[4L+3] = weighted total (sum_k weight_k * loss_k), out[4L+4] = class_error
+ *   out[4L+3] = weighted total (sum_k weight_k * loss_k), out[4L+4] = class_error, out[4L+5] = loss_weak_p
  * and the UNWEIGHTED per-term gradients: dlogits = d loss_ce_d / d logits, dboxes = d loss_bbox_d / d boxes, dboxes2 =
  * d loss_giou_d / d boxes (each layer slice holds the gradient of its own layer's loss), dat = d loss_weak / d at.
  * at / gt_weak / dat may be null together (model without audio-tag head).
- * sedt_set_criterion_bwd combines them with the gradient g[4L+5] that reached `out`:
+ * --pooling models (sedt.py:96-119, sedt_pool_at below) add at_p [Bp][C], the pooled clip-level probabilities: loss_weak_p =
+ * BCE(at_p[rows], gt_weak[rows]) (sedt.py:182-185) over the weak clips rows = [ns, n_lab), or - wp_all != 0, the reference's
+ * weak_mask None - over all labelled clips [0, n_lab); an empty row range gives NaN, as the reference's mean over nothing.
+ * dat_p [Bp][C] = d loss_weak_p / d at_p.  at_p / dat_p may be null together; at_p needs at (the reference forms gt there).
+ * sedt_set_criterion_bwd combines them with the gradient g[4L+6] that reached `out`:
  *   glogits = (g[4d] + g[4L+3] w_ce[d]) dlogits,  gboxes = (g[4d+1] + g[4L+3] w_bbox[d]) dboxes + (g[4d+2] + ...) dboxes2,
- *   gat = (g[4L+2] + g[4L+3] w_weak) dat. */
+ *   gat = (g[4L+2] + g[4L+3] w_weak) dat,  gat_p = (g[4L+5] + g[4L+3] w_weak_p) dat_p. */
 #define SEDT_CRIT_MAXL 8
-#define SEDT_CRIT_MAXOUT (4 * SEDT_CRIT_MAXL + 5)
+#define SEDT_CRIT_MAXOUT (4 * SEDT_CRIT_MAXL + 6)
 #define SEDT_CRIT_MAXCARD 8192 /* limit on L * B */
 typedef struct SedtCriterion {
   const float* logits;
@@ -549,7 +553,7 @@ typedef struct SedtCriterion {
   float* dboxes;
   float* dboxes2;
   float* dat;
-  float* out; /* [4L+5] */
+  float* out; /* [4L+6] */
   int32_t L, B, ns, Q, C, n_lab, Bat;
   int32_t layer_of[SEDT_CRIT_MAXL];
   float w_ce[SEDT_CRIT_MAXL], w_bbox[SEDT_CRIT_MAXL], w_giou[SEDT_CRIT_MAXL];
@@ -571,12 +575,37 @@ typedef struct SedtCriterion {
    * otherwise Qs = Q, q0 = 0).  The per-term gradient buffers dlogits / dboxes / dboxes2 stay compact ([L][B][Q]). */
   int32_t Qs, q0;
   float* total; /* optional: receives out[4L+3] as a separate scalar (its own autograd output: no select/backward-of-select) */
+  const float* at_p; /* [Bp][C] pooled probabilities (--pooling), or null */
+  float* dat_p;      /* [Bp][C] */
+  float w_weak_p;
+  int32_t wp_all, Bp;
 } SedtCriterion;
 size_t sedt_set_criterion_scratch(int L, int B, int Q); /* bytes of `scratch`: per-row loss terms, summed per layer in a fixed order */
 int sedt_set_criterion(const SedtCriterion* args, float* scratch, void* stream);
-/* g: gradient that reached out[4L+5] (or null), gtotal: gradient that reached the separate total scalar (or null) */
+/* g: gradient that reached out[4L+6] (or null), gtotal: gradient that reached the separate total scalar (or null) */
 int sedt_set_criterion_bwd(const SedtCriterion* args, const float* g, const float* gtotal, float* glogits, float* gboxes,
-                           float* gat, void* stream);
+                           float* gat, float* gat_p /* or null */, void* stream);
+
+/* ------------------------------------------------------------------ --pooling variants of SEDT (sedt/sedt.py:47-61, 96-119)
+ * at_p[b][c], c < C: the clip-level probability pooled over the Q event queries' class probabilities
+ * y[b][q][c] = softmax(logits[b][q0 + q])[c] of the FINAL decoder layer (replaces nn.AdaptiveMaxPool2d / AdaptiveAvgPool2d((1, None)),
+ * the attn_pooling closure and the weighted sum of sedt.py:98-100):
+ *   SEDT_POOL_MAX  max_q y        SEDT_POOL_AVG  mean_q y
+ *   SEDT_POOL_ATTN s = clamp(softmax_c(attn[b][q]), 1e-7, 1); sum_q s y / sum_q s   (attn = attn_dense_softmax(hs[-1]) [B][Q][C])
+ *   SEDT_POOL_WSUM clip(sum_q y * boxes[b][q0 + q][1], 0, 1)                        (the predicted event length as weight)
+ * logits [B][Qs][C+1] / boxes [B][Qs][2] are the head outputs over ALL Qs query rows (dec_at models: q0 = 1 skips the
+ * audio-tag query).  sedt_pool_at_bwd: g [B][C] -> glogits [B][Qs][C+1] (zero rows outside the window), gboxes [B][Qs][2]
+ * (WSUM; may be null otherwise), gattn [B][Q][C] (ATTN; may be null otherwise); max sends the gradient to the first maximal
+ * query, clamp / clip pass it where the value lies inside the closed interval (torch semantics).  Q * (C+1) <= 4096. */
+enum { SEDT_POOL_MAX = 0, SEDT_POOL_AVG = 1, SEDT_POOL_ATTN = 2, SEDT_POOL_WSUM = 3 };
+typedef struct SedtPoolAt {
+  const float* logits;
+  const float* boxes; /* WSUM, else may be null */
+  const float* attn;  /* ATTN, else may be null */
+  int32_t B, Qs, q0, Q, C, mode;
+} SedtPoolAt;
+int sedt_pool_at(const SedtPoolAt* args, float* at_p /* [B][C] */, void* stream);
+int sedt_pool_at_bwd(const SedtPoolAt* args, const float* g, float* glogits, float* gboxes, float* gattn, void* stream);
 
 /* ------------------------------------------------------------------ SP-SEDT feature-reconstruction loss (sedt/sedt.py:263-283)
  * For dense layer d, strong clip b, query q matched to patch tidx (wbox > 0):

@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsedt_hip.so')
 OBJ = os.path.join(HERE, '..', 'build', 'obj')
 SOURCES = ['igemm.hip', 'igemm3.hip', 'wgrad3.hip', 'wgrad4.hip', 'misc.hip', 'stem.hip', 'conv3x3_c64.hip',
-           'norm_attn.hip', 'attn_mfma.hip', 'attn_f32_mfma.hip', 'enc_slab.hip', 'heads_slab.hip', 'bneck.hip', 'bneck3.hip', 'criterion.hip', 'postproc.hip', 'input.hip', 'skinny.hip', 'split3.hip', 'host.cpp']
+           'norm_attn.hip', 'attn_mfma.hip', 'attn_f32_mfma.hip', 'enc_slab.hip', 'heads_slab.hip', 'bneck.hip', 'bneck3.hip', 'criterion.hip', 'postproc.hip', 'input.hip', 'skinny.hip', 'split3.hip', 'pool_at.hip', 'host.cpp']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-failed']
 if os.environ.get('SEDT_DEV_BUILD') == '1':
     # developer build: the tuning switches read the environment (csrc/common.h: dev_getenv) and the ablation hooks are compiled in.

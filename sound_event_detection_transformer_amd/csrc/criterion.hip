@@ -248,8 +248,28 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
     weak = block_sum_1024(weak, red);
     total += a.w_weak * weak;
   }
+  // ---------------- BCE of the pooled clip-level probabilities (--pooling, sedt.py:182-185) on the weak clips; weak_mask None
+  //                  (wp_all) = every labelled clip.  An empty range divides 0 by 0 like the reference's mean over nothing.
+  float weak_p = 0.f;
+  if (a.at_p) {
+    const int r0 = a.wp_all ? 0 : ns_eff, r1 = n_lab_eff;
+    const int n = max(r1 - r0, 0) * C;
+    for (int r = t; r < a.Bp * C; r += 1024) {
+      float g = 0.f;
+      const int b = r / C;
+      if (b >= r0 && b < r1) {
+        const float p = a.at_p[r], y = a.gt_weak[r];
+        weak_p += -(y * fmaxf(__logf(p), -100.f) + (1.f - y) * fmaxf(__logf(1.f - p), -100.f));
+        g = (p - y) / fmaxf(p * (1.f - p), 1e-12f) / (float)n;
+      }
+      a.dat_p[r] = g;
+    }
+    weak_p = block_sum_1024(weak_p, red) / (float)n;
+    total += a.w_weak_p * weak_p;
+  }
   if (t == 0) {
     a.out[SLOT_WEAK] = weak;
+    a.out[4 * L + 5] = weak_p;
     a.out[4 * L + 3] = total;                   // weighted total
     if (a.total) a.total[0] = total;
     if (a.nonfinite && !(fabsf(total) <= 3.0e38f)) *a.nonfinite = 1;      // NaN or inf (engine.py:70-73)
@@ -261,7 +281,8 @@ __global__ __launch_bounds__(1024) void set_criterion_kernel(const SedtCriterion
 // rows of queries outside [q0, q0 + Q) - the audio-tag query of dec_at models - get zeros.
 __global__ __launch_bounds__(256) void set_criterion_bwd_kernel(const SedtCriterion a, const float* __restrict__ g,
                                                                 const float* __restrict__ gtotal, float* __restrict__ glogits,
-                                                                float* __restrict__ gboxes, float* __restrict__ gat) {
+                                                                float* __restrict__ gboxes, float* __restrict__ gat,
+                                                                float* __restrict__ gat_p) {
   const int L = a.L, B = a.B, Q = a.Q, Qs = a.Qs, C1 = a.C + 1;
   const float gtot = (g ? g[4 * L + 3] : 0.f) + (gtotal ? gtotal[0] : 0.f);
   const int nrows = L * B * Qs;
@@ -286,6 +307,10 @@ __global__ __launch_bounds__(256) void set_criterion_bwd_kernel(const SedtCriter
   if (gat) {
     const float kw = (g ? g[4 * L + 2] : 0.f) + gtot * a.w_weak;
     for (int r = blockIdx.x * 256 + threadIdx.x; r < a.Bat * a.C; r += gridDim.x * 256) gat[r] = kw * a.dat[r];
+  }
+  if (gat_p) {
+    const float kw = (g ? g[4 * L + 5] : 0.f) + gtot * a.w_weak_p;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < a.Bp * a.C; r += gridDim.x * 256) gat_p[r] = kw * a.dat_p[r];
   }
 }
 
@@ -538,6 +563,9 @@ extern "C" int sedt_set_criterion(const SedtCriterion* args, float* scratch, voi
                    a.empty_weight && a.out,
                "set_criterion: null pointer");
   SEDT_REQUIRE((a.at == nullptr) == (a.dat == nullptr), "set_criterion: at and dat go together");
+  SEDT_REQUIRE((a.at_p == nullptr) == (a.dat_p == nullptr), "set_criterion: at_p and dat_p go together");
+  SEDT_REQUIRE(a.at_p == nullptr || (a.at != nullptr && a.gt_weak != nullptr && a.Bp >= a.n_lab),
+               "set_criterion: at_p needs the audio-tag targets (at / gt_weak) and at least n_lab=%d rows (Bp=%d)", a.n_lab, a.Bp);
   SEDT_REQUIRE(a.L * a.B <= SEDT_CRIT_MAXCARD, "set_criterion: L*B = %d exceeds %d", a.L * a.B, SEDT_CRIT_MAXCARD);
   SEDT_REQUIRE(a.q0 >= 0 && a.Qs >= a.q0 + a.Q, "set_criterion: query window q0=%d Q=%d outside Qs=%d", a.q0, a.Q, a.Qs);
   hipLaunchKernelGGL(set_criterion_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), a, scratch);
@@ -545,15 +573,16 @@ extern "C" int sedt_set_criterion(const SedtCriterion* args, float* scratch, voi
 }
 
 extern "C" int sedt_set_criterion_bwd(const SedtCriterion* args, const float* g, const float* gtotal, float* glogits, float* gboxes,
-                                      float* gat, void* stream) {
+                                      float* gat, float* gat_p, void* stream) {
   using namespace sedt;
   SEDT_REQUIRE(args != nullptr && (g || gtotal) && glogits && gboxes, "set_criterion_bwd: null pointer");
   const SedtCriterion& a = *args;
   SEDT_REQUIRE(a.L >= 1 && a.L <= SEDT_CRIT_MAXL, "set_criterion_bwd: L=%d", a.L);
-  SEDT_REQUIRE(a.dlogits && a.dboxes && a.dboxes2 && ((gat == nullptr) || a.dat), "set_criterion_bwd: null gradient buffers");
+  SEDT_REQUIRE(a.dlogits && a.dboxes && a.dboxes2 && ((gat == nullptr) || a.dat) && ((gat_p == nullptr) || a.dat_p),
+               "set_criterion_bwd: null gradient buffers");
   const int rows = a.L * a.B * a.Qs;
   hipLaunchKernelGGL(set_criterion_bwd_kernel, dim3((rows + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, g,
-                     gtotal, glogits, gboxes, gat);
+                     gtotal, glogits, gboxes, gat, gat_p);
   return check_launch("set_criterion_bwd");
 }
 

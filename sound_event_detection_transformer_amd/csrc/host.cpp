@@ -100,6 +100,7 @@ extern "C" int sedt_sizeof(int which) {
     case 7: return (int)sizeof(SedtBnJob);
     case 8: return (int)sizeof(SedtPackJob);
     case 9: return (int)sizeof(SedtFragJob);
+    case 10: return (int)sizeof(SedtPoolAt);
     default: return -1;
   }
 }

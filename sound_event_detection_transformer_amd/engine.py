@@ -491,7 +491,7 @@ class GraphedTrainStep(_GraphedBase):
         B = len(example_targets)
         ns = len(example_targets[self.ms])
         n_lab = self.mw.stop if self.mw is not None else self.ms.stop
-        return TargetTables(B, ns, n_lab, self.dev, max_targets=max_targets, dynamic_split=bool(self.mix),
+        return TargetTables(B, ns, n_lab, self.dev, max_targets=max_targets, dynamic_split=bool(self.mix), weak_mask_none=self.mw is None,
                             with_ratio=bool(self.mix) or any('ratio' in t for t in example_targets)).load(example_targets)
 
     def _forward(self):
@@ -664,7 +664,7 @@ class GraphedPredictStep(object):
         dev = example_input.device
         self.static_x = example_input.clone()
         B = len(example_targets)
-        self.tables = TargetTables(B, B, B, dev, max_targets=max_targets, with_ratio=False).load(example_targets)
+        self.tables = TargetTables(B, B, B, dev, max_targets=max_targets, with_ratio=False, weak_mask_none=True).load(example_targets)
         self.sizes = torch.stack([t['orig_size'] for t in example_targets], dim=0).to(dev).float().clone()
         stream = train_stream(dev)
         stream.wait_stream(torch.cuda.current_stream())
@@ -874,9 +874,9 @@ class GraphedSemiStep(_GraphedBase):
         n_lab = mask_weak.stop if mask_weak is not None else mask_strong.stop
         Q = model.num_queries
         self.counter = torch.zeros(criterion.num_classes, dtype=torch.int32, device=dev)
-        self.tab_l = TargetTables(n_l, ns, n_lab, dev, max_targets=max_targets, dynamic_split=bool(self.mix),
+        self.tab_l = TargetTables(n_l, ns, n_lab, dev, max_targets=max_targets, dynamic_split=bool(self.mix), weak_mask_none=mask_weak is None,
                                   with_ratio=bool(self.mix) or any('ratio' in t for t in lab_t)).load(lab_t)
-        self.tab_u = TargetTables(n_u, n_u, n_u, dev, max_targets=max(Q, 1))
+        self.tab_u = TargetTables(n_u, n_u, n_u, dev, max_targets=max(Q, 1), weak_mask_none=True)      # engine.py:159: weak_mask None
         if self.mix:
             # mix-up inside the step (engine.py:128-133, 150-153): raw labelled / unlabelled-student clips are static inputs, the two
             # feature mixings are kernels of the graph writing the student's input x_cat; the labelled targets arrive mixed from
@@ -888,7 +888,7 @@ class GraphedSemiStep(_GraphedBase):
                 raise ValueError(f'mixup_label_unlabel mixes {self.mix_num_u} unlabelled clips, the batch has {n_u}')
             self.x_lab_raw, self.x_stu_raw = self.x_lab.clone(), self.x_stu.clone()
             self.tab_p = self.tab_u                           # pseudo labels as the teacher gives them
-            self.tab_u = TargetTables(n_u, n_u, n_u, dev, max_targets=max(max_targets, max_events, Q), with_ratio=True)
+            self.tab_u = TargetTables(n_u, n_u, n_u, dev, max_targets=max(max_targets, max_events, Q), with_ratio=True, weak_mask_none=True)
             self._jobs_l = _Upload(16 * n_l, dev)
             self._jobs_l.send(job_table([(i, 0, 1, 0.0) for i in range(n_l)]))
             self._lam_u = _Upload(8, dev)

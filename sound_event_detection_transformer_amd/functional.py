@@ -111,6 +111,31 @@ class LinearFn(Function):
         return gx, gw, gb, None, None, None, None, None
 
 
+class PoolAtFn(Function):
+    """the --pooling variants (reference sedt.py:96-119) as one launch each way (csrc/pool_at.hip): the final decoder layer's class
+    logits [B,Qp,C+1] (event queries q0 .. q0+Q-1) -> clip-level probabilities at_p [B,C]; ``boxes`` [B,Qp,2] feeds mode
+    'weighted_sum', ``attn`` [B,Q,C] (attn_dense_softmax of the event queries) mode 'attn'."""
+
+    @staticmethod
+    def forward(ctx, logits, boxes, attn, mode, q0, Q):
+        f32c = lambda t: t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().float().contiguous()
+        lg = f32c(logits)
+        bx = f32c(boxes) if mode == 'weighted_sum' else None
+        at = f32c(attn) if mode == 'attn' else None
+        ctx.cfg = (mode, q0, Q)
+        ctx.dts = (logits.dtype, None if boxes is None else boxes.dtype, None if attn is None else attn.dtype)
+        ctx.save_for_backward(lg, bx, at)
+        return ops.pool_at(lg, bx, at, mode, q0, Q)
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, bx, at = ctx.saved_tensors
+        mode, q0, Q = ctx.cfg
+        gl, gb, ga = ops.pool_at_bwd(lg, bx, at, mode, q0, Q, g)
+        return (gl.to(ctx.dts[0]), None if gb is None else gb.to(ctx.dts[1]), None if ga is None else ga.to(ctx.dts[2]),
+                None, None, None)
+
+
 class HeadsFn(Function):
     """the prediction heads on the stacked decoder output hs [L,B,Qp,d] (reference sedt.py:88-95): class_embed on every row,
     bbox_embed (3-layer MLP + sigmoid) on every row, and - dec_at - weak_class_embed + sigmoid on query 0 of the last layer,

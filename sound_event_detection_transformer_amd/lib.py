@@ -63,7 +63,16 @@ class SedtCriterion(C.Structure):
                [('layer_of', C.c_int32 * CRIT_MAXL), ('w_ce', C.c_float * CRIT_MAXL), ('w_bbox', C.c_float * CRIT_MAXL),
                 ('w_giou', C.c_float * CRIT_MAXL), ('w_weak', C.c_float), ('fl', C.c_int32), ('alpha_fl', C.c_float),
                 ('gamma_fl', C.c_float), ('nonfinite', C.c_void_p), ('split', C.c_void_p), ('Qs', C.c_int32), ('q0', C.c_int32),
-                ('total', C.c_void_p)]
+                ('total', C.c_void_p), ('at_p', C.c_void_p), ('dat_p', C.c_void_p), ('w_weak_p', C.c_float), ('wp_all', C.c_int32),
+                ('Bp', C.c_int32)]
+
+
+class SedtPoolAt(C.Structure):
+    _fields_ = [('logits', C.c_void_p), ('boxes', C.c_void_p), ('attn', C.c_void_p)] + \
+               [(n, C.c_int32) for n in ('B', 'Qs', 'q0', 'Q', 'C', 'mode')]
+
+
+POOL_MODES = {'max': 0, 'avg': 1, 'attn': 2, 'weighted_sum': 3}
 
 
 class SedtMatch(C.Structure):
@@ -179,11 +188,13 @@ SIGNATURES = {
     'sedt_multi_adamw': (_i, [_vp, _i, _vp, _f, _f, _f, _f, _vp, _vp, _vp]),
     'sedt_set_criterion_scratch': (_sz, [_i, _i, _i]),
     'sedt_set_criterion': (_i, [C.POINTER(SedtCriterion), _vp, _vp]),
-    'sedt_set_criterion_bwd': (_i, [C.POINTER(SedtCriterion), _vp, _vp, _vp, _vp, _vp, _vp]),
+    'sedt_set_criterion_bwd': (_i, [C.POINTER(SedtCriterion), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'sedt_match_targets': (_i, [C.POINTER(SedtMatch), _vp]),
     'sedt_feature_loss': (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'sedt_scale_layers': (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i64, _vp]),
     'sedt_sum_f32': (_i, [_vp, _i, _vp, _vp]),
+    'sedt_pool_at': (_i, [C.POINTER(SedtPoolAt), _vp, _vp]),
+    'sedt_pool_at_bwd': (_i, [C.POINTER(SedtPoolAt), _vp, _vp, _vp, _vp, _vp]),
     'sedt_box_transform': (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     'sedt_mixup': (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),
     'sedt_mixup_targets': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),

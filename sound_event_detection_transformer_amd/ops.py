@@ -1316,11 +1316,13 @@ def adamw_clip(p, g, m, v, sumsq_t, max_norm, lr, beta1, beta2, eps, weight_deca
 
 
 def set_criterion(logits, boxes, at, dense, empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak, fl=False, alpha_fl=0.5,
-                  gamma_fl=1.0, nonfinite=None, q0=0):
+                  gamma_fl=1.0, nonfinite=None, q0=0, at_p=None, w_weak_p=0.0, wp_all=False):
     """device half of SetCriterion in one launch (csrc/criterion.hip).  logits [L,B,Qs,C+1], boxes [L,B,Qs,2] (the Q queries
     q0 .. q0+Q-1 of every clip take part, Q from the dense targets), at [Bat,C] or None - all f32 contiguous; dense =
     SetCriterion.dense_views(...).  fl: the focal-loss variant (sedt.py:176, 211-218).  nonfinite: optional int32 device word set
-    to 1 when the weighted total is NaN/inf.  Returns (out[4L+5], total scalar, state); state feeds set_criterion_bwd."""
+    to 1 when the weighted total is NaN/inf.  at_p [Bp,C]: the pooled clip-level probabilities of a --pooling model (loss_weak_p over
+    the weak clips, or over all labelled ones when wp_all = the reference's weak_mask None).  Returns (out[4L+6], total scalar,
+    state); state feeds set_criterion_bwd."""
     _dev_check(logits, boxes)
     Lh, B, Qs, C1 = logits.shape
     Q = dense['tc'].shape[2]
@@ -1330,7 +1332,7 @@ def set_criterion(logits, boxes, at, dense, empty_weight, layer_of, w_ce, w_bbox
     dl = torch.empty((Lh, B, Q, C1), device=logits.device, dtype=torch.float32)
     db, db2 = torch.empty((Lh, B, Q, 2), device=logits.device, dtype=torch.float32), torch.empty((Lh, B, Q, 2), device=logits.device, dtype=torch.float32)
     dat = None
-    out = torch.empty(4 * Lh + 5, device=logits.device, dtype=torch.float32)
+    out = torch.empty(4 * Lh + 6, device=logits.device, dtype=torch.float32)
     total = torch.empty((), device=logits.device, dtype=torch.float32)
     a.logits, a.boxes, a.out, a.total = logits.data_ptr(), boxes.data_ptr(), out.data_ptr(), total.data_ptr()
     a.dlogits, a.dboxes, a.dboxes2 = dl.data_ptr(), db.data_ptr(), db2.data_ptr()
@@ -1346,6 +1348,13 @@ def set_criterion(logits, boxes, at, dense, empty_weight, layer_of, w_ce, w_bbox
         dat = torch.empty_like(at)
         a.at, a.dat, a.gt_weak, a.Bat = at.data_ptr(), dat.data_ptr(), dense['gt_weak'].data_ptr(), at.shape[0]
         assert dense['n_lab'] <= at.shape[0]
+    dat_p = None
+    if at_p is not None:
+        assert at is not None, 'loss_weak_p needs the audio-tag output (the reference builds its targets in loss_weak)'
+        assert at_p.dtype == torch.float32 and at_p.is_contiguous() and at_p.dim() == 2 and at_p.shape[1] == C1 - 1
+        assert dense['n_lab'] <= at_p.shape[0]
+        dat_p = torch.empty_like(at_p)
+        a.at_p, a.dat_p, a.Bp, a.w_weak_p, a.wp_all = at_p.data_ptr(), dat_p.data_ptr(), at_p.shape[0], w_weak_p, int(bool(wp_all))
     for i in range(Lh):
         a.layer_of[i], a.w_ce[i], a.w_bbox[i], a.w_giou[i] = layer_of[i], w_ce[i], w_bbox[i], w_giou[i]
     a.w_weak = w_weak
@@ -1358,20 +1367,21 @@ def set_criterion(logits, boxes, at, dense, empty_weight, layer_of, w_ce, w_bbox
         a.split = dense['split'].data_ptr()
     scratch = torch.empty(Lh * B * Q * 5, device=logits.device, dtype=torch.float32)
     L.check(L.load().sedt_set_criterion(a, _p(scratch), L.stream_ptr()), 'set_criterion')
-    return out, total, (a, dl, db, db2, dat, (Lh, B, Qs, C1))
+    return out, total, (a, dl, db, db2, dat, dat_p, (Lh, B, Qs, C1))
 
 
 def set_criterion_bwd(state, g, gtotal=None):
-    """gradients of (logits, boxes, at) - in the layout of the head outputs, zero rows for queries outside the window - given the
-    gradient g[4L+5] of the loss vector and / or the gradient of the separately returned total (either may be None)"""
-    a, dl, db, db2, dat, (Lh, B, Qs, C1) = state
+    """gradients of (logits, boxes, at, at_p) - in the layout of the head outputs, zero rows for queries outside the window - given the
+    gradient g[4L+6] of the loss vector and / or the gradient of the separately returned total (either may be None)"""
+    a, dl, db, db2, dat, dat_p, (Lh, B, Qs, C1) = state
     g = None if g is None else g.contiguous().float()
     gtotal = None if gtotal is None else gtotal.contiguous().float()
     gl = torch.empty((Lh, B, Qs, C1), device=dl.device, dtype=torch.float32)
     gb = torch.empty((Lh, B, Qs, 2), device=dl.device, dtype=torch.float32)
     gat = None if dat is None else torch.empty_like(dat)
-    L.check(L.load().sedt_set_criterion_bwd(a, _p(g), _p(gtotal), _p(gl), _p(gb), _p(gat), L.stream_ptr()), 'set_criterion_bwd')
-    return gl, gb, gat
+    gat_p = None if dat_p is None else torch.empty_like(dat_p)
+    L.check(L.load().sedt_set_criterion_bwd(a, _p(g), _p(gtotal), _p(gl), _p(gb), _p(gat), _p(gat_p), L.stream_ptr()), 'set_criterion_bwd')
+    return gl, gb, gat, gat_p
 
 
 def match_targets(logits, boxes, tables, dense, layer_of, w_class, w_bbox, w_giou, max_targets, assign=None, fl=False,
@@ -1430,6 +1440,41 @@ def sum_f32(x, out=None):
         out = torch.empty(1, device=x.device, dtype=torch.float32)
     L.check(L.load().sedt_sum_f32(_p(x), x.numel(), _p(out), L.stream_ptr()), 'sum_f32')
     return out
+
+
+def _pool_args(logits, boxes, attn, mode, q0, Q):
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.dim() == 3 and logits.is_cuda
+    B, Qs, C1 = logits.shape
+    a = L.SedtPoolAt()
+    a.logits, a.B, a.Qs, a.q0, a.Q, a.C, a.mode = logits.data_ptr(), B, Qs, q0, Q, C1 - 1, L.POOL_MODES[mode]
+    if mode == 'weighted_sum':
+        assert boxes is not None and boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.shape == (B, Qs, 2)
+        a.boxes = boxes.data_ptr()
+    if mode == 'attn':
+        assert attn is not None and attn.dtype == torch.float32 and attn.is_contiguous() and attn.shape == (B, Q, C1 - 1)
+        a.attn = attn.data_ptr()
+    return a
+
+
+def pool_at(logits, boxes, attn, mode, q0, Q):
+    """--pooling variants (sedt.py:96-119; csrc/pool_at.hip): at_p [B,C] from the final layer's class logits [B,Qs,C+1] (event
+    queries q0 .. q0+Q-1), the boxes [B,Qs,2] (mode 'weighted_sum') or the attention logits [B,Q,C] (mode 'attn'); all f32."""
+    a = _pool_args(logits, boxes, attn, mode, q0, Q)
+    out = torch.empty((a.B, a.C), device=logits.device, dtype=torch.float32)
+    L.check(L.load().sedt_pool_at(a, _p(out), L.stream_ptr()), 'pool_at')
+    return out
+
+
+def pool_at_bwd(logits, boxes, attn, mode, q0, Q, g):
+    """(glogits [B,Qs,C+1], gboxes [B,Qs,2] | None, gattn [B,Q,C] | None) for the gradient g [B,C] that reached at_p"""
+    a = _pool_args(logits, boxes, attn, mode, q0, Q)
+    g = g.contiguous().float()
+    assert g.shape == (a.B, a.C)
+    gl = torch.empty_like(logits)
+    gb = torch.empty_like(boxes) if mode == 'weighted_sum' else None
+    ga = torch.empty_like(attn) if mode == 'attn' else None
+    L.check(L.load().sedt_pool_at_bwd(a, _p(g), _p(gl), _p(gb), _p(ga), L.stream_ptr()), 'pool_at_bwd')
+    return gl, gb, ga
 
 
 def feature_loss(pred, gt, dense, layer_of, num_boxes, w=None, nonfinite=None):

@@ -59,8 +59,12 @@ class SEDT(nn.Module):
 
     def __init__(self, backbone, transformer, num_classes, num_queries, aux_loss=False, dec_at=False, pooling=None):
         super().__init__()
-        if pooling is not None:
-            raise NotImplementedError('--pooling variants (sedt.py:47-61) are off in every supported config')
+        self.pool_mode = None
+        if pooling is not None:                  # sedt.py:47-61; --pooling takes exactly these four names (train_sedt.py:72)
+            if pooling not in ('max', 'avg', 'attn', 'weighted_sum') or (pooling == 'weighted_sum' and not dec_at):
+                raise ValueError(f"pooling={pooling!r}: the reference defines max / avg / attn, and weighted_sum for dec_at models only "
+                                 "(sedt.py:47-61, 98-100: without dec_at it fails there with a missing pooling_func)")
+            self.pool_mode = pooling
         self.num_queries = num_queries
         self.transformer = transformer
         hidden_dim = transformer.d_model
@@ -83,6 +87,8 @@ class SEDT(nn.Module):
             self.weak_class_embed = HipLinear(hidden_dim, num_classes)
         else:
             self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        if self.pool_mode == 'attn':                             # sedt.py:52-53
+            self.attn_dense_softmax = HipLinear(hidden_dim, num_classes)
 
     def pack_plan(self):
         """the model's weight-preparation plans (two launches prepare every weight / FrozenBN of a forward), cached per
@@ -113,7 +119,7 @@ class SEDT(nn.Module):
                               l.multihead_attn.out_proj.weight, l.linear1.weight, l.linear2.weight]
                 lin += [self.class_embed.weight] + [m.weight for m in self.bbox_embed.layers]
                 frags += [m.weight for m in self.bbox_embed.layers[:2]]
-                for name in ('weak_class_embed', 'patch2query'):
+                for name in ('weak_class_embed', 'patch2query', 'attn_dense_softmax'):
                     if hasattr(self, name):
                         lin.append(getattr(self, name).weight)
                 if hasattr(self, 'feature_align'):
@@ -156,6 +162,11 @@ class SEDT(nn.Module):
             out['at'] = res[2].squeeze()
         out['pred_logits'] = outputs_class[-1]
         out['pred_boxes'] = outputs_coord[-1]
+        if self.pool_mode is not None:                           # sedt.py:96-106 / 112-119: one launch (csrc/pool_at.hip)
+            mode, Q = self.pool_mode, cls_full.shape[2] - q0
+            attn = self.attn_dense_softmax(hs[-1][:, q0:, :].contiguous(), out_f32=True) if mode == 'attn' else None
+            at_p = Fn.PoolAtFn.apply(cls_full[-1], box_full[-1] if mode == 'weighted_sum' else None, attn, mode, q0, Q)
+            out['at_p'] = at_p.squeeze() if mode in ('max', 'avg') else at_p
         if self.aux_loss:
             out['aux_outputs'] = self._set_aux_loss(outputs_class, outputs_coord)
             out['_stacked'] = (cls_full, box_full)          # all decoder layers and all query rows, for the fused criterion kernels
@@ -182,13 +193,17 @@ class TargetTables(object):
     laid out in a pinned staging buffer and travel in ONE asynchronous host->device copy per batch; device-resident targets
     are copied table by table."""
 
-    def __init__(self, batch, ns, n_lab, device, max_targets=32, with_ratio=False, slots=4, dynamic_split=False):
+    def __init__(self, batch, ns, n_lab, device, max_targets=32, with_ratio=False, slots=4, dynamic_split=False,
+                 weak_mask_none=False):
         """ns / n_lab: number of strongly labelled / labelled clips.  dynamic_split=True: they are only the FIRST batch's values -
         every ``load`` may bring another split (mix-up moves clips across the strong | weak boundary, utilities/mixup.py:13-127);
         the tables then have room for ``batch`` strong clips and the current split travels to the kernels as two device words."""
         if not 1 <= max_targets <= 63:
             raise ValueError('max_targets must be in 1..63 (one wave lane per target)')
         self.dynamic = bool(dynamic_split)
+        # the reference's criterion called with weak_mask=None (a fully strong batch): loss_weak_p of --pooling models then runs
+        # over every labelled clip instead of the weak ones (sedt.py:184)
+        self.weak_mask_none = bool(weak_mask_none)
         self.B, self.max_targets, self.dev = batch, max_targets, device
         self.ns, self.n_lab = (batch, batch) if self.dynamic else (ns, max(n_lab, ns))          # capacities = strides
         self.cur_ns, self.cur_n_lab = ns, max(n_lab, ns)
@@ -307,24 +322,28 @@ class _CriterionFn(torch.autograd.Function):
     entries, e.g. a caller's own ``sum(loss_dict[k] * weight_dict[k])``) and / or the total."""
 
     @staticmethod
-    def forward(ctx, logits_all, boxes_all, at, dense, empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak, fl, nonfinite, q0):
+    def forward(ctx, logits_all, boxes_all, at, dense, empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak, fl, nonfinite, q0,
+                at_p=None, w_weak_p=0.0):
         from .. import ops
         ctx.set_materialize_grads(False)           # usually only the total carries a gradient: no zero-filled g for the vector
         f32c = lambda t: t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().float().contiguous()
         out, total, ctx.state = ops.set_criterion(f32c(logits_all), f32c(boxes_all), None if at is None else f32c(at), dense,
                                                   empty_weight, layer_of, w_ce, w_bbox, w_giou, w_weak, fl=fl, alpha_fl=ALPHA_FL,
-                                                  gamma_fl=GAMMA_FL, nonfinite=nonfinite, q0=q0)
-        ctx.dts = (logits_all.dtype, boxes_all.dtype, None if at is None else at.dtype)
+                                                  gamma_fl=GAMMA_FL, nonfinite=nonfinite, q0=q0,
+                                                  at_p=None if at_p is None else f32c(at_p), w_weak_p=w_weak_p,
+                                                  wp_all=bool(dense.get('wp_all', False)))
+        ctx.dts = (logits_all.dtype, boxes_all.dtype, None if at is None else at.dtype, None if at_p is None else at_p.dtype)
         return out, total
 
     @staticmethod
     def backward(ctx, g, gtotal):
         from .. import ops
         if g is None and gtotal is None:
-            return (None,) * 13
-        gl, gb, gat = ops.set_criterion_bwd(ctx.state, g, gtotal)
+            return (None,) * 15
+        gl, gb, gat, gat_p = ops.set_criterion_bwd(ctx.state, g, gtotal)
         return (gl.to(ctx.dts[0]), gb.to(ctx.dts[1]), None if gat is None else gat.to(ctx.dts[2]),
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None,
+                None if gat_p is None else gat_p.to(ctx.dts[3]), None)
 
 
 class _FeatureLossFn(torch.autograd.Function):
@@ -484,6 +503,7 @@ class SetCriterion(nn.Module):
                                gt_weak.ravel(), tgt_len, np.asarray([num_boxes], np.float32)])
         d = torch.from_numpy(pack).to(dev, non_blocking=True)                       # the ONE host->device copy
         dense = self.dense_views(d, (L, ns, Q, n_lab, C, len(targets)))
+        dense['wp_all'] = weak_mask is None           # loss_weak_p indexes with weak_mask: None = every labelled clip (sedt.py:184)
         idx0 = []
         for b in range(ns):                           # reference order: surviving Hungarian pairs, then the added queries
             first = np.nonzero(matched[0, b] & ~extra0[b])[0]
@@ -524,6 +544,7 @@ class SetCriterion(nn.Module):
             pack = torch.empty(self.dense_numel(meta), device=logits_all.device, dtype=torch.float32)
         dense = self.dense_views(pack, meta)
         dense['split'] = getattr(tables, 'split', None)      # {ns, n_lab} as device words: the split is data, not graph structure
+        dense['wp_all'] = bool(getattr(tables, 'weak_mask_none', False))
         m = self.matcher
         seed_ptr = runtime.seed_ptr(logits_all.device) if (fine_tune and ft_rand is None) else None
         f32c = lambda t: t.detach() if (t.dtype == torch.float32 and t.is_contiguous()) else t.detach().float().contiguous()
@@ -571,6 +592,7 @@ class SetCriterion(nn.Module):
         at = outputs['at'] if ('weak' in self.losses and 'at' in outputs) else None
         if at is not None and at.dim() == 1:
             at = at[None]
+        at_p = self._pooled(outputs, at)
         zero = [0.0] * L
         dev = logits_all.device
         ew = self._dev_const('ew', lambda: self.empty_weight.detach().float().cpu(), dev)
@@ -579,7 +601,8 @@ class SetCriterion(nn.Module):
             self._weights('loss_ce', L) if 'labels' in self.losses else zero,
             self._weights('loss_bbox', L) if 'boxes' in self.losses else zero,
             self._weights('loss_giou', L) if 'boxes' in self.losses else zero,
-            float(self.weight_dict.get('loss_weak', 0.0)) if at is not None else 0.0, fl, self.nonfinite, q0)
+            float(self.weight_dict.get('loss_weak', 0.0)) if at is not None else 0.0, fl, self.nonfinite, q0,
+            at_p, float(self.weight_dict.get('loss_weak_p', 0.0)) if at_p is not None else 0.0)
         out = {}
         names = []
         if 'labels' in self.losses:
@@ -595,6 +618,8 @@ class SetCriterion(nn.Module):
                 out[k if d == 0 else f'{k}_{d - 1}'] = v.detach() if slot == 3 else v
         if at is not None:
             out['loss_weak'] = vec[4 * L + 2]
+        if at_p is not None:
+            out['loss_weak_p'] = vec[4 * L + 5]
         if 'feature' in self.losses:
             if '_stacked_feature' in outputs:
                 feats = outputs['_stacked_feature']
@@ -611,6 +636,14 @@ class SetCriterion(nn.Module):
             total = total + fv[L]
         self.last_total = total
         return out
+
+    def _pooled(self, outputs, at):
+        """outputs['at_p'] [B,C] when loss_weak_p applies (sedt.py:182-185: inside loss_weak, i.e. only with 'weak' among the losses)"""
+        if 'weak' not in self.losses or 'at_p' not in outputs:
+            return None
+        if at is None:
+            raise ValueError("loss_weak_p needs outputs['at']: the reference builds its targets from it (sedt.py:164-175)")
+        return outputs['at_p'].reshape(-1, self.num_classes)
 
     def compute(self, outputs, dense, fl=False):
         if outputs['pred_logits'].is_cuda:
@@ -686,6 +719,10 @@ class SetCriterion(nn.Module):
                 out['loss_weak'] = ce.sum(1).mean()
             else:
                 out['loss_weak'] = F.binary_cross_entropy(pw, gw)
+        at_p = self._pooled(outputs, outputs.get('at'))
+        if at_p is not None:
+            r0 = 0 if dense.get('wp_all', False) else ns
+            out['loss_weak_p'] = F.binary_cross_entropy(at_p[r0:dense['n_lab']].float(), dense['gt_weak'][r0:])
         wd = self.weight_dict
         total = None
         for k, v in vec.items():
@@ -693,8 +730,9 @@ class SetCriterion(nn.Module):
             if any(wts):
                 term = (v * torch.tensor(wts, device=v.device, dtype=v.dtype)).sum()
                 total = term if total is None else total + term
-        if 'loss_weak' in out and wd.get('loss_weak', 0.0):
-            total = out['loss_weak'] * wd['loss_weak'] + (total if total is not None else 0.0)
+        for k in ('loss_weak', 'loss_weak_p'):
+            if k in out and wd.get(k, 0.0):
+                total = out[k] * wd[k] + (total if total is not None else 0.0)
         self.last_total = total
         return out
 
