@@ -257,3 +257,80 @@ def test_pooling_model_bf16_and_graphed_step(pkg, golden_dir, mode):
             assert rel(res['graph'][1][k], res['eager'][1][k]) < 5e-3, k
     finally:
         runtime.set_compute_dtype('f32')
+
+
+def test_mean_teacher_step_with_pooling_against_oracle(pkg):
+    """the semi-supervised iteration (reference engine.py:117-181) of a --pooling model: the labelled loss takes loss_weak_p over
+    the weak clips, the pseudo-label loss over all unlabelled clips (criterion called with weak_mask None, engine.py:159); f32
+    mode against the oracle's iteration on the CPU (total 1e-3, every gradient norm 2e-3), then the one-graph step against the
+    eager one"""
+    from collections import Counter
+    from oracle import semi_oracle as S
+    runtime, sedt = pkg
+    from sound_event_detection_transformer_amd.engine import semi_train_step, GraphedSemiStep, build_optimizer
+    from sound_event_detection_transformer_amd.utilities.utils import EMA
+    runtime.set_compute_dtype('f32')
+    c = GI.SEMI
+    ns, nw, nu = c['n_strong'], c['n_weak'], c['n_unl']
+    masks = dict(mask_strong=slice(ns), mask_weak=slice(ns, ns + nw), mask_label=slice(ns + nw), mask_unlabel=slice(ns + nw, ns + nw + nu))
+    x_t, x_s, targets = GI.semi_batch()
+    thr = torch.full((10,), c['thr'])
+    # ---- oracle
+    om = O.build_oracle_model(10, 20, 6, 3, True, True, True, dropout=0.0, pooling='max')
+    om.load_state_dict(O.seeded_state_dict(om.state_dict(), c['seed_w']))
+    om.train()
+    oc = build_oracle_criterion(10, 3, True, True, pooling='max', weak_loss_p_coef=0.7)
+    oema = S.EMA(om, 0.9)
+    oema.register()
+    gen = torch.Generator().manual_seed(5)
+    for n in oema.shadow:
+        oema.shadow[n] = oema.shadow[n] + 0.02 * oema.shadow[n].abs().mean() * torch.randn(oema.shadow[n].shape, generator=gen)
+    shadow = {n: v.clone() for n, v in oema.shadow.items()}
+    sup_r, unsup_r, total_r, pseudo_r = S.semi_step(om, oema, oc, None, x_t, x_s, targets, classwise_threshold=thr, do_step=False,
+                                                    counter=Counter(), **masks)
+    assert 'loss_weak_p' in sup_r and 'loss_weak_p' in unsup_r
+    assert sum(len(t['labels']) for t in pseudo_r) > 0
+    gn_r = {n: p.grad.norm().item() for n, p in om.named_parameters() if p.requires_grad}
+
+    def hip_model():
+        model, crit, _ = sedt.build_model(sedt.default_args(enc_layers=6, num_queries=20, dropout=0.0, pooling='max', weak_loss_p_coef=0.7))
+        model.load_state_dict(O.seeded_state_dict(model.state_dict(), c['seed_w']))
+        model.cuda().train()
+        ema = EMA(model, 0.9)
+        ema.register()
+        for n in ema.shadow:
+            ema.shadow[n].copy_(shadow[n])
+        return model, crit.cuda(), ema, build_optimizer(model)
+    cuda_t = [{k: v.cuda() for k, v in t.items()} for t in targets]
+    model, crit, ema, opt = hip_model()
+    sup, unsup, total, pseudo = semi_train_step(model, ema, crit, opt, x_t.cuda(), x_s.cuda(), cuda_t, classwise_threshold=thr.cuda(),
+                                                counter=Counter(), do_step=False, do_ema=False, **masks)
+    assert [len(t['labels']) for t in pseudo] == [len(t['labels']) for t in pseudo_r]
+    assert abs(total.item() - total_r.item()) < 1e-3 * abs(total_r.item())
+    for k in ('loss_weak_p', 'loss_weak'):
+        assert abs(sup[k].item() - sup_r[k].item()) < 1e-3 * max(1.0, abs(sup_r[k].item())), k
+        assert abs(unsup[k].item() - unsup_r[k].item()) < 1e-3 * max(1.0, abs(unsup_r[k].item())), k
+    bad = [(n, p.grad.norm().item(), gn_r[n]) for n, p in model.named_parameters()
+           if p.requires_grad and abs(p.grad.norm().item() - gn_r[n]) > 2e-3 * gn_r[n] + 1e-6]
+    assert not bad, bad[:10]
+    # ---- one graph == eager (bf16, two batches)
+    runtime.set_compute_dtype('bf16')
+    try:
+        res = {}
+        for how in ('eager', 'graph'):
+            model, crit, ema, opt = hip_model()
+            if how == 'graph':
+                stepper = GraphedSemiStep(model, ema, crit, opt, x_t.cuda(), x_s.cuda(), cuda_t, classwise_threshold=thr.cuda(), **masks)
+            tot = []
+            for i in range(2):
+                if how == 'eager':
+                    tot.append(float(semi_train_step(model, ema, crit, opt, x_t.cuda(), x_s.cuda(), cuda_t,
+                                                     classwise_threshold=thr.cuda(), **masks)[2].detach()))
+                else:
+                    tot.append(float(stepper(x_t.cuda(), x_s.cuda(), cuda_t)[0].detach()))
+            res[how] = (tot, {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()})
+        np.testing.assert_allclose(res['graph'][0], res['eager'][0], rtol=2e-3)
+        for k in res['eager'][1]:
+            assert rel(res['graph'][1][k], res['eager'][1][k]) < 5e-3, k
+    finally:
+        runtime.set_compute_dtype('f32')
