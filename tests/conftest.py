@@ -39,3 +39,16 @@ def _x3_mode(request):
     patched('f32')
     yield
     runtime.set_compute_dtype = real
+
+
+def x3_skips_gradient_elements():
+    """The f32-mode fixture tests call this right before their gradient NORM / ELEMENT assertions.  Under ``--x3`` (every f32-mode test
+    re-run in the bf16x3 mode) outputs, losses, matchings and pseudo labels above the call have been checked at the f32 mode's own
+    tolerances; the gradient bounds of the f32 mode (norms 2e-3, cosine 1 - 5e-6, elements 5e-3) are not claimed for bf16x3 - a product
+    error of 2^-16 shows at 0.5-1 % on the six scalars of conv0 (single cancelling sums over every input position) and at 1-2e-2 on
+    single elements where one ReLU decision falls the other way.  Its own bounds (norms 5e-3, cosine 1 - 1e-4, elements 2e-2) are
+    measured by tests/test_x3_gpu.py::test_x3_gradients_against_the_oracle."""
+    from sound_event_detection_transformer_amd import runtime
+    if runtime.compute_mode() == 'bf16x3':
+        pytest.skip('--x3: outputs / losses checked at the f32 bounds; gradient bounds of the bf16x3 mode: tests/test_x3_gpu.py')
+
