@@ -336,3 +336,33 @@ def test_mean_teacher_step_with_pooling_against_oracle(pkg):
             assert rel(res['graph'][1][k], res['eager'][1][k]) < 5e-3, k
     finally:
         runtime.set_compute_dtype('f32')
+
+
+@pytest.mark.parametrize('mode', ['max', 'avg', 'attn'])
+def test_pooling_without_the_audio_tag_query_against_oracle(pkg, mode):
+    """dec_at=False (sedt.py:108-119): all queries are event queries, at_p is an output only (no 'weak' loss consumes it), a single
+    clip squeezes to [C] as the reference's .squeeze() does; f32 mode against the oracle"""
+    runtime, sedt = pkg
+    runtime.set_compute_dtype('f32')
+    oracle = O.build_oracle_model(10, 10, 3, 3, False, True, True, dropout=0.0, pooling=mode).eval()
+    sd = O.seeded_state_dict(oracle.state_dict(), 1700)
+    oracle.load_state_dict(sd)
+    model, crit, _ = sedt.build_model(sedt.default_args(enc_layers=3, num_queries=10, dropout=0.0, dec_at=False, pooling=mode))
+    model.load_state_dict(sd)
+    model.cuda().eval()
+    assert 'weak' not in crit.losses and 'loss_weak_p' in crit.weight_dict          # sedt/__init__.py:41-45
+    for B in (3, 1):
+        x = torch.randn(B, 1, 248, 64, generator=torch.Generator().manual_seed(1701 + B))
+        with torch.no_grad():
+            ref = oracle(x)
+            got = model(x.cuda())
+        assert 'at' not in got and got['at_p'].shape == ref['at_p'].shape
+        assert rel(got['at_p'], ref['at_p']) < 1e-3 and rel(got['pred_logits'], ref['pred_logits']) < 1e-3
+    # a training step: the criterion leaves at_p alone (no gradient reaches the attention-pooling layer, as in the reference)
+    model.train()
+    x = torch.randn(2, 1, 248, 64, generator=torch.Generator().manual_seed(1705)).cuda()
+    ld, _ = crit(model(x), [{k: v.cuda() for k, v in t.items()} for t in synthetic_targets(2, 1706, 10)], None, slice(2))
+    assert 'loss_weak_p' not in ld and 'loss_weak' not in ld
+    crit.last_total.backward()
+    if mode == 'attn':
+        assert model.attn_dense_softmax.weight.grad is None
