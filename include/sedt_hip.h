@@ -232,6 +232,13 @@ int sedt_add_n(const void* const* srcs, int n, void* out, int64_t numel, int dty
 int sedt_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, void* stream);
 /* out = y > 0 ? g : 0 (ReLU backward), compute dtype, elementwise over n */
 int sedt_relu_mask(const void* g, const void* y, void* out, int64_t n, int dtype, void* stream);
+/* the FFN activation "gelu" of reference sedt/transformer.py:423-431 (F.gelu, erf form) with the FFN's dropout behind it
+ * (transformer.py:187 / :203: dropout(activation(linear1(x)))):  a = keep(seed, e) * gelu(h) / (1-p);
+ * backward: out = keep(seed, e) * g * gelu'(h) / (1-p).  h is the saved PRE-activation.  Elementwise over n (a multiple of 8) in the
+ * compute dtype; the keep decision is the GEMM epilogue's (seed, element index) hash; p = 0: no dropout */
+int sedt_gelu_fwd(const void* h, void* a, int64_t n, float p, uint32_t seed, const uint32_t* seed_ptr, int dtype, void* stream);
+int sedt_gelu_bwd(const void* g, const void* h, void* out, int64_t n, float p, uint32_t seed, const uint32_t* seed_ptr, int dtype,
+                  void* stream);
 /* y = g * s * (1 - s) (sigmoid backward), all f32 */
 int sedt_sigmoid_grad(const float* g, const float* s, float* out, int64_t n, void* stream);
 

@@ -255,11 +255,24 @@ def _with_pos(t, pos):
     return t if pos is None else t + pos
 
 
+def _activation(name):
+    """transformer.py:423-431 (`_get_activation_fn`): "relu" / "gelu" / "glu" by name, RuntimeError otherwise.  (F.glu halves the
+    hidden width, so linear2 of a layer built with it fails in the reference too; kept for the same behaviour.)"""
+    if name == "relu":
+        return F.relu
+    if name == "gelu":
+        return F.gelu
+    if name == "glu":
+        return F.glu
+    raise RuntimeError(F"activation should be relu/gelu, not {name}.")
+
+
 class TransformerEncoderLayer(nn.Module):
     """transformer.py:155-212."""
 
-    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, normalize_before=False):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, normalize_before=False, activation="relu"):
         super().__init__()
+        self.activation = _activation(activation)
         self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.dropout = nn.Dropout(dropout)
@@ -277,20 +290,21 @@ class TransformerEncoderLayer(nn.Module):
             src2 = self.self_attn(q, k, src2, attn_mask=src_mask, key_padding_mask=src_key_padding_mask)[0]
             src = src + self.dropout1(src2)
             src2 = self.norm2(src)
-            src2 = self.linear2(self.dropout(F.relu(self.linear1(src2))))
+            src2 = self.linear2(self.dropout(self.activation(self.linear1(src2))))
             return src + self.dropout2(src2)
         q = k = _with_pos(src, pos)                                      # forward_post :177-190
         src2 = self.self_attn(q, k, src, attn_mask=src_mask, key_padding_mask=src_key_padding_mask)[0]
         src = self.norm1(src + self.dropout1(src2))
-        src2 = self.linear2(self.dropout(F.relu(self.linear1(src))))
+        src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
         return self.norm2(src + self.dropout2(src2))
 
 
 class TransformerDecoderLayer(nn.Module):
     """transformer.py:215-297."""
 
-    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, normalize_before=False):
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, normalize_before=False, activation="relu"):
         super().__init__()
+        self.activation = _activation(activation)
         self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
         self.multihead_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
@@ -316,7 +330,7 @@ class TransformerDecoderLayer(nn.Module):
                                      attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask)[0]
             tgt = tgt + self.dropout2(t2)
             t2 = self.norm3(tgt)
-            t2 = self.linear2(self.dropout(F.relu(self.linear1(t2))))
+            t2 = self.linear2(self.dropout(self.activation(self.linear1(t2))))
             return tgt + self.dropout3(t2)
         q = k = _with_pos(tgt, query_pos)                                # forward_post :240-261
         t2 = self.self_attn(q, k, tgt, attn_mask=tgt_mask, key_padding_mask=tgt_key_padding_mask)[0]
@@ -324,7 +338,7 @@ class TransformerDecoderLayer(nn.Module):
         t2 = self.multihead_attn(_with_pos(tgt, query_pos), _with_pos(memory, pos), memory,
                                  attn_mask=memory_mask, key_padding_mask=memory_key_padding_mask)[0]
         tgt = self.norm2(tgt + self.dropout2(t2))
-        t2 = self.linear2(self.dropout(F.relu(self.linear1(tgt))))
+        t2 = self.linear2(self.dropout(self.activation(self.linear1(tgt))))
         return self.norm3(tgt + self.dropout3(t2))
 
 
@@ -369,14 +383,14 @@ class Transformer(nn.Module):
     """transformer.py:18-86 (enc_at_embed branch :70-80 is unreachable from SEDT and omitted)."""
 
     def __init__(self, d_model=256, nhead=8, num_encoder_layers=3, num_decoder_layers=3, dim_feedforward=2048,
-                 dropout=0.1, normalize_before=True, return_intermediate_dec=True, self_sup=False):
+                 dropout=0.1, normalize_before=True, return_intermediate_dec=True, self_sup=False, activation="relu"):
         super().__init__()
         enc_norm = nn.LayerNorm(d_model) if normalize_before else None
         self.encoder = TransformerEncoder(
-            lambda: TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout, normalize_before),
+            lambda: TransformerEncoderLayer(d_model, nhead, dim_feedforward, dropout, normalize_before, activation),
             num_encoder_layers, enc_norm)
         self.decoder = TransformerDecoder(
-            lambda: TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout, normalize_before),
+            lambda: TransformerDecoderLayer(d_model, nhead, dim_feedforward, dropout, normalize_before, activation),
             num_decoder_layers, nn.LayerNorm(d_model), return_intermediate=return_intermediate_dec)
         for p in self.parameters():                                      # transformer.py:42-45
             if p.dim() > 1:

@@ -295,6 +295,44 @@ __global__ void relu_mask_kernel(const T* __restrict__ g, const T* __restrict__ 
   if (e < n) out[e] = ((float)y[e] > 0.f) ? g[e] : (T)0.f;
 }
 
+// GELU (erf form: torch's F.gelu default, reference transformer.py:423-431 "gelu") followed by the FFN's dropout:
+//   a = drop(gelu(h));  backward g_h = drop'(g_a) * (Phi(h) + h * phi(h)).  The keep decision is the epilogue dropout's
+// (seed, row * cols + col) hash, so forward and backward agree without a stored mask.  8 elements per thread.
+template <typename T>
+__global__ void gelu_fwd_kernel(const T* __restrict__ h, T* __restrict__ a, long n8, uint32_t thresh, float inv_keep, uint32_t seed,
+                                const uint32_t* seed_ptr) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n8) return;
+  const uint32_t sd = eff_seed(seed, seed_ptr);
+  const VecT<T, 8> v = reinterpret_cast<const VecT<T, 8>*>(h)[e];
+  VecT<T, 8> o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = (float)v.v[i];
+    const float y = 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    o.v[i] = (T)((thresh == 0u || drop_keep(sd, (uint64_t)(e * 8 + i), thresh)) ? y * inv_keep : 0.f);
+  }
+  reinterpret_cast<VecT<T, 8>*>(a)[e] = o;
+}
+
+template <typename T>
+__global__ void gelu_bwd_kernel(const T* __restrict__ g, const T* __restrict__ h, T* __restrict__ out, long n8, uint32_t thresh,
+                                float inv_keep, uint32_t seed, const uint32_t* seed_ptr) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n8) return;
+  const uint32_t sd = eff_seed(seed, seed_ptr);
+  const VecT<T, 8> gv = reinterpret_cast<const VecT<T, 8>*>(g)[e];
+  const VecT<T, 8> hv = reinterpret_cast<const VecT<T, 8>*>(h)[e];
+  VecT<T, 8> o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = (float)hv.v[i];
+    const float d = 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * expf(-0.5f * x * x);
+    o.v[i] = (T)((thresh == 0u || drop_keep(sd, (uint64_t)(e * 8 + i), thresh)) ? (float)gv.v[i] * d * inv_keep : 0.f);
+  }
+  reinterpret_cast<VecT<T, 8>*>(out)[e] = o;
+}
+
 __global__ void sigmoid_grad_kernel(const float* g, const float* s, float* out, long n) {
   long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n) out[e] = g[e] * s[e] * (1.f - s[e]);
@@ -1048,6 +1086,32 @@ extern "C" int sedt_cast(const void* in, int in_dtype, void* out, int out_dtype,
     hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, S(stream), (const bf16_t*)in, (bf16_t*)out, (long)n);
   else { set_error("cast: bad dtypes %d -> %d", in_dtype, out_dtype); return 1; }
   return check_launch("cast");
+}
+
+extern "C" int sedt_gelu_fwd(const void* h, void* a, int64_t n, float p, uint32_t seed, const uint32_t* seed_ptr, int dtype, void* stream) {
+  SEDT_REQUIRE(p >= 0.f && p < 1.f, "gelu_fwd: p out of range");
+  SEDT_REQUIRE(n % 8 == 0 && ((uintptr_t)h & 15) == 0 && ((uintptr_t)a & 15) == 0, "gelu_fwd: numel must be a multiple of 8, pointers 16-byte aligned");
+  const uint32_t th = p > 0.f ? drop_threshold(p) : 0u;
+  const float ik = 1.f / (1.f - p);
+  const long n8 = n / 8;
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(gelu_fwd_kernel<float>, dim3(nblk(n8)), dim3(256), 0, S(stream), (const float*)h, (float*)a, n8, th, ik, seed, seed_ptr),
+           hipLaunchKernelGGL(gelu_fwd_kernel<bf16_t>, dim3(nblk(n8)), dim3(256), 0, S(stream), (const bf16_t*)h, (bf16_t*)a, n8, th, ik, seed, seed_ptr));
+  return check_launch("gelu_fwd");
+}
+
+extern "C" int sedt_gelu_bwd(const void* g, const void* h, void* out, int64_t n, float p, uint32_t seed, const uint32_t* seed_ptr, int dtype,
+                             void* stream) {
+  SEDT_REQUIRE(p >= 0.f && p < 1.f, "gelu_bwd: p out of range");
+  SEDT_REQUIRE(n % 8 == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)h & 15) == 0 && ((uintptr_t)out & 15) == 0,
+               "gelu_bwd: numel must be a multiple of 8, pointers 16-byte aligned");
+  const uint32_t th = p > 0.f ? drop_threshold(p) : 0u;
+  const float ik = 1.f / (1.f - p);
+  const long n8 = n / 8;
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(nblk(n8)), dim3(256), 0, S(stream), (const float*)g, (const float*)h, (float*)out, n8, th, ik, seed, seed_ptr),
+           hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3(nblk(n8)), dim3(256), 0, S(stream), (const bf16_t*)g, (const bf16_t*)h, (bf16_t*)out, n8, th, ik, seed, seed_ptr));
+  return check_launch("gelu_bwd");
 }
 
 extern "C" int sedt_relu_mask(const void* g, const void* y, void* out, int64_t n, int dtype, void* stream) {

@@ -437,10 +437,17 @@ def _mha_bwd(dt, s, g_out, w_in, w_out, need_q=True, need_k=True, need_v=True, b
     return g_q, g_k, g_v, d_win, d_bin, d_wo, d_bo
 
 
-def _ffn_fwd(dt, x_in, w1, b1, w2, b2, res, p, seeds, train=True, out=None):
+def _ffn_fwd(dt, x_in, w1, b1, w2, b2, res, p, seeds, train=True, out=None, act='relu'):
+    """res + drop(linear2(drop(act(linear1(x_in)))));  act 'relu' rides in linear1's epilogue with its dropout (the saved h = drop(relu(.))
+    is its own backward mask); 'gelu' (transformer.py:423-431) keeps the PRE-activation and runs gelu + dropout as one launch"""
     sp = runtime.seed_ptr(x_in.device) if p > 0 else None
     wf1, wb1 = _prep_linear(dt, w1, train)
     wf2, wb2 = _prep_linear(dt, w2, train)
+    if act == 'gelu':
+        h_pre = ops.linear(dt, x_in, wf1, bias=b1)
+        h = ops.gelu_fwd(dt, h_pre, p, seeds[0], sp)
+        out = ops.linear(dt, h, wf2, out, bias=b2, drop_p=p, seed=seeds[1], seed_ptr=sp, res=res, ldr=res.stride(0))
+        return out, dict(x_in=x_in, h=h, h_pre=h_pre, p=p, seeds=seeds, wb1=wb1, wb2=wb2)
     h = ops.linear(dt, x_in, wf1, bias=b1, act=ACT_RELU, drop_p=p, seed=seeds[0], seed_ptr=sp)
     out = ops.linear(dt, h, wf2, out, bias=b2, drop_p=p, seed=seeds[1], seed_ptr=sp, res=res, ldr=res.stride(0))
     return out, dict(x_in=x_in, h=h, p=p, seeds=seeds, wb1=wb1, wb2=wb2)
@@ -455,8 +462,11 @@ def _ffn_bwd(dt, s, g_out, w1, w2, res_for_gx=None, batch=None, g_dropped=None):
         g2 = ops.dropout_grad(dt, g_out, p, s['seeds'][1], runtime.seed_ptr(g_out.device)) if p > 0 else g_out
     d_b2 = torch.empty((g2.shape[1],), device=g2.device, dtype=torch.float32)
     d_w2 = ops.linear_wgrad(dt, g2, s['h'], bias_out=d_b2, batch=batch, param=w2)
-    # d_hidden = (g2 @ W2) * [h > 0] / (1-p): h = drop(relu(.)) is positive exactly where kept and active
-    gh = ops.linear(dt, g2, s['wb2'], mask=s['h'], ldm=s['h'].stride(0), alpha=1.0 / (1.0 - p) if p > 0 else 1.0)
+    if s.get('h_pre') is not None:          # gelu: d_hidden = drop'(g2 @ W2) * gelu'(h_pre)
+        gh = ops.gelu_bwd(dt, ops.linear(dt, g2, s['wb2']), s['h_pre'], p, s['seeds'][0], runtime.seed_ptr(g2.device) if p > 0 else None)
+    else:
+        # d_hidden = (g2 @ W2) * [h > 0] / (1-p): h = drop(relu(.)) is positive exactly where kept and active
+        gh = ops.linear(dt, g2, s['wb2'], mask=s['h'], ldm=s['h'].stride(0), alpha=1.0 / (1.0 - p) if p > 0 else 1.0)
     d_b1 = torch.empty((gh.shape[1],), device=gh.device, dtype=torch.float32)
     d_w1 = ops.linear_wgrad(dt, gh, s['x_in'], bias_out=d_b1, batch=batch, param=w1)
     if res_for_gx is not None:
@@ -484,7 +494,8 @@ class EncoderLayerFn(Function):
         sv = {}
         tr = any(ctx.needs_input_grad)
         fr = None
-        if cfg['pre_norm'] and ops.encoder_slab_ok(dt, x.shape[1], H, S, w1.shape[0], amask, B):
+        act = cfg.get('act', 'relu')
+        if cfg['pre_norm'] and act == 'relu' and ops.encoder_slab_ok(dt, x.shape[1], H, S, w1.shape[0], amask, B):
             fr = [packing.lookup_frag(w) for w in (w_in, w_o, w1, w2)]
             fr = fr if all(f is not None for f in fr) else None
         if fr is not None:
@@ -518,13 +529,13 @@ class EncoderLayerFn(Function):
             xn, xnp, m1, r1 = ops.layernorm_fwd(dt, x, g1, be1, add_t=pos)
             x1, sv['mha'] = _mha_fwd(dt, xnp, xnp, xn, True, w_in, b_in, w_o, b_o, x, B, H, S, S, kpm, amask, p, seeds[0:2], tr)
             x1n, _, m2, r2 = ops.layernorm_fwd(dt, x1, g2, be2)
-            x2, sv['ffn'] = _ffn_fwd(dt, x1n, w1, b1, w2, b2, x1, p, seeds[2:4], tr)
+            x2, sv['ffn'] = _ffn_fwd(dt, x1n, w1, b1, w2, b2, x1, p, seeds[2:4], tr, act=act)
             sv.update(x=x, x1=x1, m1=m1, r1=r1, m2=m2, r2=r2)
         else:
             xp = ops.add(dt, x, pos)
             t, sv['mha'] = _mha_fwd(dt, xp, xp, x, True, w_in, b_in, w_o, b_o, x, B, H, S, S, kpm, amask, p, seeds[0:2], tr)
             x1, _, m1, r1 = ops.layernorm_fwd(dt, t, g1, be1)
-            t2, sv['ffn'] = _ffn_fwd(dt, x1, w1, b1, w2, b2, x1, p, seeds[2:4], tr)
+            t2, sv['ffn'] = _ffn_fwd(dt, x1, w1, b1, w2, b2, x1, p, seeds[2:4], tr, act=act)
             x2, _, m2, r2 = ops.layernorm_fwd(dt, t2, g2, be2)
             sv.update(t=t, t2=t2, m1=m1, r1=r1, m2=m2, r2=r2)
         ctx.sv, ctx.cfg, ctx.P = sv, cfg, P
@@ -617,7 +628,7 @@ class DecoderLayerFn(Function):
             t1n, t1np, m2, r2 = ops.layernorm_fwd(dt, t1, g2, be2, add_t=qpos)
             t2, sv['ca'] = _mha_fwd(dt, t1np, mem_pos, mem, False, cw_in, cb_in, cw_o, cb_o, t1, B, H, Q, S, kpm, None, p, seeds[2:4], tr)
             t2n, _, m3, r3 = ops.layernorm_fwd(dt, t2, g3, be3)
-            t3, sv['ffn'] = _ffn_fwd(dt, t2n, w1, b1, w2, b2, t2, p, seeds[4:6], tr, out=cfg.get('out'))
+            t3, sv['ffn'] = _ffn_fwd(dt, t2n, w1, b1, w2, b2, t2, p, seeds[4:6], tr, out=cfg.get('out'), act=cfg.get('act', 'relu'))
             sv.update(tgt=tgt, t1=t1, t2=t2, m1=m1, r1=r1, m2=m2, r2=r2, m3=m3, r3=r3)
         else:
             tp = ops.add(dt, tgt, qpos)
@@ -626,7 +637,7 @@ class DecoderLayerFn(Function):
             t1p = ops.add(dt, t1, qpos)
             c, sv['ca'] = _mha_fwd(dt, t1p, mem_pos, mem, False, cw_in, cb_in, cw_o, cb_o, t1, B, H, Q, S, kpm, None, p, seeds[2:4], tr)
             t2, _, m2, r2 = ops.layernorm_fwd(dt, c, g2, be2)
-            f, sv['ffn'] = _ffn_fwd(dt, t2, w1, b1, w2, b2, t2, p, seeds[4:6], tr)
+            f, sv['ffn'] = _ffn_fwd(dt, t2, w1, b1, w2, b2, t2, p, seeds[4:6], tr, act=cfg.get('act', 'relu'))
             t3, _, m3, r3 = ops.layernorm_fwd(dt, f, g3, be3)
             sv.update(a=a, c=c, f=f, m1=m1, r1=r1, m2=m2, r2=r2, m3=m3, r3=r3)
         if tr and cfg.get('chain') is not None and cfg.get('layer_idx', 0) == 0:

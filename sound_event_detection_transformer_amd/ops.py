@@ -826,6 +826,22 @@ def relu_mask(dtype, g, y):
     return out
 
 
+def gelu_fwd(dtype, h, p=0.0, seed=0, seed_ptr=None):
+    """a = dropout(gelu(h)) in one launch (reference transformer.py:423-431 'gelu' + the FFN dropout); h: the linear1 output"""
+    h = h.contiguous()
+    a = torch.empty_like(h)
+    L.check(L.load().sedt_gelu_fwd(_p(h), _p(a), h.numel(), p, seed & 0xffffffff, _p(seed_ptr), dtype, L.stream_ptr()), 'gelu_fwd')
+    return a
+
+
+def gelu_bwd(dtype, g, h, p=0.0, seed=0, seed_ptr=None):
+    """gradient wrt the pre-activation h of a = dropout(gelu(h)), given the gradient wrt a"""
+    g, h = g.contiguous(), h.contiguous()
+    out = torch.empty_like(g)
+    L.check(L.load().sedt_gelu_bwd(_p(g), _p(h), _p(out), g.numel(), p, seed & 0xffffffff, _p(seed_ptr), dtype, L.stream_ptr()), 'gelu_bwd')
+    return out
+
+
 def sigmoid_grad(g, s):
     g, s = g.contiguous(), s.contiguous()
     out = torch.empty_like(g)

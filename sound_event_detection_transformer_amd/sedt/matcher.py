@@ -76,12 +76,49 @@ class HungarianMatcher(nn.Module):
         return coef
 
     @torch.no_grad()
-    def forward(self, outputs, targets, fine_tune=False, normalize=False, fl=False):
-        """reference-compatible single-layer interface: (indices, coefficients).  The fine_tune / fl variants live in
-        SetCriterion.prepare / prepare_device (they need the loss-side bookkeeping); this entry covers the plain matching."""
-        if fine_tune or fl:
-            raise NotImplementedError('call SetCriterion(outputs, targets, ..., fine_tune=, fl=): the variants are implemented there')
-        idx = self.match_layers(outputs["pred_logits"][None], outputs["pred_boxes"][None], targets)[0]
+    def forward(self, outputs, targets, fine_tune=False, normalize=False, fl=False, ft_rand=None):
+        """reference matcher.py:42-133, single layer: (indices, coefficients) with every switch of the reference.
+        fl: focal matching cost on sigmoid probabilities (:73-78).  fine_tune (:97-121): a Hungarian pair survives only when its
+        query's nearest target (localisation cost only) is closer than ``epsilon``; every other query that close to a target joins
+        it with probability alpha * num_gt / num_queries (one uniform per candidate, in query order).  normalize / 'ratio' (:123-132):
+        the per-pair loss coefficients.  ft_rand: optional list (one row per clip) of the uniforms to consume instead of torch.rand
+        (tests inject the draws the reference made).  SetCriterion.prepare / prepare_device run the same rules for all decoder
+        layers at once; this entry is what a caller of ``build_matcher(args)(outputs, targets, ...)`` gets."""
+        from .sedt import ALPHA_FL, GAMMA_FL
+        logits, boxes = outputs["pred_logits"], outputs["pred_boxes"]
+        B, Q = logits.shape[:2]
+        sizes = [len(v["boxes"]) for v in targets]
+        e = torch.empty(0, dtype=torch.int64)
+        if sum(sizes) == 0:
+            idx = [(e, e) for _ in range(B)]
+            return idx, self.coefficients(idx, targets, normalize)
+        dev = logits.device
+        tgt_ids = torch.cat([v["labels"][:len(v["boxes"])] for v in targets]).to(dev)
+        tgt_bbox = torch.cat([v["boxes"].reshape(-1, 2) for v in targets]).to(dev).float()
+        cost, loc = self.cost_matrices(logits[None], boxes[None], tgt_ids, tgt_bbox, fl=fl, with_loc=fine_tune,
+                                       alpha_fl=ALPHA_FL, gamma_fl=GAMMA_FL)
+        cost = cost[0].cpu()
+        loc = loc[0].cpu() if fine_tune else None
+        idx, off = [], 0
+        for b, n in enumerate(sizes):
+            i, j = linear_sum_assignment(cost[b, :, off:off + n])
+            i, j = torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)
+            if fine_tune:
+                if n == 0:
+                    raise ValueError('fine_tune needs at least one event in every clip (matcher.py:103 takes a min over them)')
+                near_c, near_t = loc[b, :, off:off + n].min(-1)
+                close = near_c < self.epsilon
+                num_gt = len(j)
+                keep = close[i]
+                i, j = i[keep], j[keep]
+                cand = close.clone()
+                cand[i] = False
+                cq = torch.where(cand)[0]
+                u = torch.as_tensor(ft_rand[b], dtype=torch.float32)[:len(cq)] if ft_rand is not None else torch.rand(len(cq))
+                add = cq[~(u > (self.alpha * num_gt / Q))]
+                i, j = torch.cat([i, add]), torch.cat([j, near_t[add]])
+            idx.append((i, j))
+            off += n
         return idx, self.coefficients(idx, targets, normalize)
 
 

@@ -23,11 +23,21 @@ def _u8(mask):
     return None if mask is None else mask.contiguous().view(torch.uint8)
 
 
+def _activation_name(activation):
+    """reference transformer.py:423-431 accepts "relu" / "gelu" / "glu".  relu: fused into linear1's epilogue (and the slab encoder);
+    gelu: sedt_gelu_fwd / sedt_gelu_bwd around the per-op FFN GEMMs; glu halves the hidden width, so the reference's own linear2
+    (dim_feedforward -> d_model) rejects its output - refused at construction here instead of at the first forward"""
+    if activation in ("relu", "gelu"):
+        return activation
+    if activation == "glu":
+        raise ValueError('activation "glu" halves the FFN width: linear2 of the reference layer (transformer.py:160) fails on it too')
+    raise RuntimeError(F"activation should be relu/gelu, not {activation}.")
+
+
 class TransformerEncoderLayer(nn.Module):
     def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False):
         super().__init__()
-        if activation != "relu":
-            raise ValueError('only relu is on the HIP path (the reference never passes another activation)')
+        self.activation = _activation_name(activation)
         self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.dropout = nn.Dropout(dropout)
@@ -48,7 +58,7 @@ class TransformerEncoderLayer(nn.Module):
     def forward_tokens(self, x, pos, kpm, B, S, src_mask=None, chain=None):
         """chain (ops.BackwardChain or None): links this layer's backward to the one that runs after it (weight prefetch hints)"""
         cfg = dict(dt=runtime.compute_dtype(), B=B, S=S, H=self.nhead, dropout=self.p, training=self.training,
-                   pre_norm=self.normalize_before, chain=chain)
+                   pre_norm=self.normalize_before, chain=chain, act=self.activation)
         return Fn.EncoderLayerFn.apply(x, pos, kpm, src_mask, cfg, *self.params())
 
     def forward(self, src, src_mask: Optional[Tensor] = None, src_key_padding_mask: Optional[Tensor] = None,
@@ -64,8 +74,7 @@ class TransformerEncoderLayer(nn.Module):
 class TransformerDecoderLayer(nn.Module):
     def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", normalize_before=False):
         super().__init__()
-        if activation != "relu":
-            raise ValueError('only relu is on the HIP path (the reference never passes another activation)')
+        self.activation = _activation_name(activation)
         self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
         self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
@@ -94,7 +103,7 @@ class TransformerDecoderLayer(nn.Module):
         acc: (GradAccumulator for mem, GradAccumulator for qpos) shared by the layers of one decoder pass, or None"""
         cfg = dict(kv_fused=kv_fused, dt=runtime.compute_dtype(), B=B, S=S, Q=Q, H=self.nhead, dropout=self.p, training=self.training,
                    pre_norm=self.normalize_before, out=out, acc_mem=None if acc is None else acc[0],
-                   acc_qpos=None if acc is None else acc[1], share=share, layer_idx=layer_idx, chain=chain)
+                   acc_qpos=None if acc is None else acc[1], share=share, layer_idx=layer_idx, chain=chain, act=self.activation)
         return Fn.DecoderLayerFn.apply(tgt, mem, mem_pos, qpos, kpm, tgt_mask, cfg, *self.params())
 
 

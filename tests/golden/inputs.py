@@ -127,3 +127,16 @@ def pool_batch():
         t['boxes'] = torch.zeros(0, 2)
     return x, targets
 
+
+def g17_inputs():
+    """inputs of fixture G17 (also imported by the tests): src, pos, query, key-padding mask, and the two weight tensors of the linear
+    loss  sum(hs * w_hs) + sum(mem * w_mem)"""
+    g = torch.Generator().manual_seed(171)
+    src = torch.randn(2, 256, 32, 4, generator=g)
+    pos = torch.randn(2, 256, 32, 4, generator=g) * 0.5
+    query = torch.randn(11, 256, generator=g)
+    mask = torch.zeros(2, 32, 4, dtype=torch.bool)
+    mask[1, 27:, :] = True
+    w_hs = torch.randn(3, 2, 11, 256, generator=g)
+    w_mem = torch.randn(2, 128, 256, generator=g) * 0.1
+    return src, pos, query, mask, w_hs, w_mem

@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 from oracle import sedt_oracle as O              # noqa: E402
 from oracle.criterion_oracle import synthetic_targets  # noqa: E402
 sys.path.insert(0, HERE)
-from inputs import g9_inputs as _g9_inputs, g10_inputs as _g10_inputs, g11_inputs as _g11_inputs, SEMI, semi_batch as _semi_batch, SEMI_MIX, SUP_MIX, semi_mix_batch as _semi_mix_batch, sup_mix_batch as _sup_mix_batch, POOL, pool_batch as _pool_batch  # noqa: E402
+from inputs import g9_inputs as _g9_inputs, g10_inputs as _g10_inputs, g11_inputs as _g11_inputs, SEMI, semi_batch as _semi_batch, SEMI_MIX, SUP_MIX, semi_mix_batch as _semi_mix_batch, sup_mix_batch as _sup_mix_batch, POOL, pool_batch as _pool_batch, g17_inputs  # noqa: E402
 
 
 # ----------------------------------------------------------------------------- shim
@@ -856,6 +856,41 @@ def g16_pooling(out, rsedt):
     print('G16 ok', {m: (float(res[f'{m}_train_loss_loss_weak_p']), float(res[f'{m}_train_total'])) for m in c['modes'] + ('max_nomask',)})
 
 
+def g17_activation_postnorm(out):
+    """G17: the reference transformer (transformer.py loaded by path) with activation='gelu' (transformer.py:423-431), pre- and
+    post-norm, and the post-norm ReLU stack: forward (eval) AND every parameter's gradient under a linear loss in train mode with
+    dropout 0 - pins the backward of forward_post (:177-190, :240-261), which G1 covers in the forward only."""
+    rt = load_ref_transformer_module()
+    cases = {'gelu_pre': dict(act='gelu', pre=True), 'gelu_post': dict(act='gelu', pre=False), 'relu_post': dict(act='relu', pre=False)}
+    res = {}
+    src, pos, query, mask, w_hs, w_mem = g17_inputs()
+    for name, c in cases.items():
+        torch.manual_seed(0)
+        m = rt.Transformer(d_model=256, nhead=8, num_encoder_layers=3, num_decoder_layers=3, dim_feedforward=2048, dropout=0.0,
+                           activation=c['act'], normalize_before=c['pre'], return_intermediate_dec=True, self_sup=False)
+        seeded_load(m, 17)
+        m.eval()
+        with torch.no_grad():
+            hs, mem = m(src, mask, query, pos)
+        res[f'{name}_hs'], res[f'{name}_mem'] = npy(hs), npy(mem)
+        m.train()
+        m.zero_grad()
+        s_, q_ = src.clone().requires_grad_(True), query.clone().requires_grad_(True)
+        hs, mem = m(s_, mask, q_, pos)
+        loss = (hs * w_hs).sum() + (mem * w_mem).sum()
+        loss.backward()
+        res[f'{name}_loss'] = np.float32(loss.item())
+        names = [n for n, p_ in m.named_parameters()]
+        res[f'{name}_gradnames'] = np.array(names)
+        res[f'{name}_gradnorm'] = np.array([p_.grad.norm().item() if p_.grad is not None else 0.0 for _, p_ in m.named_parameters()], np.float32)
+        for n, p_ in m.named_parameters():
+            if p_.grad is not None:
+                res[f'{name}_grad_{n}'] = digest(p_.grad, 32)
+        res[f'{name}_dsrc'], res[f'{name}_dquery'] = digest(s_.grad, 256), npy(q_.grad)
+    np.savez_compressed(os.path.join(out, 'g17_activation_postnorm.npz'), **res)
+    print('G17 ok', len(res))
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='', help='comma list of fixtures to (re)generate, e.g. g9,g12 (default: all)')
@@ -867,6 +902,8 @@ if __name__ == '__main__':
     out = cli.out
     if on('g1'):
         g1_transformer(out)
+    if on('g17'):
+        g17_activation_postnorm(out)
     rsedt, ru = import_reference()
     if on('g6'):
         g6_posenc(out, rsedt)

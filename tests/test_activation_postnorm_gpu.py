@@ -1,0 +1,176 @@
+"""GPU: the post-norm layer stacks (reference sedt/transformer.py:177-190, :240-261, `--pre_norm` off) in the BACKWARD, and the
+activation switch (transformer.py:423-431: "gelu") - HIP transformer against fixture G17, which holds the REFERENCE's forward and every
+parameter gradient under a linear loss for {gelu pre-norm, gelu post-norm, relu post-norm}; plus the two GELU kernels against torch.
+
+f32 mode: outputs 1e-3 (north_star), gradient norms 2e-3, every gradient tensor element-wise against the oracle's autograd (the oracle is
+pinned to G17 by tests/test_oracle_golden.py).  bf16 mode: stated looser bounds."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, x3_skips_gradient_elements
+
+sys.path.insert(0, GOLDEN)
+import inputs as GI                                                   # noqa: E402
+from oracle import sedt_oracle as O                                   # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+CASES = [('gelu_pre', 'gelu', True), ('gelu_post', 'gelu', False), ('relu_post', 'relu', False)]
+
+
+def rel(got, ref):
+    got = torch.as_tensor(got).float().cpu()
+    ref = torch.as_tensor(ref).float().cpu()
+    return ((got - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
+
+
+def _digest(t, n):
+    t = t.detach().float().flatten().cpu()
+    idx = torch.linspace(0, t.numel() - 1, n).long()
+    return np.concatenate([[t.mean().item(), t.abs().mean().item()], t[idx].numpy()]).astype(np.float32)
+
+
+def _seed_load(model, seed):
+    model.load_state_dict(O.seeded_state_dict(model.state_dict(), seed))
+    return model
+
+
+def _hip_transformer(act, pre, dropout=0.0):
+    from sound_event_detection_transformer_amd import sedt
+    return _seed_load(sedt.Transformer(256, 8, 3, 3, 2048, dropout, act, pre, True, False), 17).cuda()
+
+
+def _run_hip(m, train):
+    src, pos, query, mask, w_hs, w_mem = GI.g17_inputs()
+    s_ = src.cuda().requires_grad_(train)
+    q_ = query.cuda().requires_grad_(train)
+    hs, mem = m(s_, mask.cuda(), q_, pos.cuda())
+    if not train:
+        return hs, mem
+    loss = (hs.float() * w_hs.cuda()).sum() + (mem.float() * w_mem.cuda()).sum()
+    loss.backward()
+    return loss, s_.grad, q_.grad
+
+
+@pytest.mark.parametrize('name,act,pre', CASES)
+def test_g17_forward_and_backward_f32(golden_dir, name, act, pre):
+    from sound_event_detection_transformer_amd import runtime
+    runtime.set_compute_dtype('f32')
+    g = np.load(os.path.join(golden_dir, 'g17_activation_postnorm.npz'))
+    m = _hip_transformer(act, pre)
+    assert m.encoder.layers[0].activation == act and m.decoder.layers[2].normalize_before == pre
+    m.eval()
+    with torch.no_grad():
+        hs, mem = _run_hip(m, False)
+    assert rel(hs, g[f'{name}_hs']) < 1e-3, rel(hs, g[f'{name}_hs'])
+    assert rel(mem, g[f'{name}_mem']) < 1e-3
+    m.train()
+    loss, dsrc, dquery = _run_hip(m, True)
+    assert abs(loss.item() - float(g[f'{name}_loss'])) <= 1e-3 * abs(float(g[f'{name}_loss']))
+    x3_skips_gradient_elements()
+    names = [n for n, _ in m.named_parameters()]
+    assert names == list(g[f'{name}_gradnames'])
+    norms = np.array([p.grad.norm().item() if p.grad is not None else 0.0 for _, p in m.named_parameters()], np.float32)
+    ref = g[f'{name}_gradnorm']
+    bad = [(n, a, b) for n, a, b in zip(names, norms, ref) if abs(a - b) > 2e-3 * max(abs(b), 1e-6) + 1e-6]
+    assert not bad, bad[:5]
+    for n, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        r = g[f'{name}_grad_{n}']
+        d = _digest(p.grad, 32)
+        assert np.abs(d - r).max() <= 5e-3 * np.abs(r).max() + 1e-6, (n, np.abs(d - r).max(), np.abs(r).max())
+    assert rel(dquery, g[f'{name}_dquery']) < 2e-3
+    r = g[f'{name}_dsrc']
+    assert np.abs(_digest(dsrc, 256) - r).max() <= 5e-3 * np.abs(r).max()
+
+
+@pytest.mark.parametrize('name,act,pre', CASES)
+def test_every_gradient_tensor_matches_the_oracle_f32(name, act, pre):
+    """element-wise, every trainable tensor: the oracle's autograd on the same weights / inputs (cosine and worst element), the check
+    `tests/test_gradient_parity_gpu.py` runs for the pre-norm ReLU models - here for normalize_before=False and for GELU"""
+    from sound_event_detection_transformer_amd import runtime
+    runtime.set_compute_dtype('f32')
+    src, pos, query, mask, w_hs, w_mem = GI.g17_inputs()
+    om = _seed_load(O.Transformer(256, 8, 3, 3, 2048, 0.0, pre, True, False, activation=act), 17).train()
+    s_, q_ = src.clone().requires_grad_(True), query.clone().requires_grad_(True)
+    hs, mem = om(s_, mask, q_, pos)
+    ((hs * w_hs).sum() + (mem * w_mem).sum()).backward()
+    m = _hip_transformer(act, pre).train()
+    _, dsrc, dquery = _run_hip(m, True)
+    x3_skips_gradient_elements()
+    og = dict(om.named_parameters())
+    worst_cos, worst_el = 1.0, 0.0
+    for n, p in m.named_parameters():
+        a, b = p.grad.float().cpu().flatten(), og[n].grad.flatten()
+        cos = torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)
+        el = ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+        worst_cos, worst_el = min(worst_cos, cos.item()), max(worst_el, el)
+        assert cos > 1 - 5e-6 and el < 5e-3, (n, cos.item(), el)
+    assert rel(dsrc, s_.grad) < 5e-3 and rel(dquery, q_.grad) < 5e-3
+    print(f'{name}: worst cosine {worst_cos:.8f}, worst element {worst_el:.2e}')
+
+
+@pytest.mark.parametrize('name,act,pre', CASES)
+def test_g17_bf16(golden_dir, name, act, pre):
+    """throughput mode: outputs against the reference at the bf16 bounds of the other model-level tests; gradient direction per tensor"""
+    from sound_event_detection_transformer_amd import runtime
+    runtime.set_compute_dtype('bf16')
+    try:
+        g = np.load(os.path.join(golden_dir, 'g17_activation_postnorm.npz'))
+        m = _hip_transformer(act, pre).eval()
+        with torch.no_grad():
+            hs, mem = _run_hip(m, False)
+        assert rel(hs, g[f'{name}_hs']) < 3e-2, rel(hs, g[f'{name}_hs'])
+        assert rel(mem, g[f'{name}_mem']) < 3e-2
+        m.train()
+        loss, dsrc, dquery = _run_hip(m, True)
+        assert abs(loss.item() - float(g[f'{name}_loss'])) <= 2e-2 * abs(float(g[f'{name}_loss'])) + 1.0
+        names = [n for n, _ in m.named_parameters()]
+        norms = np.array([p.grad.norm().item() for _, p in m.named_parameters()], np.float32)
+        ref = g[f'{name}_gradnorm']
+        err = np.abs(norms - ref) / np.maximum(ref, 1e-6)
+        assert np.median(err) < 1e-2 and err.max() < 8e-2, (np.median(err), err.max(), names[int(err.argmax())])
+    finally:
+        runtime.set_compute_dtype('f32')
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('p', [0.0, 0.1])
+def test_gelu_kernels_against_torch(dtype, p):
+    """sedt_gelu_fwd / sedt_gelu_bwd: erf-GELU (torch's default) with the epilogue dropout's keep decisions; the backward regenerates
+    the same decisions (kept set identical, rate ~ 1 - p)"""
+    from sound_event_detection_transformer_amd import ops
+    from sound_event_detection_transformer_amd.lib import F32, BF16
+    dt, td = (F32, torch.float32) if dtype == 'f32' else (BF16, torch.bfloat16)
+    g = torch.Generator().manual_seed(5)
+    h = (torch.randn(704, 2048, generator=g) * 2).to(td).cuda()
+    gy = torch.randn(704, 2048, generator=g).to(td).cuda()
+    a = ops.gelu_fwd(dt, h, p, 1234)
+    gh = ops.gelu_bwd(dt, gy, h, p, 1234)
+    hf = h.float().requires_grad_(True)
+    ref = torch.nn.functional.gelu(hf)
+    keep = (a != 0) | (ref.detach().abs() < 1e-30) if p > 0 else torch.ones_like(a, dtype=torch.bool)
+    if p > 0:
+        rate = (a != 0).float().mean().item()
+        assert abs(rate - (1 - p)) < 5e-3, rate
+    scale = 1.0 / (1.0 - p)
+    tol = 1e-5 if dtype == 'f32' else 1e-2
+    assert ((a.float() - ref.detach() * keep * scale).abs().max() / ref.detach().abs().max()).item() < tol
+    (ref * keep * scale * gy.float()).sum().backward()
+    assert ((gh.float() - hf.grad).abs().max() / hf.grad.abs().max()).item() < tol
+    if p > 0:          # a different seed draws a different mask
+        a2 = ops.gelu_fwd(dt, h, p, 99)
+        assert ((a2 != 0) != (a != 0)).float().mean().item() > 0.05
+
+
+def test_unknown_activation_is_refused_like_the_reference():
+    from sound_event_detection_transformer_amd import sedt
+    with pytest.raises(RuntimeError):
+        sedt.Transformer(256, 8, 1, 1, 512, 0.1, 'swish')
+    with pytest.raises(ValueError):
+        sedt.Transformer(256, 8, 1, 1, 512, 0.1, 'glu')

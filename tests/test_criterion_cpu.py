@@ -175,3 +175,45 @@ def test_pooling_argument_validation():
         build_model(default_args(pooling='median'))
     m = build_model(default_args(pooling='attn'))[0]
     assert 'attn_dense_softmax.weight' in m.state_dict() and m.attn_dense_softmax.weight.shape == (10, 256)
+
+
+@pytest.mark.parametrize('name', list(G9_CASES))
+def test_g9_matcher_forward_takes_the_reference_switches(golden_dir, name):
+    """reference sedt/matcher.py:42-133: ``build_matcher(args)(outputs, targets, fine_tune, normalize, fl)`` returns the final layer's
+    (indices, coefficients); the indices are the ones fixture G9 holds (the reference's criterion returns exactly those)"""
+    from collections import Counter
+    g = np.load(os.path.join(golden_dir, 'g9_criterion_variants.npz'))
+    ft, norm, fl, eps = G9_CASES[name]
+    m = _crit().matcher
+    m.epsilon = eps
+    outputs, targets, B, Q = GI.g9_inputs()
+    o = {k: v for k, v in outputs.items() if k != 'aux_outputs'}
+    idx, coef = m(o, targets, ft, norm, fl, ft_rand=_rows(g[f'{name}_rand']) if ft else None)
+    assert len(idx) == len(coef) == B
+    for b, (i, j) in enumerate(idx):
+        np.testing.assert_array_equal(i.numpy(), _rows(g[f'{name}_src'])[b])
+        np.testing.assert_array_equal(j.numpy(), _rows(g[f'{name}_tgt'])[b])
+        assert i.dtype == j.dtype == torch.int64
+        if norm:
+            cnt = Counter(j.tolist())
+            np.testing.assert_allclose(coef[b].numpy(), [1.0 / cnt[t] for t in j.tolist()])
+        else:
+            np.testing.assert_array_equal(coef[b].numpy(), np.ones(len(j), np.float32))
+
+
+def test_matcher_forward_plain_and_ratio(golden_dir):
+    """the switch-less call against fixture G5's indices, and 'ratio' targets handed back as the coefficients (matcher.py:130)"""
+    g5 = np.load(os.path.join(golden_dir, 'g5_criterion.npz'))
+    outputs, targets, _ = _fixed()
+    m = _crit().matcher
+    idx, coef = m({k: v for k, v in outputs.items() if k != 'aux_outputs'}, targets)
+    np.testing.assert_array_equal(np.concatenate([i.numpy() for i, _ in idx]), g5['match_src'])
+    np.testing.assert_array_equal(np.concatenate([j.numpy() for _, j in idx]), g5['match_tgt'])
+    t2 = [dict(t) for t in targets]
+    t2[0]['ratio'] = torch.full((len(t2[0]['labels']),), 0.25)
+    _, coef = m({k: v for k, v in outputs.items() if k != 'aux_outputs'}, t2)
+    np.testing.assert_array_equal(coef[0].numpy(), t2[0]['ratio'].numpy())
+    # no target anywhere: empty pairs (the reference's cat over an empty list fails; a loader never produces it)
+    t3 = [{'labels': torch.zeros(0, dtype=torch.int64), 'boxes': torch.zeros(0, 2)} for _ in targets]
+    idx, _ = m({k: v for k, v in outputs.items() if k != 'aux_outputs'}, t3)
+    assert all(len(i) == 0 for i, _ in idx)

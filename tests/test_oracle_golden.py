@@ -219,3 +219,37 @@ def test_g16_pooling(golden_dir, mode):
         if key.startswith(f'{mode}_train_grad::'):
             ref = g[key]
             np.testing.assert_allclose(_digest(params[key.split('::')[1]].grad, 32), ref, rtol=2e-3, atol=2e-4 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize('name,act,pre', [('gelu_pre', 'gelu', True), ('gelu_post', 'gelu', False), ('relu_post', 'relu', False)])
+def test_g17_activation_and_postnorm_backward(golden_dir, name, act, pre):
+    """fixture G17 (reference transformer.py with activation='gelu', :423-431, and the post-norm stacks :177-190 / :240-261): the oracle's
+    forward AND every parameter gradient under a linear loss - what pins the oracle for the HIP path's post-norm / GELU backward tests"""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import inputs as GI
+    g = np.load(os.path.join(golden_dir, 'g17_activation_postnorm.npz'))
+    src, pos, query, mask, w_hs, w_mem = GI.g17_inputs()
+    m = _load(O.Transformer(256, 8, 3, 3, 2048, 0.0, pre, True, False, activation=act), 17)
+    m.eval()
+    with torch.no_grad():
+        hs, mem = m(src, mask, query, pos)
+    np.testing.assert_allclose(hs.numpy(), g[f'{name}_hs'], **TOL)
+    np.testing.assert_allclose(mem.numpy(), g[f'{name}_mem'], **TOL)
+    m.train()
+    s_, q_ = src.clone().requires_grad_(True), query.clone().requires_grad_(True)
+    hs, mem = m(s_, mask, q_, pos)
+    loss = (hs * w_hs).sum() + (mem * w_mem).sum()
+    loss.backward()
+    assert abs(loss.item() - float(g[f'{name}_loss'])) <= 1e-4 * abs(float(g[f'{name}_loss']))
+    names = [n for n, _ in m.named_parameters()]
+    assert names == list(g[f'{name}_gradnames'])
+    norms = np.array([p.grad.norm().item() if p.grad is not None else 0.0 for _, p in m.named_parameters()], np.float32)
+    np.testing.assert_allclose(norms, g[f'{name}_gradnorm'], rtol=2e-4, atol=1e-6)
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            ref = g[f'{name}_grad_{n}']
+            np.testing.assert_allclose(_digest(p.grad, 32), ref, rtol=2e-3, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+    np.testing.assert_allclose(q_.grad.numpy(), g[f'{name}_dquery'], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(_digest(s_.grad, 256), g[f'{name}_dsrc'], rtol=2e-3, atol=2e-5)

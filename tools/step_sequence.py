@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The ordered kernel sequence of ONE steady-state step from a rocprofv3 kernel trace of bench.py: index, start offset, duration,
 gap to the previous kernel's end, name.  Steps are split at the stem forward kernel.
-usage: step_sequence.py <dir with *_kernel_trace.csv> [out.txt]"""
+usage: step_sequence.py <dir with *_kernel_trace.csv> [out.txt] [stem launches per step, default 1: C4 (clips + patches) and C5 (teacher +
+student) run the stem twice per step]"""
 import csv
 import glob
 import re
@@ -12,7 +13,8 @@ f = glob.glob(d + '/**/*_kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
 idx = [i for i, e in enumerate(ev) if 'stem_pool_fwd' in e[2] or 'stem_im2col' in e[2]]
-a, b = idx[-4], idx[-3]
+per = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+a, b = idx[-4 * per], idx[-3 * per]
 seg = ev[a:b]
 
 
