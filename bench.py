@@ -19,6 +19,7 @@ for the north-star kernels, timed live with HIP events), `cpu_baseline` (the CPU
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -72,6 +73,7 @@ def parse():
     ap.add_argument('--force-graph-fallback', action='store_true',
                     help='readiness test: pretend the captured data-parallel stepper cannot be built (every rank then has to agree on the '
                          'eager fallback out of band)')
+    ap.add_argument('--no-clocks', action='store_true', help='skip the rocm-smi clock reading under load')
     ap.add_argument('--no-families', action='store_true',
                     help='skip roofline.families (the in-process kernel trace of three extra steps; use under rocprofv3, which owns the tracer)')
     ap.add_argument('--loader', action='store_true',
@@ -176,6 +178,36 @@ def cpu_baseline(budget_s=25.0):
             "sample": f"CPU oracle, URBAN-SED SEDT E=3 Q=10 dec_at, f32, dropout on, torch.set_num_threads({cores}): "
                       f"1 warm-up + {n64} full train steps at B=64 (value), 1+{n1} at B=4 (BASELINE config C1), "
                       f"1+{nfb} fwd+bwd-only at B=64"}
+
+
+def clocks_under_load(step, seconds=1.5):
+    """{'sclk_mhz': ..., 'mclk_mhz': ...} read by `rocm-smi --showclocks` in a child process while this process keeps replaying the step
+    (an idle GPU drops its clocks within milliseconds, so the reading has to be taken with the step running); None when the tool is
+    missing or prints nothing parseable.  A diagnostic for 'why does this box read 3 % slower': never allowed to cost the result line"""
+    import re
+    import shutil
+    import torch
+    tool = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+    if not os.path.exists(tool):
+        return None
+    try:
+        child = subprocess.Popen([tool, '--showclocks'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        t0 = time.perf_counter()
+        while child.poll() is None and time.perf_counter() - t0 < 20.0:
+            step()
+        torch.cuda.synchronize()
+        if child.poll() is None:
+            child.kill()
+            return None
+        out = child.stdout.read()
+        res = {}
+        for key in ('sclk', 'mclk', 'fclk'):
+            m = re.search(key + r' clock level[^(]*\((\d+)\s*Mhz\)', out, re.I)
+            if m:
+                res[key + '_mhz'] = int(m.group(1))
+        return res or {"raw": out.strip()[:300]}
+    except Exception as e:                           # noqa: BLE001
+        return {"error": repr(e)[:120]}
 
 
 def agree_out_of_band(ok, rank, world, tag, timeout_s=180.0):
@@ -565,20 +597,24 @@ def family_report(step, rec, dtype, n_params, step_ms):
         a, dt_, _, _, hint = ent
         flop, nb = gemm_algorithmic(ent, es)
         alg_gemm_bytes += nb
-        label = None
+        label, share = None, 1.0
         if hint == 'conv3x3_c64_kernel':
             label = match('conv3x3_c64_kernel')
-        elif hint == 'igemm_group':
-            label = match('igemm3_group_kernel<2>') or match('igemm3_group_kernel<3>') or match('igemm3_group_kernel')
+        elif isinstance(hint, tuple) and hint[0] == 'group':
+            # the measured step runs this problem inside a grouped launch (sedt_igemm_group_describe gave its kernel instance at record
+            # time), possibly in a form that executes a share of the recorded problem's flops: layer4's dilated 3x3 as two column
+            # halves walks 6 of 9 taps, a stride-2 input gradient by output parity a quarter of the transposed walk
+            label, share = (match(hint[1]) if hint[1] else None), hint[2]
         if label is None:
             if lib.sedt_igemm_describe(ctypes.byref(a), dt_, 1 if hint == 'wgrad_group' else 0, buf, 128) == 0:
                 label = match(buf.value.decode())
         if label is None:
             unmatched += 1
             continue
-        w = work.setdefault(label, [0.0, 0.0])
-        w[0] += flop
+        w = work.setdefault(label, [0.0, 0.0, 0.0])
+        w[0] += flop * share             # flops the launch executes
         w[1] += nb
+        w[2] += flop                     # flops of the convolution / linear it implements (SURVEY 8d counts these)
     # the fused Bottleneck launches of the recorded step (ops.PROFILE_FUSED: kernel-name prefix, flop, bytes)
     from sound_event_detection_transformer_amd import ops as ops_
     for name, flop, nb in ops_.PROFILE_FUSED:
@@ -587,28 +623,35 @@ def family_report(step, rec, dtype, n_params, step_ms):
         if label is None:
             unmatched += 1
             continue
-        w = work.setdefault(label, [0.0, 0.0])
+        w = work.setdefault(label, [0.0, 0.0, 0.0])
         w[0] += flop
         w[1] += nb
+        w[2] += flop
     # the streaming kernels whose byte counts follow from the parameter count alone
     for k in times:
         if k.startswith('multi_adamw_kernel'):
-            work[k] = [0.0, 28.0 * n_params]
+            work[k] = [0.0, 28.0 * n_params, 0.0]
         elif k.startswith('multi_sumsq_kernel'):
-            work[k] = [0.0, 4.0 * n_params]
+            work[k] = [0.0, 4.0 * n_params, 0.0]
     fams = []
     for k, (us, n) in sorted(times.items(), key=lambda kv: -kv[1][0]):
         row = {"kernel": k, "launches": round(n, 1), "us": round(us, 1), "share": round(us / (step_ms * 1e3), 4)}
         if k in work:
-            flop, nb = work[k]
+            flop, nb, flop_alg = work[k]
             t = us * 1e-6
             t_m, t_h = flop / peak, nb / HBM_PEAK
             row.update(flop=flop, bytes=nb)
+            if abs(flop_alg - flop) > 1e-6 * max(flop_alg, 1.0):
+                row.update(flop_algorithmic=flop_alg)        # (the row's achieved / frac are over the flops it EXECUTES)
             if t_m >= t_h:
                 row.update(bound="mfma", achieved=round(flop / t / 1e12, 1), unit="TFLOP/s", peak=peak / 1e12, frac=round(t_m / t, 4))
             else:
                 row.update(bound="hbm", achieved=round(nb / t / 1e9, 1), unit="GB/s", peak=HBM_PEAK / 1e9, frac=round(t_h / t, 4))
         fams.append(row)
+    # a GEMM kernel row with time but no flop record means the join above lost its problems: counted as unmatched, listed by name
+    no_flops = [r["kernel"] for r in fams if "flop" not in r and rec is not None and
+                any(r["kernel"].startswith(pfx) for pfx in ('igemm', 'wgrad3', 'wgrad4', 'conv3x3', 'bneck'))]
+    unmatched += len(no_flops)
     small = [r for r in fams if r["share"] < 0.004 and "flop" not in r]
     keep = [r for r in fams if not (r["share"] < 0.004 and "flop" not in r)]
     if small:
@@ -618,8 +661,29 @@ def family_report(step, rec, dtype, n_params, step_ms):
     # algorithmic bytes of one step AS IT IS LAUNCHED (no cross-launch fusion assumed): every GEMM operand once (above), the optimizer's
     # 28 B per trainable parameter + 4 B for the norm, the two packed bf16 weight layouts (4 B read + 2 x 2 B written per parameter)
     alg = alg_gemm_bytes + (28.0 + 4.0 + 8.0) * n_params
-    return {"families": keep, "kernel_time_us": round(total_us, 1), "unmatched_gemm_records": unmatched,
+    return {"families": keep, "kernel_time_us": round(total_us, 1), "unmatched_gemm_records": unmatched, "gemm_rows_without_flops": no_flops,
             "algorithmic_bytes": round(alg), "algorithmic_bytes_gemm_operands": round(alg_gemm_bytes)}
+
+
+def in_step_rows(prefixes):
+    """what the named kernels do INSIDE the measured step, from the newest committed per-kernel PMC table (profiles/rNN_step_c2.csv:
+    launches per step, summed microseconds, FETCH x2 + WRITE bytes): 'N launches, T us, X MB -> Y GB/s (file)'"""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_step_c2.csv')))
+    if not files:
+        return 'no per-kernel PMC table under profiles/'
+    n = us = kb = 0.0
+    with open(files[-1]) as f:
+        for r in csv.DictReader(f):
+            if any(pfx in r['kernel'] for pfx in prefixes):
+                n += float(r['launches_per_step'])
+                us += float(r['time_us'])
+                kb += float(r['FETCH_KB_x2'] or 0) + float(r['WRITE_KB'] or 0)
+    if not us:
+        return 'not in ' + os.path.basename(files[-1])
+    return '%d launches, %.0f us, %.0f MB moved = %.0f GB/s fabric-side (%s; the launches sit on the ~4.7 us launch floor)' % (
+        n, us, kb * 1.024e-3, kb * 1024 / us / 1e3, os.path.basename(files[-1]))
 
 
 def kernel_report(dtype, dev):
@@ -807,8 +871,23 @@ def kernel_report(dtype, dev):
         t = timeit(lambda: ops.stem_pool_wgrad(xs, gpool, idx, pool, sc1, B, 500, 64))
         hb("stem backward, one launch + reduce (conv0 gradients from the pooled gradient)", xs.numel() * 4.0 + pool.numel() * 5.0, t,
            "the max-pool backward -> weight-gradient GEMM chain it replaced: 122 us")
+    # LayerNorm against the HBM roofline, honestly: the launches of one capture rotate over NBUF distinct input / output pairs
+    # (>= 512 MB in total, twice the 256 MB Infinity Cache), so no launch finds its rows on the die; beside it the back-to-back replay on ONE
+    # 8 MB pair (an L2 / Infinity-Cache figure, labelled so) and what the step's own LayerNorm launches reach (rocprofv3 PMC table)
+    NBUF = max(2, int(math.ceil(512e6 / (2.0 * M * E * es))))
+    xs_ln = [torch.randn(M, E, device=dev).to(td) for _ in range(NBUF)]
+    ys_ln = [(torch.empty_like(xs_ln[0]), torch.empty(M, device=dev), torch.empty(M, device=dev)) for _ in range(NBUF)]
+
+    def ln_rotate():
+        for i in range(NBUF):
+            ops.layernorm_fwd(dt, xs_ln[i], gam, bet, out=ys_ln[i])
+    t = timeit(ln_rotate, reps=1) / NBUF
+    in_step = in_step_rows(('ln_fwd_kernel', 'ln_bwd_kernel'))
+    hb("LayerNorm fwd 8192 x 256 (sedt_layernorm_fwd), %d distinct buffer pairs = %.0f MB per pass: every row comes from HBM" % (NBUF, NBUF * 2.0 * M * E * es / 1e6),
+       2.0 * M * E * es, t, "in the step: " + in_step)
+    del xs_ln, ys_ln
     t = timeit(lambda: ops.layernorm_fwd(dt, x, gam, bet))
-    hb("LayerNorm fwd 8192 x 256 (sedt_layernorm_fwd)", 2.0 * M * E * es, t)
+    hb("LayerNorm fwd 8192 x 256, back-to-back replays on ONE 8 MB buffer pair (an L2 / Infinity-Cache rate, not an HBM figure)", 2.0 * M * E * es, t)
     if dt == L.BF16:
         # ---- round 5: zero-tap elimination (the same problem with the plain nine-tap gather beside it) and the parity-grade bf16x3 pieces
         def ab(flag, fn):
@@ -911,6 +990,27 @@ def other_configs(args, dev, keep_alive, replays=20, settle=30):
             res[name] = {"ms_per_step": round(wall * 1e3, 3), "ms_per_step_hip_events": round(ms, 3), "clips_per_step": clips,
                          "clips_s": round(clips / wall, 1), "dtype": a.dtype, "frac": round(flop / wall / MFMA_PEAK[a.dtype], 4),
                          "peak_tflops": MFMA_PEAK[a.dtype] / 1e12, "replays": replays, "settle_replays": settle, "workload": what}
+            if name == 'c2_bf16x3':
+                # the parity-grade mode against ITS OWN ceiling: every product is three bf16 MFMAs (hi.hi + lo.hi + hi.lo), so a third of the
+                # dense bf16 peak bounds it; and where its step goes, per kernel instance (in-process trace of three further replays)
+                ceil_ = MFMA_PEAK['bf16'] / 3.0
+                roof = {"bound": "mfma", "achieved": round(flop / (ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s (f32-grade products)",
+                        "peak": round(ceil_ / 1e12, 1), "frac_of_mode_ceiling": round(flop / (ms * 1e-3) / ceil_, 4),
+                        "frac_of_bf16_peak": round(flop / (ms * 1e-3) / MFMA_PEAK['bf16'], 4),
+                        "note": "peak = dense bf16 peak / 3; outputs and losses within 1e-3 of the oracle, gradients within 2e-2 (DESIGN.md section 2)"}
+                try:
+                    kt = kernel_times(step)
+                    rows = sorted(kt.items(), key=lambda kv: -kv[1][0])
+                    tot = sum(v[0] for v in kt.values())
+                    gemm_us = sum(v[0] for k_, v in kt.items() if k_.startswith(('igemm', 'wgrad3', 'wgrad4', 'bneck', 'conv3x3', 'enc_')))
+                    roof["families"] = [{"kernel": k_, "launches": round(v[1], 1), "us": round(v[0], 1), "share": round(v[0] / tot, 4)} for k_, v in rows[:14]]
+                    roof["kernel_time_us"] = round(tot, 1)
+                    roof["kernels_per_step"] = round(sum(v[1] for v in kt.values()), 1)
+                    roof["gemm_family"] = {"us": round(gemm_us, 1), "frac_of_mode_ceiling": round(flop / (gemm_us * 1e-6) / ceil_, 4)}
+                    roof["split3_launches"] = round(sum(v[1] for k_, v in kt.items() if k_.startswith('split3')), 1)
+                except Exception as e:           # noqa: BLE001
+                    roof["families_error"] = repr(e)[:200]
+                res[name]["roofline"] = roof
             del step, ex
         except Exception as e:                   # noqa: BLE001
             res[name] = {"error": repr(e)[:200]}
@@ -977,22 +1077,36 @@ def main():
     # un-timed settle replays BEFORE the --warmup / --steps the caller asked for, so that a short timed region (the driver's
     # --steps 20 --warmup 5) reads the same steady state as a long one
     settle = args.settle if graphed else 0
-    for _ in range(settle):
-        step()
+    settle_ev = {}
+    for i in range(settle):
+        if i < 5 or i >= settle - 5:             # the first and last five settle replays are timed one by one (HIP events): does the step
+            a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)      # still drift when the timed region starts?
+            a_.record()
+            step()
+            b_.record()
+            settle_ev[i] = (a_, b_)
+        else:
+            step()
     for _ in range(args.warmup):
         step()
     barrier()
+    settle_ms = {i: round(a_.elapsed_time(b_), 3) for i, (a_, b_) in settle_ev.items()}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
     for _ in range(args.steps):
         step()
+    host_issue = time.perf_counter() - t0               # the host's share: refreshing the tables + queueing the graphs (and collectives) of K steps
     e1.record()
     barrier()
     elapsed = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1) / args.steps           # HIP events on the stream the step's graphs are launched on
     per_rank = [elapsed]
     rccl_world = 1
+    # clocks UNDER LOAD, after the timed region: rocm-smi runs in a child while this process keeps replaying the step
+    clocks = None
+    if rank == 0 and graphed and not args.no_clocks:
+        clocks = clocks_under_load(step)
     if world > 1:
         dist = torch.distributed
         t = torch.tensor([elapsed], device=dev if dist.get_backend() == 'nccl' else 'cpu', dtype=torch.float64)
@@ -1144,7 +1258,13 @@ def main():
                "config": {"workload": what, "name": args.config, "global_batch": world * clips, "parallelism": f"dp{world}"},
                "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "hip_graph": graphed,
                "rccl_world": rccl_world, "ms_per_step_per_rank": [round(v / args.steps * 1e3, 3) for v in per_rank],
-               "exposed_comm": exposed, "settle_replays": settle, "build_stamp": stamp, "kernels_per_step": kps}
+               "exposed_comm": exposed, "settle_replays": settle, "build_stamp": stamp, "kernels_per_step": kps,
+               "settle_replay_ms": {"first": [settle_ms[i] for i in sorted(settle_ms) if i < 5],
+                                    "last": [settle_ms[i] for i in sorted(settle_ms) if i >= 5 or settle <= 5][-5:]},
+               "clocks_under_load": clocks,
+               # time the host spends ISSUING one step (table refresh, graph launches, RCCL enqueues) before it blocks on anything: while
+               # this stays below ms_per_step the GPU never waits for the host; at N > 1 it tells exposed communication from host issue time
+               "host_launch_us_per_step": round(host_issue / args.steps * 1e6, 1)}
         if others is not None:
             out["other_configs"] = others
         if ex.get('graph_fallback'):

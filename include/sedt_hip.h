@@ -150,6 +150,9 @@ int sedt_igemm_splitk(int M, int N, int K, int dtype);
  * through sedt_igemm (grouped = 0) or through sedt_wgrad_group (grouped = 1, trans problems).  Nothing is launched.  bench.py joins
  * these names with the per-kernel times of the measured step to price every kernel family against its roofline. */
 int sedt_igemm_describe(const SedtIgemm* args, int dtype, int grouped, char* out, int cap);
+/* the same for sedt_igemm_group: the ONE kernel instance the njobs problems run on as a group ("igemm3_group_kernel<2>",
+ * "igemm3_w8_group_kernel<128, 128, 3>"), or "" when the dispatcher would launch them one by one */
+int sedt_igemm_group_describe(const SedtIgemm* jobs, int njobs, int dtype, char* out, int cap);
 
 /* out[r][c...] = rowscale[r] * sum_z slab[z][r][tap][c], written in (R, Ci, taps) order
  * (the torch (Cout, Cin, KH, KW) parameter layout) as f32.  taps == 1: plain [R][Ci]. */

@@ -715,6 +715,20 @@ extern "C" int sedt_igemm_group(const SedtIgemm* jobs, int njobs, int dtype, voi
   return 0;
 }
 
+// the kernel instance sedt_igemm_group would run the problems on ("" when they fall back to one launch each); nothing is launched
+extern "C" int sedt_igemm_group_describe(const SedtIgemm* jobs, int njobs, int dtype, char* out, int cap) {
+  using namespace sedt;
+  SEDT_REQUIRE(jobs && njobs >= 1 && out && cap > 0, "igemm_group_describe: bad arguments");
+  out[0] = 0;
+  if (dtype != SEDT_BF16 || njobs < 2) return 0;
+  describe.on = true;
+  describe.name[0] = 0;
+  const int r = igemm3_group_try(jobs, njobs, nullptr);
+  describe.on = false;
+  if (r == 0) snprintf(out, cap, "%s", describe.name);
+  return r > 0 ? r : 0;
+}
+
 extern "C" int sedt_wgrad_group(const SedtIgemm* jobs, int njobs, int dtype, void* stream) {
   SEDT_REQUIRE(jobs && njobs >= 1, "wgrad_group: bad arguments");
   if (dtype == SEDT_BF16) {

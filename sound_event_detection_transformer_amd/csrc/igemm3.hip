@@ -772,6 +772,8 @@ int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
     blk += big ? ((p.N + 127) / 128) * ((p.M + 127) / 128) : ((p.N + 63) / 64) * ((p.M + 63) / 64);
   }
   g.blk0[njobs] = blk;
+  if (big) SEDT_DESCRIBE("igemm3_w8_group_kernel<128, 128, 3>");
+  else SEDT_DESCRIBE("igemm3_group_kernel<%d>", S == 3 ? 3 : 2);
   if (big) return launch3_w8_group<128, 128, 3>(g, blk, st);
   if (S == 3) {
     constexpr size_t lds = (size_t)3 * (64 + 64) * ROWB;

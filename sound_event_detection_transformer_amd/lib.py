@@ -119,6 +119,7 @@ SIGNATURES = {
     'sedt_igemm_co': (_i, [C.POINTER(SedtIgemm), C.POINTER(SedtIgemm), _i, _i, _vp, C.POINTER(C.c_int)]),
     'sedt_igemm_splitk': (_i, [_i, _i, _i, _i]),
     'sedt_igemm_describe': (_i, [C.POINTER(SedtIgemm), _i, _i, C.c_char_p, _i]),
+    'sedt_igemm_group_describe': (_i, [C.POINTER(SedtIgemm), _i, _i, C.c_char_p, _i]),
     'sedt_wgrad_reduce': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sedt_wgrad_reduce_bias': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'sedt_split3': (_i, [C.POINTER(SedtSplitJob), _i, _vp]),

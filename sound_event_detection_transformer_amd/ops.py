@@ -45,7 +45,7 @@ def _dev_env(name, default):
 RELU_BITS = _dev_env('SEDT_RELU_BITS', '1') != '0'      # developer A/B switch: 0 = the backward masks with the bf16 activations
 PROFILE = None   # bench.py sets this to a list: every GEMM launch then also records (argument block, dtype, shape, operands, hint)
 PROFILE_FUSED = []     # with PROFILE on: (kernel-name prefix, algorithmic flop, algorithmic bytes) of every fused-Bottleneck launch of the recorded step
-PROFILE_HINT = None   # how the un-profiled step launches the problem being recorded: 'conv3x3_c64_kernel' (direct kernel), 'igemm_group'
+PROFILE_HINT = None   # how the un-profiled step launches the problem being recorded: 'conv3x3_c64_kernel' (direct kernel), ('group', kernel label, share of the recorded problem's flops the grouped form executes)
 
 
 def _dev_check(*ts):
@@ -172,9 +172,11 @@ X3_FAST = _dev_env('SEDT_X3_FAST', '1') != '0'
 
 
 # An activation / gradient is a GEMM operand twice per step (x: its layer's forward and weight gradient; dY: input and weight gradient):
-# its [hi | lo | hi] image is kept from the first use to the second.  Keyed by (pointer, rows, cols, row stride); an entry holds the
-# SOURCE tensor as well, so the caching allocator cannot hand that memory to another tensor while the entry lives (a key can only ever
-# mean one tensor's contents - nothing on this path rewrites a GEMM operand in place).  Emptied when a model forward starts
+# its [hi | lo] image is kept from the first use to the second.  Keyed by (pointer, rows, cols, row stride); an entry holds the
+# SOURCE tensor as well, so the caching allocator cannot hand that memory to another tensor while the entry lives, and the source's
+# autograd version counter at the time the image was made: a torch in-place op on a cached operand bumps the counter and the stale
+# image is dropped at the next lookup.  Writes through this library's own raw pointers do not bump it, so a GEMM that writes a tensor
+# WITHOUT leaving its image (no split_out) pops that tensor's entry (igemm / _igemm_x3_fast).  Emptied when a model forward starts
 # (packing.PlanSet / PackPlan) and by the optimizer step.
 X3_CACHE = {}
 X3_CACHE_ON = _dev_env('SEDT_X3_CACHE', '1') != '0'
@@ -192,7 +194,7 @@ def _split3(jobs):
     for i, (t, off, rows, cols, ld, pattern) in enumerate(jobs):
         key = (t.data_ptr() + 4 * off, rows, cols, ld)
         hit = X3_CACHE.get(key) if (pattern == 0 and X3_CACHE_ON) else None
-        if hit is not None:
+        if hit is not None and hit[2] == t._version:
             outs[i] = hit[1]
             continue
         d = torch.empty((rows, (3 if pattern else 2) * cols), device=t.device, dtype=torch.bfloat16)
@@ -201,7 +203,7 @@ def _split3(jobs):
         if pattern == 0 and X3_CACHE_ON:
             if len(X3_CACHE) >= 1024:           # (op-level callers outside a model forward never reach a clearing point: bound what is held)
                 X3_CACHE.clear()
-            X3_CACHE[key] = (t, d)
+            X3_CACHE[key] = (t, d, t._version)
     if todo:
         arr = (L.SedtSplitJob * len(todo))()
         for n, (i, key) in enumerate(todo):
@@ -241,6 +243,12 @@ def _x3_fast_ok(M, N, K, A, lda, B, ldb, Cout, ldc, kw):
         return False
     if mask is not None and not kw.get('mask_bits') and (mask.dtype != torch.float32 or mask.data_ptr() % 16 or kw.get('ldm', 0) % 4):
         return False
+    if mask is not None and kw.get('mask_bits') and (mask.data_ptr() % 4 or kw.get('ldm', 0) % 4):     # 1-bit image: ldm in BYTES (igemm3.hip envelope)
+        return False
+    for k_ in ('scale', 'bias'):                      # per-column epilogue operands are read as 16-byte vectors (igemm_lds_try)
+        t_ = kw.get(k_)
+        if t_ is not None and t_.data_ptr() % 16:
+            return False
     rows = _x3_rows(M, conv)
     return rows * 3 * Ci * 2 < (1 << 31) and N * 3 * K * 2 < (1 << 31)
 
@@ -264,7 +272,9 @@ def _igemm_x3_fast(M, N, K, A, lda, B, ldb, Cout, ldc, kw):
     if X3_CACHE_ON and X3_SPLIT_OUT and (kw.get('act', ACT_NONE) == ACT_RELU or kw.get('mask') is not None) and N % 8 == 0:
         img = torch.empty((M, 2 * N), device=Cout.device, dtype=torch.bfloat16)
         a.split_out = img.data_ptr()
-        X3_CACHE[(Cout.data_ptr(), M, N, ldc)] = (Cout, img)
+        X3_CACHE[(Cout.data_ptr(), M, N, ldc)] = (Cout, img, Cout._version)
+    else:
+        X3_CACHE.pop((Cout.data_ptr(), M, N, ldc), None)          # (rewritten without a new image: a cached one would be stale)
     if PROFILE is not None:
         PROFILE.append((a, BF16, (M, N, 3 * K, 0, 0 if conv is None else 1), (A, B, Cout, kw, A3, B3), PROFILE_HINT))
     if L.LAUNCH_LOG is not None:
@@ -278,6 +288,8 @@ def igemm(dtype, M, N, K, A, lda, B, ldb, Cout, ldc, **kw):
     """raw implicit GEMM call (arguments as igemm_args)"""
     if dtype == F32 and L.GEMM_X3 and _x3_fast_ok(M, N, K, A, lda, B, ldb, Cout, ldc, kw):
         return _igemm_x3_fast(M, N, K, A, lda, B, ldb, Cout, ldc, kw)
+    if dtype == F32 and L.GEMM_X3 and Cout is not None and X3_CACHE:
+        X3_CACHE.pop((Cout.data_ptr(), M, N, ldc), None)          # the generic kernel rewrites Cout and leaves no operand image
     a = igemm_args(M, N, K, A, lda, B, ldb, Cout, ldc, **kw)
     conv, trans = kw.get('conv'), kw.get('trans', 0)
     if _co['on'] and POOL.gemms and not trans and dtype == BF16:
@@ -362,6 +374,16 @@ def skinny_linear_bwd(dtype, g, ysaved, w, x, act=ACT_NONE, mask=None, need_gx=T
     return gx, dw, db
 
 
+def _group_label(jobs):
+    """bench.py's recorded step runs a group's problems one by one; this is the kernel instance the UN-recorded step launches them on as one
+    group (sedt_igemm_group_describe), so that roofline.families books their flops on the row that actually ran"""
+    arr = (L.SedtIgemm * len(jobs))(*jobs)
+    buf = C.create_string_buffer(160)
+    if L.load().sedt_igemm_group_describe(arr, len(jobs), BF16, buf, 160) != 0:
+        return None
+    return buf.value.decode() or None
+
+
 def linear_group(dtype, items):
     """several independent ``linear`` calls (each item: (x, w, kwargs of linear)) as one launch when the kernel allows it
     (sedt_igemm_group) - the q / k / v projections of an attention block, or their three dgrads.  Returns the outputs."""
@@ -378,7 +400,8 @@ def linear_group(dtype, items):
         args.append(((M, N, K, x, x.stride(0), w, w.stride(0), out, out.stride(0)), dict(out_f32=int(out_f32), **kw)))
     if len(args) == 1 or PROFILE is not None or (_co['on'] and POOL.gemms) or (dtype == F32 and L.GEMM_X3 and X3_FAST):
         global PROFILE_HINT
-        PROFILE_HINT = 'igemm_group' if len(args) > 1 else None
+        if len(args) > 1 and PROFILE is not None and dtype == BF16:
+            PROFILE_HINT = ('group', _group_label([igemm_args(*a, **kw) for a, kw in args]), 1.0)
         for a, kw in args:
             igemm(dtype, *a, **kw)
         PROFILE_HINT = None
@@ -416,6 +439,9 @@ def conv_fwd(dtype, x, B, g, wf, out=None, **ep):
     global PROFILE_HINT
     if PROFILE is not None and _conv3_c64_ok(dtype, x, g, ep, out, True):
         PROFILE_HINT = 'conv3x3_c64_kernel'
+    elif PROFILE is not None and dtype == BF16 and _dil_halves_ok(dtype, x, g, wf, out, ep, False, True):
+        # the un-recorded step runs this conv as two column halves in one grouped launch, 6 of the 9 taps each (2/3 of the flops)
+        PROFILE_HINT = ('group', _conv_dil_halves(x, B, g, wf, out, ep, False, False, describe=True), 2.0 / 3.0)
     igemm(dtype, M, g.Co, g.taps * g.Ci, x, x.stride(0), wf, g.taps * g.Ci, out, out.stride(0), conv=conv, **ep)
     PROFILE_HINT = None
     return out
@@ -430,7 +456,7 @@ def conv_fwd(dtype, x, B, g, wf, out=None, **ep):
 S2_PARITY = _dev_env('SEDT_S2_PARITY', '1') != '0'
 
 
-def _dgrad_s2_ok(dtype, dy, g, wb, out, ep):
+def _dgrad_s2_ok(dtype, dy, g, wb, out, ep, profiling_ok=False):
     """bf16, or the fast bf16x3 form of the f32 mode (split operand images, f32 epilogue)"""
     x3 = dtype == F32 and L.GEMM_X3 and X3_FAST
     if not (dtype == BF16 or x3):
@@ -439,14 +465,15 @@ def _dgrad_s2_ok(dtype, dy, g, wb, out, ep):
                    and (ep.get('res') is None or ep['res'].dtype == torch.float32)
                    and (ep.get('mask') is None or ep.get('mask_bits') or ep['mask'].dtype == torch.float32)):
         return False
-    return (S2_PARITY and PROFILE is None and not _co['on'] and g.KH == 3 and g.KW == 3 and g.sh == 2 and g.sw == 2
+    return (S2_PARITY and (PROFILE is None or profiling_ok) and not _co['on'] and g.KH == 3 and g.KW == 3 and g.sh == 2 and g.sw == 2
             and g.ph == 1 and g.pw == 1 and g.dh == 1 and g.dw == 1 and g.Co % 64 == 0 and g.Ci % 8 == 0 and wb.stride(0) == 9 * g.Co
             and dy.stride(0) % 8 == 0 and out.stride(0) % 8 == 0 and set(ep) <= {'mask', 'ldm', 'mask_bits', 'res', 'ldr', 'alpha'})
 
 
-def _conv_dgrad_s2(dy, B, g, wb, out, ep, x3=False):
+def _conv_dgrad_s2(dy, B, g, wb, out, ep, x3=False, describe=False):
+    """describe: build the four problems and return the label of the kernel their grouped launch runs on (nothing is launched)"""
     Co = g.Co
-    if x3:                                               # operand images: dY [pixels][2 Co] = [hi | lo], the weight [Ci][9][3 Co] = [hi | hi | lo] per tap
+    if x3 and not describe:                                               # operand images: dY [pixels][2 Co] = [hi | lo], the weight [Ci][9][3 Co] = [hi | hi | lo] per tap
         dy, wb = _split3([(dy, 0, B * g.Ho * g.Wo, g.Co, dy.stride(0), 0), (wb, 0, g.Ci * 9, g.Co, g.Co, 1)])
         wb = wb.view(g.Ci, 27 * g.Co)
         Co = 3 * g.Co
@@ -468,6 +495,8 @@ def _conv_dgrad_s2(dy, B, g, wb, out, ep, x3=False):
             for t_, (kh, kw) in enumerate(taps):
                 a.btap[t_] = (kh * 3 + kw) * Co
             jobs.append(a)
+    if describe:
+        return _group_label(jobs)
     arr = (L.SedtIgemm * len(jobs))(*jobs)
     L.check(L.load().sedt_igemm_group(arr, len(jobs), BF16, L.stream_ptr()), 'igemm_group_s2')
     return out
@@ -481,9 +510,9 @@ def _conv_dgrad_s2(dy, B, g, wb, out, ep, x3=False):
 DIL_HALVES = _dev_env('SEDT_DIL_HALVES', '1') != '0'
 
 
-def _dil_halves_ok(dtype, t, g, w, out, ep, transposed):
+def _dil_halves_ok(dtype, t, g, w, out, ep, transposed, profiling_ok=False):
     x3 = dtype == F32 and L.GEMM_X3 and X3_FAST
-    if not (DIL_HALVES and (dtype == BF16 or x3) and PROFILE is None and not _co['on']):
+    if not (DIL_HALVES and (dtype == BF16 or x3) and (PROFILE is None or profiling_ok) and not _co['on']):
         return False
     d = g.dh
     cin, cout = (g.Co, g.Ci) if transposed else (g.Ci, g.Co)          # channels of the gathered tensor / of the output
@@ -501,12 +530,12 @@ def _dil_halves_ok(dtype, t, g, w, out, ep, transposed):
         and (B_rows // 2 // 128) * (cout // 128) >= 96
 
 
-def _conv_dil_halves(t, B, g, w, out, ep, transposed, x3):
+def _conv_dil_halves(t, B, g, w, out, ep, transposed, x3, describe=False):
     """t = x (forward) or dY (input gradient); w = the packed forward / dgrad operand [cout][9][cin]"""
     d = g.dh
     cin, cout = (g.Co, g.Ci) if transposed else (g.Ci, g.Co)
     C = cin
-    if x3:
+    if x3 and not describe:
         t, w = _split3([(t, 0, B * g.Hi * g.Wi, cin, t.stride(0), 0), (w, 0, cout * 9, cin, cin, 1)])
         w = w.view(cout, 27 * cin)
         C = 3 * cin
@@ -523,6 +552,8 @@ def _conv_dil_halves(t, B, g, w, out, ep, transposed, x3):
             for j in range(2):
                 a.btap[kh * 2 + j] = (kh * 3 + kw0 + j) * C
         jobs.append(a)
+    if describe:
+        return _group_label(jobs)
     arr = (L.SedtIgemm * 2)(*jobs)
     L.check(L.load().sedt_igemm_group(arr, 2, BF16, L.stream_ptr()), 'igemm_group_dil')
     return out
@@ -543,6 +574,11 @@ def conv_dgrad(dtype, dy, B, g, wb, out=None, **ep):
     global PROFILE_HINT
     if PROFILE is not None and _conv3_c64_ok(dtype, dy, g, ep, out, True) and 'scale' not in ep and 'bias' not in ep:
         PROFILE_HINT = 'conv3x3_c64_kernel'
+    elif PROFILE is not None and dtype == BF16 and _dgrad_s2_ok(dtype, dy, g, wb, out, ep, True):
+        # stride-2 input gradient by output parity: four problems of 1 + 2 + 2 + 4 taps over a quarter of the pixels each = 1/4 of the walk
+        PROFILE_HINT = ('group', _conv_dgrad_s2(dy, B, g, wb, out, ep, describe=True), 0.25)
+    elif PROFILE is not None and dtype == BF16 and _dil_halves_ok(dtype, dy, g, wb, out, ep, True, True):
+        PROFILE_HINT = ('group', _conv_dil_halves(dy, B, g, wb, out, ep, True, False, describe=True), 2.0 / 3.0)
     igemm(dtype, M, g.Ci, g.taps * g.Co, dy, dy.stride(0), wb, g.taps * g.Co, out, out.stride(0), conv=conv,
           transposed=0 if g.plain else 1, **ep)
     PROFILE_HINT = None
@@ -1367,6 +1403,11 @@ def set_criterion(logits, boxes, at, dense, empty_weight, layer_of, w_ce, w_bbox
     dat_p = None
     if at_p is not None:
         assert at is not None, 'loss_weak_p needs the audio-tag output (the reference builds its targets in loss_weak)'
+        if wp_all and at_p.shape[0] != dense['n_lab']:
+            # reference sedt.py:184 with weak_mask None indexes both tensors with None: [1, B, C] against [1, n_lab, C] - BCELoss raises
+            # on the shape mismatch whenever unlabelled clips ride in the batch
+            raise ValueError(f"loss_weak_p with weak_mask=None needs every clip of the batch labelled (at_p has {at_p.shape[0]} clips, "
+                             f"{dense['n_lab']} are labelled): the reference's BCELoss rejects the shapes (sedt.py:184)")
         assert at_p.dtype == torch.float32 and at_p.is_contiguous() and at_p.dim() == 2 and at_p.shape[1] == C1 - 1
         assert dense['n_lab'] <= at_p.shape[0]
         dat_p = torch.empty_like(at_p)

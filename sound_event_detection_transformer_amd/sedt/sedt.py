@@ -391,6 +391,7 @@ class SetCriterion(nn.Module):
         self.last_total = None
         self._wvec = {}
         self.nonfinite = None                     # optional int32 device word (engine: polled instead of a sync per step)
+        self.host_compute = None                  # test hook: a callable (criterion, outputs, dense, fl) for CPU tensors (tests/host_criterion.py)
 
     # ------------------------------------------------------------------ host part
     @torch.no_grad()
@@ -651,90 +652,11 @@ class SetCriterion(nn.Module):
             if L > 8 or L * B > 8192:
                 raise NotImplementedError(f'fused criterion handles up to 8 decoder layers and L*B <= 8192 (got {L}, {B})')
             return self._compute_fused(outputs, dense, fl)
-        return self._compute_host(outputs, dense, fl)
-
-    def _compute_host(self, outputs, dense, fl=False):
-        """the same losses with torch ops on HOST tensors - only for exercising the matching / target logic without a GPU
-        (tests/test_criterion_cpu.py); GPU tensors always take the fused kernels"""
-        layers = [outputs] + list(outputs.get('aux_outputs', []))
-        L, ns, nb = dense['L'], dense['ns'], dense['num_boxes']
-        if nb is None:
-            nb = dense['wbox'][0].sum()
-        C1 = self.num_classes + 1
-        logits_all = torch.stack([o['pred_logits'] for o in layers]).float()          # [L,B,Q,C+1]
-        boxes = torch.stack([o['pred_boxes'][:ns] for o in layers]).float()           # [L,ns,Q,2]
-        logits = logits_all[:, :ns]
-        out = {}
-        vec = {}
-        tc = dense['tc'].long()
-        if 'labels' in self.losses:
-            if fl:
-                onehot = F.one_hot(tc, C1).float()
-                p = logits.sigmoid()
-                ce = F.binary_cross_entropy_with_logits(logits, onehot, pos_weight=self.empty_weight.to(logits.device), reduction='none')
-                ce = ce * (1 - (p * onehot + (1 - p) * (1 - onehot))) ** GAMMA_FL
-                if ALPHA_FL >= 0:
-                    ce = ce * (ALPHA_FL * onehot + (1 - ALPHA_FL) * (1 - onehot))
-                ce = ce.sum(-1).view(L, -1)
-            else:
-                ce = F.cross_entropy(logits.reshape(-1, C1), tc.reshape(-1), self.empty_weight.to(logits.device),
-                                     reduction='none').view(L, -1)
-            vec['loss_ce'] = (ce * dense['coef'].view(L, -1)).sum(1) / nb
-            with torch.no_grad():
-                m = (dense['wbox'][0] > 0)
-                hit = ((logits[0].argmax(-1) == tc[0]) & m).float().sum()
-                out['class_error'] = 100 - 100 * hit / m.float().sum().clamp(min=1)
-        if 'boxes' in self.losses:
-            s1, e1 = boxes[..., 0] - boxes[..., 1] / 2, boxes[..., 0] + boxes[..., 1] / 2
-            t = dense['tbox']
-            s2, e2 = t[..., 0] - t[..., 1] / 2, t[..., 0] + t[..., 1] / 2
-            l1 = (s1 - s2).abs() + (e1 - e2).abs()
-            inter = (torch.min(e1, e2) - torch.max(s1, s2)).clamp(min=0)
-            union = (e1 - s1) + (e2 - s2) - inter
-            hull = (torch.max(e1, e2) - torch.min(s1, s2)).clamp(min=0)
-            giou = inter / union - (hull - union) / hull
-            w = dense['wbox']
-            vec['loss_bbox'] = (l1 * w).view(L, -1).sum(1) / nb
-            vec['loss_giou'] = ((1 - giou) * w).view(L, -1).sum(1) / nb
-        if 'cardinality' in self.losses:
-            with torch.no_grad():
-                card = (logits_all.argmax(-1) != C1 - 1).sum(2).float()              # [L,B]
-                vec['cardinality_error'] = (card - dense['tgt_len'][None]).abs().mean(1)
-        if 'feature' in self.losses:
-            feats = torch.stack([o['pred_feature'][:ns] for o in layers]).float()     # [L,ns,Q,F]
-            gt = outputs['gt_feature'].float()
-            gt = gt.view(ns, gt.shape[0] // ns, -1)
-            tgt = gt[torch.arange(ns, device=gt.device)[None, :, None], dense['tidx'].long()]   # [L,ns,Q,F]
-            mse = (F.normalize(feats, dim=-1) - F.normalize(tgt, dim=-1)).square().sum(-1)
-            vec['loss_feature'] = (mse * (dense['wbox'] > 0).float()).view(L, -1).sum(1) / nb
-        for k, v in vec.items():
-            for li in range(L):
-                out[k if li == 0 else f'{k}_{li - 1}'] = v[li]
-        if 'weak' in self.losses and 'at' in outputs:
-            pw, gw = outputs['at'][:dense['n_lab']].float(), dense['gt_weak']
-            if fl:
-                ce = F.binary_cross_entropy(pw, gw, reduction='none') * (1 - (pw * gw + (1 - pw) * (1 - gw))) ** GAMMA_FL
-                if ALPHA_FL >= 0:
-                    ce = ce * (ALPHA_FL * gw + (1 - ALPHA_FL) * (1 - gw))
-                out['loss_weak'] = ce.sum(1).mean()
-            else:
-                out['loss_weak'] = F.binary_cross_entropy(pw, gw)
-        at_p = self._pooled(outputs, outputs.get('at'))
-        if at_p is not None:
-            r0 = 0 if dense.get('wp_all', False) else ns
-            out['loss_weak_p'] = F.binary_cross_entropy(at_p[r0:dense['n_lab']].float(), dense['gt_weak'][r0:])
-        wd = self.weight_dict
-        total = None
-        for k, v in vec.items():
-            wts = [wd.get(k if li == 0 else f'{k}_{li - 1}', 0.0) for li in range(L)]
-            if any(wts):
-                term = (v * torch.tensor(wts, device=v.device, dtype=v.dtype)).sum()
-                total = term if total is None else total + term
-        for k in ('loss_weak', 'loss_weak_p'):
-            if k in out and wd.get(k, 0.0):
-                total = out[k] * wd[k] + (total if total is not None else 0.0)
-        self.last_total = total
-        return out
+        if self.host_compute is None:
+            raise RuntimeError('SetCriterion computes its losses on the MI355X HIP path only (sedt_set_criterion): the outputs are not GPU '
+                               'tensors.  (The CPU tests of the matching / target logic install tests/host_criterion.py through '
+                               '`criterion.host_compute`; the product has no CPU implementation.)')
+        return self.host_compute(self, outputs, dense, fl)
 
     def forward(self, outputs, targets, weak_mask=None, strong_mask=None, fine_tune=False, normalize=False, fl=False,
                 ft_rand=None):
