@@ -235,6 +235,17 @@ int sedt_add_n(const void* const* srcs, int n, void* out, int64_t numel, int dty
 int sedt_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, void* stream);
 /* out = y > 0 ? g : 0 (ReLU backward), compute dtype, elementwise over n */
 int sedt_relu_mask(const void* g, const void* y, void* out, int64_t n, int dtype, void* stream);
+/* SP-SEDT decoder input, reference sedt/spsedt.py:48-69 in one launch each way.  patch [B*P][D] (compute dtype: patch2query of the pooled patch
+ * features), query f32 [Q][D] (query_embed.weight rows from `start`), out [B*Q][D] token-major (compute dtype):
+ *   train: out[b][q] = 2 * query[q] + keep(q, b) * patch[b][q / qpp]     eval: out[b][q] = query[q] + patch[b][q / qpp]
+ * keep_in f32 [Q][B] (may be NULL): the Bernoulli(1 - ratio) query-patch mask of spsedt.py:65; NULL = drawn from the counter hash of
+ * (seed (+ *seed_ptr), q * B + b), ratio <= 0 keeps every patch.  keep_out f32 [Q][B] (may be NULL) receives the mask used.
+ * Backward: d_patch [B*P][D] (compute dtype, may be NULL) = sum over the qpp queries of a patch of keep * g; d_query f32 [Q][D] =
+ * (train ? 2 : 1) * sum_b g[b][q], summed in clip order.  D a multiple of 8 (forward), D <= 1024 (backward). */
+int sedt_spsedt_dec_in(const void* patch, const float* query, const float* keep_in, float* keep_out, void* out, int B, int Q, int P, int qpp,
+                       int D, int train, float ratio, uint32_t seed, const uint32_t* seed_ptr, int dtype, void* stream);
+int sedt_spsedt_dec_in_bwd(const void* g, const float* keep, void* d_patch, float* d_query, int B, int Q, int P, int qpp, int D, int train,
+                           int dtype, void* stream);
 /* the FFN activation "gelu" of reference sedt/transformer.py:423-431 (F.gelu, erf form) with the FFN's dropout behind it
  * (transformer.py:187 / :203: dropout(activation(linear1(x)))):  a = keep(seed, e) * gelu(h) / (1-p);
  * backward: out = keep(seed, e) * g * gelu'(h) / (1-p).  h is the saved PRE-activation.  Elementwise over n (a multiple of 8) in the

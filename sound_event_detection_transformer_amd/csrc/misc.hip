@@ -338,6 +338,64 @@ __global__ void sigmoid_grad_kernel(const float* g, const float* s, float* out, 
   if (e < n) out[e] = g[e] * s[e] * (1.f - s[e]);
 }
 
+// ------------------------------------------------------------------ SP-SEDT decoder input (reference sedt/spsedt.py:48-69)
+// training: dec_in[b][q] = 2 * query[q] + keep(q, b) * patch[b][q / qpp]     (spsedt.py:65-67: decoder_input += patches * mask + decoder_input)
+// eval:     dec_in[b][q] = query[q] + patch[b][q / qpp]
+// The reference builds it with repeat / flatten / permute / contiguous copies, a torch.rand draw, a compare and three elementwise ops
+// (~10 launches and their autograd nodes); here one launch each way.  Token-major [B*Q][D] output (the decoder's query-position rows),
+// keep(q, b) either given (f32 [Q][B]: tests inject the reference's draw) or drawn from the counter hash of (seed, q * B + b) with
+// probability 1 - ratio and written to keep_out for the backward.  D = 256: one thread per 8 columns, 32 threads per row.
+template <typename T>
+__global__ void spsedt_dec_in_kernel(const T* __restrict__ patch, const float* __restrict__ query, const float* __restrict__ keep_in,
+                                     float* __restrict__ keep_out, T* __restrict__ out, int B, int Q, int P, int qpp, int D, int train,
+                                     uint32_t thresh, uint32_t seed, const uint32_t* seed_ptr) {
+  const int row = blockIdx.x * (blockDim.x / 32) + threadIdx.x / 32;          // b * Q + q
+  if (row >= B * Q) return;
+  const int b = row / Q, q = row - b * Q, c0 = (threadIdx.x & 31) * 8;
+  float k = 1.f;
+  if (train) {
+    if (keep_in) k = keep_in[(long)q * B + b];
+    else k = (thresh == 0u || drop_keep(eff_seed(seed, seed_ptr), (uint64_t)q * B + b, thresh)) ? 1.f : 0.f;
+    if (keep_out && c0 == 0) keep_out[(long)q * B + b] = k;
+  }
+  const float qs = train ? 2.f : 1.f;
+  for (int c = c0; c < D; c += 256) {
+    const VecT<T, 8> pv = *reinterpret_cast<const VecT<T, 8>*>(patch + ((long)b * P + q / qpp) * D + c);
+    const float4 qa = *reinterpret_cast<const float4*>(query + (long)q * D + c), qb = *reinterpret_cast<const float4*>(query + (long)q * D + c + 4);
+    const float qv[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+    VecT<T, 8> o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o.v[i] = (T)(qs * qv[i] + k * (float)pv.v[i]);
+    *reinterpret_cast<VecT<T, 8>*>(out + (long)row * D + c) = o;
+  }
+}
+
+// backward: blocks [0, B*P): d_patch[b][p] = sum_{r < qpp} keep(p*qpp + r, b) * g[b][p*qpp + r]  (compute dtype);
+//           blocks [B*P, B*P + Q): d_query[q] = (train ? 2 : 1) * sum_b g[b][q]  (f32, fixed order over b)
+template <typename T>
+__global__ void spsedt_dec_in_bwd_kernel(const T* __restrict__ g, const float* __restrict__ keep, T* __restrict__ d_patch,
+                                         float* __restrict__ d_query, int B, int Q, int P, int qpp, int D, int train) {
+  const int blk = blockIdx.x, c = threadIdx.x;
+  if (c >= D) return;
+  if (blk < B * P) {
+    if (!d_patch) return;
+    const int b = blk / P, p = blk - b * P;
+    float acc = 0.f;
+    for (int r = 0; r < qpp; ++r) {
+      const int q = p * qpp + r;
+      if (q >= Q) break;
+      const float k = (train && keep) ? keep[(long)q * B + b] : 1.f;
+      acc += k * (float)g[((long)b * Q + q) * D + c];
+    }
+    d_patch[(long)blk * D + c] = (T)acc;
+  } else {
+    const int q = blk - B * P;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += (float)g[((long)b * Q + q) * D + c];
+    d_query[(long)q * D + c] = (train ? 2.f : 1.f) * acc;
+  }
+}
+
 // ------------------------------------------------------------------ backbone support
 __global__ void bn_fold_kernel(const float* w, const float* b, const float* rm, const float* rv, float* scale,
                                float* bias, int n) {
@@ -1086,6 +1144,34 @@ extern "C" int sedt_cast(const void* in, int in_dtype, void* out, int out_dtype,
     hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, S(stream), (const bf16_t*)in, (bf16_t*)out, (long)n);
   else { set_error("cast: bad dtypes %d -> %d", in_dtype, out_dtype); return 1; }
   return check_launch("cast");
+}
+
+extern "C" int sedt_spsedt_dec_in(const void* patch, const float* query, const float* keep_in, float* keep_out, void* out, int B, int Q,
+                                  int P, int qpp, int D, int train, float ratio, uint32_t seed, const uint32_t* seed_ptr, int dtype,
+                                  void* stream) {
+  SEDT_REQUIRE(patch && query && out && B > 0 && Q > 0 && P > 0 && qpp > 0 && (Q + qpp - 1) / qpp <= P, "spsedt_dec_in: bad arguments");
+  SEDT_REQUIRE(D % 8 == 0 && ((uintptr_t)patch & 15) == 0 && ((uintptr_t)query & 15) == 0 && ((uintptr_t)out & 15) == 0,
+               "spsedt_dec_in: D must be a multiple of 8 and the pointers 16-byte aligned");
+  const uint32_t th = (train && !keep_in && ratio > 0.f) ? drop_threshold(ratio < 1.f ? ratio : 0.99999f) : 0u;
+  const int rows = B * Q;
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(spsedt_dec_in_kernel<float>, dim3((rows + 7) / 8), dim3(256), 0, S(stream), (const float*)patch, query, keep_in,
+                              keep_out, (float*)out, B, Q, P, qpp, D, train, th, seed, seed_ptr),
+           hipLaunchKernelGGL(spsedt_dec_in_kernel<bf16_t>, dim3((rows + 7) / 8), dim3(256), 0, S(stream), (const bf16_t*)patch, query,
+                              keep_in, keep_out, (bf16_t*)out, B, Q, P, qpp, D, train, th, seed, seed_ptr));
+  return check_launch("spsedt_dec_in");
+}
+
+extern "C" int sedt_spsedt_dec_in_bwd(const void* g, const float* keep, void* d_patch, float* d_query, int B, int Q, int P, int qpp, int D,
+                                      int train, int dtype, void* stream) {
+  SEDT_REQUIRE(g && d_query && B > 0 && Q > 0 && P > 0 && qpp > 0 && D > 0 && D <= 1024, "spsedt_dec_in_bwd: bad arguments");
+  const int thr = ((D + 63) / 64) * 64;
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL(spsedt_dec_in_bwd_kernel<float>, dim3(B * P + Q), dim3(thr), 0, S(stream), (const float*)g, keep, (float*)d_patch,
+                              d_query, B, Q, P, qpp, D, train),
+           hipLaunchKernelGGL(spsedt_dec_in_bwd_kernel<bf16_t>, dim3(B * P + Q), dim3(thr), 0, S(stream), (const bf16_t*)g, keep,
+                              (bf16_t*)d_patch, d_query, B, Q, P, qpp, D, train));
+  return check_launch("spsedt_dec_in_bwd");
 }
 
 extern "C" int sedt_gelu_fwd(const void* h, void* a, int64_t n, float p, uint32_t seed, const uint32_t* seed_ptr, int dtype, void* stream) {

@@ -78,6 +78,21 @@ def train_stream(dev):
 _CAPTURE = dict(capture_error_mode='thread_local')
 
 
+def quiesce_collectives(dev=None):
+    """call before a stream capture when an RCCL process group exists.  ProcessGroupNCCL's watchdog thread polls the completion event of
+    every collective it still lists (hipEventQuery, every 100 ms) and HIP answers hipErrorCapturedEvent when the stream such an event
+    was last recorded on is capturing at that moment - the watchdog then terminates the PROCESS ('operation not permitted on an event
+    last recorded in a capturing stream').  The collectives of the warm-up steps (or of the replays before a second stepper is built)
+    run on the training stream, the one the captures use: seen once in ~10 runs of tests/test_dp_gpu.py when a capture started
+    inside the watchdog's polling period.  Draining the device and sleeping three polling periods lets the watchdog retire every
+    finished work before the capture begins."""
+    dist = torch.distributed
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl':
+        import time
+        torch.cuda.synchronize(dev)
+        time.sleep(0.35)
+
+
 def train_step(model, criterion, optimizer, batch_input, targets, mask_weak=None, mask_strong=None, max_norm=0.1,
                normalize=False, check_finite=True, patches=None, allreduce=False, fine_tune=False, fl=False, mix_up_ratio=0,
                do_step=True):
@@ -437,6 +452,7 @@ class GraphedTrainStep(_GraphedBase):
             optimizer.enable_flat_grads(grad_dtype)          # pinned staging + flat buffer: not allocatable during capture
             optimizer._flat_g.zero_()
         gc.collect()
+        quiesce_collectives(self.dev)
         self.device_matching = device_matching
         self.g_fwd = torch.cuda.CUDAGraph()
         self.g_bwd = self.g_opt = None
@@ -673,6 +689,7 @@ class GraphedPredictStep(object):
                 self._body()
         torch.cuda.current_stream().wait_stream(stream)
         torch.cuda.synchronize()
+        quiesce_collectives(dev)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=stream, **_CAPTURE):
             self.out = self._body()
@@ -912,6 +929,7 @@ class GraphedSemiStep(_GraphedBase):
         self.sup = self.unsup = self.total = None
         optimizer.zero_grad(set_to_none=True)
         gc.collect()
+        quiesce_collectives(self.dev)
         if self.flat_mode:
             optimizer.enable_flat_grads(grad_dtype)
             optimizer._flat_g.zero_()

@@ -233,6 +233,29 @@ class HeadsFn(Function):
         return (dhs.view(Lh, B, Qp, d), d_wc, d_bc, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_wa, d_ba, None)
 
 
+class SpDecInFn(Function):
+    """SP-SEDT decoder input (reference sedt/spsedt.py:48-69) as one launch each way: patch queries [B*P, D] (compute dtype) + query
+    embedding rows [Q, D] (f32 parameter view) -> token-major [B*Q, D]; the Bernoulli query-patch mask is injected (``keep`` [Q, B]) or
+    drawn inside the launch (a counter hash, fresh per graph replay through the device seed word)"""
+
+    @staticmethod
+    def forward(ctx, patch, query, keep, B, Q, P, qpp, train, ratio, dt):
+        patch = _as(patch, dt)
+        q = query.detach().float().contiguous()
+        sp = runtime.seed_ptr(patch.device) if (train and keep is None and ratio > 0) else None
+        out, keep_used = ops.spsedt_dec_in(dt, patch, q, B, Q, P, qpp, train, ratio, keep, runtime.next_seed() if sp is not None else 0, sp)
+        ctx.cfg = (B, Q, P, qpp, train, dt, patch.dtype)
+        ctx.save_for_backward(keep_used)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Q, P, qpp, train, dt, _ = ctx.cfg
+        keep, = ctx.saved_tensors
+        d_patch, d_query = ops.spsedt_dec_in_bwd(dt, _as(g, dt), keep, B, Q, P, qpp, train, need_patch=ctx.needs_input_grad[0])
+        return d_patch, d_query, None, None, None, None, None, None, None, None
+
+
 class GradAccumulator(object):
     """side channel for a tensor that several autograd nodes of one chain consume (the decoder layers all read the encoder
     memory and the query position embedding): instead of each node returning its share - which autograd then adds pair by pair,

@@ -134,6 +134,8 @@ SIGNATURES = {
     'sedt_add_n': (_i, [C.POINTER(C.c_void_p), _i, _vp, _i64, _i, _vp]),
     'sedt_cast': (_i, [_vp, _i, _vp, _i, _i64, _vp]),
     'sedt_relu_mask': (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    'sedt_spsedt_dec_in': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _u32, _vp, _i, _vp]),
+    'sedt_spsedt_dec_in_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'sedt_gelu_fwd': (_i, [_vp, _vp, _i64, _f, _u32, _vp, _i, _vp]),
     'sedt_gelu_bwd': (_i, [_vp, _vp, _vp, _i64, _f, _u32, _vp, _i, _vp]),
     'sedt_sigmoid_grad': (_i, [_vp, _vp, _vp, _i64, _vp]),

@@ -862,6 +862,30 @@ def relu_mask(dtype, g, y):
     return out
 
 
+def spsedt_dec_in(dtype, patch, query, B, Q, P, qpp, train, ratio=0.0, keep=None, seed=0, seed_ptr=None):
+    """SP-SEDT decoder input [B*Q, D] from the patch queries [B*P, D] and the query embedding rows [Q, D] (f32); returns (dec_in, keep
+    [Q, B] f32 or None) - reference spsedt.py:48-69 in one launch"""
+    D = patch.shape[1]
+    assert patch.is_contiguous() and patch.shape[0] == B * P and query.dtype == torch.float32 and query.is_contiguous() and query.shape == (Q, D)
+    out = torch.empty((B * Q, D), device=patch.device, dtype=patch.dtype)
+    keep_out = torch.empty((Q, B), device=patch.device, dtype=torch.float32) if train else None
+    if keep is not None:
+        keep = keep.to(device=patch.device, dtype=torch.float32).reshape(Q, B).contiguous()
+    L.check(L.load().sedt_spsedt_dec_in(_p(patch), _p(query), _p(keep), _p(keep_out), _p(out), B, Q, P, qpp, D, int(train),
+                                        float(ratio), seed & 0xffffffff, _p(seed_ptr), dtype, L.stream_ptr()), 'spsedt_dec_in')
+    return out, keep_out
+
+
+def spsedt_dec_in_bwd(dtype, g, keep, B, Q, P, qpp, train, need_patch=True):
+    D = g.shape[1]
+    g = g.contiguous()
+    d_patch = torch.empty((B * P, D), device=g.device, dtype=g.dtype) if need_patch else None
+    d_query = torch.empty((Q, D), device=g.device, dtype=torch.float32)
+    L.check(L.load().sedt_spsedt_dec_in_bwd(_p(g), _p(keep), _p(d_patch), _p(d_query), B, Q, P, qpp, D, int(train), dtype, L.stream_ptr()),
+            'spsedt_dec_in_bwd')
+    return d_patch, d_query
+
+
 def gelu_fwd(dtype, h, p=0.0, seed=0, seed_ptr=None):
     """a = dropout(gelu(h)) in one launch (reference transformer.py:423-431 'gelu' + the FFN dropout); h: the linear1 output"""
     h = h.contiguous()

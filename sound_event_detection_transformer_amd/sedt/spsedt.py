@@ -2,6 +2,7 @@
 import torch
 from torch import nn
 
+from .. import functional as Fn
 from .. import ops, runtime
 from ..ops import ACT_SIGMOID
 from ..utilities.utils import NestedTensor
@@ -47,21 +48,30 @@ class SPSEDT(SEDT):
         pf = self.backbone(patches.flatten(0, 1))[-1]                        # (B*P, 2048, h', w') NHWC memory
         BP, C, ph, pw = pf.shape
         gt = ops.avgpool(runtime.compute_dtype(), pf.permute(0, 2, 3, 1).reshape(BP * ph * pw, C), BP, ph * pw, C)
-        pq = self.patch2query(gt).float().view(bs, bnp, 1, -1).repeat(1, 1, self.num_queries // self.num_patches, 1) \
-            .flatten(1, 2).permute(1, 0, 2).contiguous()                     # (Q, B, d)
+        pq = self.patch2query(gt)                                            # [B*P, d], compute dtype
         start = 1 if self.dec_at else 0
+        qpp = self.num_queries // self.num_patches
+        d = pq.shape[-1]
+        dt = runtime.compute_dtype()
         if self.training:
-            qe = self.query_embed.weight[start:, :]
+            if bnp != self.num_patches:
+                raise ValueError(f'training uses a fixed number of query patches ({self.num_patches}, spsedt.py:63), got {bnp}')
+            qe = self.query_embed.weight[start:, :] if start else self.query_embed.weight      # (no slice node when there is nothing to cut)
             if self.query_shuffle:                                          # spsedt.py:60: the queries are permuted
                 qe = qe[torch.randperm(self.num_queries, device=dev)]
-            if query_mask is None:
-                query_mask = (torch.rand(self.num_queries, bs, 1, device=dev) > self.mask_ratio).float()
-            dec_in = (qe * 2).unsqueeze(1) + pq * query_mask.to(dev)        # spsedt.py:66-67: 2*query + patch*mask
+            nq = self.num_queries
+            # spsedt.py:65-67 as ONE launch (csrc/misc.hip: spsedt_dec_in): 2 * query + patch * Bernoulli(1 - mask_ratio) mask, drawn in the launch
+            tok = Fn.SpDecInFn.apply(pq, qe, query_mask, bs, nq, bnp, qpp, True, float(self.mask_ratio), dt)
             am = self.attention_mask
         else:
             nq = bnp * self.num_queries // self.num_patches
-            dec_in = pq + self.query_embed.weight[start:nq, :].unsqueeze(1)
+            qe = self.query_embed.weight[start:nq, :]                       # spsedt.py:74 (with dec_at the reference's shapes do not add up either)
+            if qe.shape[0] != nq:
+                raise ValueError(f'query_embed.weight[{start}:{nq}] has {qe.shape[0]} rows for {nq} patch queries (spsedt.py:74)')
+            tok = Fn.SpDecInFn.apply(pq, qe, None, bs, nq, bnp, qpp, False, 0.0, dt)
             am = self.attention_mask[:nq, :nq]
+        dec_in = tok.view(bs, nq, d).permute(1, 0, 2)                       # (Q, B, d) view of the token-major rows: the transformer's own
+        #                                                                     permute(1, 0, 2).reshape(B * Q, d) is then a zero-copy view again
         hs, memory = self.transformer(self.input_proj(src), mask, dec_in, pos[-1], decoder_mask=am)
         outputs_class = self.class_embed(hs, out_f32=True)
         outputs_coord = self.bbox_embed(hs, final_act=ACT_SIGMOID, out_f32=True)
