@@ -396,13 +396,14 @@ def build_workload(args, dev, rank, world):
             l = (torch.randn(P, generator=gen) * 0.26 + 0.2).clamp(0.05, 0.799)
             c = l / 2 + torch.rand(P, generator=gen) * (1 - l)
             targets.append({'labels': torch.zeros(P, dtype=torch.int64), 'boxes': torch.stack([c, l], -1)})
-        targets = to_dev(targets)
+        # (the targets stay on the host, where a loader leaves them - as for C2 / C3: TargetTables lays them out in pinned memory and sends
+        #  ONE host->device copy per step; device-resident targets cost four concatenation kernels, two fills and three copies per step)
         g = GraphedTrainStep(model, criterion, opt, x, targets, slice(B), slice(B), max_norm=0.1, example_patches=patches,
                              overlap_allreduce=not args.no_overlap, dp_cuts=args.dp_cuts,
                              grad_dtype=torch.bfloat16 if args.bf16_buckets else None)
         if world > 1 and not agree_out_of_band(True, rank, world, 'graphed_dp_step'):
             os._exit(3)
-        extras.update(stepper=g, model=model)
+        extras.update(stepper=g, model=model, targets=targets)
 
         def step():
             g(x, targets, patches=patches)
@@ -1096,16 +1097,22 @@ def main():
     e0.record()
     for _ in range(args.steps):
         step()
-    host_issue = time.perf_counter() - t0               # the host's share: refreshing the tables + queueing the graphs (and collectives) of K steps
     e1.record()
     barrier()
     elapsed = time.perf_counter() - t0
+    # the host's own cost of ISSUING a step (table refresh, graph launches, RCCL enqueues): three steps queued onto an idle device - the
+    # pinned upload rings have four slots, so the host does not block on the GPU inside this burst.  Every rank runs it (collectives match)
+    t1 = time.perf_counter()
+    for _ in range(3):
+        step()
+    host_issue = (time.perf_counter() - t1) / 3.0
+    barrier()
     dev_ms = e0.elapsed_time(e1) / args.steps           # HIP events on the stream the step's graphs are launched on
     per_rank = [elapsed]
     rccl_world = 1
     # clocks UNDER LOAD, after the timed region: rocm-smi runs in a child while this process keeps replaying the step
     clocks = None
-    if rank == 0 and graphed and not args.no_clocks:
+    if rank == 0 and world == 1 and graphed and not args.no_clocks:      # (world > 1: a step contains collectives - no rank may run extra ones)
         clocks = clocks_under_load(step)
     if world > 1:
         dist = torch.distributed
@@ -1262,9 +1269,9 @@ def main():
                "settle_replay_ms": {"first": [settle_ms[i] for i in sorted(settle_ms) if i < 5],
                                     "last": [settle_ms[i] for i in sorted(settle_ms) if i >= 5 or settle <= 5][-5:]},
                "clocks_under_load": clocks,
-               # time the host spends ISSUING one step (table refresh, graph launches, RCCL enqueues) before it blocks on anything: while
+               # time the host spends ISSUING one step (table refresh, graph launches, RCCL enqueues; measured as a burst of three onto an idle device): while
                # this stays below ms_per_step the GPU never waits for the host; at N > 1 it tells exposed communication from host issue time
-               "host_launch_us_per_step": round(host_issue / args.steps * 1e6, 1)}
+               "host_launch_us_per_step": round(host_issue * 1e6, 1)}
         if others is not None:
             out["other_configs"] = others
         if ex.get('graph_fallback'):

@@ -177,7 +177,7 @@ typedef struct SedtPrefetch {
  *   pattern 1 (a weight operand; rows = Cout * taps, cols = Cin): dst [rows][3 * cols] = [hi | hi | lo].
  * A bf16 GEMM whose contraction walks hi, lo, hi of the activation (SedtIgemm.awrap: the last third wraps back onto hi) against
  * [hi | hi | lo] of the weight yields hi hi + lo hi + hi lo in its f32 accumulator: an f32 product to ~2^-16 at bf16 MFMA rate (with
- * SedtIgemm.f32ep for the epilogue).  Up to 4 jobs per launch (HOST array, copied into the kernel arguments).  cols and ld multiples of 4,
+ * SedtIgemm.f32ep for the epilogue).  Up to 8 jobs per launch (HOST array, copied into the kernel arguments).  cols and ld multiples of 4,
  * src 16-byte aligned. */
 typedef struct SedtSplitJob {
   const float* src;
@@ -639,7 +639,9 @@ int sedt_pool_at_bwd(const SedtPoolAt* args, const float* g, float* glogits, flo
 int sedt_feature_loss(const float* pred, const float* gt, const float* wbox, const float* tidx, const float* num_boxes,
                       const int32_t* layer_of /* host [L] */, const float* w /* device [L] or null */, int L, int B, int ns,
                       int Q, int P, int F, float* rowloss, float* out /* [L+1]: out[L] = sum_d w[d] out[d] */, float* dpred,
-                      int32_t* nonfinite /* or null: set to 1 when out[L] is NaN / inf (see SedtCriterion.nonfinite) */, void* stream);
+                      int32_t* nonfinite /* or null: set to 1 when out[L] is NaN / inf (see SedtCriterion.nonfinite) */,
+                      const float* base /* or null */, float* total_out /* or null: *total_out = out[L] + base[0] - the step's weighted total
+                      with SetCriterion's (sedt_set_criterion's `total`) folded in, so the sum costs no launch of its own */, void* stream);
 int sedt_scale_layers(float* x, const float* g, const float* gtot, const float* w, const int32_t* idx /* host [L] or null */,
                       int L, int64_t per_layer, void* stream);
 /* out[0] = sum_i x[i] (one workgroup, fixed order): num_boxes = sum of the final layer's box weights (sedt.py:322-324) */

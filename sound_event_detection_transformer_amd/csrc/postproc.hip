@@ -235,7 +235,8 @@ __global__ __launch_bounds__(256) void feature_loss_kernel(const float* __restri
 // out[d] = sum of rowloss[d][ns*Q] in a fixed order for every dense layer d, out[L] = sum_d w[d] * out[d] (one workgroup)
 __global__ __launch_bounds__(256) void feature_loss_reduce_kernel(const float* __restrict__ rowloss, int n, int L,
                                                                   const float* __restrict__ w, float* __restrict__ out,
-                                                                  int32_t* nonfinite) {
+                                                                  int32_t* nonfinite, const float* __restrict__ base,
+                                                                  float* __restrict__ total_out) {
   __shared__ float red[4];
   float tot = 0.f;
   for (int d = 0; d < L; ++d) {
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(256) void feature_loss_reduce_kernel(const float* _
   }
   if (threadIdx.x == 0) {
     out[L] = tot;
+    if (total_out) *total_out = tot + (base ? base[0] : 0.f);       // the step's running weighted total (SetCriterion's + this loss)
     if (nonfinite && !(fabsf(tot) <= 3.0e38f)) *nonfinite = 1;      // same word as SedtCriterion.nonfinite
   }
 }
@@ -317,7 +319,7 @@ extern "C" int sedt_pseudo_labels(const float* logits, const float* boxes, const
 
 extern "C" int sedt_feature_loss(const float* pred, const float* gt, const float* wbox, const float* tidx, const float* num_boxes,
                                  const int32_t* layer_of, const float* w, int L, int B, int ns, int Q, int P, int F, float* rowloss,
-                                 float* out, float* dpred, int32_t* nonfinite, void* stream) {
+                                 float* out, float* dpred, int32_t* nonfinite, const float* base, float* total_out, void* stream) {
   using namespace sedt;
   SEDT_REQUIRE(pred && gt && wbox && tidx && num_boxes && layer_of && rowloss && out && dpred, "feature_loss: null pointer");
   SEDT_REQUIRE(L >= 1 && L <= SEDT_CRIT_MAXL && F % 4 == 0 && ns <= B && P >= 1, "feature_loss: L=%d F=%d ns=%d B=%d P=%d", L, F, ns, B, P);
@@ -328,7 +330,7 @@ extern "C" int sedt_feature_loss(const float* pred, const float* gt, const float
                      gt, wbox, tidx, num_boxes, lay[0], lay[1], lay[2], lay[3], lay[4], lay[5], lay[6], lay[7],
                      L, B, ns, Q, P, F, rowloss, dpred);
   hipLaunchKernelGGL(feature_loss_reduce_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rowloss, ns * Q, L, w, out,
-                     nonfinite);
+                     nonfinite, base, total_out);
   return check_launch("feature_loss");
 }
 

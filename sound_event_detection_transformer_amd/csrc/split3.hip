@@ -17,7 +17,7 @@
 
 namespace sedt {
 
-constexpr int SPLIT_MAXJ = 4;
+constexpr int SPLIT_MAXJ = 8;
 struct SplitJobs {
   int n;
   SedtSplitJob j[SPLIT_MAXJ];

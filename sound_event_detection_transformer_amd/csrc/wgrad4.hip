@@ -52,7 +52,16 @@ __device__ __forceinline__ void wgrad4_impl(const SedtIgemm& p, const unsigned a
     vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
   int m0, n0;
-  if (nmajor & 1) { n0 = (vid / ntm) * BN; m0 = (vid % ntm) * BM; }
+  if (CONV && (nmajor & 4)) {
+    // channel-block-major order (3x3 problems, Ci % 128 == 0): consecutive tiles - one XCD's share - are the NINE TAPS of one 128-channel
+    // block of X against ONE dY tile, so that XCD's L2 fetches one channel block of X (the taps re-read it shifted by a few pixel rows)
+    // and one dY tile instead of 4-5 column tiles of different blocks and every dY tile
+    const int taps = p.KH * p.KW, ncb = p.Ci / BN;
+    const int cb = vid / (ntm * taps), rem = vid - cb * (ntm * taps);
+    const int mt = rem / taps, tap = rem - mt * taps;
+    m0 = mt * BM;
+    n0 = (tap * ncb + cb) * BN;
+  } else if (nmajor & 1) { n0 = (vid / ntm) * BN; m0 = (vid % ntm) * BM; }
   else { m0 = (vid / ntn) * BM; n0 = (vid % ntn) * BN; }
 
   const int nkb_total = (p.K + BKP - 1) / BKP;
@@ -399,6 +408,16 @@ bool wgrad4_ok(const SedtIgemm& p) {
          (reinterpret_cast<uintptr_t>(p.slab) & 15) == 0;
 }
 
+// channel-block-major tile order for the 3x3 problems (see wgrad4_impl); SEDT_WGRAD4_CBMAJOR=0/1 in the developer build
+static bool wg4_cbmajor(const SedtIgemm& p) {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = sedt::dev_getenv("SEDT_WGRAD4_CBMAJOR");
+    on = e ? atoi(e) : 0;
+  }
+  return on && p.conv && p.KH * p.KW > 1 && (p.Ci % 128) == 0 && p.N == p.KH * p.KW * p.Ci;
+}
+
 template <typename K>
 static int wg4_attr(K kern, const char* what) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wg4_lds());
@@ -437,7 +456,7 @@ int launch_wgrad4_group(WgradGroup& g, hipStream_t st) {
     const SedtIgemm& p = g.p[i];
     const int bm = wgrad4_tile_m(p.M, p.N);
     g.nwg[i] = (p.N / 128) * (p.M / bm);
-    g.nmajor[i] = (p.N > p.M ? 1 : 0) | (bm == 256 ? 2 : 0);
+    g.nmajor[i] = (p.N > p.M ? 1 : 0) | (bm == 256 ? 2 : 0) | (wg4_cbmajor(p) ? 4 : 0);
     g.blk0[i] = blk;
     blk += (g.nwg[i] * (p.splitk > 1 ? p.splitk : 1) + 7) / 8 * 8;
   }

@@ -233,6 +233,30 @@ class HeadsFn(Function):
         return (dhs.view(Lh, B, Qp, d), d_wc, d_bc, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_wa, d_ba, None)
 
 
+class FanoutFn(Function):
+    """n handles on one tensor for n independent consumers (SP-SEDT's stacked decoder output feeds the class head, the box MLP and the
+    feature-alignment MLP: spsedt.py:79-83).  As plain autograd the consumers' input gradients are added pair by pair (n - 1 elementwise
+    launches of torch); here the backward is ONE sedt_add_n over the gradients that arrived."""
+
+    @staticmethod
+    def forward(ctx, x, n, dt):
+        ctx.set_materialize_grads(False)
+        ctx.dt = dt
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [_as(g, ctx.dt) for g in gs if g is not None]
+        if not gs:
+            return None, None, None
+        if len(gs) == 1 or gs[0].numel() % 8:
+            out = gs[0]
+            for g in gs[1:]:
+                out = out + g
+            return out, None, None
+        return ops.add_n(ctx.dt, gs), None, None
+
+
 class SpDecInFn(Function):
     """SP-SEDT decoder input (reference sedt/spsedt.py:48-69) as one launch each way: patch queries [B*P, D] (compute dtype) + query
     embedding rows [Q, D] (f32 parameter view) -> token-major [B*Q, D]; the Bernoulli query-patch mask is injected (``keep`` [Q, B]) or

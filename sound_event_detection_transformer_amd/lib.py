@@ -195,7 +195,7 @@ SIGNATURES = {
     'sedt_set_criterion': (_i, [C.POINTER(SedtCriterion), _vp, _vp]),
     'sedt_set_criterion_bwd': (_i, [C.POINTER(SedtCriterion), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'sedt_match_targets': (_i, [C.POINTER(SedtMatch), _vp]),
-    'sedt_feature_loss': (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'sedt_feature_loss': (_i, [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'sedt_scale_layers': (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _i64, _vp]),
     'sedt_sum_f32': (_i, [_vp, _i, _vp, _vp]),
     'sedt_pool_at': (_i, [C.POINTER(SedtPoolAt), _vp, _vp]),

@@ -179,38 +179,95 @@ X3_FAST = _dev_env('SEDT_X3_FAST', '1') != '0'
 # WITHOUT leaving its image (no split_out) pops that tensor's entry (igemm / _igemm_x3_fast).  Emptied when a model forward starts
 # (packing.PlanSet / PackPlan) and by the optimizer step.
 X3_CACHE = {}
+# weight operand images [rows][3 cols] = [hi | hi | lo] of WHOLE packed operands, by base pointer: (rows, cols, ld, image, source tensor).
+# A GEMM asks for its weight's image; on a miss ONE split launch makes it together with the next few operands the model consumes
+# (packing.weight_neighbours), row slices of a cached operand (the q|k and v halves of an in_proj weight) are views of its image.
+W3_CACHE = {}
+W3_STARTS = []                      # sorted base pointers of W3_CACHE (range lookup for row slices)
+X3_WGROUP = int(_dev_env('SEDT_X3_WGROUP', '3'))       # further operands prepared with the one that missed (0: one split launch per weight).
+# Same-box A/B on the C2 bf16x3 step (profiles/r06_ab_x3_wgroup.txt): 0 -> 13.74-13.78 ms, 3 -> 13.69-13.72, 5 -> 13.85-13.87, 7 -> 13.83-13.93:
+# an image made more than a few GEMMs ahead of its use is read back cold, which costs more than the launches it saves
 X3_CACHE_ON = _dev_env('SEDT_X3_CACHE', '1') != '0'
 X3_SPLIT_OUT = _dev_env('SEDT_X3_SPLIT_OUT', '1') != '0'      # GEMM epilogues write the operand image of outputs that feed GEMMs again
 
 
 def x3_cache_clear():
     X3_CACHE.clear()
+    W3_CACHE.clear()
+    del W3_STARTS[:]
+
+
+def _w3_lookup(ptr, rows, cols, ld):
+    """image of the weight operand (ptr, rows, cols, ld) if it is a cached operand or a row slice of one"""
+    import bisect
+    k = bisect.bisect_right(W3_STARTS, ptr) - 1
+    if k < 0:
+        return None
+    base = W3_STARTS[k]
+    r_, c_, ld_, img, src = W3_CACHE[base]
+    off = ptr - base
+    if c_ != cols or ld_ != ld or off % (4 * ld) or off // (4 * ld) + rows > r_:
+        return None
+    r0 = off // (4 * ld)
+    return img[r0:r0 + rows]
+
+
+def _w3_plan(t, off, rows, cols, ld):
+    """split jobs (tensor, 0, rows, cols, ld, 1) that make the missing weight image AND those of the operands consumed next"""
+    from . import packing
+    ptr = t.data_ptr() + 4 * off
+    jobs = []
+    if X3_WGROUP > 0 and X3_CACHE_ON:
+        for wt, r_, c_ in packing.weight_neighbours(ptr, X3_WGROUP):
+            if wt.data_ptr() in W3_CACHE or c_ % 64 or (wt.data_ptr() % 16):
+                continue
+            jobs.append((wt, 0, r_, c_, c_, 1))
+    return jobs
+
+
+SPLIT_MAXJ = 8                      # jobs per sedt_split3 launch (csrc/split3.hip)
 
 
 def _split3(jobs):
-    """jobs: (tensor, element offset of the view's first element, rows, cols, row stride, pattern); one launch for up to four.  Returns the
-    bf16 images: [rows, 2 * cols] = [hi | lo] for pattern 0 (activations / gradients), [rows, 3 * cols] = [hi | hi | lo] for pattern 1 (weights)"""
-    outs, todo = [None] * len(jobs), []
+    """jobs: (tensor, element offset of the view's first element, rows, cols, row stride, pattern); one launch for up to SPLIT_MAXJ.  Returns
+    the bf16 images: [rows, 2 * cols] = [hi | lo] for pattern 0 (activations / gradients), [rows, 3 * cols] = [hi | hi | lo] for pattern 1 (weights)"""
+    import bisect
+    outs, todo = [None] * len(jobs), []           # todo: (job tuple, destination, index in outs or None)
     for i, (t, off, rows, cols, ld, pattern) in enumerate(jobs):
         key = (t.data_ptr() + 4 * off, rows, cols, ld)
+        if pattern == 1 and X3_CACHE_ON:
+            hit = _w3_lookup(key[0], rows, cols, ld)
+            if hit is not None:
+                outs[i] = hit
+                continue
+            extra = _w3_plan(t, off, rows, cols, ld)
+            for wt, _, r_, c_, ld_, _ in extra[:SPLIT_MAXJ - len(jobs)]:
+                d = torch.empty((r_, 3 * c_), device=wt.device, dtype=torch.bfloat16)
+                todo.append(((wt, 0, r_, c_, ld_, 1), d, None))
+                W3_CACHE[wt.data_ptr()] = (r_, c_, ld_, d, wt)
+                bisect.insort(W3_STARTS, wt.data_ptr())
+            hit = _w3_lookup(key[0], rows, cols, ld)          # (the operand itself is the first neighbour when a plan knows it)
+            if hit is not None:
+                outs[i] = hit
+                continue
         hit = X3_CACHE.get(key) if (pattern == 0 and X3_CACHE_ON) else None
         if hit is not None and hit[2] == t._version:
             outs[i] = hit[1]
             continue
         d = torch.empty((rows, (3 if pattern else 2) * cols), device=t.device, dtype=torch.bfloat16)
         outs[i] = d
-        todo.append((i, key))
+        todo.append(((t, off, rows, cols, ld, pattern), d, i))
         if pattern == 0 and X3_CACHE_ON:
             if len(X3_CACHE) >= 1024:           # (op-level callers outside a model forward never reach a clearing point: bound what is held)
                 X3_CACHE.clear()
             X3_CACHE[key] = (t, d, t._version)
-    if todo:
-        arr = (L.SedtSplitJob * len(todo))()
-        for n, (i, key) in enumerate(todo):
-            t, off, rows, cols, ld, pattern = jobs[i]
-            arr[n].src, arr[n].ld, arr[n].dst = key[0], ld, outs[i].data_ptr()
+    for base in range(0, len(todo), SPLIT_MAXJ):
+        chunk = todo[base:base + SPLIT_MAXJ]
+        arr = (L.SedtSplitJob * len(chunk))()
+        for n, ((t, off, rows, cols, ld, pattern), d, _) in enumerate(chunk):
+            arr[n].src, arr[n].ld, arr[n].dst = t.data_ptr() + 4 * off, ld, d.data_ptr()
             arr[n].rows, arr[n].cols, arr[n].pattern = rows, cols, pattern
-        L.check(L.load().sedt_split3(arr, len(todo), L.stream_ptr()), 'split3')
+        L.check(L.load().sedt_split3(arr, len(chunk), L.stream_ptr()), 'split3')
     return outs
 
 
@@ -292,6 +349,14 @@ def igemm(dtype, M, N, K, A, lda, B, ldb, Cout, ldc, **kw):
         X3_CACHE.pop((Cout.data_ptr(), M, N, ldc), None)          # the generic kernel rewrites Cout and leaves no operand image
     a = igemm_args(M, N, K, A, lda, B, ldb, Cout, ldc, **kw)
     conv, trans = kw.get('conv'), kw.get('trans', 0)
+    if (dtype == BF16 and kw.get('out_f32') and not trans and kw.get('res') is None and (kw.get('mask') is None or kw.get('mask_bits'))
+            and kw.get('act', ACT_NONE) != ACT_SIGMOID):
+        # an f32 OUTPUT of bf16 operands (SP-SEDT's feature_align head: 12,000 x 2048 at C4): the LDS-DMA kernels write f32 through
+        # their f32 epilogue (SedtIgemm.f32ep); asked for only when the dispatcher says the problem is inside their envelope
+        a.f32ep = 1
+        buf = C.create_string_buffer(96)
+        if L.load().sedt_igemm_describe(C.byref(a), L.gemm_dtype(dtype), 0, buf, 96) != 0 or not buf.value.decode().startswith('igemm3'):
+            a.f32ep = 0
     if _co['on'] and POOL.gemms and not trans and dtype == BF16:
         riders = POOL.take(((M + 63) // 64) * ((N + 63) // 64))
         arr = (L.SedtIgemm * len(riders))(*[r[0] for r in riders])
@@ -1558,10 +1623,11 @@ def pool_at_bwd(logits, boxes, attn, mode, q0, Q, g):
     return gl, gb, ga
 
 
-def feature_loss(pred, gt, dense, layer_of, num_boxes, w=None, nonfinite=None):
+def feature_loss(pred, gt, dense, layer_of, num_boxes, w=None, nonfinite=None, base=None):
     """SP-SEDT feature-reconstruction loss (sedt.py:263-283) of every decoder layer in one launch.  pred [L,B,Q,F] f32,
     gt [B*P,F] f32, w [L] f32 layer weights.  Returns (out[L+1]: loss per dense layer + their weighted sum,
-    dpred [L,B,Q,F] = d loss[d] / d pred, unweighted)."""
+    dpred [L,B,Q,F] = d loss[d] / d pred, unweighted) - and, with base (a device scalar: the criterion's running weighted total), a third
+    result total = base + out[L]."""
     _dev_check(pred, gt)
     Lh, B, Q, F = pred.shape
     assert pred.dtype == torch.float32 and gt.dtype == torch.float32 and pred.is_contiguous() and gt.is_contiguous()
@@ -1572,9 +1638,12 @@ def feature_loss(pred, gt, dense, layer_of, num_boxes, w=None, nonfinite=None):
     rowloss = torch.empty(Lh * ns * Q, device=pred.device, dtype=torch.float32)
     out = torch.empty(Lh + 1, device=pred.device, dtype=torch.float32)
     lay = (C.c_int32 * Lh)(*layer_of)
+    total = torch.empty((), device=pred.device, dtype=torch.float32) if base is not None else None
+    if base is not None:
+        assert base.dtype == torch.float32 and base.numel() == 1 and base.is_cuda
     L.check(L.load().sedt_feature_loss(_p(pred), _p(gt), _p(dense['wbox']), _p(dense['tidx']), _p(num_boxes), lay, _p(w), Lh, B, ns, Q, P, F,
-                                       _p(rowloss), _p(out), _p(dpred), _p(nonfinite), L.stream_ptr()), 'feature_loss')
-    return out, dpred
+                                       _p(rowloss), _p(out), _p(dpred), _p(nonfinite), _p(base), _p(total), L.stream_ptr()), 'feature_loss')
+    return (out, dpred) if base is None else (out, dpred, total)
 
 
 def scale_layers(x, g, gtot, w, idx=None):

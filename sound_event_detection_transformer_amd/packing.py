@@ -20,6 +20,28 @@ _FJ = np.dtype([('w', np.uint64), ('wf', np.uint64), ('wb', np.uint64), ('N', np
 _CHUNK = 32768
 
 _active = []          # stack of plans whose prepared tensors are valid right now (inside a model forward)
+_plans = None         # weak set of every PackPlan alive (weight_neighbours: the backward runs after the forward's plan scope has closed)
+
+
+def _plan_set():
+    global _plans
+    if _plans is None:
+        import weakref
+        _plans = weakref.WeakSet()
+    return _plans
+
+
+def weight_neighbours(ptr, n):
+    """bf16x3 operand images (ops._split3): the GEMM about to run needs the image of the weight operand at `ptr`; the n operands the
+    model consumes NEXT are returned with it so that one split launch prepares them all, shortly before their use (an image made a whole
+    forward ahead is read back cold from HBM: measured +2.5 % on the step; made a few GEMMs ahead it is still in L2 / Infinity Cache).
+    Forward operands follow each other in model order, dgrad operands in reverse.  Returns a list of (tensor, rows, cols) - the operand
+    containing `ptr` first (the whole tensor when ptr addresses a row slice of it) - or [] when no plan knows the pointer."""
+    for plan in list(reversed(_active)) + [p for p in _plan_set() if p not in _active]:
+        got = plan._neighbours(ptr, n)
+        if got:
+            return got
+    return []
 
 
 def lookup_frag(weight):
@@ -134,6 +156,33 @@ class PackPlan(object):
         self._host_pk = torch.empty(max(self._pk.nbytes, 8), dtype=torch.uint8).pin_memory()
         self._last = None
         self._init_frags(frags if dt == BF16 else (), device, conv_frags if dt == BF16 else ())
+        _plan_set().add(self)
+        self._ranges = None
+
+    def _neighbours(self, ptr, n):
+        if self.dt != F32:
+            return []
+        if self._ranges is None:       # (start, end, direction, index) of every f32 operand: packed forward / dgrad forms, linears' masters
+            fwd, bwd = [], []
+            for w, wf, wb, _, _ in self._entries:
+                Co, Ci = w.shape[0], w.shape[1]
+                taps = w.numel() // (Co * Ci)
+                f = wf if wf is not None else (w if w.dim() == 2 else None)
+                if f is not None:
+                    fwd.append((f, Co * taps, Ci))
+                if wb is not None:
+                    bwd.append((wb, Ci * taps, Co))
+            self._ord = {1: fwd, -1: bwd}
+            self._ranges = sorted([(t.data_ptr(), t.data_ptr() + t.numel() * 4, d, i) for d, lst in self._ord.items() for i, (t, _, _) in enumerate(lst)])
+            self._starts = [r[0] for r in self._ranges]
+        import bisect
+        k = bisect.bisect_right(self._starts, ptr) - 1
+        if k < 0 or not (self._ranges[k][0] <= ptr < self._ranges[k][1]):
+            return []
+        _, _, d, i = self._ranges[k]
+        lst = self._ord[d]
+        idx = range(i, min(i + n + 1, len(lst))) if d > 0 else range(i, max(i - n - 1, -1), -1)
+        return [lst[j] for j in idx]
 
     def _init_frags(self, frags, device, conv_frags):
         self.frag_table, self._fr_params, self._fr_entries = {}, [], []
@@ -194,6 +243,7 @@ class PackPlan(object):
                 self._host_bn.numpy()[:self._bn.nbytes] = self._bn.view(np.uint8)
                 self._dev_bn.copy_(self._host_bn, non_blocking=True)
             self._last = key
+            self._ranges = None
             self.table = {w.data_ptr(): (wf if wf is not None else w, wb, sc, bi) for w, wf, wb, sc, bi in self._entries}
             if len(self._fj):
                 # (the fragment-packed weights are a subset of the linears: a pointer change there changed `key` as well)

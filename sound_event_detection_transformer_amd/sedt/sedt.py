@@ -351,25 +351,39 @@ class _FeatureLossFn(torch.autograd.Function):
     out[L] = their weighted sum.  The forward launch also leaves the unweighted gradient; backward scales it per layer."""
 
     @staticmethod
-    def forward(ctx, pred_all, gt, dense, layer_of, num_boxes, wvec, nonfinite=None):
+    def forward(ctx, pred_all, gt, dense, layer_of, num_boxes, wvec, nonfinite=None, base_total=None):
+        """base_total (optional device scalar with its own autograd history: SetCriterion's weighted total): the second result is then
+        base_total + sum_d w[d] loss[d], added inside the launch (a torch add, and the zero-fill + copy of indexing the vector in the
+        backward, are three launches otherwise)"""
         from .. import ops
-        out, ctx.dpred = ops.feature_loss(pred_all.detach().float().contiguous(), gt.detach().float().contiguous(), dense,
-                                          layer_of, num_boxes, wvec, nonfinite)
+        ctx.set_materialize_grads(False)
+        res = ops.feature_loss(pred_all.detach().float().contiguous(), gt.detach().float().contiguous(), dense,
+                               layer_of, num_boxes, wvec, nonfinite, None if base_total is None else base_total.detach().float())
+        out, ctx.dpred = res[0], res[1]
         ctx.wvec, ctx.dt = wvec, pred_all.dtype
         inv = [0] * len(layer_of)
         for d, ml in enumerate(layer_of):
             inv[ml] = d
         ctx.inv = inv                                  # dpred is in the model's layer order, the loss vector in dense order
-        return out
+        ctx.has_base = base_total is not None
+        return (out, res[2]) if ctx.has_base else out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, gtotal=None):
         from .. import ops
-        g = g.contiguous().float()
-        L = g.numel() - 1
-        d = ops.scale_layers(ctx.dpred, g[:L], g[L:], ctx.wvec, ctx.inv)
+        if g is None and gtotal is None:
+            return (None,) * 8
+        L = len(ctx.inv)
+        gl = gt_ = None
+        if g is not None:
+            g = g.contiguous().float()
+            gl, gt_ = g[:L], g[L:]
+        if gtotal is not None:
+            gtotal = gtotal.reshape(1).float()
+            gt_ = gtotal if gt_ is None else gt_ + gtotal
+        d = ops.scale_layers(ctx.dpred, gl, gt_, ctx.wvec, ctx.inv)
         ctx.dpred = None
-        return d.to(ctx.dt), None, None, None, None, None, None
+        return d.to(ctx.dt), None, None, None, None, None, None, (gtotal.reshape(()) if (ctx.has_base and gtotal is not None) else None)
 
 
 class SetCriterion(nn.Module):
@@ -631,10 +645,9 @@ class SetCriterion(nn.Module):
             if nb is None:
                 from .. import ops
                 nb = ops.sum_f32(dense['wbox'][0])
-            fv = _FeatureLossFn.apply(feats, outputs['gt_feature'], dense, layer_of, nb, wv, self.nonfinite)
+            fv, total = _FeatureLossFn.apply(feats, outputs['gt_feature'], dense, layer_of, nb, wv, self.nonfinite, total)
             for d in range(L):
                 out['loss_feature' if d == 0 else f'loss_feature_{d - 1}'] = fv[d]
-            total = total + fv[L]
         self.last_total = total
         return out
 

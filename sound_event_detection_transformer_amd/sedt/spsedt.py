@@ -73,10 +73,15 @@ class SPSEDT(SEDT):
         dec_in = tok.view(bs, nq, d).permute(1, 0, 2)                       # (Q, B, d) view of the token-major rows: the transformer's own
         #                                                                     permute(1, 0, 2).reshape(B * Q, d) is then a zero-copy view again
         hs, memory = self.transformer(self.input_proj(src), mask, dec_in, pos[-1], decoder_mask=am)
-        outputs_class = self.class_embed(hs, out_f32=True)
-        outputs_coord = self.bbox_embed(hs, final_act=ACT_SIGMOID, out_f32=True)
+        if torch.is_grad_enabled() and hs.requires_grad:
+            # three (two) heads read hs: one gradient sum in the backward instead of autograd's pairwise adds (functional.FanoutFn)
+            hs_c, hs_b, hs_f = Fn.FanoutFn.apply(hs, 3, dt) if self.feature_recon else (Fn.FanoutFn.apply(hs, 2, dt) + (None,))
+        else:
+            hs_c = hs_b = hs_f = hs
+        outputs_class = self.class_embed(hs_c, out_f32=True)
+        outputs_coord = self.bbox_embed(hs_b, final_act=ACT_SIGMOID, out_f32=True)
         if self.feature_recon:
-            outputs_feature = self.feature_align(hs, out_f32=True)
+            outputs_feature = self.feature_align(hs_f, out_f32=True)
             out = {'pred_logits': outputs_class[-1], 'pred_feature': outputs_feature[-1], 'gt_feature': gt,
                    'pred_boxes': outputs_coord[-1]}
             if self.aux_loss:

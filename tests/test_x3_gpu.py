@@ -242,3 +242,36 @@ def test_x3_gradients_against_the_oracle(capsys):
         assert worst[0] > 1 - 1e-4 and worst[1] < 2e-2 and worst[2] < 5e-3, worst
     finally:
         runtime.set_compute_dtype('f32')
+
+
+def test_x3_weight_images_are_prepared_in_groups_and_change_nothing():
+    """round 6: on a weight-image miss ONE split launch also prepares the operands the model consumes next (packing.weight_neighbours,
+    ops.X3_WGROUP), row slices of an in_proj weight are views of the whole tensor's image: fewer `split3` launches, bit-identical step"""
+    from sound_event_detection_transformer_amd import lib, ops, runtime, sedt
+    from oracle import sedt_oracle as O
+    runtime.set_compute_dtype('bf16x3')
+    try:
+        x = torch.randn(2, 1, 500, 64, generator=torch.Generator().manual_seed(3)).cuda()
+        res = {}
+        for grp in (0, 5):
+            keep = ops.X3_WGROUP
+            ops.X3_WGROUP = grp
+            try:
+                model, _, _ = sedt.build_model(sedt.default_args(dropout=0.0))
+                model.load_state_dict(O.seeded_state_dict(model.state_dict(), 9))
+                model.cuda().train()
+                with lib.launch_log() as log:
+                    o = model(x)
+                    loss = o['pred_logits'].square().mean() + o['pred_boxes'].square().mean() + o['at'].square().mean()
+                    loss.backward()
+                torch.cuda.synchronize()
+                res[grp] = (log['split3'], o['pred_logits'].detach().clone(), o['pred_boxes'].detach().clone(),
+                            torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None]))
+            finally:
+                ops.X3_WGROUP = keep
+        n0, n5 = res[0][0], res[5][0]
+        assert n5 <= 0.7 * n0, (n0, n5)
+        for a, b in zip(res[0][1:], res[5][1:]):
+            assert torch.equal(a, b)
+    finally:
+        runtime.set_compute_dtype('f32')

@@ -3,7 +3,8 @@
   time (kernel trace), HBM-side bytes (FETCH_SIZE x 2 as the guide prescribes for wide coalesced reads on gfx950, WRITE_SIZE),
   matrix-core busy share (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): rocprofv3 sums GRBM_GUI_ACTIVE over the 8
   XCDs; calibrated on the layer4 3x3 conv: 1.18 M MFMAs x 32 cycles over 1024 SIMDs), VALU instructions per MFMA.
-usage: pmc_step_summary.py <gpurun_out/prof_<tag>> <profiles/rNN_step_c2.csv> <profiles/rNN_pmc_c2.json> [config, default c2]
+usage: pmc_step_summary.py <gpurun_out/prof_<tag>> <profiles/rNN_step_c2.csv> <profiles/rNN_pmc_c2.json> [config, default c2] [stem launches per
+step, default 1 (2 for c4: clips + patches, and c5: teacher + student)]
 Steps are split at the stem forward launch (stem_pool_fwd, or stem_im2col in builds before the one-launch stem: one per forward of the supervised step)."""
 import collections
 import csv
@@ -14,6 +15,7 @@ import sys
 
 root, out_csv, out_json = sys.argv[1], sys.argv[2], sys.argv[3]
 cfg = sys.argv[4] if len(sys.argv) > 4 else 'c2'
+PER = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 
 
 def short(n):
@@ -25,7 +27,7 @@ def short(n):
 def last_step(rows, key):
     rows = sorted(rows, key=key)
     marks = [i for i, r in enumerate(rows) if 'stem_im2col' in r['Kernel_Name'] or 'stem_pool_fwd' in r['Kernel_Name']]
-    return rows[marks[-2]:marks[-1]]
+    return rows[marks[-1 - PER]:marks[-1]]
 
 
 def counters(d):
