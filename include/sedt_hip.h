@@ -131,7 +131,7 @@ typedef struct SedtIgemm {
 
 int sedt_igemm(const SedtIgemm* args, int dtype, void* stream);
 /* sizeof of an argument struct as THIS library was compiled (0 SedtIgemm, 1 SedtReduceJob, 2 SedtSplitJob, 3 SedtPrefetch, 4 SedtCriterion,
- * 5 SedtMatch, 6 SedtChunk, 7 SedtBnJob, 8 SedtPackJob, 9 SedtFragJob; -1 otherwise): lets a binding verify its mirror of the structs */
+ * 5 SedtMatch, 6 SedtChunk, 7 SedtBnJob, 8 SedtPackJob, 9 SedtFragJob, 10 SedtPoolAt, 11 SedtCopyJob; -1 otherwise): lets a binding verify its mirror of the structs */
 int sedt_sizeof(int which);
 /* njobs (<= 8 per launch) independent trans == 0 problems - e.g. the q / k / v projections of an attention block; one
  * launch when every problem resolves to the 64x64 2-stage bf16 kernel, otherwise njobs sedt_igemm calls.  HOST array. */
@@ -235,6 +235,19 @@ int sedt_add_n(const void* const* srcs, int n, void* out, int64_t numel, int dty
 int sedt_cast(const void* in, int in_dtype, void* out, int out_dtype, int64_t n, void* stream);
 /* out = y > 0 ? g : 0 (ReLU backward), compute dtype, elementwise over n */
 int sedt_relu_mask(const void* g, const void* y, void* out, int64_t n, int dtype, void* stream);
+/* up to 8 strided 2-D copies in one launch (jobs: HOST array, copied into the kernel arguments): `outer` items of `inner` bytes (multiple of 4),
+ * src_stride / dst_stride bytes apart.  The clip-range split of the stacked head outputs [L][B][Q][C] between the two criterion calls of the
+ * mean-teacher step (reference engine.py:134-165 computes a supervised and an unsupervised loss on two forwards; here ONE student forward
+ * covers both clip sets) and the merge of their gradients are one launch each. */
+typedef struct SedtCopyJob {
+  const void* src;
+  void* dst;
+  int64_t src_stride, dst_stride;
+  int32_t outer, inner;
+  int32_t blk0;           /* filled by the library */
+  int32_t pad_;
+} SedtCopyJob;
+int sedt_copy2d(const SedtCopyJob* jobs, int njobs, void* stream);
 /* SP-SEDT decoder input, reference sedt/spsedt.py:48-69 in one launch each way.  patch [B*P][D] (compute dtype: patch2query of the pooled patch
  * features), query f32 [Q][D] (query_embed.weight rows from `start`), out [B*Q][D] token-major (compute dtype):
  *   train: out[b][q] = 2 * query[q] + keep(q, b) * patch[b][q / qpp]     eval: out[b][q] = query[q] + patch[b][q / qpp]

@@ -101,6 +101,7 @@ extern "C" int sedt_sizeof(int which) {
     case 8: return (int)sizeof(SedtPackJob);
     case 9: return (int)sizeof(SedtFragJob);
     case 10: return (int)sizeof(SedtPoolAt);
+    case 11: return (int)sizeof(SedtCopyJob);
     default: return -1;
   }
 }

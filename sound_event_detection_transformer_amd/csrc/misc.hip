@@ -338,6 +338,28 @@ __global__ void sigmoid_grad_kernel(const float* g, const float* s, float* out, 
   if (e < n) out[e] = g[e] * s[e] * (1.f - s[e]);
 }
 
+// ------------------------------------------------------------------ strided 2-D copies, several per launch
+// job: `outer` items of `inner` bytes (a multiple of 4), items src_stride / dst_stride bytes apart.  The mean-teacher step runs ONE student
+// forward over labelled + unlabelled clips and two criterion calls on the clip ranges of its stacked head outputs [L][B][Q][C]
+// (engine.GraphedSemiStep): the six range copies are one launch, and so is the merge of the six gradient parts in the backward (as
+// autograd slices: ~20 torch copy / fill / add launches per step).
+constexpr int COPY_MAXJ = 8;
+struct CopyJobs {
+  int n;
+  SedtCopyJob j[COPY_MAXJ];
+};
+__global__ __launch_bounds__(256) void copy2d_kernel(const CopyJobs jobs) {
+  int i = 0;
+  while (i + 1 < jobs.n && (int)blockIdx.x >= jobs.j[i + 1].blk0) ++i;
+  const SedtCopyJob& J = jobs.j[i];
+  const long w = (long)(blockIdx.x - J.blk0) * 256 + threadIdx.x;          // 4-byte word of the job
+  const long per = J.inner / 4;
+  if (w >= per * J.outer) return;
+  const long o = w / per, k = w - o * per;
+  reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(J.dst) + o * J.dst_stride)[k] =
+      reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(J.src) + o * J.src_stride)[k];
+}
+
 // ------------------------------------------------------------------ SP-SEDT decoder input (reference sedt/spsedt.py:48-69)
 // training: dec_in[b][q] = 2 * query[q] + keep(q, b) * patch[b][q / qpp]     (spsedt.py:65-67: decoder_input += patches * mask + decoder_input)
 // eval:     dec_in[b][q] = query[q] + patch[b][q / qpp]
@@ -1173,6 +1195,24 @@ extern "C" int sedt_cast(const void* in, int in_dtype, void* out, int out_dtype,
     hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, b, 0, S(stream), (const bf16_t*)in, (bf16_t*)out, (long)n);
   else { set_error("cast: bad dtypes %d -> %d", in_dtype, out_dtype); return 1; }
   return check_launch("cast");
+}
+
+extern "C" int sedt_copy2d(const SedtCopyJob* jobs, int njobs, void* stream) {
+  SEDT_REQUIRE(jobs && njobs >= 1 && njobs <= COPY_MAXJ, "copy2d: 1..%d jobs", COPY_MAXJ);
+  CopyJobs a;
+  a.n = njobs;
+  int blk = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const SedtCopyJob& j = jobs[i];
+    SEDT_REQUIRE(j.src && j.dst && j.outer >= 1 && j.inner >= 4 && (j.inner & 3) == 0 && (j.src_stride & 3) == 0 && (j.dst_stride & 3) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(j.src) | reinterpret_cast<uintptr_t>(j.dst)) & 3) == 0,
+                 "copy2d: job %d: outer %d inner %d (bytes, multiples of 4; 4-byte aligned pointers and strides)", i, j.outer, j.inner);
+    a.j[i] = j;
+    a.j[i].blk0 = blk;
+    blk += (int)(((long)j.outer * (j.inner / 4) + 255) / 256);
+  }
+  hipLaunchKernelGGL(copy2d_kernel, dim3(blk), dim3(256), 0, S(stream), a);
+  return check_launch("copy2d");
 }
 
 extern "C" int sedt_spsedt_dec_in(const void* patch, const float* query, const float* keep_in, float* keep_out, void* out, int B, int Q,

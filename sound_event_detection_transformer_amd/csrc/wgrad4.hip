@@ -413,7 +413,10 @@ static bool wg4_cbmajor(const SedtIgemm& p) {
   static int on = -1;
   if (on < 0) {
     const char* e = sedt::dev_getenv("SEDT_WGRAD4_CBMAJOR");
-    on = e ? atoi(e) : 0;
+    // same-box A/B on the C2 step (profiles/r06_ab_wgrad4_cbmajor.txt): FETCH_SIZE of the wgrad4 launches 2.38 -> 2.08 GB (x2-corrected),
+    // their L2 hit rate 0.44 -> 0.50, step 5.142-5.173 -> 5.134-5.168 ms: a seventh less fabric traffic and no measurable time - the
+    // launches are not bound by it.  On by default because it is never slower
+    on = e ? atoi(e) : 1;
   }
   return on && p.conv && p.KH * p.KW > 1 && (p.Ci % 128) == 0 && p.N == p.KH * p.KW * p.Ci;
 }

@@ -813,6 +813,36 @@ def _slice_outputs(out, sl):
     return o
 
 
+def _split_outputs(out, n):
+    """(clips [0, n), clips [n, B)) of a model output dict for two criterion calls: the tensors the fused criterion reads - the stacked
+    head outputs and the audio-tag output - are split by ONE launch into contiguous parts (functional.SplitClipsFn: one more launch merges
+    their gradients), everything else is a view"""
+    from . import functional as Fn
+    if '_stacked' not in out or not out['_stacked'][0].is_cuda:
+        return _slice_outputs(out, slice(0, n)), _slice_outputs(out, slice(n, None))
+    la, ba = out['_stacked']
+    ts, dims = [la, ba], [1, 1]
+    if out.get('at') is not None:
+        ts.append(out['at'])
+        dims.append(0)
+    parts = Fn.SplitClipsFn.apply(n, tuple(dims), *ts)
+    k = len(ts)
+    res = []
+    for half, sl in ((parts[:k], slice(0, n)), (parts[k:], slice(n, None))):
+        q0 = out.get('_q0', 0)
+        lg, bx = half[0], half[1]
+        Q = lg.shape[2] - q0
+        o = {'pred_logits': lg[-1][:, q0:q0 + Q], 'pred_boxes': bx[-1][:, q0:q0 + Q], '_stacked': (lg, bx), '_q0': q0}
+        if k == 3:
+            o['at'] = half[2]
+        o['aux_outputs'] = [{'pred_logits': lg[i][:, q0:q0 + Q], 'pred_boxes': bx[i][:, q0:q0 + Q]} for i in range(lg.shape[0] - 1)]
+        for key, v in out.items():          # whatever else the model returned (e.g. at_p): plain views
+            if torch.is_tensor(v) and key not in o:
+                o[key] = v[sl]
+        res.append(o)
+    return res[0], res[1]
+
+
 class GraphedSemiStep(_GraphedBase):
     """The mean-teacher step (reference engine.py:117-181) as ONE HIP graph: labelled forward + device matching + fused
     loss, teacher forward through the EMA weights (no grad), pseudo labels written by ``sedt_pseudo_labels`` straight into the
@@ -983,7 +1013,7 @@ class GraphedSemiStep(_GraphedBase):
         if self.fuse:
             out = model(self.x_cat)
             n = self.x_lab.shape[0]
-            out_l, out_s = _slice_outputs(out, slice(0, n)), _slice_outputs(out, slice(n, None))
+            out_l, out_s = _split_outputs(out, n)
             self.sup = crit.compute(out_l, crit.prepare_device(out_l, self.tab_l, **self.flags), self.fl)
             total_l = crit.last_total
         else:

@@ -233,6 +233,62 @@ class HeadsFn(Function):
         return (dhs.view(Lh, B, Qp, d), d_wc, d_bc, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3, d_wa, d_ba, None)
 
 
+class SplitClipsFn(Function):
+    """clip ranges [0, n) and [n, B) of tensors laid out [..., B, ...] - the stacked head outputs [L, B, Q, C] and the audio-tag output
+    [B, C] of ONE student forward over labelled + unlabelled clips, handed to the two criterion calls of the mean-teacher step
+    (reference engine.py:134-165) - as contiguous tensors from ONE launch (sedt_copy2d); the backward writes the gradient parts into
+    full-size tensors with ONE launch (every element is covered by exactly one part: no zero fill, no adds).  As autograd slices this
+    is ~20 torch copy / fill / add launches per step.  Inputs: (n, batch_dim_of_each, *tensors); returns (first parts..., second parts...)"""
+
+    @staticmethod
+    def forward(ctx, n, dims, *ts):
+        ctx.set_materialize_grads(False)
+        ts = [t.contiguous() for t in ts]
+        metas, outs_a, outs_b, jobs = [], [], [], []
+        for t, d in zip(ts, dims):
+            B = t.shape[d]
+            outer = 1
+            for s_ in t.shape[:d]:
+                outer *= s_
+            per = t.numel() // (outer * B) * t.element_size()             # bytes of one clip inside one outer item
+            a = torch.empty(t.shape[:d] + (n,) + t.shape[d + 1:], device=t.device, dtype=t.dtype)
+            b = torch.empty(t.shape[:d] + (B - n,) + t.shape[d + 1:], device=t.device, dtype=t.dtype)
+            jobs.append((t.data_ptr(), a.data_ptr(), outer, n * per, B * per, n * per))
+            jobs.append((t.data_ptr() + n * per, b.data_ptr(), outer, (B - n) * per, B * per, (B - n) * per))
+            metas.append((tuple(t.shape), t.dtype, outer, per, B))
+            outs_a.append(a)
+            outs_b.append(b)
+        ops.copy2d(jobs)
+        ctx.n, ctx.metas = n, metas
+        return tuple(outs_a + outs_b)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        k = len(ctx.metas)
+        grads, jobs = [], []
+        for i, (shape, dtype, outer, per, B) in enumerate(ctx.metas):
+            ga, gb = gs[i], gs[k + i]
+            if ga is None and gb is None:
+                grads.append(None)
+                continue
+            n = ctx.n
+            full = torch.empty(shape, device=(ga if ga is not None else gb).device, dtype=dtype)
+            if ga is None or gb is None:
+                full.zero_()
+            if ga is not None:
+                ga = ga.contiguous().to(dtype)
+                jobs.append((ga.data_ptr(), full.data_ptr(), outer, n * per, n * per, B * per))
+            if gb is not None:
+                gb = gb.contiguous().to(dtype)
+                jobs.append((gb.data_ptr(), full.data_ptr() + n * per, outer, (B - n) * per, (B - n) * per, B * per))
+            grads.append(full)
+            ctx.keep = getattr(ctx, 'keep', []) + [ga, gb]
+        if jobs:
+            ops.copy2d(jobs)
+        ctx.keep = None
+        return (None, None) + tuple(grads)
+
+
 class FanoutFn(Function):
     """n handles on one tensor for n independent consumers (SP-SEDT's stacked decoder output feeds the class head, the box MLP and the
     feature-alignment MLP: spsedt.py:79-83).  As plain autograd the consumers' input gradients are added pair by pair (n - 1 elementwise

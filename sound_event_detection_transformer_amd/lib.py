@@ -90,6 +90,11 @@ class SedtSplitJob(C.Structure):
                 ('pattern', C.c_int32), ('blk0', C.c_int32)]
 
 
+class SedtCopyJob(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('src_stride', C.c_int64), ('dst_stride', C.c_int64), ('outer', C.c_int32),
+                ('inner', C.c_int32), ('blk0', C.c_int32), ('pad_', C.c_int32)]
+
+
 class SedtPrefetch(C.Structure):
     _fields_ = [('ptr', C.c_void_p * 3), ('bytes', C.c_size_t * 3)]
 
@@ -123,6 +128,7 @@ SIGNATURES = {
     'sedt_wgrad_reduce': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'sedt_wgrad_reduce_bias': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'sedt_split3': (_i, [C.POINTER(SedtSplitJob), _i, _vp]),
+    'sedt_copy2d': (_i, [C.POINTER(SedtCopyJob), _i, _vp]),
     'sedt_multi_wgrad_reduce': (_i, [C.POINTER(SedtReduceJob), _i, C.POINTER(SedtPrefetch), _vp]),
     'sedt_skinny_linear_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp]),
     'sedt_skinny_linear_bwd_scratch': (_sz, [_i]),

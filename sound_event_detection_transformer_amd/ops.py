@@ -927,6 +927,17 @@ def relu_mask(dtype, g, y):
     return out
 
 
+def copy2d(jobs):
+    """jobs: (src tensor view start, dst tensor view start, outer, inner_bytes, src_stride_bytes, dst_stride_bytes) given as
+    (src_ptr, dst_ptr, outer, inner, sstride, dstride) integers; up to 8 per launch (sedt_copy2d)"""
+    for base in range(0, len(jobs), 8):
+        chunk = jobs[base:base + 8]
+        arr = (L.SedtCopyJob * len(chunk))()
+        for n, (sp, dp, outer, inner, ss, ds) in enumerate(chunk):
+            arr[n].src, arr[n].dst, arr[n].outer, arr[n].inner, arr[n].src_stride, arr[n].dst_stride = sp, dp, outer, inner, ss, ds
+        L.check(L.load().sedt_copy2d(arr, len(chunk), L.stream_ptr()), 'copy2d')
+
+
 def spsedt_dec_in(dtype, patch, query, B, Q, P, qpp, train, ratio=0.0, keep=None, seed=0, seed_ptr=None):
     """SP-SEDT decoder input [B*Q, D] from the patch queries [B*P, D] and the query embedding rows [Q, D] (f32); returns (dec_in, keep
     [Q, B] f32 or None) - reference spsedt.py:48-69 in one launch"""

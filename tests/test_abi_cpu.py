@@ -31,7 +31,7 @@ def test_struct_mirrors_have_the_sizes_the_library_was_compiled_with():
     want = {0: ctypes.sizeof(lib.SedtIgemm), 1: ctypes.sizeof(lib.SedtReduceJob), 2: ctypes.sizeof(lib.SedtSplitJob),
             3: ctypes.sizeof(lib.SedtPrefetch), 4: ctypes.sizeof(lib.SedtCriterion), 5: ctypes.sizeof(lib.SedtMatch),
             6: optim._DT.itemsize, 7: packing._BN.itemsize, 8: packing._PK.itemsize, 9: packing._FJ.itemsize,
-            10: ctypes.sizeof(lib.SedtPoolAt)}
+            10: ctypes.sizeof(lib.SedtPoolAt), 11: ctypes.sizeof(lib.SedtCopyJob)}
     got = {k: l.sedt_sizeof(k) for k in want}
     assert got == want, {k: (got[k], want[k]) for k in want if got[k] != want[k]}
     assert l.sedt_sizeof(99) == -1
