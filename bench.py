@@ -74,6 +74,9 @@ def parse():
                     help='readiness test: pretend the captured data-parallel stepper cannot be built (every rank then has to agree on the '
                          'eager fallback out of band)')
     ap.add_argument('--no-clocks', action='store_true', help='skip the rocm-smi clock reading under load')
+    ap.add_argument('--no-gemm-family', action='store_true',
+                    help='skip the eager recorded step + the back-to-back replay of every GEMM launch (roofline.gemm_family): use under rocprofv3 '
+                         'so that the kernel statistics hold the captured step only')
     ap.add_argument('--no-families', action='store_true',
                     help='skip roofline.families (the in-process kernel trace of three extra steps; use under rocprofv3, which owns the tracer)')
     ap.add_argument('--loader', action='store_true',
@@ -1026,8 +1029,8 @@ def pmc_traffic(config, stamp, kernels_per_step):
     profiles/rNN_pmc_<config>.json) - but only when that profile was taken ON THIS BUILD: its `build_stamp` must equal the running
     sources' stamp (_build.source_stamp) and, when the per-family trace of this run is available, its kernel count per step must
     equal the running step's.  A stale profile yields (None, why)"""
-    for rnd in ('r05', 'r04', 'r03', 'r02'):
-        path = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_{config}.json')
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', f'r*_pmc_{config}.json')), reverse=True):      # newest round first
         try:
             with open(path) as f:
                 prof = json.load(f)
@@ -1149,7 +1152,7 @@ def main():
     #      then replayed back to back on the launch stream between two HIP events
     gemm = None
     gemm_rec = None
-    if args.config in ('c2', 'c3') and not args.model_only:
+    if args.config in ('c2', 'c3') and not args.model_only and not args.no_gemm_family:
         if rank != 0 and world > 1 and not graphed:
             ops.PROFILE = []                      # eager DDP: the extra step contains collectives, every rank must take part
             from sound_event_detection_transformer_amd.engine import train_step
