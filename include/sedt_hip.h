@@ -254,7 +254,8 @@ int sedt_copy2d(const SedtCopyJob* jobs, int njobs, void* stream);
  * keep_in f32 [Q][B] (may be NULL): the Bernoulli(1 - ratio) query-patch mask of spsedt.py:65; NULL = drawn from the counter hash of
  * (seed (+ *seed_ptr), q * B + b), ratio <= 0 keeps every patch.  keep_out f32 [Q][B] (may be NULL) receives the mask used.
  * Backward: d_patch [B*P][D] (compute dtype, may be NULL) = sum over the qpp queries of a patch of keep * g; d_query f32 [Q][D] =
- * (train ? 2 : 1) * sum_b g[b][q], summed in clip order.  D a multiple of 8 (forward), D <= 1024 (backward). */
+ * (train ? 2 : 1) * sum_b g[b][q], a fixed-order sum (four consecutive clip ranges added in clip order, then the four partials in range
+ * order).  D a multiple of 8 (forward); a multiple of 64, <= 256 (backward). */
 int sedt_spsedt_dec_in(const void* patch, const float* query, const float* keep_in, float* keep_out, void* out, int B, int Q, int P, int qpp,
                        int D, int train, float ratio, uint32_t seed, const uint32_t* seed_ptr, int dtype, void* stream);
 int sedt_spsedt_dec_in_bwd(const void* g, const float* keep, void* d_patch, float* d_query, int B, int Q, int P, int qpp, int D, int train,

@@ -14,7 +14,8 @@ rows = list(csv.DictReader(open(f)))
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
 idx = [i for i, e in enumerate(ev) if 'stem_pool_fwd' in e[2] or 'stem_im2col' in e[2]]
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-a, b = idx[-4 * per], idx[-3 * per]
+# a step INSIDE bench.py's timed loop: the last three replays of a run are the host-issue burst that follows the closing barrier (round 6)
+a, b = idx[-6 * per], idx[-5 * per]
 seg = ev[a:b]
 
 
