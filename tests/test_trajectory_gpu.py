@@ -10,7 +10,8 @@ What the curves can and cannot agree on.  The per-step loss is chaotic: AdamW's 
 so weights whose gradient is near zero move by +-lr on rounding noise, and a Hungarian assignment that flips moves a clip's loss at
 once.  Two f32 runs whose initial weights differ by 1e-6 (relative, random) are 1e-2-scale apart after ten steps - as far as the f32 mode
 is from the CPU oracle, and the scale of the bf16-to-f32 distance too.  The test therefore states:
-  * oracle vs f32 mode: steps 1-3 within 1e-4 (before the chaos has grown: the same arithmetic), steps 1-10 within 3e-2;
+  * oracle vs f32 mode: steps 1-2 within 1e-5, step 3 within 5e-4 (before the chaos has grown: the same arithmetic; measured 7e-8, 8e-7,
+    4e-5), steps 1-10 within 5e-2 (measured 1.5e-2; the oracle's own rounding depends on the host's thread count);
   * the chaos floor: f32 against its 1e-6-perturbed twin, per step and on the 8-step moving average (two passes over the batch cycle);
   * bf16 / bf16x3 vs f32 on the moving average: maximum within 3 x the floor's maximum (and 8e-2), MEAN within 2 x the floor's mean + 5e-3;
     per step within 1.5e-1.  (Measured: floor 2.0e-2 max / 5.6e-3 mean; bf16 1.4e-2 / 6.1e-3 - indistinguishable from the floor;
@@ -111,7 +112,7 @@ def test_bf16_and_bf16x3_training_track_f32_over_100_steps_and_the_oracle_over_1
     for c in (f32, twin, x3, bf):
         assert np.all(np.isfinite(c))
     assert drop(f32) > 0.2 * f32[0], 'the f32 run did not train'
-    assert e_or[:3].max() < 1e-4 and e_or.max() < 3e-2, e_or
+    assert e_or[:2].max() < 1e-5 and e_or[2] < 5e-4 and e_or.max() < 5e-2, e_or
     floor, floor_mean = max(smo['twin'].max(), 1e-3), smo['twin'].mean()
     for k in ('bf16', 'bf16x3'):
         assert smo[k].max() < max(3 * floor, 1e-2) and smo[k].max() < 8e-2, (k, smo[k].max(), floor)
