@@ -435,7 +435,10 @@ class GraphedTrainStep(_GraphedBase):
         side = train_stream(dev)
         self._capture = dict(stream=side, **_CAPTURE)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), optimizer.table_set(self._tabname):
+        # gradients another stepper's captured backward left attached to the parameters would be ACCUMULATED into by the warm-up's
+        # eager backward (and the stack-level weight-gradient launches need fresh tensors: ops.defer_layer_wgrads)
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.stream(side), optimizer.table_set(self._tabname), ops.defer_layer_wgrads():
             for _ in range(warmup):                          # eager steps: lazy inits (LDS attributes, optimizer state)
                 if device_matching:
                     self._eager_device_step(example_targets, max_targets)
@@ -458,7 +461,7 @@ class GraphedTrainStep(_GraphedBase):
         self.g_bwd = self.g_opt = None
         self.g_seg, self.flat_parts = [], []
         acc = self.accum_steps > 1
-        with optimizer.table_set(self._tabname):
+        with optimizer.table_set(self._tabname), ops.defer_layer_wgrads():
             if device_matching:
                 self.tables = self._make_tables(example_targets, max_targets)
                 with torch.cuda.graph(self.g_fwd, **self._capture):
@@ -945,7 +948,8 @@ class GraphedSemiStep(_GraphedBase):
         side = train_stream(dev)
         self._capture = dict(stream=side, **_CAPTURE)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), optimizer.table_set(self._tabname):
+        optimizer.zero_grad(set_to_none=True)                 # (see GraphedTrainStep: no stale .grad under the warm-up's eager backward)
+        with torch.cuda.stream(side), optimizer.table_set(self._tabname), ops.defer_layer_wgrads():
             for _ in range(warmup):
                 self._body()
         torch.cuda.current_stream().wait_stream(side)
@@ -966,7 +970,7 @@ class GraphedSemiStep(_GraphedBase):
         self.graph = torch.cuda.CUDAGraph()
         self.g_opt = self.g_ema = None
         self.g_seg, self.flat_parts = [], []
-        with optimizer.table_set(self._tabname):
+        with optimizer.table_set(self._tabname), ops.defer_layer_wgrads():
             with torch.cuda.graph(self.graph, **self._capture):
                 self._body(part='fwd_bwd' if self.flat_mode else 'all')
             for k in range(1, len(self.segs or [])):          # data parallel: one graph per further segment of the backward

@@ -650,7 +650,11 @@ class EncoderLayerFn(Function):
         dt = cfg['dt']
         (w_in, b_in, w_o, b_o, w1, b1, w2, b2, g1, be1, g2, be2) = P
         gx2 = _as(gx2, dt)
-        rb = ops.ReduceBatch()
+        # weight gradients: this layer's own grouped launch + reduce launch, or - per-op path inside a captured stepper - the stack's
+        # shared batch, launched once when the backward leaves the stack (ops.WgradShare).  The slab path keeps its per-layer reduce
+        # launch: that launch also touches the weights the layer below streams first
+        share = cfg.get('wg_share') if not (sv.get('slab') is not None and ops.SLAB_ENC_BWD) else None
+        rb = share.batch() if share is not None else ops.ReduceBatch()
         if sv.get('slab') is not None and ops.SLAB_ENC_BWD:
             # the input-gradient chain on the slab kernels: [FFN + LayerNorm2 + out-proj] | attention core | [in-proj + LayerNorm1];
             # the weight gradients stay the layer's one grouped GEMM launch + one reduce launch
@@ -704,7 +708,10 @@ class EncoderLayerFn(Function):
                                                        drop=_drop_args(sv['mha'], dev))
             g_qk, _, g_v, d_win, d_bin, d_wo, d_bo = _mha_bwd(dt, sv['mha'], g_t, w_in, w_o, batch=rb, g_dropped=g_td)
             gx = ops.add(dt, ops.add(dt, g_qk, g_v), g_t)
-        rb.flush()
+        if share is not None:
+            share.layer_done(last=cfg.get('layer_idx', 0) == 0)
+        else:
+            rb.flush()
         ctx.sv = None
         return (gx, None, None, None, None, d_win, d_bin, d_wo, d_bo, d_w1, d_b1, d_w2, d_b2, d_g1, d_be1, d_g2, d_be2)
 
@@ -754,7 +761,8 @@ class DecoderLayerFn(Function):
         dt = cfg['dt']
         (sw_in, sb_in, sw_o, sb_o, cw_in, cb_in, cw_o, cb_o, w1, b1, w2, b2, g1, be1, g2, be2, g3, be3) = P
         gt3 = _as(g3_, dt)
-        rb = ops.ReduceBatch()
+        share = cfg.get('wg_share')
+        rb = share.batch() if share is not None else ops.ReduceBatch()
         if cfg['pre_norm']:
             g_t2n, d_w1, d_b1, d_w2, d_b2 = _ffn_bwd(dt, sv['ffn'], gt3, w1, w2, batch=rb)
             gt2, d_g3, d_be3, gt2d = ops.layernorm_bwd(dt, g_t2n, sv['t2'], g3, sv['m3'], sv['r3'], dres=gt3, batch=rb,
@@ -801,7 +809,10 @@ class DecoderLayerFn(Function):
             g_qpos = ops.add(dt, g_qpos, g_qk)
         # the first decoder layer's backward is the last thing before the encoder's: its reduce launch touches the weights the top encoder
         # layer's backward streams first (only LayerNorm launches follow it)
-        rb.flush(prefetch=sv.get('bwd_next'))
+        if share is not None:
+            share.layer_done(last=cfg.get('layer_idx', 0) == 0, prefetch=sv.get('bwd_next'))
+        else:
+            rb.flush(prefetch=sv.get('bwd_next'))
         ctx.sv = None
         return (gtgt, g_mem, g_mem_pos, g_qpos, None, None, None,
                 d_swin, d_sbin, d_swo, d_sbo, d_cwin, d_cbin, d_cwo, d_cbo, d_w1, d_b1, d_w2, d_b2,

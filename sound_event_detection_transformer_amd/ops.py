@@ -661,9 +661,14 @@ class ReduceBatch(object):
     Inside a runtime.async_wgrad() scope the wgrad GEMMs themselves are deferred too: flush() then issues all of them
     plus the reduction as ONE block on the side stream (one fork per layer instead of one per GEMM)."""
 
-    def __init__(self):
+    def __init__(self, shared=False):
+        """shared: this batch outlives the backward of the layer that fills it (WgradShare): it then holds NO reference to the gradient
+        tensors - autograd's AccumulateGrad steals a gradient whose reference count is 1 and CLONES one that is still referenced, and a
+        clone taken before the deferred launch has written the tensor would be garbage"""
         self.jobs, self.keep, self.deferred, self.operands = [], [], [], []
         self.group, self.group_dtype = [], None
+        self.shared = shared
+        self.expect = []            # shared: (parameter, data_ptr of the gradient tensor handed to autograd) - checked at the final flush
 
     def add_gemm(self, dtype, args, shape, code=None):
         """a weight-gradient GEMM to be issued with the others of this batch in one grouped launch.  code: the dtype code the entry point
@@ -702,8 +707,8 @@ class ReduceBatch(object):
         j.colsum_slab = cs.data_ptr() if cs is not None else None
         j.bias_out = bias_out.data_ptr() if (cs is not None and bias_out is not None) else None
         self.jobs.append(j)
-        self.keep.append((slab, cs, rowscale, out, bias_out))
-        if len(self.jobs) == L.MAX_REDUCE_JOBS and not _co['on']:
+        self.keep.append((slab, cs, rowscale, None, None) if self.shared else (slab, cs, rowscale, out, bias_out))
+        if len(self.jobs) == L.MAX_REDUCE_JOBS and not _co['on'] and not self.shared:
             self._launch_group()
             self._launch()
 
@@ -712,7 +717,7 @@ class ReduceBatch(object):
         j = L.SedtReduceJob()
         j.colsum_slab, j.bias_out, j.splitk, j.R, j.taps, j.Ci = partial.data_ptr(), out.data_ptr(), nrows, ncols, 1, 0
         self.jobs.append(j)
-        self.keep.append((partial, None, None, out, None))
+        self.keep.append((partial, None, None, None if self.shared else out, None))
 
     def _launch(self):
         for i in range(0, len(self.jobs), L.MAX_REDUCE_JOBS):
@@ -725,6 +730,14 @@ class ReduceBatch(object):
         self.jobs, self.keep = [], []
 
     prefetch = None
+
+    def collect(self):
+        """shared batches, at the end of a layer's backward: run the layer's deferred bodies NOW - they allocate the split-K slabs and
+        build the argument blocks, nothing is launched (bf16x3: the operand splits are) - so that no closure keeps the gradient tensors
+        referenced when the layer returns them to autograd.  The launches happen in the stack's final flush."""
+        for body in self.deferred:
+            body()
+        self.deferred = []
 
     def flush(self, prefetch=None):
         """prefetch: up to three tensors (weights) the launch AFTER this batch's reduce launch will stream: that launch touches them"""
@@ -749,6 +762,66 @@ class ReduceBatch(object):
         else:
             self._launch_group()
             self._launch()
+
+
+DEFER_LAYER_WGRADS = _dev_env('SEDT_DEFER_LAYER_WGRADS', '1') != '0'
+_defer = {'on': False}
+
+
+class defer_layer_wgrads(object):
+    """scope (the captured steppers' bodies): the weight gradients of ALL layers of a transformer stack are issued as ONE grouped GEMM
+    launch + ONE reduce launch when the backward leaves the stack, instead of two launches per layer (three decoder layers at M = 704
+    rows: 6 latency-bound launches -> 2; six per-op encoder layers of the B = 32 configurations: 12 -> 2).  Only inside a stepper: the
+    gradients a layer returns are written later in stream order, which a consumer that reads them at AccumulateGrad time (torch DDP's
+    hooks on the eager path) must not see."""
+
+    def __init__(self, enable=True):
+        self.enable = bool(enable) and DEFER_LAYER_WGRADS
+
+    def __enter__(self):
+        self.prev = _defer['on']
+        _defer['on'] = self.enable
+        return self
+
+    def __exit__(self, *exc):
+        _defer['on'] = self.prev
+        return False
+
+
+class WgradShare(object):
+    """the ReduceBatch shared by the layers of one stack in one forward / backward pass (functional.EncoderLayerFn / DecoderLayerFn,
+    cfg['wg_share']); None-safe helpers keep the layers' code paths identical with and without it"""
+
+    def __init__(self):
+        self.rb = None
+        self.mark = 0               # rb.expect[:mark]: gradients of layers whose AccumulateGrad nodes have run by now
+
+    @staticmethod
+    def make():
+        return WgradShare() if (_defer['on'] and not _co['on']) else None
+
+    def batch(self):
+        if self.rb is None:
+            self.rb = ReduceBatch(shared=True)
+        return self.rb
+
+    def layer_done(self, last, prefetch=None):
+        """end of a layer's backward; last: this is the last layer of the stack to run (layer 0)"""
+        rb = self.rb
+        if rb is None:
+            return
+        rb.collect()
+        if last:
+            for param, ptr in rb.expect[:self.mark]:          # (this layer's own gradients reach AccumulateGrad after it returns)
+                g = param.grad                                # None: torch.autograd.grad captured the tensor itself (the DP segments)
+                if g is not None and g.data_ptr() != ptr:
+                    raise RuntimeError('a deferred weight gradient was cloned or accumulated by autograd before it was written: '
+                                       'defer_layer_wgrads needs parameters whose .grad is None when the backward starts')
+            rb.expect = []
+            rb.flush(prefetch=prefetch)
+            self.rb, self.mark = None, 0
+        else:
+            self.mark = len(rb.expect)
 
 
 GRAD_SINK = None      # {parameter data_ptr: f32 view}: where the weight gradient of that parameter is to be written (grad_sink())
@@ -803,10 +876,12 @@ def wgrad(dtype, dy, x, B, g, rowscale=None, out=None, bias_out=None, batch=None
     lib = L.load()
     Mo, No, Kp = g.Co, g.taps * g.Ci, B * g.Ho * g.Wo
     sk = lib.sedt_igemm_splitk(Mo, No, Kp, dtype)
+    own_out = False                     # allocated here (not the caller's buffer, not a slot of the flat gradient buffer)
     if out is None:
         out = _sink(param, (g.Co, g.Ci, g.KH, g.KW))
-    if out is None:
-        out = torch.empty((g.Co, g.Ci, g.KH, g.KW), device=dy.device, dtype=torch.float32)
+        if out is None:
+            out = torch.empty((g.Co, g.Ci, g.KH, g.KW), device=dy.device, dtype=torch.float32)
+            own_out = True
 
     def body():
         conv = None if g.plain else _geom_tuple(g)
@@ -849,6 +924,8 @@ def wgrad(dtype, dy, x, B, g, rowscale=None, out=None, bias_out=None, batch=None
 
     if batch is not None:
         batch.defer(body, (dy, x, rowscale))              # issued by batch.flush(): one grouped launch for the whole layer
+        if batch.shared and param is not None and own_out and tuple(param.shape) == tuple(out.shape[:param.dim()]):
+            batch.expect.append((param, out.data_ptr()))      # (checked at the stack's final flush: autograd must have STOLEN this tensor)
     else:
         with runtime.side(dy, x, rowscale):               # off the dgrad critical path when runtime.async_wgrad is on
             body()

@@ -55,10 +55,11 @@ class TransformerEncoderLayer(nn.Module):
                 self.linear1.bias, self.linear2.weight, self.linear2.bias, self.norm1.weight, self.norm1.bias,
                 self.norm2.weight, self.norm2.bias)
 
-    def forward_tokens(self, x, pos, kpm, B, S, src_mask=None, chain=None):
-        """chain (ops.BackwardChain or None): links this layer's backward to the one that runs after it (weight prefetch hints)"""
+    def forward_tokens(self, x, pos, kpm, B, S, src_mask=None, chain=None, wg_share=None, layer_idx=0):
+        """chain (ops.BackwardChain or None): links this layer's backward to the one that runs after it (weight prefetch hints);
+        wg_share (ops.WgradShare or None): the stack's shared weight-gradient batch, flushed by layer 0's backward"""
         cfg = dict(dt=runtime.compute_dtype(), B=B, S=S, H=self.nhead, dropout=self.p, training=self.training,
-                   pre_norm=self.normalize_before, chain=chain, act=self.activation)
+                   pre_norm=self.normalize_before, chain=chain, act=self.activation, wg_share=wg_share, layer_idx=layer_idx)
         return Fn.EncoderLayerFn.apply(x, pos, kpm, src_mask, cfg, *self.params())
 
     def forward(self, src, src_mask: Optional[Tensor] = None, src_key_padding_mask: Optional[Tensor] = None,
@@ -97,13 +98,14 @@ class TransformerDecoderLayer(nn.Module):
                 self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.norm3.weight, self.norm3.bias)
 
     def forward_tokens(self, tgt, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask=None, kv_fused=False, out=None, acc=None, share=None,
-                       layer_idx=0, chain=None):
+                       layer_idx=0, chain=None, wg_share=None):
         """kv_fused: mem_pos is mem + a constant (the decoder's own sine position add): the key and value input gradients
         of the cross-attention are returned as ONE tensor on `mem` (one K = 2E GEMM) and nothing on `mem_pos`.
         acc: (GradAccumulator for mem, GradAccumulator for qpos) shared by the layers of one decoder pass, or None"""
         cfg = dict(kv_fused=kv_fused, dt=runtime.compute_dtype(), B=B, S=S, Q=Q, H=self.nhead, dropout=self.p, training=self.training,
                    pre_norm=self.normalize_before, out=out, acc_mem=None if acc is None else acc[0],
-                   acc_qpos=None if acc is None else acc[1], share=share, layer_idx=layer_idx, chain=chain, act=self.activation)
+                   acc_qpos=None if acc is None else acc[1], share=share, layer_idx=layer_idx, chain=chain, act=self.activation,
+                   wg_share=wg_share)
         return Fn.DecoderLayerFn.apply(tgt, mem, mem_pos, qpos, kpm, tgt_mask, cfg, *self.params())
 
 
@@ -119,8 +121,13 @@ class TransformerEncoder(nn.Module):
         self.norm = norm
 
     def forward_tokens(self, x, pos, kpm, B, S, chain=None):
-        for layer in self.layers:
-            x = layer.forward_tokens(x, pos, kpm, B, S, chain=chain)
+        from .. import ops
+        # one weight-gradient launch pair for the whole stack (inside a captured stepper, when every layer trains: the launch is issued
+        # by layer 0's backward, which must therefore run)
+        wg = ops.WgradShare.make() if (torch.is_grad_enabled() and len(self.layers) > 1
+                                       and all(p.requires_grad for l in self.layers for p in l.parameters())) else None
+        for li, layer in enumerate(self.layers):
+            x = layer.forward_tokens(x, pos, kpm, B, S, chain=chain, wg_share=wg, layer_idx=li)
         if self.norm is not None:
             x = Fn.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, runtime.compute_dtype())
         return x
@@ -151,10 +158,12 @@ class TransformerDecoder(nn.Module):
         acc = ((Fn.GradAccumulator(n), Fn.GradAccumulator(n)) if (torch.is_grad_enabled() and all(l.normalize_before for l in self.layers)
                                                                   and not pos.requires_grad) else None)
         share = {} if (stack is not None and acc is not None) else None      # (see functional.StackViewFn)
+        from .. import ops
+        wg = ops.WgradShare.make() if (torch.is_grad_enabled() and n > 1 and all(p.requires_grad for l in self.layers for p in l.parameters())) else None
         for li, layer in enumerate(self.layers):
             out = layer.forward_tokens(out, mem, mem_pos, qpos, kpm, B, S, Q, tgt_mask, kv_fused=not pos.requires_grad,
                                        out=None if stack is None else stack[li * R:(li + 1) * R], acc=acc, share=share, layer_idx=li,
-                                       chain=chain)
+                                       chain=chain, wg_share=wg)
             outs.append(out)
         if self.return_intermediate:
             stacked = Fn.StackViewFn.apply(stack, share, *outs) if stack is not None else (torch.cat(outs) if n > 1 else outs[0])
