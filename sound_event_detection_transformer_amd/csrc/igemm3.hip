@@ -84,8 +84,11 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   const float* resF = f32ep ? reinterpret_cast<const float*>(p.res) : nullptr;
   const float* maskF = (f32ep && !mbits) ? reinterpret_cast<const float*>(p.mask) : nullptr;
   const uint8_t* maskB = mbits ? reinterpret_cast<const uint8_t*>(p.mask) : nullptr;
-  bf16x8 res_pf[NCH], mask_pf[NCH];
-  uint32_t mbit_pf[NCH];
+  // LATE (256-row tiles): 128 accumulators + fragments leave no room for the prefetched chunks of a 256-row epilogue (the first attempt
+  // spilled 293 VGPRs): the epilogue operands are read where they are used, as the f32 epilogue does
+  constexpr bool LATE = BM > 128;
+  bf16x8 res_pf[LATE ? 1 : NCH], mask_pf[LATE ? 1 : NCH];
+  uint32_t mbit_pf[LATE ? 1 : NCH];
   // omap (conv problems only): GEMM row (n, ho, wo) of the problem's Ho x Wo output grid lands on pixel (ho * o_sh + o_h0, wo * o_sw + o_w0)
   // of an o_Hi x o_Wi image - C, res, mask and bits_out are all indexed by that pixel.  One parity class of a stride-2 input
   // gradient writes every second row / column of dx this way (ops.conv_dgrad).
@@ -96,6 +99,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
     return ((long)n * p.o_Hi + ho * p.o_sh + p.o_h0) * p.o_Wi + wo * p.o_sw + p.o_w0;
   };
+  if constexpr (!LATE) {
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     const int u = t + c * NT;
@@ -110,6 +114,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       if (maskT) mask_pf[c] = *reinterpret_cast<const bf16x8*>(maskT + orow * p.ldm + col);
       if (maskB) mbit_pf[c] = maskB[orow * p.ldm + (col >> 3)];
     }
+  }
   }
 
   // ---- per-lane DMA rows
@@ -481,7 +486,14 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       }
     }
     if (resT) {
-      const bf16x8 rv = res_pf[c];
+      bf16x8 rv;
+      if constexpr (LATE) {
+        long rrow = orow;
+        if (p.res_mod > 0) rrow = orow % p.res_mod;
+        rv = *reinterpret_cast<const bf16x8*>(resT + rrow * p.ldr + col);
+      } else {
+        rv = res_pf[c];
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
     }
@@ -497,7 +509,9 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
     if (maskT) {
-      const bf16x8 mv = mask_pf[c];
+      bf16x8 mv;
+      if constexpr (LATE) mv = *reinterpret_cast<const bf16x8*>(maskT + orow * p.ldm + col);
+      else mv = mask_pf[c];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ((float)mv[e] > 0.f) ? v[e] : 0.f;
     }
@@ -509,7 +523,9 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       for (int e = 0; e < 8; ++e) v[e] = mv[e] > 0.f ? v[e] : 0.f;
     }
     if (maskB) {
-      const uint32_t mb = mbit_pf[c];
+      uint32_t mb;
+      if constexpr (LATE) mb = maskB[orow * p.ldm + (col >> 3)];
+      else mb = mbit_pf[c];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ((mb >> e) & 1u) ? v[e] : 0.f;
     }
@@ -881,6 +897,7 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
     SEDT_PP(64, 128)
     SEDT_PP(128, 128)
     SEDT_PP(128, 64)
+    if (bm == 256 && bn == 128 && S >= 3) return launch3_w8<256, 128, 3, 1>(p, a_bytes, b_bytes, st);
 #undef SEDT_PP
   }
   if (!plan3.on && co_group == nullptr && nw_env != 4 && !force4) {
@@ -967,6 +984,17 @@ int igemm_lds_try(const SedtIgemm& p, hipStream_t st) {
       bm128t = e ? atoi(e) : 256;
     }
     if (bn == 128 && p.K >= bm128k && (long)((p.M + 127) / 128) * (p.N / 128) >= bm128t && !igemm3_planning()) bm = 128;
+    // the wide outputs of layer4 (conv3 and the projection: N = 2048) with a short K (512 / 1024 = 8 / 16 K tiles) are prologue- and
+    // epilogue-dominated on 64x128 tiles (2048 of them at M = 8192): a 256x128 tile (85 flop per staged byte instead of 43, 512 tiles =
+    // two per CU) with the epilogue operands read late (SEDT_IGEMM_BM256=0/1 in the developer build)
+    static int bm256 = -1;
+    if (bm256 < 0) {
+      const char* e = sedt::dev_getenv("SEDT_IGEMM_BM256");
+      bm256 = e ? atoi(e) : 0;
+    }
+    if (bm256 && bn == 128 && bm == 64 && p.K >= 512 && p.K <= 1024 && (p.M % 256) == 0 && (long)(p.M / 256) * (p.N / 128) >= 512 &&
+        !igemm3_planning() && !p.f32ep)
+      bm = 256;
   }
   {   // the lean-issue kernel takes the common cases
     int r3 = igemm3_try(p, (unsigned)a_bytes, (unsigned)b_bytes, bm, bn, st);
