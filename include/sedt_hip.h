@@ -127,6 +127,8 @@ typedef struct SedtIgemm {
   int32_t awrap;          /* bf16x3, trans == 0: the A rows hold [hi | lo] = 2 awrap channels while the contraction walks 3 awrap per pixel
                              (K = 3 awrap, a convolution: Ci = 3 awrap): the last third re-reads hi.  0 = off */
   int32_t pad2_;
+  const void* bfrag;      /* or null: the fragment-major image (sedt_pack_frag) of the WHOLE B operand [N][ldb] (trans == 0, bf16): kernels
+                             that stream B from L2 into registers read it instead of B (developer build only so far) */
 } SedtIgemm;
 
 int sedt_igemm(const SedtIgemm* args, int dtype, void* stream);

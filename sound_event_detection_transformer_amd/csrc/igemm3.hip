@@ -21,6 +21,24 @@
 namespace sedt {
 
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+#ifdef SEDT_DEV
+// developer build only: shader-clock stamps of a workgroup's phases (start, K loop entered, K loop left, stores issued) and the constant
+// 100 MHz clock at its start, for the first 4096 workgroups of the most recent igemm3 launch (tools/dev/r06_phase_ts.py)
+__device__ unsigned long long g_phase_ts[5 * 4096];
+__device__ int g_ts_filter[3];      // (M, N, K) of the only problem that records, or M = 0: every launch records (sedt_dev_ts_filter)
+// (the filter is read ONCE, before the first stamp: a reload per stamp would charge an L2 miss to every phase of a launch inside a step)
+#define SEDT_TS_INIT() \
+  const bool ts_on_ = threadIdx.x == 0 && bx < 4096 && (g_ts_filter[0] == 0 || (g_ts_filter[0] == p.M && g_ts_filter[1] == p.N && g_ts_filter[2] == p.K))
+#define SEDT_TS(i_, v_)                              \
+  do {                                               \
+    if (ts_on_) g_phase_ts[bx * 5 + (i_)] = (v_);    \
+  } while (0)
+#else
+#define SEDT_TS_INIT() do {} while (0)
+#define SEDT_TS(i_, v_) do {} while (0)
+#endif
 
 // S = ring depth (stages); bx = index of this workgroup among the problem's tiles; NW = waves per workgroup: 4, or 8 = two
 // groups of four that each own the full output tile but only half of the k16 steps of every K tile (their accumulators are
@@ -33,24 +51,32 @@ __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_read
 // KH = 2 (8 waves, ping-pong only): TWO such 8-wave teams in one 1024-thread workgroup, each with its own ring, each over one half
 // of K; the four wave groups' partial sums meet in the epilogue.  For the problems with exactly one 64x128 tile per CU
 // (M = 8192, N = 256: layer3, the FFN's second linear) it doubles the waves per SIMD without shrinking the tile.
-template <int BM, int BN, int S, int NW, bool CONV, int PP = 0, int KH = 1>
+// BR = 1 (8 waves, ping-pong, BN = 128; round 6, review item 6b): the B operand (a weight) does not pass through LDS at all - every wave
+// owns a 32-column strip of the tile over all BM rows and reads its B fragments straight from L2 into registers out of the FRAGMENT-MAJOR
+// image of the operand (SedtIgemm.bfrag, the layout of sedt_pack_frag: one contiguous KB per (32 rows, k16 step)), S tiles ahead like the
+// ring; the ring holds A only.  LDS-DMA then fills a third (64x128) or half (128x128) of the bytes per K tile.
+template <int BM, int BN, int S, int NW, bool CONV, int PP = 0, int KH = 1, int BR = 0>
 __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int bx) {
-  constexpr int WM = BM / 2, WN = BN / 2, MI = WM / 32, NI = WN / 32;
-  constexpr int STAGE_BYTES = (BM + BN) * ROWB;
-  constexpr int GA = BM / (8 * NW), GB = BN / (8 * NW);
+  constexpr int WM = BR ? BM : BM / 2, WN = BR ? BN / 4 : BN / 2, MI = WM / 32, NI = WN / 32;
+  constexpr int STAGE_BYTES = (BM + (BR ? 0 : BN)) * ROWB;
+  constexpr int GA = BM / (8 * NW), GB = BR ? 0 : BN / (8 * NW);
   constexpr int NT = NW * KH * 64;
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   static_assert(KH == 1 || (KH == 2 && NW == 8 && PP), "two K halves: the ping-pong 8-wave form only");
-  static_assert(GA >= 1 && GB >= 1, "tile too small for the wave count");
+  static_assert(GA >= 1 && (BR || GB >= 1), "tile too small for the wave count");
+  static_assert(!BR || (NW == 8 && PP && KH == 1 && BN == 128), "register-streamed B: the 8-wave ping-pong form, 128 columns");
   constexpr unsigned OOB = 0x80000000u;          // >= 2^31 > num_records; stays out of range after adding any K offset
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  SEDT_TS_INIT();
+  SEDT_TS(0, __builtin_amdgcn_s_memtime());
+  SEDT_TS(4, __builtin_amdgcn_s_memrealtime());
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave_all = uniform_i32(t >> 6);
   const int khalf = KH == 2 ? wave_all >> 3 : 0;       // which half of K (and which ring) this wave's team works on
   const int wave = KH == 2 ? (wave_all & 7) : wave_all;
   const int kgrp = wave >> 2;                          // 0, or 0/1 with 8 waves: which half of the k16 steps
-  const int wm = ((wave & 3) >> 1) * WM, wn = (wave & 1) * WN;
+  const int wm = BR ? 0 : ((wave & 3) >> 1) * WM, wn = BR ? (wave & 3) * WN : (wave & 1) * WN;
   unsigned char* const ring = smem + khalf * (S * STAGE_BYTES);
 
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
@@ -117,6 +143,28 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   }
   }
 
+  // the per-column operands (folded FrozenBN scale / bias): read in the epilogue they cost it one exposed L2 round trip (≈ 450 of its ≈ 4300
+  // clocks on the 64x128 tile, tools/dev/r06_phase_ts.py).  The 8-wave kernels have the 16 registers to hold them across the K loop; on the 4-wave
+  // 64x64 kernel they would cost a wave of occupancy per SIMD (108 -> 148 VGPRs), so it keeps reading them late
+  static_assert(NT % CPR == 0, "column of a thread's chunks must not depend on the chunk");
+  constexpr bool EARLY_AFFINE = NW == 8 && !LATE;
+  const int ccol = n0 + (t % CPR) * 8;
+  const bool col_ok = ccol < p.N;
+  float sc8[8], bi8[8];
+  auto load_affine = [&]() {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc8[e] = 1.f; bi8[e] = 0.f; }
+    if (col_ok && p.scale) {
+      const float4 s0 = *reinterpret_cast<const float4*>(p.scale + ccol), s1 = *reinterpret_cast<const float4*>(p.scale + ccol + 4);
+      sc8[0] = s0.x; sc8[1] = s0.y; sc8[2] = s0.z; sc8[3] = s0.w; sc8[4] = s1.x; sc8[5] = s1.y; sc8[6] = s1.z; sc8[7] = s1.w;
+    }
+    if (col_ok && p.bias) {
+      const float4 s0 = *reinterpret_cast<const float4*>(p.bias + ccol), s1 = *reinterpret_cast<const float4*>(p.bias + ccol + 4);
+      bi8[0] = s0.x; bi8[1] = s0.y; bi8[2] = s0.z; bi8[3] = s0.w; bi8[4] = s1.x; bi8[5] = s1.y; bi8[6] = s1.z; bi8[7] = s1.w;
+    }
+  };
+  if constexpr (EARLY_AFFINE) load_affine();
+
   // ---- per-lane DMA rows
   const int lrow = lane >> 3, pc = lane & 7;
   const int taps = CONV ? p.KH * p.KW : 1;
@@ -160,7 +208,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     if (!CONV && !mask) a_off[i] = OOB;        // plain rows beyond M: the offset itself is out of range, no per-tile test
     a_mask[i] = mask;
   }
-  unsigned b_off[GB];
+  unsigned b_off[GB ? GB : 1];
 #pragma unroll
   for (int i = 0; i < GB; ++i) {
     const int trow = (i * NW + wave) * 8 + lrow;
@@ -168,6 +216,13 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     const int swz = (pc ^ ((trow >> 1) & 7)) * 8;
     b_off[i] = row < p.N ? (unsigned)(((long)row * p.ldb + swz) * 2) : OOB;
   }
+  // BR: byte offset of this lane's 16 bytes inside the wave's first fragment block of a K tile: block (n / 32, k / 16) of the image is the KB at
+  // ((n / 32) * (ldb / 16) + k / 16) * 1024; the wave group's two k16 steps of a tile are neighbours
+  __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BR ? p.bfrag : p.B), 0,
+                                                                 BR ? (unsigned)((long)p.N * p.ldb * 2) : b_bytes, 0x00020000);
+  const unsigned f_off = (BR && n0 + wn < p.N) ? ((unsigned)((n0 + wn) >> 5) * (unsigned)(p.ldb >> 4) + 2u * (unsigned)kgrp) * 1024u + (unsigned)lane * 16u
+                                               : OOB;
+  u32x4 fbr[BR ? S : 1][2];
 
   // ---- wave-uniform K position: channel offset inside the tap, tap index, its pixel shift in bytes
   int c0 = 0, tap = 0, kh = 0, kw = 0, k0 = kb0 * BK2;
@@ -229,6 +284,11 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   auto issue = [&](const int stage) {
 #pragma unroll
     for (int i = 0; i < GA + GB; ++i) issue_piece(stage, i);
+    if constexpr (BR) {            // the tile's two B fragments of this wave: wave-uniform K position as the scalar offset (64 bytes per k)
+      const int kpos = (CONV && p.btap_on) ? cur_bt + c0 : k0;
+      fbr[stage][0] = __builtin_amdgcn_raw_buffer_load_b128(rsF, f_off, kpos * 64, 0);
+      fbr[stage][1] = __builtin_amdgcn_raw_buffer_load_b128(rsF, f_off + 1024u, kpos * 64, 0);
+    }
     advance();
   };
 
@@ -268,26 +328,31 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     for (int kq = 0; kq < NKQ; ++kq) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) fa[kq][i] = *reinterpret_cast<const bf16x8*>(st + a_rd[kq][i]);
+      if constexpr (!BR) {
 #pragma unroll
-      for (int j = 0; j < NI; ++j) fb[kq][j] = *reinterpret_cast<const bf16x8*>(st + b_rd[kq][j]);
+        for (int j = 0; j < NI; ++j) fb[kq][j] = *reinterpret_cast<const bf16x8*>(st + b_rd[kq][j]);
+      }
     }
   };
-  auto mfma_all = [&]() {
+  auto mfma_all = [&](const int stage) {
 #pragma unroll
     for (int kq = 0; kq < NKQ; ++kq)
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kq][i], fb[kq][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NI; ++j) {
+          if constexpr (BR) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kq][i], __builtin_bit_cast(bf16x8, fbr[stage][kq]), acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kq][i], fb[kq][j], acc[i][j], 0, 0, 0);
+        }
   };
   auto compute = [&](const int stage) {
     load_frags(stage);
-    mfma_all();
+    mfma_all(stage);
   };
   // ---- S-stage pipeline, unrolled by the ring depth (stage indices are literals after unrolling).  A wave waits only for
   //      its own oldest tile: (S-2) later tiles x G DMA instructions may stay in flight.
-  constexpr int G = GA + GB;
+  SEDT_TS(1, __builtin_amdgcn_s_memtime());
+  constexpr int G = GA + GB + (BR ? 2 : 0);            // vector-memory operations of one tile and wave: LDS-DMA pieces + register loads, in issue order
   if constexpr (PP) {
     // Ping-pong: every stage is two barrier-delimited segments - "load" (fragment reads of tile s, LDS-DMA issue of tile
     // s+S-1) and "math" (the MFMAs of tile s) - and the second wave group runs ONE BARRIER behind the first, so on every
@@ -316,7 +381,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         lds_barrier();
         __builtin_amdgcn_s_setprio(1);
-        mfma_all();
+        mfma_all(ph);
         __builtin_amdgcn_s_setprio(0);
       }
     }
@@ -333,7 +398,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           lds_barrier();
           __builtin_amdgcn_s_setprio(1);
-          mfma_all();
+          mfma_all(ph);
           __builtin_amdgcn_s_setprio(0);
         }
       }
@@ -360,7 +425,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       lds_barrier();
       load_frags(ph);
       issue((ph + S - 1) % S);
-      mfma_all();
+      mfma_all(ph);
     }
   }
   for (; S > 1 && it + S <= nkb; it += S) {
@@ -372,7 +437,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       lds_barrier();
       load_frags(ph);
       if (more) issue((ph + S - 1) % S);
-      mfma_all();
+      mfma_all(ph);
     }
   }
 #pragma unroll
@@ -384,13 +449,14 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
     }
   }
   lds_barrier();
+  SEDT_TS(2, __builtin_amdgcn_s_memtime());
 
   // ---- epilogue through LDS (identical to igemm2)
   constexpr int CP = BN + 4;
   // 8 waves: the two groups hold the two halves of the K sum.  When the ring has room for two staging tiles each group
   // writes its own and the chunk loop adds them (one phase, one barrier); otherwise the second group adds into the first
   // group's tile in a second phase.
-  constexpr bool TWO_CS = NW == 8 && (size_t)KH * S * (BM + BN) * ROWB >= (size_t)2 * KH * BM * CP * sizeof(float);
+  constexpr bool TWO_CS = NW == 8 && (size_t)KH * S * STAGE_BYTES >= (size_t)2 * KH * BM * CP * sizeof(float);
   static_assert(KH == 1 || TWO_CS, "two K halves: the rings must hold the four staging tiles");
   float* Cs = reinterpret_cast<float*>(smem);
   float* Cs2 = Cs + BM * CP;
@@ -428,20 +494,7 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
   bf16_t* outT = reinterpret_cast<bf16_t*>(p.C);
   // a thread's chunks all sit in the same 8 columns (NT is a multiple of the chunks per row): per-column operands once.
   // The K <= 256 problems are instruction-issue bound in this epilogue (PMC: 17 VALU per MFMA), so it is kept lean.
-  static_assert(NT % CPR == 0, "column of a thread's chunks must not depend on the chunk");
-  const int ccol = n0 + (t % CPR) * 8;
-  const bool col_ok = ccol < p.N;
-  float sc8[8], bi8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { sc8[e] = 1.f; bi8[e] = 0.f; }
-  if (col_ok && p.scale) {
-    const float4 s0 = *reinterpret_cast<const float4*>(p.scale + ccol), s1 = *reinterpret_cast<const float4*>(p.scale + ccol + 4);
-    sc8[0] = s0.x; sc8[1] = s0.y; sc8[2] = s0.z; sc8[3] = s0.w; sc8[4] = s1.x; sc8[5] = s1.y; sc8[6] = s1.z; sc8[7] = s1.w;
-  }
-  if (col_ok && p.bias) {
-    const float4 s0 = *reinterpret_cast<const float4*>(p.bias + ccol), s1 = *reinterpret_cast<const float4*>(p.bias + ccol + 4);
-    bi8[0] = s0.x; bi8[1] = s0.y; bi8[2] = s0.z; bi8[3] = s0.w; bi8[4] = s1.x; bi8[5] = s1.y; bi8[6] = s1.z; bi8[7] = s1.w;
-  }
+  if constexpr (!EARLY_AFFINE) load_affine();
   const bool affine = p.scale != nullptr || p.bias != nullptr;
   const bool relu_pre = !p.act_post_res && p.act == SEDT_ACT_RELU, relu_post = p.act_post_res && p.act == SEDT_ACT_RELU;
 #pragma unroll
@@ -567,12 +620,13 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
       p.bits_out[orow * p.ldbits + (col >> 3)] = (uint8_t)ob;
     }
   }
+  SEDT_TS(3, __builtin_amdgcn_s_memtime());
 }
 
-template <int BM, int BN, int S, int NW = 4, int PP = 0, int KH = 1>
+template <int BM, int BN, int S, int NW = 4, int PP = 0, int KH = 1, int BR = 0>
 __device__ __forceinline__ void igemm3_body(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int bx) {
-  if (p.conv) igemm3_impl<BM, BN, S, NW, true, PP, KH>(p, a_bytes, b_bytes, bx);      // uniform branch: two specialised programs
-  else igemm3_impl<BM, BN, S, NW, false, PP, KH>(p, a_bytes, b_bytes, bx);
+  if (p.conv) igemm3_impl<BM, BN, S, NW, true, PP, KH, BR>(p, a_bytes, b_bytes, bx);      // uniform branch: two specialised programs
+  else igemm3_impl<BM, BN, S, NW, false, PP, KH, BR>(p, a_bytes, b_bytes, bx);
 }
 
 template <int BM, int BN, int S>
@@ -583,6 +637,12 @@ __global__ __launch_bounds__(256) void igemm3_kernel(const SedtIgemm p, const un
 template <int BM, int BN, int S, int PP = 0>
 __global__ __launch_bounds__(512) void igemm3_w8_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes) {
   igemm3_body<BM, BN, S, 8, PP>(p, a_bytes, b_bytes, blockIdx.x);
+}
+
+// 8 waves, ping-pong, B through registers out of the fragment-major image (BR = 1)
+template <int BM, int BN, int S>
+__global__ __launch_bounds__(512) void igemm3_br_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes) {
+  igemm3_body<BM, BN, S, 8, 1, 1, 1>(p, a_bytes, b_bytes, blockIdx.x);
 }
 
 // 16 waves: two 8-wave ping-pong teams, each over one half of K (KH = 2)
@@ -633,6 +693,27 @@ static int launch3_w8(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hi
   return check_launch("igemm3_w8");
 }
 
+template <int BM, int BN, int S>
+static int launch3_br(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
+  SEDT_DESCRIBE("igemm3_br_kernel<%d, %d, %d>", BM, BN, S);
+  constexpr size_t ring = (size_t)S * BM * ROWB;
+  constexpr size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);
+  constexpr size_t lds = ring > ctile ? ring : ctile;
+  static bool attr_set = false;
+  auto kern = igemm3_br_kernel<BM, BN, S>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("igemm3 br: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+      return 1;
+    }
+    attr_set = true;
+  }
+  const int nwg = ((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, st, p, a_bytes, b_bytes);
+  return check_launch("igemm3_br");
+}
+
 // Co-scheduled launch: the first nwg_main workgroups run the forward / dgrad GEMM p, the rest run pending weight-gradient
 // problems.  At batch 64 most GEMMs of the backward chain occupy 2 of the ~5 workgroup slots of a CU; weight gradients
 // are needed only by the optimizer, so their tiles ride in the spare slots of the chain's launches instead of taking
@@ -680,6 +761,32 @@ __global__ __launch_bounds__(512) void igemm3_w8_group_kernel(const IgemmGroup g
   int i = 0;
   while (i + 1 < g.n && (int)blockIdx.x >= g.blk0[i + 1]) ++i;
   igemm3_body<BM, BN, S, 8, 1>(g.p[i], g.a_bytes[i], g.b_bytes[i], (int)blockIdx.x - g.blk0[i]);
+}
+
+template <int BM, int BN, int S>
+__global__ __launch_bounds__(512) void igemm3_br_group_kernel(const IgemmGroup g) {
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.blk0[i + 1]) ++i;
+  igemm3_body<BM, BN, S, 8, 1, 1, 1>(g.p[i], g.a_bytes[i], g.b_bytes[i], (int)blockIdx.x - g.blk0[i]);
+}
+
+template <int BM, int BN, int S>
+static int launch3_br_group(const IgemmGroup& g, int nblk, hipStream_t st) {
+  constexpr size_t ring = (size_t)S * BM * ROWB;
+  constexpr size_t ctile = (size_t)BM * (BN + 4) * sizeof(float);
+  constexpr size_t lds = ring > ctile ? ring : ctile;
+  static bool attr_set = false;
+  auto kern = igemm3_br_group_kernel<BM, BN, S>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("igemm3 br group: hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+      return 1;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, st, g);
+  return check_launch("igemm3_br_group");
 }
 
 template <int BM, int BN, int S>
@@ -788,6 +895,19 @@ int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
     blk += big ? ((p.N + 127) / 128) * ((p.M + 127) / 128) : ((p.N + 63) / 64) * ((p.M + 63) / 64);
   }
   g.blk0[njobs] = blk;
+  if (big) {
+    const char* e = sedt::dev_getenv("SEDT_IGEMM_BREG");
+    bool br = e && atoi(e) != 0;
+    for (int i = 0; i < njobs && br; ++i) {
+      const SedtIgemm& p = jobs[i];
+      br = p.bfrag != nullptr && !p.f32ep && !p.awrap && (p.N % 32) == 0 && (p.ldb % 64) == 0 && (reinterpret_cast<uintptr_t>(p.bfrag) & 15) == 0 &&
+           (long)p.N * p.ldb * 2 < (1L << 31);
+    }
+    if (br) {
+      SEDT_DESCRIBE("igemm3_br_group_kernel<128, 128, 3>");
+      return launch3_br_group<128, 128, 3>(g, blk, st);
+    }
+  }
   if (big) SEDT_DESCRIBE("igemm3_w8_group_kernel<128, 128, 3>");
   else SEDT_DESCRIBE("igemm3_group_kernel<%d>", S == 3 ? 3 : 2);
   if (big) return launch3_w8_group<128, 128, 3>(g, blk, st);
@@ -888,6 +1008,19 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
   if (small16 && !plan3.on && co_group == nullptr && bm == 64 && bn == 64 && S >= 3 && p.K >= w16_mink && (p.K / BK2) % 2 == 0) {
     const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
     if (tiles <= 320) return launch3_w16<64, 64, 3>(p, a_bytes, b_bytes, st);
+  }
+  // B through registers (SedtIgemm.bfrag given; SEDT_IGEMM_BREG=1 in the developer build): the 64x128 / 128x128 ping-pong problems
+  static int breg = -1;
+  if (breg < 0) {
+    const char* e = sedt::dev_getenv("SEDT_IGEMM_BREG");
+    breg = e ? atoi(e) : 0;
+  }
+  if (breg && p.bfrag != nullptr && !plan3.on && co_group == nullptr && bn == 128 && (bm == 64 || bm == 128) && !p.f32ep && !p.awrap &&
+      (p.N % 32) == 0 && (p.ldb % 64) == 0 && (reinterpret_cast<uintptr_t>(p.bfrag) & 15) == 0 && (long)p.N * p.ldb * 2 < (1L << 31)) {
+    // (the ring holds A only and the epilogue's staging tile sets the LDS size, so a fourth / fifth stage is free: measured, 4 stages -4 % on
+    // these launches, 5 no better, profiles/r06_ab_breg.txt - the instances were removed again)
+    if (bm == 64) return S >= 3 ? launch3_br<64, 128, 3>(p, a_bytes, b_bytes, st) : launch3_br<64, 128, 2>(p, a_bytes, b_bytes, st);
+    return S >= 3 ? launch3_br<128, 128, 3>(p, a_bytes, b_bytes, st) : launch3_br<128, 128, 2>(p, a_bytes, b_bytes, st);
   }
   if (!plan3.on && co_group == nullptr && nw_env != 4 && pp_env && !force4) {
 #define SEDT_PP(BM_, BN_)                                                                                   \
@@ -1005,3 +1138,14 @@ int igemm_lds_try(const SedtIgemm& p, hipStream_t st) {
 }
 
 }  // namespace sedt
+
+#ifdef SEDT_DEV
+extern "C" int sedt_dev_ts_filter(int M, int N, int K) {
+  const int v[3] = {M, N, K};
+  return hipMemcpyToSymbol(HIP_SYMBOL(sedt::g_ts_filter), v, sizeof(v)) == hipSuccess ? 0 : 1;
+}
+extern "C" int sedt_dev_phase_ts(unsigned long long* out, int nwg) {
+  if (nwg > 4096) nwg = 4096;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sedt::g_phase_ts), sizeof(unsigned long long) * 5 * nwg) == hipSuccess ? 0 : 1;
+}
+#endif

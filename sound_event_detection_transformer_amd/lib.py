@@ -43,7 +43,7 @@ class SedtIgemm(C.Structure):
         ('colsum_out', C.c_void_p),
         ('bits_out', C.c_void_p), ('ldbits', C.c_int64), ('mask_bits', C.c_int32), ('f32ep', C.c_int32),
         ('omap', C.c_int32), ('o_Hi', C.c_int32), ('o_Wi', C.c_int32), ('o_sh', C.c_int32), ('o_sw', C.c_int32), ('o_h0', C.c_int32),
-        ('o_w0', C.c_int32), ('btap_on', C.c_int32), ('btap', C.c_int32 * 8), ('split_out', C.c_void_p), ('awrap', C.c_int32), ('pad2_', C.c_int32),
+        ('o_w0', C.c_int32), ('btap_on', C.c_int32), ('btap', C.c_int32 * 8), ('split_out', C.c_void_p), ('awrap', C.c_int32), ('pad2_', C.c_int32), ('bfrag', C.c_void_p),
     ]
 
 

@@ -42,6 +42,7 @@ def _dev_env(name, default):
     return os.environ.get(name, default) if os.environ.get('SEDT_DEV') == '1' else default
 
 
+IGEMM_BREG = _dev_env('SEDT_IGEMM_BREG', '0') != '0'   # developer A/B switch (csrc/igemm3.hip, BR = 1): weights through registers out of their fragment-major images
 RELU_BITS = _dev_env('SEDT_RELU_BITS', '1') != '0'      # developer A/B switch: 0 = the backward masks with the bf16 activations
 PROFILE = None   # bench.py sets this to a list: every GEMM launch then also records (argument block, dtype, shape, operands, hint)
 PROFILE_FUSED = []     # with PROFILE on: (kernel-name prefix, algorithmic flop, algorithmic bytes) of every fused-Bottleneck launch of the recorded step
@@ -90,6 +91,11 @@ def igemm_args(M, N, K, A, lda, B, ldb, Cout, ldc, *, trans=0, conv=None, transp
     if bits_out is not None:                        # sign bits of the stored output, uint8 [M, N/8]
         assert bits_out.dtype == torch.uint8 and bits_out.shape == (M, N // 8) and N % 8 == 0 and bits_out.stride(1) == 1 and not trans
         a.bits_out, a.ldbits = bits_out.data_ptr(), bits_out.stride(0)
+    if IGEMM_BREG and not trans and B.dtype == torch.bfloat16:
+        from . import packing
+        fr = packing.lookup_operand_frag(B.data_ptr())
+        if fr is not None and fr.numel() == B.numel() and ldb * B.shape[0] == B.numel():
+            a.bfrag = fr.data_ptr()
     return a
 
 

@@ -63,6 +63,16 @@ def lookup_conv_frag(weight):
     return None
 
 
+def lookup_operand_frag(ptr):
+    """the fragment-major image of the packed convolution operand that starts at `ptr` (a plan's ``conv_frags``), or None: what
+    SedtIgemm.bfrag points at.  The backward runs after the forward's plan scope has closed, so every live plan is asked."""
+    for plan in list(reversed(_active)) + [p for p in _plan_set() if p not in _active]:
+        hit = plan.operand_frag.get(ptr)
+        if hit is not None:
+            return hit
+    return None
+
+
 def lookup(weight):
     """(wf, wb, scale, bias) prepared for this parameter (or a view of it) by the active plan, or None"""
     for plan in reversed(_active):
@@ -187,6 +197,7 @@ class PackPlan(object):
     def _init_frags(self, frags, device, conv_frags):
         self.frag_table, self._fr_params, self._fr_entries = {}, [], []
         self.conv_frag_table, self._cf_entries = {}, []
+        self.operand_frag = {}                                        # packed operand pointer (fixed, inside self.wbuf) -> its fragment-major image
         frags = [w for w in frags if w.dim() == 2 and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0]
         packed = {id(w): (wf, wb) for w, wf, wb, _, _ in self._entries}
         conv_frags = [w for w in conv_frags if id(w) in packed and packed[id(w)][0] is not None and packed[id(w)][1] is not None
@@ -217,6 +228,7 @@ class PackPlan(object):
                 row = self._fj[r]
                 row['wf'], row['N'], row['K'], row['blk0'], row['src_bf16'] = base + 2 * off, N, K, self._fr_blocks, 1
                 outs.append(self.fbuf[off:off + n])
+                self.operand_frag[src.data_ptr()] = outs[-1]
                 self._fr_blocks += (N // 32) * (K // 32)
                 off += n
                 self._fr_params.append(src)

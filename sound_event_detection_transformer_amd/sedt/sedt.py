@@ -7,7 +7,7 @@ import torch
 from torch import nn
 
 from .. import functional as Fn
-from .. import packing, runtime
+from .. import ops, packing, runtime
 from ..ops import ACT_NONE, ACT_RELU, ACT_SIGMOID
 from ..utilities.utils import NestedTensor, nested_tensor_from_tensor_list
 
@@ -101,6 +101,7 @@ class SEDT(nn.Module):
             def factory():
                 body = self.backbone[0].body
                 convs = []
+                l34 = set(id(p_) for layer in (body.layer3, body.layer4) for p_ in layer.parameters())
                 bn_only = [(body.conv1.weight, body.bn1.tensors())]        # 7x7 stem: only its FrozenBN fold is needed
                 for layer in (body.layer1, body.layer2, body.layer3, body.layer4):
                     for b in layer:
@@ -130,6 +131,9 @@ class SEDT(nn.Module):
                        for w in (b.conv1.weight, b.conv2.weight, b.conv3.weight)]
                 for b0 in (body.layer1[0], body.layer2[0]):     # the two projection blocks: fused forwards (bneck0 / bneck2_fwd_kernel)
                     cfr += [b0.conv1.weight, b0.conv2.weight, b0.conv3.weight, b0.downsample[0].weight]
+                if ops.IGEMM_BREG:                              # developer A/B: B through registers in the LDS-DMA GEMMs of layer3 block 0 / layer4
+                    have = set(id(w) for w in cfr)
+                    cfr += [w for w, _ in convs if id(w) not in have and id(w) in l34]
                 return packing.PackPlan(dt, dev, convs, lin, bn_only, frags, cfr)
             plans[key] = packing.PlanSet(factory)
         return plans[key]
