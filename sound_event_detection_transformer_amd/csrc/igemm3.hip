@@ -23,6 +23,11 @@ namespace sedt {
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
+// The own-code prefetch of igemm3_impl reads up to 32 KB past a point inside a kernel.  Every kernel of this file is followed by other code
+// except the last one of .text: this zero-initialised tail (a later segment of the same loaded image, which the loader allocates as ONE
+// region) keeps that read inside the image whatever the order of the kernels is.
+__device__ __attribute__((used)) unsigned char g_code_tail_pad[64 * 1024];
+
 #ifdef SEDT_DEV
 // developer build only: shader-clock stamps of a workgroup's phases (start, K loop entered, K loop left, stores issued) and the constant
 // 100 MHz clock at its start, for the first 4096 workgroups of the most recent igemm3 launch (tools/dev/r06_phase_ts.py)
@@ -56,7 +61,9 @@ __device__ int g_ts_filter[3];      // (M, N, K) of the only problem that record
 // image of the operand (SedtIgemm.bfrag, the layout of sedt_pack_frag: one contiguous KB per (32 rows, k16 step)), S tiles ahead like the
 // ring; the ring holds A only.  LDS-DMA then fills a third (64x128) or half (128x128) of the bytes per K tile.
 template <int BM, int BN, int S, int NW, bool CONV, int PP = 0, int KH = 1, int BR = 0>
-__device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a_bytes, const unsigned b_bytes, const int bx) {
+__device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a_bytes_flag, const unsigned b_bytes_flag, const int bx) {
+  const unsigned b_bytes = b_bytes_flag & 0x7fffffffu;      // (bit 31: cooperative weight prefetch on, see below)
+  const unsigned a_bytes = a_bytes_flag & 0x7fffffffu;      // (bit 31: the first workgroups prefetch this program's own code, see below)
   constexpr int WM = BR ? BM : BM / 2, WN = BR ? BN / 4 : BN / 2, MI = WM / 32, NI = WN / 32;
   constexpr int STAGE_BYTES = (BM + (BR ? 0 : BN)) * ROWB;
   constexpr int GA = BM / (8 * NW), GB = BR ? 0 : BN / (8 * NW);
@@ -92,6 +99,41 @@ __device__ __forceinline__ void igemm3_impl(const SedtIgemm& p, const unsigned a
 
   __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, a_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, b_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rsF0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BR ? p.bfrag : p.B), 0,
+                                                                  BR ? (unsigned)((long)p.N * p.ldb * 2) : b_bytes, 0x00020000);
+
+  // ---- cooperative weight prefetch.  Inside a training step the weight operand is cold in the Infinity Cache (packed a whole forward earlier)
+  //      while the activations - just written - are not: the K loop of a launch whose workgroups all start together then waits for B k-slice by
+  //      k-slice, one HBM round trip after the other (measured with the phase stamps: K loop 35.6 k clocks with B from HBM against 25.8 k with B
+  //      resident, 38.2 k inside the step: profiles/r06_ab_breg.txt).  So the first workgroups each TOUCH one slice of the whole B operand before
+  //      anything else - one LDS-DMA dword per 128-byte line, 64 lines per instruction - and all of B is on its way from HBM at once.  The
+  //      dwords land in the LDS bytes of this wave's own first A piece, which the same wave's real piece - a later load, and loads of a wave
+  //      return in order - overwrites.
+  // ---- the program's own code.  Inside a step every launch starts with its code cold (197 other kernels and 13 GB of traffic since its last
+  //      run): the straight-line prologue and epilogue are fetched from HBM one instruction-cache miss after the other (a 128x128 launch whose
+  //      256 workgroups all start together: prologue 3.3 k -> 10.1 k clocks, epilogue 6.7 k -> 13.1 k with cold code and warm data,
+  //      tools/dev/r06_phase_ts_step.py).  The first workgroups touch the CODE_KB KB that follow this point - this specialisation's prologue,
+  //      loop and epilogue - so that the lines are on their way from HBM together (same LDS-DMA trick as the weight prefetch below).
+  constexpr int CODE_KB = BM * BN >= 128 * 128 ? 32 : 24;
+  if ((a_bytes_flag >> 31) && wave_all == 0 && bx < CODE_KB / 8) {
+    const uint64_t pc = __builtin_amdgcn_s_getpc() & ~(uint64_t)127;
+    __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(pc), 0, CODE_KB * 1024u, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsC, (lds_void*)(ring), 4, (unsigned)bx * 8192u + (unsigned)lane * 128u, 0, 0, 0);
+  }
+  if ((b_bytes_flag >> 31) && !p.f32ep && wave_all == 0) {
+    const int npf = nwg < 256 ? nwg : 256;
+    if (bx < npf) {
+      const unsigned total = BR ? (unsigned)((long)p.N * p.ldb * 2) : b_bytes;
+      const unsigned chunk = ((total + npf - 1) / npf + 127u) & ~127u;
+      const unsigned lo = (unsigned)bx * chunk, hi = lo + chunk < total ? lo + chunk : total;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned off = lo + (unsigned)i * 8192u + (unsigned)lane * 128u;
+        if (lo + (unsigned)i * 8192u < hi)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(BR ? rsF0 : rsB, (lds_void*)(ring), 4, off < hi ? off : OOB, 0, 0, 0);
+      }
+    }
+  }
 
   // ---- epilogue operands (residual, ReLU mask of the consumer) are fetched NOW into registers: the small-K problems of
   //      layer1/layer2 are HBM streams whose per-workgroup time is a chain of memory round trips (A tile -> residual ->
@@ -1130,7 +1172,21 @@ int igemm_lds_try(const SedtIgemm& p, hipStream_t st) {
       bm = 256;
   }
   {   // the lean-issue kernel takes the common cases
-    int r3 = igemm3_try(p, (unsigned)a_bytes, (unsigned)b_bytes, bm, bn, st);
+    // bit 31 of the B descriptor size = "the first workgroups prefetch the whole B operand" (igemm3_impl): on for every forward / dgrad problem -
+    // B is a weight there (same-box A/B in profiles/r06_ab_bpf.txt; SEDT_IGEMM_BPF=0 in the developer build)
+    static int bpf = -1;
+    if (bpf < 0) {
+      const char* e = sedt::dev_getenv("SEDT_IGEMM_BPF");
+      bpf = e ? atoi(e) : 1;
+    }
+    // bit 31 of the A descriptor size = "the first workgroups prefetch this program's own code" (igemm3_impl; SEDT_IGEMM_CPF=0 in the developer build;
+    // same-box A/B in profiles/r06_ab_bpf.txt)
+    static int cpf = -1;
+    if (cpf < 0) {
+      const char* e = sedt::dev_getenv("SEDT_IGEMM_CPF");
+      cpf = e ? atoi(e) : 1;
+    }
+    int r3 = igemm3_try(p, (unsigned)a_bytes | (cpf ? 0x80000000u : 0u), (unsigned)b_bytes | (bpf ? 0x80000000u : 0u), bm, bn, st);
     if (r3 >= 0) return r3;
     if (igemm3_planning()) return -1;      // dry run (sedt_igemm_group): never launch from here
   }

@@ -16,6 +16,7 @@ lib = L.load()
 lib.sedt_dev_phase_ts.argtypes = [C.c_void_p, C.c_int]
 g = torch.Generator().manual_seed(1)
 flush = torch.empty(768 << 20, dtype=torch.uint8, device='cuda')
+small = torch.empty(48 << 20, dtype=torch.uint8, device='cuda')      # evicts the L2s (32 MB), stays inside the Infinity Cache next to the problem
 
 
 def frag(w):
@@ -29,6 +30,9 @@ def run(M, N, K, tile, use_frag, cold, with_res=True):
     res = torch.randn(M, N, generator=g).bfloat16().cuda()
     sc, bi = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda()
     fr = frag(w)
+    x2, res2 = x.clone(), res.clone()
+    wcopies = [w.clone() for _ in range(max(8, (352 << 20) // (w.numel() * 2)))] if cold == 'Bhbm' else []
+    wi = [0]
     y = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
     if with_res:
         a = ops.igemm_args(M, N, K, x, K, w, K, y, N, scale=sc, bias=bi, res=res, ldr=N, act=L.ACT_RELU, act_post_res=1, tile=tile)
@@ -44,8 +48,22 @@ def run(M, N, K, tile, use_frag, cold, with_res=True):
     bm, bn = [int(v) for v in name.split('<')[1].split(',')[:2]]
     nwg = min(4096, ((M + bm - 1) // bm) * ((N + bn - 1) // bn))
     stats = []
-    for rep in range(4):
-        if cold:
+    for rep in range(6):
+        if cold == 'Bhbm':                      # the weight from HBM (a fresh copy out of 320+ MB of copies every launch), everything else warm
+            L.check(lib.sedt_igemm(C.byref(a), L.BF16, L.stream_ptr()), 'igemm')
+            wi[0] = (wi[0] + 1) % len(wcopies)
+            a.B = wcopies[wi[0]].data_ptr()
+        elif cold == 'wrA':                       # A freshly WRITTEN by another kernel (as inside the step), everything else warm
+            L.check(lib.sedt_igemm(C.byref(a), L.BF16, L.stream_ptr()), 'igemm')
+            x.copy_(x2)
+        elif cold == 'wrAR':                    # A and the residual freshly written
+            L.check(lib.sedt_igemm(C.byref(a), L.BF16, L.stream_ptr()), 'igemm')
+            x.copy_(x2)
+            res.copy_(res2)
+        elif cold == 'mall':
+            L.check(lib.sedt_igemm(C.byref(a), L.BF16, L.stream_ptr()), 'igemm')
+            small.fill_(rep)
+        elif cold:
             flush.fill_(rep)
         else:
             L.check(lib.sedt_igemm(C.byref(a), L.BF16, L.stream_ptr()), 'igemm')
@@ -62,12 +80,12 @@ def run(M, N, K, tile, use_frag, cold, with_res=True):
         span_rt = (ts[:, 4].max() - ts[:, 4].min()) / 100.0           # us between the first and the last workgroup START (100 MHz clock)
         stats.append((e0.elapsed_time(e1) * 1e3, np.median(pro), np.median(loop), np.median(epi), np.percentile(loop, 90), span_rt))
     s = np.asarray(stats[1:]).mean(0)
-    print(f'{M:6d} {N:5d} {K:5d} {name:34s} {"res  " if with_res is True else "nores" if with_res is False else "plain"} {"cold" if cold else "hot ":4s} launch {s[0]:7.1f} us | wg clocks: prologue {s[1]:7.0f}  K loop {s[2]:7.0f} (p90 {s[4]:7.0f})  '
+    print(f'{M:6d} {N:5d} {K:5d} {name:34s} {"res  " if with_res is True else "nores" if with_res is False else "plain"} {cold if isinstance(cold, str) else "cold" if cold else "hot ":4s} launch {s[0]:7.1f} us | wg clocks: prologue {s[1]:7.0f}  K loop {s[2]:7.0f} (p90 {s[4]:7.0f})  '
           f'epilogue {s[3]:7.0f} | first..last wg start {s[5]:6.1f} us, {nwg} wgs', flush=True)
 
 
 for (M, N, K, tile) in ((8192, 2048, 512, (0, 0)), (8192, 2048, 1024, (0, 0)), (8192, 512, 2048, (0, 0)), (8192, 512, 1024, (64, 128)), (32256, 256, 1024, (64, 128))):
     for use_frag in (False, True) if os.environ.get('SEDT_IGEMM_BREG') == '1' else (False,):
-        for with_res in (True, False, None):
-            for cold in (False,):
+        for with_res in (True,):
+            for cold in ('Bhbm', 'wrAR', False):
                 run(M, N, K, tile, use_frag, cold, with_res)
