@@ -1,5 +1,6 @@
 """developer build: where a workgroup of the LDS-DMA GEMM spends its life (csrc/igemm3.hip, SEDT_TS): prologue (descriptors, gather
-offsets, epilogue-operand prefetch, first tiles issued) | K loop | epilogue (LDS staging, residual / mask, stores issued), shader clocks.
+offsets, epilogue-operand prefetch, first tiles issued) | K loop | epilogue (LDS staging, residual / mask, stores issued), shader clocks,
+for one problem alone in five cache states (profiles/r06_ab_bpf.txt; SEDT_IGEMM_BPF=0 SEDT_IGEMM_CPF=0 shows the kernels without their prefetches).
 usage (on the GPU box): SEDT_DEV=1 SEDT_LIB_AB=build/dev/libsedt_hip_dev.so SEDT_IGEMM_BREG=1 python tools/dev/r06_phase_ts.py"""
 import ctypes as C
 import os
@@ -87,5 +88,5 @@ def run(M, N, K, tile, use_frag, cold, with_res=True):
 for (M, N, K, tile) in ((8192, 2048, 512, (0, 0)), (8192, 2048, 1024, (0, 0)), (8192, 512, 2048, (0, 0)), (8192, 512, 1024, (64, 128)), (32256, 256, 1024, (64, 128))):
     for use_frag in (False, True) if os.environ.get('SEDT_IGEMM_BREG') == '1' else (False,):
         for with_res in (True,):
-            for cold in ('Bhbm', 'wrAR', False):
+            for cold in (True, 'mall', 'wrAR', 'Bhbm', False):      # flushed | L2 evicted | A + residual rewritten | weight from HBM | repeated
                 run(M, N, K, tile, use_frag, cold, with_res)
