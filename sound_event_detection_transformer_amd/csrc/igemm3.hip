@@ -681,11 +681,13 @@ __global__ __launch_bounds__(512) void igemm3_w8_kernel(const SedtIgemm p, const
   igemm3_body<BM, BN, S, 8, PP>(p, a_bytes, b_bytes, blockIdx.x);
 }
 
+#ifdef SEDT_DEV            // (the register-streamed weight operand is a measured developer variant, profiles/r06_ab_breg.txt: not compiled into the product)
 // 8 waves, ping-pong, B through registers out of the fragment-major image (BR = 1)
 template <int BM, int BN, int S>
 __global__ __launch_bounds__(512) void igemm3_br_kernel(const SedtIgemm p, const unsigned a_bytes, const unsigned b_bytes) {
   igemm3_body<BM, BN, S, 8, 1, 1, 1>(p, a_bytes, b_bytes, blockIdx.x);
 }
+#endif
 
 // 16 waves: two 8-wave ping-pong teams, each over one half of K (KH = 2)
 template <int BM, int BN, int S>
@@ -735,6 +737,7 @@ static int launch3_w8(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hi
   return check_launch("igemm3_w8");
 }
 
+#ifdef SEDT_DEV
 template <int BM, int BN, int S>
 static int launch3_br(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hipStream_t st) {
   SEDT_DESCRIBE("igemm3_br_kernel<%d, %d, %d>", BM, BN, S);
@@ -755,6 +758,7 @@ static int launch3_br(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, hi
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), lds, st, p, a_bytes, b_bytes);
   return check_launch("igemm3_br");
 }
+#endif
 
 // Co-scheduled launch: the first nwg_main workgroups run the forward / dgrad GEMM p, the rest run pending weight-gradient
 // problems.  At batch 64 most GEMMs of the backward chain occupy 2 of the ~5 workgroup slots of a CU; weight gradients
@@ -805,6 +809,7 @@ __global__ __launch_bounds__(512) void igemm3_w8_group_kernel(const IgemmGroup g
   igemm3_body<BM, BN, S, 8, 1>(g.p[i], g.a_bytes[i], g.b_bytes[i], (int)blockIdx.x - g.blk0[i]);
 }
 
+#ifdef SEDT_DEV
 template <int BM, int BN, int S>
 __global__ __launch_bounds__(512) void igemm3_br_group_kernel(const IgemmGroup g) {
   int i = 0;
@@ -830,6 +835,7 @@ static int launch3_br_group(const IgemmGroup& g, int nblk, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, st, g);
   return check_launch("igemm3_br_group");
 }
+#endif
 
 template <int BM, int BN, int S>
 static int launch3_w8_group(const IgemmGroup& g, int nblk, hipStream_t st) {
@@ -937,6 +943,7 @@ int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
     blk += big ? ((p.N + 127) / 128) * ((p.M + 127) / 128) : ((p.N + 63) / 64) * ((p.M + 63) / 64);
   }
   g.blk0[njobs] = blk;
+#ifdef SEDT_DEV
   if (big) {
     const char* e = sedt::dev_getenv("SEDT_IGEMM_BREG");
     bool br = e && atoi(e) != 0;
@@ -950,6 +957,7 @@ int igemm3_group_try(const SedtIgemm* jobs, int njobs, hipStream_t st) {
       return launch3_br_group<128, 128, 3>(g, blk, st);
     }
   }
+#endif
   if (big) SEDT_DESCRIBE("igemm3_w8_group_kernel<128, 128, 3>");
   else SEDT_DESCRIBE("igemm3_group_kernel<%d>", S == 3 ? 3 : 2);
   if (big) return launch3_w8_group<128, 128, 3>(g, blk, st);
@@ -1051,6 +1059,7 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
     const long tiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
     if (tiles <= 320) return launch3_w16<64, 64, 3>(p, a_bytes, b_bytes, st);
   }
+#ifdef SEDT_DEV
   // B through registers (SedtIgemm.bfrag given; SEDT_IGEMM_BREG=1 in the developer build): the 64x128 / 128x128 ping-pong problems
   static int breg = -1;
   if (breg < 0) {
@@ -1064,6 +1073,7 @@ int igemm3_try(const SedtIgemm& p, unsigned a_bytes, unsigned b_bytes, int bm, i
     if (bm == 64) return S >= 3 ? launch3_br<64, 128, 3>(p, a_bytes, b_bytes, st) : launch3_br<64, 128, 2>(p, a_bytes, b_bytes, st);
     return S >= 3 ? launch3_br<128, 128, 3>(p, a_bytes, b_bytes, st) : launch3_br<128, 128, 2>(p, a_bytes, b_bytes, st);
   }
+#endif
   if (!plan3.on && co_group == nullptr && nw_env != 4 && pp_env && !force4) {
 #define SEDT_PP(BM_, BN_)                                                                                   \
   if (bm == BM_ && bn == BN_) {                                                                             \
