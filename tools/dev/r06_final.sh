@@ -8,5 +8,5 @@ bash tools/dev/r06_profile.sh > gpurun_out/r06_profile.log 2>&1
 tail -12 gpurun_out/r06_profile.log
 bash tools/dev/r06_sequences.sh > gpurun_out/r06_sequences.log 2>&1
 tail -6 gpurun_out/r06_sequences.log
-python bench.py --steps 20 --warmup 5 > gpurun_out/r06_bench7.json 2> gpurun_out/r06_bench7.err
-tail -c 300 gpurun_out/r06_bench7.json
+python bench.py --steps 20 --warmup 5 > gpurun_out/r06_bench9.json 2> gpurun_out/r06_bench9.err
+tail -c 300 gpurun_out/r06_bench9.json
